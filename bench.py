@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric: CSR SpMV GFLOP/s + achieved HBM GB/s (% of roofline).
+
+  python bench.py [--gpus N --steps K --warmup W] [--workload spmv|spmm|spgemm|spmv_rmat]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Default (N=1): cfg2 = fp32 CSR SpMV, 10M x 10M, exactly 10 nnz/row, columns iid uniform
+(unsorted), values/x U[0,1), int32 indices, inputs resident in HBM before the timed region.
+A "step" = one multiply(info, A, x, y) (the inspect phase runs once, outside the timed
+region, and is reported separately).  N>1: the SAME global matrix row-sharded over N
+ranks (strong scaling), step = local SpMV + ONE RCCL all-gather of y (in the timed region).
+One JSON line on rank 0.  roofline.achieved = algorithmic bytes per launch (SURVEY.md
+section 8d: nnz*(sizeof(T)+4) + (m+1)*4 + n*sizeof(T) + m*sizeof(T)) / average kernel
+duration from HIP events recorded on the launch stream around the timed steps.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+CHUNK_ROWS = 250_000   # the global matrix is generated per fixed row chunk => identical for every N
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=50)
+    p.add_argument("--warmup", type=int, default=5)
+    p.add_argument("--workload", default="spmv", choices=["spmv", "spmv_poisson", "spmv_rmat", "spmm", "spgemm"])
+    p.add_argument("--rows", type=int, default=None, help="override the row count (debug only; reported)")
+    p.add_argument("--alg", default="auto", choices=["auto", "vector", "rowblock", "sliced", "noplan"])
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    return p.parse_args()
+
+
+def gen_rows(row_begin, row_end, n, per_row, poisson, dtype, device):
+    """Rows [row_begin,row_end) of the global cfg matrix, generated chunk by chunk with
+    seed = chunk index so that every world size sees the same matrix."""
+    from spblas_reference_amd import generate
+    vals, cols, lens = [], [], []
+    c0 = row_begin // CHUNK_ROWS
+    c1 = (row_end + CHUNK_ROWS - 1) // CHUNK_ROWS
+    for c in range(c0, c1):
+        lo, hi = c * CHUNK_ROWS, (c + 1) * CHUNK_ROWS
+        v, rp, ci, _, _ = generate.uniform_csr_device(hi - lo, n, per_row, dtype=dtype, seed=1000 + c, device=device,
+                                                      poisson=poisson, offset_dtype=torch.int64)
+        a, b = max(row_begin, lo) - lo, min(row_end, hi) - lo
+        p0, p1 = int(rp[a]), int(rp[b])
+        vals.append(v[p0:p1])
+        cols.append(ci[p0:p1])
+        lens.append(rp[a + 1:b + 1] - rp[a:b])
+    lens = torch.cat(lens)
+    rowptr = torch.zeros(row_end - row_begin + 1, dtype=torch.int64, device=device)
+    torch.cumsum(lens, 0, out=rowptr[1:])
+    return torch.cat(vals), rowptr.to(torch.int32), torch.cat(cols), int(rowptr[-1])
+
+
+def spmv_bytes(m, n, nnz, tsize):
+    return nnz * (tsize + 4) + (m + 1) * 4 + n * tsize + m * tsize
+
+
+def read_pmc_traffic(name):
+    """HBM bytes per launch from the committed PMC profile (profiles/<round>_pmc.json), or None."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get(name)
+    except Exception:
+        return None
+
+
+def cpu_baseline_spmv(values, rowptr, colind, shape, x, nnz):
+    """Reference CPU path restated (oracle, kind 'port'): 1 core, reference flags
+    (-O3 -march=native, built on THIS host), best of 3 on the full workload."""
+    from oracle import oracle
+    v, rp, ci, xh = values.cpu().numpy(), rowptr.cpu().numpy(), colind.cpu().numpy(), x.cpu().numpy()
+    try:
+        oracle.load(native=True)
+        native = True
+    except Exception:
+        native = False
+    best = float("inf")
+    for _ in range(3):
+        t0 = time.perf_counter()
+        oracle.spmv(shape, rp, ci, v, xh, native=native)
+        best = min(best, time.perf_counter() - t0)
+    best_omp = float("inf")
+    for _ in range(3):
+        t0 = time.perf_counter()
+        oracle.spmv_omp(rp, ci, v, xh, native=native)
+        best_omp = min(best_omp, time.perf_counter() - t0)
+    ncpu = os.cpu_count()
+    return {"value": 2.0 * nnz / best / 1e9, "unit": "GFLOP/s", "cores": 1, "kind": "port",
+            "sample": f"full workload ({nnz} nnz), best of 3 runs of oracle_spmv (-O3 -march={'native' if native else 'x86-64-v3'})",
+            "seconds": best,
+            "all_cores": {"value": 2.0 * nnz / best_omp / 1e9, "cores": ncpu, "seconds": best_omp,
+                          "note": "OpenMP static row-parallel variant of the same loop"}}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
+                     "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    import spblas_reference_amd as sp
+    from spblas_reference_amd import _capi, sharded
+    sp._capi.lib()  # fail loudly if the HIP library is missing
+
+    if args.workload in ("spmm", "spgemm", "spmv_rmat"):
+        from bench_extra import run_extra  # secondary configs (cfg3/cfg4/cfg5), 1 GPU
+        return run_extra(args, device)
+
+    poisson = args.workload == "spmv_poisson"
+    m = n = args.rows or 10_000_000
+    per_row = 10
+    dtype, tsize = torch.float32, 4
+    bounds = sharded.partition_rows_even(m, world)  # exact-10 rows: equal rows == equal nnz
+    if poisson and world > 1:
+        bounds = [(b // CHUNK_ROWS) * CHUNK_ROWS for b in bounds[:-1]] + [m]
+    r0, r1 = bounds[rank], bounds[rank + 1]
+    values, rowptr, colind, nnz_local = gen_rows(r0, r1, n, per_row, poisson, dtype, device)
+    g = torch.Generator(device=device).manual_seed(7)
+    x = torch.rand(n, dtype=dtype, device=device, generator=g)  # same on every rank (replicated)
+    a_local = sp.csr_view(values, rowptr, colind, (r1 - r0, n), nnz_local)
+    nnz_t = torch.tensor([nnz_local], dtype=torch.int64, device=device)
+    if world > 1:
+        dist.all_reduce(nnz_t)
+    nnz = int(nnz_t.item())
+
+    algs = {"auto": _capi.SPMV_AUTO, "vector": _capi.SPMV_VECTOR, "rowblock": _capi.SPMV_ROWBLOCK,
+            "sliced": _capi.SPMV_SLICED}
+    op = sharded.ShardedSpMV(a_local, bounds, inspect=False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    if args.alg != "noplan":
+        op.info = sp.multiply_inspect(a_local, x, op.y_local[:r1 - r0], alg=algs[args.alg])
+    torch.cuda.synchronize()
+    inspect_ms = (time.perf_counter() - t0) * 1e3
+    plan_info = op.info.state_.info() if op.info.state_ is not None else {"alg": "plan-free"}
+
+    for _ in range(args.warmup):
+        op.step(x)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ev[i][0].record()
+        op.local(x)
+        ev[i][1].record()
+        op.gather()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    el = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+    kern_ms = sorted(a.elapsed_time(b) for a, b in ev)
+    kern_avg_ms = sum(kern_ms) / len(kern_ms)
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        gflops = 2.0 * nnz / (elapsed / args.steps) / 1e9
+        local_bytes = spmv_bytes(r1 - r0, n, nnz_local, tsize)
+        achieved = local_bytes / (kern_avg_ms * 1e-3) / 1e9
+        out = {
+            "metric": "csr_spmv_gflops", "value": gflops, "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"cfg2: fp32 CSR SpMV {m}x{n}, {'Poisson(10)' if poisson else 'exactly 10'} nnz/row, "
+                                   f"uniform random unsorted columns, int32 indices, nnz={nnz}",
+                       "rows": m, "cols": n, "nnz": nnz, "index_type": "int32",
+                       "parallelism": f"row-sharded x{world} + RCCL all-gather(y)" if world > 1 else "single GPU",
+                       "alg": args.alg, "plan": plan_info, "inspect_ms_untimed": inspect_ms},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": read_pmc_traffic("spmv_cfg2"),
+                         "kernel": "spmv_rowblock_kernel<float,int,2048>" if plan_info.get("alg") == 2 else "spmv kernel",
+                         "algorithmic_bytes_per_launch": local_bytes, "kernel_avg_ms": kern_avg_ms,
+                         "kernel_min_ms": kern_ms[0], "kernel_median_ms": kern_ms[len(kern_ms) // 2],
+                         "algorithmic_gbs_whole_step": spmv_bytes(m, n, nnz, tsize) / (elapsed / args.steps) / 1e9},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline_spmv(values, rowptr, colind, (m, n), x, nnz)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,168 @@
+/*
+ * spblas_gfx950.h -- C ABI of the MI355X (gfx950 / CDNA4) Sparse BLAS backend for
+ * the spblas-reference view/operator API.
+ *
+ * This is the drop-in boundary.  The reference has no runtime
+ * plugin ABI of its own: a backend is a set of C++ overloads compiled in with
+ * -DSPBLAS_ENABLE_<NAME> whose bodies call a vendor C library.  The entry points
+ * below are exactly what our overload set (the headers under
+ * include/spblas/vendor/gfx950/) binds, one for each vendor-library call the existing AMD slot makes
+ * (paths relative to /root/reference/include/spblas/):
+ *
+ *   rocsparse_create_handle / rocsparse_set_stream / rocsparse_destroy_handle
+ *       vendor/rocsparse/detail/abstract_operation_state.hpp:20-28,
+ *       vendor/rocsparse/multiply_spgemm.hpp:34-43      -> spblas_gfx950_create/destroy/set_stream
+ *   rocsparse_spmv(..., stage_buffer_size) + allocate_workspace
+ *       vendor/rocsparse/detail/spmv_impl.hpp:60-69     -> spblas_gfx950_spmv_plan_create  (multiply_inspect)
+ *   rocsparse_spmv(..., stage_compute)
+ *       vendor/rocsparse/detail/spmv_impl.hpp:72-77     -> spblas_gfx950_spmv
+ *   oneapi::mkl::sparse::gemm (the only device SpMM in the reference)
+ *       vendor/onemkl_sycl/spmm_impl.hpp:116-120        -> spblas_gfx950_spmm
+ *   rocsparse_spgemm stage_buffer_size + stage_nnz + rocsparse_spmat_get_size
+ *       vendor/rocsparse/multiply_spgemm.hpp:94-115     -> spblas_gfx950_spgemm_symbolic (multiply_compute)
+ *   rocsparse_spgemm stage_compute / stage_symbolic / stage_numeric
+ *       vendor/rocsparse/multiply_spgemm.hpp:137-213    -> spblas_gfx950_spgemm_numeric  (multiply_fill / multiply_numeric)
+ *
+ * Conventions
+ *   - Plain C: pointers, sizes, enums.  No C++/torch types cross this boundary.
+ *   - Every array pointer is a DEVICE pointer owned by the caller (csr_view is
+ *     non-owning, views/csr_view.hpp:12-77).  alpha/beta are HOST pointers to one
+ *     scalar of the value type.  The library never frees caller memory.
+ *   - Work is enqueued on the handle's hipStream_t and is asynchronous with respect
+ *     to the host, like the rocSPARSE slot; the only host synchronisations are in
+ *     plan creation and in spgemm_symbolic (it must return nnz(C), as
+ *     rocsparse_spmat_get_size does at multiply_spgemm.hpp:114-115).
+ *   - Every function returns a spblas_gfx950_status; the C++ header layer maps
+ *     them to the reference's exception types (std::invalid_argument for shape
+ *     errors, std::runtime_error otherwise, std::bad_alloc for allocation).
+ *   - Zero-based indices; column indices within a row may be unsorted and may
+ *     repeat (backend/generate.hpp:112-117 shuffles them).
+ *   - One handle / plan per host thread; no internal locking (the reference makes
+ *     no thread-safety statement either).
+ */
+#ifndef SPBLAS_GFX950_H
+#define SPBLAS_GFX950_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct spblas_gfx950_handle_s* spblas_gfx950_handle_t;
+typedef struct spblas_gfx950_plan_s* spblas_gfx950_plan_t;
+typedef struct spblas_gfx950_spgemm_s* spblas_gfx950_spgemm_t;
+
+typedef enum spblas_gfx950_status {
+  SPBLAS_GFX950_STATUS_SUCCESS = 0,
+  SPBLAS_GFX950_STATUS_INVALID_HANDLE = 1,
+  SPBLAS_GFX950_STATUS_INVALID_POINTER = 2,
+  SPBLAS_GFX950_STATUS_INVALID_SIZE = 3,  /* shape mismatch -> std::invalid_argument */
+  SPBLAS_GFX950_STATUS_INVALID_VALUE = 4, /* bad enum / flag */
+  SPBLAS_GFX950_STATUS_NOT_SUPPORTED = 5,
+  SPBLAS_GFX950_STATUS_ALLOC_FAILED = 6,       /* -> std::bad_alloc */
+  SPBLAS_GFX950_STATUS_HIP_ERROR = 7,          /* see spblas_gfx950_last_hip_error */
+  SPBLAS_GFX950_STATUS_INSUFFICIENT_SPACE = 8, /* "SpGEMM ran out of memory" */
+  SPBLAS_GFX950_STATUS_PLAN_MISMATCH = 9       /* plan built for a different matrix */
+} spblas_gfx950_status;
+
+typedef enum spblas_gfx950_datatype {
+  SPBLAS_GFX950_F32 = 0, /* float  : vendor/rocsparse/types.hpp:42-44 */
+  SPBLAS_GFX950_F64 = 1  /* double : vendor/rocsparse/types.hpp:47-49 */
+} spblas_gfx950_datatype;
+
+typedef enum spblas_gfx950_indextype {
+  SPBLAS_GFX950_I32 = 0, /* vendor/rocsparse/types.hpp:11-12 (index_t = offset_t = int32_t) */
+  SPBLAS_GFX950_I64 = 1  /* row offsets only; column indices are always int32 */
+} spblas_gfx950_indextype;
+
+typedef enum spblas_gfx950_operation {
+  SPBLAS_GFX950_OP_N = 0, /* csr_view                      (vendor/rocsparse/detail/get_transpose.hpp:25-26) */
+  SPBLAS_GFX950_OP_T = 1  /* csc_view / transposed(csr)    (vendor/rocsparse/detail/get_transpose.hpp:27-28) */
+} spblas_gfx950_operation;
+
+/* SpMV algorithm selector (plan creation).  AUTO picks from the row statistics. */
+typedef enum spblas_gfx950_spmv_alg {
+  SPBLAS_GFX950_SPMV_AUTO = 0,
+  SPBLAS_GFX950_SPMV_VECTOR = 1,   /* sub-wavefront group per row, no plan data */
+  SPBLAS_GFX950_SPMV_ROWBLOCK = 2, /* nnz-window row blocks staged through LDS   */
+  SPBLAS_GFX950_SPMV_SLICED = 3    /* column-sliced reorder (x slice L2-resident) */
+} spblas_gfx950_spmv_alg;
+
+/* ---- library / handle ---------------------------------------------------- */
+int spblas_gfx950_version(void);
+const char* spblas_gfx950_status_string(int status);
+/* hipError_t of the most recent STATUS_HIP_ERROR on this thread (0 if none). */
+int spblas_gfx950_last_hip_error(void);
+
+/* stream: a hipStream_t (NULL = the null stream), cf. hip_allocator(hipStream_t),
+ * vendor/rocsparse/hip_allocator.hpp:22. */
+int spblas_gfx950_create(spblas_gfx950_handle_t* handle, void* stream);
+int spblas_gfx950_destroy(spblas_gfx950_handle_t handle);
+int spblas_gfx950_set_stream(spblas_gfx950_handle_t handle, void* stream);
+int spblas_gfx950_get_stream(spblas_gfx950_handle_t handle, void** stream);
+
+/* ---- SpMV:  y = alpha * op(A) * x + beta * y ------------------------------ */
+/* multiply_inspect(A, x, y): device-side analysis of the sparsity pattern.
+ * Builds the nnz-window row partition, the long-row list and (SLICED) the
+ * column-sliced reorder; the result lives in device memory owned by the plan.
+ * `values` may be NULL unless alg == SLICED (the reorder copies the values; call
+ * spblas_gfx950_spmv_plan_update_values after changing them in place).
+ * The plan is tied to (m, n, nnz, rowptr, colind). */
+int spblas_gfx950_spmv_plan_create(spblas_gfx950_handle_t handle, spblas_gfx950_plan_t* plan,
+                                   int64_t m, int64_t n, int64_t nnz, const void* rowptr,
+                                   const int32_t* colind, const void* values, int offset_type,
+                                   int value_type, int alg);
+int spblas_gfx950_spmv_plan_update_values(spblas_gfx950_handle_t handle, spblas_gfx950_plan_t plan,
+                                          const void* values);
+int spblas_gfx950_plan_destroy(spblas_gfx950_handle_t handle, spblas_gfx950_plan_t plan);
+/* Introspection for tests/bench: info[0]=alg, [1]=window nnz, [2]=#windows,
+ * [3]=#long rows, [4]=max row length, [5]=device bytes held, [6]=#column slices,
+ * [7]=#empty rows. */
+int spblas_gfx950_plan_info(spblas_gfx950_plan_t plan, int64_t info[8]);
+
+/* multiply(info, A, x, y) / multiply(A, x, y).  plan may be NULL (no inspect):
+ * a plan-free kernel is chosen from nnz/m.  op == OP_T computes y = alpha*A^T*x
+ * for an m x n CSR A (y has n entries, x has m): the CSC / transposed case. */
+int spblas_gfx950_spmv(spblas_gfx950_handle_t handle, spblas_gfx950_plan_t plan, int op, int64_t m,
+                       int64_t n, int64_t nnz, const void* alpha, const void* rowptr,
+                       const int32_t* colind, const void* values, const void* x, const void* beta,
+                       void* y, int offset_type, int value_type);
+
+/* ---- SpMM:  C = alpha * A * B + beta * C,  B (k x n), C (m x n) row-major --- */
+/* ldb/ldc are row strides in elements (mdspan layout_right, test/gtest/spmm_test.cpp). */
+int spblas_gfx950_spmm(spblas_gfx950_handle_t handle, spblas_gfx950_plan_t plan, int64_t m, int64_t k,
+                       int64_t n, int64_t nnz, const void* alpha, const void* rowptr,
+                       const int32_t* colind, const void* values, const void* B, int64_t ldb,
+                       const void* beta, void* C, int64_t ldc, int offset_type, int value_type);
+
+/* ---- SpGEMM:  C = alpha * A * B   (CSR x CSR -> CSR, int32 indices) -------- */
+/* State object = spgemm_state_t (vendor/rocsparse/multiply_spgemm.hpp:28-230). */
+int spblas_gfx950_spgemm_create(spblas_gfx950_handle_t handle, spblas_gfx950_spgemm_t* state);
+int spblas_gfx950_spgemm_destroy(spblas_gfx950_handle_t handle, spblas_gfx950_spgemm_t state);
+/* multiply_compute / multiply_symbolic_compute: structural product.  Writes
+ * c_rowptr[0..m] (device, caller-allocated: test/gtest/device/spgemm_test.cpp:37-40)
+ * and returns nnz(C) = sum_i |union_{k in A_i} cols(B_k)| in *c_nnz (host).
+ * Synchronises the stream once. */
+int spblas_gfx950_spgemm_symbolic(spblas_gfx950_handle_t handle, spblas_gfx950_spgemm_t state, int64_t m,
+                                  int64_t k, int64_t n, int64_t a_nnz, const int32_t* a_rowptr,
+                                  const int32_t* a_colind, int64_t b_nnz, const int32_t* b_rowptr,
+                                  const int32_t* b_colind, int32_t* c_rowptr, int64_t* c_nnz);
+/* multiply_fill / multiply_symbolic_fill + multiply_numeric: fills c_colind
+ * (ascending within each row, as spgemm_gustavsons.hpp:42 sorts them) and c_values.
+ * c_capacity = entries available in c_colind / c_values; fewer than nnz(C) ->
+ * STATUS_INSUFFICIENT_SPACE (csr_builder.hpp:18-22).  c_rowptr is rewritten from
+ * the state's copy, so a different buffer than the one passed to symbolic is fine
+ * (test/gtest/device/spgemm_reuse_test.cpp).  a_values/b_values may change between
+ * calls; the pattern may not. */
+int spblas_gfx950_spgemm_numeric(spblas_gfx950_handle_t handle, spblas_gfx950_spgemm_t state, const void* alpha,
+                                 const int32_t* a_rowptr, const int32_t* a_colind, const void* a_values,
+                                 const int32_t* b_rowptr, const int32_t* b_colind, const void* b_values,
+                                 int32_t* c_rowptr, int32_t* c_colind, void* c_values, int64_t c_capacity,
+                                 int value_type);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPBLAS_GFX950_H */

@@ -1,0 +1,314 @@
+/*
+ * spblas_oracle.c -- CPU restatement of the spblas-reference `multiply()` hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product: only
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this
+ * library, and there only as the checker / the timed CPU baseline.  The product
+ * (spblas-reference_amd/, include/) never links, imports or falls back to it.
+ *
+ * PINNING STATUS: "parity unpinned" by reference-executed vectors.  The reference
+ * is a header-only C++23 library whose own build fetches range-v3 / kokkos-mdspan
+ * with CMake FetchContent (CMakeLists.txt:120-124,143-147); neither is in this
+ * image, g++ 11 has no std::views::zip / <mdspan>
+ * (include/spblas/detail/ranges.hpp:5-53, detail/mdspan.hpp:5-42), and the rules of
+ * this build forbid stand-in headers, so the reference cannot be compiled here and
+ * the reference ships NO stored golden vectors.  What the
+ * oracle IS checked against (tests/test_oracle.py): the inline comparator loops of
+ * the reference's own tests (test/gtest/spmv_test.cpp:23-30, spmm_test.cpp,
+ * spgemm_test.cpp:38-67) restated on the reference's test shapes, an independent
+ * scipy.sparse product, and hand-computed known answers in tests/golden/.
+ *
+ * Each function cites the reference lines it follows (paths relative to
+ * /root/reference/include/spblas/).  Build flags mirror the reference's
+ * (-O3 -march=native, CMakeLists.txt:7); like the reference build, the compiler
+ * may contract a*b+c into an FMA.
+ *
+ * Index types: colind int32 (vendor/rocsparse/types.hpp:11-12: GPU backends use
+ * index_t = offset_t = int32_t); rowptr int32 or int64 (suffix _o64).
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORACLE_OK 0
+#define ORACLE_ERR_SHAPE 1   /* std::invalid_argument in the reference */
+#define ORACLE_ERR_NOSPACE 2 /* std::runtime_error("SpGEMM ran out of memory") */
+#define ORACLE_ERR_ALLOC 3
+
+/* ------------------------------------------------------------------------ */
+/* SpMV  y = A x   (algorithms/multiply_impl.hpp:33-53)                       */
+/*                                                                            */
+/* Reference order of operations:                                             */
+/*   1. shape check  (multiply_impl.hpp:37-41)  -> ORACLE_ERR_SHAPE           */
+/*   2. y[i] = 0 for all i (multiply_impl.hpp:43-46)                          */
+/*   3. for each row i in order, for each stored entry p of the row in        */
+/*      STORAGE order (backend/algorithms.hpp:11-19,                          */
+/*      backend/view_customizations.hpp:48-66,90-101):                        */
+/*        y[i] += a_v * x[k]            accumulated directly in y's type      */
+/*   scaled(alpha, A): the row element is alpha*value, formed per element     */
+/*      (views/scaled_view_impl.hpp:145-163) -> y[i] += (alpha*a_v) * x[k]    */
+/*   scaled(alpha, x): lookup(x,k) is alpha*x[k]                              */
+/*      (views/scaled_view_impl.hpp vector part) -> y[i] += a_v*(alpha*x[k])  */
+/* has_sa / has_sx say whether the corresponding scaled_view is present.      */
+/* ------------------------------------------------------------------------ */
+#define DEF_SPMV(NAME, T, O)                                                   \
+  int NAME(int64_t m, int64_t n, int64_t a_rows, int64_t a_cols,               \
+           const O* rowptr, const int32_t* colind, const T* values,            \
+           int has_sa, T sa, const T* x, int has_sx, T sx, T* y) {             \
+    if (a_rows != m || a_cols != n)                                            \
+      return ORACLE_ERR_SHAPE;                                                 \
+    for (int64_t i = 0; i < m; i++)                                            \
+      y[i] = 0;                                                                \
+    for (int64_t i = 0; i < m; i++) {                                          \
+      for (O p = rowptr[i]; p < rowptr[i + 1]; p++) {                          \
+        T a_v = values[p];                                                     \
+        if (has_sa)                                                            \
+          a_v = sa * a_v;                                                      \
+        T b_v = x[colind[p]];                                                  \
+        if (has_sx)                                                            \
+          b_v = sx * b_v;                                                      \
+        y[i] += a_v * b_v;                                                     \
+      }                                                                        \
+    }                                                                          \
+    return ORACLE_OK;                                                          \
+  }
+
+DEF_SPMV(oracle_spmv_f32, float, int32_t)
+DEF_SPMV(oracle_spmv_f64, double, int32_t)
+DEF_SPMV(oracle_spmv_f32_o64, float, int64_t)
+DEF_SPMV(oracle_spmv_f64_o64, double, int64_t)
+
+/* Row-parallel variant used ONLY for the "all host cores" CPU baseline number
+ * (SURVEY.md section 8d).  Same per-row arithmetic and order as above, rows are
+ * independent so results are bitwise identical to the serial oracle. */
+#define DEF_SPMV_OMP(NAME, T, O)                                               \
+  int NAME(int64_t m, const O* rowptr, const int32_t* colind,                  \
+           const T* values, const T* x, T* y) {                                \
+    _Pragma("omp parallel for schedule(static)") for (int64_t i = 0; i < m;    \
+                                                      i++) {                   \
+      T s = 0;                                                                 \
+      for (O p = rowptr[i]; p < rowptr[i + 1]; p++)                            \
+        s += values[p] * x[colind[p]];                                         \
+      y[i] = s;                                                                \
+    }                                                                          \
+    return ORACLE_OK;                                                          \
+  }
+DEF_SPMV_OMP(oracle_spmv_omp_f32, float, int32_t)
+DEF_SPMV_OMP(oracle_spmv_omp_f64, double, int32_t)
+
+/* ------------------------------------------------------------------------ */
+/* SpMV with a CSC operand (y = A x, A stored by columns), the transposed     */
+/* traversal of backend/algorithms.hpp:21-29: for each column j, for each     */
+/* stored (i, v): y[i] += v * x[j].                */
+/* ------------------------------------------------------------------------ */
+#define DEF_SPMV_CSC(NAME, T, O)                                               \
+  int NAME(int64_t m, int64_t n, int64_t a_rows, int64_t a_cols,               \
+           const O* colptr, const int32_t* rowind, const T* values,            \
+           int has_sa, T sa, const T* x, int has_sx, T sx, T* y) {             \
+    if (a_rows != m || a_cols != n)                                            \
+      return ORACLE_ERR_SHAPE;                                                 \
+    for (int64_t i = 0; i < m; i++)                                            \
+      y[i] = 0;                                                                \
+    for (int64_t j = 0; j < n; j++) {                                          \
+      for (O p = colptr[j]; p < colptr[j + 1]; p++) {                          \
+        T a_v = values[p];                                                     \
+        if (has_sa)                                                            \
+          a_v = sa * a_v;                                                      \
+        T b_v = x[j];                                                          \
+        if (has_sx)                                                            \
+          b_v = sx * b_v;                                                      \
+        y[rowind[p]] += a_v * b_v;                                             \
+      }                                                                        \
+    }                                                                          \
+    return ORACLE_OK;                                                          \
+  }
+DEF_SPMV_CSC(oracle_spmv_csc_f32, float, int32_t)
+DEF_SPMV_CSC(oracle_spmv_csc_f64, double, int32_t)
+
+/* ------------------------------------------------------------------------ */
+/* SpMM  C = A B, B (k x n) and C (m x n) dense with leading dimensions       */
+/* (algorithms/multiply_impl.hpp:66-92; mdspan lookup                         */
+/* backend/view_customizations.hpp:230-240).                                  */
+/*   C = 0 (:78-81); for each stored (i,k,a_v) in row-major storage order:    */
+/*     for j < n: C(i,j) += a_v * B(k,j)          (:85-91)                    */
+/* row_major != 0: X(r,c) = X[r*ld + c]; else column-major X[c*ld + r].       */
+/* ------------------------------------------------------------------------ */
+#define DEF_SPMM(NAME, T, O)                                                   \
+  int NAME(int64_t m, int64_t k, int64_t n, int64_t a_rows, int64_t a_cols,    \
+           int64_t b_rows, int64_t b_cols, const O* rowptr,                    \
+           const int32_t* colind, const T* values, int has_sa, T sa,           \
+           const T* B, int64_t ldb, int has_sb, T sb, T* C, int64_t ldc,       \
+           int row_major) {                                                    \
+    if (a_rows != m || b_cols != n || a_cols != b_rows || a_cols != k)         \
+      return ORACLE_ERR_SHAPE;                                                 \
+    for (int64_t i = 0; i < m; i++)                                            \
+      for (int64_t j = 0; j < n; j++)                                          \
+        C[row_major ? i * ldc + j : j * ldc + i] = 0;                          \
+    for (int64_t i = 0; i < m; i++) {                                          \
+      for (O p = rowptr[i]; p < rowptr[i + 1]; p++) {                          \
+        T a_v = values[p];                                                     \
+        if (has_sa)                                                            \
+          a_v = sa * a_v;                                                      \
+        int64_t kk = colind[p];                                                \
+        for (int64_t j = 0; j < n; j++) {                                      \
+          T b_v = B[row_major ? kk * ldb + j : j * ldb + kk];                  \
+          if (has_sb)                                                          \
+            b_v = sb * b_v;                                                    \
+          C[row_major ? i * ldc + j : j * ldc + i] += a_v * b_v;               \
+        }                                                                      \
+      }                                                                        \
+    }                                                                          \
+    return ORACLE_OK;                                                          \
+  }
+DEF_SPMM(oracle_spmm_f32, float, int32_t)
+DEF_SPMM(oracle_spmm_f64, double, int32_t)
+
+/* ------------------------------------------------------------------------ */
+/* SpGEMM symbolic: multiply_compute(A,B,C)                                   */
+/* (algorithms/detail/spgemm/spgemm_gustavsons.hpp:57-89 with spa_set         */
+/* backend/spa_accumulator.hpp:66-104).  Structural count only:               */
+/*   nnz(C) = sum_i | union_{k in A_i} cols(B_k) |                            */
+/* The reference returns operation_info_t{shape(C), nnz} and does NOT write   */
+/* C's arrays; row_nnz (may be NULL) additionally reports the per-row counts  */
+/* so device rowptr output can be compared exactly.                           */
+/* ------------------------------------------------------------------------ */
+int oracle_spgemm_symbolic(int64_t m, int64_t k, int64_t n, int64_t c_rows,
+                           int64_t c_cols, int64_t b_rows,
+                           const int32_t* a_rowptr, const int32_t* a_colind,
+                           const int32_t* b_rowptr, const int32_t* b_colind,
+                           int64_t* row_nnz, int64_t* nnz_out) {
+  if (m != c_rows || n != c_cols || k != b_rows)
+    return ORACLE_ERR_SHAPE;
+  uint8_t* set = (uint8_t*) calloc((size_t) (n > 0 ? n : 1), 1);
+  int32_t* stored = (int32_t*) malloc(sizeof(int32_t) * (size_t) (n > 0 ? n : 1));
+  if (!set || !stored) {
+    free(set);
+    free(stored);
+    return ORACLE_ERR_ALLOC;
+  }
+  int64_t nnz = 0;
+  for (int64_t i = 0; i < m; i++) {
+    int64_t cnt = 0;
+    for (int32_t p = a_rowptr[i]; p < a_rowptr[i + 1]; p++) {
+      int32_t kk = a_colind[p];
+      for (int32_t q = b_rowptr[kk]; q < b_rowptr[kk + 1]; q++) {
+        int32_t j = b_colind[q];
+        if (!set[j]) {
+          set[j] = 1;
+          stored[cnt++] = j;
+        }
+      }
+    }
+    for (int64_t t = 0; t < cnt; t++)
+      set[stored[t]] = 0;
+    if (row_nnz)
+      row_nnz[i] = cnt;
+    nnz += cnt;
+  }
+  free(set);
+  free(stored);
+  *nnz_out = nnz;
+  return ORACLE_OK;
+}
+
+static int cmp_i32(const void* a, const void* b) {
+  int32_t x = *(const int32_t*) a, y = *(const int32_t*) b;
+  return (x > y) - (x < y);
+}
+
+/* ------------------------------------------------------------------------ */
+/* SpGEMM numeric: multiply_fill(info,A,B,C) -> multiply(A,B,C)               */
+/* (algorithms/multiply_impl.hpp:143-147 ->                                   */
+/*  algorithms/detail/spgemm/spgemm_gustavsons.hpp:17-52, spa_accumulator     */
+/*  backend/spa_accumulator.hpp:14-64, csr_builder backend/csr_builder.hpp:   */
+/*  16-39).  Per row i: SPA c_row[j] += a_v*b_v in (k, then B-row storage)    */
+/* order (:37-41); sort columns ascending (:42); append; rowptr[i+1] = running */
+/* count; capacity overflow -> "SpGEMM ran out of memory" (:44-48).           */
+/* scaled(alpha,A) / scaled(alpha,B): element = alpha*value per element.      */
+/* ------------------------------------------------------------------------ */
+#define DEF_SPGEMM_NUMERIC(NAME, T)                                            \
+  int NAME(int64_t m, int64_t k, int64_t n, int64_t c_rows, int64_t c_cols,    \
+           int64_t b_rows, const int32_t* a_rowptr, const int32_t* a_colind,   \
+           const T* a_values, int has_sa, T sa, const int32_t* b_rowptr,       \
+           const int32_t* b_colind, const T* b_values, int has_sb, T sb,       \
+           int32_t* c_rowptr, int32_t* c_colind, T* c_values,                  \
+           int64_t capacity, int64_t* nnz_out) {                               \
+    if (m != c_rows || n != c_cols || k != b_rows)                             \
+      return ORACLE_ERR_SHAPE;                                                 \
+    size_t nn = (size_t) (n > 0 ? n : 1);                                      \
+    T* data = (T*) calloc(nn, sizeof(T));                                      \
+    uint8_t* set = (uint8_t*) calloc(nn, 1);                                   \
+    int32_t* stored = (int32_t*) malloc(sizeof(int32_t) * nn);                 \
+    if (!data || !set || !stored) {                                            \
+      free(data);                                                              \
+      free(set);                                                               \
+      free(stored);                                                            \
+      return ORACLE_ERR_ALLOC;                                                 \
+    }                                                                          \
+    int64_t jp = 0;                                                            \
+    int rc = ORACLE_OK;                                                        \
+    c_rowptr[0] = 0;                                                           \
+    for (int64_t i = 0; i < m; i++) {                                          \
+      int64_t cnt = 0;                                                         \
+      for (int32_t p = a_rowptr[i]; p < a_rowptr[i + 1]; p++) {                \
+        int32_t kk = a_colind[p];                                              \
+        T a_v = a_values[p];                                                   \
+        if (has_sa)                                                            \
+          a_v = sa * a_v;                                                      \
+        for (int32_t q = b_rowptr[kk]; q < b_rowptr[kk + 1]; q++) {            \
+          int32_t j = b_colind[q];                                             \
+          T b_v = b_values[q];                                                 \
+          if (has_sb)                                                          \
+            b_v = sb * b_v;                                                    \
+          if (!set[j]) {                                                       \
+            set[j] = 1;                                                        \
+            stored[cnt++] = j;                                                 \
+          }                                                                    \
+          data[j] += a_v * b_v;                                                \
+        }                                                                      \
+      }                                                                        \
+      qsort(stored, (size_t) cnt, sizeof(int32_t), cmp_i32);                   \
+      if (jp + cnt > capacity) {                                               \
+        rc = ORACLE_ERR_NOSPACE;                                               \
+        for (int64_t t = 0; t < cnt; t++) {                                    \
+          set[stored[t]] = 0;                                                  \
+          data[stored[t]] = 0;                                                 \
+        }                                                                      \
+        break;                                                                 \
+      }                                                                        \
+      for (int64_t t = 0; t < cnt; t++) {                                      \
+        int32_t j = stored[t];                                                 \
+        c_values[jp] = data[j];                                                \
+        c_colind[jp] = j;                                                      \
+        jp++;                                                                  \
+        set[j] = 0;                                                            \
+        data[j] = 0;                                                           \
+      }                                                                        \
+      c_rowptr[i + 1] = (int32_t) jp;                                          \
+    }                                                                          \
+    free(data);                                                                \
+    free(set);                                                                 \
+    free(stored);                                                              \
+    *nnz_out = jp;                                                             \
+    return rc;                                                                 \
+  }
+DEF_SPGEMM_NUMERIC(oracle_spgemm_numeric_f32, float)
+DEF_SPGEMM_NUMERIC(oracle_spgemm_numeric_f64, double)
+
+/* Per-row sum of |a_v * x_k| -- the norm the parity tolerance is scaled by
+ * (SURVEY section 8c "Tolerance note"; reference comparator test/gtest/util.hpp:7-23
+ * is likewise norm-wise).  Computed in double. */
+#define DEF_ABSROW(NAME, T)                                                    \
+  void NAME(int64_t m, const int32_t* rowptr, const int32_t* colind,           \
+            const T* values, const T* x, double* out) {                        \
+    for (int64_t i = 0; i < m; i++) {                                          \
+      double s = 0;                                                            \
+      for (int32_t p = rowptr[i]; p < rowptr[i + 1]; p++) {                    \
+        double t = (double) values[p] * (double) x[colind[p]];                 \
+        s += t < 0 ? -t : t;                                                   \
+      }                                                                        \
+      out[i] = s;                                                              \
+    }                                                                          \
+  }
+DEF_ABSROW(oracle_spmv_absrow_f32, float)
+DEF_ABSROW(oracle_spmv_absrow_f64, double)

@@ -1,0 +1,17 @@
+"""spblas-reference_amd: MI355X (gfx950) backend for the spblas-reference multiply() path.
+
+Layout (only what the hot path needs):
+  csrc/      hand-written HIP kernels + the C ABI (include/spblas_gfx950.h)
+  _capi.py   ctypes binding of that ABI (no fallback path)
+  api.py     host-side mirror of the reference's view/operator interface
+  sharded.py row-sharded multi-GPU SpMV (one process per GPU, RCCL all-gather of y)
+  generate.py synthetic inputs
+Import name: `spblas_reference_amd` (see the shim module at the repo root).
+"""
+from . import _build, _capi, generate  # noqa: F401
+from ._capi import BackendError  # noqa: F401
+from .api import (  # noqa: F401
+    conjugated, csc_view, csr_view, get_scaling_factor, get_ultimate_base, has_matrix_opt, index, is_conjugated,
+    matrix_opt, multiply, multiply_compute, multiply_fill, multiply_inspect, multiply_numeric,
+    multiply_symbolic_compute, multiply_symbolic_fill, operation_info_t, scaled, scaled_view, spgemm_state_t,
+    transposed)

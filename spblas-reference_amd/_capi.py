@@ -1,0 +1,108 @@
+"""ctypes binding of the C ABI in include/spblas_gfx950.h.
+
+This is the ONLY route from the Python host layer to compute: there is no CPU or
+torch fallback.  If the HIP library is missing or fails to load, every operation
+raises (the product path must fail loudly, never degrade silently).
+"""
+import ctypes
+import os
+
+from . import _build
+
+c_void_p = ctypes.c_void_p
+c_int = ctypes.c_int
+c_i64 = ctypes.c_int64
+
+SUCCESS = 0
+INVALID_HANDLE = 1
+INVALID_POINTER = 2
+INVALID_SIZE = 3
+INVALID_VALUE = 4
+NOT_SUPPORTED = 5
+ALLOC_FAILED = 6
+HIP_ERROR = 7
+INSUFFICIENT_SPACE = 8
+PLAN_MISMATCH = 9
+
+F32, F64 = 0, 1
+I32, I64 = 0, 1
+OP_N, OP_T = 0, 1
+SPMV_AUTO, SPMV_VECTOR, SPMV_ROWBLOCK, SPMV_SLICED = 0, 1, 2, 3
+
+# every symbol include/spblas_gfx950.h declares: (name, restype, argtypes)
+PROTOTYPES = [
+    ("spblas_gfx950_version", c_int, []),
+    ("spblas_gfx950_status_string", ctypes.c_char_p, [c_int]),
+    ("spblas_gfx950_last_hip_error", c_int, []),
+    ("spblas_gfx950_create", c_int, [ctypes.POINTER(c_void_p), c_void_p]),
+    ("spblas_gfx950_destroy", c_int, [c_void_p]),
+    ("spblas_gfx950_set_stream", c_int, [c_void_p, c_void_p]),
+    ("spblas_gfx950_get_stream", c_int, [c_void_p, ctypes.POINTER(c_void_p)]),
+    ("spblas_gfx950_spmv_plan_create", c_int,
+     [c_void_p, ctypes.POINTER(c_void_p), c_i64, c_i64, c_i64, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int]),
+    ("spblas_gfx950_spmv_plan_update_values", c_int, [c_void_p, c_void_p, c_void_p]),
+    ("spblas_gfx950_plan_destroy", c_int, [c_void_p, c_void_p]),
+    ("spblas_gfx950_plan_info", c_int, [c_void_p, ctypes.POINTER(c_i64)]),
+    ("spblas_gfx950_spmv", c_int,
+     [c_void_p, c_void_p, c_int, c_i64, c_i64, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+      c_void_p, c_int, c_int]),
+    ("spblas_gfx950_spmm", c_int,
+     [c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64,
+      c_void_p, c_void_p, c_i64, c_int, c_int]),
+    ("spblas_gfx950_spgemm_create", c_int, [c_void_p, ctypes.POINTER(c_void_p)]),
+    ("spblas_gfx950_spgemm_destroy", c_int, [c_void_p, c_void_p]),
+    ("spblas_gfx950_spgemm_symbolic", c_int,
+     [c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_void_p,
+      ctypes.POINTER(c_i64)]),
+    ("spblas_gfx950_spgemm_numeric", c_int,
+     [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+      c_void_p, c_i64, c_int]),
+]
+
+_LIB = None
+
+
+class BackendError(RuntimeError):
+    """Non-success status from the gfx950 library (std::runtime_error in the C++ layer)."""
+
+    def __init__(self, status, where):
+        self.status = status
+        msg = lib().spblas_gfx950_status_string(status).decode()
+        if status == HIP_ERROR:
+            msg += f" (hipError_t {lib().spblas_gfx950_last_hip_error()})"
+        super().__init__(f"{where}: {msg}")
+
+
+def library_path():
+    return _build.LIBPATH
+
+
+def lib():
+    """Load (never build silently on a GPU box: build() is explicit) the C-ABI library."""
+    global _LIB
+    if _LIB is None:
+        path = library_path()
+        if not os.path.exists(path):
+            raise RuntimeError(
+                f"{path} is missing: the gfx950 HIP backend is not built. Run "
+                "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). "
+                "There is no CPU fallback.")
+        dll = ctypes.CDLL(path)
+        for name, restype, argtypes in PROTOTYPES:
+            fn = getattr(dll, name)  # AttributeError = ABI drift, surface it
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _LIB = dll
+    return _LIB
+
+
+def check(status, where):
+    """Map a status to the exception type the reference throws at this boundary
+    (SURVEY.md section 8b 'Error convention')."""
+    if status == SUCCESS:
+        return
+    if status == INVALID_SIZE:
+        raise ValueError(f"{where}: matrix dimensions are incompatible.")  # std::invalid_argument
+    if status == ALLOC_FAILED:
+        raise MemoryError(f"{where}: device allocation failed")  # std::bad_alloc
+    raise BackendError(status, where)

@@ -1,0 +1,578 @@
+"""Host-side mirror of the spblas-reference operator interface for the multiply() path.
+
+Same names, argument meaning and error behaviour as the reference (paths relative to
+/root/reference/include/spblas/):
+
+  csr_view / csc_view          views/csr_view.hpp:12-77, views/csc_view.hpp
+  scaled / scaled_view         algorithms/scaled.hpp, views/scaled_view_impl.hpp:97-219
+  conjugated                   views/conjugated_view_impl.hpp (rejected by GPU backends,
+                               vendor/rocsparse/detail/spmv_impl.hpp:29-33)
+  transposed                   algorithms/transposed.hpp:7-21 (zero-copy CSR<->CSC relabel)
+  matrix_opt                   views/matrix_opt_impl.hpp:14-93 (caches the inspect result)
+  operation_info_t             detail/operation_info_t.hpp:28-104
+  spgemm_state_t               vendor/rocsparse/multiply_spgemm.hpp:28-230
+  multiply, multiply_inspect   algorithms/multiply.hpp, vendor/rocsparse/detail/spmv_impl.hpp:18-90,
+                               vendor/onemkl_sycl/spmm_impl.hpp:40-198
+  multiply_compute/_fill, multiply_symbolic_compute/_fill, multiply_numeric
+                               algorithms/multiply.hpp:48-55, vendor/rocsparse/multiply_spgemm.hpp:232-317
+
+The reference is C++; its toolchain dependencies (range-v3, mdspan) are absent from
+this image, so the C++ header layer (include/spblas/vendor/gfx950/) cannot be
+exercised here and this Python layer is what the tests drive.  Device memory is
+held in torch CUDA tensors (plumbing only): a view wraps caller-owned tensors exactly
+as csr_view wraps caller-owned device pointers.  All compute goes through the C ABI
+(include/spblas_gfx950.h); nothing here computes on the CPU or through torch ops.
+"""
+import ctypes
+
+import torch
+
+from . import _capi
+from ._capi import check
+
+
+# --------------------------------------------------------------------------- views
+class index(tuple):
+    """spblas::index<I> (detail/index.hpp:14-55): a (rows, cols) pair."""
+
+    def __new__(cls, a, b=None):
+        if b is None:
+            a, b = a
+        return super().__new__(cls, (int(a), int(b)))
+
+
+def _is_tensor(t):
+    return isinstance(t, torch.Tensor)
+
+
+class view_base:
+    pass
+
+
+class csr_view(view_base):
+    """Non-owning CSR view over caller-owned device arrays (views/csr_view.hpp:20-26)."""
+
+    def __init__(self, values, rowptr, colind, shape, nnz):
+        self._values, self._rowptr, self._colind = values, rowptr, colind
+        self._shape, self._nnz = index(shape), int(nnz)
+
+    def update(self, values, rowptr, colind, shape=None, nnz=None):  # csr_view.hpp:36-49
+        self._values, self._rowptr, self._colind = values, rowptr, colind
+        if shape is not None:
+            self._shape, self._nnz = index(shape), int(nnz)
+
+    def values(self):
+        return self._values
+
+    def rowptr(self):
+        return self._rowptr
+
+    def colind(self):
+        return self._colind
+
+    def shape(self):
+        return self._shape
+
+    def size(self):
+        return self._nnz
+
+
+class csc_view(view_base):
+    """Non-owning CSC view (views/csc_view.hpp)."""
+
+    def __init__(self, values, colptr, rowind, shape, nnz):
+        self._values, self._colptr, self._rowind = values, colptr, rowind
+        self._shape, self._nnz = index(shape), int(nnz)
+
+    def values(self):
+        return self._values
+
+    def colptr(self):
+        return self._colptr
+
+    def rowind(self):
+        return self._rowind
+
+    def shape(self):
+        return self._shape
+
+    def size(self):
+        return self._nnz
+
+
+class scaled_view(view_base):
+    def __init__(self, alpha, base):
+        self._alpha, self._base = alpha, base
+
+    def alpha(self):
+        return self._alpha
+
+    def base(self):
+        return self._base
+
+    def shape(self):
+        return _shape_of(self._base)
+
+
+class conjugated_view(view_base):
+    def __init__(self, base):
+        self._base = base
+
+    def base(self):
+        return self._base
+
+    def shape(self):
+        return _shape_of(self._base)
+
+
+class matrix_opt(view_base):
+    """matrix_opt<M> (views/matrix_opt_impl.hpp): owns the cached vendor handle -- here
+    the SpMV/SpMM plan built by multiply_inspect."""
+
+    def __init__(self, matrix):
+        if not isinstance(matrix, (csr_view, csc_view)):
+            raise TypeError("matrix_opt wraps a csr_view or csc_view")
+        self.matrix_ = matrix
+        self._plan = None
+
+    def base(self):
+        return self.matrix_
+
+    def shape(self):
+        return self.matrix_.shape()
+
+    def size(self):
+        return self.matrix_.size()
+
+
+def scaled(alpha, t):
+    return scaled_view(alpha, t)
+
+
+def conjugated(t):
+    return conjugated_view(t)
+
+
+def transposed(a):
+    """algorithms/transposed.hpp:7-21: re-label CSR<->CSC with zero copy."""
+    if isinstance(a, csr_view):
+        return csc_view(a.values(), a.rowptr(), a.colind(), (a.shape()[1], a.shape()[0]), a.size())
+    if isinstance(a, csc_view):
+        return csr_view(a.values(), a.colptr(), a.rowind(), (a.shape()[1], a.shape()[0]), a.size())
+    raise TypeError("transposed() expects a csr_view or csc_view")
+
+
+# ----------------------------------------------------------- detail/view_inspectors.hpp
+def get_ultimate_base(t):  # view_inspectors.hpp:104-111
+    while isinstance(t, (scaled_view, conjugated_view, matrix_opt)):
+        t = t.base()
+    return t
+
+
+def get_scaling_factor(*ts):  # view_inspectors.hpp:22-77: product of all factors, or None
+    out = None
+    for t in ts:
+        while isinstance(t, (scaled_view, conjugated_view, matrix_opt)):
+            if isinstance(t, scaled_view):
+                out = t.alpha() if out is None else out * t.alpha()
+            t = t.base()
+    return out
+
+
+def is_conjugated(t):  # view_inspectors.hpp:81-97: odd number of conjugated_views
+    c = False
+    while isinstance(t, (scaled_view, conjugated_view, matrix_opt)):
+        if isinstance(t, conjugated_view):
+            c = not c
+        t = t.base()
+    return c
+
+
+def has_matrix_opt(t):  # view_inspectors.hpp:113-122
+    while isinstance(t, (scaled_view, conjugated_view, matrix_opt)):
+        if isinstance(t, matrix_opt):
+            return True
+        t = t.base()
+    return False
+
+
+def _get_matrix_opt(t):
+    while isinstance(t, (scaled_view, conjugated_view, matrix_opt)):
+        if isinstance(t, matrix_opt):
+            return t
+        t = t.base()
+    return None
+
+
+def _shape_of(t):
+    if _is_tensor(t):
+        return t.shape[0] if t.dim() == 1 else index(t.shape[0], t.shape[1])
+    return t.shape()
+
+
+# --------------------------------------------------------------------------- state
+class _Handle:
+    _by_device = {}
+
+    def __init__(self, device):
+        self.device = device
+        h = ctypes.c_void_p()
+        with torch.cuda.device(device):
+            check(_capi.lib().spblas_gfx950_create(ctypes.byref(h), None), "spblas_gfx950_create")
+        self.h = h
+
+    @classmethod
+    def current(cls, device):
+        if device.type != "cuda":
+            raise RuntimeError("gfx950 backend: arrays must live in device (HIP) memory; there is no CPU fallback")
+        key = device.index if device.index is not None else torch.cuda.current_device()
+        hd = cls._by_device.get(key)
+        if hd is None:
+            hd = cls._by_device[key] = cls(key)
+        stream = torch.cuda.current_stream(key).cuda_stream
+        check(_capi.lib().spblas_gfx950_set_stream(hd.h, ctypes.c_void_p(stream)), "spblas_gfx950_set_stream")
+        return hd
+
+
+class _Plan:
+    """Owner of a spblas_gfx950_plan_t (released with the handle's stream order)."""
+
+    def __init__(self, handle, plan, key):
+        self.handle, self.plan, self.key = handle, plan, key
+
+    def info(self):
+        arr = (ctypes.c_int64 * 8)()
+        check(_capi.lib().spblas_gfx950_plan_info(self.plan, arr), "spblas_gfx950_plan_info")
+        names = ["alg", "window", "n_windows", "n_long_rows", "max_row_len", "device_bytes", "n_slices",
+                 "empty_rows"]
+        return dict(zip(names, list(arr)))
+
+    def __del__(self):
+        try:
+            if self.plan:
+                _capi.lib().spblas_gfx950_plan_destroy(self.handle.h, self.plan)
+                self.plan = None
+        except Exception:
+            pass
+
+
+class operation_info_t:
+    """detail/operation_info_t.hpp:28-104: result_shape(), result_nnz(), backend state_."""
+
+    def __init__(self, result_shape=(0, 0), result_nnz=0, state=None):
+        self._result_shape, self._result_nnz = index(result_shape), int(result_nnz)
+        self.state_ = state
+
+    def result_shape(self):
+        return self._result_shape
+
+    def result_nnz(self):
+        return self._result_nnz
+
+    def update_impl_(self, result_shape, result_nnz):
+        self._result_shape, self._result_nnz = index(result_shape), int(result_nnz)
+
+
+class spgemm_state_t:
+    """vendor/rocsparse/multiply_spgemm.hpp:28-230."""
+
+    def __init__(self):
+        self._handle = None
+        self._state = None
+        self._result_shape = index(0, 0)
+        self._result_nnz = 0
+
+    def result_shape(self):
+        return self._result_shape
+
+    def result_nnz(self):
+        return self._result_nnz
+
+    def _ensure(self, device):
+        if self._state is None:
+            self._handle = _Handle.current(device)
+            st = ctypes.c_void_p()
+            check(_capi.lib().spblas_gfx950_spgemm_create(self._handle.h, ctypes.byref(st)),
+                  "spblas_gfx950_spgemm_create")
+            self._state = st
+        else:
+            _Handle.current(device)  # refresh the stream
+        return self._handle, self._state
+
+    def __del__(self):
+        try:
+            if self._state:
+                _capi.lib().spblas_gfx950_spgemm_destroy(self._handle.h, self._state)
+                self._state = None
+        except Exception:
+            pass
+
+
+# --------------------------------------------------------------------------- helpers
+_VT = {torch.float32: (_capi.F32, ctypes.c_float), torch.float64: (_capi.F64, ctypes.c_double)}
+_OT = {torch.int32: _capi.I32, torch.int64: _capi.I64}
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None and t.numel() > 0 else ctypes.c_void_p(
+        t.data_ptr() if t is not None else 0)
+
+
+def _vtype(t, what):
+    if t.dtype not in _VT:
+        raise TypeError(f"{what}: gfx950 backend supports float32/float64 values, got {t.dtype}")
+    return _VT[t.dtype]
+
+
+def _check_csr(a, what):
+    if a.colind() is not None and a.colind().dtype != torch.int32:
+        raise TypeError(f"{what}: column indices must be int32 (spblas::index_t on GPU backends)")
+    if a.rowptr().dtype not in _OT:
+        raise TypeError(f"{what}: row offsets must be int32 or int64")
+    for t in (a.values(), a.rowptr(), a.colind()):
+        if t is not None and not t.is_contiguous():
+            raise ValueError(f"{what}: arrays must be contiguous")
+
+
+def _reject_conjugated(*ts):
+    if any(is_conjugated(t) for t in ts):
+        raise RuntimeError("gfx950 backend does not support conjugated views.")  # spmv_impl.hpp:29-33
+
+
+def _plan_key(a_base):
+    return (a_base.rowptr().data_ptr(), a_base.colind().data_ptr(), a_base.values().data_ptr(),
+            tuple(a_base.shape()), a_base.size(), a_base.rowptr().dtype, a_base.values().dtype)
+
+
+def _build_plan(a_base, alg=_capi.SPMV_AUTO):
+    hd = _Handle.current(a_base.rowptr().device)
+    vt, _ = _vtype(a_base.values(), "multiply_inspect")
+    plan = ctypes.c_void_p()
+    m, n = a_base.shape()
+    check(_capi.lib().spblas_gfx950_spmv_plan_create(hd.h, ctypes.byref(plan), m, n, a_base.size(),
+                                                     _ptr(a_base.rowptr()), _ptr(a_base.colind()),
+                                                     _ptr(a_base.values()), _OT[a_base.rowptr().dtype], vt, alg),
+          "multiply_inspect")
+    return _Plan(hd, plan, _plan_key(a_base))
+
+
+def _find_plan(info, a, a_base):
+    key = _plan_key(a_base)
+    if info is not None and isinstance(info.state_, _Plan) and info.state_.key == key:
+        return info.state_
+    mo = _get_matrix_opt(a)
+    if mo is not None and isinstance(mo._plan, _Plan) and mo._plan.key == key:
+        return mo._plan
+    return None
+
+
+# --------------------------------------------------------------------------- SpMV / SpMM
+def _spmv(info, a, b, c):
+    a_base, b_base = get_ultimate_base(a), get_ultimate_base(b)
+    _reject_conjugated(a, b, c)
+    if not _is_tensor(c) or c.dim() != 1:
+        raise TypeError("multiply: the output vector must be a plain 1-D device tensor")
+    op = _capi.OP_N
+    if isinstance(a_base, csc_view):
+        # CSC = CSR of the transpose + TRANSPOSE (vendor/rocsparse/detail/get_transpose.hpp:19-29)
+        a_csr = csr_view(a_base.values(), a_base.colptr(), a_base.rowind(),
+                         (a_base.shape()[1], a_base.shape()[0]), a_base.size())
+        op = _capi.OP_T
+    else:
+        a_csr = a_base
+    _check_csr(a_csr, "multiply")
+    if a_base.shape()[0] != c.shape[0] or a_base.shape()[1] != b_base.shape[0]:
+        # algorithms/multiply_impl.hpp:37-41
+        raise ValueError("multiply: matrix and vector dimensions are incompatible.")
+    vt, ct = _vtype(a_csr.values(), "multiply")
+    if b_base.dtype != a_csr.values().dtype or c.dtype != a_csr.values().dtype:
+        raise TypeError("multiply: A, x and y must share one value type")
+    if not (b_base.is_contiguous() and c.is_contiguous()):
+        raise ValueError("multiply: x and y must be contiguous")
+    alpha_opt = get_scaling_factor(a, b)
+    alpha = ct(1 if alpha_opt is None else alpha_opt)  # spmv_impl.hpp:35-37
+    beta = ct(0)
+    hd = _Handle.current(c.device)
+    plan = _find_plan(info, a, a_base) if op == _capi.OP_N else None
+    m, n = a_csr.shape()
+    check(_capi.lib().spblas_gfx950_spmv(hd.h, plan.plan if plan else None, op, m, n, a_csr.size(),
+                                         ctypes.byref(alpha), _ptr(a_csr.rowptr()), _ptr(a_csr.colind()),
+                                         _ptr(a_csr.values()), _ptr(b_base), ctypes.byref(beta), _ptr(c),
+                                         _OT[a_csr.rowptr().dtype], vt), "multiply")
+
+
+def _spmm(info, a, b, c):
+    a_base, b_base = get_ultimate_base(a), get_ultimate_base(b)
+    _reject_conjugated(a, b, c)
+    if not isinstance(a_base, csr_view):
+        raise NotImplementedError("gfx950 SpMM: A must have a csr_view base")
+    if not _is_tensor(c) or c.dim() != 2:
+        raise TypeError("multiply: the output matrix must be a plain 2-D row-major device tensor")
+    _check_csr(a_base, "multiply")
+    if (a_base.shape()[0] != c.shape[0] or b_base.shape[1] != c.shape[1]
+            or a_base.shape()[1] != b_base.shape[0]):
+        raise ValueError("multiply: matrix dimensions are incompatible.")  # multiply_impl.hpp:70-76
+    vt, ct = _vtype(a_base.values(), "multiply")
+    if b_base.dtype != a_base.values().dtype or c.dtype != a_base.values().dtype:
+        raise TypeError("multiply: A, B and C must share one value type")
+    for t in (b_base, c):  # layout_right only (vendor/onemkl_sycl/spmm_impl.hpp:133-138)
+        if t.numel() > 0 and t.stride(1) != 1:
+            raise ValueError("multiply: dense operands must be row-major (layout_right)")
+    alpha_opt = get_scaling_factor(a, b)
+    alpha, beta = ct(1 if alpha_opt is None else alpha_opt), ct(0)
+    hd = _Handle.current(c.device)
+    m, k = a_base.shape()
+    n = c.shape[1]
+    ldb = b_base.stride(0) if b_base.shape[0] > 1 else max(n, 1)
+    ldc = c.stride(0) if c.shape[0] > 1 else max(n, 1)
+    check(_capi.lib().spblas_gfx950_spmm(hd.h, None, m, k, n, a_base.size(), ctypes.byref(alpha),
+                                         _ptr(a_base.rowptr()), _ptr(a_base.colind()), _ptr(a_base.values()),
+                                         _ptr(b_base), ldb, ctypes.byref(beta), _ptr(c), ldc,
+                                         _OT[a_base.rowptr().dtype], vt), "multiply")
+
+
+def _is_sparse(t):
+    return isinstance(get_ultimate_base(t), (csr_view, csc_view))
+
+
+def _split_info(args):
+    if len(args) == 4:
+        return args[0], args[1], args[2], args[3]
+    if len(args) == 3:
+        return None, args[0], args[1], args[2]
+    raise TypeError("expected (a, b, c) or (info, a, b, c)")
+
+
+def multiply(*args):
+    """multiply(a, b, c) / multiply(info, a, b, c): c = a * b.
+    SpMV when b is a vector, SpMM when b is a dense matrix
+    (vendor/rocsparse/detail/spmv_impl.hpp:25,87; vendor/onemkl_sycl/spmm_impl.hpp:96-125)."""
+    info, a, b, c = _split_info(args)
+    b_base = get_ultimate_base(b)
+    if isinstance(info, spgemm_state_t) or _is_sparse(b):
+        raise TypeError("SpGEMM is two-phase on device backends: use multiply_compute + multiply_fill")
+    if not _is_tensor(b_base):
+        raise TypeError("multiply: b must be a device tensor (vector or row-major matrix)")
+    if b_base.dim() == 1:
+        return _spmv(info, a, b, c)
+    return _spmm(info, a, b, c)
+
+
+def multiply_inspect(*args, alg=_capi.SPMV_AUTO):
+    """multiply_inspect(a, b, c) -> operation_info_t, or multiply_inspect(info, a, b, c).
+    Builds the gfx950 row partition on device and stores it in the info's state_; when A
+    is wrapped in matrix_opt it is cached there too (the oneMKL model,
+    vendor/onemkl_sycl/spmm_impl.hpp:48-61, views/matrix_opt_impl.hpp:90-92)."""
+    info, a, b, c = _split_info(args)
+    ret = info is None
+    if info is None:
+        info = operation_info_t()
+    if isinstance(info, spgemm_state_t):
+        return None  # vendor/rocsparse/multiply_spgemm.hpp:232-235: no-op
+    a_base = get_ultimate_base(a)
+    _reject_conjugated(a, b, c)
+    if isinstance(a_base, csr_view) and not _is_sparse(b) and a_base.values() is not None:
+        _check_csr(a_base, "multiply_inspect")
+        plan = _build_plan(a_base, alg)
+        info.state_ = plan
+        mo = _get_matrix_opt(a)
+        if mo is not None:
+            mo._plan = plan
+    return info if ret else None
+
+
+# --------------------------------------------------------------------------- SpGEMM
+def _spgemm_operands(a, b, c):
+    a_base, b_base = get_ultimate_base(a), get_ultimate_base(b)
+    if not (isinstance(a_base, csr_view) and isinstance(b_base, csr_view) and isinstance(c, csr_view)):
+        raise NotImplementedError("gfx950 SpGEMM supports CSR * CSR -> CSR")
+    _reject_conjugated(a, b)
+    for t in (a_base, b_base):
+        _check_csr(t, "multiply_compute")
+        if t.rowptr().dtype != torch.int32:
+            raise TypeError("SpGEMM: int32 row offsets only")
+    if (a_base.shape()[0] != c.shape()[0] or b_base.shape()[1] != c.shape()[1]
+            or a_base.shape()[1] != b_base.shape()[0]):
+        raise ValueError("multiply: matrix dimensions are incompatible.")  # spgemm_gustavsons.hpp:22-27
+    return a_base, b_base
+
+
+def _symbolic(state, a, b, c):
+    a_base, b_base = _spgemm_operands(a, b, c)
+    if c.rowptr() is None or c.rowptr().dtype != torch.int32 or c.rowptr().numel() < c.shape()[0] + 1:
+        raise ValueError("multiply_compute: c.rowptr must hold shape[0]+1 int32 entries")
+    hd, st = state._ensure(c.rowptr().device)
+    nnz = ctypes.c_int64(0)
+    m, k = a_base.shape()
+    n = b_base.shape()[1]
+    check(_capi.lib().spblas_gfx950_spgemm_symbolic(hd.h, st, m, k, n, a_base.size(), _ptr(a_base.rowptr()),
+                                                    _ptr(a_base.colind()), b_base.size(), _ptr(b_base.rowptr()),
+                                                    _ptr(b_base.colind()), _ptr(c.rowptr()), ctypes.byref(nnz)),
+          "multiply_compute")
+    state._result_shape, state._result_nnz = index(m, n), nnz.value
+
+
+def _numeric(state, a, b, c):
+    a_base, b_base = _spgemm_operands(a, b, c)
+    if state._state is None:
+        raise RuntimeError("multiply_fill: multiply_compute has not been called on this state")
+    hd, st = state._ensure(c.rowptr().device)
+    nnz = state._result_nnz
+    cap = 0
+    if c.values() is not None and c.colind() is not None:
+        cap = min(c.values().numel(), c.colind().numel())
+    if cap < nnz:
+        raise RuntimeError("multiply: SpGEMM ran out of memory.")  # spgemm_gustavsons.hpp:44-48
+    vt, ct = _vtype(a_base.values(), "multiply_fill")
+    alpha_opt = get_scaling_factor(a, b)
+    alpha = ct(1 if alpha_opt is None else alpha_opt)
+    check(_capi.lib().spblas_gfx950_spgemm_numeric(hd.h, st, ctypes.byref(alpha), _ptr(a_base.rowptr()),
+                                                   _ptr(a_base.colind()), _ptr(a_base.values()),
+                                                   _ptr(b_base.rowptr()), _ptr(b_base.colind()),
+                                                   _ptr(b_base.values()), _ptr(c.rowptr()), _ptr(c.colind()),
+                                                   _ptr(c.values()), cap, vt), "multiply_fill")
+    c.update(c.values(), c.rowptr(), c.colind(), state._result_shape, nnz)  # spgemm_gustavsons.hpp:50-51
+
+
+def multiply_compute(*args):
+    """multiply_compute(a, b, c) -> operation_info_t; multiply_compute(info, a, b, c);
+    multiply_compute(spgemm_state, a, b, c)   (algorithms/multiply.hpp:48-52,
+    vendor/rocsparse/multiply_spgemm.hpp:72-118,277-283).  Writes c.rowptr, reports nnz(C)."""
+    info, a, b, c = _split_info(args)
+    if isinstance(info, spgemm_state_t):
+        return _symbolic(info, a, b, c)
+    ret = info is None
+    if info is None:
+        info = operation_info_t()
+    if not isinstance(info.state_, spgemm_state_t):
+        info.state_ = spgemm_state_t()
+    _symbolic(info.state_, a, b, c)
+    info.update_impl_(info.state_.result_shape(), info.state_.result_nnz())
+    return info if ret else None
+
+
+def multiply_fill(info, a, b, c):
+    """multiply_fill(info | spgemm_state, a, b, c) (algorithms/multiply.hpp:54-55,
+    vendor/rocsparse/multiply_spgemm.hpp:123-145)."""
+    state = info if isinstance(info, spgemm_state_t) else info.state_
+    if not isinstance(state, spgemm_state_t):
+        raise RuntimeError("multiply_fill: info does not come from multiply_compute")
+    return _numeric(state, a, b, c)
+
+
+# symbolic/numeric reuse family (vendor/rocsparse/multiply_spgemm.hpp:252-274,293-317)
+def multiply_symbolic_compute(state, a, b, c):
+    return _symbolic(state, a, b, c)
+
+
+def multiply_symbolic_fill(state, a, b, c):
+    """Binds C's arrays; the structure (rowptr) is already final after symbolic_compute,
+    colind is produced together with the values by multiply_numeric."""
+    _spgemm_operands(a, b, c)
+    if state._state is None:
+        raise RuntimeError("multiply_symbolic_fill: multiply_symbolic_compute has not been called")
+    return None
+
+
+def multiply_numeric(state, a, b, c):
+    return _numeric(state, a, b, c)

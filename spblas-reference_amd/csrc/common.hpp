@@ -1,0 +1,105 @@
+// Shared host/device helpers of the gfx950 backend library (not part of the ABI).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+
+#include "spblas_gfx950.h"
+
+#define SPB_WAVE 64  // CDNA wavefront width
+
+struct spblas_gfx950_handle_s {
+  hipStream_t stream;
+  int device;
+  int num_cus;
+};
+
+namespace spb {
+
+extern thread_local int g_last_hip_error;
+
+inline int hip_fail(hipError_t e) {
+  g_last_hip_error = (int) e;
+  return e == hipErrorOutOfMemory ? SPBLAS_GFX950_STATUS_ALLOC_FAILED : SPBLAS_GFX950_STATUS_HIP_ERROR;
+}
+
+#define SPB_HIP(expr)                                                                              \
+  do {                                                                                             \
+    hipError_t spb_e_ = (expr);                                                                    \
+    if (spb_e_ != hipSuccess)                                                                      \
+      return ::spb::hip_fail(spb_e_);                                                              \
+  } while (0)
+
+// Stream-ordered device allocation, the same primitive the reference's
+// hip_allocator uses (vendor/rocsparse/hip_allocator.hpp:34-47).
+inline int dev_alloc(void** p, size_t bytes, hipStream_t s) {
+  *p = nullptr;
+  if (bytes == 0)
+    return SPBLAS_GFX950_STATUS_SUCCESS;
+  hipError_t e = hipMallocAsync(p, bytes, s);
+  if (e != hipSuccess) {
+    (void) hipGetLastError();
+    e = hipMalloc(p, bytes);
+  }
+  if (e != hipSuccess) {
+    g_last_hip_error = (int) e;
+    return SPBLAS_GFX950_STATUS_ALLOC_FAILED;
+  }
+  return SPBLAS_GFX950_STATUS_SUCCESS;
+}
+
+inline void dev_free(void* p, hipStream_t s) {
+  if (!p)
+    return;
+  if (hipFreeAsync(p, s) != hipSuccess) {
+    (void) hipGetLastError();
+    (void) hipFree(p);
+  }
+}
+
+template <typename T>
+struct scalar_of;
+template <>
+struct scalar_of<float> {
+  static constexpr int id = SPBLAS_GFX950_F32;
+};
+template <>
+struct scalar_of<double> {
+  static constexpr int id = SPBLAS_GFX950_F64;
+};
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+
+// Sum over the `width` (power of two <= 64) consecutive lanes a lane belongs to.
+template <typename T>
+__device__ __forceinline__ T group_sum(T v, int width) {
+  for (int o = width >> 1; o > 0; o >>= 1)
+    v += __shfl_xor(v, o, SPB_WAVE);
+  return v;
+}
+
+template <int WIDTH, typename T>
+__device__ __forceinline__ T group_sum_c(T v) {
+#pragma unroll
+  for (int o = WIDTH >> 1; o > 0; o >>= 1)
+    v += __shfl_xor(v, o, SPB_WAVE);
+  return v;
+}
+
+// Streaming (read-once) loads: keep A's arrays from evicting x / B out of L2.
+template <typename V>
+__device__ __forceinline__ V stream_load(const V* p) {
+  return __builtin_nontemporal_load(p);
+}
+
+inline int64_t cdiv(int64_t a, int64_t b) {
+  return (a + b - 1) / b;
+}
+
+} // namespace spb

@@ -1,0 +1,80 @@
+// Handle / status plumbing of the gfx950 backend C ABI (include/spblas_gfx950.h).
+// Replaces rocsparse_create_handle / rocsparse_set_stream / rocsparse_destroy_handle
+// (/root/reference/include/spblas/vendor/rocsparse/detail/abstract_operation_state.hpp:20-28,
+//  vendor/rocsparse/multiply_spgemm.hpp:34-43).
+#include "common.hpp"
+
+#include <new>
+
+namespace spb {
+thread_local int g_last_hip_error = 0;
+}
+
+extern "C" {
+
+int spblas_gfx950_version(void) {
+  return 100;  // 0.1.0
+}
+
+const char* spblas_gfx950_status_string(int status) {
+  switch (status) {
+  case SPBLAS_GFX950_STATUS_SUCCESS: return "success";
+  case SPBLAS_GFX950_STATUS_INVALID_HANDLE: return "invalid handle";
+  case SPBLAS_GFX950_STATUS_INVALID_POINTER: return "invalid pointer";
+  case SPBLAS_GFX950_STATUS_INVALID_SIZE: return "matrix dimensions are incompatible";
+  case SPBLAS_GFX950_STATUS_INVALID_VALUE: return "invalid value";
+  case SPBLAS_GFX950_STATUS_NOT_SUPPORTED: return "not supported";
+  case SPBLAS_GFX950_STATUS_ALLOC_FAILED: return "device allocation failed";
+  case SPBLAS_GFX950_STATUS_HIP_ERROR: return "HIP runtime error";
+  case SPBLAS_GFX950_STATUS_INSUFFICIENT_SPACE: return "SpGEMM ran out of memory";
+  case SPBLAS_GFX950_STATUS_PLAN_MISMATCH: return "plan does not match the matrix";
+  default: return "unknown status";
+  }
+}
+
+int spblas_gfx950_last_hip_error(void) {
+  return spb::g_last_hip_error;
+}
+
+int spblas_gfx950_create(spblas_gfx950_handle_t* handle, void* stream) {
+  if (!handle)
+    return SPBLAS_GFX950_STATUS_INVALID_POINTER;
+  *handle = nullptr;
+  int dev = 0;
+  SPB_HIP(hipGetDevice(&dev));
+  int cus = 0;
+  SPB_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  auto* h = new (std::nothrow) spblas_gfx950_handle_s();
+  if (!h)
+    return SPBLAS_GFX950_STATUS_ALLOC_FAILED;
+  h->stream = static_cast<hipStream_t>(stream);
+  h->device = dev;
+  h->num_cus = cus;
+  *handle = h;
+  return SPBLAS_GFX950_STATUS_SUCCESS;
+}
+
+int spblas_gfx950_destroy(spblas_gfx950_handle_t handle) {
+  if (!handle)
+    return SPBLAS_GFX950_STATUS_INVALID_HANDLE;
+  delete handle;
+  return SPBLAS_GFX950_STATUS_SUCCESS;
+}
+
+int spblas_gfx950_set_stream(spblas_gfx950_handle_t handle, void* stream) {
+  if (!handle)
+    return SPBLAS_GFX950_STATUS_INVALID_HANDLE;
+  handle->stream = static_cast<hipStream_t>(stream);
+  return SPBLAS_GFX950_STATUS_SUCCESS;
+}
+
+int spblas_gfx950_get_stream(spblas_gfx950_handle_t handle, void** stream) {
+  if (!handle)
+    return SPBLAS_GFX950_STATUS_INVALID_HANDLE;
+  if (!stream)
+    return SPBLAS_GFX950_STATUS_INVALID_POINTER;
+  *stream = handle->stream;
+  return SPBLAS_GFX950_STATUS_SUCCESS;
+}
+
+} // extern "C"

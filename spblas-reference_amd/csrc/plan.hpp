@@ -1,0 +1,43 @@
+// SpMV/SpMM plan: the product of multiply_inspect (device-side analysis).
+#pragma once
+
+#include "common.hpp"
+
+struct spblas_gfx950_plan_s {
+  // identity of the matrix the plan was built for
+  int64_t m = 0, n = 0, nnz = 0;
+  const void* rowptr = nullptr;
+  const int32_t* colind = nullptr;
+  int offset_type = 0, value_type = 0;
+
+  int alg = SPBLAS_GFX950_SPMV_VECTOR;
+  int vector_lpr = 8;  // lanes per row for the plan-free kernel
+
+  // ROWBLOCK: nnz windows of `win` entries; win_row[w] = first row whose start
+  // offset is >= w*win (w = 0..nwin), win_row[nwin] = m.
+  int win = 0;
+  int64_t nwin = 0;
+  int32_t* win_row = nullptr;
+  // rows longer than `win` are split across the windows they cover
+  int64_t n_long = 0;
+  int32_t* long_rows = nullptr;
+  void* part_head = nullptr;  // T[nwin]: partial of the long row entering window w
+  void* part_tail = nullptr;  // T[nwin]: partial of the long row starting in window w
+
+  // statistics
+  int64_t max_row_len = 0;
+  int64_t empty_rows = 0;
+
+  // SLICED: column-sliced copy of A (see spmv_sliced.hip)
+  int n_slices = 0;
+  int slice_cols = 0;
+  int rows_per_blk = 0;
+  int64_t n_rblk = 0;
+  int64_t* seg_ptr = nullptr;   // [n_rblk * n_slices + 1] offsets into s_* arrays
+  int32_t* s_colind = nullptr;  // [nnz] column index
+  void* s_values = nullptr;     // [nnz] T
+  uint16_t* s_lrow = nullptr;   // [nnz] row index local to the row block
+  int64_t* s_perm = nullptr;    // [nnz] source position in the CSR arrays
+
+  size_t device_bytes = 0;
+};

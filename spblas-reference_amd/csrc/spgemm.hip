@@ -1,0 +1,603 @@
+// CSR x CSR -> CSR SpGEMM for gfx950:  C = alpha * A * B.
+//
+// Replaces the rocsparse_spgemm stages used at
+// /root/reference/include/spblas/vendor/rocsparse/multiply_spgemm.hpp:94-115 (buffer_size+nnz),
+// :137-144 (compute), :167-172 (symbolic), :209-213 (numeric).  Results follow the CPU
+// path include/spblas/algorithms/detail/spgemm/spgemm_gustavsons.hpp:17-89: nnz(C) is the
+// STRUCTURAL count (no numeric cancellation), columns ascending within each row.
+//
+// Row-wise Gustavson with per-row accumulators sized from an upper bound
+// ub[i] = sum_{k in A_i} len(B_k) (number of products):
+//   bin 0: ub == 0                      empty row
+//   bin 1: ub <= 64     LDS hash 128    16 lanes / row, 16 rows / workgroup
+//   bin 2: ub <= 512    LDS hash 1024   one wavefront / row, 4 rows / workgroup
+//   bin 3: ub <= 4096   LDS hash 8192   one workgroup / row
+//   bin 4: ub  > 4096   dense bitmap (+ dense values) per workgroup in HBM
+// Symbolic counts distinct keys; numeric accumulates with LDS float atomics, compacts,
+// rank-sorts the (unique) keys and writes colind/values in ascending column order.
+// Integer/byte traffic bound: algorithmic bytes = A + B once + C once.
+#include "common.hpp"
+
+#include <new>
+
+#define SPG_NBINS 5
+
+struct spblas_gfx950_spgemm_s {
+  int64_t m = 0, k = 0, n = 0, a_nnz = 0, b_nnz = 0, c_nnz = -1;
+  const int32_t *a_rowptr = nullptr, *a_colind = nullptr, *b_rowptr = nullptr, *b_colind = nullptr;
+  int32_t* rowptr = nullptr;  // [m+1] device copy of C's row offsets
+  int32_t* perm = nullptr;    // [m] rows grouped by bin
+  int64_t bin_off[SPG_NBINS + 1] = {0, 0, 0, 0, 0, 0};
+  int sub = 16;  // lanes cooperating on one B row
+  // bin-4 workspace
+  int dense_blocks = 0;
+  uint32_t* dense_bits = nullptr;  // [dense_blocks * ceil(n/32)]
+  void* dense_vals = nullptr;      // [dense_blocks * n] T
+  int dense_vals_type = -1;
+};
+
+namespace spb {
+
+__device__ __forceinline__ int spg_bin_of(int64_t ub) {
+  if (ub == 0)
+    return 0;
+  if (ub <= 64)
+    return 1;
+  if (ub <= 512)
+    return 2;
+  if (ub <= 4096)
+    return 3;
+  return 4;
+}
+
+// ub per row (8 lanes per row) + per-bin row counts.
+__global__ __launch_bounds__(256) void spg_bound_kernel(int64_t m, const int32_t* __restrict__ a_rowptr,
+                                                        const int32_t* __restrict__ a_colind,
+                                                        const int32_t* __restrict__ b_rowptr,
+                                                        int32_t* __restrict__ bin_of_row,
+                                                        unsigned long long* __restrict__ bin_count) {
+  __shared__ unsigned int hist[SPG_NBINS];
+  if (threadIdx.x < SPG_NBINS)
+    hist[threadIdx.x] = 0;
+  __syncthreads();
+  const int64_t row = (int64_t) blockIdx.x * 32 + threadIdx.x / 8;
+  const int lane = threadIdx.x % 8;
+  int64_t ub = 0;
+  if (row < m) {
+    for (int p = a_rowptr[row] + lane; p < a_rowptr[row + 1]; p += 8) {
+      const int kk = a_colind[p];
+      ub += b_rowptr[kk + 1] - b_rowptr[kk];
+    }
+  }
+  ub = group_sum_c<8>(ub);
+  if (row < m && lane == 0) {
+    const int b = spg_bin_of(ub);
+    bin_of_row[row] = b;
+    atomicAdd(&hist[b], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x < SPG_NBINS && hist[threadIdx.x])
+    atomicAdd(&bin_count[threadIdx.x], (unsigned long long) hist[threadIdx.x]);
+}
+
+__global__ __launch_bounds__(256) void spg_fill_perm_kernel(int64_t m, const int32_t* __restrict__ bin_of_row,
+                                                            unsigned long long* __restrict__ cursor,
+                                                            int32_t* __restrict__ perm) {
+  const int64_t row = (int64_t) blockIdx.x * 256 + threadIdx.x;
+  if (row < m) {
+    const unsigned long long slot = atomicAdd(&cursor[bin_of_row[row]], 1ull);
+    perm[slot] = (int32_t) row;
+  }
+}
+
+__device__ __forceinline__ unsigned spg_hash(int key, int log2hs) {
+  return ((unsigned) key * 0x9E3779B1u) >> (32 - log2hs);
+}
+
+// Hash kernel.  TPR threads cooperate on one row; a workgroup of 256 threads
+// handles 256/TPR rows taken from perm[first .. first+count).  SUB lanes walk one
+// B row together.  NUMERIC = false: count distinct columns into row_nnz[row].
+// NUMERIC = true: accumulate, sort, write colind/values at c_rowptr[row].
+template <typename T, int LOG2HS, int TPR, bool NUMERIC>
+__global__ __launch_bounds__(256) void spg_hash_kernel(
+    int64_t count, const int32_t* __restrict__ perm, const int32_t* __restrict__ a_rowptr,
+    const int32_t* __restrict__ a_colind, const T* __restrict__ a_values, const int32_t* __restrict__ b_rowptr,
+    const int32_t* __restrict__ b_colind, const T* __restrict__ b_values, int32_t* __restrict__ c_rowptr,
+    int32_t* __restrict__ c_colind, T* __restrict__ c_values, T alpha, int sub) {
+  constexpr int HS = 1 << LOG2HS;
+  constexpr int RPB = 256 / TPR;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  int* keys = reinterpret_cast<int*>(smem);                            // [RPB][HS]
+  int* cnt = keys + RPB * HS;                                          // [RPB] (+ pad to 4)
+  T* vals = reinterpret_cast<T*>(cnt + ((RPB + 3) & ~3) + (sizeof(T) == 8 ? 0 : 0));  // [RPB][HS]
+  int* list = NUMERIC ? reinterpret_cast<int*>(vals + RPB * HS) : nullptr;  // [RPB][HS/2] compacted slots
+
+  const int team = threadIdx.x / TPR;
+  const int lt = threadIdx.x % TPR;
+  const int64_t idx = (int64_t) blockIdx.x * RPB + team;
+  const bool live = idx < count;
+  const int row = live ? perm[idx] : 0;
+  int* tkeys = keys + team * HS;
+  T* tvals = NUMERIC ? vals + team * HS : nullptr;
+
+  for (int i = lt; i < HS; i += TPR) {
+    tkeys[i] = -1;
+    if (NUMERIC)
+      tvals[i] = T(0);
+  }
+  if (lt == 0)
+    cnt[team] = 0;
+  __syncthreads();
+
+  if (live) {
+    const int p0 = a_rowptr[row], p1 = a_rowptr[row + 1];
+    const int sg = lt / sub, sl = lt % sub, nsg = TPR / sub;
+    for (int p = p0 + sg; p < p1; p += nsg) {
+      const int kk = a_colind[p];
+      T av = T(0);
+      if (NUMERIC)
+        av = alpha * a_values[p];
+      const int q1 = b_rowptr[kk + 1];
+      for (int q = b_rowptr[kk] + sl; q < q1; q += sub) {
+        const int col = b_colind[q];
+        unsigned slot = spg_hash(col, LOG2HS);
+        while (true) {
+          const int old = atomicCAS(&tkeys[slot], -1, col);
+          if (old == -1) {
+            if (!NUMERIC)
+              atomicAdd(&cnt[team], 1);
+            break;
+          }
+          if (old == col)
+            break;
+          slot = (slot + 1) & (HS - 1);
+        }
+        if (NUMERIC)
+          unsafeAtomicAdd(&tvals[slot], av * b_values[q]);
+      }
+    }
+  }
+  __syncthreads();
+
+  if (!NUMERIC) {
+    if (live && lt == 0)
+      c_rowptr[row] = cnt[team];
+    return;
+  } else {
+    // compact occupied slots (order irrelevant: keys are unique, ranks decide)
+    int* tlist = list + team * (HS / 2);
+    if (live) {
+      for (int i = lt; i < HS; i += TPR)
+        if (tkeys[i] != -1)
+          tlist[atomicAdd(&cnt[team], 1)] = i;
+    }
+    __syncthreads();
+    if (live) {
+      const int d = cnt[team];
+      const int out0 = c_rowptr[row];
+      for (int e = lt; e < d; e += TPR) {
+        const int slot = tlist[e];
+        const int key = tkeys[slot];
+        int rank = 0;
+        for (int j = 0; j < d; ++j)
+          rank += tkeys[tlist[j]] < key;
+        c_colind[out0 + rank] = key;
+        c_values[out0 + rank] = tvals[slot];
+      }
+    }
+  }
+}
+
+// bin 4: dense accumulator per workgroup.  bits: ceil(n/32) words (all zero on
+// entry and on exit), vals: n values (all zero on entry and exit).  All accesses to
+// the workspace are agent-scope atomics so nothing stale is read out of the CU's L1.
+template <typename T, bool NUMERIC>
+__global__ __launch_bounds__(256) void spg_dense_kernel(
+    int64_t count, const int32_t* __restrict__ perm, int64_t n, const int32_t* __restrict__ a_rowptr,
+    const int32_t* __restrict__ a_colind, const T* __restrict__ a_values, const int32_t* __restrict__ b_rowptr,
+    const int32_t* __restrict__ b_colind, const T* __restrict__ b_values, int32_t* __restrict__ c_rowptr,
+    int32_t* __restrict__ c_colind, T* __restrict__ c_values, T alpha, uint32_t* __restrict__ bits_all,
+    T* __restrict__ vals_all) {
+  __shared__ int scan[256];
+  __shared__ int running;
+  const int64_t nwords = (n + 31) / 32;
+  uint32_t* bits = bits_all + (int64_t) blockIdx.x * nwords;
+  T* vals = NUMERIC ? vals_all + (int64_t) blockIdx.x * n : nullptr;
+  const int tid = threadIdx.x;
+  const int wave = tid / 64, lane = tid % 64;
+
+  for (int64_t idx = blockIdx.x; idx < count; idx += gridDim.x) {
+    const int row = perm[idx];
+    const int p0 = a_rowptr[row], p1 = a_rowptr[row + 1];
+    // one wavefront per A entry, lanes across the B row
+    for (int p = p0 + wave; p < p1; p += 4) {
+      const int kk = a_colind[p];
+      T av = T(0);
+      if (NUMERIC)
+        av = alpha * a_values[p];
+      const int q1 = b_rowptr[kk + 1];
+      for (int q = b_rowptr[kk] + lane; q < q1; q += 64) {
+        const int col = b_colind[q];
+        atomicOr(&bits[col >> 5], 1u << (col & 31));
+        if (NUMERIC)
+          unsafeAtomicAdd(&vals[col], av * b_values[q]);
+      }
+    }
+    if (tid == 0)
+      running = 0;
+    __syncthreads();  // all atomics of this workgroup are complete (performed at L2)
+    const int out0 = NUMERIC ? c_rowptr[row] : 0;
+    for (int64_t w0 = 0; w0 < nwords; w0 += 256) {
+      const int64_t w = w0 + tid;
+      uint32_t word = 0;
+      if (w < nwords) {
+        word = __hip_atomic_load(&bits[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (word)
+          __hip_atomic_store(&bits[w], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      const int pc = __popc(word);
+      // workgroup exclusive scan of pc
+      scan[tid] = pc;
+      __syncthreads();
+      for (int o = 1; o < 256; o <<= 1) {
+        const int t = tid >= o ? scan[tid - o] : 0;
+        __syncthreads();
+        scan[tid] += t;
+        __syncthreads();
+      }
+      const int excl = scan[tid] - pc;
+      const int base = running;
+      if (NUMERIC) {
+        int o = out0 + base + excl;
+        while (word) {
+          const int b = __ffs((int) word) - 1;
+          word &= word - 1;
+          const int64_t col = w * 32 + b;
+          c_colind[o] = (int32_t) col;
+          c_values[o] = __hip_atomic_load(&vals[col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(&vals[col], T(0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ++o;
+        }
+      }
+      __syncthreads();
+      if (tid == 255)
+        running = base + scan[255];
+      __syncthreads();
+    }
+    if (!NUMERIC && tid == 0)
+      c_rowptr[row] = running;
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void spg_zero_rows_kernel(int64_t count, const int32_t* __restrict__ perm,
+                                                            int32_t* __restrict__ c_rowptr) {
+  const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
+  if (i < count)
+    c_rowptr[perm[i]] = 0;
+}
+
+// ---- exclusive scan of int32 counts (in place), total in int64 ----------------
+// data[0..n) counts -> offsets; block partial sums in `partials` (int64).
+__global__ __launch_bounds__(256) void scan_block_sums_kernel(int64_t n, const int32_t* __restrict__ data,
+                                                              long long* __restrict__ partials) {
+  __shared__ long long red[4];
+  const int64_t base = (int64_t) blockIdx.x * 2048;
+  long long s = 0;
+  for (int i = threadIdx.x; i < 2048; i += 256)
+    if (base + i < n)
+      s += data[base + i];
+  s = group_sum_c<64>(s);
+  if ((threadIdx.x & 63) == 0)
+    red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    partials[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// single workgroup: exclusive scan of partials[0..nb) in place, partials[nb] = total
+__global__ __launch_bounds__(256) void scan_partials_kernel(int64_t nb, long long* __restrict__ partials) {
+  __shared__ long long sm[256];
+  __shared__ long long carry;
+  if (threadIdx.x == 0)
+    carry = 0;
+  __syncthreads();
+  for (int64_t b0 = 0; b0 < nb; b0 += 256) {
+    const int64_t i = b0 + threadIdx.x;
+    const long long v = i < nb ? partials[i] : 0;
+    sm[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+      const long long t = threadIdx.x >= o ? sm[threadIdx.x - o] : 0;
+      __syncthreads();
+      sm[threadIdx.x] += t;
+      __syncthreads();
+    }
+    const long long c = carry;
+    if (i < nb)
+      partials[i] = c + sm[threadIdx.x] - v;
+    __syncthreads();
+    if (threadIdx.x == 255)
+      carry = c + sm[255];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0)
+    partials[nb] = carry;
+}
+
+// data[0..n) counts -> exclusive offsets, data[n] = total (n+1 entries written)
+__global__ __launch_bounds__(256) void scan_apply_kernel(int64_t n, int32_t* __restrict__ data,
+                                                         const long long* __restrict__ partials) {
+  __shared__ int sm[256];
+  const int64_t base = (int64_t) blockIdx.x * 2048;
+  // each thread owns 8 consecutive entries
+  int v[8];
+  int s = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int64_t i = base + threadIdx.x * 8 + j;
+    v[j] = i < n ? data[i] : 0;
+    s += v[j];
+  }
+  sm[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 1; o < 256; o <<= 1) {
+    const int t = threadIdx.x >= o ? sm[threadIdx.x - o] : 0;
+    __syncthreads();
+    sm[threadIdx.x] += t;
+    __syncthreads();
+  }
+  long long off = partials[blockIdx.x] + sm[threadIdx.x] - s;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int64_t i = base + threadIdx.x * 8 + j;
+    if (i < n)
+      data[i] = (int32_t) off;
+    off += v[j];
+  }
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0)
+    data[n] = (int32_t) partials[gridDim.x];
+}
+
+template <typename T, int LOG2HS, int TPR, bool NUMERIC>
+static size_t hash_smem_bytes() {
+  constexpr int HS = 1 << LOG2HS;
+  constexpr int RPB = 256 / TPR;
+  size_t b = (size_t) RPB * HS * 4 + (size_t) ((RPB + 3) & ~3) * 4;
+  if (NUMERIC)
+    b += (size_t) RPB * HS * sizeof(T) + (size_t) RPB * (HS / 2) * 4;
+  else
+    b += 16;
+  return b;
+}
+
+template <typename T, int LOG2HS, int TPR, bool NUMERIC>
+static int launch_hash(hipStream_t s, const spblas_gfx950_spgemm_s* st, int bin, const T* a_values,
+                       const T* b_values, int32_t* c_rowptr, int32_t* c_colind, T* c_values, T alpha) {
+  const int64_t count = st->bin_off[bin + 1] - st->bin_off[bin];
+  if (count == 0)
+    return SPBLAS_GFX950_STATUS_SUCCESS;
+  constexpr int RPB = 256 / TPR;
+  const size_t smem = hash_smem_bytes<T, LOG2HS, TPR, NUMERIC>();
+  auto kern = spg_hash_kernel<T, LOG2HS, TPR, NUMERIC>;
+  if (smem > 48 * 1024)
+    SPB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int) smem));
+  int sub = st->sub < TPR ? st->sub : TPR;
+  hipLaunchKernelGGL(kern, dim3((unsigned) cdiv(count, RPB)), dim3(256), smem, s, count,
+                     st->perm + st->bin_off[bin], st->a_rowptr, st->a_colind, a_values, st->b_rowptr,
+                     st->b_colind, b_values, c_rowptr, c_colind, c_values, alpha, sub);
+  SPB_HIP(hipGetLastError());
+  return SPBLAS_GFX950_STATUS_SUCCESS;
+}
+
+template <typename T, bool NUMERIC>
+static int run_bins(spblas_gfx950_handle_t h, spblas_gfx950_spgemm_s* st, const T* a_values, const T* b_values,
+                    int32_t* c_rowptr, int32_t* c_colind, T* c_values, T alpha) {
+  hipStream_t s = h->stream;
+  int rc;
+  if ((rc = launch_hash<T, 7, 16, NUMERIC>(s, st, 1, a_values, b_values, c_rowptr, c_colind, c_values, alpha)))
+    return rc;
+  if ((rc = launch_hash<T, 10, 64, NUMERIC>(s, st, 2, a_values, b_values, c_rowptr, c_colind, c_values, alpha)))
+    return rc;
+  if ((rc = launch_hash<T, 13, 256, NUMERIC>(s, st, 3, a_values, b_values, c_rowptr, c_colind, c_values, alpha)))
+    return rc;
+  const int64_t cnt4 = st->bin_off[5] - st->bin_off[4];
+  if (cnt4 > 0) {
+    const int64_t nwords = (st->n + 31) / 32;
+    if (!st->dense_bits) {
+      st->dense_blocks = (int) (cnt4 < 64 ? cnt4 : 64);
+      if ((rc = dev_alloc((void**) &st->dense_bits, (size_t) st->dense_blocks * nwords * 4, s)))
+        return rc;
+      SPB_HIP(hipMemsetAsync(st->dense_bits, 0, (size_t) st->dense_blocks * nwords * 4, s));
+    }
+    if (NUMERIC && (!st->dense_vals || st->dense_vals_type != (int) sizeof(T))) {
+      dev_free(st->dense_vals, s);
+      st->dense_vals = nullptr;
+      if ((rc = dev_alloc(&st->dense_vals, (size_t) st->dense_blocks * st->n * sizeof(T), s)))
+        return rc;
+      SPB_HIP(hipMemsetAsync(st->dense_vals, 0, (size_t) st->dense_blocks * st->n * sizeof(T), s));
+      st->dense_vals_type = (int) sizeof(T);
+    }
+    hipLaunchKernelGGL((spg_dense_kernel<T, NUMERIC>), dim3((unsigned) st->dense_blocks), dim3(256), 0, s, cnt4,
+                       st->perm + st->bin_off[4], st->n, st->a_rowptr, st->a_colind, a_values, st->b_rowptr,
+                       st->b_colind, b_values, c_rowptr, c_colind, c_values, alpha, st->dense_bits,
+                       static_cast<T*>(st->dense_vals));
+    SPB_HIP(hipGetLastError());
+  }
+  return SPBLAS_GFX950_STATUS_SUCCESS;
+}
+
+static void spgemm_release(spblas_gfx950_spgemm_s* st, hipStream_t s) {
+  dev_free(st->rowptr, s);
+  dev_free(st->perm, s);
+  dev_free(st->dense_bits, s);
+  dev_free(st->dense_vals, s);
+  st->rowptr = nullptr;
+  st->perm = nullptr;
+  st->dense_bits = nullptr;
+  st->dense_vals = nullptr;
+  st->dense_vals_type = -1;
+  st->c_nnz = -1;
+}
+
+} // namespace spb
+
+using namespace spb;
+
+extern "C" {
+
+int spblas_gfx950_spgemm_create(spblas_gfx950_handle_t handle, spblas_gfx950_spgemm_t* state) {
+  if (!handle)
+    return SPBLAS_GFX950_STATUS_INVALID_HANDLE;
+  if (!state)
+    return SPBLAS_GFX950_STATUS_INVALID_POINTER;
+  *state = new (std::nothrow) spblas_gfx950_spgemm_s();
+  return *state ? SPBLAS_GFX950_STATUS_SUCCESS : SPBLAS_GFX950_STATUS_ALLOC_FAILED;
+}
+
+int spblas_gfx950_spgemm_destroy(spblas_gfx950_handle_t handle, spblas_gfx950_spgemm_t state) {
+  if (!handle)
+    return SPBLAS_GFX950_STATUS_INVALID_HANDLE;
+  if (!state)
+    return SPBLAS_GFX950_STATUS_SUCCESS;
+  spgemm_release(state, handle->stream);
+  delete state;
+  return SPBLAS_GFX950_STATUS_SUCCESS;
+}
+
+int spblas_gfx950_spgemm_symbolic(spblas_gfx950_handle_t handle, spblas_gfx950_spgemm_t st, int64_t m, int64_t k,
+                                  int64_t n, int64_t a_nnz, const int32_t* a_rowptr, const int32_t* a_colind,
+                                  int64_t b_nnz, const int32_t* b_rowptr, const int32_t* b_colind,
+                                  int32_t* c_rowptr, int64_t* c_nnz) {
+  if (!handle)
+    return SPBLAS_GFX950_STATUS_INVALID_HANDLE;
+  if (!st || !c_nnz || !a_rowptr || !b_rowptr || !c_rowptr || (a_nnz > 0 && !a_colind) ||
+      (b_nnz > 0 && !b_colind))
+    return SPBLAS_GFX950_STATUS_INVALID_POINTER;
+  if (m < 0 || k < 0 || n < 0 || a_nnz < 0 || b_nnz < 0 || m >= INT32_MAX || k > INT32_MAX || n > INT32_MAX ||
+      a_nnz > INT32_MAX || b_nnz > INT32_MAX)
+    return SPBLAS_GFX950_STATUS_INVALID_SIZE;
+  hipStream_t s = handle->stream;
+  spgemm_release(st, s);
+  st->m = m; st->k = k; st->n = n; st->a_nnz = a_nnz; st->b_nnz = b_nnz;
+  st->a_rowptr = a_rowptr; st->a_colind = a_colind; st->b_rowptr = b_rowptr; st->b_colind = b_colind;
+  // lanes per B row: power of two near the average B row length
+  const double avg_b = k > 0 ? (double) b_nnz / (double) k : 0.0;
+  st->sub = 4;
+  while (st->sub < 64 && st->sub < avg_b)
+    st->sub <<= 1;
+  if (st->sub > 16)
+    st->sub = 16;  // bin 1 teams are 16 lanes wide
+
+  int rc;
+  if ((rc = dev_alloc((void**) &st->rowptr, (size_t) (m + 1) * 4, s)))
+    return rc;
+  if (m == 0) {
+    SPB_HIP(hipMemsetAsync(st->rowptr, 0, 4, s));
+    SPB_HIP(hipMemsetAsync(c_rowptr, 0, 4, s));
+    SPB_HIP(hipStreamSynchronize(s));
+    st->c_nnz = 0;
+    *c_nnz = 0;
+    return SPBLAS_GFX950_STATUS_SUCCESS;
+  }
+  if ((rc = dev_alloc((void**) &st->perm, (size_t) m * 4, s)))
+    return rc;
+  int32_t* bin_of_row = nullptr;
+  unsigned long long* d_cnt = nullptr;
+  long long* partials = nullptr;
+  const int64_t nb = cdiv(m, 2048);
+  if ((rc = dev_alloc((void**) &bin_of_row, (size_t) m * 4, s)))
+    return rc;
+  if ((rc = dev_alloc((void**) &d_cnt, 2 * SPG_NBINS * sizeof(unsigned long long), s)))
+    return rc;
+  if ((rc = dev_alloc((void**) &partials, (size_t) (nb + 1) * sizeof(long long), s)))
+    return rc;
+  SPB_HIP(hipMemsetAsync(d_cnt, 0, 2 * SPG_NBINS * sizeof(unsigned long long), s));
+  hipLaunchKernelGGL(spg_bound_kernel, dim3((unsigned) cdiv(m, 32)), dim3(256), 0, s, m, a_rowptr, a_colind,
+                     b_rowptr, bin_of_row, d_cnt);
+  SPB_HIP(hipGetLastError());
+  unsigned long long counts[SPG_NBINS];
+  SPB_HIP(hipMemcpyAsync(counts, d_cnt, sizeof(counts), hipMemcpyDeviceToHost, s));
+  SPB_HIP(hipStreamSynchronize(s));
+  unsigned long long cursors[SPG_NBINS];
+  st->bin_off[0] = 0;
+  for (int b = 0; b < SPG_NBINS; ++b) {
+    cursors[b] = (unsigned long long) st->bin_off[b];
+    st->bin_off[b + 1] = st->bin_off[b] + (int64_t) counts[b];
+  }
+  SPB_HIP(hipMemcpyAsync(d_cnt + SPG_NBINS, cursors, sizeof(cursors), hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(spg_fill_perm_kernel, dim3((unsigned) cdiv(m, 256)), dim3(256), 0, s, m, bin_of_row,
+                     d_cnt + SPG_NBINS, st->perm);
+  SPB_HIP(hipGetLastError());
+
+  // distinct-column counts per row -> st->rowptr (as counts)
+  if (st->bin_off[1] > 0)
+    hipLaunchKernelGGL(spg_zero_rows_kernel, dim3((unsigned) cdiv(st->bin_off[1], 256)), dim3(256), 0, s,
+                       st->bin_off[1], st->perm, st->rowptr);
+  rc = run_bins<float, false>(handle, st, nullptr, nullptr, st->rowptr, nullptr, nullptr, 0.f);
+  if (rc == SPBLAS_GFX950_STATUS_SUCCESS) {
+    hipLaunchKernelGGL(scan_block_sums_kernel, dim3((unsigned) nb), dim3(256), 0, s, m, st->rowptr, partials);
+    hipLaunchKernelGGL(scan_partials_kernel, dim3(1), dim3(256), 0, s, nb, partials);
+    long long total = 0;
+    hipError_t e = hipMemcpyAsync(&total, partials + nb, sizeof(total), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess)
+      e = hipStreamSynchronize(s);
+    if (e != hipSuccess)
+      rc = hip_fail(e);
+    else if (total > INT32_MAX)
+      rc = SPBLAS_GFX950_STATUS_INVALID_SIZE;  // nnz(C) does not fit int32 offsets
+    else {
+      hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned) nb), dim3(256), 0, s, m, st->rowptr, partials);
+      e = hipMemcpyAsync(c_rowptr, st->rowptr, (size_t) (m + 1) * 4, hipMemcpyDeviceToDevice, s);
+      if (e == hipSuccess)
+        e = hipStreamSynchronize(s);
+      if (e != hipSuccess)
+        rc = hip_fail(e);
+      else {
+        st->c_nnz = total;
+        *c_nnz = total;
+      }
+    }
+  }
+  dev_free(bin_of_row, s);
+  dev_free(d_cnt, s);
+  dev_free(partials, s);
+  return rc;
+}
+
+int spblas_gfx950_spgemm_numeric(spblas_gfx950_handle_t handle, spblas_gfx950_spgemm_t st, const void* alpha,
+                                 const int32_t* a_rowptr, const int32_t* a_colind, const void* a_values,
+                                 const int32_t* b_rowptr, const int32_t* b_colind, const void* b_values,
+                                 int32_t* c_rowptr, int32_t* c_colind, void* c_values, int64_t c_capacity,
+                                 int value_type) {
+  if (!handle)
+    return SPBLAS_GFX950_STATUS_INVALID_HANDLE;
+  if (!st || !alpha || !a_rowptr || !b_rowptr || !c_rowptr)
+    return SPBLAS_GFX950_STATUS_INVALID_POINTER;
+  if (st->c_nnz < 0)
+    return SPBLAS_GFX950_STATUS_INVALID_VALUE;  // symbolic has not run
+  if (value_type != SPBLAS_GFX950_F32 && value_type != SPBLAS_GFX950_F64)
+    return SPBLAS_GFX950_STATUS_INVALID_VALUE;
+  if (c_capacity < st->c_nnz)
+    return SPBLAS_GFX950_STATUS_INSUFFICIENT_SPACE;
+  if (st->c_nnz > 0 && (!c_colind || !c_values || !a_values || !b_values || !a_colind || !b_colind))
+    return SPBLAS_GFX950_STATUS_INVALID_POINTER;
+  hipStream_t s = handle->stream;
+  // pointers may be rebound between calls as long as the pattern is unchanged
+  // (multiply_spgemm.hpp:195-208 rebinds them with rocsparse_csr_set_pointers)
+  st->a_rowptr = a_rowptr; st->a_colind = a_colind; st->b_rowptr = b_rowptr; st->b_colind = b_colind;
+  if (c_rowptr != st->rowptr)
+    SPB_HIP(hipMemcpyAsync(c_rowptr, st->rowptr, (size_t) (st->m + 1) * 4, hipMemcpyDeviceToDevice, s));
+  if (st->c_nnz == 0)
+    return SPBLAS_GFX950_STATUS_SUCCESS;
+  if (value_type == SPBLAS_GFX950_F32)
+    return run_bins<float, true>(handle, st, static_cast<const float*>(a_values),
+                                 static_cast<const float*>(b_values), st->rowptr, c_colind,
+                                 static_cast<float*>(c_values), *static_cast<const float*>(alpha));
+  return run_bins<double, true>(handle, st, static_cast<const double*>(a_values),
+                                static_cast<const double*>(b_values), st->rowptr, c_colind,
+                                static_cast<double*>(c_values), *static_cast<const double*>(alpha));
+}
+
+} // extern "C"

@@ -1,0 +1,597 @@
+// CSR SpMV for gfx950:  y = alpha * op(A) * x + beta * y.
+//
+// Replaces rocsparse_spmv(..., rocsparse_spmv_alg_csr_stream, ...) at
+// /root/reference/include/spblas/vendor/rocsparse/detail/spmv_impl.hpp:60-77; the
+// maths is the reference CPU path include/spblas/algorithms/multiply_impl.hpp:33-53
+// with alpha folded to one scalar as the rocSPARSE slot does (spmv_impl.hpp:35-37).
+//
+// Kernels (all HBM-bound; algorithmic bytes per nonzero = sizeof(T)+4, per row =
+// sizeof(O)+sizeof(T), per column = sizeof(T)):
+//   spmv_vector_kernel    plan-free; a power-of-two group of lanes per row.
+//   spmv_rowblock_kernel  plan (multiply_inspect); one 256-thread workgroup per
+//                         nnz window: coalesced 16-byte streaming loads of
+//                         colind/values, x gathers, products staged in LDS, then a
+//                         sub-wavefront group per row reduces out of LDS.
+//   spmv_long_fixup_kernel sums the per-window partials of rows longer than a window.
+//   spmv_transpose_kernel  op = T (CSC / transposed(csr)): scatter with HW float atomics.
+#include "common.hpp"
+#include "plan.hpp"
+
+namespace spb {
+
+// ---------------------------------------------------------------------------
+// plan-free kernel: LPR lanes per row
+// ---------------------------------------------------------------------------
+template <typename T, typename O, int LPR>
+__global__ __launch_bounds__(256) void spmv_vector_kernel(int64_t m, const O* __restrict__ rowptr,
+                                                          const int32_t* __restrict__ colind,
+                                                          const T* __restrict__ values,
+                                                          const T* __restrict__ x, T* __restrict__ y,
+                                                          T alpha, T beta) {
+  constexpr int ROWS = 256 / LPR;
+  const int64_t row = (int64_t) blockIdx.x * ROWS + threadIdx.x / LPR;
+  const int lane = threadIdx.x % LPR;
+  T s = 0;
+  if (row < m) {
+    const O p0 = rowptr[row], p1 = rowptr[row + 1];
+    for (O p = p0 + lane; p < p1; p += LPR)
+      s += stream_load(values + p) * x[stream_load(colind + p)];
+  }
+  s = group_sum_c<LPR>(s);
+  if (row < m && lane == 0)
+    y[row] = beta == T(0) ? alpha * s : alpha * s + beta * y[row];
+}
+
+// ---------------------------------------------------------------------------
+// row-block kernel
+// ---------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void load4_stream(const T* p, T (&out)[4]);
+template <>
+__device__ __forceinline__ void load4_stream<float>(const float* p, float (&out)[4]) {
+  f32x4 v = stream_load(reinterpret_cast<const f32x4*>(p));
+  out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
+}
+template <>
+__device__ __forceinline__ void load4_stream<double>(const double* p, double (&out)[4]) {
+  f64x2 a = stream_load(reinterpret_cast<const f64x2*>(p));
+  f64x2 b = stream_load(reinterpret_cast<const f64x2*>(p) + 1);
+  out[0] = a.x; out[1] = a.y; out[2] = b.x; out[3] = b.y;
+}
+
+// Sum of values[p]*x[colind[p]] for p in [lo, hi) over the whole workgroup.
+// Result valid in thread 0.
+template <typename T, typename O>
+__device__ T block_segment_dot(O lo, O hi, const int32_t* __restrict__ colind,
+                               const T* __restrict__ values, const T* __restrict__ x, T* red) {
+  T s = 0;
+  for (O p = lo + (O) threadIdx.x; p < hi; p += 256)
+    s += stream_load(values + p) * x[stream_load(colind + p)];
+  s = group_sum_c<64>(s);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0)
+    red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+// Window w owns the rows whose first entry lies in [w*WIN, (w+1)*WIN).  A row no
+// longer than WIN is computed entirely by its owner (its entries end before
+// (w+2)*WIN, hence the 2*WIN LDS slots).  A row longer than WIN ("long") is
+// split: every window it covers reduces its own slice into part_tail[w] (the
+// window where the row starts) or part_head[w] (later windows).
+template <typename T, typename O, int WIN, bool HAS_LONG, bool VEC>
+__global__ __launch_bounds__(256) void spmv_rowblock_kernel(
+    int64_t nnz, const O* __restrict__ rowptr, const int32_t* __restrict__ colind,
+    const T* __restrict__ values, const T* __restrict__ x, T* __restrict__ y, T alpha, T beta,
+    const int32_t* __restrict__ win_row, T* __restrict__ part_head, T* __restrict__ part_tail) {
+  constexpr int CAP = 2 * WIN;
+  constexpr int ITERS = CAP / 4 / 256;
+  static_assert(CAP % 1024 == 0, "window must be a multiple of 512");
+  __shared__ T prod[CAP];
+  __shared__ T red[4];
+
+  const int tid = threadIdx.x;
+  const int64_t w = blockIdx.x;
+  const int r_begin = win_row[w];
+  int r_end = win_row[w + 1];
+  const O wlo = (O) (w * WIN);
+  const O whi = (O) ((w + 1) * WIN < nnz ? (w + 1) * WIN : nnz);
+
+  const O a = rowptr[r_begin];  // first entry of the first owned row (>= wlo)
+  O e = rowptr[r_end];          // one past the last entry of the last owned row
+
+  if (HAS_LONG) {
+    // long row entering this window from an earlier one
+    if (r_begin > 0 && a > wlo) {
+      const O hs = rowptr[r_begin - 1];
+      if (a - hs > (O) WIN) {
+        T s = block_segment_dot<T, O>(wlo, a < whi ? a : whi, colind, values, x, red);
+        if (tid == 0)
+          part_head[w] = s;
+        __syncthreads();
+      }
+    }
+    // long row starting in this window (necessarily the last owned row)
+    if (r_end > r_begin) {
+      const O ls = rowptr[r_end - 1];
+      if (e - ls > (O) WIN) {
+        T s = block_segment_dot<T, O>(ls, whi, colind, values, x, red);
+        if (tid == 0)
+          part_tail[w] = s;
+        __syncthreads();
+        r_end -= 1;
+        e = ls;
+      }
+    }
+  }
+
+  const O a_al = a & ~(O) 3;  // 16-byte aligned start; a_al >= wlo because WIN % 4 == 0
+  const int total = (int) (e - a_al);
+
+  // ---- phase 1: stream colind/values (16 B per lane), gather x, stage products
+  int32_t c[ITERS][4];
+  T v[ITERS][4];
+#pragma unroll
+  for (int it = 0; it < ITERS; ++it) {
+    const int q = (it * 256 + tid) * 4;
+    const O p = a_al + (O) q;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      c[it][j] = 0;
+      v[it][j] = T(0);
+    }
+    if (q < total) {
+      if (VEC && (int64_t) p + 4 <= nnz) {
+        i32x4 cc = stream_load(reinterpret_cast<const i32x4*>(colind + p));
+        c[it][0] = cc.x; c[it][1] = cc.y; c[it][2] = cc.z; c[it][3] = cc.w;
+        load4_stream<T>(values + p, v[it]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if ((int64_t) p + j < nnz) {
+            c[it][j] = stream_load(colind + p + j);
+            v[it][j] = stream_load(values + p + j);
+          }
+      }
+    }
+  }
+  T xv[ITERS][4];
+#pragma unroll
+  for (int it = 0; it < ITERS; ++it)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      xv[it][j] = x[c[it][j]];
+#pragma unroll
+  for (int it = 0; it < ITERS; ++it) {
+    const int q = (it * 256 + tid) * 4;
+    if (q < total) {
+      const O p = a_al + (O) q;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bool in = (p + j >= a) && (p + j < e);
+        prod[q + j] = in ? v[it][j] * xv[it][j] : T(0);
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 2: a group of `lpr` lanes reduces each owned row out of LDS
+  const int nrows = r_end - r_begin;
+  int lpr = 1;
+  while (lpr < 64 && nrows * lpr * 2 <= 256)
+    lpr <<= 1;
+  const int grp = tid / lpr, lig = tid % lpr, ngrp = 256 / lpr;
+  for (int r = r_begin + grp; r < r_end; r += ngrp) {
+    const int s0 = (int) (rowptr[r] - a_al), s1 = (int) (rowptr[r + 1] - a_al);
+    T s = 0;
+    for (int q = s0 + lig; q < s1; q += lpr)
+      s += prod[q];
+    s = group_sum(s, lpr);
+    if (lig == 0)
+      y[r] = beta == T(0) ? alpha * s : alpha * s + beta * y[r];
+  }
+}
+
+// One wavefront per long row: y[r] = alpha * (tail + heads) + beta * y[r].
+template <typename T, typename O>
+__global__ __launch_bounds__(64) void spmv_long_fixup_kernel(int64_t n_long, int win,
+                                                             const int32_t* __restrict__ long_rows,
+                                                             const O* __restrict__ rowptr,
+                                                             const T* __restrict__ part_head,
+                                                             const T* __restrict__ part_tail,
+                                                             T* __restrict__ y, T alpha, T beta) {
+  const int64_t i = blockIdx.x;
+  if (i >= n_long)
+    return;
+  const int r = long_rows[i];
+  const int64_t p0 = (int64_t) rowptr[r], p1 = (int64_t) rowptr[r + 1];
+  const int64_t w0 = p0 / win, w1 = (p1 - 1) / win;
+  T s = 0;
+  for (int64_t w = w0 + 1 + threadIdx.x; w <= w1; w += 64)
+    s += part_head[w];
+  s = group_sum_c<64>(s);
+  if (threadIdx.x == 0) {
+    s += part_tail[w0];
+    y[r] = beta == T(0) ? alpha * s : alpha * s + beta * y[r];
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void scale_vector_kernel(int64_t n, T* __restrict__ y, T beta) {
+  const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
+  if (i < n)
+    y[i] = beta == T(0) ? T(0) : beta * y[i];
+}
+
+// op = T: y (n entries) += alpha * A^T x.  One 8-lane group per row of A.
+template <typename T, typename O>
+__global__ __launch_bounds__(256) void spmv_transpose_kernel(int64_t m, const O* __restrict__ rowptr,
+                                                             const int32_t* __restrict__ colind,
+                                                             const T* __restrict__ values,
+                                                             const T* __restrict__ x, T* __restrict__ y,
+                                                             T alpha) {
+  const int64_t row = (int64_t) blockIdx.x * 32 + threadIdx.x / 8;
+  const int lane = threadIdx.x % 8;
+  if (row >= m)
+    return;
+  const T xi = alpha * x[row];
+  const O p0 = rowptr[row], p1 = rowptr[row + 1];
+  for (O p = p0 + lane; p < p1; p += 8)
+    unsafeAtomicAdd(y + stream_load(colind + p), stream_load(values + p) * xi);
+}
+
+// ---------------------------------------------------------------------------
+// inspect kernels
+// ---------------------------------------------------------------------------
+// win_row[w] = first row r with rowptr[r] >= w*win  (w = 0..nwin-1); win_row[nwin] = m.
+template <typename O>
+__global__ __launch_bounds__(256) void plan_window_rows_kernel(int64_t m, int64_t nwin, int win,
+                                                               const O* __restrict__ rowptr,
+                                                               int32_t* __restrict__ win_row) {
+  const int64_t w = (int64_t) blockIdx.x * 256 + threadIdx.x;
+  if (w > nwin)
+    return;
+  if (w == nwin) {
+    win_row[w] = (int32_t) m;
+    return;
+  }
+  const int64_t target = w * win;
+  int64_t lo = 0, hi = m;  // answer in [0, m]
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if ((int64_t) rowptr[mid] < target)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  win_row[w] = (int32_t) lo;
+}
+
+// stats[0] = max row length, stats[1] = #long rows, stats[2] = #empty rows.
+// Long rows are appended to long_rows (capacity nnz/win + 1 always suffices).
+template <typename O>
+__global__ __launch_bounds__(256) void plan_row_stats_kernel(int64_t m, int win,
+                                                             const O* __restrict__ rowptr,
+                                                             unsigned long long* __restrict__ stats,
+                                                             int32_t* __restrict__ long_rows) {
+  const int64_t r = (int64_t) blockIdx.x * 256 + threadIdx.x;
+  unsigned long long len = 0;
+  bool empty = false;
+  if (r < m) {
+    len = (unsigned long long) (rowptr[r + 1] - rowptr[r]);
+    empty = len == 0;
+    if (len > (unsigned long long) win) {
+      unsigned long long slot = atomicAdd(&stats[1], 1ull);
+      long_rows[slot] = (int32_t) r;
+    }
+  }
+  // wave-level max / count before touching the global counters
+  unsigned long long mx = len;
+  for (int o = 32; o > 0; o >>= 1) {
+    unsigned long long other = __shfl_xor(mx, o, SPB_WAVE);
+    mx = other > mx ? other : mx;
+  }
+  const unsigned long long nempty = __popcll(__ballot(empty));
+  if ((threadIdx.x & 63) == 0) {
+    if (mx > 0)
+      atomicMax(&stats[0], mx);
+    if (nempty)
+      atomicAdd(&stats[2], nempty);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+template <typename T, typename O, int LPR>
+static void launch_vector(hipStream_t s, int64_t m, const O* rowptr, const int32_t* colind,
+                          const T* values, const T* x, T* y, T alpha, T beta) {
+  constexpr int ROWS = 256 / LPR;
+  const int64_t grid = cdiv(m, ROWS);
+  hipLaunchKernelGGL((spmv_vector_kernel<T, O, LPR>), dim3((unsigned) grid), dim3(256), 0, s, m, rowptr,
+                     colind, values, x, y, alpha, beta);
+}
+
+static int pick_lpr(int64_t m, int64_t nnz) {
+  const double avg = m > 0 ? (double) nnz / (double) m : 0.0;
+  int lpr = 2;
+  while (lpr < 64 && (double) lpr * 1.5 < avg)
+    lpr <<= 1;
+  return lpr;
+}
+
+template <typename T, typename O>
+static int run_vector(hipStream_t s, int lpr, int64_t m, const O* rowptr, const int32_t* colind,
+                      const T* values, const T* x, T* y, T alpha, T beta) {
+  switch (lpr) {
+  case 2: launch_vector<T, O, 2>(s, m, rowptr, colind, values, x, y, alpha, beta); break;
+  case 4: launch_vector<T, O, 4>(s, m, rowptr, colind, values, x, y, alpha, beta); break;
+  case 8: launch_vector<T, O, 8>(s, m, rowptr, colind, values, x, y, alpha, beta); break;
+  case 16: launch_vector<T, O, 16>(s, m, rowptr, colind, values, x, y, alpha, beta); break;
+  case 32: launch_vector<T, O, 32>(s, m, rowptr, colind, values, x, y, alpha, beta); break;
+  default: launch_vector<T, O, 64>(s, m, rowptr, colind, values, x, y, alpha, beta); break;
+  }
+  SPB_HIP(hipGetLastError());
+  return SPBLAS_GFX950_STATUS_SUCCESS;
+}
+
+template <typename T>
+struct window_of {
+  // f32: 2*2048*4 B = 16 KiB LDS; f64: 2*1024*8 B = 16 KiB LDS -> 8+ workgroups/CU.
+  static constexpr int value = sizeof(T) == 4 ? 2048 : 1024;
+};
+
+template <typename T, typename O, bool HAS_LONG>
+static void launch_rowblock(hipStream_t s, const spblas_gfx950_plan_s* pl, const O* rowptr,
+                            const int32_t* colind, const T* values, const T* x, T* y, T alpha, T beta) {
+  constexpr int WIN = window_of<T>::value;
+  const bool vec = (((uintptr_t) colind | (uintptr_t) values) & 15) == 0;
+  T* ph = static_cast<T*>(pl->part_head);
+  T* pt = static_cast<T*>(pl->part_tail);
+  if (vec)
+    hipLaunchKernelGGL((spmv_rowblock_kernel<T, O, WIN, HAS_LONG, true>), dim3((unsigned) pl->nwin),
+                       dim3(256), 0, s, pl->nnz, rowptr, colind, values, x, y, alpha, beta, pl->win_row,
+                       ph, pt);
+  else
+    hipLaunchKernelGGL((spmv_rowblock_kernel<T, O, WIN, HAS_LONG, false>), dim3((unsigned) pl->nwin),
+                       dim3(256), 0, s, pl->nnz, rowptr, colind, values, x, y, alpha, beta, pl->win_row,
+                       ph, pt);
+}
+
+int spmv_sliced_exec(spblas_gfx950_handle_t h, const spblas_gfx950_plan_s* pl, const void* alpha,
+                     const void* x, const void* beta, void* y);
+int spmv_sliced_build(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const void* values);
+int spmv_sliced_update(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const void* values);
+void spmv_sliced_free(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl);
+
+template <typename T, typename O>
+static int spmv_typed(spblas_gfx950_handle_t h, const spblas_gfx950_plan_s* pl, int op, int64_t m, int64_t n,
+                      int64_t nnz, const void* alpha_p, const void* rowptr_p, const int32_t* colind,
+                      const void* values_p, const void* x_p, const void* beta_p, void* y_p) {
+  const T alpha = *static_cast<const T*>(alpha_p);
+  const T beta = *static_cast<const T*>(beta_p);
+  const O* rowptr = static_cast<const O*>(rowptr_p);
+  const T* values = static_cast<const T*>(values_p);
+  const T* x = static_cast<const T*>(x_p);
+  T* y = static_cast<T*>(y_p);
+  hipStream_t s = h->stream;
+
+  if (op == SPBLAS_GFX950_OP_T) {
+    // y has n entries: scale, then scatter-add.
+    if (n > 0)
+      hipLaunchKernelGGL((scale_vector_kernel<T>), dim3((unsigned) cdiv(n, 256)), dim3(256), 0, s, n, y,
+                         beta);
+    if (m > 0 && nnz > 0)
+      hipLaunchKernelGGL((spmv_transpose_kernel<T, O>), dim3((unsigned) cdiv(m, 32)), dim3(256), 0, s, m,
+                         rowptr, colind, values, x, y, alpha);
+    SPB_HIP(hipGetLastError());
+    return SPBLAS_GFX950_STATUS_SUCCESS;
+  }
+
+  if (m == 0)
+    return SPBLAS_GFX950_STATUS_SUCCESS;
+  if (nnz == 0) {
+    hipLaunchKernelGGL((scale_vector_kernel<T>), dim3((unsigned) cdiv(m, 256)), dim3(256), 0, s, m, y, beta);
+    SPB_HIP(hipGetLastError());
+    return SPBLAS_GFX950_STATUS_SUCCESS;
+  }
+
+  if (pl && pl->alg == SPBLAS_GFX950_SPMV_SLICED)
+    return spmv_sliced_exec(h, pl, alpha_p, x_p, beta_p, y_p);
+
+  if (pl && pl->alg == SPBLAS_GFX950_SPMV_ROWBLOCK) {
+    if (pl->n_long > 0) {
+      launch_rowblock<T, O, true>(s, pl, rowptr, colind, values, x, y, alpha, beta);
+      hipLaunchKernelGGL((spmv_long_fixup_kernel<T, O>), dim3((unsigned) pl->n_long), dim3(64), 0, s,
+                         pl->n_long, pl->win, pl->long_rows, rowptr, static_cast<const T*>(pl->part_head),
+                         static_cast<const T*>(pl->part_tail), y, alpha, beta);
+    } else {
+      launch_rowblock<T, O, false>(s, pl, rowptr, colind, values, x, y, alpha, beta);
+    }
+    SPB_HIP(hipGetLastError());
+    return SPBLAS_GFX950_STATUS_SUCCESS;
+  }
+
+  const int lpr = pl ? pl->vector_lpr : pick_lpr(m, nnz);
+  return run_vector<T, O>(s, lpr, m, rowptr, colind, values, x, y, alpha, beta);
+}
+
+template <typename O>
+static int plan_build(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, int alg_req) {
+  hipStream_t s = h->stream;
+  const O* rowptr = static_cast<const O*>(pl->rowptr);
+  const int64_t m = pl->m, nnz = pl->nnz;
+  pl->win = pl->value_type == SPBLAS_GFX950_F32 ? window_of<float>::value : window_of<double>::value;
+  pl->nwin = nnz / pl->win + 1;
+  pl->vector_lpr = pick_lpr(m, nnz);
+  const size_t tsz = pl->value_type == SPBLAS_GFX950_F32 ? 4 : 8;
+
+  int rc;
+  unsigned long long* d_stats = nullptr;
+  const int64_t long_cap = nnz / pl->win + 1;
+  if ((rc = dev_alloc((void**) &d_stats, 3 * sizeof(unsigned long long), s)))
+    return rc;
+  if ((rc = dev_alloc((void**) &pl->long_rows, (size_t) long_cap * 4, s)))
+    return rc;
+  if ((rc = dev_alloc((void**) &pl->win_row, (size_t) (pl->nwin + 1) * 4, s)))
+    return rc;
+  SPB_HIP(hipMemsetAsync(d_stats, 0, 3 * sizeof(unsigned long long), s));
+  if (m > 0) {
+    hipLaunchKernelGGL((plan_row_stats_kernel<O>), dim3((unsigned) cdiv(m, 256)), dim3(256), 0, s, m,
+                       pl->win, rowptr, d_stats, pl->long_rows);
+  }
+  hipLaunchKernelGGL((plan_window_rows_kernel<O>), dim3((unsigned) cdiv(pl->nwin + 1, 256)), dim3(256), 0,
+                     s, m, pl->nwin, pl->win, rowptr, pl->win_row);
+  SPB_HIP(hipGetLastError());
+  unsigned long long stats[3];
+  SPB_HIP(hipMemcpyAsync(stats, d_stats, sizeof(stats), hipMemcpyDeviceToHost, s));
+  SPB_HIP(hipStreamSynchronize(s));
+  dev_free(d_stats, s);
+  pl->max_row_len = (int64_t) stats[0];
+  pl->n_long = (int64_t) stats[1];
+  pl->empty_rows = (int64_t) stats[2];
+  pl->device_bytes = (size_t) long_cap * 4 + (size_t) (pl->nwin + 1) * 4;
+  if (pl->n_long > 0) {
+    if ((rc = dev_alloc(&pl->part_head, (size_t) pl->nwin * tsz, s)))
+      return rc;
+    if ((rc = dev_alloc(&pl->part_tail, (size_t) pl->nwin * tsz, s)))
+      return rc;
+    pl->device_bytes += 2 * (size_t) pl->nwin * tsz;
+  }
+
+  int alg = alg_req;
+  if (alg == SPBLAS_GFX950_SPMV_AUTO) {
+    // Row blocks need enough entries per window to amortise the block; matrices
+    // that are mostly empty rows (nnz << m) are served by the plan-free kernel.
+    alg = (nnz >= m / 2) ? SPBLAS_GFX950_SPMV_ROWBLOCK : SPBLAS_GFX950_SPMV_VECTOR;
+  }
+  pl->alg = alg;
+  return SPBLAS_GFX950_STATUS_SUCCESS;
+}
+
+} // namespace spb
+
+using namespace spb;
+
+extern "C" {
+
+int spblas_gfx950_spmv_plan_create(spblas_gfx950_handle_t handle, spblas_gfx950_plan_t* plan, int64_t m,
+                                   int64_t n, int64_t nnz, const void* rowptr, const int32_t* colind,
+                                   const void* values, int offset_type, int value_type, int alg) {
+  if (!handle)
+    return SPBLAS_GFX950_STATUS_INVALID_HANDLE;
+  if (!plan)
+    return SPBLAS_GFX950_STATUS_INVALID_POINTER;
+  *plan = nullptr;
+  if (m < 0 || n < 0 || nnz < 0 || m > INT32_MAX || n > INT32_MAX)
+    return SPBLAS_GFX950_STATUS_INVALID_SIZE;
+  if (offset_type == SPBLAS_GFX950_I32 && nnz > INT32_MAX)
+    return SPBLAS_GFX950_STATUS_INVALID_SIZE;
+  if ((offset_type != SPBLAS_GFX950_I32 && offset_type != SPBLAS_GFX950_I64) ||
+      (value_type != SPBLAS_GFX950_F32 && value_type != SPBLAS_GFX950_F64) || alg < 0 ||
+      alg > SPBLAS_GFX950_SPMV_SLICED)
+    return SPBLAS_GFX950_STATUS_INVALID_VALUE;
+  if (!rowptr || (nnz > 0 && !colind))
+    return SPBLAS_GFX950_STATUS_INVALID_POINTER;
+  if (alg == SPBLAS_GFX950_SPMV_SLICED && nnz > 0 && !values)
+    return SPBLAS_GFX950_STATUS_INVALID_POINTER;
+
+  auto* pl = new (std::nothrow) spblas_gfx950_plan_s();
+  if (!pl)
+    return SPBLAS_GFX950_STATUS_ALLOC_FAILED;
+  pl->m = m;
+  pl->n = n;
+  pl->nnz = nnz;
+  pl->rowptr = rowptr;
+  pl->colind = colind;
+  pl->offset_type = offset_type;
+  pl->value_type = value_type;
+  int rc = offset_type == SPBLAS_GFX950_I32 ? plan_build<int32_t>(handle, pl, alg)
+                                            : plan_build<int64_t>(handle, pl, alg);
+  if (rc == SPBLAS_GFX950_STATUS_SUCCESS && pl->alg == SPBLAS_GFX950_SPMV_SLICED)
+    rc = spmv_sliced_build(handle, pl, values);
+  if (rc != SPBLAS_GFX950_STATUS_SUCCESS) {
+    spblas_gfx950_plan_destroy(handle, pl);
+    return rc;
+  }
+  *plan = pl;
+  return SPBLAS_GFX950_STATUS_SUCCESS;
+}
+
+int spblas_gfx950_spmv_plan_update_values(spblas_gfx950_handle_t handle, spblas_gfx950_plan_t plan,
+                                          const void* values) {
+  if (!handle)
+    return SPBLAS_GFX950_STATUS_INVALID_HANDLE;
+  if (!plan || !values)
+    return SPBLAS_GFX950_STATUS_INVALID_POINTER;
+  if (plan->alg != SPBLAS_GFX950_SPMV_SLICED)
+    return SPBLAS_GFX950_STATUS_SUCCESS;  // other algorithms read the caller's values directly
+  return spmv_sliced_update(handle, plan, values);
+}
+
+int spblas_gfx950_plan_destroy(spblas_gfx950_handle_t handle, spblas_gfx950_plan_t plan) {
+  if (!handle)
+    return SPBLAS_GFX950_STATUS_INVALID_HANDLE;
+  if (!plan)
+    return SPBLAS_GFX950_STATUS_SUCCESS;
+  hipStream_t s = handle->stream;
+  dev_free(plan->win_row, s);
+  dev_free(plan->long_rows, s);
+  dev_free(plan->part_head, s);
+  dev_free(plan->part_tail, s);
+  spmv_sliced_free(handle, plan);
+  delete plan;
+  return SPBLAS_GFX950_STATUS_SUCCESS;
+}
+
+int spblas_gfx950_plan_info(spblas_gfx950_plan_t plan, int64_t info[8]) {
+  if (!plan || !info)
+    return SPBLAS_GFX950_STATUS_INVALID_POINTER;
+  info[0] = plan->alg;
+  info[1] = plan->win;
+  info[2] = plan->nwin;
+  info[3] = plan->n_long;
+  info[4] = plan->max_row_len;
+  info[5] = (int64_t) plan->device_bytes;
+  info[6] = plan->n_slices;
+  info[7] = plan->empty_rows;
+  return SPBLAS_GFX950_STATUS_SUCCESS;
+}
+
+int spblas_gfx950_spmv(spblas_gfx950_handle_t handle, spblas_gfx950_plan_t plan, int op, int64_t m, int64_t n,
+                       int64_t nnz, const void* alpha, const void* rowptr, const int32_t* colind,
+                       const void* values, const void* x, const void* beta, void* y, int offset_type,
+                       int value_type) {
+  if (!handle)
+    return SPBLAS_GFX950_STATUS_INVALID_HANDLE;
+  if (m < 0 || n < 0 || nnz < 0 || m > INT32_MAX || n > INT32_MAX)
+    return SPBLAS_GFX950_STATUS_INVALID_SIZE;
+  if (offset_type == SPBLAS_GFX950_I32 && nnz > INT32_MAX)
+    return SPBLAS_GFX950_STATUS_INVALID_SIZE;
+  if ((op != SPBLAS_GFX950_OP_N && op != SPBLAS_GFX950_OP_T) ||
+      (offset_type != SPBLAS_GFX950_I32 && offset_type != SPBLAS_GFX950_I64) ||
+      (value_type != SPBLAS_GFX950_F32 && value_type != SPBLAS_GFX950_F64))
+    return SPBLAS_GFX950_STATUS_INVALID_VALUE;
+  const int64_t ylen = op == SPBLAS_GFX950_OP_N ? m : n, xlen = op == SPBLAS_GFX950_OP_N ? n : m;
+  if (!alpha || !beta || !rowptr || (nnz > 0 && (!colind || !values)) || (ylen > 0 && !y) ||
+      (xlen > 0 && nnz > 0 && !x))
+    return SPBLAS_GFX950_STATUS_INVALID_POINTER;
+  if (plan) {
+    if (plan->m != m || plan->n != n || plan->nnz != nnz || plan->rowptr != rowptr ||
+        plan->colind != colind || plan->offset_type != offset_type || plan->value_type != value_type)
+      return SPBLAS_GFX950_STATUS_PLAN_MISMATCH;
+    if (op != SPBLAS_GFX950_OP_N)
+      plan = nullptr;  // plans describe op = N only
+  }
+  if (value_type == SPBLAS_GFX950_F32) {
+    return offset_type == SPBLAS_GFX950_I32
+               ? spmv_typed<float, int32_t>(handle, plan, op, m, n, nnz, alpha, rowptr, colind, values, x, beta, y)
+               : spmv_typed<float, int64_t>(handle, plan, op, m, n, nnz, alpha, rowptr, colind, values, x, beta, y);
+  }
+  return offset_type == SPBLAS_GFX950_I32
+             ? spmv_typed<double, int32_t>(handle, plan, op, m, n, nnz, alpha, rowptr, colind, values, x, beta, y)
+             : spmv_typed<double, int64_t>(handle, plan, op, m, n, nnz, alpha, rowptr, colind, values, x, beta, y);
+}
+
+} // extern "C"

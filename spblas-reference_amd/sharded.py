@@ -1,0 +1,111 @@
+"""Row-sharded multi-GPU SpMV: one process per GPU, y all-gathered over RCCL/xGMI.
+
+The reference is single-device (no collectives anywhere); this is
+new capability layered on the same multiply() path.  CSR rows are independent
+(/root/reference/include/spblas/algorithms/multiply_impl.hpp:48-52), so each rank owns a
+contiguous row range chosen by NNZ PREFIX on rowptr (mandatory for power-law inputs),
+keeps x replicated, computes its slice of y with the single-GPU kernel and exchanges
+slices with ONE all-gather per step -- the only data-path collective.  In an iterative
+solver y is the next x, which is why the gather belongs to the step.
+
+xGMI is point-to-point (7 links x ~153 GB/s per GPU): an all-gather moves each shard
+once over each link, so bigger, fewer collectives win; y shards are gathered in a single
+call, in place when the shards are equal-sized.
+"""
+import torch
+import torch.distributed as dist
+
+from . import api
+
+
+def partition_rows_by_nnz(rowptr, world_size):
+    """Row boundaries b[0..P] with b[g] = first row whose start offset >= g*nnz/P.
+    `rowptr` is a 1-D integer tensor (host or device) of m+1 offsets."""
+    m = rowptr.numel() - 1
+    nnz = int(rowptr[-1].item())
+    targets = torch.tensor([(g * nnz) // world_size for g in range(world_size + 1)], dtype=rowptr.dtype,
+                           device=rowptr.device)
+    b = torch.searchsorted(rowptr.contiguous(), targets, right=False).clamp_(max=m)
+    b[0] = 0
+    b[-1] = m
+    b = torch.cummax(b, 0).values
+    return [int(v) for v in b.tolist()]
+
+
+def partition_rows_even(m, world_size):
+    return [(g * m) // world_size for g in range(world_size + 1)]
+
+
+def shard_csr(values, rowptr, colind, shape, row_begin, row_end):
+    """Local shard of a global CSR: rows [row_begin, row_end), rowptr rebased to 0,
+    column indices stay global (x is replicated)."""
+    p0 = int(rowptr[row_begin].item())
+    p1 = int(rowptr[row_end].item())
+    local_rowptr = (rowptr[row_begin:row_end + 1] - p0).to(rowptr.dtype).contiguous()
+    return api.csr_view(values[p0:p1].contiguous(), local_rowptr, colind[p0:p1].contiguous(),
+                        (row_end - row_begin, shape[1]), p1 - p0)
+
+
+def _hip_local_spmv(info, a_local, x, y_local):
+    api.multiply(info, a_local, x, y_local)
+
+
+class ShardedSpMV:
+    """y = A x with A row-sharded over the ranks of `group`.
+
+    a_local   csr_view of this rank's rows (rebased rowptr, global columns)
+    bounds    row boundaries b[0..P] shared by all ranks
+    local_spmv(info, a_local, x, y_local): defaults to the HIP path; CPU (gloo) tests
+              inject the oracle here to exercise the sharding/gather logic without a GPU.
+    """
+
+    def __init__(self, a_local, bounds, group=None, local_spmv=None, inspect=True):
+        self.group = group
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        assert len(bounds) == self.world + 1
+        self.bounds = list(bounds)
+        self.m = bounds[-1]
+        self.a_local = a_local
+        self.local_spmv = local_spmv or _hip_local_spmv
+        counts = [bounds[g + 1] - bounds[g] for g in range(self.world)]
+        assert a_local.shape()[0] == counts[self.rank]
+        self.counts = counts
+        self.equal = len(set(counts)) == 1
+        vals = a_local.values()
+        self.y_full = torch.zeros(self.m, dtype=vals.dtype, device=vals.device)
+        if self.equal:
+            self.y_local = self.y_full[bounds[self.rank]:bounds[self.rank + 1]]  # in-place gather
+            self.pad = None
+        else:
+            self.maxc = max(counts)
+            self.pad = torch.zeros(self.world * self.maxc, dtype=vals.dtype, device=vals.device)
+            self.y_local = torch.zeros(self.maxc, dtype=vals.dtype, device=vals.device)
+        self.info = api.operation_info_t()
+        if inspect and local_spmv is None:
+            x_probe = torch.empty(a_local.shape()[1], dtype=vals.dtype, device=vals.device)
+            self.info = api.multiply_inspect(a_local, x_probe, self.y_local[:counts[self.rank]])
+
+    def local(self, x):
+        self.local_spmv(self.info, self.a_local, x, self.y_local[:self.counts[self.rank]])
+
+    def gather(self):
+        if self.world == 1:
+            if not self.equal:
+                self.y_full.copy_(self.y_local[:self.m])
+            return self.y_full
+        if self.equal:
+            dist.all_gather_into_tensor(self.y_full, self.y_local, group=self.group)
+        else:
+            # unequal (nnz-balanced) shards: one padded all-gather, then P contiguous copies
+            dist.all_gather_into_tensor(self.pad, self.y_local, group=self.group)
+            for g in range(self.world):
+                c = self.counts[g]
+                if c:
+                    self.y_full[self.bounds[g]:self.bounds[g + 1]].copy_(self.pad[g * self.maxc:g * self.maxc + c])
+        return self.y_full
+
+    def step(self, x):
+        """One sharded SpMV: local rows, then all-gather(y).  Returns the full y."""
+        self.local(x)
+        return self.gather()

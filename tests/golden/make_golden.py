@@ -1,0 +1,125 @@
+"""Generates the known-answer fixtures in this directory.
+
+The reference cannot be run in this image and stores no vectors of its own, so these
+fixtures are computed HERE with exact Python integer arithmetic -- independently of both
+oracle/ and the HIP kernels -- on small-integer data.  Every intermediate is an integer
+below 2**24, so float32/float64 evaluation in ANY summation order reproduces the expected
+arrays bit for bit: they pin the oracle and the GPU kernels exactly, including the edge
+cases the reference's generator produces (unsorted columns, backend/generate.hpp:112-117)
+or merely permits (duplicate columns, empty rows, one very long row, numeric cancellation
+in SpGEMM that must still count structurally, spgemm_gustavsons.hpp:57-89).
+
+Run:  python tests/golden/make_golden.py     (deterministic; fixtures are committed)
+"""
+import os
+import random
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def rand_csr(rng, m, n, row_lens, vmax=8, allow_dups=True):
+    rowptr, colind, values = [0], [], []
+    for L in row_lens:
+        cols = [rng.randrange(n) for _ in range(L)] if allow_dups else rng.sample(range(n), L)
+        colind += cols
+        values += [rng.choice([v for v in range(-vmax, vmax + 1) if v != 0]) for _ in range(L)]
+        rowptr.append(len(colind))
+    return rowptr, colind, values
+
+
+def exact_spmv(rowptr, colind, values, x, sa=1, sx=1):
+    return [sum(sa * values[p] * sx * x[colind[p]] for p in range(rowptr[i], rowptr[i + 1]))
+            for i in range(len(rowptr) - 1)]
+
+
+def save(name, **kw):
+    np.savez(os.path.join(HERE, name + ".npz"), **kw)
+
+
+def spmv_case(name, m, n, row_lens, dtype, seed, sa=None, sx=None):
+    rng = random.Random(seed)
+    rowptr, colind, values = rand_csr(rng, m, n, row_lens)
+    x = [rng.randrange(-4, 5) for _ in range(n)]
+    y = exact_spmv(rowptr, colind, values, x, sa or 1, sx or 1)
+    assert max(abs(v) for v in y + [0]) < 2 ** 24
+    kw = dict(kind="spmv", shape=np.array([m, n]), rowptr=np.array(rowptr, np.int32),
+              colind=np.array(colind, np.int32), values=np.array(values, dtype), x=np.array(x, dtype),
+              y=np.array(y, dtype))
+    if sa is not None:
+        kw["scale_a"] = np.array(sa, dtype)
+    if sx is not None:
+        kw["scale_x"] = np.array(sx, dtype)
+    save(name, **kw)
+
+
+def main():
+    rng = random.Random(0)
+    # examples/simple_spmv.cpp:12-14 shape: 100 x 100 with 10 nonzeros (most rows empty)
+    lens = [0] * 100
+    for _ in range(10):
+        lens[rng.randrange(100)] += 1
+    spmv_case("spmv_example_100x100_nnz10", 100, 100, lens, np.float32, 1)
+    # ragged: empty rows, duplicates, unsorted columns, one 3000-entry row, trailing empties
+    lens = [rng.choice([0, 0, 1, 2, 3, 7, 10, 33, 64, 65]) for _ in range(400)]
+    lens[137] = 3000
+    lens[-5:] = [0] * 5
+    spmv_case("spmv_ragged_f32", 400, 513, lens, np.float32, 2)
+    spmv_case("spmv_ragged_f64", 400, 513, lens, np.float64, 3)
+    spmv_case("spmv_scaled_a_m10", 120, 90, [rng.randrange(0, 20) for _ in range(120)], np.float32, 4, sa=-10)
+    spmv_case("spmv_scaled_x_5", 120, 90, [rng.randrange(0, 20) for _ in range(120)], np.float32, 5, sx=5)
+    # rows much longer than one nnz window (2048 fp32 / 1024 fp64): the split-row path
+    lens = [5] * 64
+    lens[3] = 9000
+    lens[40] = 2500
+    lens[41] = 2049
+    spmv_case("spmv_long_rows_f32", 64, 2000, lens, np.float32, 6)
+    spmv_case("spmv_long_rows_f64", 64, 2000, lens, np.float64, 7)
+
+    # SpMM: n = 8 (vector width 4) and n = 3 (scalar path)
+    for n, seed in ((8, 8), (3, 9), (130, 10)):
+        r = random.Random(seed)
+        m, k = 60, 50
+        rowptr, colind, values = rand_csr(r, m, k, [r.randrange(0, 12) for _ in range(m)])
+        B = [[r.randrange(-4, 5) for _ in range(n)] for _ in range(k)]
+        C = [[sum(values[p] * B[colind[p]][j] for p in range(rowptr[i], rowptr[i + 1])) for j in range(n)]
+             for i in range(m)]
+        save(f"spmm_n{n}", kind="spmm", shape=np.array([m, k]), rowptr=np.array(rowptr, np.int32),
+             colind=np.array(colind, np.int32), values=np.array(values, np.float32),
+             B=np.array(B, np.float32), C=np.array(C, np.float32))
+
+    # SpGEMM: duplicates inside A rows, and products that cancel numerically (must still be
+    # counted and stored, with value 0)
+    r = random.Random(11)
+    m, k, n = 70, 40, 55
+    ar, ac, av = rand_csr(r, m, k, [r.randrange(0, 9) for _ in range(m)])
+    br, bc, bv = rand_csr(r, k, n, [r.randrange(0, 9) for _ in range(k)], allow_dups=False)
+    # force a cancellation: row 0 of A = {(k0, +1), (k0, -1)}
+    k0 = next(i for i in range(k) if br[i + 1] > br[i])
+    la = ar[1] - ar[0]
+    ac[ar[0]:ar[1]] = []
+    av[ar[0]:ar[1]] = []
+    ac[0:0] = [k0, k0]
+    av[0:0] = [1, -1]
+    ar = [0] + [p - la + 2 for p in ar[1:]]
+    c_rowptr, c_colind, c_values = [0], [], []
+    for i in range(m):
+        acc = {}
+        for p in range(ar[i], ar[i + 1]):
+            for q in range(br[ac[p]], br[ac[p] + 1]):
+                acc[bc[q]] = acc.get(bc[q], 0) + av[p] * bv[q]
+        for j in sorted(acc):
+            c_colind.append(j)
+            c_values.append(acc[j])
+        c_rowptr.append(len(c_colind))
+    assert c_rowptr[1] > 0 and all(v == 0 for v in c_values[:c_rowptr[1]])
+    save("spgemm_dups_cancel", kind="spgemm", a_shape=np.array([m, k]), b_shape=np.array([k, n]),
+         a_rowptr=np.array(ar, np.int32), a_colind=np.array(ac, np.int32), a_values=np.array(av, np.float32),
+         b_rowptr=np.array(br, np.int32), b_colind=np.array(bc, np.int32), b_values=np.array(bv, np.float32),
+         c_rowptr=np.array(c_rowptr, np.int32), c_colind=np.array(c_colind, np.int32),
+         c_values=np.array(c_values, np.float32), c_nnz=np.array(len(c_colind)))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,237 @@
+"""-m gpu parity tests for CSR SpMV: the HIP path (through the C ABI) vs the CPU oracle.
+
+Cases mirror /root/reference/test/gtest/device/spmv_test.cpp:11-146 (CsrView SpMV,
+SpMV_Ascaled, SpMV_BScaled on util::dims with alpha in {-10,1,5}) and add the edge cases
+SURVEY.md section 8c lists (empty/ragged rows, unsorted + duplicate columns, one very long
+row, int64 offsets, fp64, inspect/execute, matrix_opt reuse, CSC/transposed operand).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import gpu_util as G
+import spblas_reference_amd as sp
+import util
+from oracle import oracle
+from spblas_reference_amd import _capi, generate
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+ALGS = {"noplan": None, "auto": _capi.SPMV_AUTO, "vector": _capi.SPMV_VECTOR, "rowblock": _capi.SPMV_ROWBLOCK}
+
+
+def run_spmv(a_view, x, m, alg, scale_a=None, scale_x=None):
+    y = torch.full((m,), float("nan"), dtype=x.dtype, device=x.device)  # beta = 0 must not read y
+    a = sp.scaled(scale_a, a_view) if scale_a is not None else a_view
+    b = sp.scaled(scale_x, x) if scale_x is not None else x
+    if alg is None:
+        sp.multiply(a, b, y)
+    else:
+        info = sp.multiply_inspect(a, b, y, alg=alg)
+        sp.multiply(info, a, b, y)
+    return G.host(y)
+
+
+def check(values, rowptr, colind, shape, x, y, scale=1.0, what=""):
+    y_ref = oracle.spmv(shape, rowptr, colind, values, x, scale_a=None if scale == 1.0 else scale)
+    exact, absrow = util.spmv_exact(rowptr, colind, values, x)
+    absrow = absrow * abs(scale)
+    lens = np.diff(rowptr)
+    util.assert_parity(y, y_ref, absrow, values.dtype, row_len=lens, what=what + " vs oracle")
+    util.assert_parity(y, exact * scale, absrow, values.dtype, what=what + " vs float64")
+    util.expect_eq_ref(y_ref, y)  # the reference's own comparator (test/gtest/util.hpp:7-23)
+
+
+@pytest.mark.parametrize("alg", list(ALGS))
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("dim", util.dims)
+def test_spmv_reference_device_test(gpu, dim, dtype, alg):
+    # device/spmv_test.cpp:11-49: b = ones
+    m, n, nnz = dim
+    values, rowptr, colind, shape, _ = generate.generate_csr(m, n, nnz, dtype=dtype)
+    a = G.csr_on_device(values, rowptr, colind, shape, nnz)
+    x = np.ones(n, dtype=dtype)
+    y = run_spmv(a, G.dev(x), m, ALGS[alg])
+    check(values, rowptr, colind, shape, x, y, what=f"spmv {dim} {alg}")
+
+
+@pytest.mark.parametrize("alpha", [-10, 1, 5])
+@pytest.mark.parametrize("dim", util.dims)
+def test_spmv_scaled_views(gpu, dim, alpha):
+    # device/spmv_test.cpp:51-146: scaled(alpha, a) and scaled(alpha, b)
+    m, n, nnz = dim
+    values, rowptr, colind, shape, _ = generate.generate_csr(m, n, nnz)
+    a = G.csr_on_device(values, rowptr, colind, shape, nnz)
+    x = np.ones(n, dtype=np.float32)
+    for kw in ({"scale_a": alpha}, {"scale_x": alpha}):
+        for alg in (None, _capi.SPMV_ROWBLOCK):
+            y = run_spmv(a, G.dev(x), m, alg, **kw)
+            ref = util.naive_spmv(rowptr, colind, values, x, alpha_a=kw.get("scale_a"), alpha_b=kw.get("scale_x"))
+            util.expect_eq_ref(ref, y)
+            check(values, rowptr, colind, shape, x, y, scale=float(alpha), what=f"scaled {kw}")
+    # both at once: alpha = product of all factors (detail/view_inspectors.hpp:55-77)
+    y = run_spmv(a, G.dev(x), m, None, scale_a=alpha, scale_x=2.0)
+    check(values, rowptr, colind, shape, x, y, scale=2.0 * alpha, what="scaled both")
+
+
+@pytest.mark.parametrize("alg", list(ALGS))
+@pytest.mark.parametrize("name", sorted(f for f in os.listdir(GOLDEN) if f.startswith("spmv_")))
+def test_spmv_golden_bit_exact(gpu, name, alg):
+    g = np.load(os.path.join(GOLDEN, name))
+    a = G.csr_on_device(g["values"], g["rowptr"], g["colind"], tuple(g["shape"]), len(g["values"]))
+    kw = {}
+    if "scale_a" in g:
+        kw["scale_a"] = float(g["scale_a"])
+    if "scale_x" in g:
+        kw["scale_x"] = float(g["scale_x"])
+    y = run_spmv(a, G.dev(g["x"]), int(g["shape"][0]), ALGS[alg], **kw)
+    assert np.array_equal(y, g["y"]), f"{name} {alg}: integer-valued fixture must be bit exact"
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("alg", list(ALGS))
+def test_spmv_ragged_powerlaw_int64_offsets(gpu, dtype, alg):
+    rng = np.random.default_rng(5)
+    m, n = 3000, 4099
+    lens = np.minimum(rng.zipf(1.6, m), 20000).astype(np.int64)
+    lens[rng.random(m) < 0.3] = 0
+    lens[17] = 9000
+    lens[2998] = 5000
+    rowptr = np.zeros(m + 1, np.int64)
+    np.cumsum(lens, out=rowptr[1:])
+    nnz = int(rowptr[-1])
+    colind = rng.integers(0, n, nnz).astype(np.int32)
+    values = (rng.random(nnz) - 0.5).astype(dtype)
+    x = (rng.random(n) - 0.5).astype(dtype)
+    for off64 in (False, True):
+        a = G.csr_on_device(values, rowptr, colind, (m, n), nnz, offset64=off64)
+        y = run_spmv(a, G.dev(x), m, ALGS[alg])
+        check(values, rowptr.astype(np.int32), colind, (m, n), x, y, what=f"ragged {alg} off64={off64}")
+
+
+def test_spmv_plan_introspection_and_long_rows(gpu):
+    lens = np.full(500, 3, np.int64)
+    lens[100] = 10000
+    rowptr = np.concatenate([[0], np.cumsum(lens)])
+    nnz = int(rowptr[-1])
+    rng = np.random.default_rng(1)
+    colind = rng.integers(0, 777, nnz).astype(np.int32)
+    values = rng.random(nnz).astype(np.float32)
+    a = G.csr_on_device(values, rowptr, colind, (500, 777), nnz)
+    x = G.dev(rng.random(777).astype(np.float32))
+    y = torch.zeros(500, device="cuda")
+    info = sp.multiply_inspect(a, x, y)
+    pi = info.state_.info()
+    assert pi["alg"] == _capi.SPMV_ROWBLOCK and pi["n_long_rows"] == 1 and pi["max_row_len"] == 10000
+    assert pi["n_windows"] == nnz // pi["window"] + 1 and pi["empty_rows"] == 0
+    sp.multiply(info, a, x, y)
+    check(values, rowptr.astype(np.int32), colind, (500, 777), G.host(x), G.host(y), what="long row")
+
+
+def test_spmv_matrix_opt_caches_plan_and_values_may_change(gpu):
+    values, rowptr, colind, shape, nnz = generate.generate_csr(1000, 1000, 20000, seed=9)
+    a = G.csr_on_device(values, rowptr, colind, shape, nnz)
+    a_opt = sp.matrix_opt(a)
+    x = G.dev(np.random.default_rng(0).random(1000).astype(np.float32))
+    y = torch.zeros(1000, device="cuda")
+    sp.multiply_inspect(a_opt, x, y)
+    assert a_opt._plan is not None
+    sp.multiply(a_opt, x, y)  # no info: the plan comes from the matrix_opt
+    check(values, rowptr, colind, shape, G.host(x), G.host(y), what="matrix_opt")
+    # row-partition plans read the caller's arrays: changing values in place stays correct
+    a.values().mul_(3.0)
+    sp.multiply(a_opt, x, y)
+    check(values * np.float32(3), rowptr, colind, shape, G.host(x), G.host(y), what="matrix_opt rescaled")
+
+
+def test_spmv_csc_and_transposed_operand(gpu):
+    # y = A x with A given as csc_view, and y = A^T x via transposed(csr)
+    # (vendor/rocsparse/detail/get_transpose.hpp:19-29; test/gtest/spmv_test.cpp:110-208)
+    values, rowptr, colind, shape, nnz = generate.generate_csr(300, 200, 4000, seed=4)
+    x = np.random.default_rng(3).random(300).astype(np.float32)
+    a = G.csr_on_device(values, rowptr, colind, shape, nnz)
+    y = torch.full((200,), float("nan"), device="cuda")
+    sp.multiply(sp.transposed(a), G.dev(x), y)  # A^T (200x300) as csc_view
+    y_ref = oracle.spmv_csc((200, 300), rowptr, colind, values, x)
+    import scipy.sparse as sps
+    absrow = sps.csr_matrix((np.abs(values).astype(np.float64), colind, rowptr), shape=shape).T @ np.abs(x)
+    util.assert_parity(G.host(y), y_ref, absrow, np.float32, row_len=np.full(200, 64), what="csc spmv")
+    sp.multiply(sp.scaled(2.0, sp.transposed(a)), G.dev(x), y)
+    util.assert_parity(G.host(y), 2 * y_ref, 2 * absrow, np.float32, row_len=np.full(200, 64), what="csc scaled")
+
+
+def test_spmv_degenerate_shapes(gpu):
+    # all rows empty; zero rows; single entry
+    z = sp.csr_view(torch.zeros(0, device="cuda"), torch.zeros(6, dtype=torch.int32, device="cuda"),
+                    torch.zeros(0, dtype=torch.int32, device="cuda"), (5, 7), 0)
+    y = torch.full((5,), 3.0, device="cuda")
+    sp.multiply(z, torch.ones(7, device="cuda"), y)
+    assert np.array_equal(G.host(y), np.zeros(5, np.float32))
+    info = sp.multiply_inspect(z, torch.ones(7, device="cuda"), y)
+    sp.multiply(info, z, torch.ones(7, device="cuda"), y)
+    assert np.array_equal(G.host(y), np.zeros(5, np.float32))
+    one = sp.csr_view(torch.tensor([2.5], device="cuda"), torch.tensor([0, 0, 1], dtype=torch.int32, device="cuda"),
+                      torch.tensor([1], dtype=torch.int32, device="cuda"), (2, 3), 1)
+    y2 = torch.zeros(2, device="cuda")
+    sp.multiply(one, torch.tensor([1., 4., 9.], device="cuda"), y2)
+    assert np.array_equal(G.host(y2), np.array([0, 10], np.float32))
+
+
+def test_spmv_errors_on_device(gpu):
+    values, rowptr, colind, shape, nnz = generate.generate_csr(40, 40, 1000)
+    a = G.csr_on_device(values, rowptr, colind, shape, nnz)
+    with pytest.raises(ValueError):  # multiply_impl.hpp:37-41
+        sp.multiply(a, torch.ones(39, device="cuda"), torch.zeros(40, device="cuda"))
+    with pytest.raises(RuntimeError, match="conjugated"):  # spmv_impl.hpp:29-33
+        sp.multiply(sp.conjugated(a), torch.ones(40, device="cuda"), torch.zeros(40, device="cuda"))
+    # a plan built for another matrix is refused by the library
+    other = G.csr_on_device(*generate.generate_csr(40, 40, 900, seed=2))
+    info = sp.multiply_inspect(other, torch.ones(40, device="cuda"), torch.zeros(40, device="cuda"))
+    sp.multiply(info, a, torch.ones(40, device="cuda"), torch.zeros(40, device="cuda"))  # key differs -> plan-free
+
+
+@pytest.mark.parametrize("poisson", [False, True])
+def test_spmv_full_size_properties_cfg2(gpu, poisson):
+    """BASELINE cfg2 (10M x 10M, avg 10 nnz/row, fp32) through size-independent properties:
+    (1) a seeded sample of rows against the oracle, (2) linearity A(ax+by) = aAx + bAy,
+    (3) plan and plan-free kernels agree, (4) sum(y) == column-weighted checksum in fp64."""
+    m = n = 10_000_000
+    values, rowptr, colind, shape, nnz = generate.uniform_csr_device(m, n, 10, poisson=poisson, seed=0)
+    a = sp.csr_view(values, rowptr, colind, shape, nnz)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    x1 = torch.rand(n, device="cuda", generator=g)
+    x2 = torch.rand(n, device="cuda", generator=g)
+    y1, y2, y3, y1v = (torch.empty(m, device="cuda") for _ in range(4))
+    info = sp.multiply_inspect(a, x1, y1)
+    assert info.state_.info()["alg"] == _capi.SPMV_ROWBLOCK
+    sp.multiply(info, a, x1, y1)
+    sp.multiply(info, a, x2, y2)
+    sp.multiply(info, a, 0.5 * x1 - 2.0 * x2, y3)
+    sp.multiply(a, x1, y1v)
+    # (2) linearity, norm-wise: |y3 - (.5y1 - 2y2)| <= 4e-6 * (|.5 y1| + |2 y2|)
+    lin = (y3 - (0.5 * y1 - 2.0 * y2)).abs()
+    assert bool((lin <= 4e-6 * (0.5 * y1.abs() + 2.0 * y2.abs()) + 1e-30).all())
+    # (3) the two kernels agree to rounding
+    assert bool(((y1 - y1v).abs() <= 2e-6 * y1.abs() + 1e-30).all())
+    # (4) checksum: sum_i y_i == sum_p v_p x_{c_p} in float64
+    lhs = y1.double().sum().item()
+    rhs = (values.double() * x1[colind.long()].double()).sum().item()
+    assert abs(lhs - rhs) <= 1e-6 * abs(rhs)
+    # (1) oracle on the first and last 2000 rows and 2000 random rows
+    rp = rowptr.cpu().numpy().astype(np.int64)
+    rows = np.unique(np.concatenate([np.arange(2000), np.arange(m - 2000, m),
+                                     np.random.default_rng(0).integers(0, m, 2000)]))
+    x_h = x1.cpu().numpy()
+    y_h = y1.cpu().numpy()
+    for chunk in (rows[:2000], rows[2000:]):
+        lens = rp[chunk + 1] - rp[chunk]
+        sub_rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        idx = np.concatenate([np.arange(rp[r], rp[r + 1]) for r in chunk]) if lens.sum() else np.zeros(0, np.int64)
+        idx_t = torch.from_numpy(idx).cuda()
+        sub_c = colind[idx_t].cpu().numpy()
+        sub_v = values[idx_t].cpu().numpy()
+        y_ref = oracle.spmv((len(chunk), n), sub_rp, sub_c, sub_v, x_h)
+        absrow = oracle.spmv_absrow(sub_rp, sub_c, sub_v, x_h)
+        util.assert_parity(y_h[chunk], y_ref, absrow, np.float32, what="cfg2 sampled rows")
