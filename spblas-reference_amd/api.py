@@ -247,6 +247,12 @@ class _Plan:
                  "empty_rows"]
         return dict(zip(names, list(arr)))
 
+    def update_values(self, values):
+        """Refresh the plan after A's values changed in place (only the SLICED re-tiling keeps
+        a copy of them; the other algorithms read the caller's array on every call)."""
+        check(_capi.lib().spblas_gfx950_spmv_plan_update_values(self.handle.h, self.plan, _ptr(values)),
+              "update_values")
+
     def __del__(self):
         try:
             if self.plan:

@@ -28,16 +28,18 @@ struct spblas_gfx950_plan_s {
   int64_t max_row_len = 0;
   int64_t empty_rows = 0;
 
-  // SLICED: column-sliced copy of A (see spmv_sliced.hip)
-  int n_slices = 0;
+  // SLICED: column-sliced re-tiling of A (see spmv_sliced.hip)
+  int n_slices = 0;      // S column slices of slice_cols columns
   int slice_cols = 0;
-  int rows_per_blk = 0;
-  int64_t n_rblk = 0;
-  int64_t* seg_ptr = nullptr;   // [n_rblk * n_slices + 1] offsets into s_* arrays
-  int32_t* s_colind = nullptr;  // [nnz] column index
-  void* s_values = nullptr;     // [nnz] T
-  uint16_t* s_lrow = nullptr;   // [nnz] row index local to the row block
-  int64_t* s_perm = nullptr;    // [nnz] source position in the CSR arrays
+  int rows_per_blk = 0;  // H rows per bin
+  int64_t n_rblk = 0;    // NB bins
+  void* seg_ptr = nullptr;     // int32[S*NB + 1] segment offsets in A' order, key = s*NB + b
+  void* s_segT = nullptr;      // int2[NB*S] (start, length) per (b, s)
+  void* s_colind = nullptr;    // uint16[nnz] column inside the slice
+  void* s_values = nullptr;    // T[nnz]
+  uint16_t* s_lrow = nullptr;  // uint16[nnz] row inside the bin
+  void* s_perm = nullptr;      // int32[nnz] source position in the caller's CSR arrays
+  void* s_products = nullptr;  // T[nnz] workspace: expanded products
 
   size_t device_bytes = 0;
 };

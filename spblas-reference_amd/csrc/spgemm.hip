@@ -17,6 +17,7 @@
 // rank-sorts the (unique) keys and writes colind/values in ascending column order.
 // Integer/byte traffic bound: algorithmic bytes = A + B once + C once.
 #include "common.hpp"
+#include "scan.hpp"
 
 #include <new>
 
@@ -275,88 +276,6 @@ __global__ __launch_bounds__(256) void spg_zero_rows_kernel(int64_t count, const
   const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
   if (i < count)
     c_rowptr[perm[i]] = 0;
-}
-
-// ---- exclusive scan of int32 counts (in place), total in int64 ----------------
-// data[0..n) counts -> offsets; block partial sums in `partials` (int64).
-__global__ __launch_bounds__(256) void scan_block_sums_kernel(int64_t n, const int32_t* __restrict__ data,
-                                                              long long* __restrict__ partials) {
-  __shared__ long long red[4];
-  const int64_t base = (int64_t) blockIdx.x * 2048;
-  long long s = 0;
-  for (int i = threadIdx.x; i < 2048; i += 256)
-    if (base + i < n)
-      s += data[base + i];
-  s = group_sum_c<64>(s);
-  if ((threadIdx.x & 63) == 0)
-    red[threadIdx.x >> 6] = s;
-  __syncthreads();
-  if (threadIdx.x == 0)
-    partials[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
-}
-
-// single workgroup: exclusive scan of partials[0..nb) in place, partials[nb] = total
-__global__ __launch_bounds__(256) void scan_partials_kernel(int64_t nb, long long* __restrict__ partials) {
-  __shared__ long long sm[256];
-  __shared__ long long carry;
-  if (threadIdx.x == 0)
-    carry = 0;
-  __syncthreads();
-  for (int64_t b0 = 0; b0 < nb; b0 += 256) {
-    const int64_t i = b0 + threadIdx.x;
-    const long long v = i < nb ? partials[i] : 0;
-    sm[threadIdx.x] = v;
-    __syncthreads();
-    for (int o = 1; o < 256; o <<= 1) {
-      const long long t = threadIdx.x >= o ? sm[threadIdx.x - o] : 0;
-      __syncthreads();
-      sm[threadIdx.x] += t;
-      __syncthreads();
-    }
-    const long long c = carry;
-    if (i < nb)
-      partials[i] = c + sm[threadIdx.x] - v;
-    __syncthreads();
-    if (threadIdx.x == 255)
-      carry = c + sm[255];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0)
-    partials[nb] = carry;
-}
-
-// data[0..n) counts -> exclusive offsets, data[n] = total (n+1 entries written)
-__global__ __launch_bounds__(256) void scan_apply_kernel(int64_t n, int32_t* __restrict__ data,
-                                                         const long long* __restrict__ partials) {
-  __shared__ int sm[256];
-  const int64_t base = (int64_t) blockIdx.x * 2048;
-  // each thread owns 8 consecutive entries
-  int v[8];
-  int s = 0;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int64_t i = base + threadIdx.x * 8 + j;
-    v[j] = i < n ? data[i] : 0;
-    s += v[j];
-  }
-  sm[threadIdx.x] = s;
-  __syncthreads();
-  for (int o = 1; o < 256; o <<= 1) {
-    const int t = threadIdx.x >= o ? sm[threadIdx.x - o] : 0;
-    __syncthreads();
-    sm[threadIdx.x] += t;
-    __syncthreads();
-  }
-  long long off = partials[blockIdx.x] + sm[threadIdx.x] - s;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int64_t i = base + threadIdx.x * 8 + j;
-    if (i < n)
-      data[i] = (int32_t) off;
-    off += v[j];
-  }
-  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0)
-    data[n] = (int32_t) partials[gridDim.x];
 }
 
 template <typename T, int LOG2HS, int TPR, bool NUMERIC>

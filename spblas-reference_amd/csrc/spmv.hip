@@ -361,7 +361,7 @@ static void launch_rowblock(hipStream_t s, const spblas_gfx950_plan_s* pl, const
 
 int spmv_sliced_exec(spblas_gfx950_handle_t h, const spblas_gfx950_plan_s* pl, const void* alpha,
                      const void* x, const void* beta, void* y);
-int spmv_sliced_build(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const void* values);
+int spmv_sliced_build(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const void* values, bool auto_mode);
 int spmv_sliced_update(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const void* values);
 void spmv_sliced_free(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl);
 
@@ -470,6 +470,17 @@ static int plan_build(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, int al
   return SPBLAS_GFX950_STATUS_SUCCESS;
 }
 
+// AUTO considers the sliced re-tiling only when x cannot live in an XCD's 4 MiB L2, the
+// matrix is big enough to amortise two launches, rows are short (LDS atomics serialise on
+// hub rows) and the average (slice, bin) segment keeps a wavefront busy.
+static bool sliced_candidate(const spblas_gfx950_plan_s* pl) {
+  const size_t tsz = pl->value_type == SPBLAS_GFX950_F32 ? 4 : 8;
+  const double tile = 80.0 * 1024 / tsz;
+  const double nseg = (pl->n / tile + 1) * (pl->m / tile + 1);
+  return (size_t) pl->n * tsz >= ((size_t) 16 << 20) && pl->nnz >= ((int64_t) 8 << 20) &&
+         pl->nnz < INT32_MAX - 8 && pl->max_row_len <= 4096 && (double) pl->nnz / nseg >= 48.0;
+}
+
 } // namespace spb
 
 using namespace spb;
@@ -509,8 +520,21 @@ int spblas_gfx950_spmv_plan_create(spblas_gfx950_handle_t handle, spblas_gfx950_
   pl->value_type = value_type;
   int rc = offset_type == SPBLAS_GFX950_I32 ? plan_build<int32_t>(handle, pl, alg)
                                             : plan_build<int64_t>(handle, pl, alg);
-  if (rc == SPBLAS_GFX950_STATUS_SUCCESS && pl->alg == SPBLAS_GFX950_SPMV_SLICED)
-    rc = spmv_sliced_build(handle, pl, values);
+  if (rc == SPBLAS_GFX950_STATUS_SUCCESS && pl->alg == SPBLAS_GFX950_SPMV_SLICED) {
+    rc = spmv_sliced_build(handle, pl, values, false);
+  } else if (rc == SPBLAS_GFX950_STATUS_SUCCESS && alg == SPBLAS_GFX950_SPMV_AUTO && values &&
+             pl->alg == SPBLAS_GFX950_SPMV_ROWBLOCK && sliced_candidate(pl)) {
+    // x far larger than an XCD's L2 and no long rows: try the LDS-sliced re-tiling; it
+    // declines (NOT_SUPPORTED) when the entries cluster in few tiles.
+    const int rc2 = spmv_sliced_build(handle, pl, values, true);
+    if (rc2 == SPBLAS_GFX950_STATUS_SUCCESS) {
+      pl->alg = SPBLAS_GFX950_SPMV_SLICED;
+    } else {
+      spmv_sliced_free(handle, pl);
+      if (rc2 != SPBLAS_GFX950_STATUS_NOT_SUPPORTED)
+        rc = rc2;
+    }
+  }
   if (rc != SPBLAS_GFX950_STATUS_SUCCESS) {
     spblas_gfx950_plan_destroy(handle, pl);
     return rc;

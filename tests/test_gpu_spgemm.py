@@ -108,12 +108,12 @@ def test_spgemm_all_bins_including_dense_rows(gpu):
     a_lens[7] = 0
     ar = np.concatenate([[0], np.cumsum(a_lens)]).astype(np.int32)
     ac = np.concatenate([rng.choice(k, L, replace=False) for L in a_lens]).astype(np.int32)
-    av = (rng.random(len(ac)) - 0.5).astype(np.float32)
+    av = (rng.random(len(ac)) + 0.5).astype(np.float32)  # positive like the reference's U[0,100) data
     b_lens = rng.integers(0, 60, k)
     b_lens[ac[ar[6]]] = 5000
     br = np.concatenate([[0], np.cumsum(b_lens)]).astype(np.int32)
     bc = np.concatenate([rng.choice(n, L, replace=False) for L in b_lens]).astype(np.int32)
-    bv = (rng.random(len(bc)) - 0.5).astype(np.float32)
+    bv = (rng.random(len(bc)) + 0.5).astype(np.float32)
     a_h, b_h = (av, ar, ac, (m, k)), (bv, br, bc, (k, n))
     check_against_oracle(a_h, b_h, device_spgemm(a_h, b_h, True), np.float32)
 

@@ -19,7 +19,8 @@ from spblas_reference_amd import _capi, generate
 
 pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
-ALGS = {"noplan": None, "auto": _capi.SPMV_AUTO, "vector": _capi.SPMV_VECTOR, "rowblock": _capi.SPMV_ROWBLOCK}
+ALGS = {"noplan": None, "auto": _capi.SPMV_AUTO, "vector": _capi.SPMV_VECTOR, "rowblock": _capi.SPMV_ROWBLOCK,
+        "sliced": _capi.SPMV_SLICED}
 
 
 def run_spmv(a_view, x, m, alg, scale_a=None, scale_x=None):
@@ -34,14 +35,15 @@ def run_spmv(a_view, x, m, alg, scale_a=None, scale_x=None):
     return G.host(y)
 
 
-def check(values, rowptr, colind, shape, x, y, scale=1.0, what=""):
+def check(values, rowptr, colind, shape, x, y, scale=1.0, what="", ref_cmp=True):
     y_ref = oracle.spmv(shape, rowptr, colind, values, x, scale_a=None if scale == 1.0 else scale)
     exact, absrow = util.spmv_exact(rowptr, colind, values, x)
     absrow = absrow * abs(scale)
     lens = np.diff(rowptr)
     util.assert_parity(y, y_ref, absrow, values.dtype, row_len=lens, what=what + " vs oracle")
     util.assert_parity(y, exact * scale, absrow, values.dtype, what=what + " vs float64")
-    util.expect_eq_ref(y_ref, y)  # the reference's own comparator (test/gtest/util.hpp:7-23)
+    if ref_cmp:  # the reference's own comparator (test/gtest/util.hpp:7-23); it is relative to the
+        util.expect_eq_ref(y_ref, y)  # RESULT, so it only applies to the sign-definite data its tests use
 
 
 @pytest.mark.parametrize("alg", list(ALGS))
@@ -108,7 +110,39 @@ def test_spmv_ragged_powerlaw_int64_offsets(gpu, dtype, alg):
     for off64 in (False, True):
         a = G.csr_on_device(values, rowptr, colind, (m, n), nnz, offset64=off64)
         y = run_spmv(a, G.dev(x), m, ALGS[alg])
-        check(values, rowptr.astype(np.int32), colind, (m, n), x, y, what=f"ragged {alg} off64={off64}")
+        check(values, rowptr.astype(np.int32), colind, (m, n), x, y, what=f"ragged {alg} off64={off64}", ref_cmp=False)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_spmv_sliced_many_tiles_and_value_update(gpu, dtype, monkeypatch):
+    """The LDS-sliced re-tiling with tiny tiles (test hook env vars) so that a small matrix
+    spans many (slice, bin) segments, incl. empty segments, ragged rows and a long row;
+    then values change in place and the plan is refreshed with update_values."""
+    monkeypatch.setenv("SPBLAS_GFX950_SLICE_COLS", "100")
+    monkeypatch.setenv("SPBLAS_GFX950_SLICE_ROWS", "64")
+    rng = np.random.default_rng(11)
+    m, n = 1500, 2111
+    lens = rng.integers(0, 30, m)
+    lens[rng.random(m) < 0.2] = 0
+    lens[700] = 5000
+    rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    nnz = int(rowptr[-1])
+    colind = rng.integers(0, n, nnz).astype(np.int32)
+    colind[rowptr[3]:rowptr[4]] = 2110  # a row living entirely in the last, narrower slice
+    values = (rng.random(nnz) + 0.5).astype(dtype)
+    x = (rng.random(n) + 0.5).astype(dtype)
+    a = G.csr_on_device(values, rowptr, colind, (m, n), nnz)
+    xd = G.dev(x)
+    y = torch.full((m,), float("nan"), dtype=xd.dtype, device="cuda")
+    info = sp.multiply_inspect(a, xd, y, alg=_capi.SPMV_SLICED)
+    pi = info.state_.info()
+    assert pi["alg"] == _capi.SPMV_SLICED and pi["n_slices"] == 22
+    sp.multiply(info, sp.scaled(2.0, a), xd, y)
+    check(values, rowptr, colind, (m, n), x, G.host(y), scale=2.0, what="sliced tiles")
+    a.values().mul_(0.5)
+    info.state_.update_values(a.values())
+    sp.multiply(info, a, xd, y)
+    check(values * dtype(0.5), rowptr, colind, (m, n), x, G.host(y), what="sliced after update_values")
 
 
 def test_spmv_plan_introspection_and_long_rows(gpu):
@@ -205,11 +239,12 @@ def test_spmv_full_size_properties_cfg2(gpu, poisson):
     x2 = torch.rand(n, device="cuda", generator=g)
     y1, y2, y3, y1v = (torch.empty(m, device="cuda") for _ in range(4))
     info = sp.multiply_inspect(a, x1, y1)
-    assert info.state_.info()["alg"] == _capi.SPMV_ROWBLOCK
+    assert info.state_.info()["alg"] == _capi.SPMV_SLICED  # AUTO: x (40 MB) >> L2, random columns
     sp.multiply(info, a, x1, y1)
     sp.multiply(info, a, x2, y2)
     sp.multiply(info, a, 0.5 * x1 - 2.0 * x2, y3)
-    sp.multiply(a, x1, y1v)
+    info_rb = sp.multiply_inspect(a, x1, y1v, alg=_capi.SPMV_ROWBLOCK)
+    sp.multiply(info_rb, a, x1, y1v)
     # (2) linearity, norm-wise: |y3 - (.5y1 - 2y2)| <= 4e-6 * (|.5 y1| + |2 y2|)
     lin = (y3 - (0.5 * y1 - 2.0 * y2)).abs()
     assert bool((lin <= 4e-6 * (0.5 * y1.abs() + 2.0 * y2.abs()) + 1e-30).all())
