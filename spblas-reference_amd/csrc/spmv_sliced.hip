@@ -7,18 +7,29 @@
 // The only memory on the CU that sustains random 4-byte accesses at the needed rate is LDS,
 // so multiply_inspect re-tiles A once on the device:
 //
-//   A' order   entries grouped by (column slice s, row bin b); slice = W consecutive columns
-//              (W*sizeof(T) <= 80 KiB of LDS), bin = H consecutive rows (H*sizeof(T) <= 80 KiB)
-//   s_val[i]   value,   s_col[i] 16-bit column inside the slice,  s_row[i] 16-bit row inside the bin
+//   A' order   entries grouped by (column slice s, wave-bin wb); slice = W consecutive columns
+//              (W*sizeof(T) <= 80 KiB of LDS), wave-bin = Hw consecutive rows owned by ONE
+//              wavefront of the reduce kernel (8 wave-bins * Hw * sizeof(T) <= 80 KiB)
+//   s_val[i]   value,  s_col[i] 16-bit column inside the slice,
+//   s_row[i]   15-bit row inside the wave-bin | bit 15 = "duplicate" flag (see below)
 //
 // and multiply() runs two streaming kernels (no global gathers, no global atomics):
 //   expand  one workgroup per slice: x slice -> LDS, then P[i] = s_val[i] * xs[s_col[i]] over the
-//           slice's contiguous range of A' (coalesced 4+2 byte reads, 4 byte writes)
-//   reduce  one workgroup per bin: zero H accumulators in LDS, walk the bin's S segments of P
-//           (one wavefront per segment), ds_add_f32 into LDS, write y = alpha*acc + beta*y
+//           slice's contiguous range of A' (16-byte lane accesses)
+//   reduce  one wavefront per wave-bin: Hw accumulators in LDS, walk the bin's S runs of P;
+//           y = alpha*acc + beta*y
 // HBM traffic per nonzero: 6 B + 4 B (expand) + 6 B (reduce) = 16 B vs 8 B algorithmic, all of it
-// coalesced streams.  LDS float atomics make the summation order (not the set of addends)
-// vary between runs: results are reproducible to rounding, not bitwise (documented in DESIGN.md).
+// coalesced streams.
+//
+// Why wave-owned bins: ds_add_f32 retires ~0.33 lanes/clk/CU on gfx950 (tools/ubench/lds_atomic:
+// 1e8 LDS float atomics = 509 us, 12x slower than integer atomics or a plain read-add-write),
+// so accumulation must be a plain LDS read-modify-write.  That is race free iff (a) no other
+// wavefront touches the rows -- each wave owns its bin -- and (b) the <= 64 entries one wave
+// instruction handles hit distinct rows.  (b) is arranged at inspect time: within each
+// 64-entry chunk of a run all but one entry of a repeated row carry the duplicate flag and are
+// applied afterwards with the (slow, rare: ~1 % of entries) LDS atomic.
+// The order of additions into a row is fixed by the plan, so results are run-to-run
+// reproducible for a given plan (plans built twice may order entries differently).
 #include "common.hpp"
 #include "plan.hpp"
 #include "scan.hpp"
@@ -27,7 +38,14 @@
 
 namespace spb {
 
-static constexpr int PB_THREADS = 1024;
+static int env_int(const char* name, int dflt) {
+  const char* v = std::getenv(name);
+  return v && *v ? std::atoi(v) : dflt;
+}
+
+static constexpr int PB_THREADS = 1024;         // expand: 16 waves share one x slice
+static constexpr int PB_RTHREADS = 512;         // reduce: 8 waves, one wave-bin each
+static constexpr int PB_RWAVES = PB_RTHREADS / 64;
 static constexpr int PB_LDS_BYTES = 80 * 1024;  // two workgroups per CU (160 KiB LDS)
 
 // ---- inspect --------------------------------------------------------------------------
@@ -103,6 +121,39 @@ __global__ __launch_bounds__(256) void pb_update_values_kernel(int64_t nnz, cons
 
 // ---- execute ---------------------------------------------------------------------------
 template <typename T>
+struct pack4;
+template <>
+struct pack4<float> {
+  static __device__ __forceinline__ void load(const float* p, float (&o)[4]) {
+    const f32x4 v = stream_load(reinterpret_cast<const f32x4*>(p));
+    o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+  }
+  static __device__ __forceinline__ void store(float* p, const float (&o)[4]) {
+    f32x4 v;
+    v.x = o[0]; v.y = o[1]; v.z = o[2]; v.w = o[3];
+    __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
+  }
+};
+template <>
+struct pack4<double> {
+  static __device__ __forceinline__ void load(const double* p, double (&o)[4]) {
+    const f64x2 a = stream_load(reinterpret_cast<const f64x2*>(p));
+    const f64x2 b = stream_load(reinterpret_cast<const f64x2*>(p) + 1);
+    o[0] = a.x; o[1] = a.y; o[2] = b.x; o[3] = b.y;
+  }
+  static __device__ __forceinline__ void store(double* p, const double (&o)[4]) {
+    f64x2 a, b;
+    a.x = o[0]; a.y = o[1]; b.x = o[2]; b.y = o[3];
+    __builtin_nontemporal_store(a, reinterpret_cast<f64x2*>(p));
+    __builtin_nontemporal_store(b, reinterpret_cast<f64x2*>(p) + 1);
+  }
+};
+
+typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+
+// expand: P[i] = s_val[i] * x[slice_base + s_col[i]] over the slice's contiguous range of A'.
+// The x slice lives in LDS; A' and P are touched exactly once with 16-byte lane accesses.
+template <typename T>
 __global__ __launch_bounds__(PB_THREADS) void pb_expand_kernel(int64_t n, int W, int NB, const int32_t* __restrict__ seg,
                                                                const T* __restrict__ s_val,
                                                                const uint16_t* __restrict__ s_col,
@@ -110,84 +161,175 @@ __global__ __launch_bounds__(PB_THREADS) void pb_expand_kernel(int64_t n, int W,
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   T* xs = reinterpret_cast<T*>(smem);
   const int s = blockIdx.x;
+  const int tid = threadIdx.x;
   const int64_t c0 = (int64_t) s * W;
   const int cw = (int) ((n - c0) < W ? (n - c0) : W);
-  for (int i = threadIdx.x; i < cw; i += PB_THREADS)
+  for (int i = tid; i < cw; i += PB_THREADS)
     xs[i] = x[c0 + i];
   __syncthreads();
   const int a0 = seg[(int64_t) s * NB], a1 = seg[(int64_t) (s + 1) * NB];
-  // flat streaming pass over the slice's contiguous range of A'
-  int i = a0 + threadIdx.x;
-  for (; i + 3 * PB_THREADS < a1; i += 4 * PB_THREADS) {
-    const T v0 = stream_load(s_val + i), v1 = stream_load(s_val + i + PB_THREADS),
-            v2 = stream_load(s_val + i + 2 * PB_THREADS), v3 = stream_load(s_val + i + 3 * PB_THREADS);
-    const int k0 = stream_load(s_col + i), k1 = stream_load(s_col + i + PB_THREADS),
-              k2 = stream_load(s_col + i + 2 * PB_THREADS), k3 = stream_load(s_col + i + 3 * PB_THREADS);
-    __builtin_nontemporal_store(v0 * xs[k0], P + i);
-    __builtin_nontemporal_store(v1 * xs[k1], P + i + PB_THREADS);
-    __builtin_nontemporal_store(v2 * xs[k2], P + i + 2 * PB_THREADS);
-    __builtin_nontemporal_store(v3 * xs[k3], P + i + 3 * PB_THREADS);
+  int body0 = (a0 + 3) & ~3;
+  if (body0 > a1)
+    body0 = a1;
+  const int body1 = body0 + ((a1 - body0) & ~3);
+  // unaligned head and tail (< 4 entries each)
+  if (tid < body0 - a0)
+    P[a0 + tid] = s_val[a0 + tid] * xs[s_col[a0 + tid]];
+  if (tid < a1 - body1)
+    P[body1 + tid] = s_val[body1 + tid] * xs[s_col[body1 + tid]];
+  // aligned body: 4 entries (16 B of values, 8 B of columns) per lane per step, 2 steps in flight
+  int i = body0 + 4 * tid;
+  for (; i + 4 * PB_THREADS < body1; i += 8 * PB_THREADS) {
+    T va[4], vb[4], pa[4], pb[4];
+    pack4<T>::load(s_val + i, va);
+    pack4<T>::load(s_val + i + 4 * PB_THREADS, vb);
+    const u16x4 ca = stream_load(reinterpret_cast<const u16x4*>(s_col + i));
+    const u16x4 cb = stream_load(reinterpret_cast<const u16x4*>(s_col + i + 4 * PB_THREADS));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      pa[j] = va[j] * xs[ca[j]];
+      pb[j] = vb[j] * xs[cb[j]];
+    }
+    pack4<T>::store(P + i, pa);
+    pack4<T>::store(P + i + 4 * PB_THREADS, pb);
   }
-  for (; i < a1; i += PB_THREADS)
-    __builtin_nontemporal_store(stream_load(s_val + i) * xs[stream_load(s_col + i)], P + i);
+  for (; i < body1; i += 4 * PB_THREADS) {
+    T va[4], pa[4];
+    pack4<T>::load(s_val + i, va);
+    const u16x4 ca = stream_load(reinterpret_cast<const u16x4*>(s_col + i));
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      pa[j] = va[j] * xs[ca[j]];
+    pack4<T>::store(P + i, pa);
+  }
+}
+
+// inspect: mark duplicates.  Same walk as the reduce kernel: wave-bin -> runs -> 64-entry chunks.
+// Inside a chunk every lane writes its lane id to tag[row] and reads it back; for a repeated
+// row exactly one lane reads its own id, the others get the duplicate flag (bit 15).
+__global__ __launch_bounds__(PB_RTHREADS) void pb_flag_dups_kernel(int Hw, int S, int64_t NBw,
+                                                                   const int2* __restrict__ segT,
+                                                                   uint16_t* __restrict__ s_row) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  unsigned char* tag = smem + (size_t) wave * Hw;
+  const int64_t wb = (int64_t) blockIdx.x * PB_RWAVES + wave;
+  if (wb >= NBw)
+    return;
+  const int2* mine = segT + wb * S;
+  for (int s = 0; s < S; ++s) {
+    const int2 d = mine[s];
+    for (int base = 0; base < d.y; base += 64) {
+      const int o = base + lane;
+      int row = 0;
+      const bool ok = o < d.y;
+      if (ok) {
+        row = s_row[d.x + o] & 0x7FFF;
+        tag[row] = (unsigned char) lane;
+      }
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the tag stores have landed
+      if (ok && tag[row] != (unsigned char) lane)
+        s_row[d.x + o] = (uint16_t) (row | 0x8000);
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
+// reduce: one wavefront per wave-bin (8 per workgroup).  The wave fetches 64 run descriptors
+// with one coalesced load, then handles runs four at a time: all product/row loads of the
+// four runs are issued before the first LDS read-modify-write consumes them.
+template <typename T>
+__device__ __forceinline__ void pb_apply(T* acc, T p, int r, bool ok) {
+  const int row = r & 0x7FFF;
+  const bool dup = ok && (r & 0x8000);
+  if (ok && !dup)
+    acc[row] += p;  // plain LDS read-add-write: rows are distinct within the instruction
+  if (__builtin_amdgcn_ballot_w64(dup) != 0) {
+    if (dup)
+      unsafeAtomicAdd(acc + row, p);
+  }
 }
 
 template <typename T>
-__global__ __launch_bounds__(PB_THREADS) void pb_reduce_kernel(int64_t m, int H, int S, const int2* __restrict__ segT,
-                                                               const T* __restrict__ P,
-                                                               const uint16_t* __restrict__ s_row,
-                                                               T* __restrict__ y, T alpha, T beta) {
+__global__ __launch_bounds__(PB_RTHREADS) void pb_reduce_kernel(int64_t m, int Hw, int S, int64_t NBw,
+                                                                const int2* __restrict__ segT,
+                                                                const T* __restrict__ P,
+                                                                const uint16_t* __restrict__ s_row,
+                                                                T* __restrict__ y, T alpha, T beta) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  T* acc = reinterpret_cast<T*>(smem);
-  const int b = blockIdx.x;
-  const int64_t r0 = (int64_t) b * H;
-  const int rh = (int) ((m - r0) < H ? (m - r0) : H);
-  for (int i = threadIdx.x; i < rh; i += PB_THREADS)
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  T* acc = reinterpret_cast<T*>(smem) + (size_t) wave * Hw;
+  const int64_t wb = (int64_t) blockIdx.x * PB_RWAVES + wave;
+  if (wb >= NBw)
+    return;
+  const int64_t r0 = wb * Hw;
+  const int rh = (int) ((m - r0) < Hw ? (m - r0) : Hw);
+  for (int i = lane; i < rh; i += 64)
     acc[i] = T(0);
-  __syncthreads();
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int2* mine = segT + (int64_t) b * S;
-  for (int s = wave; s < S; s += PB_THREADS / 64) {
-    const int2 sg = mine[s];
-    const int a1 = sg.x + sg.y;
-    int i = sg.x + lane;
-    for (; i + 192 < a1; i += 256) {
-      const T p0 = stream_load(P + i), p1 = stream_load(P + i + 64), p2 = stream_load(P + i + 128),
-              p3 = stream_load(P + i + 192);
-      const int q0 = stream_load(s_row + i), q1 = stream_load(s_row + i + 64), q2 = stream_load(s_row + i + 128),
-                q3 = stream_load(s_row + i + 192);
-      unsafeAtomicAdd(acc + q0, p0);
-      unsafeAtomicAdd(acc + q1, p1);
-      unsafeAtomicAdd(acc + q2, p2);
-      unsafeAtomicAdd(acc + q3, p3);
+  const int2* mine = segT + wb * S;
+  constexpr int B = 8;  // runs in flight per wave: B * 6 bytes * 64 lanes * 16 waves/CU ~ 48 KiB
+  int2 dnext = make_int2(0, 0);
+  if (lane < S)
+    dnext = mine[lane];
+  for (int sb = 0; sb < S; sb += 64) {
+    const int2 d = dnext;
+    if (sb + 64 + lane < S)  // prefetch the next 64 descriptors behind this batch's work
+      dnext = mine[sb + 64 + lane];
+    const int cnt = (S - sb) < 64 ? (S - sb) : 64;
+    for (int j0 = 0; j0 < cnt; j0 += B) {
+      T p[B];
+      int r[B], st[B], ln[B];
+#pragma unroll
+      for (int u = 0; u < B; ++u) {
+        st[u] = __shfl(d.x, j0 + u);
+        ln[u] = (j0 + u < cnt) ? __shfl(d.y, j0 + u) : 0;
+        p[u] = T(0);
+        r[u] = 0;
+        if (lane < ln[u]) {
+          p[u] = stream_load(P + st[u] + lane);
+          r[u] = stream_load(s_row + st[u] + lane);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < B; ++u) {
+        pb_apply<T>(acc, p[u], r[u], lane < ln[u]);
+        for (int base = 64; base < ln[u]; base += 64) {  // runs longer than one wave
+          const int o = base + lane;
+          const bool ok = o < ln[u];
+          T pp = T(0);
+          int rr = 0;
+          if (ok) {
+            pp = stream_load(P + st[u] + o);
+            rr = stream_load(s_row + st[u] + o);
+          }
+          pb_apply<T>(acc, pp, rr, ok);
+        }
+      }
     }
-    for (; i < a1; i += 64)
-      unsafeAtomicAdd(acc + stream_load(s_row + i), stream_load(P + i));
   }
-  __syncthreads();
-  for (int i = threadIdx.x; i < rh; i += PB_THREADS) {
+  for (int i = lane; i < rh; i += 64) {
     const T v = alpha * acc[i];
     y[r0 + i] = beta == T(0) ? v : v + beta * y[r0 + i];
   }
 }
 
 // ---- host -------------------------------------------------------------------------------
-static int env_int(const char* name, int dflt) {
-  const char* v = std::getenv(name);
-  return v && *v ? std::atoi(v) : dflt;
-}
 
 // number of pieces: enough that one piece fits the LDS budget; for big problems a multiple
 // of 512 (2 workgroups x 256 CUs) so the single wave of workgroups fills the chip evenly.
-static void pick_tiling(int64_t extent, int max_elems, int* pieces, int* width) {
+static void pick_tiling(int64_t extent, int max_elems, int round_to, int* pieces, int* width) {
   int64_t p = cdiv(extent, max_elems);
   if (p < 1)
     p = 1;
-  if (p > 256)
-    p = cdiv(p, 512) * 512;
+  if (p > round_to / 2)
+    p = cdiv(p, round_to) * round_to;
   int64_t w = cdiv(extent, p);
-  if (w < 1)
-    w = 1;
+  w = (w + 3) & ~(int64_t) 3;
+  if (w > max_elems)
+    w = max_elems & ~3;
+  if (w < 4)
+    w = 4;
   p = cdiv(extent, w);
   if (p < 1)
     p = 1;
@@ -202,14 +344,15 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
   const int64_t m = pl->m, n = pl->n, nnz = pl->nnz;
   if (nnz > INT32_MAX - 8)
     return SPBLAS_GFX950_STATUS_NOT_SUPPORTED;
-  int max_elems = PB_LDS_BYTES / (int) sizeof(T);
-  if (max_elems > 65536)
-    max_elems = 65536;  // 16-bit local indices
+  int max_cols = PB_LDS_BYTES / (int) sizeof(T);
+  if (max_cols > 65536)
+    max_cols = 65536;  // 16-bit local column
+  int max_rows = PB_LDS_BYTES / PB_RWAVES / (int) sizeof(T);  // per wave-bin; < 32768 (15-bit row + flag)
   int S, W, NB, H;
   const int w_env = env_int("SPBLAS_GFX950_SLICE_COLS", 0);  // test hooks: force small tiles
   const int h_env = env_int("SPBLAS_GFX950_SLICE_ROWS", 0);
-  pick_tiling(n, w_env > 0 && w_env < max_elems ? w_env : max_elems, &S, &W);
-  pick_tiling(m, h_env > 0 && h_env < max_elems ? h_env : max_elems, &NB, &H);
+  pick_tiling(n, w_env > 0 && w_env < max_cols ? w_env : max_cols, 512, &S, &W);
+  pick_tiling(m, h_env > 0 && h_env < max_rows ? h_env : max_rows, 512 * PB_RWAVES, &NB, &H);
   const int64_t nseg = (int64_t) S * NB;
   if (nseg > (int64_t) 64 << 20)
     return SPBLAS_GFX950_STATUS_NOT_SUPPORTED;
@@ -268,6 +411,8 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
                      reinterpret_cast<uint16_t*>(pl->s_colind), pl->s_lrow, reinterpret_cast<int32_t*>(pl->s_perm));
   hipLaunchKernelGGL(pb_transpose_seg_kernel, dim3((unsigned) cdiv(nseg, 256)), dim3(256), 0, s, S, NB, seg,
                      static_cast<int2*>(pl->s_segT));
+  hipLaunchKernelGGL(pb_flag_dups_kernel, dim3((unsigned) cdiv(NB, PB_RWAVES)), dim3(PB_RTHREADS),
+                     (size_t) PB_RWAVES * H, s, H, S, (int64_t) NB, static_cast<const int2*>(pl->s_segT), pl->s_lrow);
   SPB_HIP(hipGetLastError());
   SPB_HIP(hipStreamSynchronize(s));
   dev_free(cursor, s);
@@ -315,10 +460,10 @@ static int sliced_exec_typed(spblas_gfx950_handle_t h, const spblas_gfx950_plan_
                      (size_t) pl->slice_cols * sizeof(T), s, pl->n, pl->slice_cols, (int) pl->n_rblk, seg,
                      static_cast<const T*>(pl->s_values), reinterpret_cast<const uint16_t*>(pl->s_colind),
                      static_cast<const T*>(x), static_cast<T*>(pl->s_products));
-  hipLaunchKernelGGL((pb_reduce_kernel<T>), dim3((unsigned) pl->n_rblk), dim3(PB_THREADS),
-                     (size_t) pl->rows_per_blk * sizeof(T), s, pl->m, pl->rows_per_blk, pl->n_slices,
-                     static_cast<const int2*>(pl->s_segT), static_cast<const T*>(pl->s_products), pl->s_lrow,
-                     static_cast<T*>(y), alpha, beta);
+  hipLaunchKernelGGL((pb_reduce_kernel<T>), dim3((unsigned) cdiv(pl->n_rblk, PB_RWAVES)), dim3(PB_RTHREADS),
+                     (size_t) PB_RWAVES * pl->rows_per_blk * sizeof(T), s, pl->m, pl->rows_per_blk, pl->n_slices,
+                     pl->n_rblk, static_cast<const int2*>(pl->s_segT), static_cast<const T*>(pl->s_products),
+                     pl->s_lrow, static_cast<T*>(y), alpha, beta);
   SPB_HIP(hipGetLastError());
   return SPBLAS_GFX950_STATUS_SUCCESS;
 }

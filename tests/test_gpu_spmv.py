@@ -41,7 +41,7 @@ def check(values, rowptr, colind, shape, x, y, scale=1.0, what="", ref_cmp=True)
     absrow = absrow * abs(scale)
     lens = np.diff(rowptr)
     util.assert_parity(y, y_ref, absrow, values.dtype, row_len=lens, what=what + " vs oracle")
-    util.assert_parity(y, exact * scale, absrow, values.dtype, what=what + " vs float64")
+    util.assert_parity(y, exact * scale, absrow, values.dtype, row_len=lens, what=what + " vs float64")
     if ref_cmp:  # the reference's own comparator (test/gtest/util.hpp:7-23); it is relative to the
         util.expect_eq_ref(y_ref, y)  # RESULT, so it only applies to the sign-definite data its tests use
 
