@@ -198,8 +198,13 @@ def main():
                        "parallelism": f"row-sharded x{world} + RCCL all-gather(y)" if world > 1 else "single GPU",
                        "alg": args.alg, "plan": plan_info, "inspect_ms_untimed": inspect_ms},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": read_pmc_traffic("spmv_cfg2"),
-                         "kernel": "spmv_rowblock_kernel<float,int,2048>" if plan_info.get("alg") == 2 else "spmv kernel",
+                         "frac": achieved / HBM_PEAK_GBS,
+                         # PMC traffic was measured for the default cfg2 / 1 GPU / sliced plan only
+                         "traffic": read_pmc_traffic("spmv_cfg2") if (world == 1 and plan_info.get("alg") == 3
+                                                                     and not poisson and args.rows is None) else None,
+                         "kernel": {3: "pb_expand_kernel<float> + pb_reduce_kernel<float> (one SpMV = this launch pair)",
+                                    2: "spmv_rowblock_kernel<float,int,2048>", 1: "spmv_vector_kernel<float,int,LPR>"
+                                    }.get(plan_info.get("alg"), "spmv_vector_kernel<float,int,LPR>"),
                          "algorithmic_bytes_per_launch": local_bytes, "kernel_avg_ms": kern_avg_ms,
                          "kernel_min_ms": kern_ms[0], "kernel_median_ms": kern_ms[len(kern_ms) // 2],
                          "algorithmic_gbs_whole_step": spmv_bytes(m, n, nnz, tsize) / (elapsed / args.steps) / 1e9},

@@ -1,0 +1,135 @@
+"""Secondary BASELINE configs on one GPU (not the headline bench line):
+  --workload spmm      cfg3: fp32 CSR x dense, A 2M x 2M 32 nnz/row, B 2M x 128 row-major
+  --workload spgemm    cfg5: fp32 CSR x CSR, 1M x 1M, 16 nnz/row, multiply_compute + multiply_fill
+  --workload spmv_rmat cfg4 (single-GPU leg): fp64 CSR SpMV, R-MAT scale 24, edge factor 16
+Same JSON contract as bench.py; `value` is GFLOP/s of the timed operation.  The CPU baseline
+(oracle, 1 core) is timed on a bounded row sample and scaled by nnz (stated in `sample`)."""
+import json
+import time
+
+import numpy as np
+import torch
+
+HBM_PEAK_GBS = 8000.0
+
+
+def _time_steps(fn, warmup, steps):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    t0 = time.perf_counter()
+    for a, b in ev:
+        a.record()
+        fn()
+        b.record()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ms = sorted(a.elapsed_time(b) for a, b in ev)
+    return elapsed, ms
+
+
+def _emit(args, metric, flops, alg_bytes, elapsed, ms, workload, extra, cpu):
+    avg = sum(ms) / len(ms)
+    out = {"metric": metric, "value": flops / (elapsed / args.steps) / 1e9, "unit": "GFLOP/s", "n_gpus": 1,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": extra.pop("dtype"),
+           "data": "synthetic", "config": {"workload": workload, **extra},
+           "roofline": {"bound": "hbm", "achieved": alg_bytes / (avg * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": alg_bytes / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                        "algorithmic_bytes_per_launch": alg_bytes, "kernel_avg_ms": avg, "kernel_min_ms": ms[0]},
+           "cpu_baseline": cpu}
+    print(json.dumps(out))
+
+
+def run_extra(args, device):
+    import spblas_reference_amd as sp
+    from oracle import oracle
+    from spblas_reference_amd import generate
+
+    if args.workload == "spmm":
+        m = args.rows or 2_000_000
+        ncols = 128
+        values, rowptr, colind, shape, nnz = generate.uniform_csr_device(m, m, 32, seed=0, device=device)
+        a = sp.csr_view(values, rowptr, colind, shape, nnz)
+        g = torch.Generator(device=device).manual_seed(3)
+        B = torch.rand((m, ncols), device=device, generator=g)
+        C = torch.empty((m, ncols), device=device)
+        info = sp.multiply_inspect(a, B, C)
+        elapsed, ms = _time_steps(lambda: sp.multiply(info, a, B, C), args.warmup, args.steps)
+        alg_bytes = nnz * 8 + (m + 1) * 4 + 2 * m * ncols * 4
+        cpu = None
+        if not args.no_cpu_baseline:
+            rows = 20_000  # bounded sample: first 20k rows (640k nnz x 128 columns)
+            rp = rowptr[:rows + 1].cpu().numpy()
+            ci, v = colind[:rp[-1]].cpu().numpy(), values[:rp[-1]].cpu().numpy()
+            Bh = B.cpu().numpy()
+            t0 = time.perf_counter()
+            oracle.spmm((rows, m), rp, ci, v, Bh)
+            dt = time.perf_counter() - t0
+            cpu = {"value": 2.0 * rp[-1] * ncols / dt / 1e9, "unit": "GFLOP/s", "cores": 1, "kind": "port",
+                   "sample": f"first {rows} rows ({int(rp[-1])} nnz x {ncols} columns) of the same A and B, 1 run of oracle_spmm"}
+        _emit(args, "csr_spmm_gflops", 2.0 * nnz * ncols, alg_bytes, elapsed, ms,
+              f"cfg3: fp32 CSR x dense SpMM, A {m}x{m} 32 nnz/row uniform random, B {m}x{ncols} row-major",
+              {"dtype": "f32", "rows": m, "nnz": nnz, "ncols": ncols, "kernel": "spmm_rowgroup_kernel<float,int,4>"}, cpu)
+        return
+
+    if args.workload == "spgemm":
+        m = args.rows or 1_000_000
+        av, ar, ac, ash, annz = generate.uniform_csr_device(m, m, 16, seed=0, device=device)
+        bv, br, bc, bsh, bnnz = generate.uniform_csr_device(m, m, 16, seed=1, device=device)
+        a, b = sp.csr_view(av, ar, ac, ash, annz), sp.csr_view(bv, br, bc, bsh, bnnz)
+        c_rp = torch.zeros(m + 1, dtype=torch.int32, device=device)
+        c = sp.csr_view(None, c_rp, None, (m, m), 0)
+        state = sp.spgemm_state_t()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        sp.multiply_compute(state, a, b, c)
+        torch.cuda.synchronize()
+        compute_ms = (time.perf_counter() - t0) * 1e3
+        cn = state.result_nnz()
+        c.update(torch.empty(cn, device=device), c_rp, torch.empty(cn, dtype=torch.int32, device=device), (m, m), cn)
+        products = int((br.long()[ac.long() + 1] - br.long()[ac.long()]).sum().item())
+        elapsed, ms = _time_steps(lambda: sp.multiply_fill(state, a, b, c), args.warmup, args.steps)
+        alg_bytes = 2 * (annz * 8 + (m + 1) * 4) + cn * 8 + (m + 1) * 4
+        cpu = None
+        if not args.no_cpu_baseline:
+            rows = 20_000
+            rp = ar[:rows + 1].cpu().numpy()
+            sub = ((rows, m), rp, ac[:rp[-1]].cpu().numpy(), av[:rp[-1]].cpu().numpy())
+            bh = ((m, m), br.cpu().numpy(), bc.cpu().numpy(), bv.cpu().numpy())
+            t0 = time.perf_counter()
+            n_ref, _ = oracle.spgemm_symbolic(sub[0], sub[1], sub[2], bh[0], bh[1], bh[2])
+            t1 = time.perf_counter()
+            oracle.spgemm_numeric(sub[0], sub[1], sub[2], sub[3], bh[0], bh[1], bh[2], bh[3], capacity=n_ref)
+            t2 = time.perf_counter()
+            cpu = {"value": 2.0 * (products * rows / m) / (t2 - t1) / 1e9, "unit": "GFLOP/s", "cores": 1, "kind": "port",
+                   "sample": f"first {rows} rows of A x full B: symbolic {t1 - t0:.3f} s, numeric {t2 - t1:.3f} s (numeric timed)"}
+        _emit(args, "csr_spgemm_fill_gflops", 2.0 * products, alg_bytes, elapsed, ms,
+              f"cfg5: fp32 CSR x CSR SpGEMM {m}x{m}, 16 nnz/row uniform random; timed step = multiply_fill (numeric)",
+              {"dtype": "f32", "rows": m, "products": products, "nnz_c": cn, "multiply_compute_ms_untimed": compute_ms,
+               "kernel": "spg_hash_kernel<float,10,64,true>"}, cpu)
+        return
+
+    # spmv_rmat: cfg4 single-GPU leg
+    scale = 24 if args.rows is None else int(np.log2(args.rows))
+    values, rowptr, colind, shape, nnz = generate.rmat_csr_device(scale, 16, dtype=torch.float64, seed=0, device=device)
+    m = shape[0]
+    a = sp.csr_view(values, rowptr, colind, shape, nnz)
+    g = torch.Generator(device=device).manual_seed(5)
+    x = torch.rand(m, dtype=torch.float64, device=device, generator=g)
+    y = torch.empty(m, dtype=torch.float64, device=device)
+    info = sp.multiply_inspect(a, x, y)
+    elapsed, ms = _time_steps(lambda: sp.multiply(info, a, x, y), args.warmup, args.steps)
+    alg_bytes = nnz * 12 + (m + 1) * 4 + 2 * m * 8
+    cpu = None
+    if not args.no_cpu_baseline:
+        rp, ci, v, xh = rowptr.cpu().numpy(), colind.cpu().numpy(), values.cpu().numpy(), x.cpu().numpy()
+        t0 = time.perf_counter()
+        oracle.spmv(shape, rp, ci, v, xh)
+        dt = time.perf_counter() - t0
+        cpu = {"value": 2.0 * nnz / dt / 1e9, "unit": "GFLOP/s", "cores": 1, "kind": "port",
+               "sample": f"full workload ({nnz} nnz), 1 run of oracle_spmv_f64"}
+    _emit(args, "csr_spmv_gflops", 2.0 * nnz, alg_bytes, elapsed, ms,
+          f"cfg4 (1-GPU leg): fp64 CSR SpMV, R-MAT scale {scale}, edge factor 16, duplicates kept, nnz={nnz}",
+          {"dtype": "f64", "rows": m, "nnz": nnz, "plan": info.state_.info()}, cpu)

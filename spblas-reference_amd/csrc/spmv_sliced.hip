@@ -44,7 +44,7 @@ static int env_int(const char* name, int dflt) {
 }
 
 static constexpr int PB_THREADS = 1024;         // expand: 16 waves share one x slice
-static constexpr int PB_RTHREADS = 512;         // reduce: 8 waves, one wave-bin each
+static constexpr int PB_RTHREADS = 512;         // reduce: 8 waves, one wave-bin each (4 or 16 measured 2.3x slower)
 static constexpr int PB_RWAVES = PB_RTHREADS / 64;
 static constexpr int PB_LDS_BYTES = 80 * 1024;  // two workgroups per CU (160 KiB LDS)
 

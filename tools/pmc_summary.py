@@ -65,23 +65,35 @@ for title, table in (("bench", bench), ("calibration (tools/calib_copy.py)", cal
             lines.append(f"    * {c}: {v:,.0f}")
     lines.append("")
 
-# calibration factors: the clone kernel reads 1 GiB and writes 1 GiB
-copy = next((cs for k, cs in calib.items() if "elementwise" in k.lower() or "copy" in k.lower()), None)
-fetch_unit = write_unit = None
-if copy and "FETCH_SIZE" in copy and "WRITE_SIZE" in copy:
-    fetch_unit = (1 << 30) / copy["FETCH_SIZE"]   # true bytes per FETCH_SIZE unit on a wide stream
-    write_unit = (1 << 30) / copy["WRITE_SIZE"]
-    lines += [f"Calibration: 1 GiB copy -> FETCH_SIZE={copy['FETCH_SIZE']:,.0f}, WRITE_SIZE={copy['WRITE_SIZE']:,.0f} "
-              f"=> {fetch_unit:.1f} B per FETCH unit, {write_unit:.1f} B per WRITE unit on coalesced streams.", ""]
+# HBM-side bytes per launch from the request-size counters (exact, no unit guessing):
+#   read  = 32*RDREQ_32B + 64*RDREQ_64B + 128*RDREQ_128B
+#   write = 64*WRREQ_64B + 32*(WRREQ - WRREQ_64B)
+# MI355X_MICROARCH.md: FETCH_SIZE (KiB) tallies 128-B requests at 64 B, i.e. reads 1/2 of a wide
+# stream -- the table above shows FETCH_SIZE*1024 == 64*RDREQ; WRITE_SIZE*1024 == the write bytes.
+def req_bytes(cs):
+    need = ("TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_RDREQ_128B_sum", "TCC_EA0_WRREQ_sum",
+            "TCC_EA0_WRREQ_64B_sum")
+    if not all(k in cs for k in need):
+        return None
+    rd = 32 * cs[need[0]] + 64 * cs[need[1]] + 128 * cs[need[2]]
+    wr = 64 * cs[need[4]] + 32 * (cs[need[3]] - cs[need[4]])
+    return {"read_bytes": rd, "write_bytes": wr, "hbm_bytes": rd + wr,
+            "fetch_size_kib": cs.get("FETCH_SIZE"), "write_size_kib": cs.get("WRITE_SIZE"),
+            "l2_hit_rate": cs["TCC_HIT_sum"] / max(1.0, cs["TCC_HIT_sum"] + cs["TCC_MISS_sum"]) if "TCC_HIT_sum" in cs else None}
+
+
 for k, cs in bench.items():
-    if "spmv" in k or "spmm" in k or "spg" in k:
-        if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs and fetch_unit:
-            traffic[k] = {"fetch_bytes": cs["FETCH_SIZE"] * fetch_unit, "write_bytes": cs["WRITE_SIZE"] * write_unit,
-                          "hbm_bytes": cs["FETCH_SIZE"] * fetch_unit + cs["WRITE_SIZE"] * write_unit}
-lines += ["## derived HBM-side traffic per launch (calibrated)", "", "```", json.dumps(traffic, indent=1), "```"]
+    if "spb::" in k:
+        t = req_bytes(cs)
+        if t:
+            traffic[k.replace("void ", "").strip()] = t
+lines += ["## derived HBM-side traffic per launch (request-size counters)", "", "```", json.dumps(traffic, indent=1), "```"]
+cal = {k: req_bytes(cs) for k, cs in calib.items() if req_bytes(cs) and req_bytes(cs)["hbm_bytes"] > 1e8}
+lines += ["", "## calibration kernels (known byte counts: 1 GiB clone = 1.07e9 B read + 1.07e9 B written; "
+          "gather = 8e8 B index read + 4e8 B written + gathered lines)", "", "```", json.dumps(cal, indent=1), "```"]
 os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
 with open(os.path.join(ROOT, "profiles", f"{tag}_summary.md"), "w") as f:
     f.write("\n".join(lines) + "\n")
-with open(os.path.join(ROOT, "gpurun_out", f"{tag}_traffic.json"), "w") as f:
+with open(os.path.join(ROOT, "profiles", f"{tag}_traffic.json"), "w") as f:
     json.dump(traffic, f, indent=1)
-print("\n".join(lines))
+print("\n".join(lines[-40:]))
