@@ -59,5 +59,28 @@ def build(force=False, verbose=False):
     return LIBPATH
 
 
+CPP_TEST_SRC = os.path.join(_ROOT, "tests", "cpp", "device_tests.cpp")
+CPP_TEST_BIN = os.path.join(_ROOT, "tests", "cpp", "device_tests")
+
+
+def build_cpp_tests(force=False):
+    """C++20 host program over the standalone API mirror (include/spblas_gfx950/spblas.hpp),
+    compiled by g++ (the reference's host compiler class) and linked to the C-ABI library."""
+    deps = [CPP_TEST_SRC, os.path.join(_ROOT, "include", "spblas_gfx950", "spblas.hpp"),
+            os.path.join(_ROOT, "include", "spblas", "vendor", "gfx950", "detail", "backend_calls.hpp"), LIBPATH]
+    if not force and os.path.exists(CPP_TEST_BIN) and os.path.getmtime(CPP_TEST_BIN) >= max(map(os.path.getmtime, deps)):
+        return CPP_TEST_BIN
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    cmd = ["g++", "-std=c++20", "-O1", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(_ROOT, "include"),
+           "-I", os.path.join(rocm, "include"), CPP_TEST_SRC, "-L", LIBDIR, "-lspblas_gfx950",
+           "-L", os.path.join(rocm, "lib"), "-lamdhip64", "-Wl,-rpath,$ORIGIN/../../spblas-reference_amd/lib",
+           "-Wl,-rpath," + os.path.join(rocm, "lib"), "-o", CPP_TEST_BIN]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"g++ failed on device_tests.cpp:\n{r.stderr}")
+    return CPP_TEST_BIN
+
+
 if __name__ == "__main__":
     print(build(force=True, verbose=True))
+    print(build_cpp_tests(force=True))

@@ -1,0 +1,322 @@
+// C++ device tests of the gfx950 backend through the standalone API mirror
+// (include/spblas_gfx950/spblas.hpp).  The cases restate the reference's device tests:
+//   SpMV, SpMV_Ascaled, SpMV_BScaled   /root/reference/test/gtest/device/spmv_test.cpp:11-146
+//   SpGEMM, SpGEMM_AScaled             test/gtest/device/spgemm_test.cpp:12-97
+//   SpGEMMReuse                        test/gtest/device/spgemm_reuse_test.cpp:12-114
+//   SpMM (n in {1,8,32,64,512})        test/gtest/spmm_test.cpp:6-44 (no device SpMM test exists)
+// with the same shapes (util.hpp:27-29), the same inline comparator loops and the same
+// EXPECT_EQ_ tolerance (util.hpp:7-23).  No gtest in this image: plain checks, exit code = failures.
+// Build: see spblas-reference_amd/_build.py (g++ -std=c++20, links the C-ABI library + amdhip64).
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <limits>
+#include <map>
+#include <random>
+#include <set>
+#include <tuple>
+#include <vector>
+
+#include <hip/hip_runtime_api.h>
+
+#include <spblas_gfx950/spblas.hpp>
+
+using value_t = float;
+using index_t = spblas::index_t;
+using offset_t = spblas::offset_t;
+
+static int g_fail = 0, g_checks = 0;
+#define CHECK(cond)                                                                                 \
+  do {                                                                                              \
+    ++g_checks;                                                                                     \
+    if (!(cond)) {                                                                                  \
+      ++g_fail;                                                                                     \
+      std::printf("FAIL %s:%d: %s\n", __FILE__, __LINE__, #cond);                                    \
+    }                                                                                               \
+  } while (0)
+
+// EXPECT_EQ_ for floating point (test/gtest/util.hpp:7-23)
+static bool near_ref(value_t t, value_t u) {
+  const double eps = 64.0 * std::numeric_limits<value_t>::epsilon();
+  const double norm = std::min<double>(std::abs((double) t) + std::abs((double) u), std::numeric_limits<value_t>::max());
+  const double abs_error = std::max<double>(std::numeric_limits<value_t>::min(), eps * norm);
+  return std::abs((double) t - (double) u) <= abs_error;
+}
+
+static const std::vector<std::tuple<int, int, int>> dims = {{1000, 100, 100}, {100, 1000, 10000}, {40, 40, 1000}};
+
+// Same distribution as spblas::generate_csr (backend/generate.hpp:49-120): nnz distinct (i,j),
+// values U[0,100), column order shuffled inside each row.
+struct host_csr {
+  std::vector<value_t> values;
+  std::vector<offset_t> rowptr;
+  std::vector<index_t> colind;
+  spblas::index<index_t> shape;
+  offset_t nnz;
+};
+static host_csr generate_csr(int m, int n, int nnz, unsigned seed = 0) {
+  std::mt19937 g(seed);
+  std::uniform_int_distribution<int> dr(0, m - 1), dc(0, n - 1);
+  std::uniform_real_distribution<value_t> dv(0, 100);
+  std::set<std::pair<int, int>> entries;
+  while ((int) entries.size() < nnz)
+    entries.emplace(dr(g), dc(g));
+  host_csr a;
+  a.shape = spblas::index<index_t>(m, n);
+  a.nnz = nnz;
+  a.rowptr.assign(m + 1, 0);
+  for (auto& e : entries) {
+    a.rowptr[e.first + 1]++;
+    a.colind.push_back(e.second);
+    a.values.push_back(dv(g));
+  }
+  for (int i = 0; i < m; i++)
+    a.rowptr[i + 1] += a.rowptr[i];
+  for (int i = 0; i < m; i++)
+    std::shuffle(a.colind.begin() + a.rowptr[i], a.colind.begin() + a.rowptr[i + 1], g);
+  return a;
+}
+
+template <typename T>
+struct dvec {
+  T* p = nullptr;
+  size_t n = 0;
+  explicit dvec(size_t count) : n(count) {
+    if (hipMalloc((void**) &p, std::max<size_t>(count, 1) * sizeof(T)) != hipSuccess)
+      std::abort();
+  }
+  explicit dvec(const std::vector<T>& h) : dvec(h.size()) {
+    upload(h);
+  }
+  void upload(const std::vector<T>& h) {
+    if (!h.empty() && hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess)
+      std::abort();
+  }
+  std::vector<T> download() const {
+    std::vector<T> h(n);
+    if (n && hipMemcpy(h.data(), p, n * sizeof(T), hipMemcpyDeviceToHost) != hipSuccess)
+      std::abort();
+    return h;
+  }
+  ~dvec() {
+    (void) hipFree(p);
+  }
+  dvec(const dvec&) = delete;
+};
+
+struct device_csr {
+  dvec<value_t> values;
+  dvec<offset_t> rowptr;
+  dvec<index_t> colind;
+  spblas::csr_view<value_t, index_t, offset_t> view;
+  explicit device_csr(const host_csr& h)
+      : values(h.values), rowptr(h.rowptr), colind(h.colind), view(values.p, rowptr.p, colind.p, h.shape, h.nnz) {}
+};
+
+static void test_spmv() {
+  for (auto&& [m, n, nnz] : dims) {
+    for (int mode = 0; mode < 3; ++mode) {  // 0: plain, 1: scaled(alpha, a), 2: scaled(alpha, b)
+      for (int alpha : {-10, 1, 5}) {
+        if (mode == 0 && alpha != 1)
+          continue;
+        auto h = generate_csr(m, n, nnz);
+        device_csr a(h);
+        std::vector<value_t> b(n, 1), c(m, 0);
+        dvec<value_t> d_b(b), d_c(c);
+        std::span<value_t> b_span(d_b.p, n), c_span(d_c.p, m);
+        if (mode == 0)
+          spblas::multiply(a.view, b_span, c_span);  // device/spmv_test.cpp:34
+        else if (mode == 1)
+          spblas::multiply(spblas::scaled(alpha, a.view), b_span, c_span);  // :81
+        else
+          spblas::multiply(a.view, spblas::scaled(alpha, b_span), c_span);  // :128
+        c = d_c.download();
+        for (int i = 0; i < m; i++) {
+          value_t ref = 0;
+          for (auto p = h.rowptr[i]; p < h.rowptr[i + 1]; p++)
+            ref += (mode == 0   ? h.values[p] * b[h.colind[p]]
+                    : mode == 1 ? alpha * h.values[p] * b[h.colind[p]]
+                                : h.values[p] * alpha * b[h.colind[p]]);
+          CHECK(near_ref(ref, c[i]));
+        }
+        if (mode == 0) {  // inspect + execute gives the same answer (README.md:36-46 call shape)
+          auto info = spblas::multiply_inspect(a.view, b_span, c_span);
+          dvec<value_t> d_c2(std::vector<value_t>(m, -1));
+          std::span<value_t> c2_span(d_c2.p, m);
+          spblas::multiply(info, a.view, b_span, c2_span);
+          auto c2 = d_c2.download();
+          for (int i = 0; i < m; i++)
+            CHECK(near_ref(c[i], c2[i]));
+        }
+      }
+    }
+  }
+  // error behaviour: shape mismatch -> std::invalid_argument (multiply_impl.hpp:37-41)
+  auto h = generate_csr(40, 40, 1000);
+  device_csr a(h);
+  dvec<value_t> d_b(39), d_c(40);
+  bool threw = false;
+  try {
+    spblas::multiply(a.view, std::span<value_t>(d_b.p, 39), std::span<value_t>(d_c.p, 40));
+  } catch (const std::invalid_argument&) {
+    threw = true;
+  }
+  CHECK(threw);
+  threw = false;
+  try {  // conjugated views are rejected (vendor/rocsparse/detail/spmv_impl.hpp:29-33)
+    spblas::multiply(spblas::conjugated(a.view), std::span<value_t>(d_c.p, 40), std::span<value_t>(d_c.p, 40));
+  } catch (const std::runtime_error&) {
+    threw = true;
+  }
+  CHECK(threw);
+  // matrix_opt caches the plan; CSC operand = transposed (test/gtest/spmv_test.cpp:110-208)
+  spblas::matrix_opt a_opt(a.view);
+  dvec<value_t> d_x(std::vector<value_t>(40, 1)), d_y(40), d_yt(40);
+  std::span<value_t> xs(d_x.p, 40), ys(d_y.p, 40), yts(d_yt.p, 40);
+  auto info = spblas::multiply_inspect(a_opt, xs, ys);
+  spblas::multiply(a_opt, xs, ys);
+  spblas::multiply(spblas::transposed(a.view), xs, yts);
+  auto y = d_y.download(), yt = d_yt.download();
+  std::vector<value_t> ref(40, 0), reft(40, 0);
+  for (int i = 0; i < 40; i++)
+    for (auto p = h.rowptr[i]; p < h.rowptr[i + 1]; p++) {
+      ref[i] += h.values[p];
+      reft[h.colind[p]] += h.values[p];
+    }
+  for (int i = 0; i < 40; i++) {
+    CHECK(near_ref(ref[i], y[i]));
+    CHECK(near_ref(reft[i], yt[i]));
+  }
+}
+
+static void test_spmm() {
+  for (auto&& [m, k, nnz] : dims) {
+    for (int n : {1, 8, 32, 64, 512}) {
+      auto h = generate_csr(m, k, nnz);
+      device_csr a(h);
+      std::mt19937 g(0);
+      std::uniform_real_distribution<value_t> d(0, 100);
+      std::vector<value_t> b((size_t) k * n), c((size_t) m * n, 0);
+      for (auto& v : b)
+        v = d(g);
+      dvec<value_t> d_b(b), d_c(c);
+      spblas::mdspan_row_major<value_t, index_t> bm(d_b.p, k, n), cm(d_c.p, m, n);
+      auto info = spblas::multiply_inspect(a.view, bm, cm);  // examples/spmm_csr.cpp:45-46
+      spblas::multiply(info, a.view, bm, cm);
+      c = d_c.download();
+      std::vector<value_t> ref((size_t) m * n, 0);
+      for (int i = 0; i < m; i++)
+        for (auto p = h.rowptr[i]; p < h.rowptr[i + 1]; p++)
+          for (int j = 0; j < n; j++)
+            ref[(size_t) i * n + j] += h.values[p] * b[(size_t) h.colind[p] * n + j];
+      bool ok = true;
+      for (size_t i = 0; i < ref.size(); i++)
+        ok &= near_ref(ref[i], c[i]);
+      CHECK(ok);
+    }
+  }
+}
+
+// per-row comparison of test/gtest/device/spgemm_test.cpp:56-93
+static void check_spgemm(const host_csr& a, const host_csr& b, value_t alpha, int m, const std::vector<value_t>& cv,
+                         const std::vector<offset_t>& cr, const std::vector<index_t>& cc) {
+  for (int i = 0; i < m; i++) {
+    std::map<index_t, value_t> ref, acc;
+    for (auto p = a.rowptr[i]; p < a.rowptr[i + 1]; p++)
+      for (auto q = b.rowptr[a.colind[p]]; q < b.rowptr[a.colind[p] + 1]; q++)
+        ref[b.colind[q]] += alpha * a.values[p] * b.values[q];
+    for (auto p = cr[i]; p < cr[i + 1]; p++)
+      acc[cc[p]] += cv[p];
+    bool ok = ref.size() == acc.size();  // distinct-column count must match exactly (:93)
+    for (auto p = cr[i]; p + 1 < cr[i + 1]; p++)
+      ok &= cc[p] < cc[p + 1];  // ascending like spgemm_gustavsons.hpp:42
+    for (auto& [j, v] : acc)
+      ok &= ref.count(j) && near_ref(ref[j], v);
+    CHECK(ok);
+  }
+}
+
+static void test_spgemm() {
+  for (auto&& [m, k, nnz] : dims) {
+    for (int n : {m, k}) {
+      for (int variant = 0; variant < 3; ++variant) {  // 0: state API, 1: A scaled by 2, 2: operation_info_t API
+        auto ha = generate_csr(m, k, nnz), hb = generate_csr(k, n, nnz, 1);
+        device_csr a(ha), b(hb);
+        dvec<offset_t> d_c_rowptr(m + 1);
+        spblas::csr_view<value_t, index_t, offset_t> d_c(nullptr, d_c_rowptr.p, nullptr, {m, n}, 0);
+        const value_t alpha = variant == 1 ? 2.0f : 1.0f;
+        spblas::spgemm_state_t state;
+        spblas::operation_info_t info;
+        std::int64_t cn;
+        if (variant == 2) {
+          info = spblas::multiply_compute(a.view, b.view, d_c);  // examples/simple_spgemm.cpp:52
+          cn = info.result_nnz();
+        } else if (variant == 1) {
+          spblas::multiply_compute(state, spblas::scaled(alpha, a.view), b.view, d_c);
+          cn = state.result_nnz();
+        } else {
+          spblas::multiply_compute(state, a.view, b.view, d_c);  // device/spgemm_test.cpp:42-43
+          cn = state.result_nnz();
+        }
+        dvec<value_t> d_c_values(cn);
+        dvec<index_t> d_c_colind(cn);
+        d_c.update(std::span<value_t>(d_c_values.p, cn), std::span<offset_t>(d_c_rowptr.p, m + 1),
+                   std::span<index_t>(d_c_colind.p, cn), {m, n}, (offset_t) cn);
+        if (variant == 2)
+          spblas::multiply_fill(info, a.view, b.view, d_c);
+        else if (variant == 1)
+          spblas::multiply_fill(state, spblas::scaled(alpha, a.view), b.view, d_c);
+        else
+          spblas::multiply_fill(state, a.view, b.view, d_c);
+        check_spgemm(ha, hb, alpha, m, d_c_values.download(), d_c_rowptr.download(), d_c_colind.download());
+      }
+    }
+  }
+  // reuse: symbolic once, numeric three times with new values (spgemm_reuse_test.cpp:42-70)
+  auto [m, k, nnz] = dims[1];
+  auto ha = generate_csr(m, k, nnz), hb = generate_csr(k, m, nnz, 1);
+  device_csr a(ha), b(hb);
+  dvec<offset_t> d_c_rowptr(m + 1);
+  spblas::csr_view<value_t, index_t, offset_t> d_c(nullptr, d_c_rowptr.p, nullptr, {m, m}, 0);
+  spblas::spgemm_state_t state;
+  spblas::multiply_symbolic_compute(state, a.view, b.view, d_c);
+  const auto cn = state.result_nnz();
+  dvec<value_t> d_c_values(cn);
+  dvec<index_t> d_c_colind(cn);
+  d_c.update(std::span<value_t>(d_c_values.p, cn), std::span<offset_t>(d_c_rowptr.p, m + 1),
+             std::span<index_t>(d_c_colind.p, cn), {m, m}, (offset_t) cn);
+  spblas::multiply_symbolic_fill(state, a.view, b.view, d_c);
+  std::mt19937 g(0);
+  for (int it = 0; it < 3; it++) {
+    if (it) {
+      std::uniform_real_distribution<value_t> d(0, 100);
+      for (auto& v : ha.values)
+        v = d(g);
+      for (auto& v : hb.values)
+        v = d(g);
+      a.values.upload(ha.values);
+      b.values.upload(hb.values);
+    }
+    spblas::multiply_numeric(state, a.view, b.view, d_c);
+    check_spgemm(ha, hb, 1.0f, m, d_c_values.download(), d_c_rowptr.download(), d_c_colind.download());
+  }
+  // out of memory (spgemm_gustavsons.hpp:44-48)
+  spblas::csr_view<value_t, index_t, offset_t> small(d_c_values.p, d_c_rowptr.p, d_c_colind.p, {m, m},
+                                                     (offset_t) cn - 1);
+  bool threw = false;
+  try {
+    spblas::multiply_fill(state, a.view, b.view, small);
+  } catch (const std::runtime_error&) {
+    threw = true;
+  }
+  CHECK(threw);
+}
+
+int main() {
+  test_spmv();
+  test_spmm();
+  test_spgemm();
+  std::printf("%s: %d checks, %d failures\n", g_fail ? "FAILED" : "PASSED", g_checks, g_fail);
+  return g_fail ? 1 : 0;
+}

@@ -54,3 +54,10 @@ def test_package_surface_mirrors_reference_names():
                  "spgemm_state_t", "multiply", "multiply_inspect", "multiply_compute", "multiply_fill",
                  "multiply_symbolic_compute", "multiply_symbolic_fill", "multiply_numeric"]:
         assert hasattr(sp, name)
+
+
+def test_cpp_host_layer_compiles_with_gxx():
+    """The C++20 host layer (standalone API mirror + shared __gfx950 call layer) builds with g++
+    and links against the C-ABI library -- no GPU needed to compile."""
+    exe = _build.build_cpp_tests()
+    assert os.path.exists(exe)

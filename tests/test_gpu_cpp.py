@@ -1,0 +1,21 @@
+"""-m gpu: the C++20 host layer end to end.  tests/cpp/device_tests.cpp restates the reference's
+device gtests (test/gtest/device/spmv_test.cpp, spgemm_test.cpp, spgemm_reuse_test.cpp and the
+SpMM cases of test/gtest/spmm_test.cpp) against include/spblas_gfx950/spblas.hpp, which calls
+the same C ABI through the same __gfx950 layer the drop-in backend headers use."""
+import os
+import subprocess
+
+import pytest
+
+from spblas_reference_amd import _build
+
+pytestmark = pytest.mark.gpu
+
+
+def test_cpp_device_tests(gpu):
+    exe = _build.CPP_TEST_BIN
+    if not os.path.exists(exe):
+        exe = _build.build_cpp_tests()
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]
+    assert "PASSED" in r.stdout

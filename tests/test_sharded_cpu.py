@@ -1,0 +1,85 @@
+"""CPU tests (gloo, world_size 2) of the row-sharded multi-GPU path: nnz-prefix partition,
+shard extraction (rebased rowptr, global columns), equal and unequal all-gather assembly.
+The local SpMV is injected (the oracle) so that the sharding/collective logic runs without a
+GPU; on GPUs the default local_spmv is the HIP path (spblas-reference_amd/sharded.py)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import spblas_reference_amd as sp
+from oracle import oracle
+from spblas_reference_amd import generate, sharded
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _oracle_local(info, a_local, x, y_local):
+    y = oracle.spmv(tuple(a_local.shape()), a_local.rowptr().numpy(), a_local.colind().numpy(),
+                    a_local.values().numpy(), x.numpy())
+    y_local.copy_(torch.from_numpy(y))
+
+
+def _worker(rank, world, port, case, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        m, n, nnz, by_nnz, dtype = case
+        values, rowptr, colind, shape, _ = generate.generate_csr(m, n, nnz, seed=3, dtype=dtype)
+        if by_nnz:  # skew the matrix: make the first rows heavy so nnz-balanced shards are unequal
+            lens = np.diff(rowptr)
+            order = np.argsort(-lens, kind="stable")
+            # rebuild CSR with rows sorted by decreasing length (still a valid test matrix)
+            new_rp = np.concatenate([[0], np.cumsum(lens[order])]).astype(np.int32)
+            idx = np.concatenate([np.arange(rowptr[r], rowptr[r + 1]) for r in order]) if nnz else np.zeros(0, np.int64)
+            values, colind, rowptr = values[idx], colind[idx], new_rp
+        t = torch.from_numpy
+        rp_t = t(rowptr)
+        bounds = sharded.partition_rows_by_nnz(rp_t, world) if by_nnz else sharded.partition_rows_even(m, world)
+        a_local = sharded.shard_csr(t(values), rp_t, t(colind), shape, bounds[rank], bounds[rank + 1])
+        assert int(a_local.rowptr()[0]) == 0 and a_local.shape() == (bounds[rank + 1] - bounds[rank], n)
+        op = sharded.ShardedSpMV(a_local, bounds, local_spmv=_oracle_local)
+        x = t(np.random.default_rng(5).random(n).astype(dtype))
+        y = op.step(x).numpy().copy()
+        y2 = op.step(x).numpy().copy()  # a second step reuses the buffers
+        y_ref = oracle.spmv(shape, rowptr, colind, values, x.numpy())
+        # gathered result == single-process result bit for bit (same per-row arithmetic)
+        assert np.array_equal(y, y_ref) and np.array_equal(y2, y_ref)
+        np.save(os.path.join(out_dir, f"ok_{rank}.npy"), np.array(bounds))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", [(1000, 100, 100, False, np.float32), (100, 1000, 10000, False, np.float64),
+                                  (999, 640, 20000, True, np.float32), (40, 40, 1000, True, np.float64)])
+def test_row_sharded_spmv_world2_gloo(case, tmp_path):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, case, str(tmp_path)), nprocs=2, join=True)
+    b0, b1 = np.load(tmp_path / "ok_0.npy"), np.load(tmp_path / "ok_1.npy")
+    assert np.array_equal(b0, b1) and b0[0] == 0 and b0[-1] == case[0]
+
+
+def test_partition_rows_by_nnz_balances_nnz():
+    rowptr = torch.tensor(np.concatenate([[0], np.cumsum([1000] * 4 + [1] * 4000)]))
+    b = sharded.partition_rows_by_nnz(rowptr, 8)
+    assert b[0] == 0 and b[-1] == 4004 and all(b[i] <= b[i + 1] for i in range(8))
+    per = [int(rowptr[b[i + 1]] - rowptr[b[i]]) for i in range(8)]
+    assert max(per) <= 1000 + 1  # no shard exceeds nnz/P by more than one (heavy) row
+    assert sharded.partition_rows_even(10, 4) == [0, 2, 5, 7, 10]
+
+
+def test_sharded_default_compute_is_the_hip_path():
+    assert sharded._hip_local_spmv.__module__.endswith("sharded")
+    a = sp.csr_view(torch.ones(1), torch.tensor([0, 1], dtype=torch.int32), torch.zeros(1, dtype=torch.int32), (1, 1), 1)
+    op = sharded.ShardedSpMV(a, [0, 1], inspect=False)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        op.step(torch.ones(1))
