@@ -37,6 +37,7 @@ def parse():
     p.add_argument("--warmup", type=int, default=5)
     p.add_argument("--workload", default="spmv", choices=["spmv", "spmv_poisson", "spmv_rmat", "spmm", "spgemm"])
     p.add_argument("--rows", type=int, default=None, help="override the row count (debug only; reported)")
+    p.add_argument("--cols", type=int, default=None, help="override the column count (debug: emulate one row shard)")
     p.add_argument("--alg", default="auto", choices=["auto", "vector", "rowblock", "sliced", "noplan"])
     p.add_argument("--no-cpu-baseline", action="store_true")
     return p.parse_args()
@@ -132,6 +133,8 @@ def main():
 
     poisson = args.workload == "spmv_poisson"
     m = n = args.rows or 10_000_000
+    if args.cols:
+        n = args.cols
     per_row = 10
     dtype, tsize = torch.float32, 4
     bounds = sharded.partition_rows_even(m, world)  # exact-10 rows: equal rows == equal nnz
@@ -201,7 +204,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS,
                          # PMC traffic was measured for the default cfg2 / 1 GPU / sliced plan only
                          "traffic": read_pmc_traffic("spmv_cfg2") if (world == 1 and plan_info.get("alg") == 3
-                                                                     and not poisson and args.rows is None) else None,
+                                                                     and not poisson and args.rows is None and args.cols is None) else None,
                          "kernel": {3: "pb_expand_kernel<float> + pb_reduce_kernel<float> (one SpMV = this launch pair)",
                                     2: "spmv_rowblock_kernel<float,int,2048>", 1: "spmv_vector_kernel<float,int,LPR>"
                                     }.get(plan_info.get("alg"), "spmv_vector_kernel<float,int,LPR>"),

@@ -40,6 +40,8 @@ struct spblas_gfx950_plan_s {
   uint16_t* s_lrow = nullptr;  // uint16[nnz] row inside the bin
   void* s_perm = nullptr;      // int32[nnz] source position in the caller's CSR arrays
   void* s_products = nullptr;  // T[nnz] workspace: expanded products
+  int n_ksplit = 1;            // reduce workgroups per bin group (slice split)
+  void* s_partial = nullptr;   // T[n_ksplit][m] partial sums when n_ksplit > 1
 
   size_t device_bytes = 0;
 };

@@ -256,11 +256,16 @@ __global__ __launch_bounds__(PB_RTHREADS) void pb_reduce_kernel(int64_t m, int H
                                                                 const int2* __restrict__ segT,
                                                                 const T* __restrict__ P,
                                                                 const uint16_t* __restrict__ s_row,
-                                                                T* __restrict__ y, T alpha, T beta) {
+                                                                T* __restrict__ y, T alpha, T beta, int s_per,
+                                                                T* __restrict__ partial, int64_t pstride) {
+  // blockIdx.y = k selects the slices [k*s_per, (k+1)*s_per): with few wave-bins (a row shard of
+  // a multi-GPU run) the slices are split over several workgroups per bin group, each writing a
+  // partial sum that pb_combine_kernel adds up in a fixed order.
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   T* acc = reinterpret_cast<T*>(smem) + (size_t) wave * Hw;
   const int64_t wb = (int64_t) blockIdx.x * PB_RWAVES + wave;
+  const int s_lo = blockIdx.y * s_per, s_hi = (s_lo + s_per) < S ? (s_lo + s_per) : S;
   if (wb >= NBw)
     return;
   const int64_t r0 = wb * Hw;
@@ -270,13 +275,13 @@ __global__ __launch_bounds__(PB_RTHREADS) void pb_reduce_kernel(int64_t m, int H
   const int2* mine = segT + wb * S;
   constexpr int B = 8;  // runs in flight per wave: B * 6 bytes * 64 lanes * 16 waves/CU ~ 48 KiB
   int2 dnext = make_int2(0, 0);
-  if (lane < S)
-    dnext = mine[lane];
-  for (int sb = 0; sb < S; sb += 64) {
+  if (s_lo + lane < s_hi)
+    dnext = mine[s_lo + lane];
+  for (int sb = s_lo; sb < s_hi; sb += 64) {
     const int2 d = dnext;
-    if (sb + 64 + lane < S)  // prefetch the next 64 descriptors behind this batch's work
+    if (sb + 64 + lane < s_hi)  // prefetch the next 64 descriptors behind this batch's work
       dnext = mine[sb + 64 + lane];
-    const int cnt = (S - sb) < 64 ? (S - sb) : 64;
+    const int cnt = (s_hi - sb) < 64 ? (s_hi - sb) : 64;
     for (int j0 = 0; j0 < cnt; j0 += B) {
       T p[B];
       int r[B], st[B], ln[B];
@@ -308,10 +313,29 @@ __global__ __launch_bounds__(PB_RTHREADS) void pb_reduce_kernel(int64_t m, int H
       }
     }
   }
+  if (partial) {
+    T* dst = partial + (int64_t) blockIdx.y * pstride + r0;
+    for (int i = lane; i < rh; i += 64)
+      dst[i] = acc[i];
+    return;
+  }
   for (int i = lane; i < rh; i += 64) {
     const T v = alpha * acc[i];
     y[r0 + i] = beta == T(0) ? v : v + beta * y[r0 + i];
   }
+}
+
+// y = alpha * (partial[0] + partial[1] + ... in this fixed order) + beta * y
+template <typename T>
+__global__ __launch_bounds__(256) void pb_combine_kernel(int64_t m, int K, const T* __restrict__ partial,
+                                                         int64_t pstride, T* __restrict__ y, T alpha, T beta) {
+  const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
+  if (i >= m)
+    return;
+  T s = partial[i];
+  for (int k = 1; k < K; ++k)
+    s += partial[(int64_t) k * pstride + i];
+  y[i] = beta == T(0) ? alpha * s : alpha * s + beta * y[i];
 }
 
 // ---- host -------------------------------------------------------------------------------
@@ -363,6 +387,18 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
   pl->slice_cols = W;
   pl->n_rblk = NB;
   pl->rows_per_blk = H;
+  {  // slice split: keep >= ~512 reduce workgroups in flight when there are few wave-bins
+    const int64_t groups = cdiv(NB, PB_RWAVES);
+    int K = env_int("SPBLAS_GFX950_PB_KSPLIT", 0);
+    if (K <= 0) {
+      K = 1;
+      while (groups * K < 384 && K < 32 && S / (2 * K) >= 8)
+        K *= 2;
+    }
+    if (K > S)
+      K = S;
+    pl->n_ksplit = K;
+  }
 
   int rc;
   int32_t* seg = nullptr;
@@ -406,6 +442,11 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
     return rc;
   if ((rc = dev_alloc((void**) &pl->s_segT, (size_t) nseg * sizeof(int2), s)))
     return rc;
+  if (pl->n_ksplit > 1) {
+    if ((rc = dev_alloc(&pl->s_partial, (size_t) pl->n_ksplit * m * sizeof(T), s)))
+      return rc;
+    pl->device_bytes += (size_t) pl->n_ksplit * m * sizeof(T);
+  }
   pl->device_bytes += (size_t) nnz * (2 * sizeof(T) + 8) + (size_t) nseg * 16;
   SPB_HIP(hipMemsetAsync(cursor, 0, (size_t) nseg * 4, s));
   scan_counts_i32(s, nseg, seg, partials);
@@ -463,10 +504,16 @@ static int sliced_exec_typed(spblas_gfx950_handle_t h, const spblas_gfx950_plan_
                      (size_t) pl->slice_cols * sizeof(T), s, pl->n, pl->slice_cols, (int) pl->n_rblk, seg,
                      static_cast<const T*>(pl->s_values), reinterpret_cast<const uint16_t*>(pl->s_colind),
                      static_cast<const T*>(x), static_cast<T*>(pl->s_products));
-  hipLaunchKernelGGL((pb_reduce_kernel<T>), dim3((unsigned) cdiv(pl->n_rblk, PB_RWAVES)), dim3(PB_RTHREADS),
-                     (size_t) PB_RWAVES * pl->rows_per_blk * sizeof(T), s, pl->m, pl->rows_per_blk, pl->n_slices,
-                     pl->n_rblk, static_cast<const int2*>(pl->s_segT), static_cast<const T*>(pl->s_products),
-                     pl->s_lrow, static_cast<T*>(y), alpha, beta);
+  const int K = pl->n_ksplit;
+  const int s_per = (int) cdiv(pl->n_slices, K);
+  hipLaunchKernelGGL((pb_reduce_kernel<T>), dim3((unsigned) cdiv(pl->n_rblk, PB_RWAVES), (unsigned) K),
+                     dim3(PB_RTHREADS), (size_t) PB_RWAVES * pl->rows_per_blk * sizeof(T), s, pl->m, pl->rows_per_blk,
+                     pl->n_slices, pl->n_rblk, static_cast<const int2*>(pl->s_segT),
+                     static_cast<const T*>(pl->s_products), pl->s_lrow, static_cast<T*>(y), alpha, beta, s_per,
+                     K > 1 ? static_cast<T*>(pl->s_partial) : nullptr, pl->m);
+  if (K > 1)
+    hipLaunchKernelGGL((pb_combine_kernel<T>), dim3((unsigned) cdiv(pl->m, 256)), dim3(256), 0, s, pl->m, K,
+                       static_cast<const T*>(pl->s_partial), pl->m, static_cast<T*>(y), alpha, beta);
   SPB_HIP(hipGetLastError());
   return SPBLAS_GFX950_STATUS_SUCCESS;
 }
@@ -486,6 +533,8 @@ void spmv_sliced_free(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl) {
   dev_free(pl->s_perm, s);
   dev_free(pl->s_products, s);
   dev_free(pl->s_segT, s);
+  dev_free(pl->s_partial, s);
+  pl->s_partial = nullptr;
   pl->seg_ptr = pl->s_colind = pl->s_values = pl->s_products = pl->s_segT = pl->s_perm = nullptr;
   pl->s_lrow = nullptr;
   pl->n_slices = 0;

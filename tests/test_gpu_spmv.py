@@ -113,13 +113,15 @@ def test_spmv_ragged_powerlaw_int64_offsets(gpu, dtype, alg):
         check(values, rowptr.astype(np.int32), colind, (m, n), x, y, what=f"ragged {alg} off64={off64}", ref_cmp=False)
 
 
+@pytest.mark.parametrize("ksplit", [0, 1, 4])
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
-def test_spmv_sliced_many_tiles_and_value_update(gpu, dtype, monkeypatch):
+def test_spmv_sliced_many_tiles_and_value_update(gpu, dtype, ksplit, monkeypatch):
     """The LDS-sliced re-tiling with tiny tiles (test hook env vars) so that a small matrix
     spans many (slice, bin) segments, incl. empty segments, ragged rows and a long row;
     then values change in place and the plan is refreshed with update_values."""
     monkeypatch.setenv("SPBLAS_GFX950_SLICE_COLS", "100")
     monkeypatch.setenv("SPBLAS_GFX950_SLICE_ROWS", "64")
+    monkeypatch.setenv("SPBLAS_GFX950_PB_KSPLIT", str(ksplit))  # slice split of the reduce (0 = heuristic)
     rng = np.random.default_rng(11)
     m, n = 1500, 2111
     lens = rng.integers(0, 30, m)
