@@ -39,6 +39,8 @@ def parse():
     p.add_argument("--rows", type=int, default=None, help="override the row count (debug only; reported)")
     p.add_argument("--cols", type=int, default=None, help="override the column count (debug: emulate one row shard)")
     p.add_argument("--alg", default="auto", choices=["auto", "vector", "rowblock", "sliced", "noplan"])
+    p.add_argument("--chunks", type=int, default=0,
+                   help="N>1: stripes per step whose all-gathers overlap the next stripe's compute (0 = auto)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     return p.parse_args()
 
@@ -137,29 +139,38 @@ def main():
         n = args.cols
     per_row = 10
     dtype, tsize = torch.float32, 4
-    bounds = sharded.partition_rows_even(m, world)  # exact-10 rows: equal rows == equal nnz
-    if poisson and world > 1:
-        bounds = [(b // CHUNK_ROWS) * CHUNK_ROWS for b in bounds[:-1]] + [m]
-    r0, r1 = bounds[rank], bounds[rank + 1]
-    values, rowptr, colind, nnz_local = gen_rows(r0, r1, n, per_row, poisson, dtype, device)
+    algs = {"auto": _capi.SPMV_AUTO, "vector": _capi.SPMV_VECTOR, "rowblock": _capi.SPMV_ROWBLOCK,
+            "sliced": _capi.SPMV_SLICED}
     g = torch.Generator(device=device).manual_seed(7)
     x = torch.rand(n, dtype=dtype, device=device, generator=g)  # same on every rank (replicated)
-    a_local = sp.csr_view(values, rowptr, colind, (r1 - r0, n), nnz_local)
+    # N = 1: one plan, no collective.  N > 1: `chunks` stripes, each split evenly over the ranks;
+    # stripe c's all-gather (RCCL, async) overlaps stripe c+1's kernels (sharded.PipelinedShardedSpMV).
+    chunks = args.chunks if args.chunks > 0 else (1 if world == 1 else (4 if world <= 4 else 2))
+    ranges = sharded.striped_row_ranges(m, world, chunks)
+    if ranges is None or poisson and world > 1:
+        chunks = 1
+        ranges = sharded.striped_row_ranges(m, world, 1)
+    if ranges is None:
+        sys.exit(f"rows={m} is not divisible by the number of ranks")
+    a_chunks, nnz_local = [], 0
+    for c in range(chunks):
+        lo, hi = ranges[c][rank]
+        v_c, rp_c, ci_c, nnz_c = gen_rows(lo, hi, n, per_row, poisson, dtype, device)
+        a_chunks.append(sp.csr_view(v_c, rp_c, ci_c, (hi - lo, n), nnz_c))
+        nnz_local += nnz_c
+    rows_local = sum(a.shape()[0] for a in a_chunks)
     nnz_t = torch.tensor([nnz_local], dtype=torch.int64, device=device)
     if world > 1:
         dist.all_reduce(nnz_t)
     nnz = int(nnz_t.item())
 
-    algs = {"auto": _capi.SPMV_AUTO, "vector": _capi.SPMV_VECTOR, "rowblock": _capi.SPMV_ROWBLOCK,
-            "sliced": _capi.SPMV_SLICED}
-    op = sharded.ShardedSpMV(a_local, bounds, inspect=False)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    if args.alg != "noplan":
-        op.info = sp.multiply_inspect(a_local, x, op.y_local[:r1 - r0], alg=algs[args.alg])
+    op = sharded.PipelinedShardedSpMV(a_chunks, ranges, inspect=args.alg != "noplan",
+                                      alg=None if args.alg == "noplan" else algs[args.alg])
     torch.cuda.synchronize()
     inspect_ms = (time.perf_counter() - t0) * 1e3
-    plan_info = op.info.state_.info() if op.info.state_ is not None else {"alg": "plan-free"}
+    plan_info = op.infos[0].state_.info() if op.infos[0].state_ is not None else {"alg": "plan-free"}
 
     for _ in range(args.warmup):
         op.step(x)
@@ -167,13 +178,11 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(chunks)]
+          for _ in range(args.steps)]
     t0 = time.perf_counter()
     for i in range(args.steps):
-        ev[i][0].record()
-        op.local(x)
-        ev[i][1].record()
-        op.gather()
+        op.step(x, events=ev[i])
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -183,8 +192,10 @@ def main():
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
-    kern_ms = sorted(a.elapsed_time(b) for a, b in ev)
+    kern_ms = sorted(sum(a.elapsed_time(b) for a, b in step_ev) for step_ev in ev)
     kern_avg_ms = sum(kern_ms) / len(kern_ms)
+    values, rowptr, colind = a_chunks[0].values(), a_chunks[0].rowptr(), a_chunks[0].colind()
+    r0, r1 = 0, rows_local
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -198,7 +209,8 @@ def main():
             "config": {"workload": f"cfg2: fp32 CSR SpMV {m}x{n}, {'Poisson(10)' if poisson else 'exactly 10'} nnz/row, "
                                    f"uniform random unsorted columns, int32 indices, nnz={nnz}",
                        "rows": m, "cols": n, "nnz": nnz, "index_type": "int32",
-                       "parallelism": f"row-sharded x{world} + RCCL all-gather(y)" if world > 1 else "single GPU",
+                       "parallelism": (f"row-sharded x{world}, {chunks} stripes per step, RCCL all-gather(y) per stripe "
+                                       "overlapped with the next stripe" if world > 1 else "single GPU"),
                        "alg": args.alg, "plan": plan_info, "inspect_ms_untimed": inspect_ms},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
@@ -212,7 +224,7 @@ def main():
                          "kernel_min_ms": kern_ms[0], "kernel_median_ms": kern_ms[len(kern_ms) // 2],
                          "algorithmic_gbs_whole_step": spmv_bytes(m, n, nnz, tsize) / (elapsed / args.steps) / 1e9},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and chunks == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_spmv(values, rowptr, colind, (m, n), x, nnz)
         else:
             out["cpu_baseline"] = None

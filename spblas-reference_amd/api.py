@@ -373,7 +373,7 @@ def _find_plan(info, a, a_base):
 
 
 # --------------------------------------------------------------------------- SpMV / SpMM
-def _spmv(info, a, b, c):
+def _spmv(info, a, b, c, prepare_only=False):
     a_base, b_base = get_ultimate_base(a), get_ultimate_base(b)
     _reject_conjugated(a, b, c)
     if not _is_tensor(c) or c.dim() != 1:
@@ -401,10 +401,28 @@ def _spmv(info, a, b, c):
     hd = _Handle.current(c.device)
     plan = _find_plan(info, a, a_base) if op == _capi.OP_N else None
     m, n = a_csr.shape()
-    check(_capi.lib().spblas_gfx950_spmv(hd.h, plan.plan if plan else None, op, m, n, a_csr.size(),
-                                         ctypes.byref(alpha), _ptr(a_csr.rowptr()), _ptr(a_csr.colind()),
-                                         _ptr(a_csr.values()), _ptr(b_base), ctypes.byref(beta), _ptr(c),
-                                         _OT[a_csr.rowptr().dtype], vt), "multiply")
+    args = (hd.h, plan.plan if plan else None, op, m, n, a_csr.size(), ctypes.byref(alpha), _ptr(a_csr.rowptr()),
+            _ptr(a_csr.colind()), _ptr(a_csr.values()), _ptr(b_base), ctypes.byref(beta), _ptr(c),
+            _OT[a_csr.rowptr().dtype], vt)
+    if prepare_only:
+        return args, (alpha, beta, plan, a, b, c)  # keep the operands alive with the bound call
+    check(_capi.lib().spblas_gfx950_spmv(*args), "multiply")
+
+
+class prepared_multiply:
+    """multiply(info, a, x, y) validated and bound ONCE; calling the object re-issues the same
+    SpMV on the stream that was current at construction.  For solver-style loops where the Python
+    host layer (view unwrapping, checks: tens of microseconds) would otherwise cost more than the
+    kernel.  The operands must stay the same tensors; their contents may change between calls."""
+
+    def __init__(self, info, a, x, y):
+        self._args, self._keep = _spmv(info, a, x, y, prepare_only=True)
+        self._fn = _capi.lib().spblas_gfx950_spmv
+
+    def __call__(self):
+        rc = self._fn(*self._args)
+        if rc:
+            check(rc, "multiply")
 
 
 def _spmm(info, a, b, c):

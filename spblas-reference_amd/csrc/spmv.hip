@@ -477,7 +477,7 @@ static bool sliced_candidate(const spblas_gfx950_plan_s* pl) {
   const size_t tsz = pl->value_type == SPBLAS_GFX950_F32 ? 4 : 8;
   const double tile = 80.0 * 1024 / tsz;
   const double nseg = (pl->n / tile + 1) * (pl->m / tile + 1);
-  return (size_t) pl->n * tsz >= ((size_t) 16 << 20) && pl->nnz >= ((int64_t) 8 << 20) &&
+  return (size_t) pl->n * tsz >= ((size_t) 16 << 20) && pl->nnz >= ((int64_t) 2 << 20) &&
          pl->nnz < INT32_MAX - 8 && pl->max_row_len <= 4096 && (double) pl->nnz / nseg >= 48.0;
 }
 

@@ -68,6 +68,33 @@ def test_row_sharded_spmv_world2_gloo(case, tmp_path):
     assert np.array_equal(b0, b1) and b0[0] == 0 and b0[-1] == case[0]
 
 
+def _worker_pipelined(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        m, n, nnz, chunks = 960, 500, 15000, 4
+        values, rowptr, colind, shape, _ = generate.generate_csr(m, n, nnz, seed=8)
+        t = torch.from_numpy
+        ranges = sharded.striped_row_ranges(m, world, chunks)
+        assert ranges is not None and ranges[0][0] == (0, 120) and ranges[-1][-1] == (840, 960)
+        a_chunks = [sharded.shard_csr(t(values), t(rowptr), t(colind), shape, *ranges[c][rank]) for c in range(chunks)]
+        op = sharded.PipelinedShardedSpMV(a_chunks, ranges, local_spmv=_oracle_local)
+        x = t(np.random.default_rng(6).random(n).astype(np.float32))
+        for _ in range(2):
+            y = op.step(x).numpy().copy()
+            assert np.array_equal(y, oracle.spmv(shape, rowptr, colind, values, x.numpy()))
+        np.save(os.path.join(out_dir, f"pipe_{rank}.npy"), np.array([1]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_pipelined_striped_all_gather_world2_gloo(tmp_path):
+    mp.spawn(_worker_pipelined, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "pipe_0.npy").exists() and (tmp_path / "pipe_1.npy").exists()
+    assert sharded.striped_row_ranges(10, 2, 4) is None  # not divisible -> caller falls back to one gather
+
+
 def test_partition_rows_by_nnz_balances_nnz():
     rowptr = torch.tensor(np.concatenate([[0], np.cumsum([1000] * 4 + [1] * 4000)]))
     b = sharded.partition_rows_by_nnz(rowptr, 8)
