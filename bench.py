@@ -41,6 +41,7 @@ def parse():
     p.add_argument("--alg", default="auto", choices=["auto", "vector", "rowblock", "sliced", "noplan"])
     p.add_argument("--chunks", type=int, default=0,
                    help="N>1: stripes per step whose all-gathers overlap the next stripe's compute (0 = auto)")
+    p.add_argument("--overlap", action="store_true", help="debug: use the N>1 overlapped step at N=1 (no collective)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     return p.parse_args()
 
@@ -145,7 +146,10 @@ def main():
     x = torch.rand(n, dtype=dtype, device=device, generator=g)  # same on every rank (replicated)
     # N = 1: one plan, no collective.  N > 1: `chunks` stripes, each split evenly over the ranks;
     # stripe c's all-gather (RCCL, async) overlaps stripe c+1's kernels (sharded.PipelinedShardedSpMV).
-    chunks = args.chunks if args.chunks > 0 else (1 if world == 1 else (4 if world <= 4 else 2))
+    # Default 1 stripe: measured on one GPU (row shards emulated with --rows/--cols/--overlap), every
+    # extra stripe costs ~20-30 us of launch/latency floor, more than the gather time it can hide
+    # at N = 4 and 8; --chunks C enables the overlapped variants.
+    chunks = args.chunks if args.chunks > 0 else 1
     ranges = sharded.striped_row_ranges(m, world, chunks)
     if ranges is None or poisson and world > 1:
         chunks = 1
@@ -166,11 +170,30 @@ def main():
 
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    op = sharded.PipelinedShardedSpMV(a_chunks, ranges, inspect=args.alg != "noplan",
-                                      alg=None if args.alg == "noplan" else algs[args.alg])
+    mode = "plain"
+    op = None
+    if (world > 1 or args.overlap) and chunks > 1 and args.alg in ("auto", "sliced"):
+        # preferred N > 1 path: ONE local plan (stripes back to back), expand once, reduce stripe by
+        # stripe with each stripe's all-gather overlapping the next reduce
+        try:
+            lens = torch.cat([a.rowptr()[1:].long() - a.rowptr()[:-1].long() for a in a_chunks])
+            rp = torch.zeros(rows_local + 1, dtype=torch.int64, device=device)
+            torch.cumsum(lens, 0, out=rp[1:])
+            a_cat = sp.csr_view(torch.cat([a.values() for a in a_chunks]), rp.to(torch.int32),
+                                torch.cat([a.colind() for a in a_chunks]), (rows_local, n), nnz_local)
+            op = sharded.OverlappedShardedSpMV(a_cat, ranges, alg=algs[args.alg])
+            a_chunks = [a_cat]
+            mode = "overlapped"
+        except RuntimeError:
+            op = None
+    if op is None:
+        op = sharded.PipelinedShardedSpMV(a_chunks, ranges, inspect=args.alg != "noplan",
+                                          alg=None if args.alg == "noplan" else algs[args.alg])
+        mode = "pipelined" if chunks > 1 else "plain"
     torch.cuda.synchronize()
     inspect_ms = (time.perf_counter() - t0) * 1e3
-    plan_info = op.infos[0].state_.info() if op.infos[0].state_ is not None else {"alg": "plan-free"}
+    info0 = op.info if mode == "overlapped" else op.infos[0]
+    plan_info = info0.state_.info() if info0.state_ is not None else {"alg": "plan-free"}
 
     for _ in range(args.warmup):
         op.step(x)
@@ -178,7 +201,7 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(chunks)]
+    ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(1 if mode == "overlapped" else chunks)]
           for _ in range(args.steps)]
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -209,8 +232,8 @@ def main():
             "config": {"workload": f"cfg2: fp32 CSR SpMV {m}x{n}, {'Poisson(10)' if poisson else 'exactly 10'} nnz/row, "
                                    f"uniform random unsorted columns, int32 indices, nnz={nnz}",
                        "rows": m, "cols": n, "nnz": nnz, "index_type": "int32",
-                       "parallelism": (f"row-sharded x{world}, {chunks} stripes per step, RCCL all-gather(y) per stripe "
-                                       "overlapped with the next stripe" if world > 1 else "single GPU"),
+                       "parallelism": (f"row-sharded x{world}, {chunks} stripes per step ({mode}), one RCCL all-gather(y) per "
+                                       "stripe overlapped with the next stripe's kernels" if world > 1 else "single GPU"),
                        "alg": args.alg, "plan": plan_info, "inspect_ms_untimed": inspect_ms},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,

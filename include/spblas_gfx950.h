@@ -103,6 +103,15 @@ int spblas_gfx950_destroy(spblas_gfx950_handle_t handle);
 int spblas_gfx950_set_stream(spblas_gfx950_handle_t handle, void* stream);
 int spblas_gfx950_get_stream(spblas_gfx950_handle_t handle, void** stream);
 
+/* Handle options consulted by later plan creations. */
+typedef enum spblas_gfx950_option {
+  /* Row-sharded multi-GPU runs gather y stripe by stripe (spblas-reference_amd/sharded.py).
+   * value > 0 asks the SLICED inspect to put its row-bin boundaries on divisors of `value`
+   * (the stripe length), so that spblas_gfx950_spmv_reduce_rows can finish whole stripes. */
+  SPBLAS_GFX950_OPT_BIN_ROW_ALIGN = 1
+} spblas_gfx950_option;
+int spblas_gfx950_set_option(spblas_gfx950_handle_t handle, int option, int64_t value);
+
 /* ---- SpMV:  y = alpha * op(A) * x + beta * y ------------------------------ */
 /* multiply_inspect(A, x, y): device-side analysis of the sparsity pattern.
  * Builds the nnz-window row partition, the long-row list and (SLICED) the
@@ -119,8 +128,18 @@ int spblas_gfx950_spmv_plan_update_values(spblas_gfx950_handle_t handle, spblas_
 int spblas_gfx950_plan_destroy(spblas_gfx950_handle_t handle, spblas_gfx950_plan_t plan);
 /* Introspection for tests/bench: info[0]=alg, [1]=window nnz, [2]=#windows,
  * [3]=#long rows, [4]=max row length, [5]=device bytes held, [6]=#column slices,
- * [7]=#empty rows. */
-int spblas_gfx950_plan_info(spblas_gfx950_plan_t plan, int64_t info[8]);
+ * [7]=#empty rows, [8]=rows per row-bin (SLICED), [9]=1 if the bins honour BIN_ROW_ALIGN. */
+int spblas_gfx950_plan_info(spblas_gfx950_plan_t plan, int64_t info[10]);
+
+/* Two-stage execution of a SLICED plan (other plans: STATUS_NOT_SUPPORTED), used to overlap the
+ * multi-GPU all-gather of finished y rows with the rest of the SpMV:
+ *   expand       products of every stored entry with x (x read once, LDS-resident slices)
+ *   reduce_rows  y[r] = alpha * (A x)[r] + beta * y[r] for the row-bins that START in
+ *                [row_begin, row_end), from the products of the last expand.  `y` is the base of
+ *                the full local y (entry r at y[r]).  spblas_gfx950_spmv == expand + reduce_rows(0, m). */
+int spblas_gfx950_spmv_expand(spblas_gfx950_handle_t handle, spblas_gfx950_plan_t plan, const void* x);
+int spblas_gfx950_spmv_reduce_rows(spblas_gfx950_handle_t handle, spblas_gfx950_plan_t plan, const void* alpha,
+                                   const void* beta, void* y, int64_t row_begin, int64_t row_end);
 
 /* multiply(info, A, x, y) / multiply(A, x, y).  plan may be NULL (no inspect):
  * a plan-free kernel is chosen from nnz/m.  op == OP_T computes y = alpha*A^T*x

@@ -28,6 +28,7 @@ F32, F64 = 0, 1
 I32, I64 = 0, 1
 OP_N, OP_T = 0, 1
 SPMV_AUTO, SPMV_VECTOR, SPMV_ROWBLOCK, SPMV_SLICED = 0, 1, 2, 3
+OPT_BIN_ROW_ALIGN = 1
 
 # every symbol include/spblas_gfx950.h declares: (name, restype, argtypes)
 PROTOTYPES = [
@@ -38,6 +39,9 @@ PROTOTYPES = [
     ("spblas_gfx950_destroy", c_int, [c_void_p]),
     ("spblas_gfx950_set_stream", c_int, [c_void_p, c_void_p]),
     ("spblas_gfx950_get_stream", c_int, [c_void_p, ctypes.POINTER(c_void_p)]),
+    ("spblas_gfx950_set_option", c_int, [c_void_p, c_int, c_i64]),
+    ("spblas_gfx950_spmv_expand", c_int, [c_void_p, c_void_p, c_void_p]),
+    ("spblas_gfx950_spmv_reduce_rows", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_i64]),
     ("spblas_gfx950_spmv_plan_create", c_int,
      [c_void_p, ctypes.POINTER(c_void_p), c_i64, c_i64, c_i64, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int]),
     ("spblas_gfx950_spmv_plan_update_values", c_int, [c_void_p, c_void_p, c_void_p]),

@@ -221,6 +221,9 @@ class _Handle:
             check(_capi.lib().spblas_gfx950_create(ctypes.byref(h), None), "spblas_gfx950_create")
         self.h = h
 
+    def set_option(self, option, value):
+        check(_capi.lib().spblas_gfx950_set_option(self.h, option, value), "spblas_gfx950_set_option")
+
     @classmethod
     def current(cls, device):
         if device.type != "cuda":
@@ -241,11 +244,30 @@ class _Plan:
         self.handle, self.plan, self.key = handle, plan, key
 
     def info(self):
-        arr = (ctypes.c_int64 * 8)()
+        arr = (ctypes.c_int64 * 10)()
         check(_capi.lib().spblas_gfx950_plan_info(self.plan, arr), "spblas_gfx950_plan_info")
         names = ["alg", "window", "n_windows", "n_long_rows", "max_row_len", "device_bytes", "n_slices",
-                 "empty_rows"]
+                 "empty_rows", "rows_per_bin", "bin_aligned"]
         return dict(zip(names, list(arr)))
+
+    # two-stage execution of a SLICED plan (include/spblas_gfx950.h: spmv_expand / spmv_reduce_rows)
+    def bind_stages(self, x, y_base_ptr, dtype, alpha=1.0, beta=0.0):
+        """Returns (expand, reduce_rows) callables with every argument pre-bound; reduce_rows(lo, hi)
+        finishes the row-bins starting in [lo, hi).  y_base_ptr is the address of local row 0."""
+        lib = _capi.lib()
+        ct = _VT[dtype][1]
+        a, b = ct(alpha), ct(beta)
+        h, p, xp, yp = self.handle.h, self.plan, ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(y_base_ptr)
+        keep = (a, b, x)
+
+        def expand():
+            check(lib.spblas_gfx950_spmv_expand(h, p, xp), "spmv_expand")
+
+        def reduce_rows(lo, hi, _keep=keep):
+            check(lib.spblas_gfx950_spmv_reduce_rows(h, p, ctypes.byref(a), ctypes.byref(b), yp, lo, hi),
+                  "spmv_reduce_rows")
+
+        return expand, reduce_rows
 
     def update_values(self, values):
         """Refresh the plan after A's values changed in place (only the SLICED re-tiling keeps

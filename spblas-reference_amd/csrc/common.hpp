@@ -14,6 +14,7 @@ struct spblas_gfx950_handle_s {
   hipStream_t stream;
   int device;
   int num_cus;
+  int64_t bin_row_align = 0;  // SPBLAS_GFX950_OPT_BIN_ROW_ALIGN
 };
 
 namespace spb {

@@ -68,6 +68,18 @@ int spblas_gfx950_set_stream(spblas_gfx950_handle_t handle, void* stream) {
   return SPBLAS_GFX950_STATUS_SUCCESS;
 }
 
+int spblas_gfx950_set_option(spblas_gfx950_handle_t handle, int option, int64_t value) {
+  if (!handle)
+    return SPBLAS_GFX950_STATUS_INVALID_HANDLE;
+  if (option == SPBLAS_GFX950_OPT_BIN_ROW_ALIGN) {
+    if (value < 0)
+      return SPBLAS_GFX950_STATUS_INVALID_VALUE;
+    handle->bin_row_align = value;
+    return SPBLAS_GFX950_STATUS_SUCCESS;
+  }
+  return SPBLAS_GFX950_STATUS_INVALID_VALUE;
+}
+
 int spblas_gfx950_get_stream(spblas_gfx950_handle_t handle, void** stream) {
   if (!handle)
     return SPBLAS_GFX950_STATUS_INVALID_HANDLE;

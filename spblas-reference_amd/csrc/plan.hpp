@@ -41,7 +41,9 @@ struct spblas_gfx950_plan_s {
   void* s_perm = nullptr;      // int32[nnz] source position in the caller's CSR arrays
   void* s_products = nullptr;  // T[nnz] workspace: expanded products
   int n_ksplit = 1;            // reduce workgroups per bin group (slice split)
-  void* s_partial = nullptr;   // T[n_ksplit][m] partial sums when n_ksplit > 1
+  void* s_partial = nullptr;   // T[s_partial_k][m] partial sums (grown on demand)
+  int s_partial_k = 0;
+  int bin_aligned = 0;         // wave-bin height divides the handle's bin_row_align option
 
   size_t device_bytes = 0;
 };

@@ -359,14 +359,17 @@ static void launch_rowblock(hipStream_t s, const spblas_gfx950_plan_s* pl, const
                        ph, pt);
 }
 
-int spmv_sliced_exec(spblas_gfx950_handle_t h, const spblas_gfx950_plan_s* pl, const void* alpha,
-                     const void* x, const void* beta, void* y);
+int spmv_sliced_exec(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const void* alpha, const void* x,
+                     const void* beta, void* y);
+int spmv_sliced_expand(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const void* x);
+int spmv_sliced_reduce_rows(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const void* alpha, const void* beta,
+                            void* y, int64_t row_begin, int64_t row_end);
 int spmv_sliced_build(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const void* values, bool auto_mode);
 int spmv_sliced_update(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const void* values);
 void spmv_sliced_free(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl);
 
 template <typename T, typename O>
-static int spmv_typed(spblas_gfx950_handle_t h, const spblas_gfx950_plan_s* pl, int op, int64_t m, int64_t n,
+static int spmv_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, int op, int64_t m, int64_t n,
                       int64_t nnz, const void* alpha_p, const void* rowptr_p, const int32_t* colind,
                       const void* values_p, const void* x_p, const void* beta_p, void* y_p) {
   const T alpha = *static_cast<const T*>(alpha_p);
@@ -554,6 +557,31 @@ int spblas_gfx950_spmv_plan_update_values(spblas_gfx950_handle_t handle, spblas_
   return spmv_sliced_update(handle, plan, values);
 }
 
+int spblas_gfx950_spmv_expand(spblas_gfx950_handle_t handle, spblas_gfx950_plan_t plan, const void* x) {
+  if (!handle)
+    return SPBLAS_GFX950_STATUS_INVALID_HANDLE;
+  if (!plan || !x)
+    return SPBLAS_GFX950_STATUS_INVALID_POINTER;
+  if (plan->alg != SPBLAS_GFX950_SPMV_SLICED)
+    return SPBLAS_GFX950_STATUS_NOT_SUPPORTED;
+  if (plan->nnz == 0)
+    return SPBLAS_GFX950_STATUS_SUCCESS;
+  return spmv_sliced_expand(handle, plan, x);
+}
+
+int spblas_gfx950_spmv_reduce_rows(spblas_gfx950_handle_t handle, spblas_gfx950_plan_t plan, const void* alpha,
+                                   const void* beta, void* y, int64_t row_begin, int64_t row_end) {
+  if (!handle)
+    return SPBLAS_GFX950_STATUS_INVALID_HANDLE;
+  if (!plan || !alpha || !beta || !y)
+    return SPBLAS_GFX950_STATUS_INVALID_POINTER;
+  if (plan->alg != SPBLAS_GFX950_SPMV_SLICED)
+    return SPBLAS_GFX950_STATUS_NOT_SUPPORTED;
+  if (row_begin < 0 || row_end > plan->m || row_begin > row_end)
+    return SPBLAS_GFX950_STATUS_INVALID_SIZE;
+  return spmv_sliced_reduce_rows(handle, plan, alpha, beta, y, row_begin, row_end);
+}
+
 int spblas_gfx950_plan_destroy(spblas_gfx950_handle_t handle, spblas_gfx950_plan_t plan) {
   if (!handle)
     return SPBLAS_GFX950_STATUS_INVALID_HANDLE;
@@ -569,7 +597,7 @@ int spblas_gfx950_plan_destroy(spblas_gfx950_handle_t handle, spblas_gfx950_plan
   return SPBLAS_GFX950_STATUS_SUCCESS;
 }
 
-int spblas_gfx950_plan_info(spblas_gfx950_plan_t plan, int64_t info[8]) {
+int spblas_gfx950_plan_info(spblas_gfx950_plan_t plan, int64_t info[10]) {
   if (!plan || !info)
     return SPBLAS_GFX950_STATUS_INVALID_POINTER;
   info[0] = plan->alg;
@@ -580,6 +608,8 @@ int spblas_gfx950_plan_info(spblas_gfx950_plan_t plan, int64_t info[8]) {
   info[5] = (int64_t) plan->device_bytes;
   info[6] = plan->n_slices;
   info[7] = plan->empty_rows;
+  info[8] = plan->rows_per_blk;
+  info[9] = plan->bin_aligned;
   return SPBLAS_GFX950_STATUS_SUCCESS;
 }
 

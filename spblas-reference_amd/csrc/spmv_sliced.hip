@@ -252,7 +252,7 @@ __device__ __forceinline__ void pb_apply(T* acc, T p, int r, bool ok) {
 }
 
 template <typename T>
-__global__ __launch_bounds__(PB_RTHREADS) void pb_reduce_kernel(int64_t m, int Hw, int S, int64_t NBw,
+__global__ __launch_bounds__(PB_RTHREADS) void pb_reduce_kernel(int64_t m, int Hw, int S, int64_t wb_begin, int64_t NBw,
                                                                 const int2* __restrict__ segT,
                                                                 const T* __restrict__ P,
                                                                 const uint16_t* __restrict__ s_row,
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(PB_RTHREADS) void pb_reduce_kernel(int64_t m, int H
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   T* acc = reinterpret_cast<T*>(smem) + (size_t) wave * Hw;
-  const int64_t wb = (int64_t) blockIdx.x * PB_RWAVES + wave;
+  const int64_t wb = wb_begin + (int64_t) blockIdx.x * PB_RWAVES + wave;  // NBw = end of the bin range
   const int s_lo = blockIdx.y * s_per, s_hi = (s_lo + s_per) < S ? (s_lo + s_per) : S;
   if (wb >= NBw)
     return;
@@ -327,10 +327,11 @@ __global__ __launch_bounds__(PB_RTHREADS) void pb_reduce_kernel(int64_t m, int H
 
 // y = alpha * (partial[0] + partial[1] + ... in this fixed order) + beta * y
 template <typename T>
-__global__ __launch_bounds__(256) void pb_combine_kernel(int64_t m, int K, const T* __restrict__ partial,
-                                                         int64_t pstride, T* __restrict__ y, T alpha, T beta) {
-  const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
-  if (i >= m)
+__global__ __launch_bounds__(256) void pb_combine_kernel(int64_t r_lo, int64_t r_hi, int K,
+                                                         const T* __restrict__ partial, int64_t pstride,
+                                                         T* __restrict__ y, T alpha, T beta) {
+  const int64_t i = r_lo + (int64_t) blockIdx.x * 256 + threadIdx.x;
+  if (i >= r_hi)
     return;
   T s = partial[i];
   for (int k = 1; k < K; ++k)
@@ -339,6 +340,10 @@ __global__ __launch_bounds__(256) void pb_combine_kernel(int64_t m, int K, const
 }
 
 // ---- host -------------------------------------------------------------------------------
+static int pick_ksplit(int64_t groups, int S);
+static int pick_ksplit_fwd(int64_t groups, int S) {
+  return pick_ksplit(groups, S);
+}
 
 // number of pieces: enough that one piece fits the LDS budget; for big problems a multiple
 // of 512 (2 workgroups x 256 CUs) so the single wave of workgroups fills the chip evenly.
@@ -380,6 +385,21 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
   const int h_env = env_int("SPBLAS_GFX950_SLICE_ROWS", 0);
   pick_tiling(n, w_env > 0 && w_env < max_cols ? w_env : max_cols, 512, 4, &S, &W);
   pick_tiling(m, h_env > 0 && h_env < max_rows ? h_env : max_rows, 512 * PB_RWAVES, 1, &NB, &H);
+  if (h->bin_row_align > 1) {
+    // caller wants bin boundaries on multiples of bin_row_align (stripe boundaries of the overlapped
+    // multi-GPU step): use the largest divisor of it that fits the LDS budget, if a decent one exists
+    int best = 0;
+    for (int d = max_rows; d >= max_rows / 4 && d >= 1; --d)
+      if (h->bin_row_align % d == 0) {
+        best = d;
+        break;
+      }
+    if (best > 0) {
+      H = best;
+      NB = (int) cdiv(m, H);
+      pl->bin_aligned = 1;
+    }
+  }
   const int64_t nseg = (int64_t) S * NB;
   if (nseg > (int64_t) 64 << 20)
     return SPBLAS_GFX950_STATUS_NOT_SUPPORTED;
@@ -387,18 +407,7 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
   pl->slice_cols = W;
   pl->n_rblk = NB;
   pl->rows_per_blk = H;
-  {  // slice split: keep >= ~512 reduce workgroups in flight when there are few wave-bins
-    const int64_t groups = cdiv(NB, PB_RWAVES);
-    int K = env_int("SPBLAS_GFX950_PB_KSPLIT", 0);
-    if (K <= 0) {
-      K = 1;
-      while (groups * K < 384 && K < 32 && S / (2 * K) >= 8)
-        K *= 2;
-    }
-    if (K > S)
-      K = S;
-    pl->n_ksplit = K;
-  }
+  pl->n_ksplit = pick_ksplit_fwd(cdiv(NB, PB_RWAVES), S);
 
   int rc;
   int32_t* seg = nullptr;
@@ -442,11 +451,6 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
     return rc;
   if ((rc = dev_alloc((void**) &pl->s_segT, (size_t) nseg * sizeof(int2), s)))
     return rc;
-  if (pl->n_ksplit > 1) {
-    if ((rc = dev_alloc(&pl->s_partial, (size_t) pl->n_ksplit * m * sizeof(T), s)))
-      return rc;
-    pl->device_bytes += (size_t) pl->n_ksplit * m * sizeof(T);
-  }
   pl->device_bytes += (size_t) nnz * (2 * sizeof(T) + 8) + (size_t) nseg * 16;
   SPB_HIP(hipMemsetAsync(cursor, 0, (size_t) nseg * 4, s));
   scan_counts_i32(s, nseg, seg, partials);
@@ -494,34 +498,83 @@ int spmv_sliced_update(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const
                                              : sliced_update_typed<double>(h, pl, values);
 }
 
+static int pick_ksplit(int64_t groups, int S) {
+  int K = env_int("SPBLAS_GFX950_PB_KSPLIT", 0);
+  if (K <= 0) {
+    K = 1;
+    while (groups * K < 384 && K < 32 && S / (2 * K) >= 8)
+      K *= 2;
+  }
+  return K > S ? S : (K < 1 ? 1 : K);
+}
+
 template <typename T>
-static int sliced_exec_typed(spblas_gfx950_handle_t h, const spblas_gfx950_plan_s* pl, const void* alpha_p,
-                             const void* x, const void* beta_p, void* y) {
-  hipStream_t s = h->stream;
-  const T alpha = *static_cast<const T*>(alpha_p), beta = *static_cast<const T*>(beta_p);
+static int sliced_expand_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const void* x) {
   const int32_t* seg = reinterpret_cast<const int32_t*>(pl->seg_ptr);
   hipLaunchKernelGGL((pb_expand_kernel<T>), dim3((unsigned) pl->n_slices), dim3(PB_THREADS),
-                     (size_t) pl->slice_cols * sizeof(T), s, pl->n, pl->slice_cols, (int) pl->n_rblk, seg,
+                     (size_t) pl->slice_cols * sizeof(T), h->stream, pl->n, pl->slice_cols, (int) pl->n_rblk, seg,
                      static_cast<const T*>(pl->s_values), reinterpret_cast<const uint16_t*>(pl->s_colind),
                      static_cast<const T*>(x), static_cast<T*>(pl->s_products));
-  const int K = pl->n_ksplit;
+  SPB_HIP(hipGetLastError());
+  return SPBLAS_GFX950_STATUS_SUCCESS;
+}
+
+// rows of the wave-bins [wb_begin, wb_end):  y = alpha * (products of the last expand) + beta * y
+template <typename T>
+static int sliced_reduce_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const void* alpha_p,
+                               const void* beta_p, void* y, int64_t wb_begin, int64_t wb_end) {
+  hipStream_t s = h->stream;
+  if (wb_end <= wb_begin)
+    return SPBLAS_GFX950_STATUS_SUCCESS;
+  const T alpha = *static_cast<const T*>(alpha_p), beta = *static_cast<const T*>(beta_p);
+  const int64_t groups = cdiv(wb_end - wb_begin, PB_RWAVES);
+  const int K = pick_ksplit(groups, pl->n_slices);
   const int s_per = (int) cdiv(pl->n_slices, K);
-  hipLaunchKernelGGL((pb_reduce_kernel<T>), dim3((unsigned) cdiv(pl->n_rblk, PB_RWAVES), (unsigned) K),
-                     dim3(PB_RTHREADS), (size_t) PB_RWAVES * pl->rows_per_blk * sizeof(T), s, pl->m, pl->rows_per_blk,
-                     pl->n_slices, pl->n_rblk, static_cast<const int2*>(pl->s_segT),
-                     static_cast<const T*>(pl->s_products), pl->s_lrow, static_cast<T*>(y), alpha, beta, s_per,
+  const int64_t r_lo = wb_begin * pl->rows_per_blk;
+  const int64_t r_hi = wb_end * pl->rows_per_blk < pl->m ? wb_end * pl->rows_per_blk : pl->m;
+  if (K > 1 && pl->s_partial_k < K) {  // grow the partial-sum workspace (stream ordered)
+    dev_free(pl->s_partial, s);
+    pl->s_partial = nullptr;
+    int rc = dev_alloc(&pl->s_partial, (size_t) K * pl->m * sizeof(T), s);
+    if (rc)
+      return rc;
+    pl->s_partial_k = K;
+  }
+  hipLaunchKernelGGL((pb_reduce_kernel<T>), dim3((unsigned) groups, (unsigned) K), dim3(PB_RTHREADS),
+                     (size_t) PB_RWAVES * pl->rows_per_blk * sizeof(T), s, pl->m, pl->rows_per_blk, pl->n_slices,
+                     wb_begin, wb_end, static_cast<const int2*>(pl->s_segT), static_cast<const T*>(pl->s_products),
+                     pl->s_lrow, static_cast<T*>(y), alpha, beta, s_per,
                      K > 1 ? static_cast<T*>(pl->s_partial) : nullptr, pl->m);
-  if (K > 1)
-    hipLaunchKernelGGL((pb_combine_kernel<T>), dim3((unsigned) cdiv(pl->m, 256)), dim3(256), 0, s, pl->m, K,
+  if (K > 1 && r_hi > r_lo)
+    hipLaunchKernelGGL((pb_combine_kernel<T>), dim3((unsigned) cdiv(r_hi - r_lo, 256)), dim3(256), 0, s, r_lo, r_hi, K,
                        static_cast<const T*>(pl->s_partial), pl->m, static_cast<T*>(y), alpha, beta);
   SPB_HIP(hipGetLastError());
   return SPBLAS_GFX950_STATUS_SUCCESS;
 }
 
-int spmv_sliced_exec(spblas_gfx950_handle_t h, const spblas_gfx950_plan_s* pl, const void* alpha, const void* x,
+int spmv_sliced_expand(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const void* x) {
+  return pl->value_type == SPBLAS_GFX950_F32 ? sliced_expand_typed<float>(h, pl, x)
+                                             : sliced_expand_typed<double>(h, pl, x);
+}
+
+// bins whose first row lies in [row_begin, row_end)
+int spmv_sliced_reduce_rows(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const void* alpha, const void* beta,
+                            void* y, int64_t row_begin, int64_t row_end) {
+  const int64_t H = pl->rows_per_blk;
+  const int64_t wb0 = cdiv(row_begin, H);
+  int64_t wb1 = cdiv(row_end, H);
+  if (wb1 > pl->n_rblk)
+    wb1 = pl->n_rblk;
+  return pl->value_type == SPBLAS_GFX950_F32 ? sliced_reduce_typed<float>(h, pl, alpha, beta, y, wb0, wb1)
+                                             : sliced_reduce_typed<double>(h, pl, alpha, beta, y, wb0, wb1);
+}
+
+int spmv_sliced_exec(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const void* alpha, const void* x,
                      const void* beta, void* y) {
-  return pl->value_type == SPBLAS_GFX950_F32 ? sliced_exec_typed<float>(h, pl, alpha, x, beta, y)
-                                             : sliced_exec_typed<double>(h, pl, alpha, x, beta, y);
+  int rc = spmv_sliced_expand(h, pl, x);
+  if (rc)
+    return rc;
+  return spmv_sliced_reduce_rows(h, pl, alpha, beta, y, 0, pl->m);
 }
 
 void spmv_sliced_free(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl) {
@@ -535,6 +588,7 @@ void spmv_sliced_free(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl) {
   dev_free(pl->s_segT, s);
   dev_free(pl->s_partial, s);
   pl->s_partial = nullptr;
+  pl->s_partial_k = 0;
   pl->seg_ptr = pl->s_colind = pl->s_values = pl->s_products = pl->s_segT = pl->s_perm = nullptr;
   pl->s_lrow = nullptr;
   pl->n_slices = 0;

@@ -188,3 +188,79 @@ class PipelinedShardedSpMV:
         for w in works:
             w.wait()
         return self.y_full
+
+
+class OverlappedShardedSpMV:
+    """Row-sharded SpMV with ONE local plan whose reduce stage is overlapped with the all-gather.
+
+    Ownership is striped (striped_row_ranges): rank r's local matrix holds its `chunks` stripes back
+    to back (local rows [c*L, (c+1)*L) = global rows ranges[c][r]).  A step is
+        expand(x)                       every product once, x read once          (compute stream)
+        for c: reduce_rows(c*L,(c+1)*L)  finishes stripe c of y                   (compute stream)
+               all_gather(stripe c)      async on RCCL's stream, overlaps reduce of stripe c+1
+    The plan must be SLICED with row-bins aligned to L (handle option BIN_ROW_ALIGN); the
+    constructor raises otherwise and callers fall back to ShardedSpMV.  `stages(x)` may be injected
+    (CPU gloo tests): it returns (expand, reduce) with reduce(c, y_stripe_local)."""
+
+    def __init__(self, a_local, ranges, group=None, stages=None, alg=None):
+        self.group = group
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.ranges, self.chunks = ranges, len(ranges)
+        self.L = ranges[0][0][1] - ranges[0][0][0]
+        assert a_local.shape()[0] == self.L * self.chunks
+        self.m = ranges[-1][-1][1]
+        self.a_local = a_local
+        vals = a_local.values()
+        self.y_full = torch.zeros(self.m, dtype=vals.dtype, device=vals.device)
+        self.y_local = [self.y_full[ranges[c][self.rank][0]:ranges[c][self.rank][1]] for c in range(self.chunks)]
+        self.y_stripe = [self.y_full[ranges[c][0][0]:ranges[c][-1][1]] for c in range(self.chunks)]
+        self._stages, self._bound_x, self._bound = stages, None, None
+        self.info = api.operation_info_t()
+        if stages is None:
+            hd = api._Handle.current(vals.device)
+            hd.set_option(api._capi.OPT_BIN_ROW_ALIGN, self.L)
+            try:
+                x_probe = torch.empty(a_local.shape()[1], dtype=vals.dtype, device=vals.device)
+                kw = {} if alg is None else {"alg": alg}
+                self.info = api.multiply_inspect(a_local, x_probe, self.y_full[:a_local.shape()[0]], **kw)
+            finally:
+                hd.set_option(api._capi.OPT_BIN_ROW_ALIGN, 0)
+            pi = self.info.state_.info()
+            if pi["alg"] != api._capi.SPMV_SLICED or not pi["bin_aligned"]:
+                raise RuntimeError("OverlappedShardedSpMV needs a SLICED plan with stripe-aligned row bins")
+
+    def _bind(self, x):
+        if self._bound_x is not x:
+            if self._stages is not None:
+                expand, reduce = self._stages(x)
+                self._bound = (expand, [lambda c=c: reduce(c, self.y_local[c]) for c in range(self.chunks)])
+            else:
+                plan, item = self.info.state_, self.y_full.element_size()
+                expand, reducers = None, []
+                for c in range(self.chunks):
+                    # base such that local row r of stripe c lands at y_full[global_lo + (r - c*L)]
+                    base = self.y_local[c].data_ptr() - c * self.L * item
+                    e, red = plan.bind_stages(x, base, self.y_full.dtype)
+                    expand = expand or e
+                    reducers.append(lambda c=c, red=red: red(c * self.L, (c + 1) * self.L))
+                self._bound = (expand, reducers)
+            self._bound_x = x
+        return self._bound
+
+    def step(self, x, events=None):
+        expand, reducers = self._bind(x)
+        if events is not None:
+            events[0][0].record()
+        expand()
+        works = []
+        for c in range(self.chunks):
+            reducers[c]()
+            if events is not None and c == self.chunks - 1:
+                events[0][1].record()
+            if self.world > 1:
+                works.append(dist.all_gather_into_tensor(self.y_stripe[c], self.y_local[c], group=self.group,
+                                                         async_op=True))
+        for w in works:
+            w.wait()
+        return self.y_full

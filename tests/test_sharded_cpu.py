@@ -89,6 +89,54 @@ def _worker_pipelined(rank, world, port, out_dir):
         dist.destroy_process_group()
 
 
+def _worker_overlapped(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        m, n, nnz, chunks = 960, 500, 15000, 4
+        values, rowptr, colind, shape, _ = generate.generate_csr(m, n, nnz, seed=9)
+        t = torch.from_numpy
+        ranges = sharded.striped_row_ranges(m, world, chunks)
+        L = ranges[0][0][1] - ranges[0][0][0]
+        parts = [sharded.shard_csr(t(values), t(rowptr), t(colind), shape, *ranges[c][rank]) for c in range(chunks)]
+        # the rank's stripes back to back = its local matrix
+        lens = torch.cat([p.rowptr()[1:] - p.rowptr()[:-1] for p in parts])
+        rp = torch.zeros(L * chunks + 1, dtype=torch.int32)
+        rp[1:] = torch.cumsum(lens, 0)
+        a_local = sp.csr_view(torch.cat([p.values() for p in parts]), rp, torch.cat([p.colind() for p in parts]),
+                              (L * chunks, n), int(rp[-1]))
+        calls = []
+
+        def stages(x):  # oracle-backed stand-in for plan.bind_stages
+            state = {}
+
+            def expand():
+                state["y"] = oracle.spmv(tuple(a_local.shape()), a_local.rowptr().numpy(), a_local.colind().numpy(),
+                                         a_local.values().numpy(), x.numpy())
+                calls.append("E")
+
+            def reduce(c, y_stripe_local):
+                y_stripe_local.copy_(torch.from_numpy(state["y"][c * L:(c + 1) * L]))
+                calls.append(c)
+
+            return expand, reduce
+
+        op = sharded.OverlappedShardedSpMV(a_local, ranges, stages=stages)
+        x = t(np.random.default_rng(6).random(n).astype(np.float32))
+        y = op.step(x).numpy().copy()
+        assert calls == ["E", 0, 1, 2, 3]
+        assert np.array_equal(y, oracle.spmv(shape, rowptr, colind, values, x.numpy()))
+        np.save(os.path.join(out_dir, f"ovl_{rank}.npy"), np.array([1]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_overlapped_single_plan_striped_world2_gloo(tmp_path):
+    mp.spawn(_worker_overlapped, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ovl_0.npy").exists() and (tmp_path / "ovl_1.npy").exists()
+
+
 def test_pipelined_striped_all_gather_world2_gloo(tmp_path):
     mp.spawn(_worker_pipelined, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
     assert (tmp_path / "pipe_0.npy").exists() and (tmp_path / "pipe_1.npy").exists()
