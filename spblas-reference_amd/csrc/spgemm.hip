@@ -10,9 +10,10 @@
 // ub[i] = sum_{k in A_i} len(B_k) (number of products):
 //   bin 0: ub == 0                      empty row
 //   bin 1: ub <= 64     LDS hash 128    16 lanes / row, 16 rows / workgroup
-//   bin 2: ub <= 512    LDS hash 1024   one wavefront / row, 4 rows / workgroup
-//   bin 3: ub <= 4096   LDS hash 8192   one workgroup / row
-//   bin 4: ub  > 4096   dense bitmap (+ dense values) per workgroup in HBM
+//   bin 2: ub <= 256    LDS hash 512    one wavefront / row, 4 rows / workgroup
+//   bin 3: ub <= 1024   LDS hash 2048   two wavefronts / row, 2 rows / workgroup
+//   bin 4: ub <= 4096   LDS hash 8192   one workgroup / row
+//   bin 5: ub  > 4096   dense bitmap (+ dense values) per workgroup in HBM
 // Symbolic counts distinct keys; numeric accumulates with LDS float atomics, compacts,
 // rank-sorts the (unique) keys and writes colind/values in ascending column order.
 // Integer/byte traffic bound: algorithmic bytes = A + B once + C once.
@@ -21,14 +22,14 @@
 
 #include <new>
 
-#define SPG_NBINS 5
+#define SPG_NBINS 6
 
 struct spblas_gfx950_spgemm_s {
   int64_t m = 0, k = 0, n = 0, a_nnz = 0, b_nnz = 0, c_nnz = -1;
   const int32_t *a_rowptr = nullptr, *a_colind = nullptr, *b_rowptr = nullptr, *b_colind = nullptr;
   int32_t* rowptr = nullptr;  // [m+1] device copy of C's row offsets
   int32_t* perm = nullptr;    // [m] rows grouped by bin
-  int64_t bin_off[SPG_NBINS + 1] = {0, 0, 0, 0, 0, 0};
+  int64_t bin_off[SPG_NBINS + 1] = {0, 0, 0, 0, 0, 0, 0};
   int sub = 16;  // lanes cooperating on one B row
   // bin-4 workspace
   int dense_blocks = 0;
@@ -44,11 +45,13 @@ __device__ __forceinline__ int spg_bin_of(int64_t ub) {
     return 0;
   if (ub <= 64)
     return 1;
-  if (ub <= 512)
+  if (ub <= 256)
     return 2;
-  if (ub <= 4096)
+  if (ub <= 1024)
     return 3;
-  return 4;
+  if (ub <= 4096)
+    return 4;
+  return 5;
 }
 
 // ub per row (8 lanes per row) + per-bin row counts.
@@ -84,10 +87,22 @@ __global__ __launch_bounds__(256) void spg_bound_kernel(int64_t m, const int32_t
 __global__ __launch_bounds__(256) void spg_fill_perm_kernel(int64_t m, const int32_t* __restrict__ bin_of_row,
                                                             unsigned long long* __restrict__ cursor,
                                                             int32_t* __restrict__ perm) {
+  // wave-aggregated append: one global atomic per (wave, bin) instead of one per row -- with
+  // uniform inputs every row lands in the same bin and per-row atomics serialise (12 ms at 1M rows)
   const int64_t row = (int64_t) blockIdx.x * 256 + threadIdx.x;
-  if (row < m) {
-    const unsigned long long slot = atomicAdd(&cursor[bin_of_row[row]], 1ull);
-    perm[slot] = (int32_t) row;
+  const int lane = threadIdx.x & 63;
+  const int bin = row < m ? bin_of_row[row] : -1;
+  for (int b = 0; b < SPG_NBINS; ++b) {
+    const unsigned long long mask = __ballot(bin == b);
+    if (mask == 0)
+      continue;
+    unsigned long long base = 0;
+    const int leader = __builtin_ctzll(mask);
+    if (lane == leader)
+      base = atomicAdd(&cursor[b], (unsigned long long) __popcll(mask));
+    base = __shfl(base, leader);
+    if (bin == b)
+      perm[base + __popcll(mask & ((1ull << lane) - 1ull))] = (int32_t) row;
   }
 }
 
@@ -104,14 +119,16 @@ __global__ __launch_bounds__(256) void spg_hash_kernel(
     int64_t count, const int32_t* __restrict__ perm, const int32_t* __restrict__ a_rowptr,
     const int32_t* __restrict__ a_colind, const T* __restrict__ a_values, const int32_t* __restrict__ b_rowptr,
     const int32_t* __restrict__ b_colind, const T* __restrict__ b_values, int32_t* __restrict__ c_rowptr,
-    int32_t* __restrict__ c_colind, T* __restrict__ c_values, T alpha, int sub) {
+    int32_t* __restrict__ c_colind, T* __restrict__ c_values, T alpha, int sub, long long ncols) {
   constexpr int HS = 1 << LOG2HS;
   constexpr int RPB = 256 / TPR;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   int* keys = reinterpret_cast<int*>(smem);                            // [RPB][HS]
   int* cnt = keys + RPB * HS;                                          // [RPB] (+ pad to 4)
   T* vals = reinterpret_cast<T*>(cnt + ((RPB + 3) & ~3) + (sizeof(T) == 8 ? 0 : 0));  // [RPB][HS]
-  int* list = NUMERIC ? reinterpret_cast<int*>(vals + RPB * HS) : nullptr;  // [RPB][HS/2] compacted slots
+  int* list = NUMERIC ? reinterpret_cast<int*>(vals + RPB * HS) : nullptr;  // [RPB][HS/2] compacted keys
+  // then [RPB][HS/2] compacted values (T), then the sort workspace [RPB][2*NBK+2] ints
+  int* sortws = NUMERIC ? reinterpret_cast<int*>(reinterpret_cast<T*>(list + RPB * (HS / 2)) + RPB * (HS / 2)) : nullptr;
 
   const int team = threadIdx.x / TPR;
   const int lt = threadIdx.x % TPR;
@@ -133,57 +150,144 @@ __global__ __launch_bounds__(256) void spg_hash_kernel(
   if (live) {
     const int p0 = a_rowptr[row], p1 = a_rowptr[row + 1];
     const int sg = lt / sub, sl = lt % sub, nsg = TPR / sub;
-    for (int p = p0 + sg; p < p1; p += nsg) {
-      const int kk = a_colind[p];
-      T av = T(0);
+    auto insert = [&](int col, T prod) {
+      unsigned slot = spg_hash(col, LOG2HS);
+      while (true) {
+        const int old = atomicCAS(&tkeys[slot], -1, col);
+        if (old == -1 || old == col)
+          break;
+        slot = (slot + 1) & (HS - 1);
+      }
       if (NUMERIC)
-        av = alpha * a_values[p];
-      const int q1 = b_rowptr[kk + 1];
-      for (int q = b_rowptr[kk] + sl; q < q1; q += sub) {
-        const int col = b_colind[q];
-        unsigned slot = spg_hash(col, LOG2HS);
-        while (true) {
-          const int old = atomicCAS(&tkeys[slot], -1, col);
-          if (old == -1) {
-            if (!NUMERIC)
-              atomicAdd(&cnt[team], 1);
-            break;
-          }
-          if (old == col)
-            break;
-          slot = (slot + 1) & (HS - 1);
+        unsafeAtomicAdd(&tvals[slot], prod);
+    };
+    if constexpr (TPR <= 64) {
+      // The team lives in one wavefront: every lane first fetches ONE entry of the A row (column,
+      // B-row bounds, scaled value) so that the three dependent loads a_colind -> b_rowptr ->
+      // b_colind are not serialised per B row; the sub-groups then pick entries up by shuffle.
+      const int tbase = (threadIdx.x & 63) - lt;  // first lane of the team in its wave
+      for (int pc = p0; pc < p1; pc += TPR) {
+        int qb = 0, qe = 0;
+        T av = T(0);
+        if (pc + lt < p1) {
+          const int kk = a_colind[pc + lt];
+          qb = b_rowptr[kk];
+          qe = b_rowptr[kk + 1];
+          if (NUMERIC)
+            av = alpha * a_values[pc + lt];
         }
-        if (NUMERIC)
-          unsafeAtomicAdd(&tvals[slot], av * b_values[q]);
+        const int cnt = (p1 - pc) < TPR ? (p1 - pc) : TPR;
+        // team-uniform trip count: a lane that left the loop would read as 0 in the shuffles
+        for (int j0 = 0; j0 < cnt; j0 += nsg) {
+          const int j = j0 + sg;
+          const int src = tbase + (j < cnt ? j : 0);
+          const int q0 = __shfl(qb, src);
+          const int q1s = __shfl(qe, src);  // unconditional: every lane of the team must take part
+          const int q1 = j < cnt ? q1s : q0;
+          const T a = NUMERIC ? __shfl(av, src) : T(0);
+          for (int q = q0 + sl; q < q1; q += sub)
+            insert(b_colind[q], NUMERIC ? a * b_values[q] : T(0));
+        }
+      }
+    } else {
+      for (int p = p0 + sg; p < p1; p += nsg) {
+        const int kk = a_colind[p];
+        const T av = NUMERIC ? alpha * a_values[p] : T(0);
+        const int q1 = b_rowptr[kk + 1];
+        for (int q = b_rowptr[kk] + sl; q < q1; q += sub)
+          insert(b_colind[q], NUMERIC ? av * b_values[q] : T(0));
       }
     }
   }
   __syncthreads();
 
+  // Occupied slots are counted / compacted in lockstep chunks of TPR slots.  A team of <= 64 lanes
+  // lives inside one wavefront, so a ballot gives every lane the team's occupancy mask and the
+  // running offset stays in a register; a 256-lane team adds one LDS atomic per wave and chunk.
+  const int wl = threadIdx.x & 63;                         // lane in wave
+  const int tshift = TPR >= 64 ? 0 : (wl / TPR) * TPR;     // first lane of the team in its wave
+  const unsigned long long tmask = TPR >= 64 ? ~0ull : (((1ull << (TPR & 63)) - 1ull) << tshift);
+  int* ckeys = NUMERIC ? list + team * (HS / 2) : nullptr;  // compacted keys
+  T* cvals = NUMERIC ? reinterpret_cast<T*>(list + RPB * (HS / 2)) + team * (HS / 2) : nullptr;
+  int running = 0;
+  for (int i0 = 0; i0 < HS; i0 += TPR) {
+    const int i = i0 + lt;
+    const int key = tkeys[i];
+    const bool occ = live && key != -1;
+    const unsigned long long mask = __ballot(occ) & tmask;
+    int base = running;
+    if (TPR > 64) {
+      int wbase = 0;
+      if (wl == 0 && mask)
+        wbase = atomicAdd(&cnt[team], (int) __popcll(mask));
+      base = __shfl(wbase, 0);
+    }
+    if (NUMERIC && occ) {
+      const int pos = base + (int) __popcll(mask & ((1ull << wl) - 1ull));
+      ckeys[pos] = key;
+      cvals[pos] = tvals[i];
+    }
+    running += (int) __popcll(mask);
+  }
+  if (TPR > 64)
+    __syncthreads();
+  const int d = TPR > 64 ? cnt[team] : running;
   if (!NUMERIC) {
     if (live && lt == 0)
-      c_rowptr[row] = cnt[team];
+      c_rowptr[row] = d;
     return;
   } else {
-    // compact occupied slots (order irrelevant: keys are unique, ranks decide)
-    int* tlist = list + team * (HS / 2);
-    if (live) {
-      for (int i = lt; i < HS; i += TPR)
-        if (tkeys[i] != -1)
-          tlist[atomicAdd(&cnt[team], 1)] = i;
+    // Sort the d unique keys: bucket them by column range (monotone, NBK buckets, LDS integer
+    // atomics are fast), then rank each key inside its bucket only.  Uniform columns give buckets
+    // of d/NBK keys; the worst case (one bucket) degrades to the plain O(d^2) rank sort.
+    constexpr int NBK = TPR < 64 ? TPR : 64;
+    int* bcnt = sortws + team * (2 * NBK + 2);  // [NBK+1] counts -> offsets
+    int* bfill = bcnt + NBK + 1;                // [NBK] cursors
+    __syncthreads();
+    if (lt <= NBK)
+      bcnt[lt] = 0;
+    if (lt < NBK)
+      bfill[lt] = 0;
+    __syncthreads();
+    if (live)
+      for (int e = lt; e < d; e += TPR)
+        atomicAdd(&bcnt[(int) (((long long) ckeys[e] * NBK) / ncols)], 1);
+    __syncthreads();
+    if (live && lt < NBK) {  // exclusive scan over the buckets inside the first NBK lanes of the team
+      const int c = bcnt[lt];
+      int incl = c;
+      for (int o = 1; o < NBK; o <<= 1) {
+        const int t = __shfl_up(incl, o, NBK);
+        if (lt >= o)
+          incl += t;
+      }
+      bcnt[lt] = incl - c;
+      if (lt == NBK - 1)
+        bcnt[NBK] = incl;
     }
     __syncthreads();
+    int* skeys = tkeys;  // the hash table is dead after compaction: reuse it for the bucketed copy
+    T* svals = tvals;
+    if (live)
+      for (int e = lt; e < d; e += TPR) {
+        const int key = ckeys[e];
+        const int bk = (int) (((long long) key * NBK) / ncols);
+        const int pos = bcnt[bk] + atomicAdd(&bfill[bk], 1);
+        skeys[pos] = key;
+        svals[pos] = cvals[e];
+      }
+    __syncthreads();
     if (live) {
-      const int d = cnt[team];
       const int out0 = c_rowptr[row];
       for (int e = lt; e < d; e += TPR) {
-        const int slot = tlist[e];
-        const int key = tkeys[slot];
-        int rank = 0;
-        for (int j = 0; j < d; ++j)
-          rank += tkeys[tlist[j]] < key;
+        const int key = skeys[e];
+        const int bk = (int) (((long long) key * NBK) / ncols);
+        const int b0 = bcnt[bk], b1 = bcnt[bk + 1];
+        int rank = b0;
+        for (int j = b0; j < b1; ++j)
+          rank += skeys[j] < key;
         c_colind[out0 + rank] = key;
-        c_values[out0 + rank] = tvals[slot];
+        c_values[out0 + rank] = svals[e];
       }
     }
   }
@@ -284,7 +388,7 @@ static size_t hash_smem_bytes() {
   constexpr int RPB = 256 / TPR;
   size_t b = (size_t) RPB * HS * 4 + (size_t) ((RPB + 3) & ~3) * 4;
   if (NUMERIC)
-    b += (size_t) RPB * HS * sizeof(T) + (size_t) RPB * (HS / 2) * 4;
+    b += (size_t) RPB * HS * sizeof(T) + (size_t) RPB * (HS / 2) * (4 + sizeof(T)) + (size_t) RPB * (2 * 64 + 2) * 4;
   else
     b += 16;
   return b;
@@ -305,7 +409,7 @@ static int launch_hash(hipStream_t s, const spblas_gfx950_spgemm_s* st, int bin,
   int sub = st->sub < TPR ? st->sub : TPR;
   hipLaunchKernelGGL(kern, dim3((unsigned) cdiv(count, RPB)), dim3(256), smem, s, count,
                      st->perm + st->bin_off[bin], st->a_rowptr, st->a_colind, a_values, st->b_rowptr,
-                     st->b_colind, b_values, c_rowptr, c_colind, c_values, alpha, sub);
+                     st->b_colind, b_values, c_rowptr, c_colind, c_values, alpha, sub, (long long) (st->n > 0 ? st->n : 1));
   SPB_HIP(hipGetLastError());
   return SPBLAS_GFX950_STATUS_SUCCESS;
 }
@@ -317,11 +421,13 @@ static int run_bins(spblas_gfx950_handle_t h, spblas_gfx950_spgemm_s* st, const 
   int rc;
   if ((rc = launch_hash<T, 7, 16, NUMERIC>(s, st, 1, a_values, b_values, c_rowptr, c_colind, c_values, alpha)))
     return rc;
-  if ((rc = launch_hash<T, 10, 64, NUMERIC>(s, st, 2, a_values, b_values, c_rowptr, c_colind, c_values, alpha)))
+  if ((rc = launch_hash<T, 9, 64, NUMERIC>(s, st, 2, a_values, b_values, c_rowptr, c_colind, c_values, alpha)))
     return rc;
-  if ((rc = launch_hash<T, 13, 256, NUMERIC>(s, st, 3, a_values, b_values, c_rowptr, c_colind, c_values, alpha)))
+  if ((rc = launch_hash<T, 11, 128, NUMERIC>(s, st, 3, a_values, b_values, c_rowptr, c_colind, c_values, alpha)))
     return rc;
-  const int64_t cnt4 = st->bin_off[5] - st->bin_off[4];
+  if ((rc = launch_hash<T, 13, 256, NUMERIC>(s, st, 4, a_values, b_values, c_rowptr, c_colind, c_values, alpha)))
+    return rc;
+  const int64_t cnt4 = st->bin_off[6] - st->bin_off[5];
   if (cnt4 > 0) {
     const int64_t nwords = (st->n + 31) / 32;
     if (!st->dense_bits) {
@@ -339,7 +445,7 @@ static int run_bins(spblas_gfx950_handle_t h, spblas_gfx950_spgemm_s* st, const 
       st->dense_vals_type = (int) sizeof(T);
     }
     hipLaunchKernelGGL((spg_dense_kernel<T, NUMERIC>), dim3((unsigned) st->dense_blocks), dim3(256), 0, s, cnt4,
-                       st->perm + st->bin_off[4], st->n, st->a_rowptr, st->a_colind, a_values, st->b_rowptr,
+                       st->perm + st->bin_off[5], st->n, st->a_rowptr, st->a_colind, a_values, st->b_rowptr,
                        st->b_colind, b_values, c_rowptr, c_colind, c_values, alpha, st->dense_bits,
                        static_cast<T*>(st->dense_vals));
     SPB_HIP(hipGetLastError());

@@ -11,7 +11,7 @@ python3 - <<PY
 import csv,glob
 f=glob.glob("$OUT/**/*kernel_stats.csv",recursive=True)[0]
 for i,r in enumerate(csv.DictReader(open(f))):
-    if i>=8: break
+    if i>=${TOPN:-8}: break
     print(f"{r['Name'].split('(')[0][-70:]:70s} calls={r['Calls']:>4s} avg_us={float(r['AverageNs'])/1e3:9.1f} min_us={float(r['MinNs'])/1e3:9.1f}")
 PY
 grep -o '"value": [0-9.]*' $OUT/run.log | head -1
