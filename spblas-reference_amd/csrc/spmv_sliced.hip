@@ -49,43 +49,62 @@ static constexpr int PB_RWAVES = PB_RTHREADS / 64;
 static constexpr int PB_LDS_BYTES = 80 * 1024;  // two workgroups per CU (160 KiB LDS)
 
 // ---- inspect --------------------------------------------------------------------------
-// one 8-lane group per CSR row: count entries per (slice, bin)
+// One workgroup per wave-bin: all entries of the bin's rows share wb, so the per-slice counts
+// live in an LDS histogram and are written out without any global atomic (the first version
+// issued one global atomic per entry: 3.7 ms + 6.7 ms at cfg2).
 template <typename O>
 __global__ __launch_bounds__(256) void pb_count_kernel(int64_t m, const O* __restrict__ rowptr,
-                                                       const int32_t* __restrict__ colind, int W, int H, int NB,
+                                                       const int32_t* __restrict__ colind, int W, int H, int S, int NB,
                                                        int32_t* __restrict__ cnt) {
-  const int64_t row = (int64_t) blockIdx.x * 32 + threadIdx.x / 8;
-  const int lane = threadIdx.x % 8;
-  if (row >= m)
-    return;
-  const int b = (int) (row / H);
-  for (O p = rowptr[row] + lane; p < rowptr[row + 1]; p += 8) {
-    const int s = colind[p] / W;
-    atomicAdd(&cnt[(int64_t) s * NB + b], 1);
+  extern __shared__ int hist[];  // [S]
+  const int wb = blockIdx.x;
+  for (int i = threadIdx.x; i < S; i += 256)
+    hist[i] = 0;
+  __syncthreads();
+  const int64_t r0 = (int64_t) wb * H, r1 = (r0 + H) < m ? (r0 + H) : m;
+  if (r0 < m) {
+    const O p0 = rowptr[r0], p1 = rowptr[r1];
+    for (O p = p0 + threadIdx.x; p < p1; p += 256)
+      atomicAdd(&hist[colind[p] / W], 1);
   }
+  __syncthreads();
+  for (int i = threadIdx.x; i < S; i += 256)
+    cnt[(int64_t) i * NB + wb] = hist[i];
 }
 
+// Same ownership for the scatter: LDS cursors start at the runs' offsets; the row of entry p is
+// found by a binary search in the bin's slice of rowptr (<= 12 probes, L1/L2 resident).
 template <typename T, typename O>
 __global__ __launch_bounds__(256) void pb_scatter_kernel(int64_t m, const O* __restrict__ rowptr,
                                                          const int32_t* __restrict__ colind,
-                                                         const T* __restrict__ values, int W, int H, int NB,
-                                                         const int32_t* __restrict__ seg, int32_t* __restrict__ cursor,
-                                                         T* __restrict__ s_val, uint16_t* __restrict__ s_col,
-                                                         uint16_t* __restrict__ s_row, int32_t* __restrict__ perm) {
-  const int64_t row = (int64_t) blockIdx.x * 32 + threadIdx.x / 8;
-  const int lane = threadIdx.x % 8;
-  if (row >= m)
+                                                         const T* __restrict__ values, int W, int H, int S, int NB,
+                                                         const int32_t* __restrict__ seg, T* __restrict__ s_val,
+                                                         uint16_t* __restrict__ s_col, uint16_t* __restrict__ s_row,
+                                                         int32_t* __restrict__ perm) {
+  extern __shared__ int cursor[];  // [S]
+  const int wb = blockIdx.x;
+  for (int i = threadIdx.x; i < S; i += 256)
+    cursor[i] = seg[(int64_t) i * NB + wb];
+  __syncthreads();
+  const int64_t r0 = (int64_t) wb * H, r1 = (r0 + H) < m ? (r0 + H) : m;
+  if (r0 >= m)
     return;
-  const int b = (int) (row / H);
-  const uint16_t lr = (uint16_t) (row - (int64_t) b * H);
-  for (O p = rowptr[row] + lane; p < rowptr[row + 1]; p += 8) {
+  const O p0 = rowptr[r0], p1 = rowptr[r1];
+  for (O p = p0 + threadIdx.x; p < p1; p += 256) {
+    int64_t lo = r0, hi = r1;  // last row with rowptr[row] <= p
+    while (hi - lo > 1) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (rowptr[mid] <= p)
+        lo = mid;
+      else
+        hi = mid;
+    }
     const int c = colind[p];
-    const int s = c / W;
-    const int64_t key = (int64_t) s * NB + b;
-    const int i = seg[key] + atomicAdd(&cursor[key], 1);
+    const int sl = c / W;
+    const int i = atomicAdd(&cursor[sl], 1);
     s_val[i] = values[p];
-    s_col[i] = (uint16_t) (c - s * W);
-    s_row[i] = lr;
+    s_col[i] = (uint16_t) (c - sl * W);
+    s_row[i] = (uint16_t) (lo - r0);
     perm[i] = (int32_t) p;
   }
 }
@@ -401,7 +420,7 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
     }
   }
   const int64_t nseg = (int64_t) S * NB;
-  if (nseg > (int64_t) 64 << 20)
+  if (nseg > (int64_t) 64 << 20 || S > 16384)  // S ints of LDS per inspect workgroup
     return SPBLAS_GFX950_STATUS_NOT_SUPPORTED;
   pl->n_slices = S;
   pl->slice_cols = W;
@@ -411,15 +430,14 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
 
   int rc;
   int32_t* seg = nullptr;
-  int32_t* cursor = nullptr;
   long long* partials = nullptr;
   if ((rc = dev_alloc((void**) &seg, (size_t) (nseg + 1) * 4, s)))
     return rc;
   pl->seg_ptr = seg;
   SPB_HIP(hipMemsetAsync(seg, 0, (size_t) (nseg + 1) * 4, s));
   const O* rowptr = static_cast<const O*>(pl->rowptr);
-  const unsigned grid = (unsigned) cdiv(m, 32);
-  hipLaunchKernelGGL((pb_count_kernel<O>), dim3(grid), dim3(256), 0, s, m, rowptr, pl->colind, W, H, NB, seg);
+  hipLaunchKernelGGL((pb_count_kernel<O>), dim3((unsigned) NB), dim3(256), (size_t) S * 4, s, m, rowptr, pl->colind, W, H, S,
+                     NB, seg);
   if (auto_mode) {
     // AUTO only: a matrix whose entries cluster in few (slice, bin) tiles (banded, block
     // structured) already gets its x reuse from L2 with the CSR kernels -- decline.
@@ -435,8 +453,6 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
     if ((double) ne < 0.25 * (double) nseg)
       return SPBLAS_GFX950_STATUS_NOT_SUPPORTED;
   }
-  if ((rc = dev_alloc((void**) &cursor, (size_t) nseg * 4, s)))
-    return rc;
   if ((rc = dev_alloc((void**) &partials, (size_t) (cdiv(nseg, 2048) + 2) * sizeof(long long), s)))
     return rc;
   if ((rc = dev_alloc((void**) &pl->s_values, (size_t) nnz * sizeof(T), s)))
@@ -452,10 +468,9 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
   if ((rc = dev_alloc((void**) &pl->s_segT, (size_t) nseg * sizeof(int2), s)))
     return rc;
   pl->device_bytes += (size_t) nnz * (2 * sizeof(T) + 8) + (size_t) nseg * 16;
-  SPB_HIP(hipMemsetAsync(cursor, 0, (size_t) nseg * 4, s));
   scan_counts_i32(s, nseg, seg, partials);
-  hipLaunchKernelGGL((pb_scatter_kernel<T, O>), dim3(grid), dim3(256), 0, s, m, rowptr, pl->colind,
-                     static_cast<const T*>(values_p), W, H, NB, seg, cursor, static_cast<T*>(pl->s_values),
+  hipLaunchKernelGGL((pb_scatter_kernel<T, O>), dim3((unsigned) NB), dim3(256), (size_t) S * 4, s, m, rowptr,
+                     pl->colind, static_cast<const T*>(values_p), W, H, S, NB, seg, static_cast<T*>(pl->s_values),
                      reinterpret_cast<uint16_t*>(pl->s_colind), pl->s_lrow, reinterpret_cast<int32_t*>(pl->s_perm));
   hipLaunchKernelGGL(pb_transpose_seg_kernel, dim3((unsigned) cdiv(nseg, 256)), dim3(256), 0, s, S, NB, seg,
                      static_cast<int2*>(pl->s_segT));
@@ -463,7 +478,6 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
                      (size_t) PB_RWAVES * H, s, H, S, (int64_t) NB, static_cast<const int2*>(pl->s_segT), pl->s_lrow);
   SPB_HIP(hipGetLastError());
   SPB_HIP(hipStreamSynchronize(s));
-  dev_free(cursor, s);
   dev_free(partials, s);
   // both kernels may use up to 80 KiB of dynamic LDS
   SPB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pb_expand_kernel<T>),
