@@ -181,6 +181,16 @@ int spblas_gfx950_spgemm_numeric(spblas_gfx950_handle_t handle, spblas_gfx950_sp
                                  int32_t* c_rowptr, int32_t* c_colind, void* c_values, int64_t c_capacity,
                                  int value_type);
 
+/* ---- transpose:  B = A^T  (CSR -> CSR, int32 indices) ------------------------------------ */
+/* Device counterpart of transpose(a, b) (algorithms/transpose_impl.hpp:14-53): stable counting
+ * sort by column, so every output row lists its entries in source order.  t_rowptr has n+1
+ * entries, t_colind / t_values nnz entries, all caller-allocated device memory.  Also what
+ * multiply_inspect uses to serve csc_view / transposed(csr) operands with the regular kernels
+ * (vendor/rocsparse/detail/get_transpose.hpp:19-29 maps CSC to a transposed CSR operation). */
+int spblas_gfx950_csr_transpose(spblas_gfx950_handle_t handle, int64_t m, int64_t n, int64_t nnz,
+                                const int32_t* rowptr, const int32_t* colind, const void* values,
+                                int32_t* t_rowptr, int32_t* t_colind, void* t_values, int value_type);
+
 #ifdef __cplusplus
 }
 #endif

@@ -478,6 +478,32 @@ void multiply(A&& a, X&& x, Y&& y) {
   multiply(info, a, x, y);
 }
 
+// ---- transpose (algorithms/transpose_impl.hpp:9-61) -------------------------------------------
+template <typename A, typename B>
+operation_info_t transpose_inspect(A&&, B&&) {
+  return {};
+}
+
+template <typename T, typename I, typename O>
+void transpose(csr_view<T, I, O> a, csr_view<T, I, O>& b) {
+  if (a.shape()[0] != b.shape()[1] || a.shape()[1] != b.shape()[0]) {
+    throw std::invalid_argument("transpose: matrix dimensions are incompatible.");
+  }
+  if (b.values().size() < static_cast<std::size_t>(a.size()) ||
+      b.colind().size() < static_cast<std::size_t>(a.size())) {
+    throw std::runtime_error("transpose: Transpose ran out of memory.");
+  }
+  __gfx950::handle_t h;
+  __gfx950::csr_transpose<T>(h, a.shape()[0], a.shape()[1], a.size(), a.rowptr().data(), a.colind().data(),
+                             a.values().data(), b.rowptr().data(), b.colind().data(), b.values().data());
+  b.update(b.values(), b.rowptr(), b.colind(), b.shape(), a.size());
+}
+
+template <typename T, typename I, typename O>
+void transpose(operation_info_t&, csr_view<T, I, O> a, csr_view<T, I, O>& b) {
+  transpose(a, b);
+}
+
 // ---- SpGEMM ----------------------------------------------------------------------------------
 class spgemm_state_t {
 public:

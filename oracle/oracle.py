@@ -210,3 +210,27 @@ def spmv_absrow(rowptr, colind, values, x):
     fn.restype = None
     fn(c_i64(out.shape[0]), _p(rowptr), _p(colind), _p(values), _p(x), _p(out))
     return out
+
+
+def transpose(shape, rowptr, colind, values, b_shape=None, capacity=None):
+    """Reference transpose(a, b) (algorithms/transpose_impl.hpp:14-53): returns CSR arrays of A^T."""
+    lib = load()
+    rowptr, colind, values = _csr_args(rowptr, colind, values)
+    rowptr = rowptr.astype(np.int32, copy=False)
+    m, n = shape
+    if b_shape is None:
+        b_shape = (n, m)
+    nnz = int(rowptr[-1])
+    if capacity is None:
+        capacity = nnz
+    t_rowptr = np.zeros(b_shape[0] + 1, dtype=np.int32)
+    t_colind = np.zeros(max(capacity, 1), dtype=np.int32)
+    t_values = np.zeros(max(capacity, 1), dtype=values.dtype)
+    fn = getattr(lib, "oracle_transpose_" + _sfx(values.dtype))
+    fn.restype = c_int
+    rc = fn(c_i64(m), c_i64(n), c_i64(b_shape[0]), c_i64(b_shape[1]), _p(rowptr), _p(colind), _p(values),
+            c_i64(capacity), _p(t_rowptr), _p(t_colind), _p(t_values))
+    if rc == 2:
+        raise RuntimeError("transpose: Transpose ran out of memory.")
+    _raise(rc)
+    return t_rowptr, t_colind[:nnz], t_values[:nnz]

@@ -312,3 +312,44 @@ DEF_SPGEMM_NUMERIC(oracle_spgemm_numeric_f64, double)
   }
 DEF_ABSROW(oracle_spmv_absrow_f32, float)
 DEF_ABSROW(oracle_spmv_absrow_f64, double)
+
+/* ------------------------------------------------------------------------ */
+/* transpose(a, b): B = A^T, CSR -> CSR (algorithms/transpose_impl.hpp:14-53). */
+/* Counting sort by column: count (:37-41), exclusive scan (:43), then place    */
+/* each entry in row-major source order (:45-52) -> every output row lists its */
+/* entries in source order.  Shape mismatch -> ERR_SHAPE (:17-21), too little   */
+/* room -> ERR_NOSPACE ("Transpose ran out of memory", :22-25).                */
+/* (also the oracle for CSC-operand SpMV plans.)     */
+/* ------------------------------------------------------------------------ */
+#define DEF_TRANSPOSE(NAME, T)                                                 \
+  int NAME(int64_t m, int64_t n, int64_t b_rows, int64_t b_cols,               \
+           const int32_t* rowptr, const int32_t* colind, const T* values,      \
+           int64_t capacity, int32_t* t_rowptr, int32_t* t_colind,             \
+           T* t_values) {                                                      \
+    if (m != b_cols || n != b_rows)                                            \
+      return ORACLE_ERR_SHAPE;                                                 \
+    const int64_t nnz = rowptr[m];                                             \
+    if (capacity < nnz)                                                        \
+      return ORACLE_ERR_NOSPACE;                                               \
+    for (int64_t j = 0; j <= n; j++)                                           \
+      t_rowptr[j] = 0;                                                         \
+    for (int64_t p = 0; p < nnz; p++)                                          \
+      t_rowptr[colind[p] + 1]++;                                               \
+    int32_t run = 0;                                                           \
+    for (int64_t j = 0; j <= n; j++) { /* exclusive scan */                    \
+      int32_t c = t_rowptr[j];                                                 \
+      t_rowptr[j] = run;                                                       \
+      run += c;                                                                \
+    }                                                                          \
+    /* after the scan t_rowptr[j+1] = start of row j; the reference uses it    \
+       as the insertion cursor, which leaves t_rowptr[j+1] = end of row j */   \
+    for (int64_t i = 0; i < m; i++)                                            \
+      for (int32_t p = rowptr[i]; p < rowptr[i + 1]; p++) {                    \
+        int32_t out = t_rowptr[colind[p] + 1]++;                               \
+        t_colind[out] = (int32_t) i;                                           \
+        t_values[out] = values[p];                                             \
+      }                                                                        \
+    return ORACLE_OK;                                                          \
+  }
+DEF_TRANSPOSE(oracle_transpose_f32, float)
+DEF_TRANSPOSE(oracle_transpose_f64, double)

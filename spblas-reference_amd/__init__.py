@@ -14,5 +14,5 @@ from .api import (  # noqa: F401
     conjugated, csc_view, csr_view, get_scaling_factor, get_ultimate_base, has_matrix_opt, index, is_conjugated,
     matrix_opt, multiply, multiply_compute, multiply_fill, multiply_inspect, multiply_numeric,
     multiply_symbolic_compute, multiply_symbolic_fill, operation_info_t, prepared_multiply, scaled, scaled_view,
-    spgemm_state_t,
+    spgemm_state_t, transpose, transpose_inspect,
     transposed)

@@ -384,6 +384,69 @@ def _build_plan(a_base, alg=_capi.SPMV_AUTO):
     return _Plan(hd, plan, _plan_key(a_base))
 
 
+class _CscPlan:
+    """multiply_inspect on a csc_view / transposed(csr) operand: the operand is materialised once as
+    row-major CSR on the device (spblas_gfx950_csr_transpose: stable counting sort, the device
+    counterpart of algorithms/transpose_impl.hpp:14-53) and planned like any CSR matrix, so the
+    execute phase runs the regular kernels instead of the atomic scatter.  Holds a snapshot of the
+    values (inspect may re-format the matrix, README.md:27-30)."""
+
+    def __init__(self, a_csc, alg):
+        self.key = _csc_key(a_csc)
+        m, n = a_csc.shape()          # logical shape of the operand
+        nnz = a_csc.size()
+        dev, vals = a_csc.values().device, a_csc.values()
+        if a_csc.colptr().dtype != torch.int32:
+            raise TypeError("multiply_inspect on csc_view: int32 offsets only")
+        self.rowptr = torch.empty(m + 1, dtype=torch.int32, device=dev)
+        self.colind = torch.empty(max(nnz, 1), dtype=torch.int32, device=dev)
+        self.values = torch.empty(max(nnz, 1), dtype=vals.dtype, device=dev)
+        hd = _Handle.current(dev)
+        # the stored arrays are the CSR of the (n x m) transpose
+        check(_capi.lib().spblas_gfx950_csr_transpose(hd.h, n, m, nnz, _ptr(a_csc.colptr()), _ptr(a_csc.rowind()),
+                                                      _ptr(vals), _ptr(self.rowptr), _ptr(self.colind),
+                                                      _ptr(self.values), _vtype(vals, "multiply_inspect")[0]),
+              "multiply_inspect")
+        self.a_csr = csr_view(self.values[:nnz], self.rowptr, self.colind[:nnz], (m, n), nnz)
+        self.plan = _build_plan(self.a_csr, alg)
+
+    def info(self):
+        return self.plan.info()
+
+
+def _csc_key(a_csc):
+    return (a_csc.colptr().data_ptr(), a_csc.rowind().data_ptr(), a_csc.values().data_ptr(), tuple(a_csc.shape()),
+            a_csc.size())
+
+
+def transpose_inspect(a, b):
+    """transpose_inspect(a, b) (algorithms/transpose_impl.hpp:9-12): nothing to prepare."""
+    return operation_info_t()
+
+
+def transpose(*args):
+    """transpose(a, b) / transpose(info, a, b): b = a^T for csr_view operands on the device, entries
+    of every output row in source order exactly like the reference's counting sort
+    (algorithms/transpose_impl.hpp:14-53).  b's arrays are caller-allocated."""
+    a, b = args[-2], args[-1]
+    if not (isinstance(a, csr_view) and isinstance(b, csr_view)):
+        raise TypeError("transpose: csr_view operands")
+    if a.shape()[0] != b.shape()[1] or a.shape()[1] != b.shape()[0]:
+        raise ValueError("transpose: matrix dimensions are incompatible.")  # transpose_impl.hpp:17-21
+    nnz = a.size()
+    if b.values() is None or b.colind() is None or b.values().numel() < nnz or b.colind().numel() < nnz:
+        raise RuntimeError("transpose: Transpose ran out of memory.")  # transpose_impl.hpp:22-25
+    _check_csr(a, "transpose")
+    if a.rowptr().dtype != torch.int32 or b.rowptr().dtype != torch.int32:
+        raise TypeError("transpose: int32 offsets only")
+    hd = _Handle.current(a.rowptr().device)
+    check(_capi.lib().spblas_gfx950_csr_transpose(hd.h, a.shape()[0], a.shape()[1], nnz, _ptr(a.rowptr()),
+                                                  _ptr(a.colind()), _ptr(a.values()), _ptr(b.rowptr()),
+                                                  _ptr(b.colind()), _ptr(b.values()),
+                                                  _vtype(a.values(), "transpose")[0]), "transpose")
+    b.update(b.values(), b.rowptr(), b.colind(), b.shape(), nnz)  # transpose_impl.hpp:54
+
+
 def _find_plan(info, a, a_base):
     key = _plan_key(a_base)
     if info is not None and isinstance(info.state_, _Plan) and info.state_.key == key:
@@ -401,11 +464,16 @@ def _spmv(info, a, b, c, prepare_only=False):
     if not _is_tensor(c) or c.dim() != 1:
         raise TypeError("multiply: the output vector must be a plain 1-D device tensor")
     op = _capi.OP_N
+    csc_plan = None
     if isinstance(a_base, csc_view):
-        # CSC = CSR of the transpose + TRANSPOSE (vendor/rocsparse/detail/get_transpose.hpp:19-29)
-        a_csr = csr_view(a_base.values(), a_base.colptr(), a_base.rowind(),
-                         (a_base.shape()[1], a_base.shape()[0]), a_base.size())
-        op = _capi.OP_T
+        if info is not None and isinstance(info.state_, _CscPlan) and info.state_.key == _csc_key(a_base):
+            csc_plan = info.state_       # inspected: regular kernels on the materialised CSR
+            a_csr = csc_plan.a_csr
+        else:
+            # CSC = CSR of the transpose + TRANSPOSE (vendor/rocsparse/detail/get_transpose.hpp:19-29)
+            a_csr = csr_view(a_base.values(), a_base.colptr(), a_base.rowind(),
+                             (a_base.shape()[1], a_base.shape()[0]), a_base.size())
+            op = _capi.OP_T
     else:
         a_csr = a_base
     _check_csr(a_csr, "multiply")
@@ -421,7 +489,7 @@ def _spmv(info, a, b, c, prepare_only=False):
     alpha = ct(1 if alpha_opt is None else alpha_opt)  # spmv_impl.hpp:35-37
     beta = ct(0)
     hd = _Handle.current(c.device)
-    plan = _find_plan(info, a, a_base) if op == _capi.OP_N else None
+    plan = csc_plan.plan if csc_plan else (_find_plan(info, a, a_base) if op == _capi.OP_N else None)
     m, n = a_csr.shape()
     args = (hd.h, plan.plan if plan else None, op, m, n, a_csr.size(), ctypes.byref(alpha), _ptr(a_csr.rowptr()),
             _ptr(a_csr.colind()), _ptr(a_csr.values()), _ptr(b_base), ctypes.byref(beta), _ptr(c),
@@ -524,6 +592,8 @@ def multiply_inspect(*args, alg=_capi.SPMV_AUTO):
         mo = _get_matrix_opt(a)
         if mo is not None:
             mo._plan = plan
+    elif isinstance(a_base, csc_view) and _is_tensor(get_ultimate_base(b)) and get_ultimate_base(b).dim() == 1:
+        info.state_ = _CscPlan(a_base, alg)
     return info if ret else None
 
 

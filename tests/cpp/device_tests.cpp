@@ -313,7 +313,38 @@ static void test_spgemm() {
   CHECK(threw);
 }
 
+// test/gtest/transpose_test.cpp:9-71: B = A^T, then (row, col, value) triples must agree
+static void test_transpose() {
+  for (auto&& [m, k, nnz] : dims) {
+    auto h = generate_csr(m, k, nnz);
+    device_csr a(h);
+    dvec<offset_t> d_rp(k + 1);
+    dvec<index_t> d_ci(nnz);
+    dvec<value_t> d_v(nnz);
+    spblas::csr_view<value_t, index_t, offset_t> b(d_v.p, d_rp.p, d_ci.p, {k, m}, nnz);
+    auto info = spblas::transpose_inspect(a.view, b);
+    spblas::transpose(info, a.view, b);
+    auto rp = d_rp.download();
+    auto ci = d_ci.download();
+    auto v = d_v.download();
+    std::vector<std::tuple<int, int, value_t>> ref, got;
+    for (int i = 0; i < m; i++)
+      for (auto p = h.rowptr[i]; p < h.rowptr[i + 1]; p++)
+        ref.emplace_back(h.colind[p], i, h.values[p]);
+    for (int j = 0; j < k; j++)
+      for (auto p = rp[j]; p < rp[j + 1]; p++)
+        got.emplace_back(j, ci[p], v[p]);
+    std::sort(ref.begin(), ref.end());
+    bool sorted_rows = true;  // counting sort leaves every output row in source (ascending row) order
+    for (size_t t = 1; t < got.size(); t++)
+      sorted_rows &= !(std::get<0>(got[t - 1]) == std::get<0>(got[t]) && std::get<1>(got[t - 1]) > std::get<1>(got[t]));
+    CHECK(sorted_rows);
+    CHECK(ref == got);
+  }
+}
+
 int main() {
+  test_transpose();
   test_spmv();
   test_spmm();
   test_spgemm();

@@ -184,3 +184,19 @@ def test_oracle_reproduces_golden_exactly(name):
         assert np.array_equal(cv, g["c_values"])
     else:
         raise AssertionError(kind)
+
+
+@pytest.mark.parametrize("dim", util.dims)
+def test_transpose_matches_reference_test(dim):
+    # test/gtest/transpose_test.cpp:9-71: B = A^T, compared as COO after sorting by (row, col)
+    m, k, nnz = dim
+    values, rowptr, colind, shape, _ = generate.generate_csr(m, k, nnz)
+    tr, tc, tv = oracle.transpose(shape, rowptr, colind, values)
+    A = sps.csr_matrix((values, colind, rowptr), shape=shape)
+    AT = A.T.tocsr()
+    AT.sort_indices()
+    assert np.array_equal(tr, AT.indptr) and np.array_equal(tc, AT.indices) and np.array_equal(tv, AT.data)
+    with pytest.raises(ValueError):
+        oracle.transpose(shape, rowptr, colind, values, b_shape=(k + 1, m))
+    with pytest.raises(RuntimeError):
+        oracle.transpose(shape, rowptr, colind, values, capacity=nnz - 1)
