@@ -518,8 +518,15 @@ class prepared_multiply:
 def _spmm(info, a, b, c):
     a_base, b_base = get_ultimate_base(a), get_ultimate_base(b)
     _reject_conjugated(a, b, c)
+    if isinstance(a_base, csc_view):
+        # CSC operand (test/gtest/spmm_test.cpp:181): run the CSR kernel on the materialised row-major
+        # form -- taken from the inspect result when there is one, otherwise transposed for this call
+        if info is not None and isinstance(info.state_, _CscPlan) and info.state_.key == _csc_key(a_base):
+            a_base = info.state_.a_csr
+        else:
+            a_base = _CscPlan(a_base, _capi.SPMV_VECTOR).a_csr
     if not isinstance(a_base, csr_view):
-        raise NotImplementedError("gfx950 SpMM: A must have a csr_view base")
+        raise NotImplementedError("gfx950 SpMM: A must have a csr_view or csc_view base")
     if not _is_tensor(c) or c.dim() != 2:
         raise TypeError("multiply: the output matrix must be a plain 2-D row-major device tensor")
     _check_csr(a_base, "multiply")
@@ -592,8 +599,8 @@ def multiply_inspect(*args, alg=_capi.SPMV_AUTO):
         mo = _get_matrix_opt(a)
         if mo is not None:
             mo._plan = plan
-    elif isinstance(a_base, csc_view) and _is_tensor(get_ultimate_base(b)) and get_ultimate_base(b).dim() == 1:
-        info.state_ = _CscPlan(a_base, alg)
+    elif isinstance(a_base, csc_view) and _is_tensor(get_ultimate_base(b)):
+        info.state_ = _CscPlan(a_base, alg if get_ultimate_base(b).dim() == 1 else _capi.SPMV_ROWBLOCK)
     return info if ret else None
 
 

@@ -39,7 +39,11 @@ inline int dev_alloc(void** p, size_t bytes, hipStream_t s) {
   *p = nullptr;
   if (bytes == 0)
     return SPBLAS_GFX950_STATUS_SUCCESS;
-  hipError_t e = hipMallocAsync(p, bytes, s);
+  // On the legacy null stream plain hipMalloc/hipFree are used: pool memory released there by
+  // stream order was seen to be recycled while still in use when the application mixes in ordinary
+  // hipMalloc/hipFree traffic (tests/cpp/device_tests.cpp exposed it).  Allocation only happens at
+  // inspect time, so the implied synchronisation is acceptable.
+  hipError_t e = s ? hipMallocAsync(p, bytes, s) : hipErrorNotSupported;
   if (e != hipSuccess) {
     (void) hipGetLastError();
     e = hipMalloc(p, bytes);
@@ -54,7 +58,7 @@ inline int dev_alloc(void** p, size_t bytes, hipStream_t s) {
 inline void dev_free(void* p, hipStream_t s) {
   if (!p)
     return;
-  if (hipFreeAsync(p, s) != hipSuccess) {
+  if (!s || hipFreeAsync(p, s) != hipSuccess) {
     (void) hipGetLastError();
     (void) hipFree(p);
   }

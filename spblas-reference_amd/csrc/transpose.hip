@@ -89,21 +89,27 @@ extern "C" int spblas_gfx950_csr_transpose(spblas_gfx950_handle_t handle, int64_
   int bits = 1;
   while (bits < 32 && ((int64_t) 1 << bits) < n)
     ++bits;
+  // Plain (synchronous) allocations and one stream synchronisation before they are released: this
+  // is an inspect-time operation, and scratch that outlives the call by stream order only was seen
+  // to be recycled under the sort's feet when mixed with ordinary hipMalloc/hipFree traffic.
   auto cleanup = [&]() {
-    dev_free(rowid, s);
-    dev_free(pos, s);
-    dev_free(sorted_cols, s);
-    dev_free(perm, s);
-    dev_free(tmp, s);
+    (void) hipStreamSynchronize(s);
+    (void) hipFree(rowid);
+    (void) hipFree(pos);
+    (void) hipFree(sorted_cols);
+    (void) hipFree(perm);
+    (void) hipFree(tmp);
   };
-  if ((rc = dev_alloc((void**) &rowid, (size_t) nnz * 4, s)) || (rc = dev_alloc((void**) &pos, (size_t) nnz * 4, s)) ||
-      (rc = dev_alloc((void**) &sorted_cols, (size_t) nnz * 4, s)) ||
-      (rc = dev_alloc((void**) &perm, (size_t) nnz * 4, s))) {
+  auto alloc = [&](void** p, size_t bytes) {
+    return hipMalloc(p, bytes) == hipSuccess ? 0 : (int) SPBLAS_GFX950_STATUS_ALLOC_FAILED;
+  };
+  if ((rc = alloc((void**) &rowid, (size_t) nnz * 4)) || (rc = alloc((void**) &pos, (size_t) nnz * 4)) ||
+      (rc = alloc((void**) &sorted_cols, (size_t) nnz * 4)) || (rc = alloc((void**) &perm, (size_t) nnz * 4))) {
     cleanup();
     return rc;
   }
   hipError_t e = rocprim::radix_sort_pairs(nullptr, tmp_bytes, colind, sorted_cols, pos, perm, (size_t) nnz, 0, bits, s);
-  if (e != hipSuccess || (rc = dev_alloc(&tmp, tmp_bytes, s))) {
+  if (e != hipSuccess || (rc = alloc(&tmp, tmp_bytes))) {
     cleanup();
     return e != hipSuccess ? hip_fail(e) : rc;
   }
@@ -120,7 +126,7 @@ extern "C" int spblas_gfx950_csr_transpose(spblas_gfx950_handle_t handle, int64_
                          static_cast<const double*>(values), t_colind, static_cast<double*>(t_values));
     e = hipGetLastError();
   }
-  cleanup();  // stream-ordered frees: run after the kernels above
+  cleanup();  // synchronises the stream, then frees
   if (e != hipSuccess)
     return hip_fail(e);
   return SPBLAS_GFX950_STATUS_SUCCESS;

@@ -146,8 +146,12 @@ static void test_spmv() {
           std::span<value_t> c2_span(d_c2.p, m);
           spblas::multiply(info, a.view, b_span, c2_span);
           auto c2 = d_c2.download();
-          for (int i = 0; i < m; i++)
+          for (int i = 0; i < m; i++) {
+            if (!near_ref(c[i], c2[i]))
+              std::printf("  inspect/execute mismatch: dims (%d,%d,%d) row %d len %d: %g vs %g\n", m, n, nnz, i,
+                          (int) (h.rowptr[i + 1] - h.rowptr[i]), c[i], c2[i]);
             CHECK(near_ref(c[i], c2[i]));
+          }
         }
       }
     }
@@ -339,15 +343,24 @@ static void test_transpose() {
     for (size_t t = 1; t < got.size(); t++)
       sorted_rows &= !(std::get<0>(got[t - 1]) == std::get<0>(got[t]) && std::get<1>(got[t - 1]) > std::get<1>(got[t]));
     CHECK(sorted_rows);
+    if (!(ref == got)) {
+      std::printf("  transpose mismatch dims (%d,%d,%d): sizes %zu %zu\n", m, k, nnz, ref.size(), got.size());
+      for (size_t t = 0, shown = 0; t < std::min(ref.size(), got.size()) && shown < 5; t++)
+        if (ref[t] != got[t]) {
+          std::printf("    [%zu] ref (%d,%d,%g) got (%d,%d,%g)\n", t, std::get<0>(ref[t]), std::get<1>(ref[t]), std::get<2>(ref[t]),
+                      std::get<0>(got[t]), std::get<1>(got[t]), std::get<2>(got[t]));
+          ++shown;
+        }
+    }
     CHECK(ref == got);
   }
 }
 
 int main() {
-  test_transpose();
   test_spmv();
   test_spmm();
   test_spgemm();
+  test_transpose();
   std::printf("%s: %d checks, %d failures\n", g_fail ? "FAILED" : "PASSED", g_checks, g_fail);
   return g_fail ? 1 : 0;
 }

@@ -94,3 +94,22 @@ def test_inspected_csc_operand_uses_regular_kernels(gpu, alg):
     y2 = torch.zeros(900, device="cuda")
     sp.multiply(sp.scaled(3.0, a_csc), G.dev(x_h), y2)
     util.assert_parity(G.host(y2), y_ref, absrow, np.float32, row_len=np.diff(tr), what="atomic csc spmv")
+
+
+@pytest.mark.parametrize("inspect", [False, True])
+def test_spmm_with_csc_operand(gpu, inspect):
+    # CscView.SpMM (test/gtest/spmm_test.cpp:181): C = A B with A held by columns
+    values, rowptr, colind, shape, nnz = generate.generate_csr(300, 200, 5000, seed=5)  # CSR of A^T (300x200)
+    a_csc = sp.transposed(G.csr_on_device(values, rowptr, colind, shape, nnz))          # A is 200x300
+    B_h = generate.generate_dense(300, 24)
+    C = torch.full((200, 24), float("nan"), device="cuda")
+    if inspect:
+        info = sp.multiply_inspect(a_csc, G.dev(B_h), C)
+        sp.multiply(info, sp.scaled(0.5, a_csc), G.dev(B_h), C)
+    else:
+        sp.multiply(sp.scaled(0.5, a_csc), G.dev(B_h), C)
+    tr, tc, tv = oracle.transpose(shape, rowptr, colind, values)  # row-major A
+    C_ref = oracle.spmm((200, 300), tr, tc, tv, B_h, scale_a=0.5)
+    import scipy.sparse as sps
+    ab = 0.5 * (sps.csr_matrix((np.abs(tv).astype(np.float64), tc, tr), shape=(200, 300)) @ np.abs(B_h).astype(np.float64))
+    util.assert_parity(G.host(C), C_ref, ab, np.float32, row_len=np.diff(tr), what="csc spmm")

@@ -67,6 +67,6 @@ def assert_parity(y, y_ref, absrow, dtype, row_len=None, what=""):
             (-1,) + (1,) * (absrow.ndim - 1)) * float(np.finfo(dt).eps))
     err = np.abs(y.astype(np.float64) - y_ref.astype(np.float64))
     bound = tol * absrow + float(np.finfo(dt).tiny)
-    bad = err > bound
+    bad = ~(err <= bound)  # NaN (an output the kernel never wrote) must fail, not slip through
     assert not bad.any(), (f"{what}: {bad.sum()} entries exceed the parity bound; worst ratio "
                            f"{(err / np.maximum(bound, 1e-300)).max():.3g}")
