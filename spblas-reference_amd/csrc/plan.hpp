@@ -41,6 +41,8 @@ struct spblas_gfx950_plan_s {
   void* s_perm = nullptr;      // int32[nnz] source position in the caller's CSR arrays
   void* s_products = nullptr;  // T[nnz] workspace: expanded products
   int n_ksplit = 1;            // reduce workgroups per bin group (slice split)
+  int rwaves = 8;              // reduce: wave-bins (= wavefronts) per workgroup
+  int rchunks = 1;             // reduce: 64-entry chunks of a run prefetched into registers
   void* s_partial = nullptr;   // T[s_partial_k][m] partial sums (grown on demand)
   int s_partial_k = 0;
   int bin_aligned = 0;         // wave-bin height divides the handle's bin_row_align option

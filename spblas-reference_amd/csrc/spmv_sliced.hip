@@ -44,8 +44,9 @@ static int env_int(const char* name, int dflt) {
 }
 
 static constexpr int PB_THREADS = 1024;         // expand: 16 waves share one x slice
-static constexpr int PB_RTHREADS = 512;         // reduce: 8 waves, one wave-bin each (4 or 16 measured 2.3x slower)
+static constexpr int PB_RTHREADS = 512;         // inspect (flag kernel): 8 waves, one wave-bin each
 static constexpr int PB_RWAVES = PB_RTHREADS / 64;
+static constexpr int PB_RWAVES_DEFAULT = 4;     // reduce: wave-bins per workgroup (plan->rwaves)
 static constexpr int PB_LDS_BYTES = 80 * 1024;  // two workgroups per CU (160 KiB LDS)
 
 // ---- inspect --------------------------------------------------------------------------
@@ -270,20 +271,24 @@ __device__ __forceinline__ void pb_apply(T* acc, T p, int r, bool ok) {
   }
 }
 
-template <typename T>
-__global__ __launch_bounds__(PB_RTHREADS) void pb_reduce_kernel(int64_t m, int Hw, int S, int64_t wb_begin, int64_t NBw,
-                                                                const int2* __restrict__ segT,
-                                                                const T* __restrict__ P,
-                                                                const uint16_t* __restrict__ s_row,
-                                                                T* __restrict__ y, T alpha, T beta, int s_per,
-                                                                T* __restrict__ partial, int64_t pstride) {
+// RW wave-bins per workgroup; C 64-entry chunks of every run held in registers.  The loop is
+// software-pipelined by hand: the loads of batch k+1 (B runs) are
+// issued before batch k is applied.  Every load is unconditional -- lanes past the end of a run
+// re-read its last entry (same cache line, no extra traffic) -- because a load inside a divergent
+// branch makes the compiler drain vmcnt(0) at the join, which would serialise the pipeline.
+template <typename T, int RW, int C>
+__global__ __launch_bounds__(RW * 64) void pb_reduce_kernel(int64_t m, int Hw, int S, int64_t wb_begin, int64_t NBw,
+                                                            const int2* __restrict__ segT, const T* __restrict__ P,
+                                                            const uint16_t* __restrict__ s_row, T* __restrict__ y,
+                                                            T alpha, T beta, int s_per, T* __restrict__ partial,
+                                                            int64_t pstride) {
   // blockIdx.y = k selects the slices [k*s_per, (k+1)*s_per): with few wave-bins (a row shard of
   // a multi-GPU run) the slices are split over several workgroups per bin group, each writing a
   // partial sum that pb_combine_kernel adds up in a fixed order.
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   T* acc = reinterpret_cast<T*>(smem) + (size_t) wave * Hw;
-  const int64_t wb = wb_begin + (int64_t) blockIdx.x * PB_RWAVES + wave;  // NBw = end of the bin range
+  const int64_t wb = wb_begin + (int64_t) blockIdx.x * RW + wave;  // NBw = end of the bin range
   const int s_lo = blockIdx.y * s_per, s_hi = (s_lo + s_per) < S ? (s_lo + s_per) : S;
   if (wb >= NBw)
     return;
@@ -291,45 +296,78 @@ __global__ __launch_bounds__(PB_RTHREADS) void pb_reduce_kernel(int64_t m, int H
   const int rh = (int) ((m - r0) < Hw ? (m - r0) : Hw);
   for (int i = lane; i < rh; i += 64)
     acc[i] = T(0);
-  const int2* mine = segT + wb * S;
-  constexpr int B = 8;  // runs in flight per wave: B * 6 bytes * 64 lanes * 16 waves/CU ~ 48 KiB
-  int2 dnext = make_int2(0, 0);
-  if (s_lo + lane < s_hi)
-    dnext = mine[s_lo + lane];
-  for (int sb = s_lo; sb < s_hi; sb += 64) {
-    const int2 d = dnext;
-    if (sb + 64 + lane < s_hi)  // prefetch the next 64 descriptors behind this batch's work
-      dnext = mine[sb + 64 + lane];
-    const int cnt = (s_hi - sb) < 64 ? (s_hi - sb) : 64;
-    for (int j0 = 0; j0 < cnt; j0 += B) {
-      T p[B];
-      int r[B], st[B], ln[B];
+  const int2* mine = segT + wb * S + s_lo;
+  const int ns = s_hi - s_lo;
+  constexpr int B = 8;  // runs per batch; 64 descriptors (one per lane) make a group of 8 batches
+  struct batch_t {
+    T p[B][C];
+    int r[B][C];
+    int st[B], ln[B];
+  };
+  auto fetch_group = [&](int g) -> int2 {  // descriptors of slices 64g .. 64g+63, one per lane
+    const int t = 64 * g + lane;
+    const int tc = t < ns ? t : (ns > 0 ? ns - 1 : 0);
+    int2 d = mine[tc];
+    if (t >= ns)
+      d.y = 0;
+    return d;
+  };
+  auto issue = [&](const int2& d, int j0, batch_t& q) {
 #pragma unroll
-      for (int u = 0; u < B; ++u) {
-        st[u] = __shfl(d.x, j0 + u);
-        ln[u] = (j0 + u < cnt) ? __shfl(d.y, j0 + u) : 0;
-        p[u] = T(0);
-        r[u] = 0;
-        if (lane < ln[u]) {
-          p[u] = stream_load(P + st[u] + lane);
-          r[u] = stream_load(s_row + st[u] + lane);
-        }
-      }
+    for (int u = 0; u < B; ++u) {
+      q.st[u] = __builtin_amdgcn_readlane(d.x, j0 + u);
+      q.ln[u] = __builtin_amdgcn_readlane(d.y, j0 + u);
+      const int last = q.ln[u] > 0 ? q.ln[u] - 1 : 0;
 #pragma unroll
-      for (int u = 0; u < B; ++u) {
-        pb_apply<T>(acc, p[u], r[u], lane < ln[u]);
-        for (int base = 64; base < ln[u]; base += 64) {  // runs longer than one wave
-          const int o = base + lane;
-          const bool ok = o < ln[u];
-          T pp = T(0);
-          int rr = 0;
-          if (ok) {
-            pp = stream_load(P + st[u] + o);
-            rr = stream_load(s_row + st[u] + o);
-          }
-          pb_apply<T>(acc, pp, rr, ok);
-        }
+      for (int c = 0; c < C; ++c) {
+        const int o = lane + 64 * c;
+        const int idx = q.st[u] + (o < last ? o : last);
+        q.p[u][c] = stream_load(P + idx);
+        q.r[u][c] = stream_load(s_row + idx);
       }
+    }
+  };
+  auto consume = [&](const batch_t& q) {
+#pragma unroll
+    for (int u = 0; u < B; ++u) {
+#pragma unroll
+      for (int c = 0; c < C; ++c)
+        pb_apply<T>(acc, q.p[u][c], q.r[u][c], lane + 64 * c < q.ln[u]);
+      // longer runs: the tail straight from memory.  Keep these loads inside the `if`: with
+      // unconditional loads here the compiler loses track of the in-flight batch and waits
+      // vmcnt(0) before every chunk of the main path.
+      for (int base = 64 * C; base < q.ln[u]; base += 64) {
+        const int o = base + lane;
+        const bool ok = o < q.ln[u];
+        T pp = T(0);
+        int rr = 0;
+        if (ok) {
+          pp = stream_load(P + q.st[u] + o);
+          rr = stream_load(s_row + q.st[u] + o);
+        }
+        pb_apply<T>(acc, pp, rr, ok);
+      }
+    }
+  };
+  if (ns > 0) {
+    const int nbatch = (ns + B - 1) / B;
+    int2 dcur = fetch_group(0), dnext = fetch_group(1);
+    // descriptors for batch kk (called with kk = 1, 2, 3, ... in order)
+    auto advance = [&](int kk) {
+      if ((kk & 7) == 0) {
+        dcur = dnext;
+        dnext = fetch_group((kk >> 3) + 1);
+      }
+    };
+    batch_t qa, qb;
+    issue(dcur, 0, qa);
+    for (int k = 0; k < nbatch; k += 2) {
+      advance(k + 1);
+      issue(dcur, ((k + 1) & 7) * B, qb);  // past the last batch the descriptors have ln = 0
+      consume(qa);
+      advance(k + 2);
+      issue(dcur, ((k + 2) & 7) * B, qa);
+      consume(qb);
     }
   }
   if (partial) {
@@ -356,6 +394,19 @@ __global__ __launch_bounds__(256) void pb_combine_kernel(int64_t r_lo, int64_t r
   for (int k = 1; k < K; ++k)
     s += partial[(int64_t) k * pstride + i];
   y[i] = beta == T(0) ? alpha * s : alpha * s + beta * y[i];
+}
+
+template <typename T>
+static const void* pb_reduce_fn(int rw, int c) {
+#define SPB_RK(RW_, C_) reinterpret_cast<const void*>(pb_reduce_kernel<T, RW_, C_>)
+#define SPB_RKC(RW_) (c == 1 ? SPB_RK(RW_, 1) : (c == 2 ? SPB_RK(RW_, 2) : SPB_RK(RW_, 4)))
+  switch (rw) {
+    case 2: return SPB_RKC(2);
+    case 4: return SPB_RKC(4);
+    default: return SPB_RKC(8);
+  }
+#undef SPB_RKC
+#undef SPB_RK
 }
 
 // ---- host -------------------------------------------------------------------------------
@@ -398,12 +449,20 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
   int max_cols = PB_LDS_BYTES / (int) sizeof(T);
   if (max_cols > 65536)
     max_cols = 65536;  // 16-bit local column
-  int max_rows = PB_LDS_BYTES / PB_RWAVES / (int) sizeof(T);  // per wave-bin; < 32768 (15-bit row + flag)
+  // reduce shape: RW wave-bins per workgroup share the 80 KiB.  Fewer, taller bins make longer runs
+  // (less cache-line over-fetch at run boundaries) but leave fewer wavefronts to hide latency.
+  int RW = env_int("SPBLAS_GFX950_PB_RWAVES", PB_RWAVES_DEFAULT);
+  if (RW != 2 && RW != 4 && RW != 8)
+    RW = PB_RWAVES_DEFAULT;
+  pl->rwaves = RW;
+  int max_rows = PB_LDS_BYTES / RW / (int) sizeof(T);  // per wave-bin; < 32768 (15-bit row + flag)
+  if (max_rows > 32767)
+    max_rows = 32767;
   int S, W, NB, H;
   const int w_env = env_int("SPBLAS_GFX950_SLICE_COLS", 0);  // test hooks: force small tiles
   const int h_env = env_int("SPBLAS_GFX950_SLICE_ROWS", 0);
   pick_tiling(n, w_env > 0 && w_env < max_cols ? w_env : max_cols, 512, 4, &S, &W);
-  pick_tiling(m, h_env > 0 && h_env < max_rows ? h_env : max_rows, 512 * PB_RWAVES, 1, &NB, &H);
+  pick_tiling(m, h_env > 0 && h_env < max_rows ? h_env : max_rows, 512 * RW, 1, &NB, &H);
   if (h->bin_row_align > 1) {
     // caller wants bin boundaries on multiples of bin_row_align (stripe boundaries of the overlapped
     // multi-GPU step): use the largest divisor of it that fits the LDS budget, if a decent one exists
@@ -426,7 +485,14 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
   pl->slice_cols = W;
   pl->n_rblk = NB;
   pl->rows_per_blk = H;
-  pl->n_ksplit = pick_ksplit_fwd(cdiv(NB, PB_RWAVES), S);
+  pl->n_ksplit = pick_ksplit_fwd(cdiv(NB, RW), S);
+  {
+    const int64_t avg_run = nnz / (nseg > 0 ? nseg : 1);
+    int C = env_int("SPBLAS_GFX950_PB_RCHUNKS", 0);
+    if (C != 1 && C != 2 && C != 4)
+      C = avg_run > 112 ? 4 : (avg_run > 48 ? 2 : 1);
+    pl->rchunks = C;
+  }
 
   int rc;
   int32_t* seg = nullptr;
@@ -474,6 +540,8 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
                      reinterpret_cast<uint16_t*>(pl->s_colind), pl->s_lrow, reinterpret_cast<int32_t*>(pl->s_perm));
   hipLaunchKernelGGL(pb_transpose_seg_kernel, dim3((unsigned) cdiv(nseg, 256)), dim3(256), 0, s, S, NB, seg,
                      static_cast<int2*>(pl->s_segT));
+  SPB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pb_flag_dups_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, PB_LDS_BYTES));
   hipLaunchKernelGGL(pb_flag_dups_kernel, dim3((unsigned) cdiv(NB, PB_RWAVES)), dim3(PB_RTHREADS),
                      (size_t) PB_RWAVES * H, s, H, S, (int64_t) NB, static_cast<const int2*>(pl->s_segT), pl->s_lrow);
   SPB_HIP(hipGetLastError());
@@ -482,8 +550,10 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
   // both kernels may use up to 80 KiB of dynamic LDS
   SPB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pb_expand_kernel<T>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, PB_LDS_BYTES));
-  SPB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pb_reduce_kernel<T>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, PB_LDS_BYTES));
+  {
+    const void* fn = pb_reduce_fn<T>(pl->rwaves, pl->rchunks);
+    SPB_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, PB_LDS_BYTES));
+  }
   return SPBLAS_GFX950_STATUS_SUCCESS;
 }
 
@@ -541,7 +611,8 @@ static int sliced_reduce_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* p
   if (wb_end <= wb_begin)
     return SPBLAS_GFX950_STATUS_SUCCESS;
   const T alpha = *static_cast<const T*>(alpha_p), beta = *static_cast<const T*>(beta_p);
-  const int64_t groups = cdiv(wb_end - wb_begin, PB_RWAVES);
+  const int RW = pl->rwaves;
+  const int64_t groups = cdiv(wb_end - wb_begin, RW);
   const int K = pick_ksplit(groups, pl->n_slices);
   const int s_per = (int) cdiv(pl->n_slices, K);
   const int64_t r_lo = wb_begin * pl->rows_per_blk;
@@ -554,11 +625,19 @@ static int sliced_reduce_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* p
       return rc;
     pl->s_partial_k = K;
   }
-  hipLaunchKernelGGL((pb_reduce_kernel<T>), dim3((unsigned) groups, (unsigned) K), dim3(PB_RTHREADS),
-                     (size_t) PB_RWAVES * pl->rows_per_blk * sizeof(T), s, pl->m, pl->rows_per_blk, pl->n_slices,
-                     wb_begin, wb_end, static_cast<const int2*>(pl->s_segT), static_cast<const T*>(pl->s_products),
-                     pl->s_lrow, static_cast<T*>(y), alpha, beta, s_per,
-                     K > 1 ? static_cast<T*>(pl->s_partial) : nullptr, pl->m);
+  {
+    const int2* segT = static_cast<const int2*>(pl->s_segT);
+    const T* Pp = static_cast<const T*>(pl->s_products);
+    const uint16_t* rowp = pl->s_lrow;
+    T* yp = static_cast<T*>(y);
+    T* part = K > 1 ? static_cast<T*>(pl->s_partial) : nullptr;
+    int64_t mm = pl->m, pstride = pl->m;
+    int Hw = pl->rows_per_blk, S = pl->n_slices, sp = s_per;
+    T a = alpha, b = beta;
+    void* args[] = {&mm, &Hw, &S, &wb_begin, &wb_end, &segT, &Pp, &rowp, &yp, &a, &b, &sp, &part, &pstride};
+    SPB_HIP(hipLaunchKernel(pb_reduce_fn<T>(RW, pl->rchunks), dim3((unsigned) groups, (unsigned) K), dim3(RW * 64), args,
+                            (size_t) RW * pl->rows_per_blk * sizeof(T), s));
+  }
   if (K > 1 && r_hi > r_lo)
     hipLaunchKernelGGL((pb_combine_kernel<T>), dim3((unsigned) cdiv(r_hi - r_lo, 256)), dim3(256), 0, s, r_lo, r_hi, K,
                        static_cast<const T*>(pl->s_partial), pl->m, static_cast<T*>(y), alpha, beta);
