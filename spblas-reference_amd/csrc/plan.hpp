@@ -43,6 +43,7 @@ struct spblas_gfx950_plan_s {
   int n_ksplit = 1;            // reduce workgroups per bin group (slice split)
   int rwaves = 8;              // reduce: wave-bins (= wavefronts) per workgroup
   int rchunks = 1;             // reduce: 64-entry chunks of a run prefetched into registers
+  int rgroup = 1;              // reduce: runs whose LDS reads are issued together (duplicate-flag group)
   void* s_partial = nullptr;   // T[s_partial_k][m] partial sums (grown on demand)
   int s_partial_k = 0;
   int bin_aligned = 0;         // wave-bin height divides the handle's bin_row_align option

@@ -224,34 +224,58 @@ __global__ __launch_bounds__(PB_THREADS) void pb_expand_kernel(int64_t n, int W,
   }
 }
 
-// inspect: mark duplicates.  Same walk as the reduce kernel: wave-bin -> runs -> 64-entry chunks.
-// Inside a chunk every lane writes its lane id to tag[row] and reads it back; for a repeated
-// row exactly one lane reads its own id, the others get the duplicate flag (bit 15).
-__global__ __launch_bounds__(PB_RTHREADS) void pb_flag_dups_kernel(int Hw, int S, int64_t NBw,
+// inspect: mark duplicates.  Same walk as the reduce kernel: wave-bin -> groups of GR runs -> chunks.
+// The reduce kernel issues the LDS reads of a whole group (GR runs x C 64-entry chunks) before the
+// first write, so every entry whose row already occurs earlier in its group gets the duplicate
+// flag (bit 15) and takes the atomic path there.  Chunks beyond the C-th of a run are applied one
+// at a time and only need flags inside the chunk.
+//   tag[row]:   lane id, resolves repeats inside one chunk (exactly one lane reads back its own id)
+//   stamp[row]: id of the last group that claimed the row; ids wrap after 255 groups, and a stale
+//               match merely sends a unique entry down the (still correct) atomic path.
+__global__ __launch_bounds__(PB_RTHREADS) void pb_flag_dups_kernel(int Hw, int S, int64_t NBw, int C, int GR,
                                                                    const int2* __restrict__ segT,
                                                                    uint16_t* __restrict__ s_row) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  unsigned char* tag = smem + (size_t) wave * Hw;
+  unsigned char* tag = smem + (size_t) wave * 2 * Hw;
+  unsigned char* stamp = tag + Hw;
   const int64_t wb = (int64_t) blockIdx.x * PB_RWAVES + wave;
   if (wb >= NBw)
     return;
+  for (int i = lane; i < Hw; i += 64)
+    stamp[i] = 0;
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0xc07f);
   const int2* mine = segT + wb * S;
-  for (int s = 0; s < S; ++s) {
-    const int2 d = mine[s];
-    for (int base = 0; base < d.y; base += 64) {
-      const int o = base + lane;
-      int row = 0;
-      const bool ok = o < d.y;
-      if (ok) {
-        row = s_row[d.x + o] & 0x7FFF;
-        tag[row] = (unsigned char) lane;
+  for (int s0 = 0, grp = 0; s0 < S; s0 += GR, ++grp) {
+    const unsigned char cur = (unsigned char) (grp % 255 + 1);
+    const int s1 = (s0 + GR) < S ? (s0 + GR) : S;
+    for (int s = s0; s < s1; ++s) {
+      const int2 d = mine[s];
+      for (int base = 0; base < d.y; base += 64) {
+        const bool grouped = base < 64 * C;
+        const int o = base + lane;
+        int row = 0;
+        const bool ok = o < d.y;
+        bool seen = false;
+        if (ok) {
+          row = s_row[d.x + o] & 0x7FFF;
+          seen = grouped && stamp[row] == cur;
+          if (!seen)
+            tag[row] = (unsigned char) lane;
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the tag stores have landed
+        if (ok) {
+          const bool won = !seen && tag[row] == (unsigned char) lane;
+          if (!won)
+            s_row[d.x + o] = (uint16_t) (row | 0x8000);
+          else if (grouped)
+            stamp[row] = cur;
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);
       }
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the tag stores have landed
-      if (ok && tag[row] != (unsigned char) lane)
-        s_row[d.x + o] = (uint16_t) (row | 0x8000);
-      __builtin_amdgcn_wave_barrier();
     }
   }
 }
@@ -276,7 +300,7 @@ __device__ __forceinline__ void pb_apply(T* acc, T p, int r, bool ok) {
 // issued before batch k is applied.  Every load is unconditional -- lanes past the end of a run
 // re-read its last entry (same cache line, no extra traffic) -- because a load inside a divergent
 // branch makes the compiler drain vmcnt(0) at the join, which would serialise the pipeline.
-template <typename T, int RW, int C>
+template <typename T, int RW, int C, int GR>
 __global__ __launch_bounds__(RW * 64) void pb_reduce_kernel(int64_t m, int Hw, int S, int64_t wb_begin, int64_t NBw,
                                                             const int2* __restrict__ segT, const T* __restrict__ P,
                                                             const uint16_t* __restrict__ s_row, T* __restrict__ y,
@@ -329,24 +353,55 @@ __global__ __launch_bounds__(RW * 64) void pb_reduce_kernel(int64_t m, int Hw, i
   };
   auto consume = [&](const batch_t& q) {
 #pragma unroll
-    for (int u = 0; u < B; ++u) {
+    for (int g = 0; g < B; g += GR) {
+      // one group: all LDS reads, then all writes.  Rows of unflagged entries are distinct inside a
+      // group (pb_flag_dups_kernel), flagged ones are added atomically afterwards.
+      T v[GR][C];
+      int row[GR][C];
+      bool plain[GR][C], dup[GR][C];
+      bool any_dup = false;
 #pragma unroll
-      for (int c = 0; c < C; ++c)
-        pb_apply<T>(acc, q.p[u][c], q.r[u][c], lane + 64 * c < q.ln[u]);
+      for (int u = 0; u < GR; ++u)
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          const int r = q.r[g + u][c];
+          const bool ok = lane + 64 * c < q.ln[g + u];
+          row[u][c] = r & 0x7FFF;
+          dup[u][c] = ok && (r & 0x8000);
+          plain[u][c] = ok && !(r & 0x8000);
+          any_dup |= dup[u][c];
+          v[u][c] = acc[plain[u][c] ? row[u][c] : 0];
+        }
+#pragma unroll
+      for (int u = 0; u < GR; ++u)
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+          if (plain[u][c])
+            acc[row[u][c]] = v[u][c] + q.p[g + u][c];
+      if (__builtin_amdgcn_ballot_w64(any_dup) != 0) {
+#pragma unroll
+        for (int u = 0; u < GR; ++u)
+#pragma unroll
+          for (int c = 0; c < C; ++c)
+            if (dup[u][c])
+              unsafeAtomicAdd(acc + row[u][c], q.p[g + u][c]);
+      }
       // longer runs: the tail straight from memory.  Keep these loads inside the `if`: with
       // unconditional loads here the compiler loses track of the in-flight batch and waits
       // vmcnt(0) before every chunk of the main path.
-      for (int base = 64 * C; base < q.ln[u]; base += 64) {
-        const int o = base + lane;
-        const bool ok = o < q.ln[u];
-        T pp = T(0);
-        int rr = 0;
-        if (ok) {
-          pp = stream_load(P + q.st[u] + o);
-          rr = stream_load(s_row + q.st[u] + o);
+#pragma unroll
+      for (int u = 0; u < GR; ++u)
+        for (int base = 64 * C; base < q.ln[g + u]; base += 64) {
+          const int o = base + lane;
+          const bool ok = o < q.ln[g + u];
+          T pp = T(0);
+          int rr = 0;
+          if (ok) {
+            pp = stream_load(P + q.st[g + u] + o);
+            rr = stream_load(s_row + q.st[g + u] + o);
+          }
+          pb_apply<T>(acc, pp, rr, ok);
         }
-        pb_apply<T>(acc, pp, rr, ok);
-      }
     }
   };
   if (ns > 0) {
@@ -397,15 +452,13 @@ __global__ __launch_bounds__(256) void pb_combine_kernel(int64_t r_lo, int64_t r
 }
 
 template <typename T>
-static const void* pb_reduce_fn(int rw, int c) {
-#define SPB_RK(RW_, C_) reinterpret_cast<const void*>(pb_reduce_kernel<T, RW_, C_>)
-#define SPB_RKC(RW_) (c == 1 ? SPB_RK(RW_, 1) : (c == 2 ? SPB_RK(RW_, 2) : SPB_RK(RW_, 4)))
-  switch (rw) {
-    case 2: return SPB_RKC(2);
-    case 4: return SPB_RKC(4);
-    default: return SPB_RKC(8);
-  }
+static const void* pb_reduce_fn(int rw, int c, int gr) {
+#define SPB_RK(RW_, C_, G_) reinterpret_cast<const void*>(pb_reduce_kernel<T, RW_, C_, G_>)
+#define SPB_RKG(RW_, C_) (gr == 1 ? SPB_RK(RW_, C_, 1) : (gr == 2 ? SPB_RK(RW_, C_, 2) : SPB_RK(RW_, C_, 4)))
+#define SPB_RKC(RW_) (c == 1 ? SPB_RKG(RW_, 1) : (c == 2 ? SPB_RKG(RW_, 2) : SPB_RKG(RW_, 4)))
+  return rw == 4 ? SPB_RKC(4) : SPB_RKC(8);
 #undef SPB_RKC
+#undef SPB_RKG
 #undef SPB_RK
 }
 
@@ -452,7 +505,7 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
   // reduce shape: RW wave-bins per workgroup share the 80 KiB.  Fewer, taller bins make longer runs
   // (less cache-line over-fetch at run boundaries) but leave fewer wavefronts to hide latency.
   int RW = env_int("SPBLAS_GFX950_PB_RWAVES", PB_RWAVES_DEFAULT);
-  if (RW != 2 && RW != 4 && RW != 8)
+  if (RW != 4 && RW != 8)
     RW = PB_RWAVES_DEFAULT;
   pl->rwaves = RW;
   int max_rows = PB_LDS_BYTES / RW / (int) sizeof(T);  // per wave-bin; < 32768 (15-bit row + flag)
@@ -492,6 +545,10 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
     if (C != 1 && C != 2 && C != 4)
       C = avg_run > 112 ? 4 : (avg_run > 48 ? 2 : 1);
     pl->rchunks = C;
+    int GR = env_int("SPBLAS_GFX950_PB_RGROUP", 0);
+    if (GR != 1 && GR != 2 && GR != 4)
+      GR = 2;
+    pl->rgroup = GR;
   }
 
   int rc;
@@ -543,7 +600,8 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
   SPB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pb_flag_dups_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, PB_LDS_BYTES));
   hipLaunchKernelGGL(pb_flag_dups_kernel, dim3((unsigned) cdiv(NB, PB_RWAVES)), dim3(PB_RTHREADS),
-                     (size_t) PB_RWAVES * H, s, H, S, (int64_t) NB, static_cast<const int2*>(pl->s_segT), pl->s_lrow);
+                     (size_t) PB_RWAVES * 2 * H, s, H, S, (int64_t) NB, pl->rchunks, pl->rgroup,
+                     static_cast<const int2*>(pl->s_segT), pl->s_lrow);
   SPB_HIP(hipGetLastError());
   SPB_HIP(hipStreamSynchronize(s));
   dev_free(partials, s);
@@ -551,7 +609,7 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
   SPB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pb_expand_kernel<T>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, PB_LDS_BYTES));
   {
-    const void* fn = pb_reduce_fn<T>(pl->rwaves, pl->rchunks);
+    const void* fn = pb_reduce_fn<T>(pl->rwaves, pl->rchunks, pl->rgroup);
     SPB_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, PB_LDS_BYTES));
   }
   return SPBLAS_GFX950_STATUS_SUCCESS;
@@ -613,8 +671,9 @@ static int sliced_reduce_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* p
   const T alpha = *static_cast<const T*>(alpha_p), beta = *static_cast<const T*>(beta_p);
   const int RW = pl->rwaves;
   const int64_t groups = cdiv(wb_end - wb_begin, RW);
-  const int K = pick_ksplit(groups, pl->n_slices);
-  const int s_per = (int) cdiv(pl->n_slices, K);
+  // slices per split: whole batches of 8 runs, so the duplicate-flag groups stay aligned
+  const int s_per = (int) cdiv(cdiv(pl->n_slices, pick_ksplit(groups, pl->n_slices)), 8) * 8;
+  const int K = (int) cdiv(pl->n_slices, s_per);
   const int64_t r_lo = wb_begin * pl->rows_per_blk;
   const int64_t r_hi = wb_end * pl->rows_per_blk < pl->m ? wb_end * pl->rows_per_blk : pl->m;
   if (K > 1 && pl->s_partial_k < K) {  // grow the partial-sum workspace (stream ordered)
@@ -635,7 +694,7 @@ static int sliced_reduce_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* p
     int Hw = pl->rows_per_blk, S = pl->n_slices, sp = s_per;
     T a = alpha, b = beta;
     void* args[] = {&mm, &Hw, &S, &wb_begin, &wb_end, &segT, &Pp, &rowp, &yp, &a, &b, &sp, &part, &pstride};
-    SPB_HIP(hipLaunchKernel(pb_reduce_fn<T>(RW, pl->rchunks), dim3((unsigned) groups, (unsigned) K), dim3(RW * 64), args,
+    SPB_HIP(hipLaunchKernel(pb_reduce_fn<T>(RW, pl->rchunks, pl->rgroup), dim3((unsigned) groups, (unsigned) K), dim3(RW * 64), args,
                             (size_t) RW * pl->rows_per_blk * sizeof(T), s));
   }
   if (K > 1 && r_hi > r_lo)
