@@ -181,6 +181,42 @@ int spblas_gfx950_spgemm_numeric(spblas_gfx950_handle_t handle, spblas_gfx950_sp
                                  int32_t* c_rowptr, int32_t* c_colind, void* c_values, int64_t c_capacity,
                                  int value_type);
 
+/* Four-argument SpGEMM  C = alpha*A*B + beta*D  (the reference
+ * surface is multiply_compute, multiply_fill, multiply_symbolic_compute, multiply_symbolic_fill and
+ * multiply_numeric taking (state, a, b, c, d),
+ * vendor/rocsparse/multiply_spgemm.hpp:118-214,237-274, with alpha = scale(a)*scale(b) and
+ * beta = scale(d); expected values test/gtest/device/rocsparse/spgemm_4args_test.cpp:78-95).
+ * set_addend registers D's pattern (m x n, int32) BEFORE spgemm_symbolic, which then counts
+ * pattern(A*B) U pattern(D); passing d_rowptr = NULL removes it again.  After such a symbolic
+ * pass the numeric step must be spgemm_numeric_addend (plain spgemm_numeric returns
+ * STATUS_PLAN_MISMATCH, and vice versa).  beta is a HOST pointer like alpha. */
+int spblas_gfx950_spgemm_set_addend(spblas_gfx950_handle_t handle, spblas_gfx950_spgemm_t state, int64_t d_nnz,
+                                    const int32_t* d_rowptr, const int32_t* d_colind);
+int spblas_gfx950_spgemm_numeric_addend(spblas_gfx950_handle_t handle, spblas_gfx950_spgemm_t state, const void* alpha,
+                                        const int32_t* a_rowptr, const int32_t* a_colind, const void* a_values,
+                                        const int32_t* b_rowptr, const int32_t* b_colind, const void* b_values,
+                                        const void* beta, const int32_t* d_rowptr, const int32_t* d_colind,
+                                        const void* d_values, int32_t* c_rowptr, int32_t* c_colind, void* c_values,
+                                        int64_t c_capacity, int value_type);
+
+/* ---- add:  C = alpha*A + beta*B  (CSR + CSR -> CSR, int32 indices) ------------------------ */
+/* Device counterpart of add(a, b, c) / add_inspect / add_compute (algorithms/add_impl.hpp:40-115;
+ * SURVEY.md section 8f rank 2).  Uses a spgemm state object (spblas_gfx950_spgemm_create): the
+ * symbolic call is add_inspect -- it writes c_rowptr (m+1) and returns nnz(C) = structural size of
+ * the union, add_impl.hpp:79-108 -- the numeric call is add_compute and may be repeated with new
+ * values.  Columns of every output row are ascending (SPA + sort, add_impl.hpp:57-65).  alpha/beta
+ * carry the scaled_view factors of a and b (HOST pointers); capacity < nnz(C) gives
+ * STATUS_INSUFFICIENT_SPACE ("add: ran out of memory", add_impl.hpp:67-72). */
+int spblas_gfx950_csr_add_symbolic(spblas_gfx950_handle_t handle, spblas_gfx950_spgemm_t state, int64_t m, int64_t n,
+                                   int64_t a_nnz, const int32_t* a_rowptr, const int32_t* a_colind, int64_t b_nnz,
+                                   const int32_t* b_rowptr, const int32_t* b_colind, int32_t* c_rowptr,
+                                   int64_t* c_nnz);
+int spblas_gfx950_csr_add_numeric(spblas_gfx950_handle_t handle, spblas_gfx950_spgemm_t state, const void* alpha,
+                                  const int32_t* a_rowptr, const int32_t* a_colind, const void* a_values,
+                                  const void* beta, const int32_t* b_rowptr, const int32_t* b_colind,
+                                  const void* b_values, int32_t* c_rowptr, int32_t* c_colind, void* c_values,
+                                  int64_t c_capacity, int value_type);
+
 /* ---- transpose:  B = A^T  (CSR -> CSR, int32 indices) ------------------------------------ */
 /* Device counterpart of transpose(a, b) (algorithms/transpose_impl.hpp:14-53): stable counting
  * sort by column, so every output row lists its entries in source order.  t_rowptr has n+1

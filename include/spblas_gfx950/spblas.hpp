@@ -15,7 +15,8 @@
 //   matrix_opt                     views/matrix_opt_impl.hpp:14-93
 //   mdspan_row_major<T, I>         detail/mdspan.hpp:38-41 (minimal 2-D row-major view)
 //   operation_info_t               detail/operation_info_t.hpp:28-104
-//   spgemm_state_t + multiply_*    vendor/rocsparse/multiply_spgemm.hpp:28-317
+//   spgemm_state_t + multiply_*    vendor/rocsparse/multiply_spgemm.hpp:28-317 (3- and 4-argument forms)
+//   add / add_inspect / add_compute algorithms/add_impl.hpp:40-115
 //   multiply / multiply_inspect    vendor/rocsparse/detail/spmv_impl.hpp:18-90,
 //                                  vendor/onemkl_sycl/spmm_impl.hpp:133-198
 #include <algorithm>
@@ -518,6 +519,13 @@ public:
 
   template <typename A, typename B, typename C>
   void compute(A&& a, B&& b, C&& c) {
+    impl_->set_addend(0, nullptr, nullptr);
+    has_addend_ = false;
+    compute_products(a, b, c);
+  }
+
+  template <typename A, typename B, typename C>
+  void compute_products(A&& a, B&& b, C&& c) {
     auto ab = __detail::get_ultimate_base(a);
     auto bb = __detail::get_ultimate_base(b);
     __gfx950::reject_conjugated(__detail::is_conjugated(a) || __detail::is_conjugated(b));
@@ -543,10 +551,73 @@ public:
     c.update(c.values(), c.rowptr(), c.colind(), c.shape(), static_cast<typename std::remove_cvref_t<C>::offset_type>(result_nnz_));
   }
 
+  // C = alpha*A*B + beta*D (multiply_spgemm.hpp:118-214): alpha = scale(a)*scale(b), beta = scale(d)
+  template <typename A, typename B, typename C, typename D>
+  void compute(A&& a, B&& b, C&& c, D&& d) {
+    auto db = __detail::get_ultimate_base(d);
+    __gfx950::reject_conjugated(__detail::is_conjugated(d));
+    if (db.shape()[0] != c.shape()[0] || db.shape()[1] != c.shape()[1]) {
+      throw std::invalid_argument("multiply: matrix dimensions are incompatible.");
+    }
+    impl_->set_addend(db.size(), db.rowptr().data(), db.colind().data());
+    has_addend_ = true;
+    compute_products(a, b, c);
+  }
+  template <typename A, typename B, typename C, typename D>
+  void numeric(A&& a, B&& b, C&& c, D&& d) {
+    if (!has_addend_) {
+      throw std::runtime_error("multiply_fill: the addend must be passed to multiply_compute as well");
+    }
+    auto ab = __detail::get_ultimate_base(a);
+    auto bb = __detail::get_ultimate_base(b);
+    auto db = __detail::get_ultimate_base(d);
+    using T = typename decltype(ab)::scalar_type;
+    const T alpha = static_cast<T>(__detail::get_scaling_factor(a, b).value_or(1.0));
+    const T beta = static_cast<T>(__detail::get_scaling_factor(d).value_or(1.0));
+    const auto capacity = static_cast<std::int64_t>(std::min(c.values().size(), c.colind().size()));
+    impl_->numeric_addend<T>(alpha, ab.rowptr().data(), ab.colind().data(), ab.values().data(), bb.rowptr().data(),
+                             bb.colind().data(), bb.values().data(), beta, db.rowptr().data(), db.colind().data(),
+                             db.values().data(), c.rowptr().data(), c.colind().data(), c.values().data(), capacity);
+    c.update(c.values(), c.rowptr(), c.colind(), c.shape(), static_cast<typename std::remove_cvref_t<C>::offset_type>(result_nnz_));
+  }
+
+  // add(a, b, c) (algorithms/add_impl.hpp:40-115)
+  template <typename A, typename B, typename C>
+  void add_symbolic(A&& a, B&& b, C&& c) {
+    auto ab = __detail::get_ultimate_base(a);
+    auto bb = __detail::get_ultimate_base(b);
+    __gfx950::reject_conjugated(__detail::is_conjugated(a) || __detail::is_conjugated(b));
+    if (ab.shape()[0] != bb.shape()[0] || ab.shape()[1] != bb.shape()[1] || bb.shape()[0] != c.shape()[0] ||
+        bb.shape()[1] != c.shape()[1]) {
+      throw std::invalid_argument("add: matrix dimensions are incompatible.");  // add_impl.hpp:44-47
+    }
+    result_nnz_ = impl_->add_symbolic(ab.shape()[0], ab.shape()[1], ab.size(), ab.rowptr().data(), ab.colind().data(),
+                                      bb.size(), bb.rowptr().data(), bb.colind().data(), c.rowptr().data());
+    result_shape_ = index<index_t>(ab.shape()[0], ab.shape()[1]);
+    has_addend_ = true;
+  }
+  template <typename A, typename B, typename C>
+  void add_numeric(A&& a, B&& b, C&& c) {
+    auto ab = __detail::get_ultimate_base(a);
+    auto bb = __detail::get_ultimate_base(b);
+    using T = typename decltype(ab)::scalar_type;
+    const T alpha = static_cast<T>(__detail::get_scaling_factor(a).value_or(1.0));
+    const T beta = static_cast<T>(__detail::get_scaling_factor(b).value_or(1.0));
+    const auto capacity = static_cast<std::int64_t>(std::min(c.values().size(), c.colind().size()));
+    if (capacity < result_nnz_) {  // add_impl.hpp:67-72
+      throw std::runtime_error("add: ran out of memory.  CSR output view has insufficient memory.");
+    }
+    impl_->add_numeric<T>(alpha, ab.rowptr().data(), ab.colind().data(), ab.values().data(), beta, bb.rowptr().data(),
+                          bb.colind().data(), bb.values().data(), c.rowptr().data(), c.colind().data(),
+                          c.values().data(), capacity);
+    c.update(c.values(), c.rowptr(), c.colind(), c.shape(), static_cast<typename std::remove_cvref_t<C>::offset_type>(result_nnz_));
+  }
+
 private:
   std::unique_ptr<__gfx950::spgemm_handle_t> impl_;
   index<index_t> result_shape_{0, 0};
   std::int64_t result_nnz_ = 0;
+  bool has_addend_ = false;
 };
 
 template <typename A, typename B, typename C>
@@ -577,6 +648,36 @@ void multiply_numeric(spgemm_state_t& s, A&& a, B&& b, C&& c) {
   s.numeric(a, b, c);
 }
 
+// four-argument family (multiply_spgemm.hpp:237-274)
+template <typename A, typename B, typename C, typename D>
+  requires(__detail::has_csr_base<A> && __detail::has_csr_base<B> && __detail::is_csr<std::remove_cvref_t<C>>::value &&
+           __detail::has_csr_base<D>)
+void multiply_compute(spgemm_state_t& s, A&& a, B&& b, C&& c, D&& d) {
+  s.compute(a, b, c, d);
+}
+template <typename A, typename B, typename C, typename D>
+  requires(__detail::has_csr_base<A> && __detail::has_csr_base<B> && __detail::is_csr<std::remove_cvref_t<C>>::value &&
+           __detail::has_csr_base<D>)
+void multiply_fill(spgemm_state_t& s, A&& a, B&& b, C&& c, D&& d) {
+  s.numeric(a, b, c, d);
+}
+template <typename A, typename B, typename C, typename D>
+  requires(__detail::has_csr_base<A> && __detail::has_csr_base<B> && __detail::is_csr<std::remove_cvref_t<C>>::value &&
+           __detail::has_csr_base<D>)
+void multiply_symbolic_compute(spgemm_state_t& s, A&& a, B&& b, C&& c, D&& d) {
+  s.compute(a, b, c, d);
+}
+template <typename A, typename B, typename C, typename D>
+  requires(__detail::has_csr_base<A> && __detail::has_csr_base<B> && __detail::is_csr<std::remove_cvref_t<C>>::value &&
+           __detail::has_csr_base<D>)
+void multiply_symbolic_fill(spgemm_state_t&, A&&, B&&, C&&, D&&) {}
+template <typename A, typename B, typename C, typename D>
+  requires(__detail::has_csr_base<A> && __detail::has_csr_base<B> && __detail::is_csr<std::remove_cvref_t<C>>::value &&
+           __detail::has_csr_base<D>)
+void multiply_numeric(spgemm_state_t& s, A&& a, B&& b, C&& c, D&& d) {
+  s.numeric(a, b, c, d);
+}
+
 template <typename A, typename B, typename C>
   requires(__detail::has_csr_base<A> && __detail::has_csr_base<B> && __detail::is_csr<std::remove_cvref_t<C>>::value)
 void multiply_compute(operation_info_t& info, A&& a, B&& b, C&& c) {
@@ -600,6 +701,39 @@ void multiply_fill(operation_info_t& info, A&& a, B&& b, C&& c) {
     throw std::runtime_error("multiply_fill: info does not come from multiply_compute");
   }
   info.spgemm_->numeric(a, b, c);
+}
+
+// ---- add (algorithms/add.hpp:8-19, add_impl.hpp:40-115) ----------------------------------------
+template <typename A, typename B, typename C>
+  requires(__detail::has_csr_base<A> && __detail::has_csr_base<B> && __detail::is_csr<std::remove_cvref_t<C>>::value)
+void add_inspect(operation_info_t& info, A&& a, B&& b, C&& c) {
+  if (!info.spgemm_) {
+    info.spgemm_ = std::make_shared<spgemm_state_t>();
+  }
+  info.spgemm_->add_symbolic(a, b, c);
+  info.update_impl_(info.spgemm_->result_shape(), info.spgemm_->result_nnz());
+}
+template <typename A, typename B, typename C>
+  requires(__detail::has_csr_base<A> && __detail::has_csr_base<B> && __detail::is_csr<std::remove_cvref_t<C>>::value)
+operation_info_t add_inspect(A&& a, B&& b, C&& c) {
+  operation_info_t info;
+  add_inspect(info, a, b, c);
+  return info;
+}
+template <typename A, typename B, typename C>
+  requires(__detail::has_csr_base<A> && __detail::has_csr_base<B> && __detail::is_csr<std::remove_cvref_t<C>>::value)
+void add_compute(operation_info_t& info, A&& a, B&& b, C&& c) {
+  if (!info.spgemm_) {
+    throw std::runtime_error("add_compute: info does not come from add_inspect");
+  }
+  info.spgemm_->add_numeric(a, b, c);
+}
+template <typename A, typename B, typename C>
+  requires(__detail::has_csr_base<A> && __detail::has_csr_base<B> && __detail::is_csr<std::remove_cvref_t<C>>::value)
+void add(A&& a, B&& b, C&& c) {
+  spgemm_state_t s;
+  s.add_symbolic(a, b, c);
+  s.add_numeric(a, b, c);
 }
 
 } // namespace spblas

@@ -199,6 +199,85 @@ def spgemm_numeric(a_shape, a_rowptr, a_colind, a_values, b_shape, b_rowptr, b_c
     return c_rowptr, c_colind[:nnz.value], c_values[:nnz.value]
 
 
+def spgemm_symbolic_d(a_shape, a_rowptr, a_colind, b_shape, b_rowptr, b_colind, d_shape, d_rowptr, d_colind,
+                      c_shape=None):
+    """Structural count of C = A*B + D (spgemm_4args_test.cpp:78-95,108): returns (nnz, row_nnz[m])."""
+    lib = load()
+    arrs = [np.ascontiguousarray(x, dtype=np.int32) for x in (a_rowptr, a_colind, b_rowptr, b_colind, d_rowptr,
+                                                               d_colind)]
+    if c_shape is None:
+        c_shape = (a_shape[0], b_shape[1])
+    row_nnz = np.zeros(a_shape[0], dtype=np.int64)
+    nnz = c_i64(0)
+    lib.oracle_spgemm_symbolic_d.restype = c_int
+    rc = lib.oracle_spgemm_symbolic_d(c_i64(a_shape[0]), c_i64(a_shape[1]), c_i64(b_shape[1]), c_i64(c_shape[0]),
+                                      c_i64(c_shape[1]), c_i64(b_shape[0]), c_i64(d_shape[0]), c_i64(d_shape[1]),
+                                      *[_p(x) for x in arrs], _p(row_nnz), ctypes.byref(nnz))
+    _raise(rc)
+    return nnz.value, row_nnz
+
+
+def spgemm_numeric_d(a_shape, a_rowptr, a_colind, a_values, b_shape, b_rowptr, b_colind, b_values, d_shape,
+                     d_rowptr, d_colind, d_values, capacity, alpha=1.0, beta=1.0, c_shape=None):
+    """C = alpha*A*B + beta*D (vendor/rocsparse/multiply_spgemm.hpp:118-214; expected values
+    spgemm_4args_test.cpp:78-95): returns (rowptr, colind, values), columns ascending."""
+    lib = load()
+    a_rowptr, a_colind, b_rowptr, b_colind, d_rowptr, d_colind = [
+        np.ascontiguousarray(x, dtype=np.int32) for x in (a_rowptr, a_colind, b_rowptr, b_colind, d_rowptr, d_colind)]
+    a_values = np.ascontiguousarray(a_values)
+    b_values = np.ascontiguousarray(b_values, dtype=a_values.dtype)
+    d_values = np.ascontiguousarray(d_values, dtype=a_values.dtype)
+    if c_shape is None:
+        c_shape = (a_shape[0], b_shape[1])
+    c_rowptr = np.zeros(c_shape[0] + 1, dtype=np.int32)
+    c_colind = np.zeros(max(capacity, 1), dtype=np.int32)
+    c_values = np.zeros(max(capacity, 1), dtype=a_values.dtype)
+    T = _ct(a_values.dtype)
+    nnz = c_i64(0)
+    fn = getattr(lib, "oracle_spgemm_numeric_d_" + _sfx(a_values.dtype))
+    fn.restype = c_int
+    rc = fn(c_i64(a_shape[0]), c_i64(a_shape[1]), c_i64(b_shape[1]), c_i64(c_shape[0]), c_i64(c_shape[1]),
+            c_i64(b_shape[0]), c_i64(d_shape[0]), c_i64(d_shape[1]), _p(a_rowptr), _p(a_colind), _p(a_values),
+            T(alpha), _p(b_rowptr), _p(b_colind), _p(b_values), T(beta), _p(d_rowptr), _p(d_colind), _p(d_values),
+            _p(c_rowptr), _p(c_colind), _p(c_values), c_i64(capacity), ctypes.byref(nnz))
+    _raise(rc)
+    return c_rowptr, c_colind[:nnz.value], c_values[:nnz.value]
+
+
+def add(shape, a_rowptr, a_colind, a_values, b_shape, b_rowptr, b_colind, b_values, capacity=None, c_shape=None,
+        scale_a=None, scale_b=None, symbolic=False):
+    """Reference add(a, b, c) (algorithms/add_impl.hpp:40-77): returns (rowptr, colind, values) of A + B with
+    ascending columns.  symbolic=True is add_inspect (:79-108): returns (nnz, rowptr)."""
+    lib = load()
+    a_rowptr, a_colind, b_rowptr, b_colind = [np.ascontiguousarray(x, dtype=np.int32)
+                                              for x in (a_rowptr, a_colind, b_rowptr, b_colind)]
+    a_values = np.ascontiguousarray(a_values)
+    b_values = np.ascontiguousarray(b_values, dtype=a_values.dtype)
+    if c_shape is None:
+        c_shape = tuple(shape)
+    if capacity is None:
+        capacity = int(a_rowptr[-1]) + int(b_rowptr[-1])
+    c_rowptr = np.zeros(c_shape[0] + 1, dtype=np.int32)
+    c_colind = np.zeros(max(capacity, 1), dtype=np.int32)
+    c_values = np.zeros(max(capacity, 1), dtype=a_values.dtype)
+    T = _ct(a_values.dtype)
+    nnz = c_i64(0)
+    fn = getattr(lib, "oracle_add_" + _sfx(a_values.dtype))
+    fn.restype = c_int
+    rc = fn(c_i64(shape[0]), c_i64(shape[1]), c_i64(b_shape[0]), c_i64(b_shape[1]), c_i64(c_shape[0]),
+            c_i64(c_shape[1]), _p(a_rowptr), _p(a_colind), _p(a_values), c_int(scale_a is not None),
+            T(0 if scale_a is None else scale_a), _p(b_rowptr), _p(b_colind), _p(b_values),
+            c_int(scale_b is not None), T(0 if scale_b is None else scale_b), _p(c_rowptr),
+            None if symbolic else _p(c_colind), None if symbolic else _p(c_values), c_i64(capacity),
+            ctypes.byref(nnz))
+    if rc == 2:
+        raise RuntimeError("add: ran out of memory.  CSR output view has insufficient memory.")
+    _raise(rc)
+    if symbolic:
+        return nnz.value, c_rowptr
+    return c_rowptr, c_colind[:nnz.value], c_values[:nnz.value]
+
+
 def spmv_absrow(rowptr, colind, values, x):
     """Per-row sum |a_v * x_k| in float64: the scale of the norm-wise tolerance."""
     lib = load()

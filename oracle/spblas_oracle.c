@@ -295,6 +295,221 @@ static int cmp_i32(const void* a, const void* b) {
 DEF_SPGEMM_NUMERIC(oracle_spgemm_numeric_f32, float)
 DEF_SPGEMM_NUMERIC(oracle_spgemm_numeric_f64, double)
 
+/* ------------------------------------------------------------------------ */
+/* Four-argument SpGEMM  C = alpha*A*B + beta*D  (SURVEY section 8f rank 3).   */
+/* The reference has no CPU implementation of this form; the device slot       */
+/* (vendor/rocsparse/multiply_spgemm.hpp:118-214, alpha = scale(a)*scale(b)     */
+/* :129-132, beta = scale(d) :133-134) is pinned by the loop its own test       */
+/* compares against, test/gtest/device/rocsparse/spgemm_4args_test.cpp:78-95:   */
+/* per row, SPA += a_v*b_v over the products, then SPA[k] += d_v over row i of  */
+/* D; nnz(C) = size of the SPA (structural union, :108).  That loop is what is  */
+/* restated here; alpha scales the A element and beta the D element, the way   */
+/* scaled views scale per element in the 3-argument oracle above (the test's    */
+/* scaled variants multiply the expected products by the same factors, within   */
+/* its tolerance).  Columns are emitted ascending like the CPU csr_builder.     */
+/* ------------------------------------------------------------------------ */
+int oracle_spgemm_symbolic_d(int64_t m, int64_t k, int64_t n, int64_t c_rows,
+                             int64_t c_cols, int64_t b_rows, int64_t d_rows,
+                             int64_t d_cols, const int32_t* a_rowptr,
+                             const int32_t* a_colind, const int32_t* b_rowptr,
+                             const int32_t* b_colind, const int32_t* d_rowptr,
+                             const int32_t* d_colind, int64_t* row_nnz,
+                             int64_t* nnz_out) {
+  if (m != c_rows || n != c_cols || k != b_rows || d_rows != m || d_cols != n)
+    return ORACLE_ERR_SHAPE;
+  uint8_t* set = (uint8_t*) calloc((size_t) (n > 0 ? n : 1), 1);
+  int32_t* stored = (int32_t*) malloc(sizeof(int32_t) * (size_t) (n > 0 ? n : 1));
+  if (!set || !stored) {
+    free(set);
+    free(stored);
+    return ORACLE_ERR_ALLOC;
+  }
+  int64_t nnz = 0;
+  for (int64_t i = 0; i < m; i++) {
+    int64_t cnt = 0;
+    for (int32_t p = a_rowptr[i]; p < a_rowptr[i + 1]; p++) {
+      int32_t kk = a_colind[p];
+      for (int32_t q = b_rowptr[kk]; q < b_rowptr[kk + 1]; q++) {
+        int32_t j = b_colind[q];
+        if (!set[j]) {
+          set[j] = 1;
+          stored[cnt++] = j;
+        }
+      }
+    }
+    for (int32_t q = d_rowptr[i]; q < d_rowptr[i + 1]; q++) {
+      int32_t j = d_colind[q];
+      if (!set[j]) {
+        set[j] = 1;
+        stored[cnt++] = j;
+      }
+    }
+    for (int64_t t = 0; t < cnt; t++)
+      set[stored[t]] = 0;
+    if (row_nnz)
+      row_nnz[i] = cnt;
+    nnz += cnt;
+  }
+  free(set);
+  free(stored);
+  *nnz_out = nnz;
+  return ORACLE_OK;
+}
+
+#define DEF_SPGEMM_NUMERIC_D(NAME, T)                                          \
+  int NAME(int64_t m, int64_t k, int64_t n, int64_t c_rows, int64_t c_cols,    \
+           int64_t b_rows, int64_t d_rows, int64_t d_cols,                     \
+           const int32_t* a_rowptr, const int32_t* a_colind,                   \
+           const T* a_values, T alpha, const int32_t* b_rowptr,                \
+           const int32_t* b_colind, const T* b_values, T beta,                 \
+           const int32_t* d_rowptr, const int32_t* d_colind,                   \
+           const T* d_values, int32_t* c_rowptr, int32_t* c_colind,            \
+           T* c_values, int64_t capacity, int64_t* nnz_out) {                  \
+    if (m != c_rows || n != c_cols || k != b_rows || d_rows != m ||            \
+        d_cols != n)                                                           \
+      return ORACLE_ERR_SHAPE;                                                 \
+    size_t nn = (size_t) (n > 0 ? n : 1);                                      \
+    T* data = (T*) calloc(nn, sizeof(T));                                      \
+    uint8_t* set = (uint8_t*) calloc(nn, 1);                                   \
+    int32_t* stored = (int32_t*) malloc(sizeof(int32_t) * nn);                 \
+    if (!data || !set || !stored) {                                            \
+      free(data);                                                              \
+      free(set);                                                               \
+      free(stored);                                                            \
+      return ORACLE_ERR_ALLOC;                                                 \
+    }                                                                          \
+    int64_t jp = 0;                                                            \
+    int rc = ORACLE_OK;                                                        \
+    c_rowptr[0] = 0;                                                           \
+    for (int64_t i = 0; i < m; i++) {                                          \
+      int64_t cnt = 0;                                                         \
+      for (int32_t p = a_rowptr[i]; p < a_rowptr[i + 1]; p++) {                \
+        int32_t kk = a_colind[p];                                              \
+        T a_v = alpha * a_values[p];                                           \
+        for (int32_t q = b_rowptr[kk]; q < b_rowptr[kk + 1]; q++) {            \
+          int32_t j = b_colind[q];                                             \
+          if (!set[j]) {                                                       \
+            set[j] = 1;                                                        \
+            stored[cnt++] = j;                                                 \
+          }                                                                    \
+          data[j] += a_v * b_values[q];                                        \
+        }                                                                      \
+      }                                                                        \
+      for (int32_t q = d_rowptr[i]; q < d_rowptr[i + 1]; q++) {                \
+        int32_t j = d_colind[q];                                               \
+        if (!set[j]) {                                                         \
+          set[j] = 1;                                                          \
+          stored[cnt++] = j;                                                   \
+        }                                                                      \
+        data[j] += beta * d_values[q];                                         \
+      }                                                                        \
+      qsort(stored, (size_t) cnt, sizeof(int32_t), cmp_i32);                   \
+      if (jp + cnt > capacity) {                                               \
+        rc = ORACLE_ERR_NOSPACE;                                               \
+        for (int64_t t = 0; t < cnt; t++) {                                    \
+          set[stored[t]] = 0;                                                  \
+          data[stored[t]] = 0;                                                 \
+        }                                                                      \
+        break;                                                                 \
+      }                                                                        \
+      for (int64_t t = 0; t < cnt; t++) {                                      \
+        int32_t j = stored[t];                                                 \
+        c_values[jp] = data[j];                                                \
+        c_colind[jp] = j;                                                      \
+        jp++;                                                                  \
+        set[j] = 0;                                                            \
+        data[j] = 0;                                                           \
+      }                                                                        \
+      c_rowptr[i + 1] = (int32_t) jp;                                          \
+    }                                                                          \
+    free(data);                                                                \
+    free(set);                                                                 \
+    free(stored);                                                              \
+    *nnz_out = jp;                                                             \
+    return rc;                                                                 \
+  }
+DEF_SPGEMM_NUMERIC_D(oracle_spgemm_numeric_d_f32, float)
+DEF_SPGEMM_NUMERIC_D(oracle_spgemm_numeric_d_f64, double)
+
+/* ------------------------------------------------------------------------ */
+/* add(a, b, c): C = A + B, CSR + CSR -> CSR (algorithms/add_impl.hpp:40-77). */
+/* Per row: SPA c_row[j] += v over row i of A, then over row i of B (:57-63),  */
+/* columns sorted ascending (:65), appended through csr_builder (:67-72; too    */
+/* little room -> "add: ran out of memory", ERR_NOSPACE).  Shape mismatch ->    */
+/* ERR_SHAPE (:44-47).  scaled(alpha, a) / scaled(beta, b) scale per element    */
+/* (views/scaled_view_impl.hpp:145-177).  add_inspect (:79-108) is the          */
+/* structural count: with values == NULL only row counts / nnz are produced.    */
+/* ------------------------------------------------------------------------ */
+#define DEF_ADD(NAME, T)                                                       \
+  int NAME(int64_t m, int64_t n, int64_t b_rows, int64_t b_cols,               \
+           int64_t c_rows, int64_t c_cols, const int32_t* a_rowptr,            \
+           const int32_t* a_colind, const T* a_values, int has_sa, T sa,       \
+           const int32_t* b_rowptr, const int32_t* b_colind,                   \
+           const T* b_values, int has_sb, T sb, int32_t* c_rowptr,             \
+           int32_t* c_colind, T* c_values, int64_t capacity,                   \
+           int64_t* nnz_out) {                                                 \
+    if (m != b_rows || n != b_cols || m != c_rows || n != c_cols)              \
+      return ORACLE_ERR_SHAPE;                                                 \
+    const int numeric = c_values != NULL;                                      \
+    size_t nn = (size_t) (n > 0 ? n : 1);                                      \
+    T* data = (T*) calloc(nn, sizeof(T));                                      \
+    uint8_t* set = (uint8_t*) calloc(nn, 1);                                   \
+    int32_t* stored = (int32_t*) malloc(sizeof(int32_t) * nn);                 \
+    if (!data || !set || !stored) {                                            \
+      free(data);                                                              \
+      free(set);                                                               \
+      free(stored);                                                            \
+      return ORACLE_ERR_ALLOC;                                                 \
+    }                                                                          \
+    int64_t jp = 0;                                                            \
+    int rc = ORACLE_OK;                                                        \
+    c_rowptr[0] = 0;                                                           \
+    for (int64_t i = 0; i < m; i++) {                                          \
+      int64_t cnt = 0;                                                         \
+      for (int32_t p = a_rowptr[i]; p < a_rowptr[i + 1]; p++) {                \
+        int32_t j = a_colind[p];                                               \
+        if (!set[j]) {                                                         \
+          set[j] = 1;                                                          \
+          stored[cnt++] = j;                                                   \
+        }                                                                      \
+        if (numeric)                                                           \
+          data[j] += has_sa ? sa * a_values[p] : a_values[p];                  \
+      }                                                                        \
+      for (int32_t p = b_rowptr[i]; p < b_rowptr[i + 1]; p++) {                \
+        int32_t j = b_colind[p];                                               \
+        if (!set[j]) {                                                         \
+          set[j] = 1;                                                          \
+          stored[cnt++] = j;                                                   \
+        }                                                                      \
+        if (numeric)                                                           \
+          data[j] += has_sb ? sb * b_values[p] : b_values[p];                  \
+      }                                                                        \
+      qsort(stored, (size_t) cnt, sizeof(int32_t), cmp_i32);                   \
+      if (numeric && jp + cnt > capacity) {                                    \
+        rc = ORACLE_ERR_NOSPACE;                                               \
+        break;                                                                 \
+      }                                                                        \
+      for (int64_t t = 0; t < cnt; t++) {                                      \
+        int32_t j = stored[t];                                                 \
+        if (numeric) {                                                         \
+          c_values[jp] = data[j];                                              \
+          c_colind[jp] = j;                                                    \
+        }                                                                      \
+        jp++;                                                                  \
+        set[j] = 0;                                                            \
+        data[j] = 0;                                                           \
+      }                                                                        \
+      c_rowptr[i + 1] = (int32_t) jp;                                          \
+    }                                                                          \
+    free(data);                                                                \
+    free(set);                                                                 \
+    free(stored);                                                              \
+    *nnz_out = jp;                                                             \
+    return rc;                                                                 \
+  }
+DEF_ADD(oracle_add_f32, float)
+DEF_ADD(oracle_add_f64, double)
+
 /* Per-row sum of |a_v * x_k| -- the norm the parity tolerance is scaled by
  * (SURVEY section 8c "Tolerance note"; reference comparator test/gtest/util.hpp:7-23
  * is likewise norm-wise).  Computed in double. */

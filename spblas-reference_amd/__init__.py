@@ -11,7 +11,7 @@ Import name: `spblas_reference_amd` (see the shim module at the repo root).
 from . import _build, _capi, generate  # noqa: F401
 from ._capi import BackendError  # noqa: F401
 from .api import (  # noqa: F401
-    conjugated, csc_view, csr_view, get_scaling_factor, get_ultimate_base, has_matrix_opt, index, is_conjugated,
+    add, add_compute, add_inspect, conjugated, csc_view, csr_view, get_scaling_factor, get_ultimate_base, has_matrix_opt, index, is_conjugated,
     matrix_opt, multiply, multiply_compute, multiply_fill, multiply_inspect, multiply_numeric,
     multiply_symbolic_compute, multiply_symbolic_fill, operation_info_t, prepared_multiply, scaled, scaled_view,
     spgemm_state_t, transpose, transpose_inspect,

@@ -63,6 +63,16 @@ PROTOTYPES = [
     ("spblas_gfx950_spgemm_numeric", c_int,
      [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
       c_void_p, c_i64, c_int]),
+    ("spblas_gfx950_csr_add_symbolic", c_int,
+     [c_void_p, c_void_p, c_i64, c_i64, c_i64, c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_void_p,
+      ctypes.POINTER(c_i64)]),
+    ("spblas_gfx950_csr_add_numeric", c_int,
+     [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+      c_void_p, c_void_p, c_i64, c_int]),
+    ("spblas_gfx950_spgemm_set_addend", c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_void_p]),
+    ("spblas_gfx950_spgemm_numeric_addend", c_int,
+     [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int]),
 ]
 
 _LIB = None

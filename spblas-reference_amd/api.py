@@ -620,7 +620,22 @@ def _spgemm_operands(a, b, c):
     return a_base, b_base
 
 
-def _symbolic(state, a, b, c):
+def _addend(d, c):
+    """Addend D of the four-argument form C = alpha*A*B + beta*D
+    (vendor/rocsparse/multiply_spgemm.hpp:118-214): CSR (optionally scaled) of C's shape."""
+    d_base = get_ultimate_base(d)
+    if not isinstance(d_base, csr_view):
+        raise NotImplementedError("gfx950 SpGEMM addend must be a csr_view")
+    _reject_conjugated(d)
+    _check_csr(d_base, "multiply_compute")
+    if d_base.rowptr().dtype != torch.int32:
+        raise TypeError("SpGEMM: int32 row offsets only")
+    if tuple(d_base.shape()) != tuple(c.shape()):
+        raise ValueError("multiply: matrix dimensions are incompatible.")
+    return d_base
+
+
+def _symbolic(state, a, b, c, d=None):
     a_base, b_base = _spgemm_operands(a, b, c)
     if c.rowptr() is None or c.rowptr().dtype != torch.int32 or c.rowptr().numel() < c.shape()[0] + 1:
         raise ValueError("multiply_compute: c.rowptr must hold shape[0]+1 int32 entries")
@@ -628,6 +643,13 @@ def _symbolic(state, a, b, c):
     nnz = ctypes.c_int64(0)
     m, k = a_base.shape()
     n = b_base.shape()[1]
+    if d is not None:
+        d_base = _addend(d, c)
+        check(_capi.lib().spblas_gfx950_spgemm_set_addend(hd.h, st, d_base.size(), _ptr(d_base.rowptr()),
+                                                          _ptr(d_base.colind())), "multiply_compute")
+    else:
+        check(_capi.lib().spblas_gfx950_spgemm_set_addend(hd.h, st, 0, None, None), "multiply_compute")
+    state._has_addend = d is not None
     check(_capi.lib().spblas_gfx950_spgemm_symbolic(hd.h, st, m, k, n, a_base.size(), _ptr(a_base.rowptr()),
                                                     _ptr(a_base.colind()), b_base.size(), _ptr(b_base.rowptr()),
                                                     _ptr(b_base.colind()), _ptr(c.rowptr()), ctypes.byref(nnz)),
@@ -635,10 +657,12 @@ def _symbolic(state, a, b, c):
     state._result_shape, state._result_nnz = index(m, n), nnz.value
 
 
-def _numeric(state, a, b, c):
+def _numeric(state, a, b, c, d=None):
     a_base, b_base = _spgemm_operands(a, b, c)
     if state._state is None:
         raise RuntimeError("multiply_fill: multiply_compute has not been called on this state")
+    if (d is not None) != getattr(state, "_has_addend", False):
+        raise RuntimeError("multiply_fill: the addend must be passed to both multiply_compute and multiply_fill")
     hd, st = state._ensure(c.rowptr().device)
     nnz = state._result_nnz
     cap = 0
@@ -649,11 +673,23 @@ def _numeric(state, a, b, c):
     vt, ct = _vtype(a_base.values(), "multiply_fill")
     alpha_opt = get_scaling_factor(a, b)
     alpha = ct(1 if alpha_opt is None else alpha_opt)
-    check(_capi.lib().spblas_gfx950_spgemm_numeric(hd.h, st, ctypes.byref(alpha), _ptr(a_base.rowptr()),
-                                                   _ptr(a_base.colind()), _ptr(a_base.values()),
-                                                   _ptr(b_base.rowptr()), _ptr(b_base.colind()),
-                                                   _ptr(b_base.values()), _ptr(c.rowptr()), _ptr(c.colind()),
-                                                   _ptr(c.values()), cap, vt), "multiply_fill")
+    if d is not None:
+        d_base = _addend(d, c)
+        if d_base.values().dtype != a_base.values().dtype:
+            raise TypeError("multiply_fill: the addend must have A's value type")
+        beta_opt = get_scaling_factor(d)
+        beta = ct(1 if beta_opt is None else beta_opt)  # multiply_spgemm.hpp:188-189
+        check(_capi.lib().spblas_gfx950_spgemm_numeric_addend(
+            hd.h, st, ctypes.byref(alpha), _ptr(a_base.rowptr()), _ptr(a_base.colind()), _ptr(a_base.values()),
+            _ptr(b_base.rowptr()), _ptr(b_base.colind()), _ptr(b_base.values()), ctypes.byref(beta),
+            _ptr(d_base.rowptr()), _ptr(d_base.colind()), _ptr(d_base.values()), _ptr(c.rowptr()),
+            _ptr(c.colind()), _ptr(c.values()), cap, vt), "multiply_fill")
+    else:
+        check(_capi.lib().spblas_gfx950_spgemm_numeric(hd.h, st, ctypes.byref(alpha), _ptr(a_base.rowptr()),
+                                                       _ptr(a_base.colind()), _ptr(a_base.values()),
+                                                       _ptr(b_base.rowptr()), _ptr(b_base.colind()),
+                                                       _ptr(b_base.values()), _ptr(c.rowptr()), _ptr(c.colind()),
+                                                       _ptr(c.values()), cap, vt), "multiply_fill")
     c.update(c.values(), c.rowptr(), c.colind(), state._result_shape, nnz)  # spgemm_gustavsons.hpp:50-51
 
 
@@ -661,6 +697,10 @@ def multiply_compute(*args):
     """multiply_compute(a, b, c) -> operation_info_t; multiply_compute(info, a, b, c);
     multiply_compute(spgemm_state, a, b, c)   (algorithms/multiply.hpp:48-52,
     vendor/rocsparse/multiply_spgemm.hpp:72-118,277-283).  Writes c.rowptr, reports nnz(C)."""
+    if len(args) == 5:  # (spgemm_state, a, b, c, d): C = alpha*A*B + beta*D, multiply_spgemm.hpp:237-243
+        if not isinstance(args[0], spgemm_state_t):
+            raise TypeError("multiply_compute(state, a, b, c, d): the five-argument form takes a spgemm_state_t")
+        return _symbolic(*args)
     info, a, b, c = _split_info(args)
     if isinstance(info, spgemm_state_t):
         return _symbolic(info, a, b, c)
@@ -674,21 +714,21 @@ def multiply_compute(*args):
     return info if ret else None
 
 
-def multiply_fill(info, a, b, c):
-    """multiply_fill(info | spgemm_state, a, b, c) (algorithms/multiply.hpp:54-55,
-    vendor/rocsparse/multiply_spgemm.hpp:123-145)."""
+def multiply_fill(info, a, b, c, d=None):
+    """multiply_fill(info | spgemm_state, a, b, c[, d]) (algorithms/multiply.hpp:54-55,
+    vendor/rocsparse/multiply_spgemm.hpp:123-145,245-250)."""
     state = info if isinstance(info, spgemm_state_t) else info.state_
     if not isinstance(state, spgemm_state_t):
         raise RuntimeError("multiply_fill: info does not come from multiply_compute")
-    return _numeric(state, a, b, c)
+    return _numeric(state, a, b, c, d)
 
 
 # symbolic/numeric reuse family (vendor/rocsparse/multiply_spgemm.hpp:252-274,293-317)
-def multiply_symbolic_compute(state, a, b, c):
-    return _symbolic(state, a, b, c)
+def multiply_symbolic_compute(state, a, b, c, d=None):
+    return _symbolic(state, a, b, c, d)
 
 
-def multiply_symbolic_fill(state, a, b, c):
+def multiply_symbolic_fill(state, a, b, c, d=None):
     """Binds C's arrays; the structure (rowptr) is already final after symbolic_compute,
     colind is produced together with the values by multiply_numeric."""
     _spgemm_operands(a, b, c)
@@ -697,5 +737,86 @@ def multiply_symbolic_fill(state, a, b, c):
     return None
 
 
-def multiply_numeric(state, a, b, c):
-    return _numeric(state, a, b, c)
+def multiply_numeric(state, a, b, c, d=None):
+    return _numeric(state, a, b, c, d)
+
+
+# --------------------------------------------------------------------------- add
+def _add_operands(a, b, c):
+    a_base, b_base = get_ultimate_base(a), get_ultimate_base(b)
+    if not (isinstance(a_base, csr_view) and isinstance(b_base, csr_view) and isinstance(c, csr_view)):
+        raise NotImplementedError("gfx950 add supports CSR + CSR -> CSR")
+    _reject_conjugated(a, b)
+    for t in (a_base, b_base):
+        _check_csr(t, "add")
+        if t.rowptr().dtype != torch.int32:
+            raise TypeError("add: int32 row offsets only")
+    if tuple(a_base.shape()) != tuple(b_base.shape()) or tuple(b_base.shape()) != tuple(c.shape()):
+        raise ValueError("add: matrix dimensions are incompatible.")  # add_impl.hpp:44-47,83-86
+    if a_base.values().dtype != b_base.values().dtype:
+        raise TypeError("add: a and b must have the same value type")
+    return a_base, b_base
+
+
+def _add_symbolic(state, a, b, c):
+    a_base, b_base = _add_operands(a, b, c)
+    if c.rowptr() is None or c.rowptr().dtype != torch.int32 or c.rowptr().numel() < c.shape()[0] + 1:
+        raise ValueError("add_inspect: c.rowptr must hold shape[0]+1 int32 entries")
+    hd, st = state._ensure(c.rowptr().device)
+    nnz = ctypes.c_int64(0)
+    m, n = a_base.shape()
+    check(_capi.lib().spblas_gfx950_csr_add_symbolic(hd.h, st, m, n, a_base.size(), _ptr(a_base.rowptr()),
+                                                     _ptr(a_base.colind()), b_base.size(), _ptr(b_base.rowptr()),
+                                                     _ptr(b_base.colind()), _ptr(c.rowptr()), ctypes.byref(nnz)),
+          "add_inspect")
+    state._result_shape, state._result_nnz = index(m, n), nnz.value
+    state._has_addend = True
+
+
+def _add_numeric(state, a, b, c):
+    a_base, b_base = _add_operands(a, b, c)
+    hd, st = state._ensure(c.rowptr().device)
+    nnz = state._result_nnz
+    cap = 0
+    if c.values() is not None and c.colind() is not None:
+        cap = min(c.values().numel(), c.colind().numel())
+    if cap < nnz:  # add_impl.hpp:67-72
+        raise RuntimeError("add: ran out of memory.  CSR output view has insufficient memory.")
+    vt, ct = _vtype(a_base.values(), "add")
+    sa, sb = get_scaling_factor(a), get_scaling_factor(b)
+    alpha, beta = ct(1 if sa is None else sa), ct(1 if sb is None else sb)
+    check(_capi.lib().spblas_gfx950_csr_add_numeric(hd.h, st, ctypes.byref(alpha), _ptr(a_base.rowptr()),
+                                                    _ptr(a_base.colind()), _ptr(a_base.values()), ctypes.byref(beta),
+                                                    _ptr(b_base.rowptr()), _ptr(b_base.colind()),
+                                                    _ptr(b_base.values()), _ptr(c.rowptr()), _ptr(c.colind()),
+                                                    _ptr(c.values()), cap, vt), "add")
+    c.update(c.values(), c.rowptr(), c.colind(), state._result_shape, nnz)  # add_impl.hpp:75-76
+
+
+def add_inspect(*args):
+    """add_inspect(a, b, c) -> operation_info_t / add_inspect(info, a, b, c)
+    (algorithms/add.hpp:15-19, add_impl.hpp:79-108): structural nnz of A + B; also writes c.rowptr."""
+    info, a, b, c = _split_info(args)
+    ret = info is None
+    if info is None:
+        info = operation_info_t()
+    if not isinstance(info.state_, spgemm_state_t):
+        info.state_ = spgemm_state_t()
+    _add_symbolic(info.state_, a, b, c)
+    info.update_impl_(info.state_.result_shape(), info.state_.result_nnz())
+    return info if ret else None
+
+
+def add_compute(info, a, b, c):
+    """add_compute(info, a, b, c) (add_impl.hpp:110-113): fill c's colind / values."""
+    if not isinstance(info.state_, spgemm_state_t) or info.state_._state is None:
+        raise RuntimeError("add_compute: info does not come from add_inspect")
+    return _add_numeric(info.state_, a, b, c)
+
+
+def add(a, b, c):
+    """add(a, b, c): c = a + b for CSR operands (add_impl.hpp:40-77); c must already own enough
+    room for the result (csr_builder semantics)."""
+    state = spgemm_state_t()
+    _add_symbolic(state, a, b, c)
+    _add_numeric(state, a, b, c)

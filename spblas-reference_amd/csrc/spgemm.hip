@@ -1,4 +1,4 @@
-// CSR x CSR -> CSR SpGEMM for gfx950:  C = alpha * A * B.
+// CSR x CSR -> CSR SpGEMM for gfx950:  C = alpha * A * B  (+ beta * D with an addend).
 //
 // Replaces the rocsparse_spgemm stages used at
 // /root/reference/include/spblas/vendor/rocsparse/multiply_spgemm.hpp:94-115 (buffer_size+nnz),
@@ -17,6 +17,16 @@
 // Symbolic counts distinct keys; numeric accumulates with LDS float atomics, compacts,
 // rank-sorts the (unique) keys and writes colind/values in ascending column order.
 // Integer/byte traffic bound: algorithmic bytes = A + B once + C once.
+//
+// Four-argument form C = alpha*A*B + beta*D (multiply_spgemm.hpp:147-214; expected result
+// test/gtest/device/rocsparse/spgemm_4args_test.cpp:78-95): row i of D is fed through the same
+// accumulator after the products of row i, so pattern(C) = pattern(AB) U pattern(D) and the row
+// bound counts len(D_i) as well.
+//
+// add(a, b, c):  C = alpha*A + beta*B  (algorithms/add_impl.hpp:40-108) is the same
+// walk with B := identity (b_rowptr == nullptr in the kernels: "row" kk of B is the single entry
+// (kk, 1), the product is the A entry itself) and D := the second summand.  add_inspect is the
+// symbolic pass, add_compute the numeric one; columns come out ascending like the CPU SPA + sort.
 #include "common.hpp"
 #include "scan.hpp"
 
@@ -27,6 +37,10 @@
 struct spblas_gfx950_spgemm_s {
   int64_t m = 0, k = 0, n = 0, a_nnz = 0, b_nnz = 0, c_nnz = -1;
   const int32_t *a_rowptr = nullptr, *a_colind = nullptr, *b_rowptr = nullptr, *b_colind = nullptr;
+  const int32_t *d_rowptr = nullptr, *d_colind = nullptr;  // addend pattern (nullptr: C = alpha*A*B)
+  int64_t d_nnz = 0;
+  bool has_addend = false;  // pattern of D was part of the last symbolic pass
+  bool identity_b = false;  // B is the identity (add(): C = alpha*A + beta*D)
   int32_t* rowptr = nullptr;  // [m+1] device copy of C's row offsets
   int32_t* perm = nullptr;    // [m] rows grouped by bin
   int64_t bin_off[SPG_NBINS + 1] = {0, 0, 0, 0, 0, 0, 0};
@@ -58,6 +72,7 @@ __device__ __forceinline__ int spg_bin_of(int64_t ub) {
 __global__ __launch_bounds__(256) void spg_bound_kernel(int64_t m, const int32_t* __restrict__ a_rowptr,
                                                         const int32_t* __restrict__ a_colind,
                                                         const int32_t* __restrict__ b_rowptr,
+                                                        const int32_t* __restrict__ d_rowptr,
                                                         int32_t* __restrict__ bin_of_row,
                                                         unsigned long long* __restrict__ bin_count) {
   __shared__ unsigned int hist[SPG_NBINS];
@@ -70,10 +85,12 @@ __global__ __launch_bounds__(256) void spg_bound_kernel(int64_t m, const int32_t
   if (row < m) {
     for (int p = a_rowptr[row] + lane; p < a_rowptr[row + 1]; p += 8) {
       const int kk = a_colind[p];
-      ub += b_rowptr[kk + 1] - b_rowptr[kk];
+      ub += b_rowptr ? b_rowptr[kk + 1] - b_rowptr[kk] : 1;  // no B: identity (add(), see below)
     }
   }
   ub = group_sum_c<8>(ub);
+  if (row < m && d_rowptr)
+    ub += d_rowptr[row + 1] - d_rowptr[row];
   if (row < m && lane == 0) {
     const int b = spg_bin_of(ub);
     bin_of_row[row] = b;
@@ -119,7 +136,9 @@ __global__ __launch_bounds__(256) void spg_hash_kernel(
     int64_t count, const int32_t* __restrict__ perm, const int32_t* __restrict__ a_rowptr,
     const int32_t* __restrict__ a_colind, const T* __restrict__ a_values, const int32_t* __restrict__ b_rowptr,
     const int32_t* __restrict__ b_colind, const T* __restrict__ b_values, int32_t* __restrict__ c_rowptr,
-    int32_t* __restrict__ c_colind, T* __restrict__ c_values, T alpha, int sub, long long ncols) {
+    int32_t* __restrict__ c_colind, T* __restrict__ c_values, T alpha, int sub, long long ncols,
+    const int32_t* __restrict__ d_rowptr, const int32_t* __restrict__ d_colind, const T* __restrict__ d_values,
+    T beta) {
   constexpr int HS = 1 << LOG2HS;
   constexpr int RPB = 256 / TPR;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -171,8 +190,8 @@ __global__ __launch_bounds__(256) void spg_hash_kernel(
         T av = T(0);
         if (pc + lt < p1) {
           const int kk = a_colind[pc + lt];
-          qb = b_rowptr[kk];
-          qe = b_rowptr[kk + 1];
+          qb = b_rowptr ? b_rowptr[kk] : kk;
+          qe = b_rowptr ? b_rowptr[kk + 1] : kk + 1;
           if (NUMERIC)
             av = alpha * a_values[pc + lt];
         }
@@ -186,17 +205,22 @@ __global__ __launch_bounds__(256) void spg_hash_kernel(
           const int q1 = j < cnt ? q1s : q0;
           const T a = NUMERIC ? __shfl(av, src) : T(0);
           for (int q = q0 + sl; q < q1; q += sub)
-            insert(b_colind[q], NUMERIC ? a * b_values[q] : T(0));
+            insert(b_rowptr ? b_colind[q] : q, NUMERIC ? (b_rowptr ? a * b_values[q] : a) : T(0));
         }
       }
     } else {
       for (int p = p0 + sg; p < p1; p += nsg) {
         const int kk = a_colind[p];
         const T av = NUMERIC ? alpha * a_values[p] : T(0);
-        const int q1 = b_rowptr[kk + 1];
-        for (int q = b_rowptr[kk] + sl; q < q1; q += sub)
-          insert(b_colind[q], NUMERIC ? av * b_values[q] : T(0));
+        const int q1 = b_rowptr ? b_rowptr[kk + 1] : kk + 1;
+        for (int q = (b_rowptr ? b_rowptr[kk] : kk) + sl; q < q1; q += sub)
+          insert(b_rowptr ? b_colind[q] : q, NUMERIC ? (b_rowptr ? av * b_values[q] : av) : T(0));
       }
+    }
+    if (d_rowptr) {  // addend row: + beta * D_i
+      const int q1 = d_rowptr[row + 1];
+      for (int q = d_rowptr[row] + lt; q < q1; q += TPR)
+        insert(d_colind[q], NUMERIC ? beta * d_values[q] : T(0));
     }
   }
   __syncthreads();
@@ -302,7 +326,8 @@ __global__ __launch_bounds__(256) void spg_dense_kernel(
     const int32_t* __restrict__ a_colind, const T* __restrict__ a_values, const int32_t* __restrict__ b_rowptr,
     const int32_t* __restrict__ b_colind, const T* __restrict__ b_values, int32_t* __restrict__ c_rowptr,
     int32_t* __restrict__ c_colind, T* __restrict__ c_values, T alpha, uint32_t* __restrict__ bits_all,
-    T* __restrict__ vals_all) {
+    T* __restrict__ vals_all, const int32_t* __restrict__ d_rowptr, const int32_t* __restrict__ d_colind,
+    const T* __restrict__ d_values, T beta) {
   __shared__ int scan[256];
   __shared__ int running;
   const int64_t nwords = (n + 31) / 32;
@@ -320,12 +345,21 @@ __global__ __launch_bounds__(256) void spg_dense_kernel(
       T av = T(0);
       if (NUMERIC)
         av = alpha * a_values[p];
-      const int q1 = b_rowptr[kk + 1];
-      for (int q = b_rowptr[kk] + lane; q < q1; q += 64) {
-        const int col = b_colind[q];
+      const int q1 = b_rowptr ? b_rowptr[kk + 1] : kk + 1;
+      for (int q = (b_rowptr ? b_rowptr[kk] : kk) + lane; q < q1; q += 64) {
+        const int col = b_rowptr ? b_colind[q] : q;
         atomicOr(&bits[col >> 5], 1u << (col & 31));
         if (NUMERIC)
-          unsafeAtomicAdd(&vals[col], av * b_values[q]);
+          unsafeAtomicAdd(&vals[col], b_rowptr ? av * b_values[q] : av);
+      }
+    }
+    if (d_rowptr) {  // addend row: + beta * D_i
+      const int q1 = d_rowptr[row + 1];
+      for (int q = d_rowptr[row] + tid; q < q1; q += 256) {
+        const int col = d_colind[q];
+        atomicOr(&bits[col >> 5], 1u << (col & 31));
+        if (NUMERIC)
+          unsafeAtomicAdd(&vals[col], beta * d_values[q]);
       }
     }
     if (tid == 0)
@@ -396,7 +430,8 @@ static size_t hash_smem_bytes() {
 
 template <typename T, int LOG2HS, int TPR, bool NUMERIC>
 static int launch_hash(hipStream_t s, const spblas_gfx950_spgemm_s* st, int bin, const T* a_values,
-                       const T* b_values, int32_t* c_rowptr, int32_t* c_colind, T* c_values, T alpha) {
+                       const T* b_values, int32_t* c_rowptr, int32_t* c_colind, T* c_values, T alpha,
+                       const T* d_values, T beta) {
   const int64_t count = st->bin_off[bin + 1] - st->bin_off[bin];
   if (count == 0)
     return SPBLAS_GFX950_STATUS_SUCCESS;
@@ -409,23 +444,29 @@ static int launch_hash(hipStream_t s, const spblas_gfx950_spgemm_s* st, int bin,
   int sub = st->sub < TPR ? st->sub : TPR;
   hipLaunchKernelGGL(kern, dim3((unsigned) cdiv(count, RPB)), dim3(256), smem, s, count,
                      st->perm + st->bin_off[bin], st->a_rowptr, st->a_colind, a_values, st->b_rowptr,
-                     st->b_colind, b_values, c_rowptr, c_colind, c_values, alpha, sub, (long long) (st->n > 0 ? st->n : 1));
+                     st->b_colind, b_values, c_rowptr, c_colind, c_values, alpha, sub, (long long) (st->n > 0 ? st->n : 1),
+                     st->d_rowptr, st->d_colind, d_values, beta);
   SPB_HIP(hipGetLastError());
   return SPBLAS_GFX950_STATUS_SUCCESS;
 }
 
 template <typename T, bool NUMERIC>
 static int run_bins(spblas_gfx950_handle_t h, spblas_gfx950_spgemm_s* st, const T* a_values, const T* b_values,
-                    int32_t* c_rowptr, int32_t* c_colind, T* c_values, T alpha) {
+                    int32_t* c_rowptr, int32_t* c_colind, T* c_values, T alpha, const T* d_values = nullptr,
+                    T beta = T(0)) {
   hipStream_t s = h->stream;
   int rc;
-  if ((rc = launch_hash<T, 7, 16, NUMERIC>(s, st, 1, a_values, b_values, c_rowptr, c_colind, c_values, alpha)))
+  if ((rc = launch_hash<T, 7, 16, NUMERIC>(s, st, 1, a_values, b_values, c_rowptr, c_colind, c_values, alpha,
+                                           d_values, beta)))
     return rc;
-  if ((rc = launch_hash<T, 9, 64, NUMERIC>(s, st, 2, a_values, b_values, c_rowptr, c_colind, c_values, alpha)))
+  if ((rc = launch_hash<T, 9, 64, NUMERIC>(s, st, 2, a_values, b_values, c_rowptr, c_colind, c_values, alpha,
+                                           d_values, beta)))
     return rc;
-  if ((rc = launch_hash<T, 11, 128, NUMERIC>(s, st, 3, a_values, b_values, c_rowptr, c_colind, c_values, alpha)))
+  if ((rc = launch_hash<T, 11, 128, NUMERIC>(s, st, 3, a_values, b_values, c_rowptr, c_colind, c_values, alpha,
+                                           d_values, beta)))
     return rc;
-  if ((rc = launch_hash<T, 13, 256, NUMERIC>(s, st, 4, a_values, b_values, c_rowptr, c_colind, c_values, alpha)))
+  if ((rc = launch_hash<T, 13, 256, NUMERIC>(s, st, 4, a_values, b_values, c_rowptr, c_colind, c_values, alpha,
+                                           d_values, beta)))
     return rc;
   const int64_t cnt4 = st->bin_off[6] - st->bin_off[5];
   if (cnt4 > 0) {
@@ -447,7 +488,7 @@ static int run_bins(spblas_gfx950_handle_t h, spblas_gfx950_spgemm_s* st, const 
     hipLaunchKernelGGL((spg_dense_kernel<T, NUMERIC>), dim3((unsigned) st->dense_blocks), dim3(256), 0, s, cnt4,
                        st->perm + st->bin_off[5], st->n, st->a_rowptr, st->a_colind, a_values, st->b_rowptr,
                        st->b_colind, b_values, c_rowptr, c_colind, c_values, alpha, st->dense_bits,
-                       static_cast<T*>(st->dense_vals));
+                       static_cast<T*>(st->dense_vals), st->d_rowptr, st->d_colind, d_values, beta);
     SPB_HIP(hipGetLastError());
   }
   return SPBLAS_GFX950_STATUS_SUCCESS;
@@ -491,13 +532,28 @@ int spblas_gfx950_spgemm_destroy(spblas_gfx950_handle_t handle, spblas_gfx950_sp
   return SPBLAS_GFX950_STATUS_SUCCESS;
 }
 
-int spblas_gfx950_spgemm_symbolic(spblas_gfx950_handle_t handle, spblas_gfx950_spgemm_t st, int64_t m, int64_t k,
-                                  int64_t n, int64_t a_nnz, const int32_t* a_rowptr, const int32_t* a_colind,
-                                  int64_t b_nnz, const int32_t* b_rowptr, const int32_t* b_colind,
-                                  int32_t* c_rowptr, int64_t* c_nnz) {
+int spblas_gfx950_spgemm_set_addend(spblas_gfx950_handle_t handle, spblas_gfx950_spgemm_t st, int64_t d_nnz,
+                                    const int32_t* d_rowptr, const int32_t* d_colind) {
   if (!handle)
     return SPBLAS_GFX950_STATUS_INVALID_HANDLE;
-  if (!st || !c_nnz || !a_rowptr || !b_rowptr || !c_rowptr || (a_nnz > 0 && !a_colind) ||
+  if (!st || (d_rowptr && d_nnz > 0 && !d_colind))
+    return SPBLAS_GFX950_STATUS_INVALID_POINTER;
+  if (d_nnz < 0 || d_nnz > INT32_MAX)
+    return SPBLAS_GFX950_STATUS_INVALID_SIZE;
+  st->d_rowptr = d_rowptr;
+  st->d_colind = d_rowptr ? d_colind : nullptr;
+  st->d_nnz = d_rowptr ? d_nnz : 0;
+  st->c_nnz = -1;  // a new symbolic pass is required
+  return SPBLAS_GFX950_STATUS_SUCCESS;
+}
+
+static int spgemm_symbolic_impl(spblas_gfx950_handle_t handle, spblas_gfx950_spgemm_t st, int64_t m, int64_t k,
+                                int64_t n, int64_t a_nnz, const int32_t* a_rowptr, const int32_t* a_colind,
+                                int64_t b_nnz, const int32_t* b_rowptr, const int32_t* b_colind,
+                                int32_t* c_rowptr, int64_t* c_nnz, bool identity_b) {
+  if (!handle)
+    return SPBLAS_GFX950_STATUS_INVALID_HANDLE;
+  if (!st || !c_nnz || !a_rowptr || (!identity_b && !b_rowptr) || !c_rowptr || (a_nnz > 0 && !a_colind) ||
       (b_nnz > 0 && !b_colind))
     return SPBLAS_GFX950_STATUS_INVALID_POINTER;
   if (m < 0 || k < 0 || n < 0 || a_nnz < 0 || b_nnz < 0 || m >= INT32_MAX || k > INT32_MAX || n > INT32_MAX ||
@@ -505,6 +561,8 @@ int spblas_gfx950_spgemm_symbolic(spblas_gfx950_handle_t handle, spblas_gfx950_s
     return SPBLAS_GFX950_STATUS_INVALID_SIZE;
   hipStream_t s = handle->stream;
   spgemm_release(st, s);
+  st->has_addend = st->d_rowptr != nullptr;
+  st->identity_b = identity_b;
   st->m = m; st->k = k; st->n = n; st->a_nnz = a_nnz; st->b_nnz = b_nnz;
   st->a_rowptr = a_rowptr; st->a_colind = a_colind; st->b_rowptr = b_rowptr; st->b_colind = b_colind;
   // lanes per B row: power of two near the average B row length
@@ -540,7 +598,7 @@ int spblas_gfx950_spgemm_symbolic(spblas_gfx950_handle_t handle, spblas_gfx950_s
     return rc;
   SPB_HIP(hipMemsetAsync(d_cnt, 0, 2 * SPG_NBINS * sizeof(unsigned long long), s));
   hipLaunchKernelGGL(spg_bound_kernel, dim3((unsigned) cdiv(m, 32)), dim3(256), 0, s, m, a_rowptr, a_colind,
-                     b_rowptr, bin_of_row, d_cnt);
+                     b_rowptr, st->d_rowptr, bin_of_row, d_cnt);
   SPB_HIP(hipGetLastError());
   unsigned long long counts[SPG_NBINS];
   SPB_HIP(hipMemcpyAsync(counts, d_cnt, sizeof(counts), hipMemcpyDeviceToHost, s));
@@ -591,27 +649,47 @@ int spblas_gfx950_spgemm_symbolic(spblas_gfx950_handle_t handle, spblas_gfx950_s
   return rc;
 }
 
-int spblas_gfx950_spgemm_numeric(spblas_gfx950_handle_t handle, spblas_gfx950_spgemm_t st, const void* alpha,
-                                 const int32_t* a_rowptr, const int32_t* a_colind, const void* a_values,
-                                 const int32_t* b_rowptr, const int32_t* b_colind, const void* b_values,
-                                 int32_t* c_rowptr, int32_t* c_colind, void* c_values, int64_t c_capacity,
-                                 int value_type) {
+int spblas_gfx950_spgemm_symbolic(spblas_gfx950_handle_t handle, spblas_gfx950_spgemm_t st, int64_t m, int64_t k,
+                                  int64_t n, int64_t a_nnz, const int32_t* a_rowptr, const int32_t* a_colind,
+                                  int64_t b_nnz, const int32_t* b_rowptr, const int32_t* b_colind,
+                                  int32_t* c_rowptr, int64_t* c_nnz) {
+  return spgemm_symbolic_impl(handle, st, m, k, n, a_nnz, a_rowptr, a_colind, b_nnz, b_rowptr, b_colind, c_rowptr,
+                              c_nnz, false);
+}
+
+static int spgemm_numeric_impl(spblas_gfx950_handle_t handle, spblas_gfx950_spgemm_t st, const void* alpha,
+                               const int32_t* a_rowptr, const int32_t* a_colind, const void* a_values,
+                               const int32_t* b_rowptr, const int32_t* b_colind, const void* b_values,
+                               const void* beta, const int32_t* d_rowptr, const int32_t* d_colind,
+                               const void* d_values, int32_t* c_rowptr, int32_t* c_colind, void* c_values,
+                               int64_t c_capacity, int value_type) {
   if (!handle)
     return SPBLAS_GFX950_STATUS_INVALID_HANDLE;
-  if (!st || !alpha || !a_rowptr || !b_rowptr || !c_rowptr)
+  if (!st || !alpha || !a_rowptr || !c_rowptr)
     return SPBLAS_GFX950_STATUS_INVALID_POINTER;
   if (st->c_nnz < 0)
     return SPBLAS_GFX950_STATUS_INVALID_VALUE;  // symbolic has not run
   if (value_type != SPBLAS_GFX950_F32 && value_type != SPBLAS_GFX950_F64)
     return SPBLAS_GFX950_STATUS_INVALID_VALUE;
+  if (st->identity_b != (b_rowptr == nullptr))
+    return SPBLAS_GFX950_STATUS_PLAN_MISMATCH;
+  if (st->has_addend != (d_rowptr != nullptr))
+    return SPBLAS_GFX950_STATUS_PLAN_MISMATCH;  // the symbolic pass saw a different operand set
+  if (st->has_addend && (!beta || (st->d_nnz > 0 && (!d_colind || !d_values))))
+    return SPBLAS_GFX950_STATUS_INVALID_POINTER;
   if (c_capacity < st->c_nnz)
     return SPBLAS_GFX950_STATUS_INSUFFICIENT_SPACE;
-  if (st->c_nnz > 0 && (!c_colind || !c_values || !a_values || !b_values || !a_colind || !b_colind))
+  if (st->c_nnz > 0 && (!c_colind || !c_values || (st->a_nnz > 0 && (!a_values || !a_colind)) ||
+                        (!st->identity_b && st->b_nnz > 0 && (!b_values || !b_colind))))
     return SPBLAS_GFX950_STATUS_INVALID_POINTER;
   hipStream_t s = handle->stream;
   // pointers may be rebound between calls as long as the pattern is unchanged
   // (multiply_spgemm.hpp:195-208 rebinds them with rocsparse_csr_set_pointers)
   st->a_rowptr = a_rowptr; st->a_colind = a_colind; st->b_rowptr = b_rowptr; st->b_colind = b_colind;
+  if (st->has_addend) {
+    st->d_rowptr = d_rowptr;
+    st->d_colind = d_colind;
+  }
   if (c_rowptr != st->rowptr)
     SPB_HIP(hipMemcpyAsync(c_rowptr, st->rowptr, (size_t) (st->m + 1) * 4, hipMemcpyDeviceToDevice, s));
   if (st->c_nnz == 0)
@@ -619,10 +697,60 @@ int spblas_gfx950_spgemm_numeric(spblas_gfx950_handle_t handle, spblas_gfx950_sp
   if (value_type == SPBLAS_GFX950_F32)
     return run_bins<float, true>(handle, st, static_cast<const float*>(a_values),
                                  static_cast<const float*>(b_values), st->rowptr, c_colind,
-                                 static_cast<float*>(c_values), *static_cast<const float*>(alpha));
+                                 static_cast<float*>(c_values), *static_cast<const float*>(alpha),
+                                 static_cast<const float*>(d_values), beta ? *static_cast<const float*>(beta) : 0.f);
   return run_bins<double, true>(handle, st, static_cast<const double*>(a_values),
                                 static_cast<const double*>(b_values), st->rowptr, c_colind,
-                                static_cast<double*>(c_values), *static_cast<const double*>(alpha));
+                                static_cast<double*>(c_values), *static_cast<const double*>(alpha),
+                                static_cast<const double*>(d_values), beta ? *static_cast<const double*>(beta) : 0.0);
+}
+
+int spblas_gfx950_spgemm_numeric(spblas_gfx950_handle_t handle, spblas_gfx950_spgemm_t st, const void* alpha,
+                                 const int32_t* a_rowptr, const int32_t* a_colind, const void* a_values,
+                                 const int32_t* b_rowptr, const int32_t* b_colind, const void* b_values,
+                                 int32_t* c_rowptr, int32_t* c_colind, void* c_values, int64_t c_capacity,
+                                 int value_type) {
+  return spgemm_numeric_impl(handle, st, alpha, a_rowptr, a_colind, a_values, b_rowptr, b_colind, b_values, nullptr,
+                             nullptr, nullptr, nullptr, c_rowptr, c_colind, c_values, c_capacity, value_type);
+}
+
+int spblas_gfx950_spgemm_numeric_addend(spblas_gfx950_handle_t handle, spblas_gfx950_spgemm_t st, const void* alpha,
+                                        const int32_t* a_rowptr, const int32_t* a_colind, const void* a_values,
+                                        const int32_t* b_rowptr, const int32_t* b_colind, const void* b_values,
+                                        const void* beta, const int32_t* d_rowptr, const int32_t* d_colind,
+                                        const void* d_values, int32_t* c_rowptr, int32_t* c_colind, void* c_values,
+                                        int64_t c_capacity, int value_type) {
+  if (!d_rowptr)
+    return SPBLAS_GFX950_STATUS_INVALID_POINTER;
+  return spgemm_numeric_impl(handle, st, alpha, a_rowptr, a_colind, a_values, b_rowptr, b_colind, b_values, beta,
+                             d_rowptr, d_colind, d_values, c_rowptr, c_colind, c_values, c_capacity, value_type);
+}
+
+/* ---- add: C = alpha*A + beta*B through the same accumulators (B := identity, D := B) ---- */
+int spblas_gfx950_csr_add_symbolic(spblas_gfx950_handle_t handle, spblas_gfx950_spgemm_t st, int64_t m, int64_t n,
+                                   int64_t a_nnz, const int32_t* a_rowptr, const int32_t* a_colind, int64_t b_nnz,
+                                   const int32_t* b_rowptr, const int32_t* b_colind, int32_t* c_rowptr,
+                                   int64_t* c_nnz) {
+  if (!handle)
+    return SPBLAS_GFX950_STATUS_INVALID_HANDLE;
+  if (!st || !b_rowptr)
+    return SPBLAS_GFX950_STATUS_INVALID_POINTER;
+  int rc = spblas_gfx950_spgemm_set_addend(handle, st, b_nnz, b_rowptr, b_colind);
+  if (rc)
+    return rc;
+  return spgemm_symbolic_impl(handle, st, m, n, n, a_nnz, a_rowptr, a_colind, 0, nullptr, nullptr, c_rowptr, c_nnz,
+                              true);
+}
+
+int spblas_gfx950_csr_add_numeric(spblas_gfx950_handle_t handle, spblas_gfx950_spgemm_t st, const void* alpha,
+                                  const int32_t* a_rowptr, const int32_t* a_colind, const void* a_values,
+                                  const void* beta, const int32_t* b_rowptr, const int32_t* b_colind,
+                                  const void* b_values, int32_t* c_rowptr, int32_t* c_colind, void* c_values,
+                                  int64_t c_capacity, int value_type) {
+  if (!b_rowptr)
+    return SPBLAS_GFX950_STATUS_INVALID_POINTER;
+  return spgemm_numeric_impl(handle, st, alpha, a_rowptr, a_colind, a_values, nullptr, nullptr, nullptr, beta,
+                             b_rowptr, b_colind, b_values, c_rowptr, c_colind, c_values, c_capacity, value_type);
 }
 
 } // extern "C"

@@ -317,6 +317,109 @@ static void test_spgemm() {
   CHECK(threw);
 }
 
+// test/gtest/device/rocsparse/spgemm_4args_test.cpp:11-110 (+ _AScaled/_BScaled/_DScaled): C = alpha*A*B + beta*D
+static void test_spgemm_4args() {
+  for (auto&& [m, k, nnz] : dims) {
+    for (int n : {m, k}) {
+      for (int variant = 0; variant < 4; ++variant) {  // 0 plain, 1 A scaled, 2 B scaled, 3 D scaled
+        auto ha = generate_csr(m, k, nnz), hb = generate_csr(k, n, nnz, 1), hd = generate_csr(m, n, nnz, 2);
+        device_csr a(ha), b(hb), d(hd);
+        dvec<offset_t> d_c_rowptr(m + 1);
+        spblas::csr_view<value_t, index_t, offset_t> d_c(nullptr, d_c_rowptr.p, nullptr, {m, n}, 0);
+        const value_t sa = variant == 1 ? 2.0f : 1.0f, sb = variant == 2 ? 2.0f : 1.0f, sd = variant == 3 ? 2.0f : 1.0f;
+        auto A = spblas::scaled(sa, a.view);
+        auto B = spblas::scaled(sb, b.view);
+        auto D = spblas::scaled(sd, d.view);
+        spblas::spgemm_state_t state;
+        spblas::multiply_compute(state, A, B, d_c, D);  // :55
+        const auto cn = state.result_nnz();
+        dvec<value_t> d_c_values(cn);
+        dvec<index_t> d_c_colind(cn);
+        d_c.update(std::span<value_t>(d_c_values.p, cn), std::span<offset_t>(d_c_rowptr.p, m + 1),
+                   std::span<index_t>(d_c_colind.p, cn), {m, n}, (offset_t) cn);
+        spblas::multiply_fill(state, A, B, d_c, D);  // :65
+        auto cv = d_c_values.download();
+        auto cr = d_c_rowptr.download();
+        auto cc = d_c_colind.download();
+        for (int i = 0; i < m; i++) {  // :78-108
+          std::map<index_t, value_t> ref, acc;
+          for (auto p = ha.rowptr[i]; p < ha.rowptr[i + 1]; p++)
+            for (auto q = hb.rowptr[ha.colind[p]]; q < hb.rowptr[ha.colind[p] + 1]; q++)
+              ref[hb.colind[q]] += sa * sb * ha.values[p] * hb.values[q];
+          for (auto p = hd.rowptr[i]; p < hd.rowptr[i + 1]; p++)
+            ref[hd.colind[p]] += sd * hd.values[p];
+          for (auto p = cr[i]; p < cr[i + 1]; p++)
+            acc[cc[p]] += cv[p];
+          bool ok = ref.size() == acc.size() && (std::int64_t) acc.size() == cr[i + 1] - cr[i];
+          for (auto& [j, v] : acc)
+            ok &= ref.count(j) && near_ref(ref[j], v);
+          CHECK(ok);
+        }
+        CHECK(cr[m] == cn);
+      }
+    }
+  }
+}
+
+// test/gtest/add_test.cpp:9-60: add_inspect -> allocate -> update -> add_compute
+static void test_add() {
+  for (auto&& [m, n, nnz] : dims) {
+    for (int variant = 0; variant < 2; ++variant) {  // 0 plain, 1 scaled(2, a) + scaled(-0.5, b)
+      auto ha = generate_csr(m, n, nnz), hb = generate_csr(m, n, nnz, 1);
+      device_csr a(ha), b(hb);
+      dvec<offset_t> d_c_rowptr(m + 1);
+      spblas::csr_view<value_t, index_t, offset_t> d_c(nullptr, d_c_rowptr.p, nullptr, {m, n}, 0);
+      const value_t sa = variant ? 2.0f : 1.0f, sb = variant ? -0.5f : 1.0f;
+      auto A = spblas::scaled(sa, a.view);
+      auto B = spblas::scaled(sb, b.view);
+      auto info = spblas::add_inspect(A, B, d_c);  // :28
+      const auto cn = info.result_nnz();
+      dvec<value_t> d_c_values(cn);
+      dvec<index_t> d_c_colind(cn);
+      d_c.update(std::span<value_t>(d_c_values.p, cn), std::span<offset_t>(d_c_rowptr.p, m + 1),
+                 std::span<index_t>(d_c_colind.p, cn), {m, n}, (offset_t) cn);
+      spblas::add_compute(info, A, B, d_c);  // :35
+      auto cv = d_c_values.download();
+      auto cr = d_c_rowptr.download();
+      auto cc = d_c_colind.download();
+      for (int i = 0; i < m; i++) {  // :40-57
+        std::map<index_t, value_t> ref;
+        for (auto p = ha.rowptr[i]; p < ha.rowptr[i + 1]; p++)
+          ref[ha.colind[p]] += sa * ha.values[p];
+        for (auto p = hb.rowptr[i]; p < hb.rowptr[i + 1]; p++)
+          ref[hb.colind[p]] += sb * hb.values[p];
+        bool ok = (std::int64_t) ref.size() == cr[i + 1] - cr[i];
+        auto it = ref.begin();
+        for (auto p = cr[i]; ok && p < cr[i + 1]; p++, ++it)
+          ok &= it->first == cc[p] && near_ref(it->second, cv[p]);  // ascending columns, SPA values
+        CHECK(ok);
+      }
+    }
+  }
+  // shape mismatch (add_impl.hpp:44-47) and too little room (:67-72)
+  auto ha = generate_csr(40, 30, 100), hb = generate_csr(40, 31, 100, 1), hc = generate_csr(40, 30, 100, 2);
+  device_csr a(ha), b(hb), c2(hc);
+  dvec<offset_t> rp(41);
+  spblas::csr_view<value_t, index_t, offset_t> d_c(nullptr, rp.p, nullptr, {40, 30}, 0);
+  bool threw = false;
+  try {
+    spblas::add_inspect(a.view, b.view, d_c);
+  } catch (const std::invalid_argument&) {
+    threw = true;
+  }
+  CHECK(threw);
+  dvec<value_t> v(3);
+  dvec<index_t> ci(3);
+  spblas::csr_view<value_t, index_t, offset_t> small(v.p, rp.p, ci.p, {40, 30}, 3);
+  threw = false;
+  try {
+    spblas::add(a.view, c2.view, small);
+  } catch (const std::runtime_error&) {
+    threw = true;
+  }
+  CHECK(threw);
+}
+
 // test/gtest/transpose_test.cpp:9-71: B = A^T, then (row, col, value) triples must agree
 static void test_transpose() {
   for (auto&& [m, k, nnz] : dims) {
@@ -360,6 +463,8 @@ int main() {
   test_spmv();
   test_spmm();
   test_spgemm();
+  test_spgemm_4args();
+  test_add();
   test_transpose();
   std::printf("%s: %d checks, %d failures\n", g_fail ? "FAILED" : "PASSED", g_checks, g_fail);
   return g_fail ? 1 : 0;

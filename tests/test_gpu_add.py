@@ -1,0 +1,232 @@
+"""-m gpu parity tests for the SURVEY 8f rows built on the SpGEMM accumulators:
+  * add(a, b, c) / add_inspect / add_compute            (algorithms/add_impl.hpp:40-115;
+    cases mirror /root/reference/test/gtest/add_test.cpp:9-60: inspect -> allocate -> update -> compute)
+  * four-argument SpGEMM  C = alpha*A*B + beta*D         (vendor/rocsparse/multiply_spgemm.hpp:118-214;
+    cases mirror test/gtest/device/rocsparse/spgemm_4args_test.cpp: plain, A/B/D scaled, reuse)
+Indices (rowptr, sorted colind, result_nnz) are compared EXACTLY with the CPU oracle, values within
+the parity bound."""
+import numpy as np
+import pytest
+import torch
+
+import gpu_util as G
+import spblas_reference_amd as sp
+import util
+from oracle import oracle
+from spblas_reference_amd import generate
+
+pytestmark = pytest.mark.gpu
+
+
+def _csr(m, n, nnz, seed, dtype):
+    return generate.generate_csr(m, n, nnz, seed=seed, dtype=dtype)[:4]
+
+
+def device_add(a_h, b_h, scale_a=None, scale_b=None, one_shot=False):
+    (av, ar, ac, ash), (bv, br, bc, bsh) = a_h, b_h
+    m, n = ash
+    d_a = G.csr_on_device(av, ar, ac, ash, len(av))
+    d_b = G.csr_on_device(bv, br, bc, bsh, len(bv))
+    A = sp.scaled(scale_a, d_a) if scale_a is not None else d_a
+    B = sp.scaled(scale_b, d_b) if scale_b is not None else d_b
+    d_rowptr = torch.full((m + 1,), -1, dtype=torch.int32, device="cuda")
+    if one_shot:  # add(a, b, c) with a pre-sized output (csr_builder semantics)
+        cap = len(av) + len(bv)
+        d_vals = torch.full((cap,), float("nan"), dtype=G.dev(av).dtype, device="cuda")
+        d_cols = torch.full((cap,), -1, dtype=torch.int32, device="cuda")
+        d_c = sp.csr_view(d_vals, d_rowptr, d_cols, (m, n), 0)
+        sp.add(A, B, d_c)
+        nnz = d_c.size()
+        return nnz, G.host(d_rowptr), G.host(d_cols)[:nnz], G.host(d_vals)[:nnz]
+    d_c = sp.csr_view(None, d_rowptr, None, (m, n), 0)           # add_test.cpp:24-26
+    info = sp.add_inspect(A, B, d_c)                              # :28
+    nnz = info.result_nnz()
+    assert info.result_shape() == (m, n)
+    d_vals = torch.full((nnz,), float("nan"), dtype=G.dev(av).dtype, device="cuda")
+    d_cols = torch.full((nnz,), -1, dtype=torch.int32, device="cuda")
+    d_c.update(d_vals, d_rowptr, d_cols)                          # :33
+    sp.add_compute(info, A, B, d_c)                               # :35
+    assert d_c.size() == nnz
+    return nnz, G.host(d_rowptr), G.host(d_cols), G.host(d_vals)
+
+
+def check_add(a_h, b_h, got, dtype, scale_a=None, scale_b=None):
+    (av, ar, ac, ash), (bv, br, bc, bsh) = a_h, b_h
+    nnz, c_rowptr, c_colind, c_values = got
+    ref_nnz, ref_rowptr = oracle.add(ash, ar, ac, av, bsh, br, bc, bv, symbolic=True)
+    assert nnz == ref_nnz
+    cr, cc, cv = oracle.add(ash, ar, ac, av, bsh, br, bc, bv, scale_a=scale_a, scale_b=scale_b)
+    assert np.array_equal(c_rowptr, cr) and np.array_equal(ref_rowptr, cr)
+    assert np.array_equal(c_colind, cc)
+    _, _, absv = oracle.add(ash, ar, ac, np.abs(av) * abs(scale_a or 1), bsh, br, bc, np.abs(bv) * abs(scale_b or 1))
+    util.assert_parity(c_values, cv, absv.astype(np.float64), dtype, what="add values")
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("dim", util.dims)
+def test_add_reference_test(gpu, dim, dtype):
+    m, n, nnz = dim
+    a_h, b_h = _csr(m, n, nnz, 0, dtype), _csr(m, n, nnz, 1, dtype)
+    check_add(a_h, b_h, device_add(a_h, b_h), dtype)
+    check_add(a_h, b_h, device_add(a_h, b_h, one_shot=True), dtype)
+
+
+@pytest.mark.parametrize("scales", [(2.0, None), (None, -0.5), (3.0, 0.25)])
+def test_add_scaled_views(gpu, scales):
+    sa, sb = scales
+    a_h, b_h = _csr(300, 200, 5000, 2, np.float32), _csr(300, 200, 3000, 3, np.float32)
+    check_add(a_h, b_h, device_add(a_h, b_h, sa, sb), np.float32, sa, sb)
+
+
+def test_add_is_bit_exact_for_unique_columns(gpu):
+    """With at most one entry per (row, column) in each operand every output value is a + b (or a
+    copy): no reassociation, so the device result must equal the oracle bit for bit."""
+    rng = np.random.default_rng(5)
+    import scipy.sparse as sps
+    A = sps.random(2000, 3000, density=0.004, format="csr", random_state=rng, dtype=np.float32)
+    B = sps.random(2000, 3000, density=0.006, format="csr", random_state=rng, dtype=np.float32)
+    a_h = (A.data, A.indptr.astype(np.int32), A.indices.astype(np.int32), A.shape)
+    b_h = (B.data, B.indptr.astype(np.int32), B.indices.astype(np.int32), B.shape)
+    nnz, cr, cc, cv = device_add(a_h, b_h)
+    rr, rc, rv = oracle.add(A.shape, a_h[1], a_h[2], a_h[0], B.shape, b_h[1], b_h[2], b_h[0])
+    assert np.array_equal(cr, rr) and np.array_equal(cc, rc)
+    assert np.array_equal(cv.view(np.uint32), rv.view(np.uint32))
+
+
+def test_add_empty_and_disjoint_and_long_rows(gpu):
+    # empty operands, empty rows, one very long row (dense accumulator bin), identical patterns
+    m, n = 64, 20000
+    rng = np.random.default_rng(7)
+    a_rp = np.zeros(m + 1, np.int32)
+    a_rp[1:] = 0
+    a_h = (np.zeros(0, np.float32), a_rp, np.zeros(0, np.int32), (m, n))
+    long_cols = rng.permutation(n)[:9000].astype(np.int32)
+    b_len = np.zeros(m, np.int64)
+    b_len[3] = 9000
+    b_len[10] = 17
+    b_rp = np.zeros(m + 1, np.int32)
+    b_rp[1:] = np.cumsum(b_len)
+    b_ci = np.concatenate([long_cols, rng.permutation(n)[:17].astype(np.int32)])
+    b_h = (rng.random(len(b_ci), dtype=np.float32), b_rp, b_ci, (m, n))
+    check_add(a_h, b_h, device_add(a_h, b_h), np.float32)
+    check_add(b_h, a_h, device_add(b_h, a_h), np.float32)
+    check_add(b_h, b_h, device_add(b_h, b_h), np.float32)
+    check_add(a_h, a_h, device_add(a_h, a_h), np.float32)
+
+
+def test_add_errors(gpu):
+    a_h, b_h = _csr(50, 40, 100, 0, np.float32), _csr(50, 41, 100, 1, np.float32)
+    d_a = G.csr_on_device(*a_h, len(a_h[0]))
+    d_b = G.csr_on_device(*b_h, len(b_h[0]))
+    rp = torch.zeros(51, dtype=torch.int32, device="cuda")
+    with pytest.raises(ValueError):                              # add_impl.hpp:44-47
+        sp.add_inspect(d_a, d_b, sp.csr_view(None, rp, None, (50, 40), 0))
+    b2 = _csr(50, 40, 100, 1, np.float32)
+    d_b2 = G.csr_on_device(*b2, len(b2[0]))
+    small = sp.csr_view(torch.zeros(3, device="cuda"), rp, torch.zeros(3, dtype=torch.int32, device="cuda"), (50, 40), 0)
+    with pytest.raises(RuntimeError):                            # add_impl.hpp:67-72
+        sp.add(d_a, d_b2, small)
+
+
+# ------------------------------------------------------------------ C = alpha*A*B + beta*D
+def device_spgemm4(a_h, b_h, d_h, sa=None, sb=None, sd=None, reuse_values=None):
+    (av, ar, ac, ash), (bv, br, bc, bsh), (dv, dr, dc, dsh) = a_h, b_h, d_h
+    m, n = ash[0], bsh[1]
+    d_a, d_b, d_d = (G.csr_on_device(v, r, c, s, len(v)) for v, r, c, s in (a_h, b_h, d_h))
+    A = sp.scaled(sa, d_a) if sa is not None else d_a
+    B = sp.scaled(sb, d_b) if sb is not None else d_b
+    D = sp.scaled(sd, d_d) if sd is not None else d_d
+    d_rowptr = torch.full((m + 1,), -1, dtype=torch.int32, device="cuda")
+    d_c = sp.csr_view(None, d_rowptr, None, (m, n), 0)            # spgemm_4args_test.cpp:49-52
+    state = sp.spgemm_state_t()
+    sp.multiply_compute(state, A, B, d_c, D)                       # :55
+    nnz = state.result_nnz()
+    d_vals = torch.full((nnz,), float("nan"), dtype=G.dev(av).dtype, device="cuda")
+    d_cols = torch.full((nnz,), -1, dtype=torch.int32, device="cuda")
+    d_c.update(d_vals, d_rowptr, d_cols, (m, n), nnz)              # :62-63
+    sp.multiply_fill(state, A, B, d_c, D)                          # :65
+    out = [(nnz, G.host(d_rowptr), G.host(d_cols), G.host(d_vals))]
+    if reuse_values is not None:                                   # numeric again with new values, same pattern
+        av2, bv2, dv2 = reuse_values
+        d_a.values().copy_(G.dev(av2))
+        d_b.values().copy_(G.dev(bv2))
+        d_d.values().copy_(G.dev(dv2))
+        d_vals.fill_(float("nan"))
+        sp.multiply_numeric(state, A, B, d_c, D)
+        out.append((nnz, G.host(d_rowptr), G.host(d_cols), G.host(d_vals)))
+    return out
+
+
+def check_spgemm4(a_h, b_h, d_h, got, dtype, alpha=1.0, beta=1.0):
+    (av, ar, ac, ash), (bv, br, bc, bsh), (dv, dr, dc, dsh) = a_h, b_h, d_h
+    nnz, c_rowptr, c_colind, c_values = got
+    ref_nnz, _ = oracle.spgemm_symbolic_d(ash, ar, ac, bsh, br, bc, dsh, dr, dc)
+    assert nnz == ref_nnz
+    cr, cc, cv = oracle.spgemm_numeric_d(ash, ar, ac, av, bsh, br, bc, bv, dsh, dr, dc, dv, ref_nnz, alpha, beta)
+    assert np.array_equal(c_rowptr, cr) and np.array_equal(c_colind, cc)
+    _, _, ab = oracle.spgemm_numeric_d(ash, ar, ac, np.abs(av), bsh, br, bc, np.abs(bv), dsh, dr, dc, np.abs(dv),
+                                       ref_nnz, abs(alpha), abs(beta))
+    util.assert_parity(c_values, cv, ab.astype(np.float64), dtype, row_len=np.full(len(cv), 64),
+                       what="spgemm4 values")
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("dim", util.dims)
+def test_spgemm_4args_reference_test(gpu, dim, dtype):
+    m, k, nnz = dim
+    for n in (m, k):
+        a_h, b_h, d_h = _csr(m, k, nnz, 0, dtype), _csr(k, n, nnz, 1, dtype), _csr(m, n, nnz, 2, dtype)
+        check_spgemm4(a_h, b_h, d_h, device_spgemm4(a_h, b_h, d_h)[0], dtype)
+
+
+@pytest.mark.parametrize("scales", [(2.0, None, None), (None, 2.0, None), (None, None, 2.0), (2.0, 3.0, -0.5)])
+def test_spgemm_4args_scaled(gpu, scales):
+    sa, sb, sd = scales                                            # _AScaled / _BScaled / _DScaled variants
+    a_h, b_h, d_h = _csr(100, 1000, 10000, 0, np.float32), _csr(1000, 100, 10000, 1, np.float32), \
+        _csr(100, 100, 3000, 2, np.float32)
+    alpha = (sa or 1.0) * (sb or 1.0)
+    check_spgemm4(a_h, b_h, d_h, device_spgemm4(a_h, b_h, d_h, sa, sb, sd)[0], np.float32, alpha, sd or 1.0)
+
+
+def test_spgemm_4args_numeric_reuse_and_mismatch(gpu):
+    rng = np.random.default_rng(3)
+    a_h, b_h, d_h = _csr(400, 300, 4000, 0, np.float32), _csr(300, 500, 6000, 1, np.float32), \
+        _csr(400, 500, 5000, 2, np.float32)
+    new = tuple(rng.random(len(x[0]), dtype=np.float32) for x in (a_h, b_h, d_h))
+    first, second = device_spgemm4(a_h, b_h, d_h, reuse_values=new)
+    check_spgemm4(a_h, b_h, d_h, first, np.float32)
+    a2, b2, d2 = ((new[i],) + t[1:] for i, t in enumerate((a_h, b_h, d_h)))
+    check_spgemm4(a2, b2, d2, second, np.float32)
+    # the addend must be given to both phases
+    d_a, d_b, d_d = (G.csr_on_device(v, r, c, s, len(v)) for v, r, c, s in (a_h, b_h, d_h))
+    rp = torch.zeros(401, dtype=torch.int32, device="cuda")
+    d_c = sp.csr_view(None, rp, None, (400, 500), 0)
+    state = sp.spgemm_state_t()
+    sp.multiply_compute(state, d_a, d_b, d_c, d_d)
+    nnz = state.result_nnz()
+    d_c.update(torch.zeros(nnz, device="cuda"), rp, torch.zeros(nnz, dtype=torch.int32, device="cuda"), (400, 500), nnz)
+    with pytest.raises(RuntimeError):
+        sp.multiply_fill(state, d_a, d_b, d_c)
+    with pytest.raises(ValueError):                                # D must have C's shape
+        sp.multiply_compute(state, d_a, d_b, d_c, d_a)
+
+
+def test_spgemm_4args_all_bins(gpu):
+    """Rows of every accumulator size (empty, 128/512/2048/8192-slot hash, dense bitmap) with an addend
+    that alone decides the bin for some rows."""
+    rng = np.random.default_rng(11)
+    m, k, n = 40, 3000, 30000
+    a_len = rng.integers(0, 3, m)
+    a_len[5], a_len[6], a_len[7] = 40, 200, 1500
+    a_rp = np.zeros(m + 1, np.int32)
+    a_rp[1:] = np.cumsum(a_len)
+    a_ci = np.concatenate([rng.permutation(k)[:l] for l in a_len]).astype(np.int32)
+    a_h = (rng.random(len(a_ci), dtype=np.float32), a_rp, a_ci, (m, k))
+    b_h = _csr(k, n, 12000, 1, np.float32)
+    d_len = rng.integers(0, 4, m)
+    d_len[0], d_len[1], d_len[2], d_len[3] = 100, 600, 3000, 9000     # rows whose products are few
+    d_rp = np.zeros(m + 1, np.int32)
+    d_rp[1:] = np.cumsum(d_len)
+    d_ci = np.concatenate([rng.permutation(n)[:l] for l in d_len]).astype(np.int32)
+    d_h = (rng.random(len(d_ci), dtype=np.float32), d_rp, d_ci, (m, n))
+    check_spgemm4(a_h, b_h, d_h, device_spgemm4(a_h, b_h, d_h, sd=0.5)[0], np.float32, 1.0, 0.5)

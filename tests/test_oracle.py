@@ -200,3 +200,64 @@ def test_transpose_matches_reference_test(dim):
         oracle.transpose(shape, rowptr, colind, values, b_shape=(k + 1, m))
     with pytest.raises(RuntimeError):
         oracle.transpose(shape, rowptr, colind, values, capacity=nnz - 1)
+
+
+# ---- add / four-argument SpGEMM ------------------------------------
+@pytest.mark.parametrize("dim", util.dims)
+def test_add_matches_reference_test_loop(dim):
+    """test/gtest/add_test.cpp:37-58: per row, SPA over row i of A then of B; every stored output
+    entry must equal the SPA value; add_inspect's nnz is the structural union."""
+    m, n, nnz = dim
+    av, ar, ac, ash, _ = generate.generate_csr(m, n, nnz, seed=0)
+    bv, br, bc, bsh, _ = generate.generate_csr(m, n, nnz, seed=1)
+    cnt, rp0 = oracle.add(ash, ar, ac, av, bsh, br, bc, bv, symbolic=True)
+    rp, ci, cv = oracle.add(ash, ar, ac, av, bsh, br, bc, bv, capacity=cnt)
+    assert np.array_equal(rp, rp0) and len(ci) == cnt == rp[-1]
+    for i in range(m):
+        spa = {}
+        for p in range(ar[i], ar[i + 1]):
+            spa[ac[p]] = np.float32(spa.get(ac[p], np.float32(0)) + av[p])
+        for p in range(br[i], br[i + 1]):
+            spa[bc[p]] = np.float32(spa.get(bc[p], np.float32(0)) + bv[p])
+        cols = ci[rp[i]:rp[i + 1]]
+        assert list(cols) == sorted(spa)                       # ascending, structural union
+        for j, v in zip(cols, cv[rp[i]:rp[i + 1]]):
+            assert v == spa[j]                                 # same order of additions: exact
+
+
+def test_add_scaled_shape_and_capacity():
+    A = sps.random(60, 50, density=0.1, format="csr", random_state=1, dtype=np.float64)
+    B = sps.random(60, 50, density=0.2, format="csr", random_state=2, dtype=np.float64)
+    rp, ci, cv = oracle.add(A.shape, A.indptr, A.indices, A.data, B.shape, B.indptr, B.indices, B.data,
+                            scale_a=2.0, scale_b=-0.5)
+    R = (2.0 * A - 0.5 * B).tocsr()
+    assert abs(sps.csr_matrix((cv, ci, rp), shape=A.shape) - R).max() < 1e-15
+    with pytest.raises(ValueError):                             # add_impl.hpp:44-47
+        oracle.add(A.shape, A.indptr, A.indices, A.data, (60, 51), B.indptr, B.indices, B.data)
+    with pytest.raises(RuntimeError):                           # add_impl.hpp:67-72
+        oracle.add(A.shape, A.indptr, A.indices, A.data, B.shape, B.indptr, B.indices, B.data, capacity=3)
+
+
+@pytest.mark.parametrize("dim", util.dims)
+def test_spgemm_4args_matches_reference_test_loop(dim):
+    """test/gtest/device/rocsparse/spgemm_4args_test.cpp:78-108: SPA += a_v*b_v over the products,
+    then += d_v over row i of D; sizes must agree."""
+    m, k, nnz = dim
+    n = k
+    av, ar, ac, ash, _ = generate.generate_csr(m, k, nnz, seed=0)
+    bv, br, bc, bsh, _ = generate.generate_csr(k, n, nnz, seed=1)
+    dv, dr, dc, dsh, _ = generate.generate_csr(m, n, nnz, seed=2)
+    cnt, row_nnz = oracle.spgemm_symbolic_d(ash, ar, ac, bsh, br, bc, dsh, dr, dc)
+    rp, ci, cv = oracle.spgemm_numeric_d(ash, ar, ac, av, bsh, br, bc, bv, dsh, dr, dc, dv, cnt)
+    assert rp[-1] == cnt and np.array_equal(np.diff(rp), row_nnz)
+    A = sps.csr_matrix((av.astype(np.float64), ac, ar), shape=ash)
+    B = sps.csr_matrix((bv.astype(np.float64), bc, br), shape=bsh)
+    D = sps.csr_matrix((dv.astype(np.float64), dc, dr), shape=dsh)
+    R = (A @ B + D).toarray()
+    C = sps.csr_matrix((cv.astype(np.float64), ci, rp), shape=(m, n)).toarray()
+    util.expect_eq_ref(R.astype(np.float32), C.astype(np.float32))      # comparator in T = float
+    for i in range(m):
+        cols = ci[rp[i]:rp[i + 1]]
+        assert np.all(np.diff(cols) > 0)
+    with pytest.raises(ValueError):
+        oracle.spgemm_symbolic_d(ash, ar, ac, bsh, br, bc, (m + 1, n), dr, dc)
