@@ -53,6 +53,7 @@ extern "C" {
 typedef struct spblas_gfx950_handle_s* spblas_gfx950_handle_t;
 typedef struct spblas_gfx950_plan_s* spblas_gfx950_plan_t;
 typedef struct spblas_gfx950_spgemm_s* spblas_gfx950_spgemm_t;
+typedef struct spblas_gfx950_trsv_s* spblas_gfx950_trsv_t;
 
 typedef enum spblas_gfx950_status {
   SPBLAS_GFX950_STATUS_SUCCESS = 0,
@@ -216,6 +217,33 @@ int spblas_gfx950_csr_add_numeric(spblas_gfx950_handle_t handle, spblas_gfx950_s
                                   const void* beta, const int32_t* b_rowptr, const int32_t* b_colind,
                                   const void* b_values, int32_t* c_rowptr, int32_t* c_colind, void* c_values,
                                   int64_t c_capacity, int value_type);
+
+/* ---- sparse triangular solve  x = inv(A) b  (CSR, int32 indices) --------------------------- */
+/* Device counterpart of triangular_solve_inspect / triangular_solve
+ * (algorithms/triangular_solve_impl.hpp:13-107).  As in the reference
+ * loop (:57-93) only the strict triangle named by uplo and the diagonal entries are read, so a
+ * general square matrix may be passed; with DIAG_UNIT stored diagonal entries are ignored.
+ *   sptrsv_create  = triangular_solve_inspect: level sets of the dependency graph, built on the
+ *                    device from rowptr/colind only (values may change between solves).
+ *   sptrsv_solve   = triangular_solve: one launch per wide level, one single-workgroup launch per
+ *                    run of narrow levels.  alpha (HOST pointer) is the scaled_view factor of A
+ *                    (x = inv(alpha*A) b); b and x are device vectors of m entries (b == x is fine).
+ *   sptrsv_info    : info[0] levels, [1] widest level, [2] kernel launches per solve, [3] lanes/row. */
+enum spblas_gfx950_uplo {
+  SPBLAS_GFX950_LOWER = 0, /* lower_triangle_t  (detail/triangular_types.hpp:10-13) */
+  SPBLAS_GFX950_UPPER = 1  /* upper_triangle_t  (detail/triangular_types.hpp:5-8)   */
+};
+enum spblas_gfx950_diag {
+  SPBLAS_GFX950_DIAG_EXPLICIT = 0, /* explicit_diagonal_t       (detail/triangular_types.hpp:20-23) */
+  SPBLAS_GFX950_DIAG_UNIT = 1      /* implicit_unit_diagonal_t  (detail/triangular_types.hpp:15-18) */
+};
+int spblas_gfx950_sptrsv_create(spblas_gfx950_handle_t handle, spblas_gfx950_trsv_t* plan, int64_t m, int64_t nnz,
+                                const int32_t* rowptr, const int32_t* colind, int uplo, int diag);
+int spblas_gfx950_sptrsv_destroy(spblas_gfx950_handle_t handle, spblas_gfx950_trsv_t plan);
+int spblas_gfx950_sptrsv_info(spblas_gfx950_trsv_t plan, int64_t info[4]);
+int spblas_gfx950_sptrsv_solve(spblas_gfx950_handle_t handle, spblas_gfx950_trsv_t plan, int64_t m, int64_t nnz,
+                               const void* alpha, const int32_t* rowptr, const int32_t* colind, const void* values,
+                               const void* b, void* x, int value_type);
 
 /* ---- transpose:  B = A^T  (CSR -> CSR, int32 indices) ------------------------------------ */
 /* Device counterpart of transpose(a, b) (algorithms/transpose_impl.hpp:14-53): stable counting

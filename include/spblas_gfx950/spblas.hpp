@@ -736,4 +736,82 @@ void add(A&& a, B&& b, C&& c) {
   s.add_numeric(a, b, c);
 }
 
+// ---- triangular_solve (algorithms/triangular_solve.hpp:8-19, triangular_solve_impl.hpp:13-107) ---
+struct upper_triangle_t {  // detail/triangular_types.hpp:5-8
+  explicit upper_triangle_t() = default;
+};
+inline constexpr upper_triangle_t upper_triangle{};
+struct lower_triangle_t {  // :10-13
+  explicit lower_triangle_t() = default;
+};
+inline constexpr lower_triangle_t lower_triangle{};
+struct implicit_unit_diagonal_t {  // :15-18
+  explicit implicit_unit_diagonal_t() = default;
+};
+inline constexpr implicit_unit_diagonal_t implicit_unit_diagonal{};
+struct explicit_diagonal_t {  // :20-23
+  explicit explicit_diagonal_t() = default;
+};
+inline constexpr explicit_diagonal_t explicit_diagonal{};
+
+namespace __gfx950 {
+template <typename A, typename Triangle, typename DiagonalStorage, typename B, typename X>
+void trsv_prepare(trsv_state_t& st, A&& a, Triangle, DiagonalStorage, B&& b, X&& x) {
+  static_assert(std::is_same_v<Triangle, upper_triangle_t> || std::is_same_v<Triangle, lower_triangle_t>);
+  static_assert(std::is_same_v<DiagonalStorage, implicit_unit_diagonal_t> ||
+                std::is_same_v<DiagonalStorage, explicit_diagonal_t>);
+  auto ab = __detail::get_ultimate_base(a);
+  reject_conjugated(__detail::is_conjugated(a));
+  // the reference asserts these (triangular_solve_impl.hpp:50-53); a device backend has to refuse
+  if (ab.shape()[0] != ab.shape()[1] || static_cast<std::int64_t>(std::ranges::size(x)) != ab.shape()[1] ||
+      static_cast<std::int64_t>(std::ranges::size(b)) != ab.shape()[0]) {
+    throw std::invalid_argument("triangular_solve: matrix and vector dimensions are incompatible.");
+  }
+  const int uplo = std::is_same_v<Triangle, upper_triangle_t> ? SPBLAS_GFX950_UPPER : SPBLAS_GFX950_LOWER;
+  const int diag =
+      std::is_same_v<DiagonalStorage, implicit_unit_diagonal_t> ? SPBLAS_GFX950_DIAG_UNIT : SPBLAS_GFX950_DIAG_EXPLICIT;
+  if (!st.matches(ab.rowptr().data(), ab.colind().data(), ab.shape()[0], ab.size(), uplo, diag)) {
+    st.inspect(ab.shape()[0], ab.size(), ab.rowptr().data(), ab.colind().data(), uplo, diag);
+  }
+}
+inline trsv_state_t& trsv_state_of(operation_info_t& info) {
+  auto* s = dynamic_cast<trsv_state_t*>(info.state_.get());
+  if (!s) {
+    info.state_ = std::make_unique<trsv_state_t>();
+    s = static_cast<trsv_state_t*>(info.state_.get());
+  }
+  return *s;
+}
+} // namespace __gfx950
+
+template <typename A, typename Triangle, typename DiagonalStorage, typename B, typename X>
+  requires(__detail::has_csr_base<A>)
+void triangular_solve_inspect(operation_info_t& info, A&& a, Triangle t, DiagonalStorage d, B&& b, X&& x) {
+  __gfx950::trsv_prepare(__gfx950::trsv_state_of(info), a, t, d, b, x);
+}
+template <typename A, typename Triangle, typename DiagonalStorage, typename B, typename X>
+  requires(__detail::has_csr_base<A>)
+operation_info_t triangular_solve_inspect(A&& a, Triangle t, DiagonalStorage d, B&& b, X&& x) {
+  operation_info_t info;
+  triangular_solve_inspect(info, a, t, d, b, x);
+  return info;
+}
+template <typename A, typename Triangle, typename DiagonalStorage, typename B, typename X>
+  requires(__detail::has_csr_base<A>)
+void triangular_solve(operation_info_t& info, A&& a, Triangle t, DiagonalStorage d, B&& b, X&& x) {
+  auto& st = __gfx950::trsv_state_of(info);
+  __gfx950::trsv_prepare(st, a, t, d, b, x);  // re-analyses only if the matrix / triangle changed
+  auto ab = __detail::get_ultimate_base(a);
+  using T = typename decltype(ab)::scalar_type;
+  const T alpha = static_cast<T>(__detail::get_scaling_factor(a).value_or(1.0));
+  st.template solve<T>(alpha, ab.rowptr().data(), ab.colind().data(), ab.values().data(), std::ranges::data(b),
+                       std::ranges::data(x));
+}
+template <typename A, typename Triangle, typename DiagonalStorage, typename B, typename X>
+  requires(__detail::has_csr_base<A>)
+void triangular_solve(A&& a, Triangle t, DiagonalStorage d, B&& b, X&& x) {
+  operation_info_t info;
+  triangular_solve(info, a, t, d, b, x);
+}
+
 } // namespace spblas

@@ -278,6 +278,23 @@ def add(shape, a_rowptr, a_colind, a_values, b_shape, b_rowptr, b_colind, b_valu
     return c_rowptr, c_colind[:nnz.value], c_values[:nnz.value]
 
 
+def triangular_solve(shape, rowptr, colind, values, b, upper=False, unit=False, scale_a=None, x_len=None):
+    """Reference triangular_solve(a, uplo, diag, b, x) (algorithms/triangular_solve_impl.hpp:41-94)."""
+    lib = load()
+    rowptr, colind, values = _csr_args(rowptr, colind, values)
+    rowptr = rowptr.astype(np.int32, copy=False)
+    b = np.ascontiguousarray(b, dtype=values.dtype)
+    x = np.zeros(shape[1] if x_len is None else x_len, dtype=values.dtype)
+    T = _ct(values.dtype)
+    fn = getattr(lib, "oracle_trsv_" + _sfx(values.dtype))
+    fn.restype = c_int
+    rc = fn(c_i64(shape[0]), c_i64(shape[1]), c_i64(b.shape[0]), c_i64(x.shape[0]), _p(rowptr), _p(colind),
+            _p(values), c_int(scale_a is not None), T(0 if scale_a is None else scale_a), c_int(bool(upper)),
+            c_int(bool(unit)), _p(b), _p(x))
+    _raise(rc)
+    return x
+
+
 def spmv_absrow(rowptr, colind, values, x):
     """Per-row sum |a_v * x_k| in float64: the scale of the norm-wise tolerance."""
     lib = load()

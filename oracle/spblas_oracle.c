@@ -510,6 +510,44 @@ DEF_SPGEMM_NUMERIC_D(oracle_spgemm_numeric_d_f64, double)
 DEF_ADD(oracle_add_f32, float)
 DEF_ADD(oracle_add_f64, double)
 
+/* ------------------------------------------------------------------------ */
+/* triangular_solve(a, uplo, diag, b, x): x = inv(A) b, CSR                    */
+/* (algorithms/triangular_solve_impl.hpp:41-94).  Rows are walked in reverse    */
+/* for the upper triangle (:57-73) and forward for the lower one (:74-92); per   */
+/* row, dot += a_v * x[k] over the entries on the strict side of the diagonal    */
+/* in storage order, an entry with k == i sets diagonal_value (the last one      */
+/* wins), entries on the other side are ignored; then                            */
+/*   explicit_diagonal:       x[i] = (b[i] - dot) / diagonal_value  (:67-69,86-88)*/
+/*   implicit_unit_diagonal:  x[i] =  b[i] - dot                    (:70-71,89-90)*/
+/* diagonal_value is declared OUTSIDE the row loop (:55) and therefore keeps     */
+/* the value of the previous row when a row stores no diagonal; restated as is.  */
+/* scaled(alpha, a) scales every element read from the row.                      */
+/* ------------------------------------------------------------------------ */
+#define DEF_TRSV(NAME, T)                                                      \
+  int NAME(int64_t m, int64_t n, int64_t b_len, int64_t x_len,                 \
+           const int32_t* rowptr, const int32_t* colind, const T* values,      \
+           int has_sa, T sa, int upper, int unit, const T* b, T* x) {          \
+    if (m != n || x_len != n || b_len != m)                                    \
+      return ORACLE_ERR_SHAPE;                                                 \
+    T diagonal_value = 0;                                                      \
+    for (int64_t t = 0; t < m; t++) {                                          \
+      const int64_t i = upper ? m - 1 - t : t;                                 \
+      T dot = 0;                                                               \
+      for (int32_t p = rowptr[i]; p < rowptr[i + 1]; p++) {                    \
+        const int64_t k = colind[p];                                           \
+        const T a_v = has_sa ? sa * values[p] : values[p];                     \
+        if (upper ? k > i : k < i)                                             \
+          dot += a_v * x[k];                                                   \
+        else if (k == i)                                                       \
+          diagonal_value = a_v;                                                \
+      }                                                                        \
+      x[i] = unit ? b[i] - dot : (b[i] - dot) / diagonal_value;                \
+    }                                                                          \
+    return ORACLE_OK;                                                          \
+  }
+DEF_TRSV(oracle_trsv_f32, float)
+DEF_TRSV(oracle_trsv_f64, double)
+
 /* Per-row sum of |a_v * x_k| -- the norm the parity tolerance is scaled by
  * (SURVEY section 8c "Tolerance note"; reference comparator test/gtest/util.hpp:7-23
  * is likewise norm-wise).  Computed in double. */

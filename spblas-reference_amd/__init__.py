@@ -15,4 +15,6 @@ from .api import (  # noqa: F401
     matrix_opt, multiply, multiply_compute, multiply_fill, multiply_inspect, multiply_numeric,
     multiply_symbolic_compute, multiply_symbolic_fill, operation_info_t, prepared_multiply, scaled, scaled_view,
     spgemm_state_t, transpose, transpose_inspect,
-    transposed)
+    transposed, triangular_solve, triangular_solve_inspect, upper_triangle_t, lower_triangle_t,
+    implicit_unit_diagonal_t, explicit_diagonal_t, upper_triangle, lower_triangle, implicit_unit_diagonal,
+    explicit_diagonal)

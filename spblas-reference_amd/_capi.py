@@ -27,6 +27,8 @@ PLAN_MISMATCH = 9
 F32, F64 = 0, 1
 I32, I64 = 0, 1
 OP_N, OP_T = 0, 1
+LOWER, UPPER = 0, 1
+DIAG_EXPLICIT, DIAG_UNIT = 0, 1
 SPMV_AUTO, SPMV_VECTOR, SPMV_ROWBLOCK, SPMV_SLICED = 0, 1, 2, 3
 OPT_BIN_ROW_ALIGN = 1
 
@@ -69,6 +71,12 @@ PROTOTYPES = [
     ("spblas_gfx950_csr_add_numeric", c_int,
      [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
       c_void_p, c_void_p, c_i64, c_int]),
+    ("spblas_gfx950_sptrsv_create", c_int,
+     [c_void_p, ctypes.POINTER(c_void_p), c_i64, c_i64, c_void_p, c_void_p, c_int, c_int]),
+    ("spblas_gfx950_sptrsv_destroy", c_int, [c_void_p, c_void_p]),
+    ("spblas_gfx950_sptrsv_info", c_int, [c_void_p, ctypes.POINTER(c_i64)]),
+    ("spblas_gfx950_sptrsv_solve", c_int,
+     [c_void_p, c_void_p, c_i64, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int]),
     ("spblas_gfx950_spgemm_set_addend", c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_void_p]),
     ("spblas_gfx950_spgemm_numeric_addend", c_int,
      [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -820,3 +820,128 @@ def add(a, b, c):
     state = spgemm_state_t()
     _add_symbolic(state, a, b, c)
     _add_numeric(state, a, b, c)
+
+
+# --------------------------------------------------------------------------- SpTRSV
+class upper_triangle_t:      # detail/triangular_types.hpp:5-8
+    pass
+
+
+class lower_triangle_t:      # detail/triangular_types.hpp:10-13
+    pass
+
+
+class implicit_unit_diagonal_t:  # detail/triangular_types.hpp:15-18
+    pass
+
+
+class explicit_diagonal_t:       # detail/triangular_types.hpp:20-23
+    pass
+
+
+upper_triangle, lower_triangle = upper_triangle_t(), lower_triangle_t()
+implicit_unit_diagonal, explicit_diagonal = implicit_unit_diagonal_t(), explicit_diagonal_t()
+
+
+class _TrsvPlan:
+    """triangular_solve_inspect state: level sets of the dependency graph (spblas_gfx950_sptrsv_create)."""
+
+    def __init__(self, hd, plan, key):
+        self.hd, self.plan, self.key = hd, plan, key
+
+    def info(self):
+        arr = (ctypes.c_int64 * 4)()
+        check(_capi.lib().spblas_gfx950_sptrsv_info(self.plan, arr), "spblas_gfx950_sptrsv_info")
+        return dict(zip(("levels", "max_level_width", "launches_per_solve", "lanes_per_row"), list(arr)))
+
+    def __del__(self):
+        try:
+            if self.plan:
+                _capi.lib().spblas_gfx950_sptrsv_destroy(self.hd.h, self.plan)
+                self.plan = None
+        except Exception:
+            pass
+
+
+def _trsv_operands(a, uplo, diag, b, x):
+    a_base = get_ultimate_base(a)
+    if not isinstance(a_base, csr_view):
+        raise NotImplementedError("gfx950 triangular_solve supports csr_view operands")
+    _reject_conjugated(a, b, x)
+    _check_csr(a_base, "triangular_solve")
+    if a_base.rowptr().dtype != torch.int32:
+        raise TypeError("triangular_solve: int32 row offsets only")
+    if not isinstance(uplo, (upper_triangle_t, lower_triangle_t)):
+        raise TypeError("triangular_solve: uplo must be upper_triangle_t or lower_triangle_t")  # :48-49 static_assert
+    if not isinstance(diag, (implicit_unit_diagonal_t, explicit_diagonal_t)):
+        raise TypeError("triangular_solve: diag must be implicit_unit_diagonal_t or explicit_diagonal_t")
+    if get_scaling_factor(b) is not None or get_scaling_factor(x) is not None:
+        raise NotImplementedError("gfx950 triangular_solve: scaled b / x views are not supported")
+    m, n = a_base.shape()
+    # the reference asserts squareness and matching vector lengths (triangular_solve_impl.hpp:50-53)
+    if m != n or not _is_tensor(b) or not _is_tensor(x) or b.dim() != 1 or x.dim() != 1 or x.numel() != n or \
+            b.numel() != m:
+        raise ValueError("triangular_solve: matrix and vector dimensions are incompatible.")
+    if b.dtype != a_base.values().dtype or x.dtype != a_base.values().dtype:
+        raise TypeError("triangular_solve: b and x must have A's value type")
+    if not (b.is_contiguous() and x.is_contiguous()):
+        raise ValueError("triangular_solve: vectors must be contiguous")
+    return a_base
+
+
+def _trsv_key(a_base, uplo, diag):
+    return (a_base.rowptr().data_ptr(), a_base.colind().data_ptr(), tuple(a_base.shape()), a_base.size(),
+            type(uplo), type(diag))
+
+
+def _trsv_plan(a_base, uplo, diag):
+    hd = _Handle.current(a_base.rowptr().device)
+    plan = ctypes.c_void_p()
+    check(_capi.lib().spblas_gfx950_sptrsv_create(
+        hd.h, ctypes.byref(plan), a_base.shape()[0], a_base.size(), _ptr(a_base.rowptr()), _ptr(a_base.colind()),
+        _capi.UPPER if isinstance(uplo, upper_triangle_t) else _capi.LOWER,
+        _capi.DIAG_UNIT if isinstance(diag, implicit_unit_diagonal_t) else _capi.DIAG_EXPLICIT),
+        "triangular_solve_inspect")
+    return _TrsvPlan(hd, plan, _trsv_key(a_base, uplo, diag))
+
+
+def triangular_solve_inspect(*args):
+    """triangular_solve_inspect(a, uplo, diag, b, x) -> operation_info_t, or with a leading info
+    (algorithms/triangular_solve.hpp:8-15).  The reference's CPU inspect is empty
+    (triangular_solve_impl.hpp:13-38); here it builds the level sets the device solve needs."""
+    if len(args) == 6:
+        info, a, uplo, diag, b, x = args
+        ret = False
+    elif len(args) == 5:
+        a, uplo, diag, b, x = args
+        info, ret = operation_info_t(), True
+    else:
+        raise TypeError("expected (a, uplo, diag, b, x) or (info, a, uplo, diag, b, x)")
+    a_base = _trsv_operands(a, uplo, diag, b, x)
+    info.state_ = _trsv_plan(a_base, uplo, diag)
+    return info if ret else None
+
+
+def triangular_solve(*args):
+    """triangular_solve(a, uplo, diag, b, x) / triangular_solve(info, a, uplo, diag, b, x):
+    x = inv(A) b using only the named triangle of A (triangular_solve_impl.hpp:41-107)."""
+    if len(args) == 6:
+        info, a, uplo, diag, b, x = args
+    elif len(args) == 5:
+        a, uplo, diag, b, x = args
+        info = None
+    else:
+        raise TypeError("expected (a, uplo, diag, b, x) or (info, a, uplo, diag, b, x)")
+    a_base = _trsv_operands(a, uplo, diag, b, x)
+    plan = info.state_ if info is not None and isinstance(info.state_, _TrsvPlan) else None
+    if plan is None or plan.key != _trsv_key(a_base, uplo, diag):
+        plan = _trsv_plan(a_base, uplo, diag)  # no usable inspect result: analyse now
+        if info is not None:
+            info.state_ = plan
+    hd = _Handle.current(a_base.rowptr().device)
+    vt, ct = _vtype(a_base.values(), "triangular_solve")
+    sa = get_scaling_factor(a)
+    alpha = ct(1 if sa is None else sa)
+    check(_capi.lib().spblas_gfx950_sptrsv_solve(hd.h, plan.plan, a_base.shape()[0], a_base.size(),
+                                                 ctypes.byref(alpha), _ptr(a_base.rowptr()), _ptr(a_base.colind()),
+                                                 _ptr(a_base.values()), _ptr(b), _ptr(x), vt), "triangular_solve")

@@ -420,6 +420,89 @@ static void test_add() {
   CHECK(threw);
 }
 
+// test/gtest/triangular_solve_test.cpp:6-104: device triangular_solve against the test's own
+// reference loop; beyond the reference's b = 0 / unit-diagonal case also explicit diagonals.
+template <typename Triangle, typename Diag>
+static void trsv_case(int n, int nnz, Triangle t, Diag d, bool zero_b) {
+  constexpr bool upper = std::is_same_v<Triangle, spblas::upper_triangle_t>;
+  constexpr bool unit = std::is_same_v<Diag, spblas::implicit_unit_diagonal_t>;
+  auto h = generate_csr(n, n, nnz);
+  for (auto& v : h.values)
+    v *= 1e-3f;  // :72-74
+  if (!unit) {   // make sure every row stores a dominant diagonal
+    host_csr g;
+    g.shape = h.shape;
+    g.rowptr.assign(n + 1, 0);
+    for (int i = 0; i < n; i++) {
+      for (auto p = h.rowptr[i]; p < h.rowptr[i + 1]; p++)
+        if (h.colind[p] != i) {
+          g.colind.push_back(h.colind[p]);
+          g.values.push_back(h.values[p]);
+        }
+      g.colind.push_back(i);
+      g.values.push_back(2.0f + 0.001f * i);
+      g.rowptr[i + 1] = (offset_t) g.colind.size();
+    }
+    g.nnz = (offset_t) g.colind.size();
+    h = g;
+  }
+  device_csr a(h);
+  std::vector<value_t> b(n, 0.0f), x_ref(n, 0.0f);
+  if (!zero_b)
+    for (int i = 0; i < n; i++)
+      b[i] = 1.0f + 0.01f * (i % 17);
+  dvec<value_t> d_b(b), d_x(std::vector<value_t>(n, 1.0f));  // x starts at 1 like :69
+  std::span<value_t> bs(d_b.p, n), xs(d_x.p, n);
+  auto info = spblas::triangular_solve_inspect(a.view, t, d, bs, xs);
+  spblas::triangular_solve(info, a.view, t, d, bs, xs);
+  for (int s = 0; s < n; s++) {  // reference_triangular_solve, :17-58
+    const int row = upper ? n - 1 - s : s;
+    value_t tmp = b[row], diag_val = 0;
+    for (auto j = h.rowptr[row]; j < h.rowptr[row + 1]; j++) {
+      const int col = h.colind[j];
+      if (upper ? col > row : col < row)
+        tmp -= h.values[j] * x_ref[col];
+      else if (col == row)
+        diag_val = h.values[j];
+    }
+    x_ref[row] = unit ? tmp : tmp / diag_val;
+  }
+  auto x = d_x.download();
+  bool ok = true;
+  for (int i = 0; i < n; i++)
+    ok &= near_ref(x_ref[i], x[i]);
+  CHECK(ok);
+  // one-shot form without inspect
+  dvec<value_t> d_x2(std::vector<value_t>(n, 1.0f));
+  std::span<value_t> xs2(d_x2.p, n);
+  spblas::triangular_solve(a.view, t, d, bs, xs2);
+  CHECK(d_x2.download() == x);
+}
+
+static void test_triangular_solve() {
+  const std::vector<std::tuple<int, int, int>> square_dims = {{1000, 1000, 100}, {100, 100, 100}, {40, 40, 1000}};
+  for (auto&& [m, n, nnz] : square_dims) {
+    (void) m;
+    trsv_case(n, nnz, spblas::lower_triangle, spblas::implicit_unit_diagonal, true);   // :88-94
+    trsv_case(n, nnz, spblas::upper_triangle, spblas::implicit_unit_diagonal, true);   // :96-102
+    trsv_case(n, nnz, spblas::lower_triangle, spblas::implicit_unit_diagonal, false);
+    trsv_case(n, nnz, spblas::upper_triangle, spblas::implicit_unit_diagonal, false);
+    trsv_case(n, nnz, spblas::lower_triangle, spblas::explicit_diagonal, false);
+    trsv_case(n, nnz, spblas::upper_triangle, spblas::explicit_diagonal, false);
+  }
+  bool threw = false;
+  try {
+    auto h = generate_csr(30, 20, 50);
+    device_csr a(h);
+    dvec<value_t> b(30), x(20);
+    spblas::triangular_solve(a.view, spblas::lower_triangle, spblas::explicit_diagonal, std::span<value_t>(b.p, 30),
+                             std::span<value_t>(x.p, 20));
+  } catch (const std::invalid_argument&) {
+    threw = true;
+  }
+  CHECK(threw);
+}
+
 // test/gtest/transpose_test.cpp:9-71: B = A^T, then (row, col, value) triples must agree
 static void test_transpose() {
   for (auto&& [m, k, nnz] : dims) {
@@ -465,6 +548,7 @@ int main() {
   test_spgemm();
   test_spgemm_4args();
   test_add();
+  test_triangular_solve();
   test_transpose();
   std::printf("%s: %d checks, %d failures\n", g_fail ? "FAILED" : "PASSED", g_checks, g_fail);
   return g_fail ? 1 : 0;

@@ -261,3 +261,53 @@ def test_spgemm_4args_matches_reference_test_loop(dim):
         assert np.all(np.diff(cols) > 0)
     with pytest.raises(ValueError):
         oracle.spgemm_symbolic_d(ash, ar, ac, bsh, br, bc, (m + 1, n), dr, dc)
+
+
+# ---- triangular_solve ---------------------------------------------------
+def _reference_triangular_solve(rowptr, colind, values, b, upper, unit):
+    """The comparator of the reference test (test/gtest/triangular_solve_test.cpp:6-60): tmp = b[row];
+    tmp -= a*x over the strict side; diag_val reset per row."""
+    T = values.dtype.type
+    m = len(rowptr) - 1
+    x = np.zeros(m, dtype=values.dtype)
+    rows = range(m - 1, -1, -1) if upper else range(m)
+    for row in rows:
+        tmp, diag = T(b[row]), T(0)
+        for j in range(rowptr[row], rowptr[row + 1]):
+            col = colind[j]
+            if (col > row) if upper else (col < row):
+                tmp = T(tmp - T(values[j] * x[col]))
+            elif col == row:
+                diag = values[j]
+        x[row] = tmp if unit else T(tmp / diag)
+    return x
+
+
+@pytest.mark.parametrize("dim", util.square_dims)
+@pytest.mark.parametrize("upper", [False, True])
+def test_triangular_solve_matches_reference_test(dim, upper):
+    """triangular_solve_test.cpp:63-86 (b = 0, values * 1e-3, unit diagonal) plus a non-trivial b."""
+    m, n, nnz = dim
+    v, rp, ci, shape, _ = generate.generate_csr(m, n, nnz)
+    v = (v * np.float32(1e-3)).astype(np.float32)
+    x = oracle.triangular_solve(shape, rp, ci, v, np.zeros(m, np.float32), upper=upper, unit=True)
+    util.expect_eq_ref(_reference_triangular_solve(rp, ci, v, np.zeros(m, np.float32), upper, True), x)
+    b = np.linspace(1, 2, m).astype(np.float32)
+    x = oracle.triangular_solve(shape, rp, ci, v, b, upper=upper, unit=True)
+    util.expect_eq_ref(_reference_triangular_solve(rp, ci, v, b, upper, True), x)
+
+
+def test_triangular_solve_vs_scipy_and_shape_check():
+    import scipy.sparse.linalg as spl
+    rng = np.random.default_rng(0)
+    n = 200
+    A = sps.random(n, n, density=0.05, format="csr", random_state=rng, dtype=np.float64)
+    b = rng.random(n)
+    for upper in (False, True):
+        T = ((sps.triu(A, 1) if upper else sps.tril(A, -1)) + sps.diags(rng.random(n) + 1.0)).tocsr()
+        x = oracle.triangular_solve(T.shape, T.indptr, T.indices, T.data, b, upper=upper)
+        assert np.allclose(x, spl.spsolve_triangular(T, b, lower=not upper), rtol=1e-10, atol=1e-12)
+        x2 = oracle.triangular_solve(T.shape, T.indptr, T.indices, T.data, b, upper=upper, scale_a=2.0)
+        assert np.allclose(2.0 * x2, x, rtol=1e-12)
+    with pytest.raises(ValueError):
+        oracle.triangular_solve((n, n), A.indptr, A.indices, A.data, b[:-1])
