@@ -121,5 +121,107 @@ def main():
          c_values=np.array(c_values, np.float32), c_nnz=np.array(len(c_colind)))
 
 
+def union_rows(m, parts):
+    """parts: list of (rowptr, colind, values, scale).  Exact row-wise sum, columns ascending."""
+    c_rowptr, c_colind, c_values = [0], [], []
+    for i in range(m):
+        acc = {}
+        for rp, ci, v, sc in parts:
+            for p in range(rp[i], rp[i + 1]):
+                acc[ci[p]] = acc.get(ci[p], 0) + sc * v[p]
+        for j in sorted(acc):
+            c_colind.append(j)
+            c_values.append(acc[j])
+        c_rowptr.append(len(c_colind))
+    return c_rowptr, c_colind, c_values
+
+
+def main_8f():
+    """Fixtures for the SURVEY 8f rows: add, four-argument SpGEMM, triangular solve."""
+    from fractions import Fraction
+    i32 = lambda a: np.array(a, np.int32)  # noqa: E731
+    # add: duplicates inside rows, entries that cancel (kept, value 0), empty rows, scaled views
+    r = random.Random(21)
+    m, n = 90, 64
+    ar, ac, av = rand_csr(r, m, n, [r.choice([0, 0, 1, 3, 8, 20]) for _ in range(m)])
+    br, bc, bv = rand_csr(r, m, n, [r.choice([0, 2, 5, 40]) for _ in range(m)])
+    # row 1: B = -A exactly (structural entries with value 0)
+    la, lb = ar[2] - ar[1], br[2] - br[1]
+    cols = ac[ar[1]:ar[2]]
+    bc[br[1]:br[2]] = cols
+    bv[br[1]:br[2]] = [-v for v in av[ar[1]:ar[2]]]
+    br = br[:2] + [p - lb + la for p in br[2:]]
+    for sa, sb, tag in ((1, 1, "plain"), (2, -3, "scaled")):
+        cr, cc, cv = union_rows(m, [(ar, ac, av, sa), (br, bc, bv, sb)])
+        assert max(abs(v) for v in cv + [0]) < 2 ** 24
+        save(f"add_{tag}", kind="add", shape=np.array([m, n]), a_rowptr=i32(ar), a_colind=i32(ac),
+             a_values=np.array(av, np.float32), b_rowptr=i32(br), b_colind=i32(bc), b_values=np.array(bv, np.float32),
+             scale_a=np.array(sa, np.float32), scale_b=np.array(sb, np.float32), c_rowptr=i32(cr), c_colind=i32(cc),
+             c_values=np.array(cv, np.float32), c_nnz=np.array(len(cc)))
+
+    # C = alpha*A*B + beta*D
+    r = random.Random(22)
+    m, k, n = 60, 45, 50
+    ar, ac, av = rand_csr(r, m, k, [r.randrange(0, 7) for _ in range(m)])
+    br, bc, bv = rand_csr(r, k, n, [r.randrange(0, 7) for _ in range(k)], allow_dups=False)
+    dr, dc, dv = rand_csr(r, m, n, [r.choice([0, 1, 4, 30]) for _ in range(m)])
+    alpha, beta = 2, -3
+    c_rowptr, c_colind, c_values = [0], [], []
+    for i in range(m):
+        acc = {}
+        for p in range(ar[i], ar[i + 1]):
+            for q in range(br[ac[p]], br[ac[p] + 1]):
+                acc[bc[q]] = acc.get(bc[q], 0) + alpha * av[p] * bv[q]
+        for p in range(dr[i], dr[i + 1]):
+            acc[dc[p]] = acc.get(dc[p], 0) + beta * dv[p]
+        for j in sorted(acc):
+            c_colind.append(j)
+            c_values.append(acc[j])
+        c_rowptr.append(len(c_colind))
+    assert max(abs(v) for v in c_values) < 2 ** 24
+    save("spgemm4_scaled", kind="spgemm4", a_shape=np.array([m, k]), b_shape=np.array([k, n]),
+         d_shape=np.array([m, n]), a_rowptr=i32(ar), a_colind=i32(ac), a_values=np.array(av, np.float32),
+         b_rowptr=i32(br), b_colind=i32(bc), b_values=np.array(bv, np.float32), d_rowptr=i32(dr), d_colind=i32(dc),
+         d_values=np.array(dv, np.float32), alpha=np.array(alpha, np.float32), beta=np.array(beta, np.float32),
+         c_rowptr=i32(c_rowptr), c_colind=i32(c_colind), c_values=np.array(c_values, np.float32),
+         c_nnz=np.array(len(c_colind)))
+
+    # triangular solves on a GENERAL matrix (both triangles stored, the other one must be ignored),
+    # entries in {-1, 1}, diagonals in {1, -1, 2, -2, 4}: every x_i is a dyadic rational, exact in
+    # float32 for any summation order as long as the partial sums stay below 2**24 ulps
+    r = random.Random(23)
+    n = 120
+    rowptr, colind, values = [0], [], []
+    for i in range(n):
+        cols = sorted(set(r.randrange(n) for _ in range(r.choice([0, 1, 2, 3]))) - {i})
+        ent = [(c, r.choice([-1, 1])) for c in cols] + [(i, r.choice([1, -1, 2, -2, 4]))]
+        r.shuffle(ent)
+        colind += [c for c, _ in ent]
+        values += [v for _, v in ent]
+        rowptr.append(len(colind))
+    b = [r.randrange(-3, 4) for _ in range(n)]
+    out = {}
+    for upper in (False, True):
+        for unit in (False, True):
+            x = [Fraction(0)] * n
+            for t in range(n):
+                i = n - 1 - t if upper else t
+                dot, diag = Fraction(0), None
+                for p in range(rowptr[i], rowptr[i + 1]):
+                    c = colind[p]
+                    if (c > i) if upper else (c < i):
+                        dot += values[p] * x[c]
+                    elif c == i:
+                        diag = values[p]
+                x[i] = (b[i] - dot) if unit else (b[i] - dot) / diag
+            for v in x:  # exactly representable, with head-room for the intermediate sums
+                assert v.denominator & (v.denominator - 1) == 0 and abs(v.numerator) * 64 < 2 ** 24, v
+            out[f"x_{'upper' if upper else 'lower'}_{'unit' if unit else 'explicit'}"] = np.array(
+                [float(v) for v in x], np.float32)
+    save("trsv_general_dyadic", kind="trsv", shape=np.array([n, n]), rowptr=i32(rowptr), colind=i32(colind),
+         values=np.array(values, np.float32), b=np.array(b, np.float32), **out)
+
+
 if __name__ == "__main__":
     main()
+    main_8f()

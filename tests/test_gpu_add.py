@@ -5,6 +5,8 @@
     cases mirror test/gtest/device/rocsparse/spgemm_4args_test.cpp: plain, A/B/D scaled, reuse)
 Indices (rowptr, sorted colind, result_nnz) are compared EXACTLY with the CPU oracle, values within
 the parity bound."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -16,6 +18,7 @@ from oracle import oracle
 from spblas_reference_amd import generate
 
 pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 
 
 def _csr(m, n, nnz, seed, dtype):
@@ -230,3 +233,29 @@ def test_spgemm_4args_all_bins(gpu):
     d_ci = np.concatenate([rng.permutation(n)[:l] for l in d_len]).astype(np.int32)
     d_h = (rng.random(len(d_ci), dtype=np.float32), d_rp, d_ci, (m, n))
     check_spgemm4(a_h, b_h, d_h, device_spgemm4(a_h, b_h, d_h, sd=0.5)[0], np.float32, 1.0, 0.5)
+
+
+# ------------------------------------------------------------------ golden fixtures (integer data: bit exact)
+@pytest.mark.parametrize("name", ["add_plain.npz", "add_scaled.npz"])
+def test_add_golden_bit_exact(gpu, name):
+    g = np.load(os.path.join(GOLDEN, name))
+    shape = tuple(int(v) for v in g["shape"])
+    a_h = (g["a_values"], g["a_rowptr"], g["a_colind"], shape)
+    b_h = (g["b_values"], g["b_rowptr"], g["b_colind"], shape)
+    sa, sb = float(g["scale_a"]), float(g["scale_b"])
+    nnz, cr, cc, cv = device_add(a_h, b_h, None if sa == 1 else sa, None if sb == 1 else sb)
+    assert nnz == int(g["c_nnz"])
+    assert np.array_equal(cr, g["c_rowptr"]) and np.array_equal(cc, g["c_colind"])
+    assert np.array_equal(cv, g["c_values"])                    # includes the row that cancels to stored zeros
+
+
+def test_spgemm_4args_golden_bit_exact(gpu):
+    g = np.load(os.path.join(GOLDEN, "spgemm4_scaled.npz"))
+    sh = [tuple(int(v) for v in g[k]) for k in ("a_shape", "b_shape", "d_shape")]
+    a_h = (g["a_values"], g["a_rowptr"], g["a_colind"], sh[0])
+    b_h = (g["b_values"], g["b_rowptr"], g["b_colind"], sh[1])
+    d_h = (g["d_values"], g["d_rowptr"], g["d_colind"], sh[2])
+    nnz, cr, cc, cv = device_spgemm4(a_h, b_h, d_h, sa=float(g["alpha"]), sd=float(g["beta"]))[0]
+    assert nnz == int(g["c_nnz"])
+    assert np.array_equal(cr, g["c_rowptr"]) and np.array_equal(cc, g["c_colind"])
+    assert np.array_equal(cv, g["c_values"])

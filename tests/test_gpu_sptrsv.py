@@ -6,6 +6,8 @@ explicit / unit diagonals, upper / lower, general matrices whose other triangle 
 scaled(alpha, a), deep chains (one level per row), wide levels, long rows, fp32 / fp64.
 Parity: the device sums a row G lanes wide, the reference sequentially -> norm-wise bound on every
 x_i, propagated through the solve by comparing residuals as well."""
+import os
+
 import numpy as np
 import pytest
 import scipy.sparse as sps
@@ -195,3 +197,21 @@ def test_errors_and_replan(gpu):
     sp.triangular_solve(info, d_u, sp.upper_triangle, sp.explicit_diagonal, bb, x)
     ref = oracle.triangular_solve(U.shape, U.indptr, U.indices, U.data.astype(np.float32), G.host(bb), upper=True)
     assert np.allclose(G.host(x), ref, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("upper", [False, True])
+@pytest.mark.parametrize("unit", [False, True])
+def test_trsv_golden_bit_exact(gpu, upper, unit):
+    """tests/golden/trsv_general_dyadic.npz: general matrix, +-1 entries, power-of-two diagonals -> every
+    x_i is a dyadic rational computed exactly in any summation order; the other triangle is ignored."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "trsv_general_dyadic.npz"))
+    n = int(g["shape"][0])
+    M = sps.csr_matrix((g["values"], g["colind"], g["rowptr"]), shape=(n, n))
+    M.has_canonical_format = True   # keep the stored (shuffled) order and duplicates untouched
+    d_a = G.csr_on_device(g["values"], g["rowptr"], g["colind"], (n, n), len(g["values"]))
+    d_b = G.dev(g["b"])
+    d_x = torch.full((n,), float("nan"), device="cuda")
+    uplo, diag = _tags(upper, unit)
+    sp.triangular_solve(d_a, uplo, diag, d_b, d_x)
+    key = f"x_{'upper' if upper else 'lower'}_{'unit' if unit else 'explicit'}"
+    assert np.array_equal(G.host(d_x), g[key])

@@ -182,6 +182,32 @@ def test_oracle_reproduces_golden_exactly(name):
                                            capacity=nnz)
         assert np.array_equal(cr, g["c_rowptr"]) and np.array_equal(cc, g["c_colind"])
         assert np.array_equal(cv, g["c_values"])
+    elif kind == "add":
+        sa, sb = float(g["scale_a"]), float(g["scale_b"])
+        args = (tuple(g["shape"]), g["a_rowptr"], g["a_colind"], g["a_values"], tuple(g["shape"]), g["b_rowptr"],
+                g["b_colind"], g["b_values"])
+        nnz, rp0 = oracle.add(*args, symbolic=True)
+        assert nnz == int(g["c_nnz"]) and np.array_equal(rp0, g["c_rowptr"])
+        cr, cc, cv = oracle.add(*args, scale_a=None if sa == 1 else sa, scale_b=None if sb == 1 else sb)
+        assert np.array_equal(cr, g["c_rowptr"]) and np.array_equal(cc, g["c_colind"])
+        assert np.array_equal(cv, g["c_values"])
+    elif kind == "spgemm4":
+        sh = [tuple(g[k]) for k in ("a_shape", "b_shape", "d_shape")]
+        nnz, _ = oracle.spgemm_symbolic_d(sh[0], g["a_rowptr"], g["a_colind"], sh[1], g["b_rowptr"], g["b_colind"],
+                                          sh[2], g["d_rowptr"], g["d_colind"])
+        assert nnz == int(g["c_nnz"])
+        cr, cc, cv = oracle.spgemm_numeric_d(sh[0], g["a_rowptr"], g["a_colind"], g["a_values"], sh[1], g["b_rowptr"],
+                                             g["b_colind"], g["b_values"], sh[2], g["d_rowptr"], g["d_colind"],
+                                             g["d_values"], nnz, float(g["alpha"]), float(g["beta"]))
+        assert np.array_equal(cr, g["c_rowptr"]) and np.array_equal(cc, g["c_colind"])
+        assert np.array_equal(cv, g["c_values"])
+    elif kind == "trsv":
+        for upper in (False, True):
+            for unit in (False, True):
+                x = oracle.triangular_solve(tuple(g["shape"]), g["rowptr"], g["colind"], g["values"], g["b"],
+                                            upper=upper, unit=unit)
+                key = f"x_{'upper' if upper else 'lower'}_{'unit' if unit else 'explicit'}"
+                assert np.array_equal(x, g[key]), key
     else:
         raise AssertionError(kind)
 
