@@ -123,6 +123,31 @@ __global__ __launch_bounds__(256) void spg_fill_perm_kernel(int64_t m, const int
   }
 }
 
+// LDS floating-point add through an integer compare-and-swap loop.  The native LDS float atomic
+// (ds_add_f32) retires only 0.33 lanes/clk/CU on this part (tools/ubench/lds_atomic.hip: 12x slower
+// than integer LDS atomics), and a hash slot is rarely contended, so read + cmpswap usually
+// succeeds at the first attempt.
+__device__ __forceinline__ void spg_lds_add(float* addr, float v) {
+  int* ai = reinterpret_cast<int*>(addr);
+  int old = *reinterpret_cast<volatile int*>(ai);
+  while (true) {
+    const int assumed = old;
+    old = atomicCAS(ai, assumed, __float_as_int(__int_as_float(assumed) + v));
+    if (old == assumed)
+      break;
+  }
+}
+__device__ __forceinline__ void spg_lds_add(double* addr, double v) {
+  unsigned long long* ai = reinterpret_cast<unsigned long long*>(addr);
+  unsigned long long old = *reinterpret_cast<volatile unsigned long long*>(ai);
+  while (true) {
+    const unsigned long long assumed = old;
+    old = atomicCAS(ai, assumed, (unsigned long long) __double_as_longlong(__longlong_as_double((long long) assumed) + v));
+    if (old == assumed)
+      break;
+  }
+}
+
 __device__ __forceinline__ unsigned spg_hash(int key, int log2hs) {
   return ((unsigned) key * 0x9E3779B1u) >> (32 - log2hs);
 }
@@ -131,6 +156,21 @@ __device__ __forceinline__ unsigned spg_hash(int key, int log2hs) {
 // handles 256/TPR rows taken from perm[first .. first+count).  SUB lanes walk one
 // B row together.  NUMERIC = false: count distinct columns into row_nnz[row].
 // NUMERIC = true: accumulate, sort, write colind/values at c_rowptr[row].
+// A team of <= 64 lanes lives inside one wavefront and only touches its own LDS region: its phases
+// are ordered by program order plus a wave-level barrier (LDS operations of a wave complete in order),
+// so rows of different length in one workgroup do not wait for each other.  Wider teams need the
+// workgroup barrier.
+template <int TPR>
+__device__ __forceinline__ void spg_team_sync() {
+  if constexpr (TPR <= 64) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  } else {
+    __syncthreads();
+  }
+}
+
 template <typename T, int LOG2HS, int TPR, bool NUMERIC>
 __global__ __launch_bounds__(256) void spg_hash_kernel(
     int64_t count, const int32_t* __restrict__ perm, const int32_t* __restrict__ a_rowptr,
@@ -164,7 +204,7 @@ __global__ __launch_bounds__(256) void spg_hash_kernel(
   }
   if (lt == 0)
     cnt[team] = 0;
-  __syncthreads();
+  spg_team_sync<TPR>();
 
   if (live) {
     const int p0 = a_rowptr[row], p1 = a_rowptr[row + 1];
@@ -178,7 +218,7 @@ __global__ __launch_bounds__(256) void spg_hash_kernel(
         slot = (slot + 1) & (HS - 1);
       }
       if (NUMERIC)
-        unsafeAtomicAdd(&tvals[slot], prod);
+        spg_lds_add(&tvals[slot], prod);
     };
     if constexpr (TPR <= 64) {
       // The team lives in one wavefront: every lane first fetches ONE entry of the A row (column,
@@ -196,16 +236,38 @@ __global__ __launch_bounds__(256) void spg_hash_kernel(
             av = alpha * a_values[pc + lt];
         }
         const int cnt = (p1 - pc) < TPR ? (p1 - pc) : TPR;
-        // team-uniform trip count: a lane that left the loop would read as 0 in the shuffles
-        for (int j0 = 0; j0 < cnt; j0 += nsg) {
-          const int j = j0 + sg;
-          const int src = tbase + (j < cnt ? j : 0);
-          const int q0 = __shfl(qb, src);
-          const int q1s = __shfl(qe, src);  // unconditional: every lane of the team must take part
-          const int q1 = j < cnt ? q1s : q0;
-          const T a = NUMERIC ? __shfl(av, src) : T(0);
-          for (int q = q0 + sl; q < q1; q += sub)
-            insert(b_rowptr ? b_colind[q] : q, NUMERIC ? (b_rowptr ? a * b_values[q] : a) : T(0));
+        // team-uniform trip count: a lane that left the loop would read as 0 in the shuffles.
+        // U rounds are taken together: the first `sub` entries of U * nsg B rows are loaded before
+        // the first insert, so the team waits for one memory round trip per U rounds, not per round
+        // (the kernel is bound by this dependent-load chain, not by bandwidth or LDS).
+        constexpr int U = 4;
+        for (int j0 = 0; j0 < cnt; j0 += U * nsg) {
+          int q0[U], q1[U], col[U];
+          T a[U], bv[U];
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const int j = j0 + u * nsg + sg;
+            const int src = tbase + (j < cnt ? j : 0);
+            q0[u] = __shfl(qb, src);
+            const int q1s = __shfl(qe, src);  // unconditional: every lane of the team must take part
+            q1[u] = j < cnt ? q1s : q0[u];
+            a[u] = NUMERIC ? __shfl(av, src) : T(0);
+            const int q = q0[u] + sl;
+            const bool in = q < q1[u];
+            // clamped, unconditional loads (q0 is always a valid position or 0 .. b_nnz-1 range start)
+            const int qc = in ? q : (q1[u] > q0[u] ? q0[u] : 0);
+            col[u] = b_rowptr ? (b_colind ? b_colind[qc] : 0) : q;
+            bv[u] = (NUMERIC && b_rowptr && b_values) ? b_values[qc] : T(1);
+            if (!in)
+              col[u] = -1;
+          }
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            if (col[u] >= 0)
+              insert(col[u], NUMERIC ? (b_rowptr ? a[u] * bv[u] : a[u]) : T(0));
+            for (int q = q0[u] + sl + sub; q < q1[u]; q += sub)  // B rows longer than `sub`
+              insert(b_rowptr ? b_colind[q] : q, NUMERIC ? (b_rowptr ? a[u] * b_values[q] : a[u]) : T(0));
+          }
         }
       }
     } else {
@@ -223,7 +285,7 @@ __global__ __launch_bounds__(256) void spg_hash_kernel(
         insert(d_colind[q], NUMERIC ? beta * d_values[q] : T(0));
     }
   }
-  __syncthreads();
+  spg_team_sync<TPR>();
 
   // Occupied slots are counted / compacted in lockstep chunks of TPR slots.  A team of <= 64 lanes
   // lives inside one wavefront, so a ballot gives every lane the team's occupancy mask and the
@@ -254,7 +316,7 @@ __global__ __launch_bounds__(256) void spg_hash_kernel(
     running += (int) __popcll(mask);
   }
   if (TPR > 64)
-    __syncthreads();
+    spg_team_sync<TPR>();
   const int d = TPR > 64 ? cnt[team] : running;
   if (!NUMERIC) {
     if (live && lt == 0)
@@ -267,16 +329,16 @@ __global__ __launch_bounds__(256) void spg_hash_kernel(
     constexpr int NBK = TPR < 64 ? TPR : 64;
     int* bcnt = sortws + team * (2 * NBK + 2);  // [NBK+1] counts -> offsets
     int* bfill = bcnt + NBK + 1;                // [NBK] cursors
-    __syncthreads();
+    spg_team_sync<TPR>();
     if (lt <= NBK)
       bcnt[lt] = 0;
     if (lt < NBK)
       bfill[lt] = 0;
-    __syncthreads();
+    spg_team_sync<TPR>();
     if (live)
       for (int e = lt; e < d; e += TPR)
         atomicAdd(&bcnt[(int) (((long long) ckeys[e] * NBK) / ncols)], 1);
-    __syncthreads();
+    spg_team_sync<TPR>();
     if (live && lt < NBK) {  // exclusive scan over the buckets inside the first NBK lanes of the team
       const int c = bcnt[lt];
       int incl = c;
@@ -289,7 +351,7 @@ __global__ __launch_bounds__(256) void spg_hash_kernel(
       if (lt == NBK - 1)
         bcnt[NBK] = incl;
     }
-    __syncthreads();
+    spg_team_sync<TPR>();
     int* skeys = tkeys;  // the hash table is dead after compaction: reuse it for the bucketed copy
     T* svals = tvals;
     if (live)
@@ -300,7 +362,7 @@ __global__ __launch_bounds__(256) void spg_hash_kernel(
         skeys[pos] = key;
         svals[pos] = cvals[e];
       }
-    __syncthreads();
+    spg_team_sync<TPR>();
     if (live) {
       const int out0 = c_rowptr[row];
       for (int e = lt; e < d; e += TPR) {
