@@ -19,7 +19,15 @@ __global__ __launch_bounds__(1024) void lds_atomic_kernel(int iters, int span, f
     int idx;
     if (MODE & 1) idx = (threadIdx.x + it * 1024) % span;      // lane-linear, conflict free
     else idx = (h >> 8) % span;                                 // random
-    if (MODE & 2) atomicAdd(reinterpret_cast<unsigned*>(acc) + idx, 1u);      // ds_add_u32
+    if (MODE & 8) {                                                            // float add as read + cmpswap loop
+      int* ai = reinterpret_cast<int*>(acc) + idx;
+      int old = *reinterpret_cast<volatile int*>(ai);
+      while (true) {
+        const int assumed = old;
+        old = atomicCAS(ai, assumed, __float_as_int(__int_as_float(assumed) + 1.0f));
+        if (old == assumed) break;
+      }
+    } else if (MODE & 2) atomicAdd(reinterpret_cast<unsigned*>(acc) + idx, 1u);      // ds_add_u32
     else if (MODE & 4) acc[idx] += 1.0f;                                      // plain RMW (racy; rate only)
     else unsafeAtomicAdd(acc + idx, 1.0f);                                    // ds_add_f32
   }
@@ -59,21 +67,25 @@ int main() {
   const int span = 19532, iters = 195, blocks = 512;  // = cfg2's reduce: 1e8 updates
   const double total = (double) blocks * 1024 * iters;
   const char* names[] = {"ds_add_f32 random", "ds_add_f32 linear", "ds_add_u32 random", "ds_add_u32 linear",
-                         "plain rmw random", "plain rmw linear"};
+                         "plain rmw random", "plain rmw linear", "cas-loop f32 random", "cas-loop f32 linear"};
   hipFuncSetAttribute((const void*) lds_atomic_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
   hipFuncSetAttribute((const void*) lds_atomic_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
   hipFuncSetAttribute((const void*) lds_atomic_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
   hipFuncSetAttribute((const void*) lds_atomic_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
   hipFuncSetAttribute((const void*) lds_atomic_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
   hipFuncSetAttribute((const void*) lds_atomic_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-  float ms[6];
+  hipFuncSetAttribute((const void*) lds_atomic_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+  hipFuncSetAttribute((const void*) lds_atomic_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+  float ms[8];
   ms[0] = time_ms([&] { hipLaunchKernelGGL(lds_atomic_kernel<0>, dim3(blocks), dim3(1024), span * 4, 0, iters, span, out); });
   ms[1] = time_ms([&] { hipLaunchKernelGGL(lds_atomic_kernel<1>, dim3(blocks), dim3(1024), span * 4, 0, iters, span, out); });
   ms[2] = time_ms([&] { hipLaunchKernelGGL(lds_atomic_kernel<2>, dim3(blocks), dim3(1024), span * 4, 0, iters, span, out); });
   ms[3] = time_ms([&] { hipLaunchKernelGGL(lds_atomic_kernel<3>, dim3(blocks), dim3(1024), span * 4, 0, iters, span, out); });
   ms[4] = time_ms([&] { hipLaunchKernelGGL(lds_atomic_kernel<4>, dim3(blocks), dim3(1024), span * 4, 0, iters, span, out); });
   ms[5] = time_ms([&] { hipLaunchKernelGGL(lds_atomic_kernel<5>, dim3(blocks), dim3(1024), span * 4, 0, iters, span, out); });
-  for (int i = 0; i < 6; ++i)
+  ms[6] = time_ms([&] { hipLaunchKernelGGL(lds_atomic_kernel<8>, dim3(blocks), dim3(1024), span * 4, 0, iters, span, out); });
+  ms[7] = time_ms([&] { hipLaunchKernelGGL(lds_atomic_kernel<9>, dim3(blocks), dim3(1024), span * 4, 0, iters, span, out); });
+  for (int i = 0; i < 8; ++i)
     printf("%-20s %8.1f us  %7.1f Gupdates/s  (%.3f lanes/clk/CU @2.4GHz)\n", names[i], ms[i] * 1e3, total / ms[i] / 1e6,
            total / (ms[i] * 1e-3) / 256 / 2.4e9);
 
