@@ -119,7 +119,9 @@ def run_extra(args, device):
     g = torch.Generator(device=device).manual_seed(5)
     x = torch.rand(m, dtype=torch.float64, device=device, generator=g)
     y = torch.empty(m, dtype=torch.float64, device=device)
-    info = sp.multiply_inspect(a, x, y)
+    algs = {"auto": sp._capi.SPMV_AUTO, "vector": sp._capi.SPMV_VECTOR, "rowblock": sp._capi.SPMV_ROWBLOCK,
+            "sliced": sp._capi.SPMV_SLICED}
+    info = sp.multiply_inspect(a, x, y, alg=algs.get(getattr(args, "alg", "auto"), sp._capi.SPMV_AUTO))
     elapsed, ms = _time_steps(lambda: sp.multiply(info, a, x, y), args.warmup, args.steps)
     alg_bytes = nnz * 12 + (m + 1) * 4 + 2 * m * 8
     cpu = None

@@ -582,11 +582,13 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
     return rc;
   if ((rc = dev_alloc((void**) &pl->s_colind, (size_t) nnz * 2, s)))
     return rc;
-  if ((rc = dev_alloc((void**) &pl->s_lrow, (size_t) nnz * 2, s)))
+  // the reduce kernel's unconditional (clamped) loads touch entry `start` of an EMPTY run, which is
+  // entry nnz for empty runs at the very end: keep one cache line of slack behind both streams
+  if ((rc = dev_alloc((void**) &pl->s_lrow, (size_t) (nnz + 64) * 2, s)))
     return rc;
   if ((rc = dev_alloc((void**) &pl->s_perm, (size_t) nnz * 4, s)))
     return rc;
-  if ((rc = dev_alloc((void**) &pl->s_products, (size_t) nnz * sizeof(T), s)))
+  if ((rc = dev_alloc((void**) &pl->s_products, (size_t) (nnz + 64) * sizeof(T), s)))
     return rc;
   if ((rc = dev_alloc((void**) &pl->s_segT, (size_t) nseg * sizeof(int2), s)))
     return rc;

@@ -147,6 +147,32 @@ def test_spmv_sliced_many_tiles_and_value_update(gpu, dtype, ksplit, monkeypatch
     check(values * dtype(0.5), rowptr, colind, (m, n), x, G.host(y), what="sliced after update_values")
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_spmv_sliced_empty_trailing_runs_on_allocation_boundary(gpu, dtype):
+    """Regression: the reduce kernel's clamped loads touch entry `start` of an EMPTY run; for empty runs
+    at the very end of the re-tiled arrays that is entry nnz.  R-MAT scale 18 (the sparsest rows and
+    columns are the last ones, nnz * 8 B = exactly 32 MiB) faulted there before the streams got their
+    slack.  Here: last rows empty, last columns unused, nnz sized so the arrays end on a 2 MiB boundary."""
+    rng = np.random.default_rng(3)
+    m, n = 40000, 50000
+    nnz = (1 << 21) // np.dtype(dtype).itemsize * 2           # products array = exactly 4 MiB
+    rows = np.sort(rng.integers(0, m - 6000, nnz))            # the last 6000 rows (>= 1 bin) stay empty
+    rowptr = np.zeros(m + 1, np.int32)
+    np.add.at(rowptr, rows + 1, 1)
+    rowptr = np.cumsum(rowptr).astype(np.int32)
+    colind = rng.integers(0, n - 25000, nnz).astype(np.int32)  # the last slice(s) stay empty
+    values = (rng.random(nnz) + 0.5).astype(dtype)
+    x = (rng.random(n) + 0.5).astype(dtype)
+    a = G.csr_on_device(values, rowptr, colind, (m, n), nnz)
+    xd = G.dev(x)
+    y = torch.full((m,), float("nan"), dtype=xd.dtype, device="cuda")
+    info = sp.multiply_inspect(a, xd, y, alg=_capi.SPMV_SLICED)
+    assert info.state_.info()["alg"] == _capi.SPMV_SLICED and info.state_.info()["n_slices"] >= 3
+    for _ in range(3):
+        sp.multiply(info, a, xd, y)
+    check(values, rowptr, colind, (m, n), x, G.host(y), what="sliced, empty trailing runs")
+
+
 def test_spmv_plan_introspection_and_long_rows(gpu):
     lens = np.full(500, 3, np.int64)
     lens[100] = 10000
