@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) void spg_hash_kernel(
     const int32_t* __restrict__ b_colind, const T* __restrict__ b_values, int32_t* __restrict__ c_rowptr,
     int32_t* __restrict__ c_colind, T* __restrict__ c_values, T alpha, int sub, long long ncols,
     const int32_t* __restrict__ d_rowptr, const int32_t* __restrict__ d_colind, const T* __restrict__ d_values,
-    T beta) {
+    T beta, int b_has_entries) {
   constexpr int HS = 1 << LOG2HS;
   constexpr int RPB = 256 / TPR;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -254,10 +254,10 @@ __global__ __launch_bounds__(256) void spg_hash_kernel(
             a[u] = NUMERIC ? __shfl(av, src) : T(0);
             const int q = q0[u] + sl;
             const bool in = q < q1[u];
-            // clamped, unconditional loads (q0 is always a valid position or 0 .. b_nnz-1 range start)
+            // clamped, unconditional loads: entry 0 exists whenever B stores anything (b_has_entries)
             const int qc = in ? q : (q1[u] > q0[u] ? q0[u] : 0);
-            col[u] = b_rowptr ? (b_colind ? b_colind[qc] : 0) : q;
-            bv[u] = (NUMERIC && b_rowptr && b_values) ? b_values[qc] : T(1);
+            col[u] = b_rowptr ? (b_has_entries ? b_colind[qc] : 0) : q;
+            bv[u] = (NUMERIC && b_rowptr && b_has_entries) ? b_values[qc] : T(1);
             if (!in)
               col[u] = -1;
           }
@@ -507,7 +507,7 @@ static int launch_hash(hipStream_t s, const spblas_gfx950_spgemm_s* st, int bin,
   hipLaunchKernelGGL(kern, dim3((unsigned) cdiv(count, RPB)), dim3(256), smem, s, count,
                      st->perm + st->bin_off[bin], st->a_rowptr, st->a_colind, a_values, st->b_rowptr,
                      st->b_colind, b_values, c_rowptr, c_colind, c_values, alpha, sub, (long long) (st->n > 0 ? st->n : 1),
-                     st->d_rowptr, st->d_colind, d_values, beta);
+                     st->d_rowptr, st->d_colind, d_values, beta, (int) (st->b_nnz > 0));
   SPB_HIP(hipGetLastError());
   return SPBLAS_GFX950_STATUS_SUCCESS;
 }

@@ -259,3 +259,16 @@ def test_spgemm_4args_golden_bit_exact(gpu):
     assert nnz == int(g["c_nnz"])
     assert np.array_equal(cr, g["c_rowptr"]) and np.array_equal(cc, g["c_colind"])
     assert np.array_equal(cv, g["c_values"])
+
+
+def test_spgemm_with_empty_operands(gpu):
+    """B (or A) without a single stored entry: no products, C = beta*D (or an all-empty C); the kernels'
+    clamped B-row loads must not touch B's (zero-length) arrays."""
+    m, k, n = 300, 200, 250
+    a_h = _csr(m, k, 3000, 0, np.float32)
+    e_kn = (np.zeros(0, np.float32), np.zeros(k + 1, np.int32), np.zeros(0, np.int32), (k, n))
+    e_mk = (np.zeros(0, np.float32), np.zeros(m + 1, np.int32), np.zeros(0, np.int32), (m, k))
+    b_h = _csr(k, n, 2000, 1, np.float32)
+    d_h = _csr(m, n, 4000, 2, np.float32)
+    check_spgemm4(a_h, e_kn, d_h, device_spgemm4(a_h, e_kn, d_h, sd=-2.0)[0], np.float32, 1.0, -2.0)
+    check_spgemm4(e_mk, b_h, d_h, device_spgemm4(e_mk, b_h, d_h)[0], np.float32)
