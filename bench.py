@@ -35,7 +35,7 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=50)
     p.add_argument("--warmup", type=int, default=5)
-    p.add_argument("--workload", default="spmv", choices=["spmv", "spmv_poisson", "spmv_rmat", "spmm", "spgemm"])
+    p.add_argument("--workload", default="spmv", choices=["spmv", "spmv_poisson", "spmv_rmat", "spmm", "spgemm", "add", "transpose", "sptrsv"])
     p.add_argument("--rows", type=int, default=None, help="override the row count (debug only; reported)")
     p.add_argument("--cols", type=int, default=None, help="override the column count (debug: emulate one row shard)")
     p.add_argument("--alg", default="auto", choices=["auto", "vector", "rowblock", "sliced", "noplan"])
@@ -130,7 +130,7 @@ def main():
     from spblas_reference_amd import _capi, sharded
     sp._capi.lib()  # fail loudly if the HIP library is missing
 
-    if args.workload in ("spmm", "spgemm", "spmv_rmat"):
+    if args.workload in ("spmm", "spgemm", "spmv_rmat", "add", "transpose", "sptrsv"):
         from bench_extra import run_extra  # secondary configs (cfg3/cfg4/cfg5), 1 GPU
         return run_extra(args, device)
 

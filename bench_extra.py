@@ -2,6 +2,7 @@
   --workload spmm      cfg3: fp32 CSR x dense, A 2M x 2M 32 nnz/row, B 2M x 128 row-major
   --workload spgemm    cfg5: fp32 CSR x CSR, 1M x 1M, 16 nnz/row, multiply_compute + multiply_fill
   --workload spmv_rmat cfg4 (single-GPU leg): fp64 CSR SpMV, R-MAT scale 24, edge factor 16
+  --workload add | transpose | sptrsv   SURVEY 8f rows: CSR + CSR, CSR transpose, lower-triangular solve
 Same JSON contract as bench.py; `value` is GFLOP/s of the timed operation.  The CPU baseline
 (oracle, 1 core) is timed on a bounded row sample and scaled by nnz (stated in `sample`)."""
 import json
@@ -31,7 +32,7 @@ def _time_steps(fn, warmup, steps):
 
 def _emit(args, metric, flops, alg_bytes, elapsed, ms, workload, extra, cpu):
     avg = sum(ms) / len(ms)
-    out = {"metric": metric, "value": flops / (elapsed / args.steps) / 1e9, "unit": "GFLOP/s", "n_gpus": 1,
+    out = {"metric": metric, "value": flops / (elapsed / args.steps) / 1e9, "unit": extra.pop("unit", "GFLOP/s"), "n_gpus": 1,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": extra.pop("dtype"),
            "data": "synthetic", "config": {"workload": workload, **extra},
@@ -109,6 +110,103 @@ def run_extra(args, device):
               f"cfg5: fp32 CSR x CSR SpGEMM {m}x{m}, 16 nnz/row uniform random; timed step = multiply_fill (numeric)",
               {"dtype": "f32", "rows": m, "products": products, "nnz_c": cn, "multiply_compute_ms_untimed": compute_ms,
                "kernel": "spg_hash_kernel<float,10,64,true>"}, cpu)
+        return
+
+    if args.workload == "add":  # C = A + B, timed step = add_compute (numeric)
+        m = args.rows or 1_000_000
+        av, ar, ac, ash, annz = generate.uniform_csr_device(m, m, 16, seed=0, device=device)
+        bv, br, bc, bsh, bnnz = generate.uniform_csr_device(m, m, 16, seed=1, device=device)
+        a, b = sp.csr_view(av, ar, ac, ash, annz), sp.csr_view(bv, br, bc, bsh, bnnz)
+        c_rp = torch.zeros(m + 1, dtype=torch.int32, device=device)
+        c = sp.csr_view(None, c_rp, None, (m, m), 0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        info = sp.add_inspect(a, b, c)
+        torch.cuda.synchronize()
+        inspect_ms = (time.perf_counter() - t0) * 1e3
+        cn = info.result_nnz()
+        c.update(torch.empty(cn, device=device), c_rp, torch.empty(cn, dtype=torch.int32, device=device), (m, m), cn)
+        elapsed, ms = _time_steps(lambda: sp.add_compute(info, a, b, c), args.warmup, args.steps)
+        alg_bytes = (annz + bnnz + cn) * 8 + 3 * (m + 1) * 4
+        cpu = None
+        if not args.no_cpu_baseline:
+            rows = 200_000
+            ra, rb = ar[:rows + 1].cpu().numpy(), br[:rows + 1].cpu().numpy()
+            t0 = time.perf_counter()
+            oracle.add((rows, m), ra, ac[:ra[-1]].cpu().numpy(), av[:ra[-1]].cpu().numpy(), (rows, m), rb,
+                       bc[:rb[-1]].cpu().numpy(), bv[:rb[-1]].cpu().numpy())
+            dt = time.perf_counter() - t0
+            cpu = {"value": (ra[-1] + rb[-1]) / dt / 1e9, "unit": "Gentries/s", "cores": 1, "kind": "port",
+                   "sample": f"first {rows} rows, oracle_add_f32 (SPA + sort per row)"}
+        _emit(args, "csr_add_gentries", float(annz + bnnz), alg_bytes, elapsed, ms,
+              f"8f: fp32 CSR + CSR add {m}x{m}, 16 nnz/row each, uniform random; timed step = add_compute; value = input entries/ns",
+              {"dtype": "f32", "unit": "Gentries/s", "rows": m, "nnz_c": cn, "add_inspect_ms_untimed": inspect_ms}, cpu)
+        return
+
+    if args.workload == "transpose":  # B = A^T (stable counting sort)
+        m = args.rows or 10_000_000
+        av, ar, ac, ash, annz = generate.uniform_csr_device(m, m, 10, seed=0, device=device)
+        a = sp.csr_view(av, ar, ac, ash, annz)
+        t_rp = torch.empty(m + 1, dtype=torch.int32, device=device)
+        t_ci = torch.empty(annz, dtype=torch.int32, device=device)
+        t_v = torch.empty(annz, device=device)
+        bview = sp.csr_view(t_v, t_rp, t_ci, (m, m), annz)
+        elapsed, ms = _time_steps(lambda: sp.transpose(a, bview), args.warmup, args.steps)
+        alg_bytes = 2 * (annz * 8 + (m + 1) * 4)
+        cpu = None
+        if not args.no_cpu_baseline:
+            rows = 1_000_000
+            rp = ar[:rows + 1].cpu().numpy()
+            t0 = time.perf_counter()
+            oracle.transpose((rows, m), rp, ac[:rp[-1]].cpu().numpy(), av[:rp[-1]].cpu().numpy())
+            dt = time.perf_counter() - t0
+            cpu = {"value": rp[-1] / dt / 1e9, "unit": "Gentries/s", "cores": 1, "kind": "port",
+                   "sample": f"first {rows} rows, oracle_transpose_f32"}
+        _emit(args, "csr_transpose_gentries", float(annz), alg_bytes, elapsed, ms,
+              f"8f: fp32 CSR transpose {m}x{m}, 10 nnz/row uniform random; value = entries/ns",
+              {"dtype": "f32", "unit": "Gentries/s", "rows": m, "nnz": annz}, cpu)
+        return
+
+    if args.workload == "sptrsv":  # x = inv(L) b, L random lower triangular + diagonal
+        m = args.rows or 4_000_000
+        k = 8
+        g = torch.Generator(device=device).manual_seed(0)
+        rows = torch.arange(m, device=device).repeat_interleave(k)
+        cols = (torch.rand(m * k, device=device, generator=g, dtype=torch.float64) * rows.double()).long().clamp_(min=0)
+        cols = torch.minimum(cols, rows)                       # col <= row; col == row only in row 0
+        vals = (torch.rand(m * k, device=device, generator=g) - 0.5) * (0.5 / k)
+        # append the diagonal as the last entry of every row
+        rp = torch.arange(m + 1, device=device, dtype=torch.int64) * (k + 1)
+        colind = torch.empty(m * (k + 1), dtype=torch.int32, device=device)
+        values = torch.empty(m * (k + 1), device=device)
+        colind.view(m, k + 1)[:, :k] = cols.view(m, k).int()
+        colind.view(m, k + 1)[:, k] = torch.arange(m, device=device, dtype=torch.int32)
+        values.view(m, k + 1)[:, :k] = vals.view(m, k)
+        values.view(m, k + 1)[:, k] = 1.0 + torch.rand(m, device=device, generator=g)
+        nnz = m * (k + 1)
+        a = sp.csr_view(values, rp.int(), colind, (m, m), nnz)
+        b = torch.rand(m, device=device, generator=g)
+        x = torch.empty(m, device=device)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        info = sp.triangular_solve_inspect(a, sp.lower_triangle, sp.explicit_diagonal, b, x)
+        torch.cuda.synchronize()
+        inspect_ms = (time.perf_counter() - t0) * 1e3
+        elapsed, ms = _time_steps(lambda: sp.triangular_solve(info, a, sp.lower_triangle, sp.explicit_diagonal, b, x),
+                                  args.warmup, args.steps)
+        alg_bytes = nnz * 8 + (m + 1) * 4 + 2 * m * 4
+        cpu = None
+        if not args.no_cpu_baseline:
+            t0 = time.perf_counter()
+            oracle.triangular_solve((m, m), rp.int().cpu().numpy(), colind.cpu().numpy(), values.cpu().numpy(),
+                                    b.cpu().numpy())
+            dt = time.perf_counter() - t0
+            cpu = {"value": 2.0 * nnz / dt / 1e9, "unit": "GFLOP/s", "cores": 1, "kind": "port",
+                   "sample": f"full workload ({nnz} nnz), oracle_trsv_f32 (sequential reference loop)"}
+        _emit(args, "csr_sptrsv_gflops", 2.0 * nnz, alg_bytes, elapsed, ms,
+              f"8f: fp32 lower-triangular solve {m}x{m}, {k} random sub-diagonal entries per row + diagonal",
+              {"dtype": "f32", "rows": m, "nnz": nnz, "plan": info.state_.info(),
+               "triangular_solve_inspect_ms_untimed": inspect_ms}, cpu)
         return
 
     # spmv_rmat: cfg4 single-GPU leg

@@ -15,6 +15,11 @@ struct spblas_gfx950_handle_s {
   int device;
   int num_cus;
   int64_t bin_row_align = 0;  // SPBLAS_GFX950_OPT_BIN_ROW_ALIGN
+  // grow-only scratch for stand-alone operations (transpose): allocated with plain hipMalloc, reused
+  // by stream order, released with the handle
+  void* scratch = nullptr;
+  size_t scratch_bytes = 0;
+  hipStream_t scratch_stream = nullptr;
 };
 
 namespace spb {
@@ -62,6 +67,32 @@ inline void dev_free(void* p, hipStream_t s) {
     (void) hipGetLastError();
     (void) hipFree(p);
   }
+}
+
+// `bytes` of handle-owned scratch, valid until the next handle_scratch call on this handle.  Work that
+// used the previous contents is ordered before the new user by the stream; when the stream changed or
+// the buffer has to grow, the old stream is drained first.
+inline int handle_scratch(spblas_gfx950_handle_s* h, size_t bytes, void** out) {
+  if (h->scratch && h->scratch_stream != h->stream)
+    (void) hipStreamSynchronize(h->scratch_stream);
+  if (bytes > h->scratch_bytes) {
+    if (h->scratch) {
+      (void) hipStreamSynchronize(h->scratch_stream);
+      (void) hipFree(h->scratch);
+      h->scratch = nullptr;
+      h->scratch_bytes = 0;
+    }
+    const hipError_t e = hipMalloc(&h->scratch, bytes);
+    if (e != hipSuccess) {
+      g_last_hip_error = (int) e;
+      h->scratch = nullptr;
+      return SPBLAS_GFX950_STATUS_ALLOC_FAILED;
+    }
+    h->scratch_bytes = bytes;
+  }
+  h->scratch_stream = h->stream;
+  *out = h->scratch;
+  return SPBLAS_GFX950_STATUS_SUCCESS;
 }
 
 template <typename T>

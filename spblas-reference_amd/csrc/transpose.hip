@@ -82,37 +82,28 @@ extern "C" int spblas_gfx950_csr_transpose(spblas_gfx950_handle_t handle, int64_
     SPB_HIP(hipMemsetAsync(t_rowptr, 0, (size_t) (n + 1) * 4, s));
     return SPBLAS_GFX950_STATUS_SUCCESS;
   }
-  int rc;
-  int32_t *rowid = nullptr, *pos = nullptr, *sorted_cols = nullptr, *perm = nullptr;
-  void* tmp = nullptr;
-  size_t tmp_bytes = 0;
   int bits = 1;
   while (bits < 32 && ((int64_t) 1 << bits) < n)
     ++bits;
-  // Plain (synchronous) allocations and one stream synchronisation before they are released: this
-  // is an inspect-time operation, and scratch that outlives the call by stream order only was seen
-  // to be recycled under the sort's feet when mixed with ordinary hipMalloc/hipFree traffic.
-  auto cleanup = [&]() {
-    (void) hipStreamSynchronize(s);
-    (void) hipFree(rowid);
-    (void) hipFree(pos);
-    (void) hipFree(sorted_cols);
-    (void) hipFree(perm);
-    (void) hipFree(tmp);
-  };
-  auto alloc = [&](void** p, size_t bytes) {
-    return hipMalloc(p, bytes) == hipSuccess ? 0 : (int) SPBLAS_GFX950_STATUS_ALLOC_FAILED;
-  };
-  if ((rc = alloc((void**) &rowid, (size_t) nnz * 4)) || (rc = alloc((void**) &pos, (size_t) nnz * 4)) ||
-      (rc = alloc((void**) &sorted_cols, (size_t) nnz * 4)) || (rc = alloc((void**) &perm, (size_t) nnz * 4))) {
-    cleanup();
+  // scratch: four int32 arrays of nnz entries + the sort's temporary storage, carved out of the
+  // handle's grow-only buffer (no allocation on repeated calls, nothing handed back to an allocator
+  // while kernels may still be using it)
+  size_t tmp_bytes = 0;
+  hipError_t e = rocprim::radix_sort_pairs(nullptr, tmp_bytes, colind, (int32_t*) nullptr, (int32_t*) nullptr,
+                                           (int32_t*) nullptr, (size_t) nnz, 0, bits, s);
+  if (e != hipSuccess)
+    return hip_fail(e);
+  const size_t arr = (((size_t) nnz * 4) + 255) & ~(size_t) 255;
+  void* base = nullptr;
+  int rc = handle_scratch(handle, 4 * arr + tmp_bytes + 256, &base);
+  if (rc)
     return rc;
-  }
-  hipError_t e = rocprim::radix_sort_pairs(nullptr, tmp_bytes, colind, sorted_cols, pos, perm, (size_t) nnz, 0, bits, s);
-  if (e != hipSuccess || (rc = alloc(&tmp, tmp_bytes))) {
-    cleanup();
-    return e != hipSuccess ? hip_fail(e) : rc;
-  }
+  char* bp = static_cast<char*>(base);
+  int32_t* rowid = reinterpret_cast<int32_t*>(bp);
+  int32_t* pos = reinterpret_cast<int32_t*>(bp + arr);
+  int32_t* sorted_cols = reinterpret_cast<int32_t*>(bp + 2 * arr);
+  int32_t* perm = reinterpret_cast<int32_t*>(bp + 3 * arr);
+  void* tmp = bp + 4 * arr;
   hipLaunchKernelGGL(spt_rowid_kernel, dim3((unsigned) cdiv(m, 32)), dim3(256), 0, s, m, rowptr, rowid, pos);
   e = rocprim::radix_sort_pairs(tmp, tmp_bytes, colind, sorted_cols, pos, perm, (size_t) nnz, 0, bits, s);
   if (e == hipSuccess) {
@@ -126,7 +117,6 @@ extern "C" int spblas_gfx950_csr_transpose(spblas_gfx950_handle_t handle, int64_
                          static_cast<const double*>(values), t_colind, static_cast<double*>(t_values));
     e = hipGetLastError();
   }
-  cleanup();  // synchronises the stream, then frees
   if (e != hipSuccess)
     return hip_fail(e);
   return SPBLAS_GFX950_STATUS_SUCCESS;
