@@ -41,6 +41,9 @@ def parse():
     p.add_argument("--alg", default="auto", choices=["auto", "vector", "rowblock", "sliced", "noplan"])
     p.add_argument("--chunks", type=int, default=0,
                    help="N>1: stripes per step whose all-gathers overlap the next stripe's compute (0 = auto)")
+    p.add_argument("--fused", default="auto", choices=["auto", "off"],
+                   help="N>1: auto = peer stores of y from the reduce kernels (hipIpc) when every rank can, "
+                        "validated against the RCCL all-gather path; off = RCCL all-gather only")
     p.add_argument("--overlap", action="store_true", help="debug: use the N>1 overlapped step at N=1 (no collective)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     return p.parse_args()
@@ -190,9 +193,19 @@ def main():
         op = sharded.PipelinedShardedSpMV(a_chunks, ranges, inspect=args.alg != "noplan",
                                           alg=None if args.alg == "noplan" else algs[args.alg])
         mode = "pipelined" if chunks > 1 else "plain"
+    if world > 1 and mode == "plain" and args.fused == "auto" and args.alg in ("auto", "sliced"):
+        # Preferred N > 1 path: no collective on the data path at all -- the reduce kernels store every
+        # finished row of y into all ranks' (IPC-mapped) copies, a device-side barrier ends the step.
+        # Adopted only if every rank can set it up AND its y is bit-identical to the RCCL path's.
+        bounds = [ranges[0][r][0] for r in range(world)] + [m]
+        fused = sharded.try_fused(a_chunks[0], bounds, x, lambda: op.step(x), alg=algs[args.alg], info=op.infos[0],
+                                  log=(lambda msg: print(f"[bench] {msg}; using RCCL all-gather", file=sys.stderr))
+                                  if rank == 0 else None)
+        if fused is not None:
+            op, mode = fused, "fused"
     torch.cuda.synchronize()
     inspect_ms = (time.perf_counter() - t0) * 1e3
-    info0 = op.info if mode == "overlapped" else op.infos[0]
+    info0 = op.info if mode in ("overlapped", "fused") else op.infos[0]
     plan_info = info0.state_.info() if info0.state_ is not None else {"alg": "plan-free"}
 
     for _ in range(args.warmup):
@@ -201,7 +214,8 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(1 if mode == "overlapped" else chunks)]
+    ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+           for _ in range(1 if mode in ("overlapped", "fused") else chunks)]
           for _ in range(args.steps)]
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -232,8 +246,11 @@ def main():
             "config": {"workload": f"cfg2: fp32 CSR SpMV {m}x{n}, {'Poisson(10)' if poisson else 'exactly 10'} nnz/row, "
                                    f"uniform random unsorted columns, int32 indices, nnz={nnz}",
                        "rows": m, "cols": n, "nnz": nnz, "index_type": "int32",
-                       "parallelism": (f"row-sharded x{world}, {chunks} stripes per step ({mode}), one RCCL all-gather(y) per "
-                                       "stripe overlapped with the next stripe's kernels" if world > 1 else "single GPU"),
+                       "parallelism": ("single GPU" if world == 1 else
+                                       f"row-sharded x{world}, all-gather(y) fused into the reduce kernels (peer stores "
+                                       "into hipIpc-mapped copies of y + device-side step barrier)" if mode == "fused" else
+                                       f"row-sharded x{world}, {chunks} stripes per step ({mode}), one RCCL all-gather(y) per "
+                                       "stripe overlapped with the next stripe's kernels"),
                        "alg": args.alg, "plan": plan_info, "inspect_ms_untimed": inspect_ms},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
@@ -253,6 +270,9 @@ def main():
             out["cpu_baseline"] = None
         print(json.dumps(out))
     if world > 1:
+        if mode == "fused":
+            op.check_status()
+            op.close()
         dist.destroy_process_group()
 
 

@@ -109,7 +109,11 @@ typedef enum spblas_gfx950_option {
   /* Row-sharded multi-GPU runs gather y stripe by stripe (spblas-reference_amd/sharded.py).
    * value > 0 asks the SLICED inspect to put its row-bin boundaries on divisors of `value`
    * (the stripe length), so that spblas_gfx950_spmv_reduce_rows can finish whole stripes. */
-  SPBLAS_GFX950_OPT_BIN_ROW_ALIGN = 1
+  SPBLAS_GFX950_OPT_BIN_ROW_ALIGN = 1,
+  /* value > 0 caps the slice split K of spblas_gfx950_spmv_reduce_rows (0 = heuristic only).  Callers
+   * that run the reduces of several stripes side by side on different streams keep K small so the
+   * partial-sum traffic does not grow with the number of stripes. */
+  SPBLAS_GFX950_OPT_MAX_KSPLIT = 2
 } spblas_gfx950_option;
 int spblas_gfx950_set_option(spblas_gfx950_handle_t handle, int option, int64_t value);
 
@@ -149,6 +153,31 @@ int spblas_gfx950_spmv(spblas_gfx950_handle_t handle, spblas_gfx950_plan_t plan,
                        int64_t n, int64_t nnz, const void* alpha, const void* rowptr,
                        const int32_t* colind, const void* values, const void* x, const void* beta,
                        void* y, int offset_type, int value_type);
+
+/* ---- multi-GPU: fused all-gather of y (second stage) -------------------- */
+/* One process per GPU; the reference has no multi-device path, so nothing is mirrored here.
+ * ipc_alloc/export/open: every rank allocates its copy of the full y (and a small flag array) with
+ * ipc_alloc, exports a 64-byte handle (hipIpcGetMemHandle) that it sends to the other ranks by any
+ * host channel, and maps their buffers with ipc_open (hipIpcOpenMemHandle, peer access enabled).
+ * spmv_reduce_rows_bcast: like spmv_reduce_rows with beta = 0, but local row r is stored as row
+ * y_row_offset + r into ALL n_peers buffers of the DEVICE array y_peers (the local copy and the mapped
+ * copies of the other ranks) -- on xGMI the traffic of a direct all-gather, issued by the reduce /
+ * combine kernels themselves.  step_signal / step_wait: device-side barrier that ends a step:
+ * signal stores `step` into slot `rank` of every rank's flag array (after the producing kernels on
+ * the same stream), wait spins until all n_peers slots of the local array reached `step`
+ * (status_dev[0] = 1 after timeout_ms without progress). */
+int spblas_gfx950_ipc_alloc(size_t bytes, void** ptr);
+int spblas_gfx950_ipc_free(void* ptr);
+int spblas_gfx950_ipc_export(void* ptr, unsigned char handle[64]);
+int spblas_gfx950_ipc_open(const unsigned char handle[64], void** ptr);
+int spblas_gfx950_ipc_close(void* ptr);
+int spblas_gfx950_spmv_reduce_rows_bcast(spblas_gfx950_handle_t handle, spblas_gfx950_plan_t plan, const void* alpha,
+                                         void* const* y_peers, int n_peers, int64_t y_row_offset,
+                                         int64_t row_begin, int64_t row_end);
+int spblas_gfx950_step_signal(spblas_gfx950_handle_t handle, void* const* flag_peers, int n_peers, int rank,
+                              int64_t step);
+int spblas_gfx950_step_wait(spblas_gfx950_handle_t handle, const void* flags, int n_peers, int64_t step,
+                            int64_t timeout_ms, int* status_dev);
 
 /* ---- SpMM:  C = alpha * A * B + beta * C,  B (k x n), C (m x n) row-major --- */
 /* ldb/ldc are row strides in elements (mdspan layout_right, test/gtest/spmm_test.cpp). */

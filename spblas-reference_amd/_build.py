@@ -11,7 +11,7 @@ _ROOT = os.path.dirname(_PKG)
 CSRC = os.path.join(_PKG, "csrc")
 LIBDIR = os.path.join(_PKG, "lib")
 LIBPATH = os.path.join(LIBDIR, "libspblas_gfx950.so")
-SOURCES = ["handle.hip", "spmv.hip", "spmv_sliced.hip", "spmm.hip", "spgemm.hip", "transpose.hip", "sptrsv.hip"]
+SOURCES = ["handle.hip", "spmv.hip", "spmv_sliced.hip", "spmm.hip", "spgemm.hip", "transpose.hip", "sptrsv.hip", "multigpu.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
          "-Wall", "-Wno-unused-function", "-I", os.path.join(_ROOT, "include"), "-I", CSRC]
 

@@ -31,6 +31,8 @@ LOWER, UPPER = 0, 1
 DIAG_EXPLICIT, DIAG_UNIT = 0, 1
 SPMV_AUTO, SPMV_VECTOR, SPMV_ROWBLOCK, SPMV_SLICED = 0, 1, 2, 3
 OPT_BIN_ROW_ALIGN = 1
+OPT_MAX_KSPLIT = 2
+OPT_MAX_KSPLIT = 2
 
 # every symbol include/spblas_gfx950.h declares: (name, restype, argtypes)
 PROTOTYPES = [
@@ -71,6 +73,15 @@ PROTOTYPES = [
     ("spblas_gfx950_csr_add_numeric", c_int,
      [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
       c_void_p, c_void_p, c_i64, c_int]),
+    ("spblas_gfx950_ipc_alloc", c_int, [ctypes.c_size_t, ctypes.POINTER(c_void_p)]),
+    ("spblas_gfx950_ipc_free", c_int, [c_void_p]),
+    ("spblas_gfx950_ipc_export", c_int, [c_void_p, c_void_p]),
+    ("spblas_gfx950_ipc_open", c_int, [c_void_p, ctypes.POINTER(c_void_p)]),
+    ("spblas_gfx950_ipc_close", c_int, [c_void_p]),
+    ("spblas_gfx950_spmv_reduce_rows_bcast", c_int,
+     [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_i64, c_i64, c_i64]),
+    ("spblas_gfx950_step_signal", c_int, [c_void_p, c_void_p, c_int, c_int, c_i64]),
+    ("spblas_gfx950_step_wait", c_int, [c_void_p, c_void_p, c_int, c_i64, c_i64, c_void_p]),
     ("spblas_gfx950_sptrsv_create", c_int,
      [c_void_p, ctypes.POINTER(c_void_p), c_i64, c_i64, c_void_p, c_void_p, c_int, c_int]),
     ("spblas_gfx950_sptrsv_destroy", c_int, [c_void_p, c_void_p]),

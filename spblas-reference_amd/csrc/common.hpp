@@ -15,6 +15,7 @@ struct spblas_gfx950_handle_s {
   int device;
   int num_cus;
   int64_t bin_row_align = 0;  // SPBLAS_GFX950_OPT_BIN_ROW_ALIGN
+  int64_t max_ksplit = 0;     // SPBLAS_GFX950_OPT_MAX_KSPLIT (0 = no cap)
   // grow-only scratch for stand-alone operations (transpose): allocated with plain hipMalloc, reused
   // by stream order, released with the handle
   void* scratch = nullptr;

@@ -81,6 +81,12 @@ int spblas_gfx950_set_option(spblas_gfx950_handle_t handle, int option, int64_t 
     handle->bin_row_align = value;
     return SPBLAS_GFX950_STATUS_SUCCESS;
   }
+  if (option == SPBLAS_GFX950_OPT_MAX_KSPLIT) {
+    if (value < 0)
+      return SPBLAS_GFX950_STATUS_INVALID_VALUE;
+    handle->max_ksplit = value;
+    return SPBLAS_GFX950_STATUS_SUCCESS;
+  }
   return SPBLAS_GFX950_STATUS_INVALID_VALUE;
 }
 

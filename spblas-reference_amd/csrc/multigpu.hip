@@ -1,0 +1,124 @@
+// Multi-GPU plumbing of the row-sharded SpMV ("second stage: fuse the gather into
+// the kernel epilogue"): inter-process mapping of the y buffers and a device-side step barrier.
+//
+// The reference is single-device; there is nothing to mirror here.  One process per GPU.  Every rank
+// allocates its copy of the full y with spblas_gfx950_ipc_alloc, exports it (hipIpcGetMemHandle), and
+// maps the other ranks' copies (hipIpcOpenMemHandle, which also enables peer access).  The reduce /
+// combine kernels of spmv_sliced.hip then store each finished row into all P copies
+// (spblas_gfx950_spmv_reduce_rows_bcast): on xGMI that is the same traffic as a direct all-gather -- each
+// shard crosses each link once -- without a collective launch and overlapped with the computation.
+// A step ends with spblas_gfx950_step_signal (tell every rank "my stores of step k are issued"; it runs
+// after the producing kernels on the same stream, so they are complete and visible system-wide) and
+// spblas_gfx950_step_wait (spin, on the device, until all P ranks have signalled step k).
+#include <cstring>
+
+#include "common.hpp"
+
+namespace spb {
+
+__global__ void step_signal_kernel(long long* const* __restrict__ flag_peers, int n_peers, int rank, long long step) {
+  const int p = threadIdx.x;
+  if (p < n_peers)
+    __hip_atomic_store(flag_peers[p] + rank, step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// status[0] = 1 when the wait timed out (a peer died): the host checks it after synchronising.
+__global__ void step_wait_kernel(const long long* __restrict__ flags, int n_peers, long long step,
+                                 long long timeout_ticks, int* __restrict__ status) {
+  const int p = threadIdx.x;
+  if (p >= n_peers)
+    return;
+  const long long t0 = wall_clock64();
+  while (__hip_atomic_load(flags + p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < step) {
+    __builtin_amdgcn_s_sleep(8);
+    if (wall_clock64() - t0 > timeout_ticks) {
+      status[0] = 1;
+      return;
+    }
+  }
+}
+
+} // namespace spb
+
+using namespace spb;
+
+extern "C" {
+
+int spblas_gfx950_ipc_alloc(size_t bytes, void** ptr) {
+  if (!ptr)
+    return SPBLAS_GFX950_STATUS_INVALID_POINTER;
+  *ptr = nullptr;
+  const hipError_t e = hipMalloc(ptr, bytes ? bytes : 1);
+  if (e != hipSuccess) {
+    g_last_hip_error = (int) e;
+    return SPBLAS_GFX950_STATUS_ALLOC_FAILED;
+  }
+  SPB_HIP(hipMemset(*ptr, 0, bytes ? bytes : 1));
+  return SPBLAS_GFX950_STATUS_SUCCESS;
+}
+
+int spblas_gfx950_ipc_free(void* ptr) {
+  if (ptr)
+    SPB_HIP(hipFree(ptr));
+  return SPBLAS_GFX950_STATUS_SUCCESS;
+}
+
+int spblas_gfx950_ipc_export(void* ptr, unsigned char handle[64]) {
+  if (!ptr || !handle)
+    return SPBLAS_GFX950_STATUS_INVALID_POINTER;
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is expected to be 64 bytes");
+  hipIpcMemHandle_t h;
+  SPB_HIP(hipIpcGetMemHandle(&h, ptr));
+  std::memcpy(handle, &h, 64);
+  return SPBLAS_GFX950_STATUS_SUCCESS;
+}
+
+int spblas_gfx950_ipc_open(const unsigned char handle[64], void** ptr) {
+  if (!handle || !ptr)
+    return SPBLAS_GFX950_STATUS_INVALID_POINTER;
+  hipIpcMemHandle_t h;
+  std::memcpy(&h, handle, 64);
+  *ptr = nullptr;
+  SPB_HIP(hipIpcOpenMemHandle(ptr, h, hipIpcMemLazyEnablePeerAccess));
+  return SPBLAS_GFX950_STATUS_SUCCESS;
+}
+
+int spblas_gfx950_ipc_close(void* ptr) {
+  if (ptr)
+    SPB_HIP(hipIpcCloseMemHandle(ptr));
+  return SPBLAS_GFX950_STATUS_SUCCESS;
+}
+
+int spblas_gfx950_step_signal(spblas_gfx950_handle_t handle, void* const* flag_peers, int n_peers, int rank,
+                              int64_t step) {
+  if (!handle)
+    return SPBLAS_GFX950_STATUS_INVALID_HANDLE;
+  if (!flag_peers)
+    return SPBLAS_GFX950_STATUS_INVALID_POINTER;
+  if (n_peers < 1 || n_peers > 64 || rank < 0 || rank >= n_peers)
+    return SPBLAS_GFX950_STATUS_INVALID_SIZE;
+  hipLaunchKernelGGL(step_signal_kernel, dim3(1), dim3(64), 0, handle->stream,
+                     reinterpret_cast<long long* const*>(flag_peers), n_peers, rank, (long long) step);
+  SPB_HIP(hipGetLastError());
+  return SPBLAS_GFX950_STATUS_SUCCESS;
+}
+
+int spblas_gfx950_step_wait(spblas_gfx950_handle_t handle, const void* flags, int n_peers, int64_t step,
+                            int64_t timeout_ms, int* status_dev) {
+  if (!handle)
+    return SPBLAS_GFX950_STATUS_INVALID_HANDLE;
+  if (!flags || !status_dev)
+    return SPBLAS_GFX950_STATUS_INVALID_POINTER;
+  if (n_peers < 1 || n_peers > 64)
+    return SPBLAS_GFX950_STATUS_INVALID_SIZE;
+  int rate_khz = 100000;  // wall_clock64 ticks at 100 MHz on gfx9
+  (void) hipDeviceGetAttribute(&rate_khz, hipDeviceAttributeWallClockRate, handle->device);
+  if (rate_khz <= 0)
+    rate_khz = 100000;
+  hipLaunchKernelGGL(step_wait_kernel, dim3(1), dim3(64), 0, handle->stream, static_cast<const long long*>(flags),
+                     n_peers, (long long) step, (long long) timeout_ms * rate_khz, status_dev);
+  SPB_HIP(hipGetLastError());
+  return SPBLAS_GFX950_STATUS_SUCCESS;
+}
+
+} // extern "C"

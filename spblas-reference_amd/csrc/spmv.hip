@@ -372,7 +372,8 @@ int spmv_sliced_exec(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const v
                      const void* beta, void* y);
 int spmv_sliced_expand(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const void* x);
 int spmv_sliced_reduce_rows(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const void* alpha, const void* beta,
-                            void* y, int64_t row_begin, int64_t row_end);
+                            void* y, int64_t row_begin, int64_t row_end, void* const* peers, int n_peers,
+                            int64_t peer_off);
 int spmv_sliced_build(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const void* values, bool auto_mode);
 int spmv_sliced_update(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const void* values);
 void spmv_sliced_free(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl);
@@ -588,7 +589,23 @@ int spblas_gfx950_spmv_reduce_rows(spblas_gfx950_handle_t handle, spblas_gfx950_
     return SPBLAS_GFX950_STATUS_NOT_SUPPORTED;
   if (row_begin < 0 || row_end > plan->m || row_begin > row_end)
     return SPBLAS_GFX950_STATUS_INVALID_SIZE;
-  return spmv_sliced_reduce_rows(handle, plan, alpha, beta, y, row_begin, row_end);
+  return spmv_sliced_reduce_rows(handle, plan, alpha, beta, y, row_begin, row_end, nullptr, 0, 0);
+}
+
+int spblas_gfx950_spmv_reduce_rows_bcast(spblas_gfx950_handle_t handle, spblas_gfx950_plan_t plan, const void* alpha,
+                                         void* const* y_peers, int n_peers, int64_t y_row_offset,
+                                         int64_t row_begin, int64_t row_end) {
+  if (!handle)
+    return SPBLAS_GFX950_STATUS_INVALID_HANDLE;
+  if (!plan || !alpha || !y_peers)
+    return SPBLAS_GFX950_STATUS_INVALID_POINTER;
+  if (plan->alg != SPBLAS_GFX950_SPMV_SLICED)
+    return SPBLAS_GFX950_STATUS_NOT_SUPPORTED;
+  if (n_peers < 1 || y_row_offset < 0 || row_begin < 0 || row_end > plan->m || row_begin > row_end)
+    return SPBLAS_GFX950_STATUS_INVALID_SIZE;
+  const double zero = 0.0;  // all-zero bit pattern: beta = 0 for both value types
+  return spmv_sliced_reduce_rows(handle, plan, alpha, &zero, nullptr, row_begin, row_end, y_peers, n_peers,
+                                 y_row_offset);
 }
 
 int spblas_gfx950_plan_destroy(spblas_gfx950_handle_t handle, spblas_gfx950_plan_t plan) {

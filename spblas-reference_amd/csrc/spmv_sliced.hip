@@ -305,7 +305,8 @@ __global__ __launch_bounds__(RW * 64) void pb_reduce_kernel(int64_t m, int Hw, i
                                                             const int2* __restrict__ segT, const T* __restrict__ P,
                                                             const uint16_t* __restrict__ s_row, T* __restrict__ y,
                                                             T alpha, T beta, int s_per, T* __restrict__ partial,
-                                                            int64_t pstride) {
+                                                            int64_t pstride, T* const* __restrict__ peers,
+                                                            int n_peers, int64_t peer_off) {
   // blockIdx.y = k selects the slices [k*s_per, (k+1)*s_per): with few wave-bins (a row shard of
   // a multi-GPU run) the slices are split over several workgroups per bin group, each writing a
   // partial sum that pb_combine_kernel adds up in a fixed order.
@@ -431,6 +432,17 @@ __global__ __launch_bounds__(RW * 64) void pb_reduce_kernel(int64_t m, int Hw, i
       dst[i] = acc[i];
     return;
   }
+  if (peers) {
+    // fused all-gather (multi-GPU row shards): local row r is row peer_off + r of the full y, and is
+    // stored straight into every rank's copy (peers[] holds the local buffer and the IPC-mapped
+    // buffers of the other ranks; stores to those travel over xGMI).  beta = 0 by contract.
+    for (int p = 0; p < n_peers; ++p) {
+      T* dst = peers[p] + peer_off + r0;
+      for (int i = lane; i < rh; i += 64)
+        dst[i] = alpha * acc[i];
+    }
+    return;
+  }
   for (int i = lane; i < rh; i += 64) {
     const T v = alpha * acc[i];
     y[r0 + i] = beta == T(0) ? v : v + beta * y[r0 + i];
@@ -441,13 +453,20 @@ __global__ __launch_bounds__(RW * 64) void pb_reduce_kernel(int64_t m, int Hw, i
 template <typename T>
 __global__ __launch_bounds__(256) void pb_combine_kernel(int64_t r_lo, int64_t r_hi, int K,
                                                          const T* __restrict__ partial, int64_t pstride,
-                                                         T* __restrict__ y, T alpha, T beta) {
+                                                         T* __restrict__ y, T alpha, T beta,
+                                                         T* const* __restrict__ peers, int n_peers,
+                                                         int64_t peer_off) {
   const int64_t i = r_lo + (int64_t) blockIdx.x * 256 + threadIdx.x;
   if (i >= r_hi)
     return;
   T s = partial[i];
   for (int k = 1; k < K; ++k)
     s += partial[(int64_t) k * pstride + i];
+  if (peers) {
+    for (int p = 0; p < n_peers; ++p)
+      peers[p][peer_off + i] = alpha * s;
+    return;
+  }
   y[i] = beta == T(0) ? alpha * s : alpha * s + beta * y[i];
 }
 
@@ -666,7 +685,8 @@ static int sliced_expand_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* p
 // rows of the wave-bins [wb_begin, wb_end):  y = alpha * (products of the last expand) + beta * y
 template <typename T>
 static int sliced_reduce_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const void* alpha_p,
-                               const void* beta_p, void* y, int64_t wb_begin, int64_t wb_end) {
+                               const void* beta_p, void* y, int64_t wb_begin, int64_t wb_end,
+                               void* const* peers_p = nullptr, int n_peers = 0, int64_t peer_off = 0) {
   hipStream_t s = h->stream;
   if (wb_end <= wb_begin)
     return SPBLAS_GFX950_STATUS_SUCCESS;
@@ -674,7 +694,10 @@ static int sliced_reduce_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* p
   const int RW = pl->rwaves;
   const int64_t groups = cdiv(wb_end - wb_begin, RW);
   // slices per split: whole batches of 8 runs, so the duplicate-flag groups stay aligned
-  const int s_per = (int) cdiv(cdiv(pl->n_slices, pick_ksplit(groups, pl->n_slices)), 8) * 8;
+  int k_want = pick_ksplit(groups, pl->n_slices);
+  if (h->max_ksplit > 0 && k_want > h->max_ksplit)
+    k_want = (int) h->max_ksplit;  // striped callers run several reduces side by side
+  const int s_per = (int) cdiv(cdiv(pl->n_slices, k_want), 8) * 8;
   const int K = (int) cdiv(pl->n_slices, s_per);
   const int64_t r_lo = wb_begin * pl->rows_per_blk;
   const int64_t r_hi = wb_end * pl->rows_per_blk < pl->m ? wb_end * pl->rows_per_blk : pl->m;
@@ -695,13 +718,16 @@ static int sliced_reduce_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* p
     int64_t mm = pl->m, pstride = pl->m;
     int Hw = pl->rows_per_blk, S = pl->n_slices, sp = s_per;
     T a = alpha, b = beta;
-    void* args[] = {&mm, &Hw, &S, &wb_begin, &wb_end, &segT, &Pp, &rowp, &yp, &a, &b, &sp, &part, &pstride};
+    T* const* peers = reinterpret_cast<T* const*>(peers_p);
+    void* args[] = {&mm, &Hw, &S, &wb_begin, &wb_end, &segT, &Pp, &rowp, &yp, &a, &b, &sp, &part, &pstride,
+                    &peers, &n_peers, &peer_off};
     SPB_HIP(hipLaunchKernel(pb_reduce_fn<T>(RW, pl->rchunks, pl->rgroup), dim3((unsigned) groups, (unsigned) K), dim3(RW * 64), args,
                             (size_t) RW * pl->rows_per_blk * sizeof(T), s));
   }
   if (K > 1 && r_hi > r_lo)
     hipLaunchKernelGGL((pb_combine_kernel<T>), dim3((unsigned) cdiv(r_hi - r_lo, 256)), dim3(256), 0, s, r_lo, r_hi, K,
-                       static_cast<const T*>(pl->s_partial), pl->m, static_cast<T*>(y), alpha, beta);
+                       static_cast<const T*>(pl->s_partial), pl->m, static_cast<T*>(y), alpha, beta,
+                       reinterpret_cast<T* const*>(peers_p), n_peers, peer_off);
   SPB_HIP(hipGetLastError());
   return SPBLAS_GFX950_STATUS_SUCCESS;
 }
@@ -713,14 +739,16 @@ int spmv_sliced_expand(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const
 
 // bins whose first row lies in [row_begin, row_end)
 int spmv_sliced_reduce_rows(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const void* alpha, const void* beta,
-                            void* y, int64_t row_begin, int64_t row_end) {
+                            void* y, int64_t row_begin, int64_t row_end, void* const* peers, int n_peers,
+                            int64_t peer_off) {
   const int64_t H = pl->rows_per_blk;
   const int64_t wb0 = cdiv(row_begin, H);
   int64_t wb1 = cdiv(row_end, H);
   if (wb1 > pl->n_rblk)
     wb1 = pl->n_rblk;
-  return pl->value_type == SPBLAS_GFX950_F32 ? sliced_reduce_typed<float>(h, pl, alpha, beta, y, wb0, wb1)
-                                             : sliced_reduce_typed<double>(h, pl, alpha, beta, y, wb0, wb1);
+  return pl->value_type == SPBLAS_GFX950_F32
+             ? sliced_reduce_typed<float>(h, pl, alpha, beta, y, wb0, wb1, peers, n_peers, peer_off)
+             : sliced_reduce_typed<double>(h, pl, alpha, beta, y, wb0, wb1, peers, n_peers, peer_off);
 }
 
 int spmv_sliced_exec(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const void* alpha, const void* x,
@@ -728,7 +756,7 @@ int spmv_sliced_exec(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const v
   int rc = spmv_sliced_expand(h, pl, x);
   if (rc)
     return rc;
-  return spmv_sliced_reduce_rows(h, pl, alpha, beta, y, 0, pl->m);
+  return spmv_sliced_reduce_rows(h, pl, alpha, beta, y, 0, pl->m, nullptr, 0, 0);
 }
 
 void spmv_sliced_free(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl) {

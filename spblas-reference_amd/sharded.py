@@ -264,3 +264,218 @@ class OverlappedShardedSpMV:
         for w in works:
             w.wait()
         return self.y_full
+
+
+# --------------------------------------------------------------------------- fused all-gather (IPC + P2P stores)
+class _IpcBuffer:
+    """Device buffer from spblas_gfx950_ipc_alloc (plain hipMalloc: exportable with hipIpcGetMemHandle),
+    visible to torch through __cuda_array_interface__ without a copy."""
+
+    def __init__(self, nbytes):
+        import ctypes
+        self._ct = ctypes
+        p = ctypes.c_void_p()
+        api.check(api._capi.lib().spblas_gfx950_ipc_alloc(max(int(nbytes), 1), ctypes.byref(p)), "ipc_alloc")
+        self.ptr, self.nbytes = p.value, int(nbytes)
+
+    def tensor(self, dtype, numel):
+        typestr = {torch.float32: "<f4", torch.float64: "<f8", torch.int64: "<i8", torch.int32: "<i4"}[dtype]
+        owner = self
+
+        class _View:
+            __cuda_array_interface__ = {"shape": (numel,), "typestr": typestr, "data": (self.ptr, False), "version": 2}
+            _keep = owner
+        return torch.as_tensor(_View(), device="cuda")
+
+    def handle(self):
+        buf = (self._ct.c_ubyte * 64)()
+        api.check(api._capi.lib().spblas_gfx950_ipc_export(self._ct.c_void_p(self.ptr), buf), "ipc_export")
+        return bytes(buf)
+
+    def free(self):
+        if self.ptr:
+            api._capi.lib().spblas_gfx950_ipc_free(self._ct.c_void_p(self.ptr))
+            self.ptr = 0
+
+
+def _ipc_open(handle_bytes):
+    import ctypes
+    buf = (ctypes.c_ubyte * 64).from_buffer_copy(handle_bytes)
+    p = ctypes.c_void_p()
+    api.check(api._capi.lib().spblas_gfx950_ipc_open(buf, ctypes.byref(p)), "ipc_open")
+    return p.value
+
+
+class FusedShardedSpMV:
+    """Row-sharded SpMV whose all-gather is FUSED into the reduce kernels (second stage).
+
+    Every rank holds two copies of the full y (double buffer) allocated with ipc_alloc and maps the
+    copies of all other ranks (hipIpc).  A step is
+        expand(x)                                   products of the local rows
+        reduce_rows_bcast(...)                       finished rows are stored into ALL P copies of y by
+                                                     the reduce / combine kernels themselves (peer stores
+                                                     over xGMI: each shard crosses each link once, like a
+                                                     direct all-gather, but with no collective launch and
+                                                     spread over the duration of the kernels)
+        step_signal / step_wait                      device-side barrier: y is complete on this rank once
+                                                     all P ranks have signalled the step
+    all on the compute stream; the host never synchronises inside a step.  y of step k lives in buffer
+    k & 1, so a fast rank writing step k+1 cannot disturb a slow rank still reading step k (as the next
+    x, say); buffer k & 1 is reused by step k+2 only after every rank signalled step k+1, i.e. after it
+    finished consuming step k.  Requires equal row shards and a SLICED local plan; raises otherwise so
+    that callers fall back to ShardedSpMV (RCCL all-gather)."""
+
+    def __init__(self, a_local, bounds, group=None, alg=None, timeout_ms=20000, info=None):
+        """info: an operation_info_t from multiply_inspect on the SAME a_local may be passed to reuse its plan
+        (no second inspect; results bit-identical to the path that plan also serves)."""
+        import ctypes
+        if not (dist.is_available() and dist.is_initialized()):
+            raise RuntimeError("FusedShardedSpMV needs an initialised process group")
+        self.group = group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self._ct = ctypes
+        self._bufs, self._opened, self.y, self.flags = [], [], [], None
+        vals = a_local.values()
+        self.dtype, self.device = vals.dtype, vals.device
+        # Every phase that can fail locally is followed by an agreement (all-reduce of a flag), so that a
+        # rank that cannot take part never leaves the others waiting inside a collective.
+        err = None
+        try:
+            counts = {bounds[g + 1] - bounds[g] for g in range(self.world)}
+            if len(counts) != 1:
+                raise RuntimeError("FusedShardedSpMV needs equal row shards")
+            self.bounds, self.m, self.L = list(bounds), bounds[-1], bounds[1] - bounds[0]
+            if a_local.shape()[0] != self.L:
+                raise RuntimeError("local matrix does not match the row bounds")
+            self.a_local = a_local
+            item = vals.element_size()
+            # local plan (must be the LDS-sliced one: only its kernels have the broadcast epilogue)
+            x_probe = torch.empty(a_local.shape()[1], dtype=self.dtype, device=self.device)
+            y_probe = torch.empty(self.L, dtype=self.dtype, device=self.device)
+            kw = {} if alg is None else {"alg": alg}
+            self.info = info if info is not None else api.multiply_inspect(a_local, x_probe, y_probe, **kw)
+            if not isinstance(self.info.state_, api._Plan) or self.info.state_.info()["alg"] != api._capi.SPMV_SLICED:
+                raise RuntimeError("FusedShardedSpMV needs a SLICED local plan")
+            # buffers: two copies of y, one flag array (slot q = last step signalled by rank q)
+            self._bufs = [_IpcBuffer(self.m * item), _IpcBuffer(self.m * item), _IpcBuffer(self.world * 8)]
+            self.y = [self._bufs[0].tensor(self.dtype, self.m), self._bufs[1].tensor(self.dtype, self.m)]
+            self.flags = self._bufs[2].tensor(torch.int64, self.world)
+            mine = [b.handle() for b in self._bufs]
+        except Exception as e:  # noqa: BLE001 - reported after the agreement
+            err, mine = e, None
+        self._agree(err, "preparing the local plan and buffers")
+        everyone = [None] * self.world
+        dist.all_gather_object(everyone, mine, group=group)
+        ptrs = [[0] * self.world for _ in range(3)]
+        try:
+            for q in range(self.world):
+                for j in range(3):
+                    if q == self.rank:
+                        ptrs[j][q] = self._bufs[j].ptr
+                    else:
+                        ptrs[j][q] = _ipc_open(everyone[q][j])
+                        self._opened.append(ptrs[j][q])
+            self._tabs = [torch.tensor(ptrs[j], dtype=torch.int64, device=self.device) for j in range(3)]
+            self._status = torch.zeros(1, dtype=torch.int32, device=self.device)
+            torch.cuda.synchronize()
+        except Exception as e:  # noqa: BLE001
+            err = e
+        self._agree(err, "mapping the peers' buffers")  # also: everything is mapped before the first peer store
+        self._step, self._timeout = 0, int(timeout_ms)
+        self._alpha = (ctypes.c_float if self.dtype == torch.float32 else ctypes.c_double)(1.0)
+        self._plan = self.info.state_
+        self._x, self._xp = None, None
+
+    def _agree(self, err, what):
+        """Collective: raise on every rank if any rank failed."""
+        on_gpu = dist.get_backend(self.group) == "nccl"
+        flag = torch.tensor([0 if err is None else 1], dtype=torch.int32, device=self.device if on_gpu else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
+        if int(flag.item()) != 0:
+            self._release()
+            raise RuntimeError(f"FusedShardedSpMV: a rank failed while {what}" + (f": {err}" if err is not None else ""))
+
+    def step(self, x, events=None):
+        """One sharded SpMV; returns the full y (valid on this rank once the stream reaches this point)."""
+        ct, lib = self._ct, api._capi.lib()
+        if self._x is not x:
+            self._x, self._xp = x, ct.c_void_p(x.data_ptr())
+        self._step += 1
+        b = self._step & 1
+        h, plan = api._Handle.current(self.device).h, self._plan.plan  # (re)binds torch's current stream
+        if events is not None:
+            events[0][0].record()
+        api.check(lib.spblas_gfx950_spmv_expand(h, plan, self._xp), "spmv_expand")
+        api.check(lib.spblas_gfx950_spmv_reduce_rows_bcast(h, plan, ct.byref(self._alpha),
+                                                           ct.c_void_p(self._tabs[b].data_ptr()), self.world,
+                                                           self.bounds[self.rank], 0, self.L), "spmv_reduce_rows_bcast")
+        if events is not None:
+            events[0][1].record()
+        api.check(lib.spblas_gfx950_step_signal(h, ct.c_void_p(self._tabs[2].data_ptr()), self.world, self.rank,
+                                                self._step), "step_signal")
+        api.check(lib.spblas_gfx950_step_wait(h, ct.c_void_p(self.flags.data_ptr()), self.world, self._step,
+                                              self._timeout, ct.c_void_p(self._status.data_ptr())), "step_wait")
+        return self.y[b]
+
+    def check_status(self):
+        """After a host synchronisation: raise if a step barrier timed out (a peer stopped responding)."""
+        if int(self._status.item()) != 0:
+            raise RuntimeError("FusedShardedSpMV: step barrier timed out")
+
+    def close(self):
+        torch.cuda.synchronize()
+        try:
+            if dist.is_initialized():
+                dist.barrier(group=self.group)  # nobody may still be storing into a buffer about to go away
+        except Exception:  # noqa: BLE001
+            pass
+        self._release()
+
+    def _release(self):
+        lib = api._capi.lib()
+        for p in self._opened:
+            lib.spblas_gfx950_ipc_close(self._ct.c_void_p(p))
+        self._opened = []
+        self.y, self.flags = [], None
+        for b in self._bufs:
+            b.free()
+        self._bufs = []
+
+
+def try_fused(a_local, bounds, x, reference_step, alg=None, group=None, log=None, info=None):
+    """Collective.  Returns a FusedShardedSpMV if EVERY rank could set it up and its full y agrees with
+    `reference_step()` (the RCCL all-gather path) on every rank; otherwise None, with everything the
+    attempt allocated released again.  Never raises: any failure means "keep the reference path".
+    With `info` (the reference path's own plan) the two paths run the same kernels on the same plan and
+    must agree bit for bit; without it each path has its own plan -- inspect orders the entries of a
+    run by arrival, so two plans of one matrix differ in summation order -- and agreement is checked to
+    1e-4 / 1e-10 relative, which still catches any wiring error (wrong offset, missing rows, stale
+    buffer)."""
+    fused, same = None, 0
+    try:
+        fused = FusedShardedSpMV(a_local, bounds, group=group, alg=alg, info=info)
+        y_ref = reference_step().clone()
+        y_fused = fused.step(x)
+        torch.cuda.synchronize()
+        fused.check_status()
+        if info is not None:
+            same = int(torch.equal(y_ref, y_fused))
+        else:
+            tol = 1e-4 if y_ref.dtype == torch.float32 else 1e-10
+            same = int(torch.allclose(y_fused, y_ref, rtol=tol, atol=tol * float(y_ref.abs().max())))
+        if not same and log:
+            log("fused all-gather disagrees with the reference path")
+    except Exception as e:  # noqa: BLE001
+        if log:
+            log(f"fused all-gather unavailable: {e}")
+        same = 0
+        if fused is not None and not fused._bufs:
+            fused = None  # the constructor already released everything
+    on_gpu = dist.get_backend(group) == "nccl"
+    flag = torch.tensor([same], dtype=torch.int32, device=x.device if on_gpu else "cpu")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    if int(flag.item()) == 1:
+        return fused
+    if fused is not None:
+        fused.close()
+    return None

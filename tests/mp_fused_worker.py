@@ -1,0 +1,96 @@
+"""Worker of tests/test_gpu_fused_sharding.py: run with torch.distributed.run, WORLD_SIZE processes that
+ALL use cuda:0 (the GPU box has one device).  Control plane: gloo; data plane: hipIpc-mapped buffers and
+peer stores from the reduce kernels -- exactly the code path of an 8-GPU node, minus xGMI."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import spblas_reference_amd as sp  # noqa: E402
+from oracle import oracle  # noqa: E402
+from spblas_reference_amd import generate, sharded  # noqa: E402
+
+
+def main():
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    m, n, per_row = 64000 * world, 90000, 9
+    dtype = torch.float64 if len(sys.argv) > 1 and sys.argv[1] == "f64" else torch.float32
+    values, rowptr, colind, shape, nnz = generate.uniform_csr_device(m, n, per_row, dtype=dtype, seed=0, device=dev)
+    bounds = sharded.partition_rows_even(m, world)
+    a_loc = sharded.shard_csr(values, rowptr, colind, shape, bounds[rank], bounds[rank + 1])
+    op = sharded.FusedShardedSpMV(a_loc, bounds, alg=sp._capi.SPMV_SLICED, timeout_ms=5000)
+    g = torch.Generator(device=dev).manual_seed(7)
+    x = torch.rand(n, dtype=dtype, device=dev, generator=g)
+    vh, rh, ch, xh = values.cpu().numpy(), rowptr.cpu().numpy(), colind.cpu().numpy(), x.cpu().numpy()
+    ref = oracle.spmv(shape, rh, ch, vh, xh)
+    absrow = oracle.spmv_absrow(rh, ch, vh, xh)
+    tol = 1e-6 if dtype == torch.float32 else 1e-12
+    outs = []
+    for it in range(4):  # exercises both y buffers twice
+        y = op.step(x)
+        torch.cuda.synchronize()
+        op.check_status()
+        yh = y.cpu().numpy()
+        err = np.abs(yh.astype(np.float64) - ref.astype(np.float64))
+        assert (err <= tol * absrow + 1e-30).all(), f"rank {rank} step {it}: parity failed ({(err / (absrow + 1e-30)).max()})"
+        outs.append(yh.copy())
+        x = x.clone()  # a new tensor object every step: the x pointer is re-bound
+    assert all(np.array_equal(outs[0], o) for o in outs[1:]), "steps disagree"
+    # every rank must hold the SAME bits (each row is computed once, by its owner)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, outs[0].tobytes())
+    assert all(gb == gathered[0] for gb in gathered), "ranks hold different y"
+    op.close()
+    # the selection helper bench.py uses: adopted only when bit-identical to a reference path on every rank
+    plans = []
+    for q in range(world):
+        a_q = sharded.shard_csr(values, rowptr, colind, shape, bounds[q], bounds[q + 1])
+        y_q = torch.empty(bounds[q + 1] - bounds[q], dtype=dtype, device=dev)
+        plans.append((sp.multiply_inspect(a_q, x, y_q, alg=sp._capi.SPMV_SLICED), a_q, y_q))
+
+    def reference_step(corrupt=False):
+        for info_q, a_q, y_q in plans:
+            sp.multiply(info_q, a_q, x, y_q)
+        y = torch.cat([p[2] for p in plans])
+        if corrupt and rank == world - 1:
+            y[5] += 1
+        return y
+
+    chosen = sharded.try_fused(a_loc, bounds, x, reference_step, alg=sp._capi.SPMV_SLICED,
+                               log=lambda msg: print(f"[rank {rank}] {msg}", flush=True))
+    assert chosen is not None, "try_fused rejected a correct fused path"
+    assert torch.allclose(chosen.step(x), reference_step(), rtol=1e-4)
+    chosen.close()
+    # reusing the reference path's own plan, against a reference that gathers every rank's OWN shard
+    # (what the RCCL all-gather path produces): the two must agree bit for bit
+    def reference_step_gathered():
+        info_r, a_r, y_r = plans[rank]
+        sp.multiply(info_r, a_r, x, y_r)
+        torch.cuda.synchronize()
+        parts = [None] * world
+        dist.all_gather_object(parts, y_r.cpu().numpy())
+        return torch.from_numpy(np.concatenate(parts)).to(dev)
+
+    chosen = sharded.try_fused(a_loc, bounds, x, reference_step_gathered, info=plans[rank][0])
+    assert chosen is not None, "try_fused rejected the plan-sharing fused path"
+    assert torch.equal(chosen.step(x), reference_step_gathered())
+    chosen.close()
+    # a disagreement on ONE rank must make EVERY rank fall back
+    assert sharded.try_fused(a_loc, bounds, x, lambda: reference_step(True), alg=sp._capi.SPMV_SLICED) is None
+    # a rank that cannot build a SLICED plan (forced row-block here) makes every rank fall back, no hang
+    bad_alg = sp._capi.SPMV_ROWBLOCK if rank == 0 else sp._capi.SPMV_SLICED
+    assert sharded.try_fused(a_loc, bounds, x, reference_step, alg=bad_alg) is None
+    dist.barrier()
+    if rank == 0:
+        print("FUSED_OK", world, str(dtype))
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
