@@ -156,8 +156,8 @@ int spblas_gfx950_spmv(spblas_gfx950_handle_t handle, spblas_gfx950_plan_t plan,
 
 /* ---- multi-GPU: fused all-gather of y (second stage) -------------------- */
 /* One process per GPU; the reference has no multi-device path, so nothing is mirrored here.
- * ipc_alloc/export/open: every rank allocates its copy of the full y (and a small flag array) with
- * ipc_alloc, exports a 64-byte handle (hipIpcGetMemHandle) that it sends to the other ranks by any
+ * ipc_alloc/export/open: every rank allocates its copy of the full y (and, with uncached = 1 because
+ * it is polled while peers write it, a small flag array) with ipc_alloc, exports a 64-byte handle (hipIpcGetMemHandle) that it sends to the other ranks by any
  * host channel, and maps their buffers with ipc_open (hipIpcOpenMemHandle, peer access enabled).
  * spmv_reduce_rows_bcast: like spmv_reduce_rows with beta = 0, but local row r is stored as row
  * y_row_offset + r into ALL n_peers buffers of the DEVICE array y_peers (the local copy and the mapped
@@ -166,7 +166,7 @@ int spblas_gfx950_spmv(spblas_gfx950_handle_t handle, spblas_gfx950_plan_t plan,
  * signal stores `step` into slot `rank` of every rank's flag array (after the producing kernels on
  * the same stream), wait spins until all n_peers slots of the local array reached `step`
  * (status_dev[0] = 1 after timeout_ms without progress). */
-int spblas_gfx950_ipc_alloc(size_t bytes, void** ptr);
+int spblas_gfx950_ipc_alloc(size_t bytes, int uncached, void** ptr);
 int spblas_gfx950_ipc_free(void* ptr);
 int spblas_gfx950_ipc_export(void* ptr, unsigned char handle[64]);
 int spblas_gfx950_ipc_open(const unsigned char handle[64], void** ptr);

@@ -73,7 +73,7 @@ PROTOTYPES = [
     ("spblas_gfx950_csr_add_numeric", c_int,
      [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
       c_void_p, c_void_p, c_i64, c_int]),
-    ("spblas_gfx950_ipc_alloc", c_int, [ctypes.c_size_t, ctypes.POINTER(c_void_p)]),
+    ("spblas_gfx950_ipc_alloc", c_int, [ctypes.c_size_t, c_int, ctypes.POINTER(c_void_p)]),
     ("spblas_gfx950_ipc_free", c_int, [c_void_p]),
     ("spblas_gfx950_ipc_export", c_int, [c_void_p, c_void_p]),
     ("spblas_gfx950_ipc_open", c_int, [c_void_p, ctypes.POINTER(c_void_p)]),

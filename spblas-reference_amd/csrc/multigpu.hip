@@ -44,11 +44,19 @@ using namespace spb;
 
 extern "C" {
 
-int spblas_gfx950_ipc_alloc(size_t bytes, void** ptr) {
+int spblas_gfx950_ipc_alloc(size_t bytes, int uncached, void** ptr) {
   if (!ptr)
     return SPBLAS_GFX950_STATUS_INVALID_POINTER;
   *ptr = nullptr;
-  const hipError_t e = hipMalloc(ptr, bytes ? bytes : 1);
+  // uncached (MTYPE UC) for memory that is POLLED while other devices write it (the step flags): a
+  // cached line would never show the remote update.  Bulk data (y) stays ordinary device memory: it is
+  // only read by kernels launched after the barrier, whose acquire makes the peers' stores visible.
+  hipError_t e = uncached ? hipExtMallocWithFlags(ptr, bytes ? bytes : 1, hipDeviceMallocUncached)
+                          : hipMalloc(ptr, bytes ? bytes : 1);
+  if (e != hipSuccess && uncached) {
+    (void) hipGetLastError();
+    e = hipExtMallocWithFlags(ptr, bytes ? bytes : 1, hipDeviceMallocFinegrained);
+  }
   if (e != hipSuccess) {
     g_last_hip_error = (int) e;
     return SPBLAS_GFX950_STATUS_ALLOC_FAILED;

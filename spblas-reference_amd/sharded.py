@@ -271,11 +271,12 @@ class _IpcBuffer:
     """Device buffer from spblas_gfx950_ipc_alloc (plain hipMalloc: exportable with hipIpcGetMemHandle),
     visible to torch through __cuda_array_interface__ without a copy."""
 
-    def __init__(self, nbytes):
+    def __init__(self, nbytes, uncached=False):
         import ctypes
         self._ct = ctypes
         p = ctypes.c_void_p()
-        api.check(api._capi.lib().spblas_gfx950_ipc_alloc(max(int(nbytes), 1), ctypes.byref(p)), "ipc_alloc")
+        api.check(api._capi.lib().spblas_gfx950_ipc_alloc(max(int(nbytes), 1), int(uncached), ctypes.byref(p)),
+                  "ipc_alloc")
         self.ptr, self.nbytes = p.value, int(nbytes)
 
     def tensor(self, dtype, numel):
@@ -357,7 +358,7 @@ class FusedShardedSpMV:
             if not isinstance(self.info.state_, api._Plan) or self.info.state_.info()["alg"] != api._capi.SPMV_SLICED:
                 raise RuntimeError("FusedShardedSpMV needs a SLICED local plan")
             # buffers: two copies of y, one flag array (slot q = last step signalled by rank q)
-            self._bufs = [_IpcBuffer(self.m * item), _IpcBuffer(self.m * item), _IpcBuffer(self.world * 8)]
+            self._bufs = [_IpcBuffer(self.m * item), _IpcBuffer(self.m * item), _IpcBuffer(self.world * 8, uncached=True)]
             self.y = [self._bufs[0].tensor(self.dtype, self.m), self._bufs[1].tensor(self.dtype, self.m)]
             self.flags = self._bufs[2].tensor(torch.int64, self.world)
             mine = [b.handle() for b in self._bufs]
@@ -453,11 +454,13 @@ def try_fused(a_local, bounds, x, reference_step, alg=None, group=None, log=None
     buffer)."""
     fused, same = None, 0
     try:
-        fused = FusedShardedSpMV(a_local, bounds, group=group, alg=alg, info=info)
+        fused = FusedShardedSpMV(a_local, bounds, group=group, alg=alg, info=info, timeout_ms=3000)
         y_ref = reference_step().clone()
-        y_fused = fused.step(x)
+        for _ in range(3):  # both y buffers, and the barrier more than once
+            y_fused = fused.step(x)
         torch.cuda.synchronize()
         fused.check_status()
+        fused._timeout = 20000
         if info is not None:
             same = int(torch.equal(y_ref, y_fused))
         else:

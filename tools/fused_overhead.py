@@ -1,0 +1,24 @@
+"""Single-process measurement of what the fused step adds on top of the plain local SpMV of one row shard
+(peer table with one entry, step_signal + step_wait kernels).  Usage: python tools/fused_overhead.py [rows]"""
+import os, sys, time, torch, torch.distributed as dist
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import spblas_reference_amd as sp
+from spblas_reference_amd import generate, sharded
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29733")
+dist.init_process_group("gloo", rank=0, world_size=1)
+dev = torch.device("cuda:0")
+rows = int(sys.argv[1]) if len(sys.argv) > 1 else 1_250_000
+n = 10_000_000
+v, rp, ci, shape, nnz = generate.uniform_csr_device(rows, n, 10, seed=0, device=dev)
+a = sp.csr_view(v, rp, ci, shape, nnz)
+x = torch.rand(n, device=dev); y = torch.empty(rows, device=dev)
+info = sp.multiply_inspect(a, x, y)
+plain = sp.prepared_multiply(info, a, x, y)
+fused = sharded.FusedShardedSpMV(a, [0, rows], info=info)
+def timeit(fn, steps=300):
+    for _ in range(30): fn()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(steps): fn()
+    torch.cuda.synchronize(); return (time.perf_counter() - t0) / steps * 1e6
+print(f"rows {rows}: plain {timeit(plain):.1f} us, fused(P=1) {timeit(lambda: fused.step(x)):.1f} us")
+fused.check_status(); fused.close(); dist.destroy_process_group()
