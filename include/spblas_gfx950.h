@@ -174,6 +174,13 @@ int spblas_gfx950_ipc_close(void* ptr);
 int spblas_gfx950_spmv_reduce_rows_bcast(spblas_gfx950_handle_t handle, spblas_gfx950_plan_t plan, const void* alpha,
                                          void* const* y_peers, int n_peers, int64_t y_row_offset,
                                          int64_t row_begin, int64_t row_end);
+/* expand + reduce_rows_bcast of the whole local matrix in one call.  stripes > 1 cuts the row bins into
+ * that many contiguous groups whose reduces alternate between the handle's stream and an auxiliary
+ * stream owned by the handle, so that the link-bound peer stores of one stripe overlap the reduce of
+ * the next; the handle's stream is joined with the auxiliary one before the call returns. */
+int spblas_gfx950_spmv_step_bcast(spblas_gfx950_handle_t handle, spblas_gfx950_plan_t plan, const void* alpha,
+                                  const void* x, void* const* y_peers, int n_peers, int64_t y_row_offset,
+                                  int stripes);
 int spblas_gfx950_step_signal(spblas_gfx950_handle_t handle, void* const* flag_peers, int n_peers, int rank,
                               int64_t step);
 int spblas_gfx950_step_wait(spblas_gfx950_handle_t handle, const void* flags, int n_peers, int64_t step,

@@ -80,6 +80,8 @@ PROTOTYPES = [
     ("spblas_gfx950_ipc_close", c_int, [c_void_p]),
     ("spblas_gfx950_spmv_reduce_rows_bcast", c_int,
      [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_i64, c_i64, c_i64]),
+    ("spblas_gfx950_spmv_step_bcast", c_int,
+     [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_i64, c_int]),
     ("spblas_gfx950_step_signal", c_int, [c_void_p, c_void_p, c_int, c_int, c_i64]),
     ("spblas_gfx950_step_wait", c_int, [c_void_p, c_void_p, c_int, c_i64, c_i64, c_void_p]),
     ("spblas_gfx950_sptrsv_create", c_int,

@@ -16,6 +16,9 @@ struct spblas_gfx950_handle_s {
   int num_cus;
   int64_t bin_row_align = 0;  // SPBLAS_GFX950_OPT_BIN_ROW_ALIGN
   int64_t max_ksplit = 0;     // SPBLAS_GFX950_OPT_MAX_KSPLIT (0 = no cap)
+  // second stream + fork/join events of the striped fused step (created on first use)
+  hipStream_t aux_stream = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   // grow-only scratch for stand-alone operations (transpose): allocated with plain hipMalloc, reused
   // by stream order, released with the handle
   void* scratch = nullptr;

@@ -57,6 +57,12 @@ int spblas_gfx950_create(spblas_gfx950_handle_t* handle, void* stream) {
 int spblas_gfx950_destroy(spblas_gfx950_handle_t handle) {
   if (!handle)
     return SPBLAS_GFX950_STATUS_INVALID_HANDLE;
+  if (handle->aux_stream) {
+    (void) hipStreamSynchronize(handle->aux_stream);
+    (void) hipEventDestroy(handle->ev_fork);
+    (void) hipEventDestroy(handle->ev_join);
+    (void) hipStreamDestroy(handle->aux_stream);
+  }
   if (handle->scratch) {
     (void) hipStreamSynchronize(handle->scratch_stream);
     (void) hipFree(handle->scratch);

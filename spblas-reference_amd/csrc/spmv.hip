@@ -374,6 +374,8 @@ int spmv_sliced_expand(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const
 int spmv_sliced_reduce_rows(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const void* alpha, const void* beta,
                             void* y, int64_t row_begin, int64_t row_end, void* const* peers, int n_peers,
                             int64_t peer_off);
+int spmv_sliced_full_ksplit(spblas_gfx950_plan_s* pl);
+int spmv_sliced_reserve_partial(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, int K);
 int spmv_sliced_build(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const void* values, bool auto_mode);
 int spmv_sliced_update(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const void* values);
 void spmv_sliced_free(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl);
@@ -606,6 +608,66 @@ int spblas_gfx950_spmv_reduce_rows_bcast(spblas_gfx950_handle_t handle, spblas_g
   const double zero = 0.0;  // all-zero bit pattern: beta = 0 for both value types
   return spmv_sliced_reduce_rows(handle, plan, alpha, &zero, nullptr, row_begin, row_end, y_peers, n_peers,
                                  y_row_offset);
+}
+
+// One fused multi-GPU step in a single host call: expand, then the reduce of `stripes` contiguous groups
+// of row bins, alternating between the handle's stream and an auxiliary stream of the handle.  With the
+// slice split active each stripe ends in a combine kernel whose peer stores are bound by the xGMI
+// links, not by the CUs; on the other stream the next stripe's reduce kernel runs meanwhile, so the
+// link time hides behind the remaining reduces instead of following them.  The caller's stream is
+// joined with the auxiliary one before returning (stream order, no host wait).
+int spblas_gfx950_spmv_step_bcast(spblas_gfx950_handle_t handle, spblas_gfx950_plan_t plan, const void* alpha,
+                                  const void* x, void* const* y_peers, int n_peers, int64_t y_row_offset,
+                                  int stripes) {
+  if (!handle)
+    return SPBLAS_GFX950_STATUS_INVALID_HANDLE;
+  if (!plan || !alpha || !x || !y_peers)
+    return SPBLAS_GFX950_STATUS_INVALID_POINTER;
+  if (plan->alg != SPBLAS_GFX950_SPMV_SLICED)
+    return SPBLAS_GFX950_STATUS_NOT_SUPPORTED;
+  if (n_peers < 1 || y_row_offset < 0 || stripes < 1)
+    return SPBLAS_GFX950_STATUS_INVALID_SIZE;
+  if (plan->nnz == 0 || plan->m == 0)
+    return SPBLAS_GFX950_STATUS_NOT_SUPPORTED;
+  const double zero = 0.0;
+  const int64_t NB = plan->n_rblk, H = plan->rows_per_blk, RW = plan->rwaves;
+  int64_t per = cdiv(cdiv(NB, RW), stripes) * RW;  // bins per stripe: whole workgroups
+  if (per < RW)
+    per = RW;
+  const int n_str = (int) cdiv(NB, per);
+  hipStream_t main_s = handle->stream;
+  int rc;
+  if (n_str <= 1) {
+    if ((rc = spmv_sliced_expand(handle, plan, x)))
+      return rc;
+    return spmv_sliced_reduce_rows(handle, plan, alpha, &zero, nullptr, 0, plan->m, y_peers, n_peers, y_row_offset);
+  }
+  if (!handle->aux_stream) {
+    SPB_HIP(hipStreamCreateWithFlags(&handle->aux_stream, hipStreamNonBlocking));
+    SPB_HIP(hipEventCreateWithFlags(&handle->ev_fork, hipEventDisableTiming));
+    SPB_HIP(hipEventCreateWithFlags(&handle->ev_join, hipEventDisableTiming));
+  }
+  const int K = spmv_sliced_full_ksplit(plan);
+  if ((rc = spmv_sliced_reserve_partial(handle, plan, K)))
+    return rc;
+  if ((rc = spmv_sliced_expand(handle, plan, x)))
+    return rc;
+  SPB_HIP(hipEventRecord(handle->ev_fork, main_s));
+  SPB_HIP(hipStreamWaitEvent(handle->aux_stream, handle->ev_fork, 0));
+  const int64_t saved_cap = handle->max_ksplit;
+  handle->max_ksplit = K;
+  rc = SPBLAS_GFX950_STATUS_SUCCESS;
+  for (int c = 0; c < n_str && rc == SPBLAS_GFX950_STATUS_SUCCESS; ++c) {
+    const int64_t b0 = c * per, b1 = (c + 1) * per < NB ? (c + 1) * per : NB;
+    const int64_t r_lo = b0 * H, r_hi = b1 * H < plan->m ? b1 * H : plan->m;
+    handle->stream = (c & 1) ? handle->aux_stream : main_s;
+    rc = spmv_sliced_reduce_rows(handle, plan, alpha, &zero, nullptr, r_lo, r_hi, y_peers, n_peers, y_row_offset);
+  }
+  handle->stream = main_s;
+  handle->max_ksplit = saved_cap;
+  SPB_HIP(hipEventRecord(handle->ev_join, handle->aux_stream));
+  SPB_HIP(hipStreamWaitEvent(main_s, handle->ev_join, 0));
+  return rc;
 }
 
 int spblas_gfx950_plan_destroy(spblas_gfx950_handle_t handle, spblas_gfx950_plan_t plan) {

@@ -732,6 +732,28 @@ static int sliced_reduce_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* p
   return SPBLAS_GFX950_STATUS_SUCCESS;
 }
 
+// slice split the reduce of the WHOLE row range would use, and the partial-sum workspace for it:
+// callers that reduce stripe by stripe on several streams cap K with it (handle->max_ksplit) and
+// reserve the workspace before they fork, so no stripe allocates.
+int spmv_sliced_full_ksplit(spblas_gfx950_plan_s* pl) {
+  return pick_ksplit(cdiv(pl->n_rblk, pl->rwaves), pl->n_slices);
+}
+
+int spmv_sliced_reserve_partial(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, int K) {
+  if (K <= 1 || pl->s_partial_k >= K)
+    return SPBLAS_GFX950_STATUS_SUCCESS;
+  hipStream_t s = h->stream;
+  dev_free(pl->s_partial, s);
+  pl->s_partial = nullptr;
+  pl->s_partial_k = 0;
+  const size_t tsz = pl->value_type == SPBLAS_GFX950_F32 ? 4 : 8;
+  int rc = dev_alloc(&pl->s_partial, (size_t) K * pl->m * tsz, s);
+  if (rc)
+    return rc;
+  pl->s_partial_k = K;
+  return SPBLAS_GFX950_STATUS_SUCCESS;
+}
+
 int spmv_sliced_expand(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const void* x) {
   return pl->value_type == SPBLAS_GFX950_F32 ? sliced_expand_typed<float>(h, pl, x)
                                              : sliced_expand_typed<double>(h, pl, x);

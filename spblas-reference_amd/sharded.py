@@ -326,7 +326,7 @@ class FusedShardedSpMV:
     finished consuming step k.  Requires equal row shards and a SLICED local plan; raises otherwise so
     that callers fall back to ShardedSpMV (RCCL all-gather)."""
 
-    def __init__(self, a_local, bounds, group=None, alg=None, timeout_ms=20000, info=None):
+    def __init__(self, a_local, bounds, group=None, alg=None, timeout_ms=20000, info=None, stripes=1):
         """info: an operation_info_t from multiply_inspect on the SAME a_local may be passed to reuse its plan
         (no second inspect; results bit-identical to the path that plan also serves)."""
         import ctypes
@@ -382,7 +382,7 @@ class FusedShardedSpMV:
         except Exception as e:  # noqa: BLE001
             err = e
         self._agree(err, "mapping the peers' buffers")  # also: everything is mapped before the first peer store
-        self._step, self._timeout = 0, int(timeout_ms)
+        self._step, self._timeout, self.stripes = 0, int(timeout_ms), max(1, int(stripes))
         self._alpha = (ctypes.c_float if self.dtype == torch.float32 else ctypes.c_double)(1.0)
         self._plan = self.info.state_
         self._x, self._xp = None, None
@@ -406,10 +406,9 @@ class FusedShardedSpMV:
         h, plan = api._Handle.current(self.device).h, self._plan.plan  # (re)binds torch's current stream
         if events is not None:
             events[0][0].record()
-        api.check(lib.spblas_gfx950_spmv_expand(h, plan, self._xp), "spmv_expand")
-        api.check(lib.spblas_gfx950_spmv_reduce_rows_bcast(h, plan, ct.byref(self._alpha),
-                                                           ct.c_void_p(self._tabs[b].data_ptr()), self.world,
-                                                           self.bounds[self.rank], 0, self.L), "spmv_reduce_rows_bcast")
+        api.check(lib.spblas_gfx950_spmv_step_bcast(h, plan, ct.byref(self._alpha), self._xp,
+                                                    ct.c_void_p(self._tabs[b].data_ptr()), self.world,
+                                                    self.bounds[self.rank], self.stripes), "spmv_step_bcast")
         if events is not None:
             events[0][1].record()
         api.check(lib.spblas_gfx950_step_signal(h, ct.c_void_p(self._tabs[2].data_ptr()), self.world, self.rank,
@@ -443,7 +442,7 @@ class FusedShardedSpMV:
         self._bufs = []
 
 
-def try_fused(a_local, bounds, x, reference_step, alg=None, group=None, log=None, info=None):
+def try_fused(a_local, bounds, x, reference_step, alg=None, group=None, log=None, info=None, stripes=1):
     """Collective.  Returns a FusedShardedSpMV if EVERY rank could set it up and its full y agrees with
     `reference_step()` (the RCCL all-gather path) on every rank; otherwise None, with everything the
     attempt allocated released again.  Never raises: any failure means "keep the reference path".
@@ -454,7 +453,7 @@ def try_fused(a_local, bounds, x, reference_step, alg=None, group=None, log=None
     buffer)."""
     fused, same = None, 0
     try:
-        fused = FusedShardedSpMV(a_local, bounds, group=group, alg=alg, info=info, timeout_ms=3000)
+        fused = FusedShardedSpMV(a_local, bounds, group=group, alg=alg, info=info, timeout_ms=3000, stripes=stripes)
         y_ref = reference_step().clone()
         for _ in range(3):  # both y buffers, and the barrier more than once
             y_fused = fused.step(x)

@@ -24,7 +24,8 @@ def main():
     values, rowptr, colind, shape, nnz = generate.uniform_csr_device(m, n, per_row, dtype=dtype, seed=0, device=dev)
     bounds = sharded.partition_rows_even(m, world)
     a_loc = sharded.shard_csr(values, rowptr, colind, shape, bounds[rank], bounds[rank + 1])
-    op = sharded.FusedShardedSpMV(a_loc, bounds, alg=sp._capi.SPMV_SLICED, timeout_ms=5000)
+    stripes = int(os.environ.get("FUSED_STRIPES", "1"))
+    op = sharded.FusedShardedSpMV(a_loc, bounds, alg=sp._capi.SPMV_SLICED, timeout_ms=5000, stripes=stripes)
     g = torch.Generator(device=dev).manual_seed(7)
     x = torch.rand(n, dtype=dtype, device=dev, generator=g)
     vh, rh, ch, xh = values.cpu().numpy(), rowptr.cpu().numpy(), colind.cpu().numpy(), x.cpu().numpy()
@@ -77,7 +78,7 @@ def main():
         dist.all_gather_object(parts, y_r.cpu().numpy())
         return torch.from_numpy(np.concatenate(parts)).to(dev)
 
-    chosen = sharded.try_fused(a_loc, bounds, x, reference_step_gathered, info=plans[rank][0])
+    chosen = sharded.try_fused(a_loc, bounds, x, reference_step_gathered, info=plans[rank][0], stripes=stripes)
     assert chosen is not None, "try_fused rejected the plan-sharing fused path"
     assert torch.equal(chosen.step(x), reference_step_gathered())
     chosen.close()
@@ -88,7 +89,7 @@ def main():
     assert sharded.try_fused(a_loc, bounds, x, reference_step, alg=bad_alg) is None
     dist.barrier()
     if rank == 0:
-        print("FUSED_OK", world, str(dtype))
+        print("FUSED_OK", world, str(dtype), "stripes", stripes)
     dist.destroy_process_group()
 
 

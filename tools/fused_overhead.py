@@ -15,10 +15,21 @@ x = torch.rand(n, device=dev); y = torch.empty(rows, device=dev)
 info = sp.multiply_inspect(a, x, y)
 plain = sp.prepared_multiply(info, a, x, y)
 fused = sharded.FusedShardedSpMV(a, [0, rows], info=info)
+striped = {st: sharded.FusedShardedSpMV(a, [0, rows], info=info, stripes=st) for st in (2, 4, 8)}
 def timeit(fn, steps=300):
     for _ in range(30): fn()
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(steps): fn()
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / steps * 1e6
-print(f"rows {rows}: plain {timeit(plain):.1f} us, fused(P=1) {timeit(lambda: fused.step(x)):.1f} us")
+print(f"rows {rows}: plain {timeit(plain):.1f} us, fused(P=1) {timeit(lambda: fused.step(x)):.1f} us, " +
+      ", ".join(f"{st} stripes {timeit(lambda op=op: op.step(x)):.1f} us" for st, op in striped.items()))
+def cpu_time(fn, steps=200):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(steps): fn()
+    t = (time.perf_counter() - t0) / steps * 1e6
+    torch.cuda.synchronize(); return t
+print("host time per call while the GPU queue is never waited for: plain %.1f us, fused %.1f us, 4 stripes %.1f us"
+      % (cpu_time(plain), cpu_time(lambda: fused.step(x)), cpu_time(lambda: striped[4].step(x))))
+for op in striped.values():
+    op.check_status(); op.close()
 fused.check_status(); fused.close(); dist.destroy_process_group()
