@@ -1,0 +1,96 @@
+"""Randomised stress of the SpMV plans against the CPU oracle (run on the GPU box):
+    python tools/fuzz_spmv.py [iterations] [first_seed]
+Random shapes, row-length distributions (uniform / power law / banded / mostly empty / duplicate-heavy),
+value types, offset types, algorithms and the SLICED test hooks (tile sizes, slice split, reduce shape)."""
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import spblas_reference_amd as sp
+from spblas_reference_amd import _capi
+from oracle import oracle
+import util
+
+iters = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+HOOKS = ["SPBLAS_GFX950_SLICE_COLS", "SPBLAS_GFX950_SLICE_ROWS", "SPBLAS_GFX950_PB_KSPLIT", "SPBLAS_GFX950_PB_RWAVES",
+         "SPBLAS_GFX950_PB_RCHUNKS", "SPBLAS_GFX950_PB_RGROUP"]
+dev = torch.device("cuda:0")
+bad = 0
+for it in range(iters):
+    rng = np.random.default_rng(seed0 + it)
+    for h in HOOKS:
+        os.environ.pop(h, None)
+    m = int(rng.choice([1, 7, 300, 5000, 40000, 150000]))
+    n = int(rng.choice([1, 13, 999, 20000, 70000, 300000]))
+    kind = rng.choice(["uniform", "powerlaw", "banded", "sparse_rows", "dups"])
+    if kind == "uniform":
+        lens = rng.integers(0, 24, m)
+    elif kind == "powerlaw":
+        lens = np.minimum(rng.zipf(1.5, m), 30000)
+    elif kind == "banded":
+        lens = np.full(m, min(n, 9))
+    elif kind == "sparse_rows":
+        lens = np.where(rng.random(m) < 0.05, rng.integers(1, 200, m), 0)
+    else:
+        lens = rng.integers(0, 80, m)
+    lens = lens.astype(np.int64)
+    if lens.sum() > 6_000_000:
+        lens = (lens * (6_000_000 / lens.sum())).astype(np.int64)
+    rowptr = np.concatenate([[0], np.cumsum(lens)])
+    nnz = int(rowptr[-1])
+    if kind == "banded":
+        rows = np.repeat(np.arange(m), lens)
+        colind = ((rows * max(n // max(m, 1), 1) + rng.integers(0, min(n, 50), nnz)) % n).astype(np.int32)
+    elif kind == "dups":
+        colind = rng.integers(0, max(1, min(n, 40)), nnz).astype(np.int32)   # few distinct columns: many duplicates
+    else:
+        colind = rng.integers(0, n, nnz).astype(np.int32)
+    dtype = rng.choice([np.float32, np.float64])
+    values = (rng.random(nnz) - (0.5 if rng.random() < 0.5 else 0.0)).astype(dtype)
+    x = (rng.random(n) - 0.5).astype(dtype)
+    alg = rng.choice(["auto", "vector", "rowblock", "sliced", "none"])
+    off64 = bool(rng.random() < 0.3)
+    hooks = {}
+    if alg == "sliced":
+        if rng.random() < 0.7:
+            hooks["SPBLAS_GFX950_SLICE_COLS"] = str(int(rng.choice([4, 64, 1000, 20000])))
+        if rng.random() < 0.7:
+            hooks["SPBLAS_GFX950_SLICE_ROWS"] = str(int(rng.choice([1, 16, 64, 700, 5000])))
+        hooks["SPBLAS_GFX950_PB_KSPLIT"] = str(int(rng.choice([0, 1, 2, 8, 32])))
+        hooks["SPBLAS_GFX950_PB_RWAVES"] = str(int(rng.choice([4, 8])))
+        hooks["SPBLAS_GFX950_PB_RCHUNKS"] = str(int(rng.choice([0, 1, 2, 4])))
+        hooks["SPBLAS_GFX950_PB_RGROUP"] = str(int(rng.choice([0, 1, 2, 4])))
+    os.environ.update(hooks)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    rp_dev = t(rowptr.astype(np.int64 if off64 else np.int32))
+    a = sp.csr_view(t(values), rp_dev, t(colind), (m, n), nnz)
+    xd = t(x)
+    y = torch.full((m,), float("nan"), dtype=xd.dtype, device=dev)
+    alpha = float(rng.choice([1.0, -2.5]))
+    desc = f"seed {seed0 + it}: {kind} {m}x{n} nnz={nnz} {np.dtype(dtype).name} alg={alg} off64={off64} alpha={alpha} {hooks}"
+    try:
+        A = sp.scaled(alpha, a) if alpha != 1.0 else a
+        if alg == "none":
+            sp.multiply(A, xd, y)
+        else:
+            algs = {"auto": _capi.SPMV_AUTO, "vector": _capi.SPMV_VECTOR, "rowblock": _capi.SPMV_ROWBLOCK, "sliced": _capi.SPMV_SLICED}
+            try:
+                info = sp.multiply_inspect(a, xd, y, alg=algs[alg])
+            except Exception as e:  # noqa: BLE001 -- "not supported" for a forced algorithm is a legal answer
+                print("SKIP", desc, "->", type(e).__name__, str(e)[:80])
+                continue
+            sp.multiply(info, A, xd, y)
+            sp.multiply(info, A, xd, y)
+        torch.cuda.synchronize()
+        yh = y.cpu().numpy()
+        rp32 = rowptr.astype(np.int32)
+        ref = oracle.spmv((m, n), rp32, colind, values, x, scale_a=None if alpha == 1.0 else alpha)
+        absrow = abs(alpha) * oracle.spmv_absrow(rp32, colind, values, x)
+        util.assert_parity(yh, ref, absrow, dtype, row_len=np.diff(rowptr), what=desc)
+        print("ok  ", desc)
+    except AssertionError as e:
+        bad += 1
+        print("FAIL", desc, "->", str(e)[:200])
+print("failures:", bad)
+sys.exit(1 if bad else 0)
