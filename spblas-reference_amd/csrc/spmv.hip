@@ -485,14 +485,15 @@ static int plan_build(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, int al
   return SPBLAS_GFX950_STATUS_SUCCESS;
 }
 
-// AUTO considers the sliced re-tiling only when x cannot live in an XCD's 4 MiB L2, the
+// AUTO considers the sliced re-tiling only when x approaches an XCD's 4 MiB L2 (measured
+// crossover on square 10-per-row matrices: n between 0.5M and 1M columns, tools/auto_sweep.sh), the
 // matrix is big enough to amortise two launches, rows are short (LDS atomics serialise on
 // hub rows) and the average (slice, bin) segment keeps a wavefront busy.
 static bool sliced_candidate(const spblas_gfx950_plan_s* pl) {
   const size_t tsz = pl->value_type == SPBLAS_GFX950_F32 ? 4 : 8;
   const double tile = 80.0 * 1024 / tsz;
   const double nseg = (pl->n / tile + 1) * (pl->m / tile + 1);
-  return (size_t) pl->n * tsz >= ((size_t) 16 << 20) && pl->nnz >= ((int64_t) 2 << 20) &&
+  return (size_t) pl->n * tsz >= ((size_t) 3 << 20) && pl->nnz >= ((int64_t) 2 << 20) &&
          pl->nnz < INT32_MAX - 8 && pl->max_row_len <= 4096 && (double) pl->nnz / nseg >= 48.0;
 }
 

@@ -187,7 +187,17 @@ __global__ __launch_bounds__(PB_THREADS) void pb_expand_kernel(int64_t n, int W,
   for (int i = tid; i < cw; i += PB_THREADS)
     xs[i] = x[c0 + i];
   __syncthreads();
-  const int a0 = seg[(int64_t) s * NB], a1 = seg[(int64_t) (s + 1) * NB];
+  // gridDim.y workgroups share one slice (matrices with few slices would otherwise leave most CUs
+  // idle): each takes a contiguous part of the slice's range, cut on multiples of 4 entries
+  int a0 = seg[(int64_t) s * NB], a1 = seg[(int64_t) (s + 1) * NB];
+  if (gridDim.y > 1) {
+    const int len = a1 - a0;
+    const int per = (((len + (int) gridDim.y - 1) / (int) gridDim.y) + 3) & ~3;
+    const int lo = a0 + (int) blockIdx.y * per;
+    const int hi = lo + per < a1 ? lo + per : a1;
+    a0 = lo < a1 ? lo : a1;
+    a1 = hi > a0 ? hi : a0;
+  }
   int body0 = (a0 + 3) & ~3;
   if (body0 > a1)
     body0 = a1;
@@ -534,7 +544,19 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
   const int w_env = env_int("SPBLAS_GFX950_SLICE_COLS", 0);  // test hooks: force small tiles
   const int h_env = env_int("SPBLAS_GFX950_SLICE_ROWS", 0);
   pick_tiling(n, w_env > 0 && w_env < max_cols ? w_env : max_cols, 512, 4, &S, &W);
-  pick_tiling(m, h_env > 0 && h_env < max_rows ? h_env : max_rows, 512 * RW, 1, &NB, &H);
+  // Matrices with few slices (n of a few million) would get runs of many hundred entries with
+  // full-height bins: beyond the C prefetched chunks a run is read in a latency-exposed loop, and there
+  // are too few bins to fill the chip.  Shorter bins bring the average run back to ~128 entries.
+  int h_want = max_rows;
+  {
+    const int64_t bins_full = cdiv(m, max_rows);
+    const int64_t run_full = nnz / (bins_full * S > 0 ? bins_full * S : 1);
+    if (run_full > 160) {
+      const int64_t h = (int64_t) ((double) m * 128.0 * (double) S / (double) (nnz > 0 ? nnz : 1));
+      h_want = (int) (h < 64 ? 64 : (h > max_rows ? max_rows : h));
+    }
+  }
+  pick_tiling(m, h_env > 0 && h_env < max_rows ? h_env : h_want, 512 * RW, 1, &NB, &H);
   if (h->bin_row_align > 1) {
     // caller wants bin boundaries on multiples of bin_row_align (stripe boundaries of the overlapped
     // multi-GPU step): use the largest divisor of it that fits the LDS budget, if a decent one exists
@@ -674,7 +696,12 @@ static int pick_ksplit(int64_t groups, int S) {
 template <typename T>
 static int sliced_expand_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const void* x) {
   const int32_t* seg = reinterpret_cast<const int32_t*>(pl->seg_ptr);
-  hipLaunchKernelGGL((pb_expand_kernel<T>), dim3((unsigned) pl->n_slices), dim3(PB_THREADS),
+  // enough workgroups for 2 per CU, but never so many parts that re-loading the x slice dominates
+  int parts = (int) cdiv(2 * (h->num_cus > 0 ? h->num_cus : 256), pl->n_slices);
+  const int64_t per_slice = pl->nnz / (pl->n_slices > 0 ? pl->n_slices : 1);
+  while (parts > 1 && per_slice / parts < 2 * (int64_t) pl->slice_cols)
+    --parts;
+  hipLaunchKernelGGL((pb_expand_kernel<T>), dim3((unsigned) pl->n_slices, (unsigned) parts), dim3(PB_THREADS),
                      (size_t) pl->slice_cols * sizeof(T), h->stream, pl->n, pl->slice_cols, (int) pl->n_rblk, seg,
                      static_cast<const T*>(pl->s_values), reinterpret_cast<const uint16_t*>(pl->s_colind),
                      static_cast<const T*>(x), static_cast<T*>(pl->s_products));
