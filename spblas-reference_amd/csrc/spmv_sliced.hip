@@ -556,7 +556,7 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
       h_want = (int) (h < 64 ? 64 : (h > max_rows ? max_rows : h));
     }
   }
-  pick_tiling(m, h_env > 0 && h_env < max_rows ? h_env : h_want, 512 * RW, 1, &NB, &H);
+  pick_tiling(m, h_env > 0 && h_env < max_rows ? h_env : h_want, env_int("SPBLAS_GFX950_PB_ROUND", 512) * RW, 1, &NB, &H);
   if (h->bin_row_align > 1) {
     // caller wants bin boundaries on multiples of bin_row_align (stripe boundaries of the overlapped
     // multi-GPU step): use the largest divisor of it that fits the LDS budget, if a decent one exists
