@@ -44,6 +44,9 @@ def parse():
     p.add_argument("--fused", default="auto", choices=["auto", "off"],
                    help="N>1: auto = peer stores of y from the reduce kernels (hipIpc) when every rank can, "
                         "validated against the RCCL all-gather path; off = RCCL all-gather only")
+    p.add_argument("--debug-multi", action="store_true",
+                   help="debug: run the N>1 code path (process group, sharded operators, fused all-gather) with "
+                        "a single rank; launch through torch.distributed.run --nproc-per-node 1")
     p.add_argument("--overlap", action="store_true", help="debug: use the N>1 overlapped step at N=1 (no collective)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     return p.parse_args()
@@ -125,7 +128,8 @@ def main():
         args.gpus = world
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    multi = world > 1 or args.debug_multi
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=device)
 
@@ -167,7 +171,7 @@ def main():
         nnz_local += nnz_c
     rows_local = sum(a.shape()[0] for a in a_chunks)
     nnz_t = torch.tensor([nnz_local], dtype=torch.int64, device=device)
-    if world > 1:
+    if multi:
         dist.all_reduce(nnz_t)
     nnz = int(nnz_t.item())
 
@@ -175,7 +179,7 @@ def main():
     t0 = time.perf_counter()
     mode = "plain"
     op = None
-    if (world > 1 or args.overlap) and chunks > 1 and args.alg in ("auto", "sliced"):
+    if (multi or args.overlap) and chunks > 1 and args.alg in ("auto", "sliced"):
         # preferred N > 1 path: ONE local plan (stripes back to back), expand once, reduce stripe by
         # stripe with each stripe's all-gather overlapping the next reduce
         try:
@@ -193,7 +197,7 @@ def main():
         op = sharded.PipelinedShardedSpMV(a_chunks, ranges, inspect=args.alg != "noplan",
                                           alg=None if args.alg == "noplan" else algs[args.alg])
         mode = "pipelined" if chunks > 1 else "plain"
-    if world > 1 and mode == "plain" and args.fused == "auto" and args.alg in ("auto", "sliced"):
+    if multi and mode == "plain" and args.fused == "auto" and args.alg in ("auto", "sliced"):
         # Preferred N > 1 path: no collective on the data path at all -- the reduce kernels store every
         # finished row of y into all ranks' (IPC-mapped) copies, a device-side barrier ends the step.
         # Adopted only if every rank can set it up AND its y is bit-identical to the RCCL path's.
@@ -211,7 +215,7 @@ def main():
     for _ in range(args.warmup):
         op.step(x)
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
@@ -221,12 +225,12 @@ def main():
     for i in range(args.steps):
         op.step(x, events=ev[i])
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     el = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    if world > 1:
+    if multi:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
     kern_ms = sorted(sum(a.elapsed_time(b) for a, b in step_ev) for step_ev in ev)
@@ -246,7 +250,7 @@ def main():
             "config": {"workload": f"cfg2: fp32 CSR SpMV {m}x{n}, {'Poisson(10)' if poisson else 'exactly 10'} nnz/row, "
                                    f"uniform random unsorted columns, int32 indices, nnz={nnz}",
                        "rows": m, "cols": n, "nnz": nnz, "index_type": "int32",
-                       "parallelism": ("single GPU" if world == 1 else
+                       "parallelism": ("single GPU" if not multi else
                                        f"row-sharded x{world}, all-gather(y) fused into the reduce kernels (peer stores "
                                        "into hipIpc-mapped copies of y + device-side step barrier)" if mode == "fused" else
                                        f"row-sharded x{world}, {chunks} stripes per step ({mode}), one RCCL all-gather(y) per "
@@ -269,7 +273,7 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
-    if world > 1:
+    if multi:
         if mode == "fused":
             op.check_status()
             op.close()

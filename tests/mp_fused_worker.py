@@ -15,7 +15,7 @@ from spblas_reference_amd import generate, sharded  # noqa: E402
 
 
 def main():
-    dist.init_process_group("gloo")
+    dist.init_process_group(os.environ.get("FUSED_BACKEND", "gloo"))
     rank, world = dist.get_rank(), dist.get_world_size()
     torch.cuda.set_device(0)
     dev = torch.device("cuda:0")

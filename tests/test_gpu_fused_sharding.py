@@ -21,3 +21,34 @@ def test_fused_sharded_spmv_multiprocess(gpu, world, dt, stripes):
            os.path.join(ROOT, "tests", "mp_fused_worker.py"), dt]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert r.returncode == 0 and "FUSED_OK" in r.stdout, (r.stdout[-3000:], r.stderr[-3000:])
+
+
+def test_fused_sharded_spmv_nccl_control_plane(gpu):
+    """Same worker with RCCL as the control plane (what bench.py uses on a multi-GPU node); one process,
+    because RCCL refuses two ranks on one device: agreement all-reduces on device tensors,
+    all_gather_object and barriers under the nccl backend."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", FUSED_BACKEND="nccl",
+               FUSED_STRIPES="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr",
+           "127.0.0.1", "--master-port", "29671", os.path.join(ROOT, "tests", "mp_fused_worker.py"), "f32"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0 and "FUSED_OK" in r.stdout, (r.stdout[-3000:], r.stderr[-3000:])
+
+
+@pytest.mark.parametrize("fused", ["auto", "off"])
+def test_bench_multi_gpu_code_path_with_one_rank(gpu, fused):
+    """bench.py's N > 1 branch (process group, sharded operators, try_fused selection, timed loop, JSON) run
+    with a single rank under the nccl backend -- the closest this one-GPU box gets to the driver's
+    `torch.distributed.run --nproc-per-node N bench.py --gpus N`."""
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr",
+           "127.0.0.1", "--master-port", "29677" if fused == "auto" else "29678", os.path.join(ROOT, "bench.py"),
+           "--gpus", "1", "--debug-multi", "--fused", fused, "--rows", "2000000", "--steps", "5", "--warmup", "2",
+           "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.stdout[-2000:], r.stderr[-2000:])
+    out = json.loads(lines[0])
+    assert out["value"] > 0 and out["steps"] == 5
+    assert ("fused into the reduce kernels" in out["config"]["parallelism"]) == (fused == "auto")
