@@ -22,10 +22,16 @@
 #include "common.hpp"
 #include "scan.hpp"
 
+#include <cstdlib>
 #include <new>
 #include <vector>
 
-#define TRSV_NARROW 2048       // levels with fewer rows are walked by the single-workgroup kernels
+static int env_int(const char* name, int def) {  // tuning / test hook
+  const char* v = std::getenv(name);
+  return v && *v ? std::atoi(v) : def;
+}
+
+#define TRSV_NARROW 2048       // inspect: frontiers with fewer rows are advanced by the single-workgroup kernel
 #define TRSV_BLOCK_THREADS 1024
 
 struct spblas_gfx950_trsv_s {
@@ -380,16 +386,18 @@ int spblas_gfx950_sptrsv_create(spblas_gfx950_handle_t handle, spblas_gfx950_trs
     return fail(hip_fail(e));
   pl->level_ptr = level_ptr;
   level_ptr = nullptr;
-  // launch groups
+  // launch groups of the solve: a level of >= `narrow` rows gets its own chip-wide launch, runs of
+  // narrower levels share one single-workgroup launch
+  const int narrow = env_int("SPBLAS_GFX950_TRSV_NARROW", 128);
   for (int32_t l = 0; l < n_levels;) {
     const int64_t w = lp[l + 1] - lp[l];
     pl->max_width = w > pl->max_width ? w : pl->max_width;
-    if (w >= TRSV_NARROW) {
+    if (w >= narrow) {
       pl->groups.push_back({l, l + 1, 1});
       ++l;
     } else {
       int32_t e1 = l + 1;
-      while (e1 < n_levels && lp[e1 + 1] - lp[e1] < TRSV_NARROW) {
+      while (e1 < n_levels && lp[e1 + 1] - lp[e1] < narrow) {
         const int64_t w2 = lp[e1 + 1] - lp[e1];
         pl->max_width = w2 > pl->max_width ? w2 : pl->max_width;
         ++e1;
