@@ -648,16 +648,17 @@ static int spgemm_symbolic_impl(spblas_gfx950_handle_t handle, spblas_gfx950_spg
   }
   if ((rc = dev_alloc((void**) &st->perm, (size_t) m * 4, s)))
     return rc;
-  int32_t* bin_of_row = nullptr;
-  unsigned long long* d_cnt = nullptr;
-  long long* partials = nullptr;
+  // temporaries of this call live in the handle's grow-only scratch: no allocation on repeated calls
+  // (on the null stream every dev_alloc / dev_free is a synchronous hipMalloc / hipFree)
   const int64_t nb = cdiv(m, 2048);
-  if ((rc = dev_alloc((void**) &bin_of_row, (size_t) m * 4, s)))
+  const size_t bin_bytes = (((size_t) m * 4) + 255) & ~(size_t) 255;
+  const size_t cnt_bytes = 256;  // 2 * SPG_NBINS counters
+  void* scratch = nullptr;
+  if ((rc = handle_scratch(handle, bin_bytes + cnt_bytes + (size_t) (nb + 1) * sizeof(long long) + 256, &scratch)))
     return rc;
-  if ((rc = dev_alloc((void**) &d_cnt, 2 * SPG_NBINS * sizeof(unsigned long long), s)))
-    return rc;
-  if ((rc = dev_alloc((void**) &partials, (size_t) (nb + 1) * sizeof(long long), s)))
-    return rc;
+  int32_t* bin_of_row = static_cast<int32_t*>(scratch);
+  unsigned long long* d_cnt = reinterpret_cast<unsigned long long*>(static_cast<char*>(scratch) + bin_bytes);
+  long long* partials = reinterpret_cast<long long*>(static_cast<char*>(scratch) + bin_bytes + cnt_bytes);
   SPB_HIP(hipMemsetAsync(d_cnt, 0, 2 * SPG_NBINS * sizeof(unsigned long long), s));
   hipLaunchKernelGGL(spg_bound_kernel, dim3((unsigned) cdiv(m, 32)), dim3(256), 0, s, m, a_rowptr, a_colind,
                      b_rowptr, st->d_rowptr, bin_of_row, d_cnt);
@@ -705,9 +706,6 @@ static int spgemm_symbolic_impl(spblas_gfx950_handle_t handle, spblas_gfx950_spg
       }
     }
   }
-  dev_free(bin_of_row, s);
-  dev_free(d_cnt, s);
-  dev_free(partials, s);
   return rc;
 }
 
