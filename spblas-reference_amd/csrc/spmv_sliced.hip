@@ -528,7 +528,11 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
   const int64_t m = pl->m, n = pl->n, nnz = pl->nnz;
   if (nnz > INT32_MAX - 8)
     return SPBLAS_GFX950_STATUS_NOT_SUPPORTED;
-  int max_cols = PB_LDS_BYTES / (int) sizeof(T);
+  // x slice of the expand: 80 KiB for fp32 (two workgroups per CU); for fp64 the whole 160 KiB of a CU
+  // (one workgroup), which halves the number of slices and doubles the run length again
+  // (10M^2, 10/row: 755 -> 651 us; for fp32 the wider slice changed nothing)
+  const int xlds = env_int("SPBLAS_GFX950_PB_XLDS_KB", sizeof(T) == 8 ? 160 : PB_LDS_BYTES / 1024) * 1024;
+  int max_cols = xlds / (int) sizeof(T);
   if (max_cols > 65536)
     max_cols = 65536;  // 16-bit local column
   // reduce shape: RW wave-bins per workgroup share the 80 KiB.  Fewer, taller bins make longer runs
@@ -650,7 +654,7 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
   dev_free(partials, s);
   // both kernels may use up to 80 KiB of dynamic LDS
   SPB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pb_expand_kernel<T>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, PB_LDS_BYTES));
+                              hipFuncAttributeMaxDynamicSharedMemorySize, xlds > PB_LDS_BYTES ? xlds : PB_LDS_BYTES));
   {
     const void* fn = pb_reduce_fn<T>(pl->rwaves, pl->rchunks, pl->rgroup);
     SPB_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, PB_LDS_BYTES));
