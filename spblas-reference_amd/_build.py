@@ -81,6 +81,32 @@ def build_cpp_tests(force=False):
     return CPP_TEST_BIN
 
 
+EXAMPLES = ["device_spmv", "device_spgemm", "device_sptrsv"]
+
+
+def build_examples(force=False):
+    """The example programs under examples/ (C++20 over the standalone API mirror), compiled by g++."""
+    exdir = os.path.join(_ROOT, "examples")
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    hdrs = [os.path.join(exdir, "common.hpp"), os.path.join(_ROOT, "include", "spblas_gfx950", "spblas.hpp"),
+            os.path.join(_ROOT, "include", "spblas", "vendor", "gfx950", "detail", "backend_calls.hpp"), LIBPATH]
+    out = []
+    for name in EXAMPLES:
+        src, binp = os.path.join(exdir, name + ".cpp"), os.path.join(exdir, name)
+        out.append(binp)
+        if not force and os.path.exists(binp) and os.path.getmtime(binp) >= max(map(os.path.getmtime, hdrs + [src])):
+            continue
+        cmd = ["g++", "-std=c++20", "-O1", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(_ROOT, "include"),
+               "-I", os.path.join(rocm, "include"), src, "-L", LIBDIR, "-lspblas_gfx950", "-L",
+               os.path.join(rocm, "lib"), "-lamdhip64", "-Wl,-rpath,$ORIGIN/../spblas-reference_amd/lib",
+               "-Wl,-rpath," + os.path.join(rocm, "lib"), "-o", binp]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"g++ failed on {name}.cpp:\n{r.stderr}")
+    return out
+
+
 if __name__ == "__main__":
     print(build(force=True, verbose=True))
     print(build_cpp_tests(force=True))
+    print(build_examples(force=True))

@@ -19,3 +19,15 @@ def test_cpp_device_tests(gpu):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]
     assert "PASSED" in r.stdout
+
+
+@pytest.mark.parametrize("name", _build.EXAMPLES)
+def test_cpp_examples(gpu, name):
+    """examples/*.cpp: the programs a user of the reference would write (views over device arrays, inspect,
+    multiply / multiply_compute + multiply_fill / add / triangular_solve), each checking itself on the host."""
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", name)
+    if not os.path.exists(exe):
+        _build.build_examples()
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert name in r.stdout
