@@ -493,9 +493,6 @@ static const void* pb_reduce_fn(int rw, int c, int gr) {
 
 // ---- host -------------------------------------------------------------------------------
 static int pick_ksplit(int64_t groups, int S);
-static int pick_ksplit_fwd(int64_t groups, int S) {
-  return pick_ksplit(groups, S);
-}
 
 // number of pieces: enough that one piece fits the LDS budget; for big problems a multiple
 // of 512 (2 workgroups x 256 CUs) so the single wave of workgroups fills the chip evenly.
@@ -583,7 +580,7 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
   pl->slice_cols = W;
   pl->n_rblk = NB;
   pl->rows_per_blk = H;
-  pl->n_ksplit = pick_ksplit_fwd(cdiv(NB, RW), S);
+  pl->n_ksplit = pick_ksplit(cdiv(NB, RW), S);
   {
     const int64_t avg_run = nnz / (nseg > 0 ? nseg : 1);
     int C = env_int("SPBLAS_GFX950_PB_RCHUNKS", 0);
