@@ -327,6 +327,10 @@ __global__ __launch_bounds__(256) void spg_hash_kernel(
     // atomics are fast), then rank each key inside its bucket only.  Uniform columns give buckets
     // of d/NBK keys; the worst case (one bucket) degrades to the plain O(d^2) rank sort.
     constexpr int NBK = TPR < 64 ? TPR : 64;
+    // bucket of a key = floor(key * NBK / ncols), as a 32x32 -> high-32 multiply (a 64-bit division per
+    // key and pass costs more than the rest of the sort): monotone in the key, < NBK for key < ncols
+    const unsigned long long bm = ((unsigned long long) NBK << 32) / (unsigned long long) ncols;
+    const unsigned bucket_mul = bm > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned) bm;
     int* bcnt = sortws + team * (2 * NBK + 2);  // [NBK+1] counts -> offsets
     int* bfill = bcnt + NBK + 1;                // [NBK] cursors
     spg_team_sync<TPR>();
@@ -337,7 +341,7 @@ __global__ __launch_bounds__(256) void spg_hash_kernel(
     spg_team_sync<TPR>();
     if (live)
       for (int e = lt; e < d; e += TPR)
-        atomicAdd(&bcnt[(int) (((long long) ckeys[e] * NBK) / ncols)], 1);
+        atomicAdd(&bcnt[(int) __umulhi((unsigned) ckeys[e], bucket_mul)], 1);
     spg_team_sync<TPR>();
     if (live && lt < NBK) {  // exclusive scan over the buckets inside the first NBK lanes of the team
       const int c = bcnt[lt];
@@ -357,7 +361,7 @@ __global__ __launch_bounds__(256) void spg_hash_kernel(
     if (live)
       for (int e = lt; e < d; e += TPR) {
         const int key = ckeys[e];
-        const int bk = (int) (((long long) key * NBK) / ncols);
+        const int bk = (int) __umulhi((unsigned) key, bucket_mul);
         const int pos = bcnt[bk] + atomicAdd(&bfill[bk], 1);
         skeys[pos] = key;
         svals[pos] = cvals[e];
@@ -367,7 +371,7 @@ __global__ __launch_bounds__(256) void spg_hash_kernel(
       const int out0 = c_rowptr[row];
       for (int e = lt; e < d; e += TPR) {
         const int key = skeys[e];
-        const int bk = (int) (((long long) key * NBK) / ncols);
+        const int bk = (int) __umulhi((unsigned) key, bucket_mul);
         const int b0 = bcnt[bk], b1 = bcnt[bk + 1];
         int rank = b0;
         for (int j = b0; j < b1; ++j)
