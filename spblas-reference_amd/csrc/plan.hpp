@@ -27,6 +27,7 @@ struct spblas_gfx950_plan_s {
   // statistics
   int64_t max_row_len = 0;
   int64_t empty_rows = 0;
+  int64_t long_nnz = 0;  // entries stored in rows longer than the window
 
   // SLICED: column-sliced re-tiling of A (see spmv_sliced.hip)
   int n_slices = 0;      // S column slices of slice_cols columns
@@ -44,6 +45,12 @@ struct spblas_gfx950_plan_s {
   int rwaves = 8;              // reduce: wave-bins (= wavefronts) per workgroup
   int rchunks = 1;             // reduce: 64-entry chunks of a run prefetched into registers
   int rgroup = 1;              // reduce: runs whose LDS reads are issued together (duplicate-flag group)
+  int hub_len = 0;             // > 0: rows longer than this are NOT in the tiles (pb_hub_rows_kernel does them)
+  int64_t s_placed = 0;        // entries in the tiles (nnz minus the hub rows' entries)
+  const void* values_ptr = nullptr;  // caller's values array (inspect / last update_values): read by the hub rows
+  const void* last_x = nullptr;      // x of the last expand
+  void* s_hub_part = nullptr;        // T[n_long * hub_parts] partial sums of the hub rows
+  int hub_parts = 1;                 // workgroups per hub row
   void* s_partial = nullptr;   // T[s_partial_k][m] partial sums (grown on demand)
   int s_partial_k = 0;
   int bin_aligned = 0;         // wave-bin height divides the handle's bin_row_align option

@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256) void plan_window_rows_kernel(int64_t m, int64_
   win_row[w] = (int32_t) lo;
 }
 
-// stats[0] = max row length, stats[1] = #long rows, stats[2] = #empty rows.
+// stats[0] = max row length, stats[1] = #long rows, stats[2] = #empty rows, stats[3] = entries in long rows.
 // Long rows are appended to long_rows (capacity nnz/win + 1 always suffices).
 template <typename O>
 __global__ __launch_bounds__(256) void plan_row_stats_kernel(int64_t m, int win,
@@ -286,6 +286,7 @@ __global__ __launch_bounds__(256) void plan_row_stats_kernel(int64_t m, int win,
     if (len > (unsigned long long) win) {
       unsigned long long slot = atomicAdd(&stats[1], 1ull);
       long_rows[slot] = (int32_t) r;
+      atomicAdd(&stats[3], len);
     }
   }
   for (int o = 32; o > 0; o >>= 1) {
@@ -445,13 +446,13 @@ static int plan_build(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, int al
   int rc;
   unsigned long long* d_stats = nullptr;
   const int64_t long_cap = nnz / pl->win + 1;
-  if ((rc = dev_alloc((void**) &d_stats, 3 * sizeof(unsigned long long), s)))
+  if ((rc = dev_alloc((void**) &d_stats, 4 * sizeof(unsigned long long), s)))
     return rc;
   if ((rc = dev_alloc((void**) &pl->long_rows, (size_t) long_cap * 4, s)))
     return rc;
   if ((rc = dev_alloc((void**) &pl->win_row, (size_t) (pl->nwin + 1) * 4, s)))
     return rc;
-  SPB_HIP(hipMemsetAsync(d_stats, 0, 3 * sizeof(unsigned long long), s));
+  SPB_HIP(hipMemsetAsync(d_stats, 0, 4 * sizeof(unsigned long long), s));
   if (m > 0) {
     hipLaunchKernelGGL((plan_row_stats_kernel<O>), dim3((unsigned) (cdiv(m, 256) < 2048 ? cdiv(m, 256) : 2048)), dim3(256), 0, s, m,
                        pl->win, rowptr, d_stats, pl->long_rows);
@@ -459,13 +460,14 @@ static int plan_build(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, int al
   hipLaunchKernelGGL((plan_window_rows_kernel<O>), dim3((unsigned) cdiv(pl->nwin + 1, 256)), dim3(256), 0,
                      s, m, pl->nwin, pl->win, rowptr, pl->win_row);
   SPB_HIP(hipGetLastError());
-  unsigned long long stats[3];
+  unsigned long long stats[4];
   SPB_HIP(hipMemcpyAsync(stats, d_stats, sizeof(stats), hipMemcpyDeviceToHost, s));
   SPB_HIP(hipStreamSynchronize(s));
   dev_free(d_stats, s);
   pl->max_row_len = (int64_t) stats[0];
   pl->n_long = (int64_t) stats[1];
   pl->empty_rows = (int64_t) stats[2];
+  pl->long_nnz = (int64_t) stats[3];
   pl->device_bytes = (size_t) long_cap * 4 + (size_t) (pl->nwin + 1) * 4;
   if (pl->n_long > 0) {
     if ((rc = dev_alloc(&pl->part_head, (size_t) pl->nwin * tsz, s)))
@@ -494,7 +496,10 @@ static bool sliced_candidate(const spblas_gfx950_plan_s* pl) {
   const double tile = 80.0 * 1024 / tsz;
   const double nseg = (pl->n / tile + 1) * (pl->m / tile + 1);
   return (size_t) pl->n * tsz >= ((size_t) 3 << 20) && pl->nnz >= ((int64_t) 2 << 20) &&
-         pl->nnz < INT32_MAX - 8 && pl->max_row_len <= 4096 && (double) pl->nnz / nseg >= 48.0;
+         pl->nnz < INT32_MAX - 8 && (double) pl->nnz / nseg >= 48.0 &&
+         // rows longer than the window are kept out of the tiles and handled by pb_hub_rows_kernel; a few
+         // dense rows are fine, a matrix living in its hub rows (power law) is not
+         (pl->max_row_len <= 4096 || (pl->n_long <= 65536 && pl->long_nnz * 4 <= pl->nnz));
 }
 
 } // namespace spb

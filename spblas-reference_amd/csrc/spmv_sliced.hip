@@ -53,10 +53,25 @@ static constexpr int PB_LDS_BYTES = 80 * 1024;  // two workgroups per CU (160 Ki
 // One workgroup per wave-bin: all entries of the bin's rows share wb, so the per-slice counts
 // live in an LDS histogram and are written out without any global atomic (the first version
 // issued one global atomic per entry: 3.7 ms + 6.7 ms at cfg2).
+// last row r in [lo, hi) with rowptr[r] <= p
+template <typename O>
+__device__ __forceinline__ int64_t pb_row_of(const O* __restrict__ rowptr, int64_t lo, int64_t hi, O p) {
+  while (hi - lo > 1) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (rowptr[mid] <= p)
+      lo = mid;
+    else
+      hi = mid;
+  }
+  return lo;
+}
+
+// hub_len > 0: entries of rows longer than hub_len are left out of the tiles (a run that repeats one
+// row hundreds of times would serialise on the LDS atomic); pb_hub_rows_kernel adds those rows.
 template <typename O>
 __global__ __launch_bounds__(256) void pb_count_kernel(int64_t m, const O* __restrict__ rowptr,
                                                        const int32_t* __restrict__ colind, int W, int H, int S, int NB,
-                                                       int32_t* __restrict__ cnt) {
+                                                       int32_t* __restrict__ cnt, int hub_len) {
   extern __shared__ int hist[];  // [S]
   const int wb = blockIdx.x;
   for (int i = threadIdx.x; i < S; i += 256)
@@ -65,8 +80,14 @@ __global__ __launch_bounds__(256) void pb_count_kernel(int64_t m, const O* __res
   const int64_t r0 = (int64_t) wb * H, r1 = (r0 + H) < m ? (r0 + H) : m;
   if (r0 < m) {
     const O p0 = rowptr[r0], p1 = rowptr[r1];
-    for (O p = p0 + threadIdx.x; p < p1; p += 256)
+    for (O p = p0 + threadIdx.x; p < p1; p += 256) {
+      if (hub_len > 0) {
+        const int64_t r = pb_row_of(rowptr, r0, r1, p);
+        if (rowptr[r + 1] - rowptr[r] > (O) hub_len)
+          continue;
+      }
       atomicAdd(&hist[colind[p] / W], 1);
+    }
   }
   __syncthreads();
   for (int i = threadIdx.x; i < S; i += 256)
@@ -81,7 +102,7 @@ __global__ __launch_bounds__(256) void pb_scatter_kernel(int64_t m, const O* __r
                                                          const T* __restrict__ values, int W, int H, int S, int NB,
                                                          const int32_t* __restrict__ seg, T* __restrict__ s_val,
                                                          uint16_t* __restrict__ s_col, uint16_t* __restrict__ s_row,
-                                                         int32_t* __restrict__ perm) {
+                                                         int32_t* __restrict__ perm, int hub_len) {
   extern __shared__ int cursor[];  // [S]
   const int wb = blockIdx.x;
   for (int i = threadIdx.x; i < S; i += 256)
@@ -92,14 +113,9 @@ __global__ __launch_bounds__(256) void pb_scatter_kernel(int64_t m, const O* __r
     return;
   const O p0 = rowptr[r0], p1 = rowptr[r1];
   for (O p = p0 + threadIdx.x; p < p1; p += 256) {
-    int64_t lo = r0, hi = r1;  // last row with rowptr[row] <= p
-    while (hi - lo > 1) {
-      const int64_t mid = (lo + hi) >> 1;
-      if (rowptr[mid] <= p)
-        lo = mid;
-      else
-        hi = mid;
-    }
+    const int64_t lo = pb_row_of(rowptr, r0, r1, p);
+    if (hub_len > 0 && rowptr[lo + 1] - rowptr[lo] > (O) hub_len)
+      continue;
     const int c = colind[p];
     const int sl = c / W;
     const int i = atomicAdd(&cursor[sl], 1);
@@ -480,6 +496,53 @@ __global__ __launch_bounds__(256) void pb_combine_kernel(int64_t r_lo, int64_t r
   y[i] = beta == T(0) ? alpha * s : alpha * s + beta * y[i];
 }
 
+// Rows that were kept out of the tiles (longer than plan->hub_len).  gridDim.y workgroups share a row
+// (a 1M-entry row on one workgroup would take milliseconds): each writes the sum of its part to
+// part[i * gridDim.y + k]; pb_hub_finish_kernel adds the parts in order (deterministic) and does
+// y[row] += alpha * sum -- the reduce kernel has already written beta*y (+ nothing) there.  Only rows
+// inside [row_begin, row_end) are touched (two-stage callers reduce row ranges).
+template <typename T, typename O>
+__global__ __launch_bounds__(256) void pb_hub_rows_kernel(int64_t n_hub, const int32_t* __restrict__ hub_rows,
+                                                          const O* __restrict__ rowptr,
+                                                          const int32_t* __restrict__ colind,
+                                                          const T* __restrict__ values, const T* __restrict__ x,
+                                                          T* __restrict__ part, int64_t row_begin, int64_t row_end) {
+  __shared__ T red[4];
+  const int64_t i = blockIdx.x;
+  const int64_t r = hub_rows[i];
+  if (r < row_begin || r >= row_end)
+    return;
+  const O p0 = rowptr[r], p1 = rowptr[r + 1];
+  const O per = ((p1 - p0) + (O) gridDim.y - 1) / (O) gridDim.y;
+  const O lo = p0 + (O) blockIdx.y * per, hi = (lo + per) < p1 ? (lo + per) : p1;
+  T s = T(0);
+  for (O p = lo + threadIdx.x; p < hi; p += 256)
+    s += stream_load(values + p) * x[stream_load(colind + p)];
+  s = group_sum_c<64>(s);
+  if ((threadIdx.x & 63) == 0)
+    red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    part[i * gridDim.y + blockIdx.y] = red[0] + red[1] + red[2] + red[3];
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void pb_hub_finish_kernel(int64_t n_hub, int parts,
+                                                            const int32_t* __restrict__ hub_rows,
+                                                            const T* __restrict__ part, T* __restrict__ y, T alpha,
+                                                            int64_t row_begin, int64_t row_end) {
+  const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_hub)
+    return;
+  const int64_t r = hub_rows[i];
+  if (r < row_begin || r >= row_end)
+    return;
+  T s = T(0);
+  for (int k = 0; k < parts; ++k)
+    s += part[i * parts + k];
+  y[r] += alpha * s;
+}
+
 template <typename T>
 static const void* pb_reduce_fn(int rw, int c, int gr) {
 #define SPB_RK(RW_, C_, G_) reinterpret_cast<const void*>(pb_reduce_kernel<T, RW_, C_, G_>)
@@ -601,8 +664,19 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
   pl->seg_ptr = seg;
   SPB_HIP(hipMemsetAsync(seg, 0, (size_t) (nseg + 1) * 4, s));
   const O* rowptr = static_cast<const O*>(pl->rowptr);
+  // rows longer than the nnz window (the plan's long_rows list) stay out of the tiles
+  pl->hub_len = pl->n_long > 0 ? pl->win : 0;
+  pl->values_ptr = values_p;
+  if (pl->hub_len > 0) {
+    // workgroups per hub row: ~16K entries each, at most 64
+    int64_t parts = cdiv(pl->max_row_len, 16384);
+    pl->hub_parts = (int) (parts < 1 ? 1 : (parts > 64 ? 64 : parts));
+    int rc_h = dev_alloc(&pl->s_hub_part, (size_t) pl->n_long * pl->hub_parts * sizeof(T), s);
+    if (rc_h)
+      return rc_h;
+  }
   hipLaunchKernelGGL((pb_count_kernel<O>), dim3((unsigned) NB), dim3(256), (size_t) S * 4, s, m, rowptr, pl->colind, W, H, S,
-                     NB, seg);
+                     NB, seg, pl->hub_len);
   if (auto_mode) {
     // AUTO only: a matrix whose entries cluster in few (slice, bin) tiles (banded, block
     // structured) already gets its x reuse from L2 with the CSR kernels -- decline.
@@ -635,10 +709,17 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
   if ((rc = dev_alloc((void**) &pl->s_segT, (size_t) nseg * sizeof(int2), s)))
     return rc;
   pl->device_bytes += (size_t) nnz * (2 * sizeof(T) + 8) + (size_t) nseg * 16;
-  scan_counts_i32(s, nseg, seg, partials);
+  {
+    long long* total_dev = scan_counts_i32(s, nseg, seg, partials);
+    long long placed = 0;
+    SPB_HIP(hipMemcpyAsync(&placed, total_dev, sizeof(placed), hipMemcpyDeviceToHost, s));
+    SPB_HIP(hipStreamSynchronize(s));
+    pl->s_placed = placed;
+  }
   hipLaunchKernelGGL((pb_scatter_kernel<T, O>), dim3((unsigned) NB), dim3(256), (size_t) S * 4, s, m, rowptr,
                      pl->colind, static_cast<const T*>(values_p), W, H, S, NB, seg, static_cast<T*>(pl->s_values),
-                     reinterpret_cast<uint16_t*>(pl->s_colind), pl->s_lrow, reinterpret_cast<int32_t*>(pl->s_perm));
+                     reinterpret_cast<uint16_t*>(pl->s_colind), pl->s_lrow, reinterpret_cast<int32_t*>(pl->s_perm),
+                     pl->hub_len);
   hipLaunchKernelGGL(pb_transpose_seg_kernel, dim3((unsigned) cdiv(nseg, 256)), dim3(256), 0, s, S, NB, seg,
                      static_cast<int2*>(pl->s_segT));
   SPB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pb_flag_dups_kernel),
@@ -670,10 +751,11 @@ int spmv_sliced_build(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const 
 
 template <typename T>
 static int sliced_update_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const void* values) {
-  if (pl->nnz == 0)
+  pl->values_ptr = values;  // the hub rows read the caller's array directly
+  if (pl->s_placed == 0)
     return SPBLAS_GFX950_STATUS_SUCCESS;
-  hipLaunchKernelGGL((pb_update_values_kernel<T>), dim3((unsigned) cdiv(pl->nnz, 256)), dim3(256), 0, h->stream,
-                     pl->nnz, reinterpret_cast<const int32_t*>(pl->s_perm), static_cast<const T*>(values),
+  hipLaunchKernelGGL((pb_update_values_kernel<T>), dim3((unsigned) cdiv(pl->s_placed, 256)), dim3(256), 0, h->stream,
+                     pl->s_placed, reinterpret_cast<const int32_t*>(pl->s_perm), static_cast<const T*>(values),
                      static_cast<T*>(pl->s_values));
   SPB_HIP(hipGetLastError());
   return SPBLAS_GFX950_STATUS_SUCCESS;
@@ -696,6 +778,7 @@ static int pick_ksplit(int64_t groups, int S) {
 
 template <typename T>
 static int sliced_expand_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const void* x) {
+  pl->last_x = x;  // the hub rows are computed in the reduce stage and gather x themselves
   const int32_t* seg = reinterpret_cast<const int32_t*>(pl->seg_ptr);
   // enough workgroups for 2 per CU, but never so many parts that re-loading the x slice dominates
   int parts = (int) cdiv(2 * (h->num_cus > 0 ? h->num_cus : 256), pl->n_slices);
@@ -756,6 +839,27 @@ static int sliced_reduce_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* p
     hipLaunchKernelGGL((pb_combine_kernel<T>), dim3((unsigned) cdiv(r_hi - r_lo, 256)), dim3(256), 0, s, r_lo, r_hi, K,
                        static_cast<const T*>(pl->s_partial), pl->m, static_cast<T*>(y), alpha, beta,
                        reinterpret_cast<T* const*>(peers_p), n_peers, peer_off);
+  if (pl->hub_len > 0 && pl->n_long > 0) {
+    // rows kept out of the tiles: y[row] += alpha * (row . x), for the rows of this bin range
+    if (peers_p)
+      return SPBLAS_GFX950_STATUS_NOT_SUPPORTED;  // the fused all-gather epilogue does not cover hub rows
+    if (!pl->values_ptr || !pl->last_x)
+      return SPBLAS_GFX950_STATUS_INVALID_VALUE;
+    if (!pl->s_hub_part)
+      return SPBLAS_GFX950_STATUS_INVALID_VALUE;
+    const dim3 grid((unsigned) pl->n_long, (unsigned) pl->hub_parts);
+    T* part = static_cast<T*>(pl->s_hub_part);
+    if (pl->offset_type == SPBLAS_GFX950_I32)
+      hipLaunchKernelGGL((pb_hub_rows_kernel<T, int32_t>), grid, dim3(256), 0, s, pl->n_long, pl->long_rows,
+                         static_cast<const int32_t*>(pl->rowptr), pl->colind, static_cast<const T*>(pl->values_ptr),
+                         static_cast<const T*>(pl->last_x), part, r_lo, r_hi);
+    else
+      hipLaunchKernelGGL((pb_hub_rows_kernel<T, int64_t>), grid, dim3(256), 0, s, pl->n_long, pl->long_rows,
+                         static_cast<const int64_t*>(pl->rowptr), pl->colind, static_cast<const T*>(pl->values_ptr),
+                         static_cast<const T*>(pl->last_x), part, r_lo, r_hi);
+    hipLaunchKernelGGL((pb_hub_finish_kernel<T>), dim3((unsigned) cdiv(pl->n_long, 256)), dim3(256), 0, s, pl->n_long,
+                       pl->hub_parts, pl->long_rows, part, static_cast<T*>(y), alpha, r_lo, r_hi);
+  }
   SPB_HIP(hipGetLastError());
   return SPBLAS_GFX950_STATUS_SUCCESS;
 }
@@ -819,7 +923,9 @@ void spmv_sliced_free(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl) {
   dev_free(pl->s_products, s);
   dev_free(pl->s_segT, s);
   dev_free(pl->s_partial, s);
+  dev_free(pl->s_hub_part, s);
   pl->s_partial = nullptr;
+  pl->s_hub_part = nullptr;
   pl->s_partial_k = 0;
   pl->seg_ptr = pl->s_colind = pl->s_values = pl->s_products = pl->s_segT = pl->s_perm = nullptr;
   pl->s_lrow = nullptr;

@@ -327,3 +327,43 @@ def test_spmv_two_stage_and_overlapped_sharding_single_rank(gpu):
     info_rb = sp.multiply_inspect(a, x, y2, alg=_capi.SPMV_ROWBLOCK)
     with pytest.raises(sp.BackendError):
         info_rb.state_.bind_stages(x, y2.data_ptr(), torch.float32)[0]()
+
+
+def test_spmv_sliced_with_a_few_dense_rows(gpu):
+    """A uniform matrix with a handful of very long rows: AUTO must still pick the LDS-sliced plan -- the
+    long rows stay out of the tiles and are added by pb_hub_rows_kernel -- and the two-stage entry points
+    must cover them as well."""
+    rng = np.random.default_rng(21)
+    m, n = 300000, 1500000
+    lens = np.full(m, 8, np.int64)
+    hubs = [5, 149999, m - 1]
+    for r, ln in zip(hubs, (120000, 30000, 5000)):
+        lens[r] = ln
+    rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    nnz = int(rowptr[-1])
+    colind = rng.integers(0, n, nnz).astype(np.int32)
+    values = (rng.random(nnz) + 0.5).astype(np.float32)
+    x = (rng.random(n) + 0.5).astype(np.float32)
+    a = G.csr_on_device(values, rowptr, colind, (m, n), nnz)
+    xd = G.dev(x)
+    y = torch.full((m,), float("nan"), device="cuda")
+    info = sp.multiply_inspect(a, xd, y)                       # AUTO
+    pi = info.state_.info()
+    assert pi["alg"] == _capi.SPMV_SLICED and pi["n_long_rows"] == 3
+    sp.multiply(info, sp.scaled(-1.5, a), xd, y)
+    check(values, rowptr, colind, (m, n), x, G.host(y), scale=-1.5, what="sliced + hub rows", ref_cmp=False)
+    # beta != 0 through the C ABI path of prepared_multiply is covered elsewhere; here: two-stage execution
+    y2 = torch.full((m,), float("nan"), device="cuda")
+    expand, reduce_rows = info.state_.bind_stages(xd, y2.data_ptr(), torch.float32, alpha=-1.5)
+    expand()
+    H = pi["rows_per_bin"]
+    cut = (m // 2 // H) * H
+    reduce_rows(cut, m)
+    reduce_rows(0, cut)
+    assert torch.equal(y, y2)
+    # values change in place: update_values refreshes the tiles, the hub rows read the caller's array
+    a.values().mul_(2.0)
+    info.state_.update_values(a.values())
+    sp.multiply(info, a, xd, y)
+    check(values * np.float32(2.0), rowptr, colind, (m, n), x, G.host(y), what="sliced + hub rows after update",
+          ref_cmp=False)
