@@ -801,6 +801,8 @@ static int sliced_reduce_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* p
   hipStream_t s = h->stream;
   if (wb_end <= wb_begin)
     return SPBLAS_GFX950_STATUS_SUCCESS;
+  if (peers_p && pl->hub_len > 0 && pl->n_long > 0)
+    return SPBLAS_GFX950_STATUS_NOT_SUPPORTED;  // the fused all-gather epilogue does not cover hub rows
   const T alpha = *static_cast<const T*>(alpha_p), beta = *static_cast<const T*>(beta_p);
   const int RW = pl->rwaves;
   const int64_t groups = cdiv(wb_end - wb_begin, RW);
@@ -841,8 +843,6 @@ static int sliced_reduce_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* p
                        reinterpret_cast<T* const*>(peers_p), n_peers, peer_off);
   if (pl->hub_len > 0 && pl->n_long > 0) {
     // rows kept out of the tiles: y[row] += alpha * (row . x), for the rows of this bin range
-    if (peers_p)
-      return SPBLAS_GFX950_STATUS_NOT_SUPPORTED;  // the fused all-gather epilogue does not cover hub rows
     if (!pl->values_ptr || !pl->last_x)
       return SPBLAS_GFX950_STATUS_INVALID_VALUE;
     if (!pl->s_hub_part)
