@@ -30,6 +30,8 @@
 // applied afterwards with the (slow, rare: ~1 % of entries) LDS atomic.
 // The order of additions into a row is fixed by the plan, so results are run-to-run
 // reproducible for a given plan (plans built twice may order entries differently).
+#include <vector>
+
 #include "common.hpp"
 #include "plan.hpp"
 #include "scan.hpp"
@@ -134,6 +136,28 @@ __global__ __launch_bounds__(256) void pb_nonempty_kernel(int64_t nseg, const in
   const unsigned long long c = __popcll(__ballot(ne));
   if ((threadIdx.x & 63) == 0 && c)
     atomicAdd(out, c);
+}
+
+// balance probe: entries per slice and per bin group (RW bins = one reduce workgroup).  One workgroup per
+// slice walks that slice's NB counters.
+__global__ __launch_bounds__(256) void pb_balance_kernel(int NB, int RW, const int32_t* __restrict__ cnt,
+                                                         unsigned long long* __restrict__ slice_sum,
+                                                         unsigned long long* __restrict__ group_sum) {
+  __shared__ unsigned long long red[4];
+  const int sl = blockIdx.x;
+  unsigned long long tot = 0;
+  for (int b = threadIdx.x; b < NB; b += 256) {
+    const unsigned long long c = (unsigned long long) cnt[(int64_t) sl * NB + b];
+    tot += c;
+    if (c)
+      atomicAdd(&group_sum[b / RW], c);
+  }
+  tot = group_sum_c<64>(tot);
+  if ((threadIdx.x & 63) == 0)
+    red[threadIdx.x >> 6] = tot;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    slice_sum[sl] = red[0] + red[1] + red[2] + red[3];
 }
 
 // segT[b*S + s] = (start, length) of segment (s, b) in A' order
@@ -691,6 +715,31 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
     dev_free(d_ne, s);
     if ((double) ne < 0.25 * (double) nseg)
       return SPBLAS_GFX950_STATUS_NOT_SUPPORTED;
+    // ... and a matrix whose entries pile up in a few slices (hot columns) or a few bin groups (heavy
+    // rows below the hub threshold) would leave most of the chip waiting for one expand / reduce
+    // workgroup: decline when the heaviest slice or group carries more than 6x the average.
+    {
+      const int64_t ngroups = cdiv(NB, RW);
+      unsigned long long* d_sum = nullptr;
+      if ((rc = dev_alloc((void**) &d_sum, (size_t) (S + ngroups) * sizeof(unsigned long long), s)))
+        return rc;
+      SPB_HIP(hipMemsetAsync(d_sum, 0, (size_t) (S + ngroups) * sizeof(unsigned long long), s));
+      hipLaunchKernelGGL(pb_balance_kernel, dim3((unsigned) S), dim3(256), 0, s, NB, RW, seg, d_sum, d_sum + S);
+      std::vector<unsigned long long> h_sum((size_t) (S + ngroups));
+      SPB_HIP(hipMemcpyAsync(h_sum.data(), d_sum, h_sum.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+      SPB_HIP(hipStreamSynchronize(s));
+      dev_free(d_sum, s);
+      unsigned long long tot = 0, max_slice = 0, max_group = 0;
+      for (int i = 0; i < S; ++i) {
+        tot += h_sum[(size_t) i];
+        max_slice = h_sum[(size_t) i] > max_slice ? h_sum[(size_t) i] : max_slice;
+      }
+      for (int64_t g = 0; g < ngroups; ++g)
+        max_group = h_sum[(size_t) (S + g)] > max_group ? h_sum[(size_t) (S + g)] : max_group;
+      const double mean_slice = (double) tot / (double) S, mean_group = (double) tot / (double) ngroups;
+      if (tot > 0 && ((double) max_slice > 6.0 * mean_slice + 65536.0 || (double) max_group > 6.0 * mean_group + 65536.0))
+        return SPBLAS_GFX950_STATUS_NOT_SUPPORTED;
+    }
   }
   if ((rc = dev_alloc((void**) &partials, (size_t) (cdiv(nseg, 2048) + 2) * sizeof(long long), s)))
     return rc;

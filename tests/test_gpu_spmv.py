@@ -367,3 +367,42 @@ def test_spmv_sliced_with_a_few_dense_rows(gpu):
     sp.multiply(info, a, xd, y)
     check(values * np.float32(2.0), rowptr, colind, (m, n), x, G.host(y), what="sliced + hub rows after update",
           ref_cmp=False)
+
+
+def test_spmv_auto_declines_sliced_for_skewed_matrices(gpu):
+    """Hot columns (one slice carries most entries) or a heavy block of rows (one bin group does): the
+    sliced plan would leave the chip waiting for a single workgroup, so AUTO must keep the row-block
+    kernel; a forced SLICED plan must still be correct."""
+    rng = np.random.default_rng(33)
+    m, n, per = 400000, 2000000, 8
+    rowptr = (np.arange(m + 1, dtype=np.int64) * per).astype(np.int32)
+    nnz = m * per
+    values = (rng.random(nnz) + 0.5).astype(np.float32)
+    x = (rng.random(n) + 0.5).astype(np.float32)
+    hot = rng.random(nnz) < 0.6
+    colind = np.where(hot, rng.integers(0, 3000, nnz), rng.integers(0, n, nnz)).astype(np.int32)
+    for cols, what in ((colind, "hot columns"),):
+        a = G.csr_on_device(values, rowptr, cols, (m, n), nnz)
+        xd = G.dev(x)
+        y = torch.full((m,), float("nan"), device="cuda")
+        info = sp.multiply_inspect(a, xd, y)
+        assert info.state_.info()["alg"] == _capi.SPMV_ROWBLOCK, what
+        sp.multiply(info, a, xd, y)
+        check(values, rowptr, cols, (m, n), x, G.host(y), what=what + " (auto)", ref_cmp=False)
+        info = sp.multiply_inspect(a, xd, y, alg=_capi.SPMV_SLICED)
+        sp.multiply(info, a, xd, y)
+        check(values, rowptr, cols, (m, n), x, G.host(y), what=what + " (forced sliced)", ref_cmp=False)
+    # heavy rows below the hub threshold concentrated in one corner of the matrix
+    lens = np.full(m, 4, np.int64)
+    lens[:3000] = 1500
+    rowptr2 = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    nnz2 = int(rowptr2[-1])
+    col2 = rng.integers(0, n, nnz2).astype(np.int32)
+    val2 = (rng.random(nnz2) + 0.5).astype(np.float32)
+    a = G.csr_on_device(val2, rowptr2, col2, (m, n), nnz2)
+    xd = G.dev(x)
+    y = torch.full((m,), float("nan"), device="cuda")
+    info = sp.multiply_inspect(a, xd, y)
+    assert info.state_.info()["alg"] == _capi.SPMV_ROWBLOCK
+    sp.multiply(info, a, xd, y)
+    check(val2, rowptr2, col2, (m, n), x, G.host(y), what="heavy row block (auto)", ref_cmp=False)
