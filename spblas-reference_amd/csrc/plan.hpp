@@ -51,6 +51,8 @@ struct spblas_gfx950_plan_s {
   const void* last_x = nullptr;      // x of the last expand
   void* s_hub_part = nullptr;        // T[n_long * hub_parts] partial sums of the hub rows
   int hub_parts = 1;                 // workgroups per hub row
+  void* s_xitems = nullptr;          // int4[n_xitems] expand work list (slice, first, last) for column-skewed matrices
+  int64_t n_xitems = 0;
   void* s_partial = nullptr;   // T[s_partial_k][m] partial sums (grown on demand)
   int s_partial_k = 0;
   int bin_aligned = 0;         // wave-bin height divides the handle's bin_row_align option

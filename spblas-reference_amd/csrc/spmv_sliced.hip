@@ -30,6 +30,7 @@
 // applied afterwards with the (slow, rare: ~1 % of entries) LDS atomic.
 // The order of additions into a row is fixed by the plan, so results are run-to-run
 // reproducible for a given plan (plans built twice may order entries differently).
+#include <algorithm>
 #include <vector>
 
 #include "common.hpp"
@@ -217,10 +218,14 @@ template <typename T>
 __global__ __launch_bounds__(PB_THREADS) void pb_expand_kernel(int64_t n, int W, int NB, const int32_t* __restrict__ seg,
                                                                const T* __restrict__ s_val,
                                                                const uint16_t* __restrict__ s_col,
-                                                               const T* __restrict__ x, T* __restrict__ P) {
+                                                               const T* __restrict__ x, T* __restrict__ P,
+                                                               const int4* __restrict__ items) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   T* xs = reinterpret_cast<T*>(smem);
-  const int s = blockIdx.x;
+  // items (column-skewed matrices): workgroup i takes entries [items[i].y, items[i].z) of slice items[i].x,
+  // so that a slice holding a large share of the matrix is spread over proportionally many workgroups
+  const int4 item = items ? items[blockIdx.x] : make_int4((int) blockIdx.x, 0, 0, 0);
+  const int s = item.x;
   const int tid = threadIdx.x;
   const int64_t c0 = (int64_t) s * W;
   const int cw = (int) ((n - c0) < W ? (n - c0) : W);
@@ -230,7 +235,10 @@ __global__ __launch_bounds__(PB_THREADS) void pb_expand_kernel(int64_t n, int W,
   // gridDim.y workgroups share one slice (matrices with few slices would otherwise leave most CUs
   // idle): each takes a contiguous part of the slice's range, cut on multiples of 4 entries
   int a0 = seg[(int64_t) s * NB], a1 = seg[(int64_t) (s + 1) * NB];
-  if (gridDim.y > 1) {
+  if (items) {
+    a0 = item.y;
+    a1 = item.z;
+  } else if (gridDim.y > 1) {
     const int len = a1 - a0;
     const int per = (((len + (int) gridDim.y - 1) / (int) gridDim.y) + 3) & ~3;
     const int lo = a0 + (int) blockIdx.y * per;
@@ -765,6 +773,41 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
     SPB_HIP(hipStreamSynchronize(s));
     pl->s_placed = placed;
   }
+  {
+    // column skew: slice sizes from the segment offsets; when one slice is far above the average the
+    // expand gets an explicit work list with workgroups in proportion to the slice sizes
+    std::vector<int32_t> start((size_t) S + 1);
+    SPB_HIP(hipMemcpy2DAsync(start.data(), 4, seg, (size_t) NB * 4, 4, (size_t) S + 1, hipMemcpyDeviceToHost, s));
+    SPB_HIP(hipStreamSynchronize(s));
+    int64_t max_len = 0;
+    for (int i = 0; i < S; ++i)
+      max_len = std::max<int64_t>(max_len, start[(size_t) i + 1] - start[(size_t) i]);
+    const int64_t total = start[(size_t) S];
+    if (total > 0 && max_len * S > 3 * total) {
+      const int cus = h->num_cus > 0 ? h->num_cus : 256;
+      const int64_t target = std::max<int64_t>(cdiv(total, 2 * cus), 4 * (int64_t) W);
+      std::vector<int4> items;
+      for (int i = 0; i < S; ++i) {
+        const int64_t lo = start[(size_t) i], hi = start[(size_t) i + 1];
+        const int64_t np = std::max<int64_t>(1, cdiv(hi - lo, target));
+        const int64_t per = (cdiv(hi - lo, np) + 3) & ~(int64_t) 3;
+        for (int64_t k = 0; k < np; ++k) {
+          // cut on multiples of 4 entries (absolute), the vector body of the kernel relies on it
+          int64_t a = k == 0 ? lo : ((lo + k * per + 3) & ~(int64_t) 3);
+          int64_t b = k == np - 1 ? hi : ((lo + (k + 1) * per + 3) & ~(int64_t) 3);
+          a = std::min(a, hi);
+          b = std::min(b, hi);
+          if (b > a || (k == 0 && np == 1))
+            items.push_back(make_int4(i, (int) a, (int) b, 0));
+        }
+      }
+      if ((rc = dev_alloc(&pl->s_xitems, items.size() * sizeof(int4), s)))
+        return rc;
+      SPB_HIP(hipMemcpyAsync(pl->s_xitems, items.data(), items.size() * sizeof(int4), hipMemcpyHostToDevice, s));
+      SPB_HIP(hipStreamSynchronize(s));
+      pl->n_xitems = (int64_t) items.size();
+    }
+  }
   hipLaunchKernelGGL((pb_scatter_kernel<T, O>), dim3((unsigned) NB), dim3(256), (size_t) S * 4, s, m, rowptr,
                      pl->colind, static_cast<const T*>(values_p), W, H, S, NB, seg, static_cast<T*>(pl->s_values),
                      reinterpret_cast<uint16_t*>(pl->s_colind), pl->s_lrow, reinterpret_cast<int32_t*>(pl->s_perm),
@@ -834,10 +877,12 @@ static int sliced_expand_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* p
   const int64_t per_slice = pl->nnz / (pl->n_slices > 0 ? pl->n_slices : 1);
   while (parts > 1 && per_slice / parts < 2 * (int64_t) pl->slice_cols)
     --parts;
-  hipLaunchKernelGGL((pb_expand_kernel<T>), dim3((unsigned) pl->n_slices, (unsigned) parts), dim3(PB_THREADS),
+  const int4* items = static_cast<const int4*>(pl->s_xitems);
+  const dim3 grid = items ? dim3((unsigned) pl->n_xitems) : dim3((unsigned) pl->n_slices, (unsigned) parts);
+  hipLaunchKernelGGL((pb_expand_kernel<T>), grid, dim3(PB_THREADS),
                      (size_t) pl->slice_cols * sizeof(T), h->stream, pl->n, pl->slice_cols, (int) pl->n_rblk, seg,
                      static_cast<const T*>(pl->s_values), reinterpret_cast<const uint16_t*>(pl->s_colind),
-                     static_cast<const T*>(x), static_cast<T*>(pl->s_products));
+                     static_cast<const T*>(x), static_cast<T*>(pl->s_products), items);
   SPB_HIP(hipGetLastError());
   return SPBLAS_GFX950_STATUS_SUCCESS;
 }
@@ -973,8 +1018,11 @@ void spmv_sliced_free(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl) {
   dev_free(pl->s_segT, s);
   dev_free(pl->s_partial, s);
   dev_free(pl->s_hub_part, s);
+  dev_free(pl->s_xitems, s);
   pl->s_partial = nullptr;
   pl->s_hub_part = nullptr;
+  pl->s_xitems = nullptr;
+  pl->n_xitems = 0;
   pl->s_partial_k = 0;
   pl->seg_ptr = pl->s_colind = pl->s_values = pl->s_products = pl->s_segT = pl->s_perm = nullptr;
   pl->s_lrow = nullptr;
