@@ -133,8 +133,9 @@ int spblas_gfx950_spmv_plan_update_values(spblas_gfx950_handle_t handle, spblas_
 int spblas_gfx950_plan_destroy(spblas_gfx950_handle_t handle, spblas_gfx950_plan_t plan);
 /* Introspection for tests/bench: info[0]=alg, [1]=window nnz, [2]=#windows,
  * [3]=#long rows, [4]=max row length, [5]=device bytes held, [6]=#column slices,
- * [7]=#empty rows, [8]=rows per row-bin (SLICED), [9]=1 if the bins honour BIN_ROW_ALIGN. */
-int spblas_gfx950_plan_info(spblas_gfx950_plan_t plan, int64_t info[10]);
+ * [7]=#empty rows, [8]=rows per row-bin (SLICED), [9]=1 if the bins honour BIN_ROW_ALIGN,
+ * [10]=#expand work items, [11]=#reduce work items (SLICED plans of skewed matrices; else 0). */
+int spblas_gfx950_plan_info(spblas_gfx950_plan_t plan, int64_t info[12]);
 
 /* Two-stage execution of a SLICED plan (other plans: STATUS_NOT_SUPPORTED), used to overlap the
  * multi-GPU all-gather of finished y rows with the rest of the SpMV:

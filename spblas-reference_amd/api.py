@@ -244,10 +244,10 @@ class _Plan:
         self.handle, self.plan, self.key = handle, plan, key
 
     def info(self):
-        arr = (ctypes.c_int64 * 10)()
+        arr = (ctypes.c_int64 * 12)()
         check(_capi.lib().spblas_gfx950_plan_info(self.plan, arr), "spblas_gfx950_plan_info")
         names = ["alg", "window", "n_windows", "n_long_rows", "max_row_len", "device_bytes", "n_slices",
-                 "empty_rows", "rows_per_bin", "bin_aligned"]
+                 "empty_rows", "rows_per_bin", "bin_aligned", "expand_items", "reduce_items"]
         return dict(zip(names, list(arr)))
 
     # two-stage execution of a SLICED plan (include/spblas_gfx950.h: spmv_expand / spmv_reduce_rows)

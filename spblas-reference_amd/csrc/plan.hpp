@@ -53,6 +53,10 @@ struct spblas_gfx950_plan_s {
   int hub_parts = 1;                 // workgroups per hub row
   void* s_xitems = nullptr;          // int4[n_xitems] expand work list (slice, first, last) for column-skewed matrices
   int64_t n_xitems = 0;
+  // reduce work list for row-skewed matrices: int4 (group, first slice, last slice, partial offset or -1),
+  // the split groups (group, K, offset of the first partial block) and the partial blocks themselves
+  void *s_ritems = nullptr, *s_rsplit = nullptr, *s_rpartial = nullptr;
+  int64_t n_ritems = 0, n_rsplit = 0;
   void* s_partial = nullptr;   // T[s_partial_k][m] partial sums (grown on demand)
   int s_partial_k = 0;
   int bin_aligned = 0;         // wave-bin height divides the handle's bin_row_align option

@@ -691,7 +691,7 @@ int spblas_gfx950_plan_destroy(spblas_gfx950_handle_t handle, spblas_gfx950_plan
   return SPBLAS_GFX950_STATUS_SUCCESS;
 }
 
-int spblas_gfx950_plan_info(spblas_gfx950_plan_t plan, int64_t info[10]) {
+int spblas_gfx950_plan_info(spblas_gfx950_plan_t plan, int64_t info[12]) {
   if (!plan || !info)
     return SPBLAS_GFX950_STATUS_INVALID_POINTER;
   info[0] = plan->alg;
@@ -704,6 +704,8 @@ int spblas_gfx950_plan_info(spblas_gfx950_plan_t plan, int64_t info[10]) {
   info[7] = plan->empty_rows;
   info[8] = plan->rows_per_blk;
   info[9] = plan->bin_aligned;
+  info[10] = plan->n_xitems;
+  info[11] = plan->n_ritems;
   return SPBLAS_GFX950_STATUS_SUCCESS;
 }
 

@@ -161,6 +161,19 @@ __global__ __launch_bounds__(256) void pb_balance_kernel(int NB, int RW, const i
     slice_sum[sl] = red[0] + red[1] + red[2] + red[3];
 }
 
+// entries of bin group g (RW bins) in slice s, from the exclusive offsets: out[g*S + s]
+__global__ __launch_bounds__(256) void pb_group_slice_kernel(int S, int NB, int RW, int64_t ngroups,
+                                                             const int32_t* __restrict__ seg,
+                                                             int32_t* __restrict__ out) {
+  const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
+  if (i >= ngroups * S)
+    return;
+  const int64_t g = i / S;
+  const int sl = (int) (i % S);
+  const int64_t b0 = g * RW, b1 = (g + 1) * RW < NB ? (g + 1) * RW : NB;
+  out[i] = seg[(int64_t) sl * NB + b1] - seg[(int64_t) sl * NB + b0];
+}
+
 // segT[b*S + s] = (start, length) of segment (s, b) in A' order
 __global__ __launch_bounds__(256) void pb_transpose_seg_kernel(int S, int NB, const int32_t* __restrict__ seg,
                                                                int2* __restrict__ segT) {
@@ -364,15 +377,24 @@ __global__ __launch_bounds__(RW * 64) void pb_reduce_kernel(int64_t m, int Hw, i
                                                             const uint16_t* __restrict__ s_row, T* __restrict__ y,
                                                             T alpha, T beta, int s_per, T* __restrict__ partial,
                                                             int64_t pstride, T* const* __restrict__ peers,
-                                                            int n_peers, int64_t peer_off) {
+                                                            int n_peers, int64_t peer_off,
+                                                            const int4* __restrict__ ritems) {
   // blockIdx.y = k selects the slices [k*s_per, (k+1)*s_per): with few wave-bins (a row shard of
   // a multi-GPU run) the slices are split over several workgroups per bin group, each writing a
   // partial sum that pb_combine_kernel adds up in a fixed order.
+  // ritems (row-skewed matrices): workgroup i reduces the slices [ritems[i].y, ritems[i].z) of bin group
+  // ritems[i].x, so that a heavy group is spread over as many workgroups as its share of the entries
+  // asks for; .w >= 0 is the offset of its partial sums (RW*Hw values, pb_combine_items_kernel adds
+  // them up), .w < 0 means the group is not split and y is written directly.
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   T* acc = reinterpret_cast<T*>(smem) + (size_t) wave * Hw;
-  const int64_t wb = wb_begin + (int64_t) blockIdx.x * RW + wave;  // NBw = end of the bin range
-  const int s_lo = blockIdx.y * s_per, s_hi = (s_lo + s_per) < S ? (s_lo + s_per) : S;
+  const int4 item = ritems ? ritems[blockIdx.x] : make_int4((int) blockIdx.x, 0, 0, 0);
+  const int64_t wb = wb_begin + (int64_t) item.x * RW + wave;  // NBw = end of the bin range
+  const int s_lo = ritems ? item.y : (int) blockIdx.y * s_per;
+  const int s_hi = ritems ? item.z : ((s_lo + s_per) < S ? (s_lo + s_per) : S);
+  if (ritems)
+    partial = item.w >= 0 ? partial + item.w + (int64_t) wave * Hw - wb * (int64_t) Hw : nullptr;
   if (wb >= NBw)
     return;
   const int64_t r0 = wb * Hw;
@@ -485,7 +507,9 @@ __global__ __launch_bounds__(RW * 64) void pb_reduce_kernel(int64_t m, int Hw, i
     }
   }
   if (partial) {
-    T* dst = partial + (int64_t) blockIdx.y * pstride + r0;
+    // uniform split: slot k of the [K][m] array; work items: the item's own RW*Hw block (pointer pre-biased
+    // above so that "+ r0" lands on this wave's part of it)
+    T* dst = partial + (ritems ? (int64_t) 0 : (int64_t) blockIdx.y * pstride) + r0;
     for (int i = lane; i < rh; i += 64)
       dst[i] = acc[i];
     return;
@@ -573,6 +597,25 @@ __global__ __launch_bounds__(256) void pb_hub_finish_kernel(int64_t n_hub, int p
   for (int k = 0; k < parts; ++k)
     s += part[i * parts + k];
   y[r] += alpha * s;
+}
+
+// Work-item variant of the combine: one entry of `cg` per SPLIT bin group = (group, K_g, offset of its
+// first partial block, rows in the group); blockIdx.y walks the group's rows in chunks of 256.  The K_g
+// partial blocks of RW*Hw values lie back to back and are added in that order.
+template <typename T>
+__global__ __launch_bounds__(256) void pb_combine_items_kernel(const int4* __restrict__ cg, int64_t group_rows,
+                                                               int64_t m, const T* __restrict__ partial,
+                                                               T* __restrict__ y, T alpha, T beta) {
+  const int4 g = cg[blockIdx.x];
+  const int64_t i = (int64_t) blockIdx.y * 256 + threadIdx.x;
+  const int64_t row = (int64_t) g.x * group_rows + i;
+  if (i >= group_rows || row >= m)
+    return;
+  const T* src = partial + (int64_t) g.z + i;
+  T s = src[0];
+  for (int k = 1; k < g.y; ++k)
+    s += src[(int64_t) k * group_rows];
+  y[row] = beta == T(0) ? alpha * s : alpha * s + beta * y[row];
 }
 
 template <typename T>
@@ -808,6 +851,86 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
       pl->n_xitems = (int64_t) items.size();
     }
   }
+  {
+    // row skew: entries per (bin group, slice).  When one group is far above the average the reduce gets a
+    // work list: every group is cut into as many slice ranges as its share of the entries asks for.
+    const int64_t ngroups = cdiv(NB, RW), cells = ngroups * S;
+    int32_t* d_gs = nullptr;
+    if ((rc = dev_alloc((void**) &d_gs, (size_t) cells * 4, s)))
+      return rc;
+    hipLaunchKernelGGL(pb_group_slice_kernel, dim3((unsigned) cdiv(cells, 256)), dim3(256), 0, s, S, NB, RW, ngroups, seg,
+                       d_gs);
+    std::vector<int32_t> gs((size_t) cells);
+    SPB_HIP(hipMemcpyAsync(gs.data(), d_gs, (size_t) cells * 4, hipMemcpyDeviceToHost, s));
+    SPB_HIP(hipStreamSynchronize(s));
+    dev_free(d_gs, s);
+    std::vector<int64_t> tot((size_t) ngroups, 0);
+    int64_t total = 0, max_tot = 0;
+    for (int64_t g = 0; g < ngroups; ++g) {
+      int64_t t = 0;
+      for (int sl = 0; sl < S; ++sl)
+        t += gs[(size_t) (g * S + sl)];
+      tot[(size_t) g] = t;
+      total += t;
+      max_tot = std::max(max_tot, t);
+    }
+    if (total > 0 && max_tot * ngroups > 3 * total && S >= 16) {
+      const int64_t target = std::max<int64_t>(total / 768, 16384);
+      const int64_t block = (int64_t) RW * H;  // values per partial block
+      std::vector<int4> items, split;
+      int64_t poff = 0;
+      for (int64_t g = 0; g < ngroups; ++g) {
+        int64_t K = (tot[(size_t) g] + target / 2) / target;
+        K = std::max<int64_t>(1, std::min<int64_t>(K, S / 8));
+        if (K == 1) {
+          items.push_back(make_int4((int) g, 0, S, -1));
+          continue;
+        }
+        if (poff + K * block > (int64_t) INT32_MAX) {  // offsets are 32-bit: stop splitting
+          items.push_back(make_int4((int) g, 0, S, -1));
+          continue;
+        }
+        // cut at multiples of 8 slices (the duplicate-flag groups of the reduce kernel) by cumulative count
+        const int64_t first = (int64_t) items.size();
+        int lo = 0;
+        int64_t run = 0, done = 0;
+        int made = 0;
+        for (int sl = 0; sl < S; ++sl) {
+          run += gs[(size_t) (g * S + sl)];
+          const bool boundary = ((sl + 1) % 8 == 0) || sl + 1 == S;
+          if (boundary && made + 1 < K && (done + run) * K >= (int64_t) (made + 1) * tot[(size_t) g] && sl + 1 < S) {
+            items.push_back(make_int4((int) g, lo, sl + 1, 0));
+            lo = sl + 1;
+            done += run;
+            run = 0;
+            ++made;
+          }
+        }
+        items.push_back(make_int4((int) g, lo, S, 0));
+        const int64_t Kg = (int64_t) items.size() - first;
+        if (Kg == 1) {
+          items.back().w = -1;
+          continue;
+        }
+        for (int64_t k = 0; k < Kg; ++k)
+          items[(size_t) (first + k)].w = (int) (poff + k * block);
+        split.push_back(make_int4((int) g, (int) Kg, (int) poff, 0));
+        poff += Kg * block;
+      }
+      if (!split.empty()) {
+        if ((rc = dev_alloc(&pl->s_ritems, items.size() * sizeof(int4), s)) ||
+            (rc = dev_alloc(&pl->s_rsplit, split.size() * sizeof(int4), s)) ||
+            (rc = dev_alloc(&pl->s_rpartial, (size_t) poff * sizeof(T), s)))
+          return rc;
+        SPB_HIP(hipMemcpyAsync(pl->s_ritems, items.data(), items.size() * sizeof(int4), hipMemcpyHostToDevice, s));
+        SPB_HIP(hipMemcpyAsync(pl->s_rsplit, split.data(), split.size() * sizeof(int4), hipMemcpyHostToDevice, s));
+        SPB_HIP(hipStreamSynchronize(s));
+        pl->n_ritems = (int64_t) items.size();
+        pl->n_rsplit = (int64_t) split.size();
+        pl->device_bytes += (size_t) poff * sizeof(T);
+      }
+    }
+  }
   hipLaunchKernelGGL((pb_scatter_kernel<T, O>), dim3((unsigned) NB), dim3(256), (size_t) S * 4, s, m, rowptr,
                      pl->colind, static_cast<const T*>(values_p), W, H, S, NB, seg, static_cast<T*>(pl->s_values),
                      reinterpret_cast<uint16_t*>(pl->s_colind), pl->s_lrow, reinterpret_cast<int32_t*>(pl->s_perm),
@@ -908,7 +1031,9 @@ static int sliced_reduce_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* p
   const int K = (int) cdiv(pl->n_slices, s_per);
   const int64_t r_lo = wb_begin * pl->rows_per_blk;
   const int64_t r_hi = wb_end * pl->rows_per_blk < pl->m ? wb_end * pl->rows_per_blk : pl->m;
-  if (K > 1 && pl->s_partial_k < K) {  // grow the partial-sum workspace (stream ordered)
+  bool K_used_items = false;
+  const bool will_use_items = pl->s_ritems && !peers_p && wb_begin == 0 && wb_end == pl->n_rblk;
+  if (!will_use_items && K > 1 && pl->s_partial_k < K) {  // grow the partial-sum workspace (stream ordered)
     dev_free(pl->s_partial, s);
     pl->s_partial = nullptr;
     int rc = dev_alloc(&pl->s_partial, (size_t) K * pl->m * sizeof(T), s);
@@ -926,12 +1051,27 @@ static int sliced_reduce_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* p
     int Hw = pl->rows_per_blk, S = pl->n_slices, sp = s_per;
     T a = alpha, b = beta;
     T* const* peers = reinterpret_cast<T* const*>(peers_p);
+    const int4* ritems = nullptr;
     void* args[] = {&mm, &Hw, &S, &wb_begin, &wb_end, &segT, &Pp, &rowp, &yp, &a, &b, &sp, &part, &pstride,
-                    &peers, &n_peers, &peer_off};
+                    &peers, &n_peers, &peer_off, &ritems};
+    if (pl->s_ritems && !peers_p && wb_begin == 0 && wb_end == pl->n_rblk) {
+      // row-skewed matrix, whole range: explicit work list (built at inspect), compact partial sums
+      ritems = static_cast<const int4*>(pl->s_ritems);
+      part = static_cast<T*>(pl->s_rpartial);
+      pstride = 0;
+      SPB_HIP(hipLaunchKernel(pb_reduce_fn<T>(RW, pl->rchunks, pl->rgroup), dim3((unsigned) pl->n_ritems), dim3(RW * 64),
+                              args, (size_t) RW * pl->rows_per_blk * sizeof(T), s));
+      if (pl->n_rsplit > 0)
+        hipLaunchKernelGGL((pb_combine_items_kernel<T>),
+                           dim3((unsigned) pl->n_rsplit, (unsigned) cdiv((int64_t) RW * pl->rows_per_blk, 256)), dim3(256),
+                           0, s, static_cast<const int4*>(pl->s_rsplit), (int64_t) RW * pl->rows_per_blk, pl->m,
+                           static_cast<const T*>(pl->s_rpartial), static_cast<T*>(y), alpha, beta);
+      K_used_items = true;
+    } else
     SPB_HIP(hipLaunchKernel(pb_reduce_fn<T>(RW, pl->rchunks, pl->rgroup), dim3((unsigned) groups, (unsigned) K), dim3(RW * 64), args,
                             (size_t) RW * pl->rows_per_blk * sizeof(T), s));
   }
-  if (K > 1 && r_hi > r_lo)
+  if (!K_used_items && K > 1 && r_hi > r_lo)
     hipLaunchKernelGGL((pb_combine_kernel<T>), dim3((unsigned) cdiv(r_hi - r_lo, 256)), dim3(256), 0, s, r_lo, r_hi, K,
                        static_cast<const T*>(pl->s_partial), pl->m, static_cast<T*>(y), alpha, beta,
                        reinterpret_cast<T* const*>(peers_p), n_peers, peer_off);
@@ -1019,6 +1159,11 @@ void spmv_sliced_free(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl) {
   dev_free(pl->s_partial, s);
   dev_free(pl->s_hub_part, s);
   dev_free(pl->s_xitems, s);
+  dev_free(pl->s_ritems, s);
+  dev_free(pl->s_rsplit, s);
+  dev_free(pl->s_rpartial, s);
+  pl->s_ritems = pl->s_rsplit = pl->s_rpartial = nullptr;
+  pl->n_ritems = pl->n_rsplit = 0;
   pl->s_partial = nullptr;
   pl->s_hub_part = nullptr;
   pl->s_xitems = nullptr;

@@ -390,6 +390,7 @@ def test_spmv_auto_declines_sliced_for_skewed_matrices(gpu):
         sp.multiply(info, a, xd, y)
         check(values, rowptr, cols, (m, n), x, G.host(y), what=what + " (auto)", ref_cmp=False)
         info = sp.multiply_inspect(a, xd, y, alg=_capi.SPMV_SLICED)
+        assert info.state_.info()["expand_items"] > 0
         sp.multiply(info, a, xd, y)
         check(values, rowptr, cols, (m, n), x, G.host(y), what=what + " (forced sliced)", ref_cmp=False)
     # heavy rows below the hub threshold concentrated in one corner of the matrix
@@ -406,3 +407,23 @@ def test_spmv_auto_declines_sliced_for_skewed_matrices(gpu):
     assert info.state_.info()["alg"] == _capi.SPMV_ROWBLOCK
     sp.multiply(info, a, xd, y)
     check(val2, rowptr2, col2, (m, n), x, G.host(y), what="heavy row block (auto)", ref_cmp=False)
+    # forced SLICED: the reduce runs from its work list (heavy bin groups split over several workgroups,
+    # pb_combine_items_kernel sums their partial rows); a row-range call takes the uniform path instead
+    info = sp.multiply_inspect(a, xd, y, alg=_capi.SPMV_SLICED)
+    assert info.state_.info()["reduce_items"] > 0
+    y.fill_(float("nan"))
+    sp.multiply(info, sp.scaled(0.5, a), xd, y)
+    check(val2, rowptr2, col2, (m, n), x, G.host(y), scale=0.5, what="heavy row block (forced sliced)",
+          ref_cmp=False)
+    y2 = torch.full((m,), float("nan"), device="cuda")
+    expand, reduce_rows = info.state_.bind_stages(xd, y2.data_ptr(), torch.float32, alpha=0.5)
+    expand()
+    H = info.state_.info()["rows_per_bin"]
+    cut = (m // 3 // H) * H
+    reduce_rows(0, cut)
+    reduce_rows(cut, m)
+    check(val2, rowptr2, col2, (m, n), x, G.host(y2), scale=0.5, what="heavy row block (two-stage)", ref_cmp=False)
+    a.values().mul_(-1.0)
+    info.state_.update_values(a.values())
+    sp.multiply(info, a, xd, y)
+    check(-val2, rowptr2, col2, (m, n), x, G.host(y), what="heavy row block (after update)", ref_cmp=False)
