@@ -403,12 +403,19 @@ __global__ __launch_bounds__(RW * 64) void pb_reduce_kernel(int64_t m, int Hw, i
     acc[i] = T(0);
   const int2* mine = segT + wb * S + s_lo;
   const int ns = s_hi - s_lo;
-  constexpr int B = 8;  // runs per batch; 64 descriptors (one per lane) make a group of 8 batches
+  constexpr int B = 8;         // runs per batch
+  constexpr int GB = 64 / B;   // 64 descriptors (one per lane) make a group of GB batches
   struct batch_t {
     T p[B][C];
     int r[B][C];
     int st[B], ln[B];
   };
+  // The wave issues one instruction at a time and only two waves share a SIMD (LDS bounds the occupancy),
+  // so the instruction count per 64-entry chunk is what the kernel time follows (SQ counters in DESIGN 4.3):
+  // 32-bit byte offsets from scalar bases for the loads, no exec-masked blocks around the stores -- lanes
+  // without a plain entry store to a per-lane dummy slot behind the accumulators instead.
+  T* const dummy = reinterpret_cast<T*>(smem) + (size_t) RW * Hw + wave * 64 + lane;
+  constexpr int SH = sizeof(T) == 4 ? 2 : 3;
   auto fetch_group = [&](int g) -> int2 {  // descriptors of slices 64g .. 64g+63, one per lane
     const int t = 64 * g + lane;
     const int tc = t < ns ? t : (ns > 0 ? ns - 1 : 0);
@@ -426,9 +433,11 @@ __global__ __launch_bounds__(RW * 64) void pb_reduce_kernel(int64_t m, int Hw, i
 #pragma unroll
       for (int c = 0; c < C; ++c) {
         const int o = lane + 64 * c;
-        const int idx = q.st[u] + (o < last ? o : last);
-        q.p[u][c] = stream_load(P + idx);
-        q.r[u][c] = stream_load(s_row + idx);
+        // lanes past the end of the run re-read its last entry; byte offsets fit 32 bits (checked at build)
+        const unsigned offP = (unsigned) (q.st[u] + (o < last ? o : last)) << SH;
+        const unsigned offR = offP >> (SH - 1);
+        q.p[u][c] = stream_load(reinterpret_cast<const T*>(reinterpret_cast<const char*>(P) + offP));
+        q.r[u][c] = stream_load(reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(s_row) + offR));
       }
     }
   };
@@ -438,34 +447,37 @@ __global__ __launch_bounds__(RW * 64) void pb_reduce_kernel(int64_t m, int Hw, i
       // one group: all LDS reads, then all writes.  Rows of unflagged entries are distinct inside a
       // group (pb_flag_dups_kernel), flagged ones are added atomically afterwards.
       T v[GR][C];
-      int row[GR][C];
+      T* slot[GR][C];
       bool plain[GR][C], dup[GR][C];
-      bool any_dup = false;
+      unsigned long long dups = 0;
 #pragma unroll
       for (int u = 0; u < GR; ++u)
 #pragma unroll
         for (int c = 0; c < C; ++c) {
-          const int r = q.r[g + u][c];
+          int r = q.r[g + u][c];
+          asm("" : "+v"(r));  // keep the row word a 32-bit value (the 16-bit forms cost extra masking)
           const bool ok = lane + 64 * c < q.ln[g + u];
-          row[u][c] = r & 0x7FFF;
-          dup[u][c] = ok && (r & 0x8000);
-          plain[u][c] = ok && !(r & 0x8000);
-          any_dup |= dup[u][c];
-          v[u][c] = acc[plain[u][c] ? row[u][c] : 0];
+          const bool flagged = (unsigned) r > 0x7FFFu;
+          slot[u][c] = acc + (r & 0x7FFF);
+          v[u][c] = *slot[u][c];  // clamped lanes hold a real entry too: the row is always in range
+          plain[u][c] = ok && !flagged;
+          dup[u][c] = ok && flagged;
+          dups |= __builtin_amdgcn_ballot_w64(dup[u][c]);
         }
 #pragma unroll
       for (int u = 0; u < GR; ++u)
 #pragma unroll
-        for (int c = 0; c < C; ++c)
-          if (plain[u][c])
-            acc[row[u][c]] = v[u][c] + q.p[g + u][c];
-      if (__builtin_amdgcn_ballot_w64(any_dup) != 0) {
+        for (int c = 0; c < C; ++c) {
+          T* w = plain[u][c] ? slot[u][c] : dummy;
+          *w = v[u][c] + q.p[g + u][c];
+        }
+      if (dups != 0) {
 #pragma unroll
         for (int u = 0; u < GR; ++u)
 #pragma unroll
           for (int c = 0; c < C; ++c)
             if (dup[u][c])
-              unsafeAtomicAdd(acc + row[u][c], q.p[g + u][c]);
+              unsafeAtomicAdd(slot[u][c], q.p[g + u][c]);
       }
       // longer runs: the tail straight from memory.  Keep these loads inside the `if`: with
       // unconditional loads here the compiler loses track of the in-flight batch and waits
@@ -490,19 +502,19 @@ __global__ __launch_bounds__(RW * 64) void pb_reduce_kernel(int64_t m, int Hw, i
     int2 dcur = fetch_group(0), dnext = fetch_group(1);
     // descriptors for batch kk (called with kk = 1, 2, 3, ... in order)
     auto advance = [&](int kk) {
-      if ((kk & 7) == 0) {
+      if ((kk % GB) == 0) {
         dcur = dnext;
-        dnext = fetch_group((kk >> 3) + 1);
+        dnext = fetch_group(kk / GB + 1);
       }
     };
     batch_t qa, qb;
     issue(dcur, 0, qa);
     for (int k = 0; k < nbatch; k += 2) {
       advance(k + 1);
-      issue(dcur, ((k + 1) & 7) * B, qb);  // past the last batch the descriptors have ln = 0
+      issue(dcur, ((k + 1) % GB) * B, qb);  // past the last batch the descriptors have ln = 0
       consume(qa);
       advance(k + 2);
-      issue(dcur, ((k + 2) & 7) * B, qa);
+      issue(dcur, ((k + 2) % GB) * B, qa);
       consume(qb);
     }
   }
@@ -661,7 +673,8 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
                               bool auto_mode) {
   hipStream_t s = h->stream;
   const int64_t m = pl->m, n = pl->n, nnz = pl->nnz;
-  if (nnz > INT32_MAX - 8)
+  // the reduce addresses the product stream with 32-bit byte offsets
+  if (nnz > INT32_MAX - 8 || (uint64_t) (nnz + 64) * sizeof(T) >= ((uint64_t) 1 << 32))
     return SPBLAS_GFX950_STATUS_NOT_SUPPORTED;
   // x slice of the expand: 80 KiB for fp32 (two workgroups per CU); for fp64 the whole 160 KiB of a CU
   // (one workgroup), which halves the number of slices and doubles the run length again
@@ -676,7 +689,8 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
   if (RW != 4 && RW != 8)
     RW = PB_RWAVES_DEFAULT;
   pl->rwaves = RW;
-  int max_rows = PB_LDS_BYTES / RW / (int) sizeof(T);  // per wave-bin; < 32768 (15-bit row + flag)
+  // per wave-bin; < 32768 (15-bit row + flag); 64 dummy slots per wave follow the accumulators
+  int max_rows = PB_LDS_BYTES / RW / (int) sizeof(T) - 64;
   if (max_rows > 32767)
     max_rows = 32767;
   int S, W, NB, H;
@@ -1060,7 +1074,7 @@ static int sliced_reduce_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* p
       part = static_cast<T*>(pl->s_rpartial);
       pstride = 0;
       SPB_HIP(hipLaunchKernel(pb_reduce_fn<T>(RW, pl->rchunks, pl->rgroup), dim3((unsigned) pl->n_ritems), dim3(RW * 64),
-                              args, (size_t) RW * pl->rows_per_blk * sizeof(T), s));
+                              args, (size_t) RW * (pl->rows_per_blk + 64) * sizeof(T), s));
       if (pl->n_rsplit > 0)
         hipLaunchKernelGGL((pb_combine_items_kernel<T>),
                            dim3((unsigned) pl->n_rsplit, (unsigned) cdiv((int64_t) RW * pl->rows_per_blk, 256)), dim3(256),
@@ -1069,7 +1083,7 @@ static int sliced_reduce_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* p
       K_used_items = true;
     } else
     SPB_HIP(hipLaunchKernel(pb_reduce_fn<T>(RW, pl->rchunks, pl->rgroup), dim3((unsigned) groups, (unsigned) K), dim3(RW * 64), args,
-                            (size_t) RW * pl->rows_per_blk * sizeof(T), s));
+                            (size_t) RW * (pl->rows_per_blk + 64) * sizeof(T), s));
   }
   if (!K_used_items && K > 1 && r_hi > r_lo)
     hipLaunchKernelGGL((pb_combine_kernel<T>), dim3((unsigned) cdiv(r_hi - r_lo, 256)), dim3(256), 0, s, r_lo, r_hi, K,
