@@ -5,7 +5,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/qs_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o qs -- python3 $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline "$@" > $OUT/run.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o qs -- python3 $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline "$@" > $OUT/run.log 2>&1
 cd $ROOT
 python3 - <<PY
 import csv,glob
