@@ -1,0 +1,10 @@
+#!/bin/bash
+# tools/extra_stats.sh <tag>: kernel-trace stats of the secondary workloads -> gpurun_out/extra_<tag>.md
+TAG=$1
+OUT=gpurun_out/extra_$TAG.md
+echo '```' > $OUT
+for w in spmm spgemm add transpose sptrsv spmv_rmat; do
+  echo "## $w" >> $OUT
+  TOPN=6 bash tools/quick_stats.sh ${TAG}_$w --workload $w 2>&1 | grep -v '"value"' >> $OUT
+done
+echo '```' >> $OUT
