@@ -84,6 +84,11 @@ class csc_view(view_base):
         self._values, self._colptr, self._rowind = values, colptr, rowind
         self._shape, self._nnz = index(shape), int(nnz)
 
+    def update(self, values, colptr, rowind, shape=None, nnz=None):  # views/csc_view.hpp
+        self._values, self._colptr, self._rowind = values, colptr, rowind
+        if shape is not None:
+            self._shape, self._nnz = index(shape), int(nnz)
+
     def values(self):
         return self._values
 
@@ -594,7 +599,10 @@ def multiply_inspect(*args, alg=_capi.SPMV_AUTO):
     _reject_conjugated(a, b, c)
     if isinstance(a_base, csr_view) and not _is_sparse(b) and a_base.values() is not None:
         _check_csr(a_base, "multiply_inspect")
-        plan = _build_plan(a_base, alg)
+        # the column-sliced plan serves SpMV only; SpMM uses the row partition (spmm_impl.hpp of the C++ layer)
+        b_base = get_ultimate_base(b)
+        is_spmm = _is_tensor(b_base) and b_base.dim() == 2
+        plan = _build_plan(a_base, _capi.SPMV_ROWBLOCK if is_spmm and alg == _capi.SPMV_AUTO else alg)
         info.state_ = plan
         mo = _get_matrix_opt(a)
         if mo is not None:
@@ -605,46 +613,67 @@ def multiply_inspect(*args, alg=_capi.SPMV_AUTO):
 
 
 # --------------------------------------------------------------------------- SpGEMM
-def _spgemm_operands(a, b, c):
-    a_base, b_base = get_ultimate_base(a), get_ultimate_base(b)
-    if not (isinstance(a_base, csr_view) and isinstance(b_base, csr_view) and isinstance(c, csr_view)):
-        raise NotImplementedError("gfx950 SpGEMM supports CSR * CSR -> CSR")
-    _reject_conjugated(a, b)
-    for t in (a_base, b_base):
-        _check_csr(t, "multiply_compute")
-        if t.rowptr().dtype != torch.int32:
-            raise TypeError("SpGEMM: int32 row offsets only")
-    if (a_base.shape()[0] != c.shape()[0] or b_base.shape()[1] != c.shape()[1]
-            or a_base.shape()[1] != b_base.shape()[0]):
-        raise ValueError("multiply: matrix dimensions are incompatible.")  # spgemm_gustavsons.hpp:22-27
-    return a_base, b_base
+def _device_transposed(x):
+    """csr_view of x^T in freshly allocated device arrays (spblas_gfx950_csr_transpose)."""
+    m, n = x.shape()
+    nnz = x.size()
+    dev = x.rowptr().device
+    t = csr_view(torch.empty(nnz, dtype=x.values().dtype, device=dev), torch.empty(n + 1, dtype=torch.int32, device=dev),
+                 torch.empty(nnz, dtype=torch.int32, device=dev), (n, m), nnz)
+    transpose(x, t)
+    return t
 
 
-def _addend(d, c):
-    """Addend D of the four-argument form C = alpha*A*B + beta*D
-    (vendor/rocsparse/multiply_spgemm.hpp:118-214): CSR (optionally scaled) of C's shape."""
-    d_base = get_ultimate_base(d)
-    if not isinstance(d_base, csr_view):
-        raise NotImplementedError("gfx950 SpGEMM addend must be a csr_view")
-    _reject_conjugated(d)
-    _check_csr(d_base, "multiply_compute")
-    if d_base.rowptr().dtype != torch.int32:
+def _csr_form(t_base, want_transposed, what):
+    """CSR arrays of X (or of X^T) for a csr_view / csc_view X.  A csc_view's arrays ARE the CSR arrays of
+    X^T (algorithms/transposed.hpp:7-21), so only one of the two forms needs the device transpose."""
+    if isinstance(t_base, csc_view):
+        t_base, want_transposed = transposed(t_base), not want_transposed
+    if not isinstance(t_base, csr_view):
+        raise NotImplementedError("gfx950 SpGEMM operands must have a csr_view or csc_view base")
+    _check_csr(t_base, what)
+    if t_base.rowptr().dtype != torch.int32:
         raise TypeError("SpGEMM: int32 row offsets only")
-    if tuple(d_base.shape()) != tuple(c.shape()):
-        raise ValueError("multiply: matrix dimensions are incompatible.")
-    return d_base
+    return _device_transposed(t_base) if want_transposed else t_base
 
 
-def _symbolic(state, a, b, c, d=None):
-    a_base, b_base = _spgemm_operands(a, b, c)
+def _spgemm_operands(a, b, c, d=None):
+    """Operands of the CSR kernel for any mix of csr_view / csc_view A, B, C (the eight combinations of
+    algorithms/detail/spgemm/spgemm_{gustavsons,innerproduct,outerproduct}.hpp): with a CSR result the
+    kernel runs on CSR(A), CSR(B); with a CSC result it computes C^T = B^T A^T, whose CSR arrays are C's CSC
+    arrays.  Operands stored the other way round are transposed on the device for this call.
+    Returns (a_eff, b_eff, c_eff, d_eff)."""
+    a_base, b_base = get_ultimate_base(a), get_ultimate_base(b)
+    if not isinstance(c, (csr_view, csc_view)):
+        raise NotImplementedError("gfx950 SpGEMM result must be a csr_view or csc_view")
+    _reject_conjugated(a, b)
+    if (_shape_of(a_base)[0] != c.shape()[0] or _shape_of(b_base)[1] != c.shape()[1]
+            or _shape_of(a_base)[1] != _shape_of(b_base)[0]):
+        raise ValueError("multiply: matrix dimensions are incompatible.")  # spgemm_gustavsons.hpp:22-27
+    d_base = None
+    if d is not None:
+        d_base = get_ultimate_base(d)
+        _reject_conjugated(d)
+        if tuple(_shape_of(d_base)) != tuple(c.shape()):
+            raise ValueError("multiply: matrix dimensions are incompatible.")
+    if isinstance(c, csr_view):
+        return (_csr_form(a_base, False, "multiply_compute"), _csr_form(b_base, False, "multiply_compute"), c,
+                None if d_base is None else _csr_form(d_base, False, "multiply_compute"))
+    c_eff = csr_view(c.values(), c.colptr(), c.rowind(), (c.shape()[1], c.shape()[0]), c.size())
+    return (_csr_form(b_base, True, "multiply_compute"), _csr_form(a_base, True, "multiply_compute"), c_eff,
+            None if d_base is None else _csr_form(d_base, True, "multiply_compute"))
+
+
+def _symbolic(state, a, b, c_user, d=None):
+    a_base, b_base, c, d_base = _spgemm_operands(a, b, c_user, d)
     if c.rowptr() is None or c.rowptr().dtype != torch.int32 or c.rowptr().numel() < c.shape()[0] + 1:
-        raise ValueError("multiply_compute: c.rowptr must hold shape[0]+1 int32 entries")
+        raise ValueError("multiply_compute: c's offsets must hold shape+1 int32 entries")
     hd, st = state._ensure(c.rowptr().device)
+    state._keep = (a_base, b_base, d_base)  # device transposes of this call stay alive with the state
     nnz = ctypes.c_int64(0)
     m, k = a_base.shape()
     n = b_base.shape()[1]
     if d is not None:
-        d_base = _addend(d, c)
         check(_capi.lib().spblas_gfx950_spgemm_set_addend(hd.h, st, d_base.size(), _ptr(d_base.rowptr()),
                                                           _ptr(d_base.colind())), "multiply_compute")
     else:
@@ -654,16 +683,17 @@ def _symbolic(state, a, b, c, d=None):
                                                     _ptr(a_base.colind()), b_base.size(), _ptr(b_base.rowptr()),
                                                     _ptr(b_base.colind()), _ptr(c.rowptr()), ctypes.byref(nnz)),
           "multiply_compute")
-    state._result_shape, state._result_nnz = index(m, n), nnz.value
+    state._result_shape, state._result_nnz = index(c_user.shape()), nnz.value
 
 
-def _numeric(state, a, b, c, d=None):
-    a_base, b_base = _spgemm_operands(a, b, c)
+def _numeric(state, a, b, c_user, d=None):
+    a_base, b_base, c, d_base = _spgemm_operands(a, b, c_user, d)
     if state._state is None:
         raise RuntimeError("multiply_fill: multiply_compute has not been called on this state")
     if (d is not None) != getattr(state, "_has_addend", False):
         raise RuntimeError("multiply_fill: the addend must be passed to both multiply_compute and multiply_fill")
     hd, st = state._ensure(c.rowptr().device)
+    state._keep = (a_base, b_base, d_base)
     nnz = state._result_nnz
     cap = 0
     if c.values() is not None and c.colind() is not None:
@@ -674,7 +704,6 @@ def _numeric(state, a, b, c, d=None):
     alpha_opt = get_scaling_factor(a, b)
     alpha = ct(1 if alpha_opt is None else alpha_opt)
     if d is not None:
-        d_base = _addend(d, c)
         if d_base.values().dtype != a_base.values().dtype:
             raise TypeError("multiply_fill: the addend must have A's value type")
         beta_opt = get_scaling_factor(d)
@@ -690,7 +719,10 @@ def _numeric(state, a, b, c, d=None):
                                                        _ptr(b_base.rowptr()), _ptr(b_base.colind()),
                                                        _ptr(b_base.values()), _ptr(c.rowptr()), _ptr(c.colind()),
                                                        _ptr(c.values()), cap, vt), "multiply_fill")
-    c.update(c.values(), c.rowptr(), c.colind(), state._result_shape, nnz)  # spgemm_gustavsons.hpp:50-51
+    if isinstance(c_user, csr_view):
+        c_user.update(c.values(), c.rowptr(), c.colind(), state._result_shape, nnz)  # spgemm_gustavsons.hpp:50-51
+    else:
+        c_user.update(c.values(), c.rowptr(), c.colind(), state._result_shape, nnz)  # the CSR arrays of C^T
 
 
 def multiply_compute(*args):
@@ -731,7 +763,6 @@ def multiply_symbolic_compute(state, a, b, c, d=None):
 def multiply_symbolic_fill(state, a, b, c, d=None):
     """Binds C's arrays; the structure (rowptr) is already final after symbolic_compute,
     colind is produced together with the values by multiply_numeric."""
-    _spgemm_operands(a, b, c)
     if state._state is None:
         raise RuntimeError("multiply_symbolic_fill: multiply_symbolic_compute has not been called")
     return None

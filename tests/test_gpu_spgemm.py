@@ -209,3 +209,59 @@ def test_spgemm_cfg5_shape_properties(gpu):
     got_v = np.concatenate([d_c.values().cpu().numpy()[rp_h[r]:rp_h[r + 1]] for r in rows])
     assert np.array_equal(got_c, cc) and np.array_equal(np.diff(cr), rp_h[rows + 1] - rp_h[rows])
     np.testing.assert_allclose(got_v, cv, rtol=1e-5)
+
+
+def _host_transpose(v, rp, ci, shape):
+    """CSR arrays of X^T on the host (scipy is test infrastructure only)."""
+    import scipy.sparse as sps
+    t = sps.csr_matrix((v, ci, rp), shape=shape).T.tocsr()
+    t.sort_indices()
+    return t.data.astype(v.dtype), t.indptr.astype(np.int32), t.indices.astype(np.int32), (shape[1], shape[0])
+
+
+@pytest.mark.parametrize("c_fmt", ["csr", "csc"])
+@pytest.mark.parametrize("b_fmt", ["csr", "csc"])
+@pytest.mark.parametrize("a_fmt", ["csr", "csc"])
+def test_spgemm_mixed_csr_csc_operands(gpu, a_fmt, b_fmt, c_fmt):
+    """The eight operand/result format combinations of the reference's CPU path
+    (test/gtest/spgemm_csr_csc.cpp:10-350 MixedViews.*, spgemm_test.cpp:203-264 CscView.SpGEMM): a CSC
+    operand is built from the transposed CSR arrays exactly as those tests do; the result must equal the
+    oracle's CSR product (indices exact), read back through the requested format."""
+    dtype = np.float32
+    for (m, k, nnz) in [(100, 100, 100), (40, 1000, 1000), (1000, 100, 10000)]:
+        n = m
+        a_h = generate.generate_csr(m, k, nnz, dtype=dtype)[:4]
+        b_h = generate.generate_csr(k, n, nnz, seed=1, dtype=dtype)[:4]
+
+        def operand(h, fmt):
+            v, rp, ci, sh = h
+            if fmt == "csr":
+                return G.csr_on_device(v, rp, ci, sh, len(v))
+            tv, trp, tci, _ = _host_transpose(v, rp, ci, sh)     # CSR of X^T == CSC of X
+            return sp.csc_view(G.dev(tv), G.dev(trp), G.dev(tci), sh, len(v))
+
+        A, B = operand(a_h, a_fmt), operand(b_h, b_fmt)
+        view = sp.csr_view if c_fmt == "csr" else sp.csc_view
+        ptr = torch.full(((m if c_fmt == "csr" else n) + 1,), -1, dtype=torch.int32, device="cuda")
+        C = view(None, ptr, None, (m, n), 0)
+        info = sp.multiply_compute(A, B, C)
+        cn = info.result_nnz()
+        assert info.result_shape() == (m, n)
+        vals = torch.full((cn,), float("nan"), device="cuda")
+        inds = torch.full((cn,), -1, dtype=torch.int32, device="cuda")
+        C.update(vals, ptr, inds, (m, n), cn)
+        sp.multiply_fill(info, sp.scaled(2.0, A), B, C)
+        assert C.size() == cn and tuple(C.shape()) == (m, n)
+        got_v, got_p, got_i = G.host(vals), G.host(ptr), G.host(inds)
+        # oracle: CSR product, transposed on the host when the result is CSC
+        ref_nnz, _ = oracle.spgemm_symbolic(a_h[3], a_h[1], a_h[2], b_h[3], b_h[1], b_h[2])
+        cr, cc, cv = oracle.spgemm_numeric(a_h[3], a_h[1], a_h[2], a_h[0], b_h[3], b_h[1], b_h[2], b_h[0],
+                                           capacity=ref_nnz, scale_a=2.0)
+        assert cn == ref_nnz
+        ab = absprod_rows(a_h, b_h, cr, cc) * 2.0
+        if c_fmt == "csc":
+            abt, _, _, _ = _host_transpose(ab.astype(np.float64), cr, cc, (m, n))
+            cv, cr, cc, _ = _host_transpose(cv, cr, cc, (m, n))
+            ab = abt
+        assert np.array_equal(got_p, cr) and np.array_equal(got_i, cc)
+        util.assert_parity(got_v, cv, ab, dtype, row_len=np.full(len(cv), 64), what=f"spgemm {a_fmt}*{b_fmt}->{c_fmt}")
