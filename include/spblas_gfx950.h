@@ -282,6 +282,11 @@ int spblas_gfx950_sptrsv_solve(spblas_gfx950_handle_t handle, spblas_gfx950_trsv
                                const void* alpha, const int32_t* rowptr, const int32_t* colind, const void* values,
                                const void* b, void* x, int value_type);
 
+/* ---- scale:  values[i] *= alpha  (algorithms/scale_impl.hpp:13-19) --------------------------- */
+/* In-place scaling of a matrix's value array or of a dense vector (n elements, device memory).  A SLICED
+ * SpMV plan holds a snapshot of the values: refresh it with spblas_gfx950_spmv_plan_update_values. */
+int spblas_gfx950_scale(spblas_gfx950_handle_t handle, int64_t n, const void* alpha, void* values, int value_type);
+
 /* ---- transpose:  B = A^T  (CSR -> CSR, int32 indices) ------------------------------------ */
 /* Device counterpart of transpose(a, b) (algorithms/transpose_impl.hpp:14-53): stable counting
  * sort by column, so every output row lists its entries in source order.  t_rowptr has n+1

@@ -11,6 +11,7 @@
 //
 //   csr_view / csc_view            views/csr_view.hpp:12-77, views/csc_view.hpp
 //   scaled(alpha, t)               algorithms/scaled.hpp, views/scaled_view_impl.hpp
+//   scale(alpha, t)                algorithms/scale_impl.hpp:13-31 (in place, on the device)
 //   transposed(a)                  algorithms/transposed.hpp:7-21
 //   matrix_opt                     views/matrix_opt_impl.hpp:14-93
 //   mdspan_row_major<T, I>         detail/mdspan.hpp:38-41 (minimal 2-D row-major view)
@@ -477,6 +478,25 @@ template <typename A, typename X, typename Y>
 void multiply(A&& a, X&& x, Y&& y) {
   operation_info_t info;
   multiply(info, a, x, y);
+}
+
+// ---- scale (algorithms/scale_impl.hpp:13-31) ---------------------------------------------------
+template <typename Scalar, typename T, typename I, typename O>
+void scale(Scalar alpha, csr_view<T, I, O> a) {
+  __gfx950::handle_t h;
+  __gfx950::scale_values<T>(h, static_cast<std::int64_t>(a.size()), static_cast<T>(alpha), a.values().data());
+}
+
+template <typename Scalar, typename T, typename I, typename O>
+void scale(Scalar alpha, csc_view<T, I, O> a) {
+  __gfx950::handle_t h;
+  __gfx950::scale_values<T>(h, static_cast<std::int64_t>(a.size()), static_cast<T>(alpha), a.values().data());
+}
+
+template <typename Scalar, typename T>
+void scale(Scalar alpha, std::span<T> v) {
+  __gfx950::handle_t h;
+  __gfx950::scale_values<T>(h, static_cast<std::int64_t>(v.size()), static_cast<T>(alpha), v.data());
 }
 
 // ---- transpose (algorithms/transpose_impl.hpp:9-61) -------------------------------------------

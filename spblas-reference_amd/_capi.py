@@ -59,6 +59,7 @@ PROTOTYPES = [
       c_void_p, c_void_p, c_i64, c_int, c_int]),
     ("spblas_gfx950_csr_transpose", c_int,
      [c_void_p, c_i64, c_i64, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int]),
+    ("spblas_gfx950_scale", c_int, [c_void_p, c_i64, c_void_p, c_void_p, c_int]),
     ("spblas_gfx950_spgemm_create", c_int, [c_void_p, ctypes.POINTER(c_void_p)]),
     ("spblas_gfx950_spgemm_destroy", c_int, [c_void_p, c_void_p]),
     ("spblas_gfx950_spgemm_symbolic", c_int,

@@ -452,6 +452,21 @@ def transpose(*args):
     b.update(b.values(), b.rowptr(), b.colind(), b.shape(), nnz)  # transpose_impl.hpp:54
 
 
+def scale(alpha, t):
+    """scale(alpha, t) (algorithms/scale_impl.hpp:13-31): multiplies the stored values of a matrix view, or the
+    elements of a dense vector, by alpha in place on the device.  An LDS-sliced SpMV plan of the matrix holds
+    a snapshot of the values: call update_values on it afterwards."""
+    base = get_ultimate_base(t)
+    vals = base if _is_tensor(base) else base.values()
+    if vals is None or not vals.is_contiguous():
+        raise ValueError("scale: the values must be a contiguous device array")
+    nvals = vals.numel() if _is_tensor(base) else base.size()
+    vt, ct = _vtype(vals, "scale")
+    a = ct(alpha)
+    hd = _Handle.current(vals.device)
+    check(_capi.lib().spblas_gfx950_scale(hd.h, nvals, ctypes.byref(a), _ptr(vals), vt), "scale")
+
+
 def _find_plan(info, a, a_base):
     key = _plan_key(a_base)
     if info is not None and isinstance(info.state_, _Plan) and info.state_.key == key:

@@ -111,6 +111,25 @@ static int transpose_typed(spblas_gfx950_handle_t handle, int64_t m, int64_t n, 
   return SPBLAS_GFX950_STATUS_SUCCESS;
 }
 
+// scale(alpha, t): 16-byte accesses over the aligned body, scalar head and tail
+template <typename T>
+__global__ __launch_bounds__(256) void scale_kernel(int64_t n, T alpha, T* __restrict__ v) {
+  constexpr int V = 16 / (int) sizeof(T);
+  typedef T vec_t __attribute__((ext_vector_type(V)));
+  const int64_t head = ((16 - (reinterpret_cast<uintptr_t>(v) & 15)) & 15) / sizeof(T);
+  const int64_t h = head < n ? head : n;
+  const int64_t nv = (n - h) / V;
+  const int64_t tid = (int64_t) blockIdx.x * 256 + threadIdx.x, stride = (int64_t) gridDim.x * 256;
+  vec_t* body = reinterpret_cast<vec_t*>(v + h);
+  for (int64_t i = tid; i < nv; i += stride)
+    body[i] = body[i] * alpha;
+  if (tid < h)
+    v[tid] *= alpha;
+  const int64_t t0 = h + nv * V;
+  if (t0 + tid < n && tid < V)
+    v[t0 + tid] *= alpha;
+}
+
 } // namespace spb
 
 using namespace spb;
@@ -135,4 +154,33 @@ extern "C" int spblas_gfx950_csr_transpose(spblas_gfx950_handle_t handle, int64_
                                   t_colind, static_cast<float*>(t_values));
   return transpose_typed<double>(handle, m, n, nnz, rowptr, colind, static_cast<const double*>(values), t_rowptr,
                                  t_colind, static_cast<double*>(t_values));
+}
+
+extern "C" int spblas_gfx950_scale(spblas_gfx950_handle_t handle, int64_t n, const void* alpha, void* values,
+                                   int value_type) {
+  if (!handle)
+    return SPBLAS_GFX950_STATUS_INVALID_HANDLE;
+  if (n < 0)
+    return SPBLAS_GFX950_STATUS_INVALID_SIZE;
+  if (value_type != SPBLAS_GFX950_F32 && value_type != SPBLAS_GFX950_F64)
+    return SPBLAS_GFX950_STATUS_INVALID_VALUE;
+  if (!alpha || (n > 0 && !values))
+    return SPBLAS_GFX950_STATUS_INVALID_POINTER;
+  if (n == 0)
+    return SPBLAS_GFX950_STATUS_SUCCESS;
+  const int64_t per = value_type == SPBLAS_GFX950_F32 ? 4 : 2;
+  int64_t blocks = cdiv(cdiv(n, per), 256);
+  const int64_t cap = (int64_t) (handle->num_cus > 0 ? handle->num_cus : 256) * 16;
+  if (blocks > cap)
+    blocks = cap;
+  if (blocks < 1)
+    blocks = 1;
+  if (value_type == SPBLAS_GFX950_F32)
+    hipLaunchKernelGGL(scale_kernel<float>, dim3((unsigned) blocks), dim3(256), 0, handle->stream, n,
+                       *static_cast<const float*>(alpha), static_cast<float*>(values));
+  else
+    hipLaunchKernelGGL(scale_kernel<double>, dim3((unsigned) blocks), dim3(256), 0, handle->stream, n,
+                       *static_cast<const double*>(alpha), static_cast<double*>(values));
+  SPB_HIP(hipGetLastError());
+  return SPBLAS_GFX950_STATUS_SUCCESS;
 }

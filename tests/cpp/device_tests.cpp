@@ -542,7 +542,32 @@ static void test_transpose() {
   }
 }
 
+// scale(alpha, t) (algorithms/scale_impl.hpp:13-31): one IEEE multiply per stored value, in place
+static void test_scale() {
+  for (auto&& [m, k, nnz] : dims) {
+    auto h = generate_csr(m, k, nnz);
+    device_csr a(h);
+    spblas::scale(2.5f, a.view);
+    auto v = a.values.download();
+    bool same = true;
+    for (int i = 0; i < nnz; i++)
+      same &= v[i] == h.values[i] * 2.5f;
+    CHECK(same);
+    std::vector<value_t> xh(k);
+    for (int i = 0; i < k; i++)
+      xh[i] = (value_t) (i % 7) - 3;
+    dvec<value_t> x(xh);
+    spblas::scale(-0.5f, std::span<value_t>(x.p, (size_t) k));
+    auto xs = x.download();
+    same = true;
+    for (int i = 0; i < k; i++)
+      same &= xs[i] == xh[i] * -0.5f;
+    CHECK(same);
+  }
+}
+
 int main() {
+  test_scale();
   test_spmv();
   test_spmm();
   test_spgemm();

@@ -113,3 +113,27 @@ def test_spmm_with_csc_operand(gpu, inspect):
     import scipy.sparse as sps
     ab = 0.5 * (sps.csr_matrix((np.abs(tv).astype(np.float64), tc, tr), shape=(200, 300)) @ np.abs(B_h).astype(np.float64))
     util.assert_parity(G.host(C), C_ref, ab, np.float32, row_len=np.diff(tr), what="csc spmm")
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_scale_in_place_matrix_and_vector(gpu, dtype):
+    """scale(alpha, t) (algorithms/scale_impl.hpp:13-31): values[i] *= alpha, bit-exact (one IEEE multiply
+    per element); odd lengths and unaligned starts exercise the scalar head and tail of the kernel."""
+    rng = np.random.default_rng(5)
+    for n, off in [(1, 0), (3, 1), (1000, 0), (4099, 3), (1 << 20, 1)]:
+        v = rng.standard_normal(n + off).astype(dtype)
+        d = G.dev(v)
+        view = d[off:]
+        sp.scale(-1.75, view)
+        exp = v.copy()
+        exp[off:] *= dtype(-1.75)
+        assert np.array_equal(G.host(d), exp)
+    a_h = generate.generate_csr(300, 200, 5000, dtype=dtype)[:4]
+    d_a = G.csr_on_device(*a_h, len(a_h[0]))
+    sp.scale(3.0, d_a)
+    assert np.array_equal(G.host(d_a.values()), a_h[0] * dtype(3.0))
+    x = G.dev((rng.random(200) + 0.5).astype(dtype))  # sign-definite: the reference's comparator applies
+    y = torch.empty(300, dtype=x.dtype, device="cuda")
+    sp.multiply(d_a, x, y)
+    ref = oracle.spmv((300, 200), a_h[1], a_h[2], a_h[0] * dtype(3.0), G.host(x))
+    util.expect_eq_ref(ref, G.host(y))
