@@ -129,36 +129,174 @@ __global__ __launch_bounds__(256) void pb_scatter_kernel(int64_t m, const O* __r
   }
 }
 
-// locality probe: number of non-empty (slice, bin) segments
-__global__ __launch_bounds__(256) void pb_nonempty_kernel(int64_t nseg, const int32_t* __restrict__ cnt,
-                                                          unsigned long long* __restrict__ out) {
-  const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
-  const bool ne = i < nseg && cnt[i] > 0;
-  const unsigned long long c = __popcll(__ballot(ne));
-  if ((threadIdx.x & 63) == 0 && c)
-    atomicAdd(out, c);
+// Staged variant of the scatter (S <= PB_STAGE_MAX_S): the direct kernel above issues four 2..4-byte
+// stores per entry to ~S different runs, which the memory side turns into one 32-byte write each
+// (rocprofv3: 361 M write requests, 11.5 GB for 1.2 GB of payload at cfg2, 5.7 ms).  Here a workgroup of
+// 1 024 threads owns the whole LDS of a CU and makes a few passes over its bin: pass k stages the positions
+// of the entries of the slices [s0, s1) -- as many as fit -- grouped by run in LDS, then every wave writes
+// whole runs with contiguous stores (gathering value and column again: L2 hits; the row is found by a binary
+// search in an LDS copy of the bin's row offsets).  colind is re-read once per pass (coalesced).
+static constexpr int PB_STAGE_THREADS = 1024;
+static constexpr int PB_STAGE_LDS = 160 * 1024;
+static constexpr int PB_STAGE_MAX_S = 2048;
+
+template <typename T, typename O>
+__global__ __launch_bounds__(PB_STAGE_THREADS) void pb_scatter_staged_kernel(
+    int64_t m, const O* __restrict__ rowptr, const int32_t* __restrict__ colind, const T* __restrict__ values, int W,
+    int H, int S, int NB, const int32_t* __restrict__ seg, T* __restrict__ s_val, uint16_t* __restrict__ s_col,
+    uint16_t* __restrict__ s_row, int32_t* __restrict__ perm, int hub_len, int cap) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  int* lcnt = reinterpret_cast<int*>(smem);  // [S] entries of this bin per slice
+  int* gdst = lcnt + S;                      // [S] start of the run in A' order
+  int* lcur = gdst + S;                      // [S] staging cursor (local offset, advanced by the atomics)
+  int* rp = lcur + S;                        // [H + 1] the bin's row offsets relative to its first entry
+  int* st = rp + H + 1;                      // [cap] staged entries (position relative to the first entry)
+  __shared__ int pass_end, pass_direct;
+  const int wb = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t r0 = (int64_t) wb * H, r1 = (r0 + H) < m ? (r0 + H) : m;
+  if (r0 >= m)
+    return;
+  const int nr = (int) (r1 - r0);
+  const O p0 = rowptr[r0], p1 = rowptr[r1];
+  const int ne = (int) (p1 - p0);
+  for (int i = tid; i < S; i += PB_STAGE_THREADS) {
+    const int a = seg[(int64_t) i * NB + wb], b = seg[(int64_t) i * NB + wb + 1];
+    gdst[i] = a;
+    lcnt[i] = b - a;
+  }
+  for (int i = tid; i <= nr; i += PB_STAGE_THREADS)
+    rp[i] = (int) (rowptr[r0 + i] - p0);
+  __syncthreads();
+  // row (inside the bin) of the entry at relative position q: last i with rp[i] <= q
+  auto row_of = [&](int q) {
+    int lo = 0, hi = nr;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (rp[mid] <= q)
+        lo = mid;
+      else
+        hi = mid;
+    }
+    return lo;
+  };
+  int s0 = 0;
+  while (s0 < S) {
+    // wave 0: the longest slice range [s0, s1) whose entries fit the staging area, and their local offsets
+    if (wave == 0) {
+      int total = 0, s1 = s0;
+      bool open = true;
+      while (open && s1 < S) {
+        const int i = s1 + lane;
+        const int c = i < S ? lcnt[i] : 0;
+        int incl = c;
+        for (int o = 1; o < 64; o <<= 1) {
+          const int t = __shfl_up(incl, o, 64);
+          if (lane >= o)
+            incl += t;
+        }
+        const bool fits = i < S && total + incl <= cap;
+        const unsigned long long fm = __ballot(fits);
+        // lanes are monotone: the first lane that does not fit ends the range
+        const int nfit = fm == ~0ull ? 64 : __builtin_ctzll(~fm);
+        if (lane < nfit)
+          lcur[i] = total + incl - c;
+        total += __shfl(incl, nfit > 0 ? nfit - 1 : 0, 64) * (nfit > 0);
+        s1 += nfit;
+        open = nfit == 64;
+      }
+      if (lane == 0) {
+        // a single run larger than the staging area goes straight to memory
+        pass_direct = s1 == s0;
+        if (s1 == s0) {
+          lcur[s0] = 0;
+          s1 = s0 + 1;
+        }
+        pass_end = s1;
+      }
+    }
+    __syncthreads();
+    const int s1 = pass_end;
+    const bool direct = pass_direct != 0;
+    for (int q = tid; q < ne; q += PB_STAGE_THREADS) {
+      const int c = colind[p0 + q];
+      const int sl = c / W;
+      if (sl < s0 || sl >= s1)
+        continue;
+      int r = -1;
+      if (hub_len > 0 || direct) {
+        r = row_of(q);
+        if (hub_len > 0 && rp[r + 1] - rp[r] > hub_len)
+          continue;
+      }
+      const int pos = atomicAdd(&lcur[sl], 1);
+      if (direct) {
+        const int i = gdst[sl] + pos;
+        s_val[i] = values[p0 + q];
+        s_col[i] = (uint16_t) (c - sl * W);
+        s_row[i] = (uint16_t) r;
+        perm[i] = (int32_t) (p0 + q);
+      } else {
+        st[pos] = q;
+      }
+    }
+    __syncthreads();
+    if (!direct)
+      for (int sl = s0 + wave; sl < s1; sl += PB_STAGE_THREADS / 64) {
+        const int n = lcnt[sl], lo = lcur[sl] - n, g = gdst[sl], c0 = sl * W;
+        for (int j = lane; j < n; j += 64) {
+          const int q = st[lo + j];
+          s_val[g + j] = values[p0 + q];  // the bin's arrays were read a moment ago: L2 hits
+          s_col[g + j] = (uint16_t) (colind[p0 + q] - c0);
+          s_row[g + j] = (uint16_t) row_of(q);
+          perm[g + j] = (int32_t) (p0 + q);
+        }
+      }
+    __syncthreads();
+    s0 = s1;
+  }
 }
 
-// balance probe: entries per slice and per bin group (RW bins = one reduce workgroup).  One workgroup per
-// slice walks that slice's NB counters.
-__global__ __launch_bounds__(256) void pb_balance_kernel(int NB, int RW, const int32_t* __restrict__ cnt,
+// balance probe: entries per slice and per bin group (RW bins = one reduce workgroup).  Workgroups
+// [0, S) sum one slice each (a contiguous row of NB counters), workgroups [S, S + ngroups) one bin group
+// each (RW counters out of every slice's row); no atomics (the first version added every counter to its
+// group with a global atomic: 0.59 ms at cfg2).
+__global__ __launch_bounds__(256) void pb_balance_kernel(int S, int NB, int RW, const int32_t* __restrict__ cnt,
                                                          unsigned long long* __restrict__ slice_sum,
+                                                         unsigned long long* __restrict__ slice_ne,
                                                          unsigned long long* __restrict__ group_sum) {
   __shared__ unsigned long long red[4];
-  const int sl = blockIdx.x;
-  unsigned long long tot = 0;
-  for (int b = threadIdx.x; b < NB; b += 256) {
-    const unsigned long long c = (unsigned long long) cnt[(int64_t) sl * NB + b];
-    tot += c;
-    if (c)
-      atomicAdd(&group_sum[b / RW], c);
+  __shared__ unsigned long long red_ne[4];
+  unsigned long long tot = 0, ne = 0;  // ne: non-empty (slice, bin) tiles -- the locality probe
+  if ((int) blockIdx.x < S) {
+    const int sl = blockIdx.x;
+    for (int b = threadIdx.x; b < NB; b += 256) {
+      const unsigned long long c = (unsigned long long) cnt[(int64_t) sl * NB + b];
+      tot += c;
+      ne += c != 0;
+    }
+  } else {
+    const int64_t g = (int64_t) blockIdx.x - S;
+    const int64_t b0 = g * RW;
+    const int nb = (int) ((b0 + RW) <= NB ? RW : (NB - b0));
+    for (int i = threadIdx.x; i < S * nb; i += 256)
+      tot += (unsigned long long) cnt[(int64_t) (i / nb) * NB + b0 + (i % nb)];
   }
   tot = group_sum_c<64>(tot);
-  if ((threadIdx.x & 63) == 0)
+  ne = group_sum_c<64>(ne);
+  if ((threadIdx.x & 63) == 0) {
     red[threadIdx.x >> 6] = tot;
+    red_ne[threadIdx.x >> 6] = ne;
+  }
   __syncthreads();
-  if (threadIdx.x == 0)
-    slice_sum[sl] = red[0] + red[1] + red[2] + red[3];
+  if (threadIdx.x == 0) {
+    const unsigned long long t = red[0] + red[1] + red[2] + red[3];
+    if ((int) blockIdx.x < S) {
+      slice_sum[blockIdx.x] = t;
+      slice_ne[blockIdx.x] = red_ne[0] + red_ne[1] + red_ne[2] + red_ne[3];
+    } else {
+      group_sum[blockIdx.x - S] = t;
+    }
+  }
 }
 
 // entries of bin group g (RW bins) in slice s, from the exclusive offsets: out[g*S + s]
@@ -772,45 +910,44 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
   }
   hipLaunchKernelGGL((pb_count_kernel<O>), dim3((unsigned) NB), dim3(256), (size_t) S * 4, s, m, rowptr, pl->colind, W, H, S,
                      NB, seg, pl->hub_len);
-  if (auto_mode) {
-    // AUTO only: a matrix whose entries cluster in few (slice, bin) tiles (banded, block
-    // structured) already gets its x reuse from L2 with the CSR kernels -- decline.
-    unsigned long long* d_ne = nullptr;
-    unsigned long long ne = 0;
-    if ((rc = dev_alloc((void**) &d_ne, sizeof(unsigned long long), s)))
+  // One probe pass over the counters, read back once: entries per slice, non-empty tiles per slice, entries
+  // per bin group.  AUTO uses them to decline matrices the plan does not suit; the work lists below use them
+  // to spot column / row skew, and their total is the number of entries placed in tiles.
+  const int64_t ngroups = cdiv(NB, RW);
+  std::vector<unsigned long long> h_sum((size_t) (2 * S + ngroups));
+  {
+    unsigned long long* d_sum = nullptr;
+    if ((rc = dev_alloc((void**) &d_sum, h_sum.size() * sizeof(unsigned long long), s)))
       return rc;
-    SPB_HIP(hipMemsetAsync(d_ne, 0, sizeof(unsigned long long), s));
-    hipLaunchKernelGGL(pb_nonempty_kernel, dim3((unsigned) cdiv(nseg, 256)), dim3(256), 0, s, nseg, seg, d_ne);
-    SPB_HIP(hipMemcpyAsync(&ne, d_ne, sizeof(ne), hipMemcpyDeviceToHost, s));
+    hipLaunchKernelGGL(pb_balance_kernel, dim3((unsigned) (S + ngroups)), dim3(256), 0, s, S, NB, RW, seg, d_sum,
+                       d_sum + S, d_sum + 2 * S);
+    SPB_HIP(hipMemcpyAsync(h_sum.data(), d_sum, h_sum.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     SPB_HIP(hipStreamSynchronize(s));
-    dev_free(d_ne, s);
+    dev_free(d_sum, s);
+  }
+  unsigned long long placed_total = 0, max_slice = 0, max_group = 0, ne = 0;
+  for (int i = 0; i < S; ++i) {
+    placed_total += h_sum[(size_t) i];
+    max_slice = std::max(max_slice, h_sum[(size_t) i]);
+    ne += h_sum[(size_t) (S + i)];
+  }
+  for (int64_t g = 0; g < ngroups; ++g)
+    max_group = std::max(max_group, h_sum[(size_t) (2 * S + g)]);
+  if (placed_total > (unsigned long long) INT32_MAX)
+    return SPBLAS_GFX950_STATUS_NOT_SUPPORTED;
+  pl->s_placed = (int64_t) placed_total;
+  if (auto_mode) {
+    // a matrix whose entries cluster in few (slice, bin) tiles (banded, block structured) already gets
+    // its x reuse from L2 with the CSR kernels -- decline
     if ((double) ne < 0.25 * (double) nseg)
       return SPBLAS_GFX950_STATUS_NOT_SUPPORTED;
     // ... and a matrix whose entries pile up in a few slices (hot columns) or a few bin groups (heavy
     // rows below the hub threshold) would leave most of the chip waiting for one expand / reduce
     // workgroup: decline when the heaviest slice or group carries more than 6x the average.
-    {
-      const int64_t ngroups = cdiv(NB, RW);
-      unsigned long long* d_sum = nullptr;
-      if ((rc = dev_alloc((void**) &d_sum, (size_t) (S + ngroups) * sizeof(unsigned long long), s)))
-        return rc;
-      SPB_HIP(hipMemsetAsync(d_sum, 0, (size_t) (S + ngroups) * sizeof(unsigned long long), s));
-      hipLaunchKernelGGL(pb_balance_kernel, dim3((unsigned) S), dim3(256), 0, s, NB, RW, seg, d_sum, d_sum + S);
-      std::vector<unsigned long long> h_sum((size_t) (S + ngroups));
-      SPB_HIP(hipMemcpyAsync(h_sum.data(), d_sum, h_sum.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-      SPB_HIP(hipStreamSynchronize(s));
-      dev_free(d_sum, s);
-      unsigned long long tot = 0, max_slice = 0, max_group = 0;
-      for (int i = 0; i < S; ++i) {
-        tot += h_sum[(size_t) i];
-        max_slice = h_sum[(size_t) i] > max_slice ? h_sum[(size_t) i] : max_slice;
-      }
-      for (int64_t g = 0; g < ngroups; ++g)
-        max_group = h_sum[(size_t) (S + g)] > max_group ? h_sum[(size_t) (S + g)] : max_group;
-      const double mean_slice = (double) tot / (double) S, mean_group = (double) tot / (double) ngroups;
-      if (tot > 0 && ((double) max_slice > 6.0 * mean_slice + 65536.0 || (double) max_group > 6.0 * mean_group + 65536.0))
-        return SPBLAS_GFX950_STATUS_NOT_SUPPORTED;
-    }
+    const double mean_slice = (double) placed_total / (double) S, mean_group = (double) placed_total / (double) ngroups;
+    if (placed_total > 0 &&
+        ((double) max_slice > 6.0 * mean_slice + 65536.0 || (double) max_group > 6.0 * mean_group + 65536.0))
+      return SPBLAS_GFX950_STATUS_NOT_SUPPORTED;
   }
   if ((rc = dev_alloc((void**) &partials, (size_t) (cdiv(nseg, 2048) + 2) * sizeof(long long), s)))
     return rc;
@@ -829,22 +966,15 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
   if ((rc = dev_alloc((void**) &pl->s_segT, (size_t) nseg * sizeof(int2), s)))
     return rc;
   pl->device_bytes += (size_t) nnz * (2 * sizeof(T) + 8) + (size_t) nseg * 16;
-  {
-    long long* total_dev = scan_counts_i32(s, nseg, seg, partials);
-    long long placed = 0;
-    SPB_HIP(hipMemcpyAsync(&placed, total_dev, sizeof(placed), hipMemcpyDeviceToHost, s));
-    SPB_HIP(hipStreamSynchronize(s));
-    pl->s_placed = placed;
-  }
+  (void) scan_counts_i32(s, nseg, seg, partials);  // the total is already known from the probe
   {
     // column skew: slice sizes from the segment offsets; when one slice is far above the average the
     // expand gets an explicit work list with workgroups in proportion to the slice sizes
-    std::vector<int32_t> start((size_t) S + 1);
-    SPB_HIP(hipMemcpy2DAsync(start.data(), 4, seg, (size_t) NB * 4, 4, (size_t) S + 1, hipMemcpyDeviceToHost, s));
-    SPB_HIP(hipStreamSynchronize(s));
-    int64_t max_len = 0;
+    // A' is slice-major: a slice starts where the entries of the slices before it end
+    std::vector<int64_t> start((size_t) S + 1, 0);
     for (int i = 0; i < S; ++i)
-      max_len = std::max<int64_t>(max_len, start[(size_t) i + 1] - start[(size_t) i]);
+      start[(size_t) i + 1] = start[(size_t) i] + (int64_t) h_sum[(size_t) i];
+    const int64_t max_len = (int64_t) max_slice;
     const int64_t total = start[(size_t) S];
     if (total > 0 && max_len * S > 3 * total) {
       const int cus = h->num_cus > 0 ? h->num_cus : 256;
@@ -874,25 +1004,23 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
   {
     // row skew: entries per (bin group, slice).  When one group is far above the average the reduce gets a
     // work list: every group is cut into as many slice ranges as its share of the entries asks for.
-    const int64_t ngroups = cdiv(NB, RW), cells = ngroups * S;
-    int32_t* d_gs = nullptr;
-    if ((rc = dev_alloc((void**) &d_gs, (size_t) cells * 4, s)))
-      return rc;
-    hipLaunchKernelGGL(pb_group_slice_kernel, dim3((unsigned) cdiv(cells, 256)), dim3(256), 0, s, S, NB, RW, ngroups, seg,
-                       d_gs);
-    std::vector<int32_t> gs((size_t) cells);
-    SPB_HIP(hipMemcpyAsync(gs.data(), d_gs, (size_t) cells * 4, hipMemcpyDeviceToHost, s));
-    SPB_HIP(hipStreamSynchronize(s));
-    dev_free(d_gs, s);
+    // (the group totals come from the probe; the per-slice breakdown is only fetched for skewed matrices)
+    const int64_t cells = ngroups * S;
     std::vector<int64_t> tot((size_t) ngroups, 0);
-    int64_t total = 0, max_tot = 0;
-    for (int64_t g = 0; g < ngroups; ++g) {
-      int64_t t = 0;
-      for (int sl = 0; sl < S; ++sl)
-        t += gs[(size_t) (g * S + sl)];
-      tot[(size_t) g] = t;
-      total += t;
-      max_tot = std::max(max_tot, t);
+    const int64_t total = (int64_t) placed_total, max_tot = (int64_t) max_group;
+    for (int64_t g = 0; g < ngroups; ++g)
+      tot[(size_t) g] = (int64_t) h_sum[(size_t) (2 * S + g)];
+    std::vector<int32_t> gs;
+    if (total > 0 && max_tot * ngroups > 3 * total && S >= 16) {
+      int32_t* d_gs = nullptr;
+      if ((rc = dev_alloc((void**) &d_gs, (size_t) cells * 4, s)))
+        return rc;
+      hipLaunchKernelGGL(pb_group_slice_kernel, dim3((unsigned) cdiv(cells, 256)), dim3(256), 0, s, S, NB, RW, ngroups,
+                         seg, d_gs);
+      gs.resize((size_t) cells);
+      SPB_HIP(hipMemcpyAsync(gs.data(), d_gs, (size_t) cells * 4, hipMemcpyDeviceToHost, s));
+      SPB_HIP(hipStreamSynchronize(s));
+      dev_free(d_gs, s);
     }
     if (total > 0 && max_tot * ngroups > 3 * total && S >= 16) {
       const int64_t target = std::max<int64_t>(total / 768, 16384);
@@ -951,6 +1079,15 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
       }
     }
   }
+  if (S <= PB_STAGE_MAX_S && env_int("SPBLAS_GFX950_PB_STAGED_SCATTER", 1)) {
+    const int cap = (int) (((size_t) PB_STAGE_LDS - (size_t) 12 * S - (size_t) 4 * (H + 1) - 128) / 4) & ~7;
+    SPB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pb_scatter_staged_kernel<T, O>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, PB_STAGE_LDS - 64));
+    hipLaunchKernelGGL((pb_scatter_staged_kernel<T, O>), dim3((unsigned) NB), dim3(PB_STAGE_THREADS),
+                       (size_t) PB_STAGE_LDS - 64, s, m, rowptr, pl->colind, static_cast<const T*>(values_p), W, H, S,
+                       NB, seg, static_cast<T*>(pl->s_values), reinterpret_cast<uint16_t*>(pl->s_colind), pl->s_lrow,
+                       reinterpret_cast<int32_t*>(pl->s_perm), pl->hub_len, cap);
+  } else
   hipLaunchKernelGGL((pb_scatter_kernel<T, O>), dim3((unsigned) NB), dim3(256), (size_t) S * 4, s, m, rowptr,
                      pl->colind, static_cast<const T*>(values_p), W, H, S, NB, seg, static_cast<T*>(pl->s_values),
                      reinterpret_cast<uint16_t*>(pl->s_colind), pl->s_lrow, reinterpret_cast<int32_t*>(pl->s_perm),
