@@ -132,10 +132,10 @@ __global__ __launch_bounds__(256) void pb_scatter_kernel(int64_t m, const O* __r
 // Staged variant of the scatter (S <= PB_STAGE_MAX_S): the direct kernel above issues four 2..4-byte
 // stores per entry to ~S different runs, which the memory side turns into one 32-byte write each
 // (rocprofv3: 361 M write requests, 11.5 GB for 1.2 GB of payload at cfg2, 5.7 ms).  Here a workgroup of
-// 1 024 threads owns the whole LDS of a CU and makes a few passes over its bin: pass k stages the positions
-// of the entries of the slices [s0, s1) -- as many as fit -- grouped by run in LDS, then every wave writes
-// whole runs with contiguous stores (gathering value and column again: L2 hits; the row is found by a binary
-// search in an LDS copy of the bin's row offsets).  colind is re-read once per pass (coalesced).
+// 1 024 threads owns the whole LDS of a CU and makes a few passes over its bin: pass k stages the entries
+// (position, value, column inside the slice) of the slices [s0, s1) -- as many as fit -- grouped by run in
+// LDS, then every wave writes whole runs with contiguous stores; the row comes from a binary search in an
+// LDS copy of the bin's row offsets.  colind is re-read once per pass (coalesced).
 static constexpr int PB_STAGE_THREADS = 1024;
 static constexpr int PB_STAGE_LDS = 160 * 1024;
 static constexpr int PB_STAGE_MAX_S = 2048;
@@ -144,13 +144,16 @@ template <typename T, typename O>
 __global__ __launch_bounds__(PB_STAGE_THREADS) void pb_scatter_staged_kernel(
     int64_t m, const O* __restrict__ rowptr, const int32_t* __restrict__ colind, const T* __restrict__ values, int W,
     int H, int S, int NB, const int32_t* __restrict__ seg, T* __restrict__ s_val, uint16_t* __restrict__ s_col,
-    uint16_t* __restrict__ s_row, int32_t* __restrict__ perm, int hub_len, int cap) {
+    uint16_t* __restrict__ s_row, int32_t* __restrict__ perm, int hub_len, int cap, int rt_len) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   int* lcnt = reinterpret_cast<int*>(smem);  // [S] entries of this bin per slice
   int* gdst = lcnt + S;                      // [S] start of the run in A' order
   int* lcur = gdst + S;                      // [S] staging cursor (local offset, advanced by the atomics)
   int* rp = lcur + S;                        // [H + 1] the bin's row offsets relative to its first entry
-  int* st = rp + H + 1;                      // [cap] staged entries (position relative to the first entry)
+  int* rt = rp + H + 1;                      // [rt_len] row of every 64th entry (narrows the row search)
+  int* st = rt + rt_len;                     // [cap] staged entries: position relative to the first entry,
+  T* stv = reinterpret_cast<T*>(st + cap);   // [cap] value,
+  uint16_t* stc = reinterpret_cast<uint16_t*>(stv + cap);  // [cap] column inside the slice
   __shared__ int pass_end, pass_direct;
   const int wb = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t r0 = (int64_t) wb * H, r1 = (r0 + H) < m ? (r0 + H) : m;
@@ -159,6 +162,8 @@ __global__ __launch_bounds__(PB_STAGE_THREADS) void pb_scatter_staged_kernel(
   const int nr = (int) (r1 - r0);
   const O p0 = rowptr[r0], p1 = rowptr[r1];
   const int ne = (int) (p1 - p0);
+  if (ne == 0)
+    return;  // nothing to place (and p0 may be the end of the arrays: the clamped gathers below need ne > 0)
   for (int i = tid; i < S; i += PB_STAGE_THREADS) {
     const int a = seg[(int64_t) i * NB + wb], b = seg[(int64_t) i * NB + wb + 1];
     gdst[i] = a;
@@ -167,9 +172,8 @@ __global__ __launch_bounds__(PB_STAGE_THREADS) void pb_scatter_staged_kernel(
   for (int i = tid; i <= nr; i += PB_STAGE_THREADS)
     rp[i] = (int) (rowptr[r0 + i] - p0);
   __syncthreads();
-  // row (inside the bin) of the entry at relative position q: last i with rp[i] <= q
-  auto row_of = [&](int q) {
-    int lo = 0, hi = nr;
+  // row (inside the bin) of the entry at relative position q: last i in [lo, hi) with rp[i] <= q
+  auto row_between = [&](int q, int lo, int hi) {
     while (hi - lo > 1) {
       const int mid = (lo + hi) >> 1;
       if (rp[mid] <= q)
@@ -178,6 +182,21 @@ __global__ __launch_bounds__(PB_STAGE_THREADS) void pb_scatter_staged_kernel(
         hi = mid;
     }
     return lo;
+  };
+  // rt[k] = row of entry 64k (k beyond the table or the bin: the last row), so that the search for an entry
+  // only covers the rows its block of 64 entries spans
+  const int nblk = (ne + 63) >> 6;
+  const bool use_rt = nblk + 1 <= rt_len;
+  if (use_rt) {
+    for (int k = tid; k <= nblk; k += PB_STAGE_THREADS)
+      rt[k] = k < nblk ? row_between(k << 6, 0, nr) : (nr > 0 ? nr - 1 : 0);
+    __syncthreads();
+  }
+  auto row_of = [&](int q) {
+    if (!use_rt)
+      return row_between(q, 0, nr);
+    const int k = q >> 6;
+    return row_between(q, rt[k], rt[k + 1] + 1);
   };
   int s0 = 0;
   while (s0 < S) {
@@ -217,8 +236,22 @@ __global__ __launch_bounds__(PB_STAGE_THREADS) void pb_scatter_staged_kernel(
     __syncthreads();
     const int s1 = pass_end;
     const bool direct = pass_direct != 0;
-    for (int q = tid; q < ne; q += PB_STAGE_THREADS) {
-      const int c = colind[p0 + q];
+    // eight column loads per thread are issued before the first is used: with one workgroup per CU the
+    // loop is bound by load latency, not bandwidth
+    constexpr int LU = 8;
+    for (int qb = tid; qb < ne; qb += LU * PB_STAGE_THREADS) {
+      int cbuf[LU];
+#pragma unroll
+      for (int u = 0; u < LU; ++u) {
+        const int qq = qb + u * PB_STAGE_THREADS;
+        cbuf[u] = colind[p0 + (qq < ne ? qq : ne - 1)];
+      }
+#pragma unroll
+      for (int u = 0; u < LU; ++u) {
+      const int q = qb + u * PB_STAGE_THREADS;
+      if (q >= ne)
+        break;
+      const int c = cbuf[u];
       const int sl = c / W;
       if (sl < s0 || sl >= s1)
         continue;
@@ -237,21 +270,31 @@ __global__ __launch_bounds__(PB_STAGE_THREADS) void pb_scatter_staged_kernel(
         perm[i] = (int32_t) (p0 + q);
       } else {
         st[pos] = q;
+        stv[pos] = values[p0 + q];  // neighbouring threads: neighbouring addresses
+        stc[pos] = (uint16_t) (c - sl * W);
+      }
       }
     }
     __syncthreads();
-    if (!direct)
-      for (int sl = s0 + wave; sl < s1; sl += PB_STAGE_THREADS / 64) {
-        const int n = lcnt[sl], lo = lcur[sl] - n, g = gdst[sl], c0 = sl * W;
+    if (!direct) {
+      // every wave writes whole runs from the staging area (contiguous stores, no global gathers: fetching
+      // value and column again by position cost 2.4 of the kernel's 2.75 ms -- random 4-byte reads, even
+      // L2 hits, run at ~10 cycles per request and CU)
+      constexpr int NW = PB_STAGE_THREADS / 64;
+      for (int sl = s0 + wave; sl < s1; sl += NW) {
+        const int n = lcnt[sl], lo = lcur[sl] - n, g = gdst[sl];
         for (int j = lane; j < n; j += 64) {
           const int q = st[lo + j];
-          s_val[g + j] = values[p0 + q];  // the bin's arrays were read a moment ago: L2 hits
-          s_col[g + j] = (uint16_t) (colind[p0 + q] - c0);
+          s_val[g + j] = stv[lo + j];
+          s_col[g + j] = stc[lo + j];
           s_row[g + j] = (uint16_t) row_of(q);
           perm[g + j] = (int32_t) (p0 + q);
         }
       }
-    __syncthreads();
+    }
+    // end of the pass: the next one reuses the LDS staging area, so LDS traffic must be complete -- but not
+    // the global stores above; __syncthreads() would also wait for those (vmcnt(0)) in every wave
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     s0 = s1;
   }
 }
@@ -1111,13 +1154,16 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
     }
   }
   if (S <= PB_STAGE_MAX_S && env_int("SPBLAS_GFX950_PB_STAGED_SCATTER", 1)) {
-    const int cap = (int) (((size_t) PB_STAGE_LDS - (size_t) 12 * S - (size_t) 4 * (H + 1) - 128) / 4) & ~7;
+    // a quarter of the staging area at most goes to the row table (one entry per 64 matrix entries of a bin)
+    const int rt_len = 2048;
+    const int cap = (int) (((size_t) PB_STAGE_LDS - (size_t) 12 * S - (size_t) 4 * (H + 1) - (size_t) 4 * rt_len - 128) /
+                           (6 + sizeof(T))) & ~7;
     SPB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pb_scatter_staged_kernel<T, O>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, PB_STAGE_LDS - 64));
     hipLaunchKernelGGL((pb_scatter_staged_kernel<T, O>), dim3((unsigned) NB), dim3(PB_STAGE_THREADS),
                        (size_t) PB_STAGE_LDS - 64, s, m, rowptr, pl->colind, static_cast<const T*>(values_p), W, H, S,
                        NB, seg, static_cast<T*>(pl->s_values), reinterpret_cast<uint16_t*>(pl->s_colind), pl->s_lrow,
-                       reinterpret_cast<int32_t*>(pl->s_perm), pl->hub_len, cap);
+                       reinterpret_cast<int32_t*>(pl->s_perm), pl->hub_len, cap, rt_len);
   } else
   hipLaunchKernelGGL((pb_scatter_kernel<T, O>), dim3((unsigned) NB), dim3(256), (size_t) S * 4, s, m, rowptr,
                      pl->colind, static_cast<const T*>(values_p), W, H, S, NB, seg, static_cast<T*>(pl->s_values),
