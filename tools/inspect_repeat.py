@@ -1,3 +1,5 @@
+"""multiply_inspect (sliced plan) at cfg2, four times: first call, second plan beside the first, and after
+freeing (the stream-ordered pool then holds the plan memory): separates allocation cost from kernel time."""
 import time, torch, ctypes, os, sys
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import spblas_reference_amd as sp
