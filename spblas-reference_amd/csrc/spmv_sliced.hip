@@ -867,11 +867,14 @@ static int pick_ksplit(int64_t groups, int S);
 // Split `extent` into pieces of at most max_elems.  Big problems get a piece count that is a
 // multiple of round_to (whole waves of workgroups over the 256 CUs); trailing pieces may then
 // be empty, which every kernel tolerates.
-static void pick_tiling(int64_t extent, int max_elems, int round_to, int align, int* pieces, int* width) {
+// pieces = as few as fit max_elems, rounded up to a multiple of round_to once there are more than
+// round_from of them (whole waves of workgroups), width = the matching piece size (multiple of align)
+static void pick_tiling(int64_t extent, int max_elems, int round_to, int round_from, int align, int* pieces,
+                        int* width) {
   int64_t p = cdiv(extent, max_elems);
   if (p < 1)
     p = 1;
-  const bool rounded = p > round_to / 2;
+  const bool rounded = p > round_from;
   if (rounded)
     p = cdiv(p, round_to) * round_to;
   int64_t w = cdiv(extent, p);
@@ -914,7 +917,16 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
   int S, W, NB, H;
   const int w_env = env_int("SPBLAS_GFX950_SLICE_COLS", 0);  // test hooks: force small tiles
   const int h_env = env_int("SPBLAS_GFX950_SLICE_ROWS", 0);
-  pick_tiling(n, w_env > 0 && w_env < max_cols ? w_env : max_cols, 512, 4, &S, &W);
+  // Slices: up to one wave of expand workgroups (512) the widest slices win -- rounding 293 slices up to
+  // 512 narrower ones shortens every run of the reduce (n = 5.3 / 6 / 7 M: -10 / -10 / -7 % time
+  // unrounded, cfg2 with 489 instead of 512 slices -1.9 %, 8 / 9 M +2 %); beyond one wave the count
+  // is rounded to whole waves (n = 16 M: 782 slices run 13 % slower than 1 024).
+  // One wave = 2 workgroups per CU with 80 KiB slices, 1 with 160 KiB slices (fp64: 489 unrounded slices on
+  // 256 slots ran 13 % slower than 512).
+  const int xround = env_int("SPBLAS_GFX950_PB_XROUND", 512);
+  const int cus = h->num_cus > 0 ? h->num_cus : 256;
+  const int one_wave = xround > 1 ? cus * (xlds > PB_LDS_BYTES ? 1 : 2) : 1;
+  pick_tiling(n, w_env > 0 && w_env < max_cols ? w_env : max_cols, xround, one_wave, 4, &S, &W);
   // Matrices with few slices (n of a few million) would get runs of many hundred entries with
   // full-height bins: beyond the C prefetched chunks a run is read in a latency-exposed loop, and there
   // are too few bins to fill the chip.  Shorter bins bring the average run back to ~128 entries.
@@ -927,7 +939,8 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
       h_want = (int) (h < 64 ? 64 : (h > max_rows ? max_rows : h));
     }
   }
-  pick_tiling(m, h_env > 0 && h_env < max_rows ? h_env : h_want, env_int("SPBLAS_GFX950_PB_ROUND", 512) * RW, 1, &NB, &H);
+  const int bround = env_int("SPBLAS_GFX950_PB_ROUND", 512) * RW;
+  pick_tiling(m, h_env > 0 && h_env < max_rows ? h_env : h_want, bround, bround / 2, 1, &NB, &H);
   if (h->bin_row_align > 1) {
     // caller wants bin boundaries on multiples of bin_row_align (stripe boundaries of the overlapped
     // multi-GPU step): use the largest divisor of it that fits the LDS budget, if a decent one exists
