@@ -204,6 +204,21 @@ __global__ __launch_bounds__(256) void spg_hash_kernel(
   }
   if (lt == 0)
     cnt[team] = 0;
+  // sort workspace of the numeric phase (see below): zeroed here so that the compaction pass can count the
+  // buckets on the fly
+  constexpr int NBK = TPR < 64 ? TPR : 64;
+  int* bcnt = NUMERIC ? sortws + team * (2 * NBK + 2) : nullptr;  // [NBK+1] counts -> offsets
+  int* bfill = NUMERIC ? bcnt + NBK + 1 : nullptr;                // [NBK] cursors
+  // bucket of a key = floor(key * NBK / ncols), as a 32x32 -> high-32 multiply (a 64-bit division per
+  // key and pass costs more than the rest of the sort): monotone in the key, < NBK for key < ncols
+  const unsigned long long bm = ((unsigned long long) NBK << 32) / (unsigned long long) (ncols > 0 ? ncols : 1);
+  const unsigned bucket_mul = bm > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned) bm;
+  if (NUMERIC) {
+    if (lt <= NBK)
+      bcnt[lt] = 0;
+    if (lt < NBK)
+      bfill[lt] = 0;
+  }
   spg_team_sync<TPR>();
 
   if (live) {
@@ -312,6 +327,7 @@ __global__ __launch_bounds__(256) void spg_hash_kernel(
       const int pos = base + (int) __popcll(mask & ((1ull << wl) - 1ull));
       ckeys[pos] = key;
       cvals[pos] = tvals[i];
+      atomicAdd(&bcnt[(int) __umulhi((unsigned) key, bucket_mul)], 1);  // bucket sizes for the sort below
     }
     running += (int) __popcll(mask);
   }
@@ -326,23 +342,7 @@ __global__ __launch_bounds__(256) void spg_hash_kernel(
     // Sort the d unique keys: bucket them by column range (monotone, NBK buckets, LDS integer
     // atomics are fast), then rank each key inside its bucket only.  Uniform columns give buckets
     // of d/NBK keys; the worst case (one bucket) degrades to the plain O(d^2) rank sort.
-    constexpr int NBK = TPR < 64 ? TPR : 64;
-    // bucket of a key = floor(key * NBK / ncols), as a 32x32 -> high-32 multiply (a 64-bit division per
-    // key and pass costs more than the rest of the sort): monotone in the key, < NBK for key < ncols
-    const unsigned long long bm = ((unsigned long long) NBK << 32) / (unsigned long long) ncols;
-    const unsigned bucket_mul = bm > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned) bm;
-    int* bcnt = sortws + team * (2 * NBK + 2);  // [NBK+1] counts -> offsets
-    int* bfill = bcnt + NBK + 1;                // [NBK] cursors
-    spg_team_sync<TPR>();
-    if (lt <= NBK)
-      bcnt[lt] = 0;
-    if (lt < NBK)
-      bfill[lt] = 0;
-    spg_team_sync<TPR>();
-    if (live)
-      for (int e = lt; e < d; e += TPR)
-        atomicAdd(&bcnt[(int) __umulhi((unsigned) ckeys[e], bucket_mul)], 1);
-    spg_team_sync<TPR>();
+    spg_team_sync<TPR>();  // the bucket counts of the compaction pass are complete
     if (live && lt < NBK) {  // exclusive scan over the buckets inside the first NBK lanes of the team
       const int c = bcnt[lt];
       int incl = c;
