@@ -900,7 +900,12 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
   // x slice of the expand: 80 KiB for fp32 (two workgroups per CU); for fp64 the whole 160 KiB of a CU
   // (one workgroup), which halves the number of slices and doubles the run length again
   // (10M^2, 10/row: 755 -> 651 us; for fp32 the wider slice changed nothing)
-  const int xlds = env_int("SPBLAS_GFX950_PB_XLDS_KB", sizeof(T) == 8 ? 160 : PB_LDS_BYTES / 1024) * 1024;
+  // fp32 switches to 160 KiB slices as well once 80 KiB slices no longer fit one wave of expand workgroups
+  // (n > 10.5 M): twice the run length for the reduce (n = 11 / 12 / 16 / 20 / 40 M: +9 / +4 / +1 / +5 / +17 %),
+  // at 10 M the 80 KiB form is 5 % faster
+  const int cus0 = h->num_cus > 0 ? h->num_cus : 256;
+  const bool wide32 = sizeof(T) == 4 && cdiv(n, PB_LDS_BYTES / 4) > 2 * (int64_t) cus0;
+  const int xlds = env_int("SPBLAS_GFX950_PB_XLDS_KB", (sizeof(T) == 8 || wide32) ? 160 : PB_LDS_BYTES / 1024) * 1024;
   int max_cols = xlds / (int) sizeof(T);
   if (max_cols > 65536)
     max_cols = 65536;  // 16-bit local column
