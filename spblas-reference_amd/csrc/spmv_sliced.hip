@@ -413,66 +413,91 @@ __global__ __launch_bounds__(PB_THREADS) void pb_expand_kernel(int64_t n, int W,
                                                                const T* __restrict__ s_val,
                                                                const uint16_t* __restrict__ s_col,
                                                                const T* __restrict__ x, T* __restrict__ P,
-                                                               const int4* __restrict__ items) {
+                                                               const int4* __restrict__ items, int S, int share) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   T* xs = reinterpret_cast<T*>(smem);
-  // items (column-skewed matrices): workgroup i takes entries [items[i].y, items[i].z) of slice items[i].x,
-  // so that a slice holding a large share of the matrix is spread over proportionally many workgroups
-  const int4 item = items ? items[blockIdx.x] : make_int4((int) blockIdx.x, 0, 0, 0);
-  const int s = item.x;
   const int tid = threadIdx.x;
-  const int64_t c0 = (int64_t) s * W;
-  const int cw = (int) ((n - c0) < W ? (n - c0) : W);
-  for (int i = tid; i < cw; i += PB_THREADS)
-    xs[i] = x[c0 + i];
-  __syncthreads();
-  // gridDim.y workgroups share one slice (matrices with few slices would otherwise leave most CUs
-  // idle): each takes a contiguous part of the slice's range, cut on multiples of 4 entries
-  int a0 = seg[(int64_t) s * NB], a1 = seg[(int64_t) (s + 1) * NB];
-  if (items) {
-    a0 = item.y;
-    a1 = item.z;
-  } else if (gridDim.y > 1) {
-    const int len = a1 - a0;
-    const int per = (((len + (int) gridDim.y - 1) / (int) gridDim.y) + 3) & ~3;
-    const int lo = a0 + (int) blockIdx.y * per;
-    const int hi = lo + per < a1 ? lo + per : a1;
-    a0 = lo < a1 ? lo : a1;
-    a1 = hi > a0 ? hi : a0;
-  }
-  int body0 = (a0 + 3) & ~3;
-  if (body0 > a1)
-    body0 = a1;
-  const int body1 = body0 + ((a1 - body0) & ~3);
-  // unaligned head and tail (< 4 entries each)
-  if (tid < body0 - a0)
-    P[a0 + tid] = s_val[a0 + tid] * xs[s_col[a0 + tid]];
-  if (tid < a1 - body1)
-    P[body1 + tid] = s_val[body1 + tid] * xs[s_col[body1 + tid]];
-  // aligned body: 4 entries (16 B of values, 8 B of columns) per lane per step, 2 steps in flight
-  int i = body0 + 4 * tid;
-  for (; i + 4 * PB_THREADS < body1; i += 8 * PB_THREADS) {
-    T va[4], vb[4], pa[4], pb[4];
-    pack4<T>::load(s_val + i, va);
-    pack4<T>::load(s_val + i + 4 * PB_THREADS, vb);
-    const u16x4 ca = stream_load(reinterpret_cast<const u16x4*>(s_col + i));
-    const u16x4 cb = stream_load(reinterpret_cast<const u16x4*>(s_col + i + 4 * PB_THREADS));
+  auto load_x = [&](int s) {
+    const int64_t c0 = (int64_t) s * W;
+    const int cw = (int) ((n - c0) < W ? (n - c0) : W);
+    for (int i = tid; i < cw; i += PB_THREADS)
+      xs[i] = x[c0 + i];
+  };
+  // entries [a0, a1) of the slice whose x values are in LDS
+  auto process = [&](int a0, int a1) {
+    int body0 = (a0 + 3) & ~3;
+    if (body0 > a1)
+      body0 = a1;
+    const int body1 = body0 + ((a1 - body0) & ~3);
+    // unaligned head and tail (< 4 entries each)
+    if (tid < body0 - a0)
+      P[a0 + tid] = s_val[a0 + tid] * xs[s_col[a0 + tid]];
+    if (tid < a1 - body1)
+      P[body1 + tid] = s_val[body1 + tid] * xs[s_col[body1 + tid]];
+    // aligned body: 4 entries (16 B of values, 8 B of columns) per lane per step, 2 steps in flight
+    int i = body0 + 4 * tid;
+    for (; i + 4 * PB_THREADS < body1; i += 8 * PB_THREADS) {
+      T va[4], vb[4], pa[4], pb[4];
+      pack4<T>::load(s_val + i, va);
+      pack4<T>::load(s_val + i + 4 * PB_THREADS, vb);
+      const u16x4 ca = stream_load(reinterpret_cast<const u16x4*>(s_col + i));
+      const u16x4 cb = stream_load(reinterpret_cast<const u16x4*>(s_col + i + 4 * PB_THREADS));
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      pa[j] = va[j] * xs[ca[j]];
-      pb[j] = vb[j] * xs[cb[j]];
+      for (int j = 0; j < 4; ++j) {
+        pa[j] = va[j] * xs[ca[j]];
+        pb[j] = vb[j] * xs[cb[j]];
+      }
+      pack4<T>::store(P + i, pa);
+      pack4<T>::store(P + i + 4 * PB_THREADS, pb);
     }
-    pack4<T>::store(P + i, pa);
-    pack4<T>::store(P + i + 4 * PB_THREADS, pb);
-  }
-  for (; i < body1; i += 4 * PB_THREADS) {
-    T va[4], pa[4];
-    pack4<T>::load(s_val + i, va);
-    const u16x4 ca = stream_load(reinterpret_cast<const u16x4*>(s_col + i));
+    for (; i < body1; i += 4 * PB_THREADS) {
+      T va[4], pa[4];
+      pack4<T>::load(s_val + i, va);
+      const u16x4 ca = stream_load(reinterpret_cast<const u16x4*>(s_col + i));
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-      pa[j] = va[j] * xs[ca[j]];
-    pack4<T>::store(P + i, pa);
+      for (int j = 0; j < 4; ++j)
+        pa[j] = va[j] * xs[ca[j]];
+      pack4<T>::store(P + i, pa);
+    }
+  };
+  if (items) {
+    // items (column-skewed matrices): workgroup i takes entries [items[i].y, items[i].z) of slice items[i].x,
+    // so that a slice holding a large share of the matrix is spread over proportionally many workgroups
+    const int4 item = items[blockIdx.x];
+    load_x(item.x);
+    __syncthreads();
+    process(item.y, item.z);
+    return;
+  }
+  // Equal shares: workgroup b takes the entries [b*share, (b+1)*share) of A' (share is a multiple of 4) and
+  // loads the x slice of every slice its range touches -- one or two for the usual case of about one slice
+  // per workgroup.  The grid is exactly one wave of workgroups whatever the slice count is (slices cut for
+  // LDS capacity rarely come in multiples of 512; a second, nearly empty round of whole-slice workgroups cost
+  // up to 2x).
+  const int total = seg[(int64_t) S * NB];
+  const long long g0l = (long long) blockIdx.x * share;
+  int g0 = g0l < total ? (int) g0l : total;
+  const int g1 = (total - g0) < share ? total : g0 + share;
+  if (g0 >= g1)
+    return;
+  int lo = 0, hi = S;  // last slice starting at or before g0
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (seg[(int64_t) mid * NB] <= g0)
+      lo = mid;
+    else
+      hi = mid;
+  }
+  for (int s = lo; g0 < g1 && s < S; ++s) {
+    const int slice_end = seg[(int64_t) (s + 1) * NB];
+    if (slice_end <= g0)
+      continue;  // empty slice
+    const int a1 = g1 < slice_end ? g1 : slice_end;
+    __syncthreads();  // everyone is done with the previous x slice
+    load_x(s);
+    __syncthreads();
+    process(g0, a1);
+    g0 = a1;
   }
 }
 
@@ -900,11 +925,12 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
   // x slice of the expand: 80 KiB for fp32 (two workgroups per CU); for fp64 the whole 160 KiB of a CU
   // (one workgroup), which halves the number of slices and doubles the run length again
   // (10M^2, 10/row: 755 -> 651 us; for fp32 the wider slice changed nothing)
-  // fp32 switches to 160 KiB slices as well once 80 KiB slices no longer fit one wave of expand workgroups
-  // (n > 10.5 M): twice the run length for the reduce (n = 11 / 12 / 16 / 20 / 40 M: +9 / +4 / +1 / +5 / +17 %),
-  // at 10 M the 80 KiB form is 5 % faster
-  const int cus0 = h->num_cus > 0 ? h->num_cus : 256;
-  const bool wide32 = sizeof(T) == 4 && cdiv(n, PB_LDS_BYTES / 4) > 2 * (int64_t) cus0;
+  // fp32 switches to 160 KiB slices as well from n = 8 M on: twice the run length for the reduce (with the
+  // equal-share expand: n = 6 M -5 %, 8 M +1 %, 10 M +2..5 %, 11 M +26 %, 40 M +17 %)
+  // ... provided a slice still carries enough entries to pay for its x load (row shards of a multi-GPU run
+  // have the columns of the whole matrix but a fraction of its entries: 2.5 M x 10 M rows ran 15 % slower)
+  const int64_t s80 = cdiv(n, PB_LDS_BYTES / 4);
+  const bool wide32 = sizeof(T) == 4 && s80 >= 390 && nnz / s80 >= 75000;
   const int xlds = env_int("SPBLAS_GFX950_PB_XLDS_KB", (sizeof(T) == 8 || wide32) ? 160 : PB_LDS_BYTES / 1024) * 1024;
   int max_cols = xlds / (int) sizeof(T);
   if (max_cols > 65536)
@@ -922,16 +948,12 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
   int S, W, NB, H;
   const int w_env = env_int("SPBLAS_GFX950_SLICE_COLS", 0);  // test hooks: force small tiles
   const int h_env = env_int("SPBLAS_GFX950_SLICE_ROWS", 0);
-  // Slices: up to one wave of expand workgroups (512) the widest slices win -- rounding 293 slices up to
-  // 512 narrower ones shortens every run of the reduce (n = 5.3 / 6 / 7 M: -10 / -10 / -7 % time
-  // unrounded, cfg2 with 489 instead of 512 slices -1.9 %, 8 / 9 M +2 %); beyond one wave the count
-  // is rounded to whole waves (n = 16 M: 782 slices run 13 % slower than 1 024).
-  // One wave = 2 workgroups per CU with 80 KiB slices, 1 with 160 KiB slices (fp64: 489 unrounded slices on
-  // 256 slots ran 13 % slower than 512).
-  const int xround = env_int("SPBLAS_GFX950_PB_XROUND", 512);
-  const int cus = h->num_cus > 0 ? h->num_cus : 256;
-  const int one_wave = xround > 1 ? cus * (xlds > PB_LDS_BYTES ? 1 : 2) : 1;
-  pick_tiling(n, w_env > 0 && w_env < max_cols ? w_env : max_cols, xround, one_wave, 4, &S, &W);
+  // Slices: as few (as wide) as LDS allows -- every extra slice shortens all runs of the reduce (293 slices
+  // at n = 6 M rounded up to 512 cost 10 %).  The expand gives every workgroup an equal share of A' whatever
+  // the slice count is, so the count needs no rounding to waves of workgroups (SPBLAS_GFX950_PB_XROUND is a
+  // test hook).
+  const int xround = env_int("SPBLAS_GFX950_PB_XROUND", 1);
+  pick_tiling(n, w_env > 0 && w_env < max_cols ? w_env : max_cols, xround, xround, 4, &S, &W);
   // Matrices with few slices (n of a few million) would get runs of many hundred entries with
   // full-height bins: beyond the C prefetched chunks a run is read in a latency-exposed loop, and there
   // are too few bins to fill the chip.  Shorter bins bring the average run back to ~128 entries.
@@ -1247,17 +1269,29 @@ template <typename T>
 static int sliced_expand_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const void* x) {
   pl->last_x = x;  // the hub rows are computed in the reduce stage and gather x themselves
   const int32_t* seg = reinterpret_cast<const int32_t*>(pl->seg_ptr);
-  // enough workgroups for 2 per CU, but never so many parts that re-loading the x slice dominates
-  int parts = (int) cdiv(2 * (h->num_cus > 0 ? h->num_cus : 256), pl->n_slices);
-  const int64_t per_slice = pl->nnz / (pl->n_slices > 0 ? pl->n_slices : 1);
-  while (parts > 1 && per_slice / parts < 2 * (int64_t) pl->slice_cols)
-    --parts;
+  // one wave of workgroups (2 per CU with 80 KiB slices, 1 with 160 KiB), but never shares so small that
+  // re-loading the x slice dominates
   const int4* items = static_cast<const int4*>(pl->s_xitems);
-  const dim3 grid = items ? dim3((unsigned) pl->n_xitems) : dim3((unsigned) pl->n_slices, (unsigned) parts);
-  hipLaunchKernelGGL((pb_expand_kernel<T>), grid, dim3(PB_THREADS),
-                     (size_t) pl->slice_cols * sizeof(T), h->stream, pl->n, pl->slice_cols, (int) pl->n_rblk, seg,
-                     static_cast<const T*>(pl->s_values), reinterpret_cast<const uint16_t*>(pl->s_colind),
-                     static_cast<const T*>(x), static_cast<T*>(pl->s_products), items);
+  const int cus = h->num_cus > 0 ? h->num_cus : 256;
+  const size_t xbytes = (size_t) pl->slice_cols * sizeof(T);
+  int64_t nwg = (int64_t) cus * (xbytes > (size_t) PB_LDS_BYTES ? 1 : 2);
+  const int64_t total = pl->s_placed;
+  const int64_t min_share = 2 * (int64_t) pl->slice_cols;
+  if (nwg * min_share > total) {
+    // ... but not fewer workgroups than slices (row shards: many slices with few entries each)
+    const int64_t floor_wg = pl->n_slices < nwg ? pl->n_slices : nwg;
+    nwg = total / min_share;
+    if (nwg < floor_wg)
+      nwg = floor_wg;
+  }
+  if (nwg < 1)
+    nwg = 1;
+  const int share = (int) ((cdiv(total > 0 ? total : 1, nwg) + 3) & ~(int64_t) 3);
+  const dim3 grid = items ? dim3((unsigned) pl->n_xitems) : dim3((unsigned) cdiv(total > 0 ? total : 1, share));
+  hipLaunchKernelGGL((pb_expand_kernel<T>), grid, dim3(PB_THREADS), xbytes, h->stream, pl->n, pl->slice_cols,
+                     (int) pl->n_rblk, seg, static_cast<const T*>(pl->s_values),
+                     reinterpret_cast<const uint16_t*>(pl->s_colind), static_cast<const T*>(x),
+                     static_cast<T*>(pl->s_products), items, (int) pl->n_slices, share);
   SPB_HIP(hipGetLastError());
   return SPBLAS_GFX950_STATUS_SUCCESS;
 }
