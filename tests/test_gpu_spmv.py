@@ -152,7 +152,9 @@ def test_spmv_sliced_empty_trailing_runs_on_allocation_boundary(gpu, dtype):
     """Regression: the reduce kernel's clamped loads touch entry `start` of an EMPTY run; for empty runs
     at the very end of the re-tiled arrays that is entry nnz.  R-MAT scale 18 (the sparsest rows and
     columns are the last ones, nnz * 8 B = exactly 32 MiB) faulted there before the streams got their
-    slack.  Here: last rows empty, last columns unused, nnz sized so the arrays end on a 2 MiB boundary."""
+    slack.  Here: last rows empty, last columns unused, nnz sized so the arrays end on a 2 MiB boundary.
+    The empty trailing bins (first entry == nnz) are also what an early form of the staged scatter of
+    multiply_inspect read one element past the caller's arrays for (found by tools/fuzz_spmv.py)."""
     rng = np.random.default_rng(3)
     m, n = 40000, 50000
     nnz = (1 << 21) // np.dtype(dtype).itemsize * 2           # products array = exactly 4 MiB
