@@ -38,6 +38,7 @@
 #include "scan.hpp"
 
 #include <cstdlib>
+#include <ctime>
 
 namespace spb {
 
@@ -914,6 +915,25 @@ static void pick_tiling(int64_t extent, int max_elems, int round_to, int round_f
   *width = (int) w;
 }
 
+// SPBLAS_GFX950_TRACE_INSPECT=1: host-side time stamps of the inspect phases on stderr (drains the stream)
+struct pb_tracer {
+  bool on;
+  hipStream_t s;
+  double t0;
+  static double now() {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+  }
+  pb_tracer(hipStream_t st) : on(env_int("SPBLAS_GFX950_TRACE_INSPECT", 0) != 0), s(st), t0(now()) {}
+  void mark(const char* what) {
+    if (!on)
+      return;
+    (void) hipStreamSynchronize(s);
+    std::fprintf(stderr, "[inspect] %8.3f ms  %s\n", now() - t0, what);
+  }
+};
+
 template <typename T, typename O>
 static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const void* values_p,
                               bool auto_mode) {
@@ -1004,10 +1024,12 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
   }
 
   int rc;
+  pb_tracer tr(s);
   int32_t* seg = nullptr;
   long long* partials = nullptr;
   if ((rc = dev_alloc((void**) &seg, (size_t) (nseg + 1) * 4, s)))
     return rc;
+  tr.mark("seg allocated");
   pl->seg_ptr = seg;
   SPB_HIP(hipMemsetAsync(seg, 0, (size_t) (nseg + 1) * 4, s));
   const O* rowptr = static_cast<const O*>(pl->rowptr);
@@ -1024,6 +1046,7 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
   }
   hipLaunchKernelGGL((pb_count_kernel<O>), dim3((unsigned) NB), dim3(256), (size_t) S * 4, s, m, rowptr, pl->colind, W, H, S,
                      NB, seg, pl->hub_len);
+  tr.mark("count kernel");
   // One probe pass over the counters, read back once: entries per slice, non-empty tiles per slice, entries
   // per bin group.  AUTO uses them to decline matrices the plan does not suit; the work lists below use them
   // to spot column / row skew, and their total is the number of entries placed in tiles.
@@ -1063,6 +1086,7 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
         ((double) max_slice > 6.0 * mean_slice + 65536.0 || (double) max_group > 6.0 * mean_group + 65536.0))
       return SPBLAS_GFX950_STATUS_NOT_SUPPORTED;
   }
+  tr.mark("probe read back");
   if ((rc = dev_alloc((void**) &partials, (size_t) (cdiv(nseg, 2048) + 2) * sizeof(long long), s)))
     return rc;
   if ((rc = dev_alloc((void**) &pl->s_values, (size_t) nnz * sizeof(T), s)))
@@ -1080,6 +1104,7 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
   if ((rc = dev_alloc((void**) &pl->s_segT, (size_t) nseg * sizeof(int2), s)))
     return rc;
   pl->device_bytes += (size_t) nnz * (2 * sizeof(T) + 8) + (size_t) nseg * 16;
+  tr.mark("plan arrays allocated");
   (void) scan_counts_i32(s, nseg, seg, partials);  // the total is already known from the probe
   {
     // column skew: slice sizes from the segment offsets; when one slice is far above the average the
@@ -1193,6 +1218,7 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
       }
     }
   }
+  tr.mark("scan + work lists");
   if (S <= PB_STAGE_MAX_S && env_int("SPBLAS_GFX950_PB_STAGED_SCATTER", 1)) {
     // a quarter of the staging area at most goes to the row table (one entry per 64 matrix entries of a bin)
     const int rt_len = 2048;
@@ -1209,6 +1235,7 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
                      pl->colind, static_cast<const T*>(values_p), W, H, S, NB, seg, static_cast<T*>(pl->s_values),
                      reinterpret_cast<uint16_t*>(pl->s_colind), pl->s_lrow, reinterpret_cast<int32_t*>(pl->s_perm),
                      pl->hub_len);
+  tr.mark("scatter");
   hipLaunchKernelGGL(pb_transpose_seg_kernel, dim3((unsigned) cdiv(nseg, 256)), dim3(256), 0, s, S, NB, seg,
                      static_cast<int2*>(pl->s_segT));
   SPB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pb_flag_dups_kernel),
@@ -1218,6 +1245,7 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
                      static_cast<const int2*>(pl->s_segT), pl->s_lrow);
   SPB_HIP(hipGetLastError());
   SPB_HIP(hipStreamSynchronize(s));
+  tr.mark("flags");
   dev_free(partials, s);
   // both kernels may use up to 80 KiB of dynamic LDS
   SPB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pb_expand_kernel<T>),
