@@ -95,3 +95,24 @@ def test_generate_csr_has_unsorted_unique_columns():
         assert len(set(cols.tolist())) == len(cols)
         unsorted += int(np.any(np.diff(cols) < 0))
     assert unsorted > 50
+
+
+def test_scale_and_mixed_format_spgemm_host_checks():
+    """Host-side behaviour of the widenings (no device needed): scale() on host memory fails loudly like every
+    other entry point; SpGEMM accepts csc_view operands/results, checks the shapes of the LOGICAL matrices
+    before any device work and rejects other operand types."""
+    a = _csr()                                   # 4 x 5
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        sp.scale(2.0, a)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        sp.scale(2.0, torch.ones(7))
+    a_csc = sp.transposed(sp.csr_view(a.values(), a.rowptr(), a.colind(), (4, 5), a.size()))  # 5 x 4 as CSC
+    c_csc = sp.csc_view(None, torch.zeros(5, dtype=torch.int32), None, (4, 4), 0)
+    with pytest.raises(ValueError):              # (4x5) * (4x5): inner dimensions differ
+        sp.multiply_compute(a, a, c_csc)
+    with pytest.raises(ValueError):              # (4x5) * (5x4) -> 4x4, but C says 4x3
+        sp.multiply_compute(a, a_csc, sp.csr_view(None, torch.zeros(5, dtype=torch.int32), None, (4, 3), 0))
+    with pytest.raises(NotImplementedError):
+        sp.multiply_compute(a, a_csc, torch.zeros(4, 4))
+    c_csc.update(torch.ones(3), torch.zeros(5, dtype=torch.int32), torch.zeros(3, dtype=torch.int32), (4, 4), 3)
+    assert c_csc.size() == 3 and c_csc.values().numel() == 3

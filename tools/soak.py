@@ -15,7 +15,7 @@ for _ in range(5): f()
 torch.cuda.synchronize()
 out = []
 t_start = time.perf_counter()
-for rep in range(40):
+for rep in range(int(os.environ.get('SOAK_BLOCKS', '40'))):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(50): f()
@@ -25,3 +25,4 @@ for rep in range(40):
     if rep in (9, 19, 29): time.sleep(2.0)   # idle gaps
 print("elapsed %.1f s" % (time.perf_counter() - t_start))
 print(out)
+print("median", sorted(out)[len(out) // 2])
