@@ -202,7 +202,7 @@ def main():
         # finished row of y into all ranks' (IPC-mapped) copies, a device-side barrier ends the step.
         # Adopted only if every rank can set it up AND its y is bit-identical to the RCCL path's.
         bounds = [ranges[0][r][0] for r in range(world)] + [m]
-        fused = sharded.try_fused(a_chunks[0], bounds, x, lambda: op.step(x), alg=algs[args.alg], info=op.infos[0],
+        fused = sharded.try_fused(a_chunks[0], bounds, x, lambda xk: op.step(xk), alg=algs[args.alg], info=op.infos[0],
                                   log=(lambda msg: print(f"[bench] {msg}; using RCCL all-gather", file=sys.stderr))
                                   if rank == 0 else None)
         if fused is not None:

@@ -113,7 +113,15 @@ typedef enum spblas_gfx950_option {
   /* value > 0 caps the slice split K of spblas_gfx950_spmv_reduce_rows (0 = heuristic only).  Callers
    * that run the reduces of several stripes side by side on different streams keep K small so the
    * partial-sum traffic does not grow with the number of stripes. */
-  SPBLAS_GFX950_OPT_MAX_KSPLIT = 2
+  SPBLAS_GFX950_OPT_MAX_KSPLIT = 2,
+  /* value = 1 lets plan creation with alg = AUTO choose the SLICED plan, which re-tiles A and keeps a COPY
+   * of its values.  Default 0: AUTO only picks plans that read the caller's value array on every multiply,
+   * which is what the reference's CPU path and the rocSPARSE slot do (algorithms/multiply_impl.hpp:48-52,
+   * vendor/rocsparse/detail/spmv_impl.hpp:72-77).  The host layers set it for operands wrapped in
+   * matrix_opt (views/matrix_opt_impl.hpp: the view that owns a vendor-optimised form of the matrix), the
+   * same opt-in oneMKL's optimize_* stage gets in vendor/onemkl_sycl/spmm_impl.hpp:48-61.  Asking for
+   * alg = SLICED explicitly needs no option. */
+  SPBLAS_GFX950_OPT_VALUE_SNAPSHOT = 3
 } spblas_gfx950_option;
 int spblas_gfx950_set_option(spblas_gfx950_handle_t handle, int option, int64_t value);
 
@@ -121,8 +129,12 @@ int spblas_gfx950_set_option(spblas_gfx950_handle_t handle, int option, int64_t 
 /* multiply_inspect(A, x, y): device-side analysis of the sparsity pattern.
  * Builds the nnz-window row partition, the long-row list and (SLICED) the
  * column-sliced reorder; the result lives in device memory owned by the plan.
- * `values` may be NULL unless alg == SLICED (the reorder copies the values; call
- * spblas_gfx950_spmv_plan_update_values after changing them in place).
+ * `values` may be NULL unless alg == SLICED.
+ * Value snapshot contract: ROWBLOCK / VECTOR plans hold structure only and every multiply reads the
+ * caller's values.  The SLICED plan -- chosen only on request (alg = SLICED) or by AUTO under
+ * SPBLAS_GFX950_OPT_VALUE_SNAPSHOT -- holds a re-tiled COPY of the values: after changing them IN PLACE call
+ * spblas_gfx950_spmv_plan_update_values; a multiply that passes a DIFFERENT values pointer than the one
+ * the copy was taken from refreshes the copy by itself first (one extra pass over A).
  * The plan is tied to (m, n, nnz, rowptr, colind). */
 int spblas_gfx950_spmv_plan_create(spblas_gfx950_handle_t handle, spblas_gfx950_plan_t* plan,
                                    int64_t m, int64_t n, int64_t nnz, const void* rowptr,

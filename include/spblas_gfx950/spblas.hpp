@@ -385,12 +385,15 @@ void multiply_inspect(operation_info_t& info, A&& a, B&& b, C&& c) {
     auto ab = __detail::get_ultimate_base(a);
     using T = typename decltype(ab)::scalar_type;
     using O = typename decltype(ab)::offset_type;
+    // a matrix_opt operand may get the plan that keeps a re-tiled copy of the values (value snapshot contract,
+    // spblas_gfx950.h); a plain view gets a plan that reads the caller's values on every multiply
+    constexpr bool opt = __detail::is_opt<std::remove_cvref_t<A>>::value;
     info.spmv_state().template inspect<T, O>(ab.shape()[0], ab.shape()[1], ab.size(), ab.rowptr().data(),
-                                             ab.colind().data(), ab.values().data());
-    if constexpr (__detail::is_opt<std::remove_cvref_t<A>>::value) {  // cache in the matrix_opt as well
+                                             ab.colind().data(), ab.values().data(), SPBLAS_GFX950_SPMV_AUTO, opt);
+    if constexpr (opt) {  // cache in the matrix_opt as well
       a.cache().spmv = std::make_unique<__gfx950::spmv_state_t>();
       a.cache().spmv->template inspect<T, O>(ab.shape()[0], ab.shape()[1], ab.size(), ab.rowptr().data(),
-                                             ab.colind().data(), ab.values().data());
+                                             ab.colind().data(), ab.values().data(), SPBLAS_GFX950_SPMV_AUTO, true);
     }
   }
 }

@@ -242,11 +242,37 @@ class _Handle:
         return hd
 
 
-class _Plan:
-    """Owner of a spblas_gfx950_plan_t (released with the handle's stream order)."""
+# In-place changes to a value array made through this module's own scale() (a raw kernel, invisible to
+# torch's version counter) are recorded here: data_ptr -> number of such changes.
+_value_epochs = {}
 
-    def __init__(self, handle, plan, key):
+
+def _values_stamp(values):
+    """(data_ptr, torch version counter, scale() epoch): changes whenever the array is rebound or modified in
+    place through torch or through this module."""
+    return values.data_ptr(), values._version, _value_epochs.get(values.data_ptr(), 0)
+
+
+class _Plan:
+    """Owner of a spblas_gfx950_plan_t (released with the handle's stream order).
+
+    Holds references to the matrix's tensors, so their addresses -- the plan's identity in the library -- cannot
+    be recycled for another matrix while the plan lives.  A SLICED plan multiplies with a re-tiled COPY of the
+    values (include/spblas_gfx950.h, "value snapshot contract"); `stamp` remembers the state of the caller's
+    value array the copy was taken from, and _spmv refreshes the copy when it sees another one."""
+
+    def __init__(self, handle, plan, key, tensors=None):
         self.handle, self.plan, self.key = handle, plan, key
+        self.tensors = tensors
+        self.snapshot = self.info()["alg"] == _capi.SPMV_SLICED
+        self.stamp = _values_stamp(tensors[2]) if tensors is not None and tensors[2] is not None else None
+
+    def refresh_if_stale(self, values):
+        """SLICED plans only: re-copy the values when the caller's array was rebound or changed in place through
+        torch or scale() since the copy was taken.  (Writes by foreign kernels are invisible here: call
+        update_values after those, as the C ABI asks.)"""
+        if self.snapshot and values is not None and _values_stamp(values) != self.stamp:
+            self.update_values(values)
 
     def info(self):
         arr = (ctypes.c_int64 * 12)()
@@ -279,6 +305,9 @@ class _Plan:
         a copy of them; the other algorithms read the caller's array on every call)."""
         check(_capi.lib().spblas_gfx950_spmv_plan_update_values(self.handle.h, self.plan, _ptr(values)),
               "update_values")
+        self.stamp = _values_stamp(values)
+        if self.tensors is not None:
+            self.tensors = (self.tensors[0], self.tensors[1], values)
 
     def __del__(self):
         try:
@@ -373,20 +402,27 @@ def _reject_conjugated(*ts):
 
 
 def _plan_key(a_base):
-    return (a_base.rowptr().data_ptr(), a_base.colind().data_ptr(), a_base.values().data_ptr(),
-            tuple(a_base.shape()), a_base.size(), a_base.rowptr().dtype, a_base.values().dtype)
+    """Identity of a plan = the structure arrays (the library's own check, csrc/spmv.hip); the value array may
+    be rebound or change between multiplies like in the reference, where inspect holds no values at all."""
+    return (a_base.rowptr().data_ptr(), a_base.colind().data_ptr(), tuple(a_base.shape()), a_base.size(),
+            a_base.rowptr().dtype, a_base.values().dtype)
 
 
-def _build_plan(a_base, alg=_capi.SPMV_AUTO):
+def _build_plan(a_base, alg=_capi.SPMV_AUTO, snapshot=False):
+    """snapshot: AUTO may choose the plan that keeps a re-tiled copy of the values (matrix_opt operands)."""
     hd = _Handle.current(a_base.rowptr().device)
     vt, _ = _vtype(a_base.values(), "multiply_inspect")
     plan = ctypes.c_void_p()
     m, n = a_base.shape()
-    check(_capi.lib().spblas_gfx950_spmv_plan_create(hd.h, ctypes.byref(plan), m, n, a_base.size(),
-                                                     _ptr(a_base.rowptr()), _ptr(a_base.colind()),
-                                                     _ptr(a_base.values()), _OT[a_base.rowptr().dtype], vt, alg),
-          "multiply_inspect")
-    return _Plan(hd, plan, _plan_key(a_base))
+    hd.set_option(_capi.OPT_VALUE_SNAPSHOT, 1 if snapshot else 0)
+    try:
+        check(_capi.lib().spblas_gfx950_spmv_plan_create(hd.h, ctypes.byref(plan), m, n, a_base.size(),
+                                                         _ptr(a_base.rowptr()), _ptr(a_base.colind()),
+                                                         _ptr(a_base.values()), _OT[a_base.rowptr().dtype], vt, alg),
+              "multiply_inspect")
+    finally:
+        hd.set_option(_capi.OPT_VALUE_SNAPSHOT, 0)
+    return _Plan(hd, plan, _plan_key(a_base), (a_base.rowptr(), a_base.colind(), a_base.values()))
 
 
 class _CscPlan:
@@ -398,6 +434,7 @@ class _CscPlan:
 
     def __init__(self, a_csc, alg):
         self.key = _csc_key(a_csc)
+        self.stamp = _values_stamp(a_csc.values())
         m, n = a_csc.shape()          # logical shape of the operand
         nnz = a_csc.size()
         dev, vals = a_csc.values().device, a_csc.values()
@@ -413,15 +450,33 @@ class _CscPlan:
                                                       _ptr(self.values), _vtype(vals, "multiply_inspect")[0]),
               "multiply_inspect")
         self.a_csr = csr_view(self.values[:nnz], self.rowptr, self.colind[:nnz], (m, n), nnz)
-        self.plan = _build_plan(self.a_csr, alg)
+        self.plan = _build_plan(self.a_csr, alg, snapshot=True)  # the materialised form is a copy anyway
+
+    def refresh_if_stale(self, a_csc):
+        """The operand's values were rebound or changed in place (torch / scale()) since inspect: transpose
+        again into the same arrays (the structure is unchanged, so the plan stays valid) and refresh the plan's
+        own copy, so that multiply reads current values like the reference (multiply_impl.hpp:48-52)."""
+        if _values_stamp(a_csc.values()) == self.stamp:
+            return
+        m, n = a_csc.shape()
+        nnz = a_csc.size()
+        hd = _Handle.current(a_csc.values().device)
+        check(_capi.lib().spblas_gfx950_csr_transpose(hd.h, n, m, nnz, _ptr(a_csc.colptr()), _ptr(a_csc.rowind()),
+                                                      _ptr(a_csc.values()), _ptr(self.rowptr), _ptr(self.colind),
+                                                      _ptr(self.values), _vtype(a_csc.values(), "multiply")[0]),
+              "multiply")
+        self.stamp = _values_stamp(a_csc.values())
+        self.key = _csc_key(a_csc)
+        if self.plan.snapshot:
+            self.plan.update_values(self.a_csr.values())
 
     def info(self):
         return self.plan.info()
 
 
 def _csc_key(a_csc):
-    return (a_csc.colptr().data_ptr(), a_csc.rowind().data_ptr(), a_csc.values().data_ptr(), tuple(a_csc.shape()),
-            a_csc.size())
+    return (a_csc.colptr().data_ptr(), a_csc.rowind().data_ptr(), tuple(a_csc.shape()), a_csc.size(),
+            a_csc.values().dtype)
 
 
 def transpose_inspect(a, b):
@@ -465,6 +520,8 @@ def scale(alpha, t):
     a = ct(alpha)
     hd = _Handle.current(vals.device)
     check(_capi.lib().spblas_gfx950_scale(hd.h, nvals, ctypes.byref(a), _ptr(vals), vt), "scale")
+    if not _is_tensor(base):  # plans holding a copy of these values see the change (_Plan.refresh_if_stale)
+        _value_epochs[vals.data_ptr()] = _value_epochs.get(vals.data_ptr(), 0) + 1
 
 
 def _find_plan(info, a, a_base):
@@ -488,6 +545,7 @@ def _spmv(info, a, b, c, prepare_only=False):
     if isinstance(a_base, csc_view):
         if info is not None and isinstance(info.state_, _CscPlan) and info.state_.key == _csc_key(a_base):
             csc_plan = info.state_       # inspected: regular kernels on the materialised CSR
+            csc_plan.refresh_if_stale(a_base)
             a_csr = csc_plan.a_csr
         else:
             # CSC = CSR of the transpose + TRANSPOSE (vendor/rocsparse/detail/get_transpose.hpp:19-29)
@@ -510,6 +568,8 @@ def _spmv(info, a, b, c, prepare_only=False):
     beta = ct(0)
     hd = _Handle.current(c.device)
     plan = csc_plan.plan if csc_plan else (_find_plan(info, a, a_base) if op == _capi.OP_N else None)
+    if plan is not None and not csc_plan:
+        plan.refresh_if_stale(a_csr.values())
     m, n = a_csr.shape()
     args = (hd.h, plan.plan if plan else None, op, m, n, a_csr.size(), ctypes.byref(alpha), _ptr(a_csr.rowptr()),
             _ptr(a_csr.colind()), _ptr(a_csr.values()), _ptr(b_base), ctypes.byref(beta), _ptr(c),
@@ -528,8 +588,13 @@ class prepared_multiply:
     def __init__(self, info, a, x, y):
         self._args, self._keep = _spmv(info, a, x, y, prepare_only=True)
         self._fn = _capi.lib().spblas_gfx950_spmv
+        a_base = get_ultimate_base(a)
+        self._plan = self._keep[2]
+        self._values = a_base.values() if isinstance(a_base, csr_view) else None
 
     def __call__(self):
+        if self._plan is not None and self._plan.snapshot and self._values is not None:
+            self._plan.refresh_if_stale(self._values)
         rc = self._fn(*self._args)
         if rc:
             check(rc, "multiply")
@@ -542,6 +607,7 @@ def _spmm(info, a, b, c):
         # CSC operand (test/gtest/spmm_test.cpp:181): run the CSR kernel on the materialised row-major
         # form -- taken from the inspect result when there is one, otherwise transposed for this call
         if info is not None and isinstance(info.state_, _CscPlan) and info.state_.key == _csc_key(a_base):
+            info.state_.refresh_if_stale(a_base)
             a_base = info.state_.a_csr
         else:
             a_base = _CscPlan(a_base, _capi.SPMV_VECTOR).a_csr
@@ -603,7 +669,15 @@ def multiply_inspect(*args, alg=_capi.SPMV_AUTO):
     """multiply_inspect(a, b, c) -> operation_info_t, or multiply_inspect(info, a, b, c).
     Builds the gfx950 row partition on device and stores it in the info's state_; when A
     is wrapped in matrix_opt it is cached there too (the oneMKL model,
-    vendor/onemkl_sycl/spmm_impl.hpp:48-61, views/matrix_opt_impl.hpp:90-92)."""
+    vendor/onemkl_sycl/spmm_impl.hpp:48-61, views/matrix_opt_impl.hpp:90-92).
+
+    Values: for a plain csr_view the plan holds structure only and every multiply reads a.values() as the
+    reference does (algorithms/multiply_impl.hpp:48-52).  Wrapping A in matrix_opt -- "this view owns an
+    optimised form of the matrix" -- additionally lets AUTO pick the LDS-sliced plan, which re-tiles A and
+    multiplies with its own copy of the values (5x faster when x misses every cache).  The copy is refreshed
+    automatically when a.values() is rebound, modified in place through torch, or scaled with scale();
+    after writing it with a kernel of your own call info.state_.update_values(values).  alg=SPMV_SLICED asks
+    for that plan explicitly, with the same contract."""
     info, a, b, c = _split_info(args)
     ret = info is None
     if info is None:
@@ -617,9 +691,10 @@ def multiply_inspect(*args, alg=_capi.SPMV_AUTO):
         # the column-sliced plan serves SpMV only; SpMM uses the row partition (spmm_impl.hpp of the C++ layer)
         b_base = get_ultimate_base(b)
         is_spmm = _is_tensor(b_base) and b_base.dim() == 2
-        plan = _build_plan(a_base, _capi.SPMV_ROWBLOCK if is_spmm and alg == _capi.SPMV_AUTO else alg)
-        info.state_ = plan
         mo = _get_matrix_opt(a)
+        plan = _build_plan(a_base, _capi.SPMV_ROWBLOCK if is_spmm and alg == _capi.SPMV_AUTO else alg,
+                           snapshot=mo is not None)
+        info.state_ = plan
         if mo is not None:
             mo._plan = plan
     elif isinstance(a_base, csc_view) and _is_tensor(get_ultimate_base(b)):

@@ -544,7 +544,9 @@ int spblas_gfx950_spmv_plan_create(spblas_gfx950_handle_t handle, spblas_gfx950_
   if (rc == SPBLAS_GFX950_STATUS_SUCCESS && pl->alg == SPBLAS_GFX950_SPMV_SLICED) {
     rc = spmv_sliced_build(handle, pl, values, false);
   } else if (rc == SPBLAS_GFX950_STATUS_SUCCESS && alg == SPBLAS_GFX950_SPMV_AUTO && values &&
-             pl->alg == SPBLAS_GFX950_SPMV_ROWBLOCK && sliced_candidate(pl)) {
+             handle->value_snapshot != 0 && pl->alg == SPBLAS_GFX950_SPMV_ROWBLOCK && sliced_candidate(pl)) {
+    // (only with SPBLAS_GFX950_OPT_VALUE_SNAPSHOT: the sliced plan keeps a copy of the values, and a caller
+    // who has not opted in expects every multiply to read its array, multiply_impl.hpp:48-52)
     // x far larger than an XCD's L2 and no long rows: try the LDS-sliced re-tiling; it
     // declines (NOT_SUPPORTED) when the entries cluster in few tiles.
     const int rc2 = spmv_sliced_build(handle, pl, values, true);
@@ -733,6 +735,13 @@ int spblas_gfx950_spmv(spblas_gfx950_handle_t handle, spblas_gfx950_plan_t plan,
       return SPBLAS_GFX950_STATUS_PLAN_MISMATCH;
     if (op != SPBLAS_GFX950_OP_N)
       plan = nullptr;  // plans describe op = N only
+    // a SLICED plan multiplies with its own re-tiled copy of the values: when the caller hands over another
+    // array than the one the copy was taken from, take the copy again first
+    if (plan && plan->alg == SPBLAS_GFX950_SPMV_SLICED && nnz > 0 && values != plan->values_ptr) {
+      const int rc = spmv_sliced_update(handle, plan, values);
+      if (rc != SPBLAS_GFX950_STATUS_SUCCESS)
+        return rc;
+    }
   }
   if (value_type == SPBLAS_GFX950_F32) {
     return offset_type == SPBLAS_GFX950_I32

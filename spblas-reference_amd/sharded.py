@@ -84,7 +84,8 @@ class ShardedSpMV:
         self.info = api.operation_info_t()
         if inspect and local_spmv is None:
             x_probe = torch.empty(a_local.shape()[1], dtype=vals.dtype, device=vals.device)
-            self.info = api.multiply_inspect(a_local, x_probe, self.y_local[:counts[self.rank]])
+            # the operator owns its shard for its lifetime: matrix_opt lets inspect keep a re-tiled copy
+            self.info = api.multiply_inspect(api.matrix_opt(a_local), x_probe, self.y_local[:counts[self.rank]])
 
     def local(self, x):
         self.local_spmv(self.info, self.a_local, x, self.y_local[:self.counts[self.rank]])
@@ -156,7 +157,7 @@ class PipelinedShardedSpMV:
             if inspect and local_spmv is None:
                 x_probe = torch.empty(a_chunks[c].shape()[1], dtype=vals.dtype, device=vals.device)
                 kw = {} if alg is None else {"alg": alg}
-                info = api.multiply_inspect(a_chunks[c], x_probe, self.y_local[c], **kw)
+                info = api.multiply_inspect(api.matrix_opt(a_chunks[c]), x_probe, self.y_local[c], **kw)
             self.infos.append(info)
 
         self._bound_x, self._bound = None, None
@@ -223,7 +224,8 @@ class OverlappedShardedSpMV:
             try:
                 x_probe = torch.empty(a_local.shape()[1], dtype=vals.dtype, device=vals.device)
                 kw = {} if alg is None else {"alg": alg}
-                self.info = api.multiply_inspect(a_local, x_probe, self.y_full[:a_local.shape()[0]], **kw)
+                self.info = api.multiply_inspect(api.matrix_opt(a_local), x_probe, self.y_full[:a_local.shape()[0]],
+                                                 **kw)
             finally:
                 hd.set_option(api._capi.OPT_BIN_ROW_ALIGN, 0)
             pi = self.info.state_.info()
@@ -354,7 +356,8 @@ class FusedShardedSpMV:
             x_probe = torch.empty(a_local.shape()[1], dtype=self.dtype, device=self.device)
             y_probe = torch.empty(self.L, dtype=self.dtype, device=self.device)
             kw = {} if alg is None else {"alg": alg}
-            self.info = info if info is not None else api.multiply_inspect(a_local, x_probe, y_probe, **kw)
+            self.info = info if info is not None else api.multiply_inspect(api.matrix_opt(a_local), x_probe,
+                                                                           y_probe, **kw)
             if not isinstance(self.info.state_, api._Plan) or self.info.state_.info()["alg"] != api._capi.SPMV_SLICED:
                 raise RuntimeError("FusedShardedSpMV needs a SLICED local plan")
             # buffers: two copies of y, one flag array (slot q = last step signalled by rank q)
@@ -444,27 +447,41 @@ class FusedShardedSpMV:
 
 def try_fused(a_local, bounds, x, reference_step, alg=None, group=None, log=None, info=None, stripes=1):
     """Collective.  Returns a FusedShardedSpMV if EVERY rank could set it up and its full y agrees with
-    `reference_step()` (the RCCL all-gather path) on every rank; otherwise None, with everything the
-    attempt allocated released again.  Never raises: any failure means "keep the reference path".
+    `reference_step(x_k)` (the RCCL all-gather path) on every rank for FOUR different vectors x_k; otherwise
+    None, with everything the attempt allocated released again.  Never raises: any failure means "keep the
+    reference path".
+
+    The vectors differ from step to step (x, 2x, x + 1, 0.5x - 1) so that a stale or missing peer store cannot
+    hide: y of step k lives in buffer k & 1, so both copies are written twice with different contents and a
+    row that a peer failed to deliver -- or delivered late, after the step barrier -- still holds the previous
+    step's (different) value and the comparison fails.  With the same x on every step both buffers would hold
+    identical bits whatever the peers did.
+
     With `info` (the reference path's own plan) the two paths run the same kernels on the same plan and
     must agree bit for bit; without it each path has its own plan -- inspect orders the entries of a
     run by arrival, so two plans of one matrix differ in summation order -- and agreement is checked to
     1e-4 / 1e-10 relative, which still catches any wiring error (wrong offset, missing rows, stale
-    buffer)."""
+    buffer).  reference_step takes the vector to multiply (callables without a parameter are called as
+    before and validated with the single x they close over)."""
+    import inspect as _inspect
     fused, same = None, 0
     try:
         fused = FusedShardedSpMV(a_local, bounds, group=group, alg=alg, info=info, timeout_ms=3000, stripes=stripes)
-        y_ref = reference_step().clone()
-        for _ in range(3):  # both y buffers, and the barrier more than once
-            y_fused = fused.step(x)
-        torch.cuda.synchronize()
-        fused.check_status()
+        takes_x = len(_inspect.signature(reference_step).parameters) >= 1
+        xs = [x, 2.0 * x, x + 1.0, 0.5 * x - 1.0] if takes_x else [x, x, x]
+        same = 1
+        for x_k in xs:
+            y_ref = (reference_step(x_k) if takes_x else reference_step()).clone()
+            y_fused = fused.step(x_k)
+            torch.cuda.synchronize()
+            fused.check_status()
+            if info is not None:
+                ok = torch.equal(y_ref, y_fused)
+            else:
+                tol = 1e-4 if y_ref.dtype == torch.float32 else 1e-10
+                ok = torch.allclose(y_fused, y_ref, rtol=tol, atol=tol * float(y_ref.abs().max()))
+            same &= int(ok)
         fused._timeout = 20000
-        if info is not None:
-            same = int(torch.equal(y_ref, y_fused))
-        else:
-            tol = 1e-4 if y_ref.dtype == torch.float32 else 1e-10
-            same = int(torch.allclose(y_fused, y_ref, rtol=tol, atol=tol * float(y_ref.abs().max())))
         if not same and log:
             log("fused all-gather disagrees with the reference path")
     except Exception as e:  # noqa: BLE001

@@ -566,8 +566,95 @@ static void test_scale() {
   }
 }
 
+// Value snapshot contract of the C ABI (spblas_gfx950.h): AUTO without OPT_VALUE_SNAPSHOT never chooses the plan
+// that copies the values; with the option (what a matrix_opt operand sets) it may; a SLICED plan that is handed
+// another value array than the one it copied refreshes its copy inside spblas_gfx950_spmv.  The reference reads the
+// caller's values on every multiply (algorithms/multiply_impl.hpp:48-52).
+static void test_value_snapshot_contract() {
+  const int m = 260000, n = 1000000, per = 9;  // x = 4 MB, 2.3 M entries: a candidate for the sliced plan
+  host_csr h;
+  h.shape = spblas::index<index_t>(m, n);
+  h.nnz = (offset_t) m * per;
+  h.rowptr.resize(m + 1);
+  for (int i = 0; i <= m; i++)
+    h.rowptr[i] = (offset_t) i * per;
+  std::mt19937 g(7);
+  std::uniform_int_distribution<int> dc(0, n - 1);
+  std::uniform_real_distribution<value_t> dv(0.5f, 1.5f);
+  h.colind.resize(h.nnz);
+  h.values.resize(h.nnz);
+  for (offset_t p = 0; p < h.nnz; p++) {
+    h.colind[p] = dc(g);
+    h.values[p] = dv(g);
+  }
+  std::vector<value_t> xh(n);
+  for (auto& v : xh)
+    v = dv(g);
+  device_csr a(h);
+  dvec<value_t> x(xh), y(m);
+  std::vector<value_t> v2(h.values);
+  for (auto& v : v2)
+    v *= 3.0f;
+  dvec<value_t> values2(v2);
+  auto row_ref = [&](int i, value_t s) {
+    value_t r = 0;
+    for (auto p = h.rowptr[i]; p < h.rowptr[i + 1]; p++)
+      r += s * h.values[p] * xh[h.colind[p]];
+    return r;
+  };
+  auto check_y = [&](value_t s) {
+    auto yh = y.download();
+    bool ok = true;
+    for (int i = 0; i < m; i += 97)
+      ok &= std::abs((double) yh[i] - (double) row_ref(i, s)) <= 2e-6 * std::abs((double) row_ref(i, s)) * per;
+    CHECK(ok);
+  };
+  spblas_gfx950_handle_t hd = nullptr;
+  CHECK(spblas_gfx950_create(&hd, nullptr) == SPBLAS_GFX950_STATUS_SUCCESS);
+  const value_t one = 1, zero = 0;
+  for (int mode = 0; mode < 3; ++mode) {  // 0: AUTO, no option; 1: AUTO + option; 2: explicit SLICED
+    spblas_gfx950_plan_t plan = nullptr;
+    CHECK(spblas_gfx950_set_option(hd, SPBLAS_GFX950_OPT_VALUE_SNAPSHOT, mode == 1) == SPBLAS_GFX950_STATUS_SUCCESS);
+    CHECK(spblas_gfx950_spmv_plan_create(hd, &plan, m, n, h.nnz, a.rowptr.p, a.colind.p, a.values.p, SPBLAS_GFX950_I32,
+                                         SPBLAS_GFX950_F32, mode == 2 ? SPBLAS_GFX950_SPMV_SLICED : SPBLAS_GFX950_SPMV_AUTO) ==
+          SPBLAS_GFX950_STATUS_SUCCESS);
+    std::int64_t info[12];
+    CHECK(spblas_gfx950_plan_info(plan, info) == SPBLAS_GFX950_STATUS_SUCCESS);
+    CHECK(info[0] == (mode == 0 ? SPBLAS_GFX950_SPMV_ROWBLOCK : SPBLAS_GFX950_SPMV_SLICED));
+    CHECK(spblas_gfx950_spmv(hd, plan, SPBLAS_GFX950_OP_N, m, n, h.nnz, &one, a.rowptr.p, a.colind.p, a.values.p, x.p,
+                             &zero, y.p, SPBLAS_GFX950_I32, SPBLAS_GFX950_F32) == SPBLAS_GFX950_STATUS_SUCCESS);
+    check_y(1.0f);
+    // same structure, another value array: the product must follow it (no update_values call)
+    CHECK(spblas_gfx950_spmv(hd, plan, SPBLAS_GFX950_OP_N, m, n, h.nnz, &one, a.rowptr.p, a.colind.p, values2.p, x.p,
+                             &zero, y.p, SPBLAS_GFX950_I32, SPBLAS_GFX950_F32) == SPBLAS_GFX950_STATUS_SUCCESS);
+    check_y(3.0f);
+    CHECK(spblas_gfx950_spmv(hd, plan, SPBLAS_GFX950_OP_N, m, n, h.nnz, &one, a.rowptr.p, a.colind.p, a.values.p, x.p,
+                             &zero, y.p, SPBLAS_GFX950_I32, SPBLAS_GFX950_F32) == SPBLAS_GFX950_STATUS_SUCCESS);
+    check_y(1.0f);
+    CHECK(spblas_gfx950_plan_destroy(hd, plan) == SPBLAS_GFX950_STATUS_SUCCESS);
+  }
+  CHECK(spblas_gfx950_set_option(hd, SPBLAS_GFX950_OPT_VALUE_SNAPSHOT, 0) == SPBLAS_GFX950_STATUS_SUCCESS);
+  (void) hipDeviceSynchronize();
+  CHECK(spblas_gfx950_destroy(hd) == SPBLAS_GFX950_STATUS_SUCCESS);
+  // the C++ layer: a plain view inspects to a structure-only plan, a matrix_opt may get the copying one; both
+  // follow a value array rebound with csr_view::update (views/csr_view.hpp:36-49)
+  std::span<value_t> xs(x.p, (size_t) n), ys(y.p, (size_t) m);
+  for (int opt = 0; opt < 2; ++opt) {
+    spblas::csr_view<value_t, index_t, offset_t> view(a.values.p, a.rowptr.p, a.colind.p, h.shape, h.nnz);
+    spblas::matrix_opt view_opt(view);
+    auto info = opt ? spblas::multiply_inspect(view_opt, xs, ys) : spblas::multiply_inspect(view, xs, ys);
+    spblas::multiply(info, view, xs, ys);
+    check_y(1.0f);
+    view.update(std::span<value_t>(values2.p, (size_t) h.nnz), std::span<offset_t>(a.rowptr.p, (size_t) m + 1),
+                std::span<index_t>(a.colind.p, (size_t) h.nnz));
+    spblas::multiply(info, view, xs, ys);
+    check_y(3.0f);
+  }
+}
+
 int main() {
   test_scale();
+  test_value_snapshot_contract();
   test_spmv();
   test_spmm();
   test_spgemm();

@@ -43,6 +43,13 @@ def main():
         outs.append(yh.copy())
         x = x.clone()  # a new tensor object every step: the x pointer is re-bound
     assert all(np.array_equal(outs[0], o) for o in outs[1:]), "steps disagree"
+    # a DIFFERENT x on every step: a row a peer failed to deliver would still hold the previous step's value
+    for it, scale in enumerate((2.0, -0.5, 3.0)):
+        y = op.step(x * scale)
+        torch.cuda.synchronize()
+        op.check_status()
+        err = np.abs(y.cpu().numpy().astype(np.float64) - scale * ref.astype(np.float64))
+        assert (err <= tol * abs(scale) * absrow + 1e-30).all(), f"rank {rank} scaled step {it}: parity failed"
     # every rank must hold the SAME bits (each row is computed once, by its owner)
     gathered = [None] * world
     dist.all_gather_object(gathered, outs[0].tobytes())
@@ -55,9 +62,10 @@ def main():
         y_q = torch.empty(bounds[q + 1] - bounds[q], dtype=dtype, device=dev)
         plans.append((sp.multiply_inspect(a_q, x, y_q, alg=sp._capi.SPMV_SLICED), a_q, y_q))
 
-    def reference_step(corrupt=False):
+    def reference_step(xk=None, corrupt=False):
+        xk = x if xk is None else xk
         for info_q, a_q, y_q in plans:
-            sp.multiply(info_q, a_q, x, y_q)
+            sp.multiply(info_q, a_q, xk, y_q)
         y = torch.cat([p[2] for p in plans])
         if corrupt and rank == world - 1:
             y[5] += 1
@@ -70,9 +78,10 @@ def main():
     chosen.close()
     # reusing the reference path's own plan, against a reference that gathers every rank's OWN shard
     # (what the RCCL all-gather path produces): the two must agree bit for bit
-    def reference_step_gathered():
+    def reference_step_gathered(xk=None):
+        xk = x if xk is None else xk
         info_r, a_r, y_r = plans[rank]
-        sp.multiply(info_r, a_r, x, y_r)
+        sp.multiply(info_r, a_r, xk, y_r)
         torch.cuda.synchronize()
         parts = [None] * world
         dist.all_gather_object(parts, y_r.cpu().numpy())
@@ -83,7 +92,7 @@ def main():
     assert torch.equal(chosen.step(x), reference_step_gathered())
     chosen.close()
     # a disagreement on ONE rank must make EVERY rank fall back
-    assert sharded.try_fused(a_loc, bounds, x, lambda: reference_step(True), alg=sp._capi.SPMV_SLICED) is None
+    assert sharded.try_fused(a_loc, bounds, x, lambda xk: reference_step(xk, True), alg=sp._capi.SPMV_SLICED) is None
     # a rank that cannot build a SLICED plan (forced row-block here) makes every rank fall back, no hang
     bad_alg = sp._capi.SPMV_ROWBLOCK if rank == 0 else sp._capi.SPMV_SLICED
     assert sharded.try_fused(a_loc, bounds, x, reference_step, alg=bad_alg) is None

@@ -210,6 +210,45 @@ def test_spmv_matrix_opt_caches_plan_and_values_may_change(gpu):
     check(values * np.float32(3), rowptr, colind, shape, G.host(x), G.host(y), what="matrix_opt rescaled")
 
 
+def test_spmv_values_changed_in_place(gpu):
+    """The reference reads A's values on every multiply (algorithms/multiply_impl.hpp:48-52; the rocSPARSE slot
+    passes the caller's pointer at execute time, vendor/rocsparse/detail/spmv_impl.hpp:72-77).  The sliced plan
+    multiplies with a re-tiled copy, so: (1) AUTO must not choose it for a plain csr_view; (2) for a matrix_opt
+    operand, or on explicit request, changes made in place through torch, through scale(), or by rebinding the
+    view must be picked up WITHOUT an update_values call."""
+    rng = np.random.default_rng(5)
+    m, n, per = 260000, 1_000_000, 9          # x = 4 MB, 2.3 M entries: AUTO's sliced candidate
+    rowptr = (np.arange(m + 1, dtype=np.int64) * per).astype(np.int32)
+    nnz = m * per
+    colind = rng.integers(0, n, nnz).astype(np.int32)
+    values = (rng.random(nnz) + 0.5).astype(np.float32)
+    x = (rng.random(n) + 0.5).astype(np.float32)
+    xd = G.dev(x)
+    for mode in ("plain", "matrix_opt", "explicit", "prepared"):
+        a = G.csr_on_device(values, rowptr, colind, (m, n), nnz)
+        y = torch.full((m,), float("nan"), device="cuda")
+        operand = sp.matrix_opt(a) if mode in ("matrix_opt", "prepared") else a
+        info = sp.multiply_inspect(operand, xd, y, alg=_capi.SPMV_SLICED if mode == "explicit" else _capi.SPMV_AUTO)
+        alg = info.state_.info()["alg"]
+        assert alg == (_capi.SPMV_ROWBLOCK if mode == "plain" else _capi.SPMV_SLICED), mode
+        run = sp.prepared_multiply(info, operand, xd, y) if mode == "prepared" else (
+            lambda: sp.multiply(info, operand, xd, y))
+        run()
+        check(values, rowptr, colind, (m, n), x, G.host(y), what=f"{mode}: as inspected", ref_cmp=False)
+        a.values().mul_(2.0)                                   # in place through torch
+        run()
+        check(values * np.float32(2), rowptr, colind, (m, n), x, G.host(y), what=f"{mode}: mul_", ref_cmp=False)
+        sp.scale(0.25, a)                                      # in place through the backend's own scale()
+        run()
+        check(values * np.float32(0.5), rowptr, colind, (m, n), x, G.host(y), what=f"{mode}: scale()", ref_cmp=False)
+        if mode != "prepared":                                 # a prepared call is bound to its tensors
+            fresh = G.dev(values * np.float32(3))
+            a.update(fresh, a.rowptr(), a.colind())            # csr_view.hpp:36-49: rebind the value array
+            run()
+            check(values * np.float32(3), rowptr, colind, (m, n), x, G.host(y), what=f"{mode}: rebound",
+                  ref_cmp=False)
+
+
 def test_spmv_csc_and_transposed_operand(gpu):
     # y = A x with A given as csc_view, and y = A^T x via transposed(csr)
     # (vendor/rocsparse/detail/get_transpose.hpp:19-29; test/gtest/spmv_test.cpp:110-208)
@@ -268,8 +307,10 @@ def test_spmv_full_size_properties_cfg2(gpu, poisson):
     x1 = torch.rand(n, device="cuda", generator=g)
     x2 = torch.rand(n, device="cuda", generator=g)
     y1, y2, y3, y1v = (torch.empty(m, device="cuda") for _ in range(4))
-    info = sp.multiply_inspect(a, x1, y1)
-    assert info.state_.info()["alg"] == _capi.SPMV_SLICED  # AUTO: x (40 MB) >> L2, random columns
+    # AUTO on a matrix_opt operand: x (40 MB) >> L2, random columns -> the LDS-sliced plan.  (A plain csr_view
+    # keeps AUTO on plans that read the caller's values: test_spmv_values_changed_in_place.)
+    info = sp.multiply_inspect(sp.matrix_opt(a), x1, y1)
+    assert info.state_.info()["alg"] == _capi.SPMV_SLICED
     sp.multiply(info, a, x1, y1)
     sp.multiply(info, a, x2, y2)
     sp.multiply(info, a, 0.5 * x1 - 2.0 * x2, y3)
@@ -349,7 +390,7 @@ def test_spmv_sliced_with_a_few_dense_rows(gpu):
     a = G.csr_on_device(values, rowptr, colind, (m, n), nnz)
     xd = G.dev(x)
     y = torch.full((m,), float("nan"), device="cuda")
-    info = sp.multiply_inspect(a, xd, y)                       # AUTO
+    info = sp.multiply_inspect(sp.matrix_opt(a), xd, y)        # AUTO, value copy allowed
     pi = info.state_.info()
     assert pi["alg"] == _capi.SPMV_SLICED and pi["n_long_rows"] == 3
     sp.multiply(info, sp.scaled(-1.5, a), xd, y)
@@ -387,7 +428,7 @@ def test_spmv_auto_declines_sliced_for_skewed_matrices(gpu):
         a = G.csr_on_device(values, rowptr, cols, (m, n), nnz)
         xd = G.dev(x)
         y = torch.full((m,), float("nan"), device="cuda")
-        info = sp.multiply_inspect(a, xd, y)
+        info = sp.multiply_inspect(sp.matrix_opt(a), xd, y)
         assert info.state_.info()["alg"] == _capi.SPMV_ROWBLOCK, what
         sp.multiply(info, a, xd, y)
         check(values, rowptr, cols, (m, n), x, G.host(y), what=what + " (auto)", ref_cmp=False)
@@ -405,7 +446,7 @@ def test_spmv_auto_declines_sliced_for_skewed_matrices(gpu):
     a = G.csr_on_device(val2, rowptr2, col2, (m, n), nnz2)
     xd = G.dev(x)
     y = torch.full((m,), float("nan"), device="cuda")
-    info = sp.multiply_inspect(a, xd, y)
+    info = sp.multiply_inspect(sp.matrix_opt(a), xd, y)
     assert info.state_.info()["alg"] == _capi.SPMV_ROWBLOCK
     sp.multiply(info, a, xd, y)
     check(val2, rowptr2, col2, (m, n), x, G.host(y), what="heavy row block (auto)", ref_cmp=False)

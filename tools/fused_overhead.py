@@ -12,7 +12,7 @@ n = 10_000_000
 v, rp, ci, shape, nnz = generate.uniform_csr_device(rows, n, 10, seed=0, device=dev)
 a = sp.csr_view(v, rp, ci, shape, nnz)
 x = torch.rand(n, device=dev); y = torch.empty(rows, device=dev)
-info = sp.multiply_inspect(a, x, y)
+info = sp.multiply_inspect(sp.matrix_opt(a), x, y)
 plain = sp.prepared_multiply(info, a, x, y)
 fused = sharded.FusedShardedSpMV(a, [0, rows], info=info)
 striped = {st: sharded.FusedShardedSpMV(a, [0, rows], info=info, stripes=st) for st in (2, 4, 8)}

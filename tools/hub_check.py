@@ -16,7 +16,7 @@ ci = torch.randint(0, m, (nnz,), dtype=torch.int32, device=dev, generator=g)
 v = torch.rand(nnz, device=dev, generator=g)
 a = sp.csr_view(v, rp.int(), ci, (m, m), nnz)
 x = torch.rand(m, device=dev, generator=g); y = torch.empty(m, device=dev)
-info = sp.multiply_inspect(a, x, y)
+info = sp.multiply_inspect(sp.matrix_opt(a), x, y)
 f = sp.prepared_multiply(info, a, x, y)
 for _ in range(10): f()
 torch.cuda.synchronize(); t0 = time.perf_counter()

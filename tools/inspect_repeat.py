@@ -11,7 +11,7 @@ a = sp.csr_view(v, rp, ci, shape, nnz)
 x = torch.rand(n, device=dev); y = torch.empty(n, device=dev)
 for rep in range(4):
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    info = sp.multiply_inspect(a, x, y)
+    info = sp.multiply_inspect(sp.matrix_opt(a), x, y)
     torch.cuda.synchronize(); t1 = time.perf_counter()
     print(f"inspect #{rep}: {(t1-t0)*1e3:.2f} ms", flush=True)
     if rep % 2 == 1:

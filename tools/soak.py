@@ -9,7 +9,7 @@ n = 10_000_000
 v, rp, ci, shape, nnz = generate.uniform_csr_device(n, n, 10, dtype=torch.float32, seed=0, device=dev)
 a = sp.csr_view(v, rp, ci, shape, nnz)
 x = torch.rand(n, device=dev); y = torch.empty(n, device=dev)
-info = sp.multiply_inspect(a, x, y)
+info = sp.multiply_inspect(sp.matrix_opt(a), x, y)
 f = sp.prepared_multiply(info, a, x, y)
 for _ in range(5): f()
 torch.cuda.synchronize()
