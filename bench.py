@@ -273,7 +273,7 @@ def main():
                          # PMC traffic was measured for the default cfg2 / 1 GPU / sliced plan only
                          "traffic": read_pmc_traffic("spmv_cfg2") if (world == 1 and plan_info.get("alg") == 3
                                                                      and not poisson and args.rows is None and args.cols is None) else None,
-                         "kernel": {3: "pb_expand_kernel<float> + pb_reduce_kernel<float,4,2,2> (one SpMV = this launch pair)",
+                         "kernel": {3: "pb_expand_kernel<float> + pb_reduce_kernel<float,4,4> (one SpMV = this launch pair)",
                                     2: "spmv_rowblock_kernel<float,int,2048>", 1: "spmv_vector_kernel<float,int,LPR>"
                                     }.get(plan_info.get("alg"), "spmv_vector_kernel<float,int,LPR>"),
                          "algorithmic_bytes_per_launch": local_bytes, "kernel_avg_ms": kern_avg_ms,

@@ -5,6 +5,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 
 #include "spblas_gfx950.h"
 
@@ -53,7 +54,8 @@ inline int dev_alloc(void** p, size_t bytes, hipStream_t s) {
   // stream order was seen to be recycled while still in use when the application mixes in ordinary
   // hipMalloc/hipFree traffic (tests/cpp/device_tests.cpp exposed it).  Allocation only happens at
   // inspect time, so the implied synchronisation is acceptable.
-  hipError_t e = s ? hipMallocAsync(p, bytes, s) : hipErrorNotSupported;
+  static const bool no_pool = std::getenv("SPBLAS_GFX950_NO_POOL") != nullptr;  // experiment knob: plain hipMalloc
+  hipError_t e = (s && !no_pool) ? hipMallocAsync(p, bytes, s) : hipErrorNotSupported;
   if (e != hipSuccess) {
     (void) hipGetLastError();
     e = hipMalloc(p, bytes);

@@ -29,31 +29,34 @@ struct spblas_gfx950_plan_s {
   int64_t empty_rows = 0;
   int64_t long_nnz = 0;  // entries stored in rows longer than the window
 
-  // SLICED: column-sliced re-tiling of A (see spmv_sliced.hip)
+  // SLICED: column-sliced re-tiling of A (see spmv_sliced.hip).  A run = the entries of one (slice, wave-bin)
+  // tile, padded to whole blocks of 32 entries.  A' order = blocks by (slice, bin): what the expand streams;
+  // P order = the same blocks by (bin, slice), every bin padded to whole groups of 8 blocks: what the reduce streams.
   int n_slices = 0;      // S column slices of slice_cols columns
   int slice_cols = 0;
-  int rows_per_blk = 0;  // H rows per bin
-  int64_t n_rblk = 0;    // NB bins
-  void* seg_ptr = nullptr;     // int32[S*NB + 1] segment offsets in A' order, key = s*NB + b
-  void* s_segT = nullptr;      // int2[NB*S] (start, length) per (b, s)
-  void* s_colind = nullptr;    // uint16[nnz] column inside the slice
-  void* s_values = nullptr;    // T[nnz]
-  uint16_t* s_lrow = nullptr;  // uint16[nnz] row inside the bin
-  void* s_perm = nullptr;      // int32[nnz] source position in the caller's CSR arrays
-  void* s_products = nullptr;  // T[nnz] workspace: expanded products
-  int n_ksplit = 1;            // reduce workgroups per bin group (slice split)
-  int rwaves = 8;              // reduce: wave-bins (= wavefronts) per workgroup
-  int rchunks = 1;             // reduce: 64-entry chunks of a run prefetched into registers
-  int rgroup = 1;              // reduce: runs whose LDS reads are issued together (duplicate-flag group)
+  int rows_per_blk = 0;  // H rows per wave-bin
+  int64_t n_rblk = 0;    // NB wave-bins
+  void* seg_ptr = nullptr;     // int32[S*NB]: entries per run, key = s*NB + b (inspect only; kept for introspection)
+  void* s_sliceblk = nullptr;  // int32[S + 1]: first A'-order block of every slice
+  void* s_binblk = nullptr;    // int32[NB + 1]: first P-order block of every wave-bin (multiples of 8)
+  void* s_blkdst = nullptr;    // int32[a_blocks]: P-order block of every A'-order block
+  void* s_colind = nullptr;    // uint16[a_blocks*32] column inside the slice (A' order; pads 0)
+  void* s_values = nullptr;    // T[a_blocks*32] (A' order; pads 0)
+  void* s_perm = nullptr;      // int32[a_blocks*32] source position in the caller's CSR arrays (pads -1)
+  uint16_t* s_lrow = nullptr;  // uint16[p_blocks*32] row inside the bin | bit 15 = duplicate flag (P order; pads = H)
+  void* s_products = nullptr;  // T[p_blocks*32] workspace: expanded products (P order)
+  int64_t a_blocks = 0, p_blocks = 0;
+  int n_ksplit = 1;            // reduce workgroups per bin group (every wave-bin's stream cut into K parts)
+  int rwaves = 4;              // reduce: wave-bins (= wavefronts) per workgroup
   int hub_len = 0;             // > 0: rows longer than this are NOT in the tiles (pb_hub_rows_kernel does them)
   int64_t s_placed = 0;        // entries in the tiles (nnz minus the hub rows' entries)
-  const void* values_ptr = nullptr;  // caller's values array (inspect / last update_values): read by the hub rows
+  const void* values_ptr = nullptr;  // caller's values array the copy was taken from (inspect / last update)
   const void* last_x = nullptr;      // x of the last expand
   void* s_hub_part = nullptr;        // T[n_long * hub_parts] partial sums of the hub rows
   int hub_parts = 1;                 // workgroups per hub row
-  void* s_xitems = nullptr;          // int4[n_xitems] expand work list (slice, first, last) for column-skewed matrices
+  void* s_xitems = nullptr;          // int4[n_xitems] expand work list (slice, first block, last block) for column-skewed matrices
   int64_t n_xitems = 0;
-  // reduce work list for row-skewed matrices: int4 (group, first slice, last slice, partial offset or -1),
+  // reduce work list for row-skewed matrices: int4 (group, part, parts, partial offset or -1),
   // the split groups (group, K, offset of the first partial block) and the partial blocks themselves
   void *s_ritems = nullptr, *s_rsplit = nullptr, *s_rpartial = nullptr;
   int64_t n_ritems = 0, n_rsplit = 0;

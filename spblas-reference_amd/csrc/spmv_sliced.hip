@@ -7,27 +7,35 @@
 // The only memory on the CU that sustains random 4-byte accesses at the needed rate is LDS,
 // so multiply_inspect re-tiles A once on the device:
 //
-//   A' order   entries grouped by (column slice s, wave-bin wb); slice = W consecutive columns
-//              (W*sizeof(T) <= 80 KiB of LDS), wave-bin = Hw consecutive rows owned by ONE
-//              wavefront of the reduce kernel (8 wave-bins * Hw * sizeof(T) <= 80 KiB)
-//   s_val[i]   value,  s_col[i] 16-bit column inside the slice,
-//   s_row[i]   15-bit row inside the wave-bin | bit 15 = "duplicate" flag (see below)
+//   tile       (column slice s, wave-bin b): slice = W consecutive columns (W*sizeof(T) <= 160 KiB of LDS),
+//              wave-bin = H consecutive rows owned by ONE wavefront of the reduce kernel
+//   run        the entries of one tile, padded to whole BLOCKS of 32 entries (pads: value 0, row = H)
+//   A' order   blocks sorted by (slice, bin): s_val[] value, s_col[] 16-bit column inside the slice
+//   P order    the same blocks sorted by (bin, slice), every bin padded to whole GROUPS of 8 blocks:
+//              s_row[] 15-bit row inside the bin | bit 15 = "duplicate" flag, P[] the products
+//   blkdst[]   P-order block of every A'-order block
 //
 // and multiply() runs two streaming kernels (no global gathers, no global atomics):
-//   expand  one workgroup per slice: x slice -> LDS, then P[i] = s_val[i] * xs[s_col[i]] over the
-//           slice's contiguous range of A' (16-byte lane accesses)
-//   reduce  one wavefront per wave-bin: Hw accumulators in LDS, walk the bin's S runs of P;
-//           y = alpha*acc + beta*y
-// HBM traffic per nonzero: 6 B + 4 B (expand) + 6 B (reduce) = 16 B vs 8 B algorithmic, all of it
-// coalesced streams.
+//   expand  x slice -> LDS; flat pass over the slice's contiguous blocks of A':
+//           P[blkdst[blk]] = s_val[blk] * xs[s_col[blk]]   -- linear 16-byte reads, and writes that are
+//           linear inside every 128-byte block (a block-permuted stream: tools/ubench/hbm_pieces.hip shows
+//           it runs within 3-5 % of the fully linear copy as long as whole lines are written)
+//   reduce  one wavefront per wave-bin: H accumulators in LDS; the bin's part of P and s_row is ONE
+//           contiguous stream, read with 16-byte / 8-byte lane accesses (4 entries per lane, no run
+//           descriptors, no line over-fetch);  y = alpha*acc + beta*y
+// Round 1 stored P in A' order, so that the reduce read it in ~100-entry runs: 142 us for 0.77 GB, issue- and
+// over-fetch-bound (34 instructions per 64 entries).  Moving the small pieces to the WRITE side (whole 128-byte
+// lines at permuted places) makes the reduce a pure stream: 4x fewer instructions per entry.
+// HBM traffic per stored entry: 6 B + 4 B (expand) + 6 B (reduce) = 16 B vs 8 B algorithmic, plus the block
+// padding (half a block per run; tall bins keep runs ~200 entries long at cfg2).
 //
 // Why wave-owned bins: ds_add_f32 retires ~0.33 lanes/clk/CU on gfx950 (tools/ubench/lds_atomic:
 // 1e8 LDS float atomics = 509 us, 12x slower than integer atomics or a plain read-add-write),
 // so accumulation must be a plain LDS read-modify-write.  That is race free iff (a) no other
-// wavefront touches the rows -- each wave owns its bin -- and (b) the <= 64 entries one wave
-// instruction handles hit distinct rows.  (b) is arranged at inspect time: within each
-// 64-entry chunk of a run all but one entry of a repeated row carry the duplicate flag and are
-// applied afterwards with the (slow, rare: ~1 % of entries) LDS atomic.
+// wavefront touches the rows -- each wave owns its bin -- and (b) the 256 entries one reduce step
+// handles (64 lanes x 4) hit distinct rows.  (b) is arranged at inspect time: within each
+// 256-entry group all but one entry of a repeated row carry the duplicate flag and are
+// applied afterwards with the (slow, rare: ~3 % of entries) LDS atomic.
 // The order of additions into a row is fixed by the plan, so results are run-to-run
 // reproducible for a given plan (plans built twice may order entries differently).
 #include <algorithm>
@@ -48,10 +56,13 @@ static int env_int(const char* name, int dflt) {
 }
 
 static constexpr int PB_THREADS = 1024;         // expand: 16 waves share one x slice
-static constexpr int PB_RTHREADS = 512;         // inspect (flag kernel): 8 waves, one wave-bin each
-static constexpr int PB_RWAVES = PB_RTHREADS / 64;
+static constexpr int PB_FTHREADS = 512;         // inspect (flag kernel): 8 waves, one wave-bin each
+static constexpr int PB_FWAVES = PB_FTHREADS / 64;
 static constexpr int PB_RWAVES_DEFAULT = 4;     // reduce: wave-bins per workgroup (plan->rwaves)
 static constexpr int PB_LDS_BYTES = 80 * 1024;  // two workgroups per CU (160 KiB LDS)
+static constexpr int PB_BLK = 32;               // entries per block: the padding unit of a run (128 B of fp32 products)
+static constexpr int PB_GRP = 256;              // entries per reduce step: 64 lanes x 4
+static constexpr int PB_GBLK = PB_GRP / PB_BLK; // blocks per group: the padding unit of a bin
 
 // ---- inspect --------------------------------------------------------------------------
 // One workgroup per wave-bin: all entries of the bin's rows share wb, so the per-slice counts
@@ -98,19 +109,88 @@ __global__ __launch_bounds__(256) void pb_count_kernel(int64_t m, const O* __res
     cnt[(int64_t) i * NB + wb] = hist[i];
 }
 
-// Same ownership for the scatter: LDS cursors start at the runs' offsets; the row of entry p is
-// found by a binary search in the bin's slice of rowptr (<= 12 probes, L1/L2 resident).
+// blocks per run, in A' order (key = s*NB + b); scanned in place into the block offsets aoff[]
+__global__ __launch_bounds__(256) void pb_nblk_kernel(int64_t nseg, const int32_t* __restrict__ cnt,
+                                                      int32_t* __restrict__ aoff) {
+  const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
+  if (i < nseg)
+    aoff[i] = (cnt[i] + PB_BLK - 1) / PB_BLK;
+}
+
+// P order: one workgroup per wave-bin b scans the block counts of its S runs: prel[b*S + s] = blocks of the bin
+// before slice s; bintot[b] = the bin's blocks rounded up to whole groups (scanned afterwards into binblk[]).
+__global__ __launch_bounds__(256) void pb_bin_prefix_kernel(int S, int NB, const int32_t* __restrict__ cnt,
+                                                            int32_t* __restrict__ prel, int32_t* __restrict__ bintot) {
+  __shared__ int sm[256];
+  __shared__ int carry;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (tid == 0)
+    carry = 0;
+  __syncthreads();
+  for (int s0 = 0; s0 < S; s0 += 256) {
+    const int s = s0 + tid;
+    const int v = s < S ? (cnt[(int64_t) s * NB + b] + PB_BLK - 1) / PB_BLK : 0;
+    sm[tid] = v;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+      const int t = tid >= o ? sm[tid - o] : 0;
+      __syncthreads();
+      sm[tid] += t;
+      __syncthreads();
+    }
+    const int c = carry;
+    if (s < S)
+      prel[(int64_t) b * S + s] = c + sm[tid] - v;
+    __syncthreads();
+    if (tid == 255)
+      carry = c + sm[255];
+    __syncthreads();
+  }
+  if (tid == 0)
+    bintot[b] = (carry + PB_GBLK - 1) / PB_GBLK * PB_GBLK;
+}
+
+// sliceblk[s] = aoff[s*NB] (first A'-order block of slice s), sliceblk[S] = all blocks
+__global__ __launch_bounds__(256) void pb_slice_blocks_kernel(int S, int NB, const int32_t* __restrict__ aoff,
+                                                              int32_t* __restrict__ sliceblk) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i <= S)
+    sliceblk[i] = aoff[(int64_t) i * NB];
+}
+
+// Direct scatter (S > PB_STAGE_MAX_S): LDS cursors start at the runs' A' positions; the row of entry p is
+// found by a binary search in the bin's slice of rowptr (<= 12 probes, L1/L2 resident).  Pads were set by
+// the memsets of the build; this kernel writes the real entries and the block map of its runs.
 template <typename T, typename O>
 __global__ __launch_bounds__(256) void pb_scatter_kernel(int64_t m, const O* __restrict__ rowptr,
                                                          const int32_t* __restrict__ colind,
                                                          const T* __restrict__ values, int W, int H, int S, int NB,
-                                                         const int32_t* __restrict__ seg, T* __restrict__ s_val,
+                                                         const int32_t* __restrict__ aoff,
+                                                         const int32_t* __restrict__ prel,
+                                                         const int32_t* __restrict__ binblk, T* __restrict__ s_val,
                                                          uint16_t* __restrict__ s_col, uint16_t* __restrict__ s_row,
-                                                         int32_t* __restrict__ perm, int hub_len) {
-  extern __shared__ int cursor[];  // [S]
+                                                         int32_t* __restrict__ perm, int32_t* __restrict__ blkdst,
+                                                         int hub_len) {
+  extern __shared__ int smem_i[];
+  int* cursor = smem_i;    // [S] next A' position of the run
+  int* pdelta = smem_i + S;  // [S] P position minus A' position of the run's entries
   const int wb = blockIdx.x;
-  for (int i = threadIdx.x; i < S; i += 256)
-    cursor[i] = seg[(int64_t) i * NB + wb];
+  const int pb0 = binblk[wb];
+  for (int i = threadIdx.x; i < S; i += 256) {
+    const int64_t key = (int64_t) i * NB + wb;
+    const int a0 = aoff[key], nb = aoff[key + 1] - a0, p0b = pb0 + prel[(int64_t) wb * S + i];
+    (void) nb;
+    cursor[i] = a0 * PB_BLK;
+    pdelta[i] = (p0b - a0) * PB_BLK;
+  }
+  __syncthreads();
+  // the block map of the bin's runs: one wavefront per run, a lane per block
+  for (int sl = threadIdx.x >> 6; sl < S; sl += 4) {
+    const int64_t key = (int64_t) sl * NB + wb;
+    const int a0 = cursor[sl] / PB_BLK, nb = aoff[key + 1] - a0, p0b = a0 + pdelta[sl] / PB_BLK;
+    for (int k = threadIdx.x & 63; k < nb; k += 64)
+      blkdst[a0 + k] = p0b + k;
+  }
   __syncthreads();
   const int64_t r0 = (int64_t) wb * H, r1 = (r0 + H) < m ? (r0 + H) : m;
   if (r0 >= m)
@@ -125,8 +205,8 @@ __global__ __launch_bounds__(256) void pb_scatter_kernel(int64_t m, const O* __r
     const int i = atomicAdd(&cursor[sl], 1);
     s_val[i] = values[p];
     s_col[i] = (uint16_t) (c - sl * W);
-    s_row[i] = (uint16_t) (lo - r0);
     perm[i] = (int32_t) p;
+    s_row[i + pdelta[sl]] = (uint16_t) (lo - r0);
   }
 }
 
@@ -144,12 +224,15 @@ static constexpr int PB_STAGE_MAX_S = 2048;
 template <typename T, typename O>
 __global__ __launch_bounds__(PB_STAGE_THREADS) void pb_scatter_staged_kernel(
     int64_t m, const O* __restrict__ rowptr, const int32_t* __restrict__ colind, const T* __restrict__ values, int W,
-    int H, int S, int NB, const int32_t* __restrict__ seg, T* __restrict__ s_val, uint16_t* __restrict__ s_col,
-    uint16_t* __restrict__ s_row, int32_t* __restrict__ perm, int hub_len, int cap, int rt_len) {
+    int H, int S, int NB, const int32_t* __restrict__ cnt, const int32_t* __restrict__ aoff,
+    const int32_t* __restrict__ prel, const int32_t* __restrict__ binblk, T* __restrict__ s_val,
+    uint16_t* __restrict__ s_col, uint16_t* __restrict__ s_row, int32_t* __restrict__ perm,
+    int32_t* __restrict__ blkdst, int hub_len, int cap, int rt_len) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   int* lcnt = reinterpret_cast<int*>(smem);  // [S] entries of this bin per slice
-  int* gdst = lcnt + S;                      // [S] start of the run in A' order
-  int* lcur = gdst + S;                      // [S] staging cursor (local offset, advanced by the atomics)
+  int* gdst = lcnt + S;                      // [S] first A' position of the run
+  int* pdst = gdst + S;                      // [S] first P position of the run
+  int* lcur = pdst + S;                      // [S] staging cursor (local offset, advanced by the atomics)
   int* rp = lcur + S;                        // [H + 1] the bin's row offsets relative to its first entry
   int* rt = rp + H + 1;                      // [rt_len] row of every 64th entry (narrows the row search)
   int* st = rt + rt_len;                     // [cap] staged entries: position relative to the first entry,
@@ -165,14 +248,23 @@ __global__ __launch_bounds__(PB_STAGE_THREADS) void pb_scatter_staged_kernel(
   const int ne = (int) (p1 - p0);
   if (ne == 0)
     return;  // nothing to place (and p0 may be the end of the arrays: the clamped gathers below need ne > 0)
+  const int pb0 = binblk[wb];
   for (int i = tid; i < S; i += PB_STAGE_THREADS) {
-    const int a = seg[(int64_t) i * NB + wb], b = seg[(int64_t) i * NB + wb + 1];
-    gdst[i] = a;
-    lcnt[i] = b - a;
+    const int64_t key = (int64_t) i * NB + wb;
+    const int a0 = aoff[key], p0b = pb0 + prel[(int64_t) wb * S + i];
+    lcnt[i] = cnt[key];
+    gdst[i] = a0 * PB_BLK;
+    pdst[i] = p0b * PB_BLK;
   }
   for (int i = tid; i <= nr; i += PB_STAGE_THREADS)
     rp[i] = (int) (rowptr[r0 + i] - p0);
   __syncthreads();
+  // the block map of the bin's runs: one wavefront per run, a lane per block
+  for (int sl = wave; sl < S; sl += PB_STAGE_THREADS / 64) {
+    const int nb = (lcnt[sl] + PB_BLK - 1) / PB_BLK, a0 = gdst[sl] / PB_BLK, p0b = pdst[sl] / PB_BLK;
+    for (int k = lane; k < nb; k += 64)
+      blkdst[a0 + k] = p0b + k;
+  }
   // row (inside the bin) of the entry at relative position q: last i in [lo, hi) with rp[i] <= q
   auto row_between = [&](int q, int lo, int hi) {
     while (hi - lo > 1) {
@@ -267,8 +359,8 @@ __global__ __launch_bounds__(PB_STAGE_THREADS) void pb_scatter_staged_kernel(
         const int i = gdst[sl] + pos;
         s_val[i] = values[p0 + q];
         s_col[i] = (uint16_t) (c - sl * W);
-        s_row[i] = (uint16_t) r;
         perm[i] = (int32_t) (p0 + q);
+        s_row[pdst[sl] + pos] = (uint16_t) r;
       } else {
         st[pos] = q;
         stv[pos] = values[p0 + q];  // neighbouring threads: neighbouring addresses
@@ -283,13 +375,13 @@ __global__ __launch_bounds__(PB_STAGE_THREADS) void pb_scatter_staged_kernel(
       // L2 hits, run at ~10 cycles per request and CU)
       constexpr int NW = PB_STAGE_THREADS / 64;
       for (int sl = s0 + wave; sl < s1; sl += NW) {
-        const int n = lcnt[sl], lo = lcur[sl] - n, g = gdst[sl];
+        const int n = lcnt[sl], lo = lcur[sl] - n, g = gdst[sl], gp = pdst[sl];
         for (int j = lane; j < n; j += 64) {
           const int q = st[lo + j];
           s_val[g + j] = stv[lo + j];
           s_col[g + j] = stc[lo + j];
-          s_row[g + j] = (uint16_t) row_of(q);
           perm[g + j] = (int32_t) (p0 + q);
+          s_row[gp + j] = (uint16_t) row_of(q);
         }
       }
     }
@@ -343,36 +435,16 @@ __global__ __launch_bounds__(256) void pb_balance_kernel(int S, int NB, int RW, 
   }
 }
 
-// entries of bin group g (RW bins) in slice s, from the exclusive offsets: out[g*S + s]
-__global__ __launch_bounds__(256) void pb_group_slice_kernel(int S, int NB, int RW, int64_t ngroups,
-                                                             const int32_t* __restrict__ seg,
-                                                             int32_t* __restrict__ out) {
-  const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
-  if (i >= ngroups * S)
-    return;
-  const int64_t g = i / S;
-  const int sl = (int) (i % S);
-  const int64_t b0 = g * RW, b1 = (g + 1) * RW < NB ? (g + 1) * RW : NB;
-  out[i] = seg[(int64_t) sl * NB + b1] - seg[(int64_t) sl * NB + b0];
-}
 
-// segT[b*S + s] = (start, length) of segment (s, b) in A' order
-__global__ __launch_bounds__(256) void pb_transpose_seg_kernel(int S, int NB, const int32_t* __restrict__ seg,
-                                                               int2* __restrict__ segT) {
-  const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
-  if (i >= (int64_t) S * NB)
-    return;
-  const int b = (int) (i / S), s = (int) (i % S);
-  const int64_t key = (int64_t) s * NB + b;
-  segT[i] = make_int2(seg[key], seg[key + 1] - seg[key]);
-}
-
+// s_val[i] = values[perm[i]] over the A'-order array; pads (perm < 0) stay 0
 template <typename T>
-__global__ __launch_bounds__(256) void pb_update_values_kernel(int64_t nnz, const int32_t* __restrict__ perm,
+__global__ __launch_bounds__(256) void pb_update_values_kernel(int64_t n_pad, const int32_t* __restrict__ perm,
                                                                const T* __restrict__ values, T* __restrict__ s_val) {
   const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
-  if (i < nnz)
-    s_val[i] = values[perm[i]];
+  if (i < n_pad) {
+    const int32_t p = stream_load(perm + i);
+    s_val[i] = p >= 0 ? values[p] : T(0);
+  }
 }
 
 // ---- execute ---------------------------------------------------------------------------
@@ -407,62 +479,65 @@ struct pack4<double> {
 
 typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
 
-// expand: P[i] = s_val[i] * x[slice_base + s_col[i]] over the slice's contiguous range of A'.
-// The x slice lives in LDS; A' and P are touched exactly once with 16-byte lane accesses.
+
+typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+
+// expand: P[blkdst[blk]] = s_val[blk] * x[slice_base + s_col[blk]] over the slice's contiguous blocks of A'.
+// The x slice lives in LDS.  Eight consecutive lanes own one block of 32 entries (4 entries = 16 B of values,
+// 8 B of columns each): the wavefront reads 8 consecutive blocks -- 1 KiB of values -- and stores 8 whole
+// 128-byte lines of products, each at the place the reduce kernel's stream wants it.
 template <typename T>
-__global__ __launch_bounds__(PB_THREADS) void pb_expand_kernel(int64_t n, int W, int NB, const int32_t* __restrict__ seg,
+__global__ __launch_bounds__(PB_THREADS) void pb_expand_kernel(int64_t n, int W, const int32_t* __restrict__ sliceblk,
                                                                const T* __restrict__ s_val,
                                                                const uint16_t* __restrict__ s_col,
+                                                               const int32_t* __restrict__ blkdst,
                                                                const T* __restrict__ x, T* __restrict__ P,
                                                                const int4* __restrict__ items, int S, int share) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   T* xs = reinterpret_cast<T*>(smem);
   const int tid = threadIdx.x;
+  const int sub = (tid & 7) * 4;  // first of this lane's 4 entries inside its block
+  const int bsel = tid >> 3;      // block inside the workgroup's pass of PB_THREADS / 8 blocks
+  constexpr int PASS = PB_THREADS / 8;
   auto load_x = [&](int s) {
     const int64_t c0 = (int64_t) s * W;
     const int cw = (int) ((n - c0) < W ? (n - c0) : W);
     for (int i = tid; i < cw; i += PB_THREADS)
       xs[i] = x[c0 + i];
   };
-  // entries [a0, a1) of the slice whose x values are in LDS
-  auto process = [&](int a0, int a1) {
-    int body0 = (a0 + 3) & ~3;
-    if (body0 > a1)
-      body0 = a1;
-    const int body1 = body0 + ((a1 - body0) & ~3);
-    // unaligned head and tail (< 4 entries each)
-    if (tid < body0 - a0)
-      P[a0 + tid] = s_val[a0 + tid] * xs[s_col[a0 + tid]];
-    if (tid < a1 - body1)
-      P[body1 + tid] = s_val[body1 + tid] * xs[s_col[body1 + tid]];
-    // aligned body: 4 entries (16 B of values, 8 B of columns) per lane per step, 2 steps in flight
-    int i = body0 + 4 * tid;
-    for (; i + 4 * PB_THREADS < body1; i += 8 * PB_THREADS) {
+  // blocks [b0, b1) of the slice whose x values are in LDS; two passes in flight
+  auto process = [&](int b0, int b1) {
+    int blk = b0 + bsel;
+    for (; blk + PASS < b1; blk += 2 * PASS) {
+      const int ea = blk * PB_BLK + sub, eb = ea + PASS * PB_BLK;
       T va[4], vb[4], pa[4], pb[4];
-      pack4<T>::load(s_val + i, va);
-      pack4<T>::load(s_val + i + 4 * PB_THREADS, vb);
-      const u16x4 ca = stream_load(reinterpret_cast<const u16x4*>(s_col + i));
-      const u16x4 cb = stream_load(reinterpret_cast<const u16x4*>(s_col + i + 4 * PB_THREADS));
+      pack4<T>::load(s_val + ea, va);
+      pack4<T>::load(s_val + eb, vb);
+      const u16x4 ca = stream_load(reinterpret_cast<const u16x4*>(s_col + ea));
+      const u16x4 cb = stream_load(reinterpret_cast<const u16x4*>(s_col + eb));
+      const int da = stream_load(blkdst + blk), db = stream_load(blkdst + blk + PASS);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         pa[j] = va[j] * xs[ca[j]];
         pb[j] = vb[j] * xs[cb[j]];
       }
-      pack4<T>::store(P + i, pa);
-      pack4<T>::store(P + i + 4 * PB_THREADS, pb);
+      pack4<T>::store(P + (int64_t) da * PB_BLK + sub, pa);
+      pack4<T>::store(P + (int64_t) db * PB_BLK + sub, pb);
     }
-    for (; i < body1; i += 4 * PB_THREADS) {
+    for (; blk < b1; blk += PASS) {
+      const int ea = blk * PB_BLK + sub;
       T va[4], pa[4];
-      pack4<T>::load(s_val + i, va);
-      const u16x4 ca = stream_load(reinterpret_cast<const u16x4*>(s_col + i));
+      pack4<T>::load(s_val + ea, va);
+      const u16x4 ca = stream_load(reinterpret_cast<const u16x4*>(s_col + ea));
+      const int da = stream_load(blkdst + blk);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         pa[j] = va[j] * xs[ca[j]];
-      pack4<T>::store(P + i, pa);
+      pack4<T>::store(P + (int64_t) da * PB_BLK + sub, pa);
     }
   };
   if (items) {
-    // items (column-skewed matrices): workgroup i takes entries [items[i].y, items[i].z) of slice items[i].x,
+    // items (column-skewed matrices): workgroup i takes the blocks [items[i].y, items[i].z) of slice items[i].x,
     // so that a slice holding a large share of the matrix is spread over proportionally many workgroups
     const int4 item = items[blockIdx.x];
     load_x(item.x);
@@ -470,12 +545,11 @@ __global__ __launch_bounds__(PB_THREADS) void pb_expand_kernel(int64_t n, int W,
     process(item.y, item.z);
     return;
   }
-  // Equal shares: workgroup b takes the entries [b*share, (b+1)*share) of A' (share is a multiple of 4) and
-  // loads the x slice of every slice its range touches -- one or two for the usual case of about one slice
-  // per workgroup.  The grid is exactly one wave of workgroups whatever the slice count is (slices cut for
-  // LDS capacity rarely come in multiples of 512; a second, nearly empty round of whole-slice workgroups cost
-  // up to 2x).
-  const int total = seg[(int64_t) S * NB];
+  // Equal shares: workgroup b takes the blocks [b*share, (b+1)*share) of A' and loads the x slice of every
+  // slice its range touches -- one or two for the usual case of about one slice per workgroup.  The grid is
+  // exactly one wave of workgroups whatever the slice count is (slices cut for LDS capacity rarely come in
+  // multiples of 512; a second, nearly empty round of whole-slice workgroups cost up to 2x).
+  const int total = sliceblk[S];
   const long long g0l = (long long) blockIdx.x * share;
   int g0 = g0l < total ? (int) g0l : total;
   const int g1 = (total - g0) < share ? total : g0 + share;
@@ -484,13 +558,13 @@ __global__ __launch_bounds__(PB_THREADS) void pb_expand_kernel(int64_t n, int W,
   int lo = 0, hi = S;  // last slice starting at or before g0
   while (hi - lo > 1) {
     const int mid = (lo + hi) >> 1;
-    if (seg[(int64_t) mid * NB] <= g0)
+    if (sliceblk[mid] <= g0)
       lo = mid;
     else
       hi = mid;
   }
   for (int s = lo; g0 < g1 && s < S; ++s) {
-    const int slice_end = seg[(int64_t) (s + 1) * NB];
+    const int slice_end = sliceblk[s + 1];
     if (slice_end <= g0)
       continue;  // empty slice
     const int a1 = g1 < slice_end ? g1 : slice_end;
@@ -502,270 +576,152 @@ __global__ __launch_bounds__(PB_THREADS) void pb_expand_kernel(int64_t n, int W,
   }
 }
 
-// inspect: mark duplicates.  Same walk as the reduce kernel: wave-bin -> groups of GR runs -> chunks.
-// The reduce kernel issues the LDS reads of a whole group (GR runs x C 64-entry chunks) before the
-// first write, so every entry whose row already occurs earlier in its group gets the duplicate
-// flag (bit 15) and takes the atomic path there.  Chunks beyond the C-th of a run are applied one
-// at a time and only need flags inside the chunk.
-//   tag[row]:   lane id, resolves repeats inside one chunk (exactly one lane reads back its own id)
-//   stamp[row]: id of the last group that claimed the row; ids wrap after 255 groups, and a stale
-//               match merely sends a unique entry down the (still correct) atomic path.
-__global__ __launch_bounds__(PB_RTHREADS) void pb_flag_dups_kernel(int Hw, int S, int64_t NBw, int C, int GR,
-                                                                   const int2* __restrict__ segT,
+// inspect: mark duplicates.  Same walk as the reduce kernel: wave-bin -> groups of 256 entries; lane l holds the
+// entries 4l .. 4l+3 of the group.  The reduce kernel issues the LDS reads of a whole group before the first
+// write, so of all entries of a group that share a row exactly one stays plain; the others get the duplicate
+// flag (bit 15) and take the atomic path there.  tag[row] = id (0..255) of the last entry that claimed the row.
+__global__ __launch_bounds__(PB_FTHREADS) void pb_flag_dups_kernel(int Hw, int64_t NBw,
+                                                                   const int32_t* __restrict__ binblk,
                                                                    uint16_t* __restrict__ s_row) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  unsigned char* tag = smem + (size_t) wave * 2 * Hw;
-  unsigned char* stamp = tag + Hw;
-  const int64_t wb = (int64_t) blockIdx.x * PB_RWAVES + wave;
+  unsigned char* tag = smem + (size_t) wave * (size_t) ((Hw + 63) & ~63);
+  const int64_t wb = (int64_t) blockIdx.x * PB_FWAVES + wave;
   if (wb >= NBw)
     return;
-  for (int i = lane; i < Hw; i += 64)
-    stamp[i] = 0;
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_s_waitcnt(0xc07f);
-  const int2* mine = segT + wb * S;
-  // one 64-entry chunk of a run: an entry whose row was already seen in this group (stamp) or is claimed by
-  // another lane of the chunk (tag) gets the flag
-  auto chunk = [&](int start, int ln, int base, int rw, bool have, unsigned char cur) {
-    const bool grouped = base < 64 * C;
-    const int o = base + lane;
-    const bool ok = o < ln;
-    int row = 0;
-    bool seen = false;
-    if (ok) {
-      row = (have ? rw : (int) s_row[start + o]) & 0x7FFF;
-      seen = grouped && stamp[row] == cur;
-      if (!seen)
-        tag[row] = (unsigned char) lane;
-    }
+  const int g0 = binblk[wb] / PB_GBLK, g1 = binblk[wb + 1] / PB_GBLK;
+  if (g0 >= g1)
+    return;
+  u16x4 nxt = *reinterpret_cast<const u16x4*>(s_row + (int64_t) g0 * PB_GRP + 4 * lane);
+  for (int g = g0; g < g1; ++g) {
+    u16x4* ptr = reinterpret_cast<u16x4*>(s_row + (int64_t) g * PB_GRP + 4 * lane);
+    u16x4 r = nxt;
+    if (g + 1 < g1)
+      nxt = *reinterpret_cast<const u16x4*>(s_row + (int64_t) (g + 1) * PB_GRP + 4 * lane);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if ((int) r[j] < Hw)  // pads carry row = Hw and never collide
+        tag[r[j]] = (unsigned char) (4 * lane + j);
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the tag stores have landed
-    if (ok) {
-      const bool won = !seen && tag[row] == (unsigned char) lane;
-      if (!won)
-        s_row[start + o] = (uint16_t) (row | 0x8000);
-      else if (grouped)
-        stamp[row] = cur;
-    }
+    bool changed = false;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if ((int) r[j] < Hw && tag[r[j]] != (unsigned char) (4 * lane + j)) {
+        r[j] = (unsigned short) (r[j] | 0x8000);
+        changed = true;
+      }
+    if (changed)
+      *ptr = r;
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-  };
-  // Runs are taken in batches of 8 (descriptors 64 at a time, one per lane): the first two chunks of all
-  // eight runs are loaded before the first is processed, so the wave waits for memory once per batch and
-  // not twice per chunk (0.77 -> 0.3 ms at cfg2).  Loads past the end of a run are clamped to its last
-  // entry (the arrays carry 64 entries of slack for empty trailing runs).
-  constexpr int B = 8, PC = 2;
-  for (int g0 = 0; g0 < S; g0 += 64) {
-    const int t = g0 + lane;
-    int2 d = mine[t < S ? t : S - 1];
-    if (t >= S)
-      d.y = 0;
-    for (int b0 = 0; b0 < 64 && g0 + b0 < S; b0 += B) {
-      int st[B], ln[B], rw[B][PC];
-#pragma unroll
-      for (int u = 0; u < B; ++u) {
-        st[u] = __builtin_amdgcn_readlane(d.x, b0 + u);
-        ln[u] = __builtin_amdgcn_readlane(d.y, b0 + u);
-        const int last = ln[u] > 0 ? ln[u] - 1 : 0;
-#pragma unroll
-        for (int c = 0; c < PC; ++c) {
-          const int o = lane + 64 * c;
-          rw[u][c] = s_row[st[u] + (o < last ? o : last)];
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < B; ++u) {
-        const int sidx = g0 + b0 + u;  // slice of this run; runs past S have ln = 0
-        const unsigned char cur = (unsigned char) ((sidx / GR) % 255 + 1);
-#pragma unroll
-        for (int c = 0; c < PC; ++c)
-          if (64 * c < ln[u])
-            chunk(st[u], ln[u], 64 * c, rw[u][c], true, cur);
-        for (int base = 64 * PC; base < ln[u]; base += 64)
-          chunk(st[u], ln[u], base, 0, false, cur);
-      }
-    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // the tag reads are done before the next group's stores
   }
 }
 
-// reduce: one wavefront per wave-bin (8 per workgroup).  The wave fetches 64 run descriptors
-// with one coalesced load, then handles runs four at a time: all product/row loads of the
-// four runs are issued before the first LDS read-modify-write consumes them.
-template <typename T>
-__device__ __forceinline__ void pb_apply(T* acc, T p, int r, bool ok) {
-  const int row = r & 0x7FFF;
-  const bool dup = ok && (r & 0x8000);
-  if (ok && !dup)
-    acc[row] += p;  // plain LDS read-add-write: rows are distinct within the instruction
-  if (__builtin_amdgcn_ballot_w64(dup) != 0) {
-    if (dup)
-      unsafeAtomicAdd(acc + row, p);
-  }
-}
-
-// RW wave-bins per workgroup; C 64-entry chunks of every run held in registers.  The loop is
-// software-pipelined by hand: the loads of batch k+1 (B runs) are
-// issued before batch k is applied.  Every load is unconditional -- lanes past the end of a run
-// re-read its last entry (same cache line, no extra traffic) -- because a load inside a divergent
-// branch makes the compiler drain vmcnt(0) at the join, which would serialise the pipeline.
-template <typename T, int RW, int C, int GR>
-__global__ __launch_bounds__(RW * 64) void pb_reduce_kernel(int64_t m, int Hw, int S, int64_t wb_begin, int64_t NBw,
-                                                            const int2* __restrict__ segT, const T* __restrict__ P,
+// reduce: RW wavefronts per workgroup, one wave-bin each.  The bin's entries are ONE contiguous stream of
+// groups (256 entries: lane l holds entries 4l..4l+3 -- a 16-byte product load and an 8-byte row load).
+// The loop is software-pipelined by hand: the loads of batch k+1 (UB groups) are issued before batch k is
+// applied; loads past the end of the stream are clamped to its last group (same lines, no extra traffic)
+// because a load inside a divergent branch makes the compiler drain vmcnt(0) at the join.
+//   item (ritems != nullptr: row-skewed matrices; else blockIdx): .x = bin group, .y / .z = this workgroup reduces
+//   part y of z equal parts of every wave-bin's stream, .w >= 0 = offset of its partial sums (RW*Hw values,
+//   pb_combine_items_kernel adds them), .w < 0 = the group is not split and y is written directly.
+template <typename T, int RW, int UB>
+__global__ __launch_bounds__(RW * 64) void pb_reduce_kernel(int64_t m, int Hw, int64_t wb_begin, int64_t NBw,
+                                                            const int32_t* __restrict__ binblk,
+                                                            const T* __restrict__ P,
                                                             const uint16_t* __restrict__ s_row, T* __restrict__ y,
-                                                            T alpha, T beta, int s_per, T* __restrict__ partial,
+                                                            T alpha, T beta, int K, T* __restrict__ partial,
                                                             int64_t pstride, T* const* __restrict__ peers,
                                                             int n_peers, int64_t peer_off,
-                                                            const int4* __restrict__ ritems) {
-  // blockIdx.y = k selects the slices [k*s_per, (k+1)*s_per): with few wave-bins (a row shard of
-  // a multi-GPU run) the slices are split over several workgroups per bin group, each writing a
-  // partial sum that pb_combine_kernel adds up in a fixed order.
-  // ritems (row-skewed matrices): workgroup i reduces the slices [ritems[i].y, ritems[i].z) of bin group
-  // ritems[i].x, so that a heavy group is spread over as many workgroups as its share of the entries
-  // asks for; .w >= 0 is the offset of its partial sums (RW*Hw values, pb_combine_items_kernel adds
-  // them up), .w < 0 means the group is not split and y is written directly.
+                                                            const int4* __restrict__ ritems, int dbg) {
+  // dbg (SPBLAS_GFX950_PB_DBG, timing experiments only -- results are wrong): 1 = skip the atomic path of flagged
+  // entries, 2 = no LDS traffic at all (the stream alone)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  T* acc = reinterpret_cast<T*>(smem) + (size_t) wave * Hw;
-  const int4 item = ritems ? ritems[blockIdx.x] : make_int4((int) blockIdx.x, 0, 0, 0);
+  T* acc = reinterpret_cast<T*>(smem) + (size_t) wave * (Hw + 64);  // Hw accumulators + 64 dummy slots
+  const int4 item = ritems ? ritems[blockIdx.x] : make_int4((int) blockIdx.x, (int) blockIdx.y, K, 0);
   const int64_t wb = wb_begin + (int64_t) item.x * RW + wave;  // NBw = end of the bin range
-  const int s_lo = ritems ? item.y : (int) blockIdx.y * s_per;
-  const int s_hi = ritems ? item.z : ((s_lo + s_per) < S ? (s_lo + s_per) : S);
   if (ritems)
-    partial = item.w >= 0 ? partial + item.w + (int64_t) wave * Hw - wb * (int64_t) Hw : nullptr;
+    partial = item.w >= 0 ? partial + item.w + (int64_t) wave * Hw : nullptr;
   if (wb >= NBw)
     return;
   const int64_t r0 = wb * Hw;
   const int rh = (int) ((m - r0) < Hw ? (m - r0) : Hw);
   for (int i = lane; i < rh; i += 64)
     acc[i] = T(0);
-  const int2* mine = segT + wb * S + s_lo;
-  const int ns = s_hi - s_lo;
-  constexpr int B = 8;         // runs per batch
-  constexpr int GB = 64 / B;   // 64 descriptors (one per lane) make a group of GB batches
+  const int gb0 = binblk[wb] / PB_GBLK, ng = binblk[wb + 1] / PB_GBLK - gb0;
+  const int g_lo = gb0 + (int) ((int64_t) ng * item.y / item.z);
+  const int g_hi = gb0 + (int) ((int64_t) ng * (item.y + 1) / item.z);
   struct batch_t {
-    T p[B][C];
-    int r[B][C];
-    int st[B], ln[B];
+    T p[UB][4];
+    u16x4 r[UB];
   };
-  // The wave issues one instruction at a time and only two waves share a SIMD (LDS bounds the occupancy),
-  // so the instruction count per 64-entry chunk is what the kernel time follows (SQ counters in DESIGN 4.3):
-  // 32-bit byte offsets from scalar bases for the loads, no exec-masked blocks around the stores -- lanes
-  // without a plain entry store to a per-lane dummy slot behind the accumulators instead.
-  T* const dummy = reinterpret_cast<T*>(smem) + (size_t) RW * Hw + wave * 64 + lane;
-  constexpr int SH = sizeof(T) == 4 ? 2 : 3;
-  auto fetch_group = [&](int g) -> int2 {  // descriptors of slices 64g .. 64g+63, one per lane
-    const int t = 64 * g + lane;
-    const int tc = t < ns ? t : (ns > 0 ? ns - 1 : 0);
-    int2 d = mine[tc];
-    if (t >= ns)
-      d.y = 0;
-    return d;
-  };
-  auto issue = [&](const int2& d, int j0, batch_t& q) {
+  // flagged entries store to a per-lane dummy slot behind the accumulators instead of sitting in an
+  // exec-masked block (the instruction count per group is what the kernel time follows once the stream is linear)
+  T* const dummy = acc + Hw + lane;
+  T dbg_sum = T(0);
+  auto issue = [&](int g, batch_t& q) {
 #pragma unroll
-    for (int u = 0; u < B; ++u) {
-      q.st[u] = __builtin_amdgcn_readlane(d.x, j0 + u);
-      q.ln[u] = __builtin_amdgcn_readlane(d.y, j0 + u);
-      const int last = q.ln[u] > 0 ? q.ln[u] - 1 : 0;
-#pragma unroll
-      for (int c = 0; c < C; ++c) {
-        const int o = lane + 64 * c;
-        // lanes past the end of the run re-read its last entry; byte offsets fit 32 bits (checked at build)
-        const unsigned offP = (unsigned) (q.st[u] + (o < last ? o : last)) << SH;
-        const unsigned offR = offP >> (SH - 1);
-        // products: read-once stream (nt: L1 bypass); row words: plain loads -- the 128-byte row lines are
-        // shared with the neighbouring chunk and hit in L1 on the second touch (reduce 147.5 -> 145 us;
-        // plain product loads instead: 173 us; plain column loads in the expand: +5 us there, +9 us here)
-        q.p[u][c] = stream_load(reinterpret_cast<const T*>(reinterpret_cast<const char*>(P) + offP));
-        if constexpr (sizeof(T) == 4)
-          q.r[u][c] = *reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(s_row) + offR);
-        else  // fp64: the plain row loads measured 2 % slower (667 vs 654 us at 10M^2)
-          q.r[u][c] = stream_load(reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(s_row) + offR));
-      }
+    for (int u = 0; u < UB; ++u) {
+      const int gg = (g + u) < g_hi ? (g + u) : (g_hi - 1);
+      // byte offsets fit 32 bits (checked at build): global_load with a scalar base
+      const unsigned offR = ((unsigned) gg * PB_GRP + 4u * (unsigned) lane) * 2u;
+      const unsigned offP = offR * (unsigned) (sizeof(T) / 2);
+      pack4<T>::load(reinterpret_cast<const T*>(reinterpret_cast<const char*>(P) + offP), q.p[u]);
+      q.r[u] = stream_load(reinterpret_cast<const u16x4*>(reinterpret_cast<const char*>(s_row) + offR));
     }
   };
-  auto consume = [&](const batch_t& q) {
+  auto consume = [&](int g, const batch_t& q) {
 #pragma unroll
-    for (int g = 0; g < B; g += GR) {
+    for (int u = 0; u < UB; ++u) {
+      if (g + u >= g_hi)
+        break;
+      if (dbg & 2) {
+        dbg_sum += q.p[u][0] + q.p[u][1] + q.p[u][2] + q.p[u][3] + T(q.r[u][0] ^ q.r[u][1] ^ q.r[u][2] ^ q.r[u][3]);
+        continue;
+      }
       // one group: all LDS reads, then all writes.  Rows of unflagged entries are distinct inside a
       // group (pb_flag_dups_kernel), flagged ones are added atomically afterwards.
-      T v[GR][C];
-      T* slot[GR][C];
-      bool plain[GR][C], dup[GR][C];
-      unsigned long long dups = 0;
+      T v[4];
+      T* slot[4];
+      bool flagged[4];
 #pragma unroll
-      for (int u = 0; u < GR; ++u)
-#pragma unroll
-        for (int c = 0; c < C; ++c) {
-          int r = q.r[g + u][c];
-          asm("" : "+v"(r));  // keep the row word a 32-bit value (the 16-bit forms cost extra masking)
-          const bool ok = lane + 64 * c < q.ln[g + u];
-          const bool flagged = (unsigned) r > 0x7FFFu;
-          slot[u][c] = acc + (r & 0x7FFF);
-          v[u][c] = *slot[u][c];  // clamped lanes hold a real entry too: the row is always in range
-          plain[u][c] = ok && !flagged;
-          dup[u][c] = ok && flagged;
-          dups |= __builtin_amdgcn_ballot_w64(dup[u][c]);
-        }
-#pragma unroll
-      for (int u = 0; u < GR; ++u)
-#pragma unroll
-        for (int c = 0; c < C; ++c) {
-          T* w = plain[u][c] ? slot[u][c] : dummy;
-          *w = v[u][c] + q.p[g + u][c];
-        }
-      if (dups != 0) {
-#pragma unroll
-        for (int u = 0; u < GR; ++u)
-#pragma unroll
-          for (int c = 0; c < C; ++c)
-            if (dup[u][c])
-              unsafeAtomicAdd(slot[u][c], q.p[g + u][c]);
+      for (int j = 0; j < 4; ++j) {
+        unsigned r = q.r[u][j];
+        asm("" : "+v"(r));  // keep the row word a 32-bit value (the 16-bit forms cost extra masking)
+        flagged[j] = r > 0x7FFFu;
+        slot[j] = acc + (r & 0x7FFFu);
+        v[j] = *slot[j];
       }
-      // longer runs: the tail straight from memory.  Keep these loads inside the `if`: with
-      // unconditional loads here the compiler loses track of the in-flight batch and waits
-      // vmcnt(0) before every chunk of the main path.
 #pragma unroll
-      for (int u = 0; u < GR; ++u)
-        for (int base = 64 * C; base < q.ln[g + u]; base += 64) {
-          const int o = base + lane;
-          const bool ok = o < q.ln[g + u];
-          T pp = T(0);
-          int rr = 0;
-          if (ok) {
-            pp = stream_load(P + q.st[g + u] + o);
-            rr = stream_load(s_row + q.st[g + u] + o);
-          }
-          pb_apply<T>(acc, pp, rr, ok);
-        }
+      for (int j = 0; j < 4; ++j) {
+        T* w = flagged[j] ? dummy : slot[j];
+        *w = v[j] + q.p[u][j];
+      }
+      if (!(dbg & 1) && __builtin_amdgcn_ballot_w64(flagged[0] | flagged[1] | flagged[2] | flagged[3]) != 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (flagged[j])
+            unsafeAtomicAdd(slot[j], q.p[u][j]);
+      }
     }
   };
-  if (ns > 0) {
-    const int nbatch = (ns + B - 1) / B;
-    int2 dcur = fetch_group(0), dnext = fetch_group(1);
-    // descriptors for batch kk (called with kk = 1, 2, 3, ... in order)
-    auto advance = [&](int kk) {
-      if ((kk % GB) == 0) {
-        dcur = dnext;
-        dnext = fetch_group(kk / GB + 1);
-      }
-    };
+  if (g_hi > g_lo) {
     batch_t qa, qb;
-    issue(dcur, 0, qa);
-    for (int k = 0; k < nbatch; k += 2) {
-      advance(k + 1);
-      issue(dcur, ((k + 1) % GB) * B, qb);  // past the last batch the descriptors have ln = 0
-      consume(qa);
-      advance(k + 2);
-      issue(dcur, ((k + 2) % GB) * B, qa);
-      consume(qb);
+    issue(g_lo, qa);
+    for (int g = g_lo; g < g_hi; g += 2 * UB) {
+      issue(g + UB, qb);
+      consume(g, qa);
+      issue(g + 2 * UB, qa);
+      consume(g + UB, qb);
     }
   }
+  if (dbg & 2)
+    *dummy = dbg_sum;
   if (partial) {
-    // uniform split: slot k of the [K][m] array; work items: the item's own RW*Hw block (pointer pre-biased
-    // above so that "+ r0" lands on this wave's part of it)
-    T* dst = partial + (ritems ? (int64_t) 0 : (int64_t) blockIdx.y * pstride) + r0;
+    // uniform split: slot k of the [K][m] array; work items: this wave's part of the item's own RW*Hw block
+    T* dst = ritems ? partial : partial + (int64_t) blockIdx.y * pstride + r0;
     for (int i = lane; i < rh; i += 64)
       dst[i] = acc[i];
     return;
@@ -875,18 +831,16 @@ __global__ __launch_bounds__(256) void pb_combine_items_kernel(const int4* __res
 }
 
 template <typename T>
-static const void* pb_reduce_fn(int rw, int c, int gr) {
-#define SPB_RK(RW_, C_, G_) reinterpret_cast<const void*>(pb_reduce_kernel<T, RW_, C_, G_>)
-#define SPB_RKG(RW_, C_) (gr == 1 ? SPB_RK(RW_, C_, 1) : (gr == 2 ? SPB_RK(RW_, C_, 2) : SPB_RK(RW_, C_, 4)))
-#define SPB_RKC(RW_) (c == 1 ? SPB_RKG(RW_, 1) : (c == 2 ? SPB_RKG(RW_, 2) : SPB_RKG(RW_, 4)))
-  return rw == 4 ? SPB_RKC(4) : SPB_RKC(8);
-#undef SPB_RKC
-#undef SPB_RKG
+static const void* pb_reduce_fn(int rw, int ub) {
+#define SPB_RK(RW_, UB_) reinterpret_cast<const void*>(pb_reduce_kernel<T, RW_, UB_>)
+  if (rw == 8)
+    return ub == 2 ? SPB_RK(8, 2) : (ub == 8 ? SPB_RK(8, 8) : SPB_RK(8, 4));
+  return ub == 2 ? SPB_RK(4, 2) : (ub == 8 ? SPB_RK(4, 8) : SPB_RK(4, 4));
 #undef SPB_RK
 }
 
 // ---- host -------------------------------------------------------------------------------
-static int pick_ksplit(int64_t groups, int S);
+static int pick_ksplit(int64_t waves, int64_t steps_per_bin);
 
 // number of pieces: enough that one piece fits the LDS budget; for big problems a multiple
 // of 512 (2 workgroups x 256 CUs) so the single wave of workgroups fills the chip evenly.
@@ -915,6 +869,7 @@ static void pick_tiling(int64_t extent, int max_elems, int round_to, int round_f
   *width = (int) w;
 }
 
+
 // SPBLAS_GFX950_TRACE_INSPECT=1: host-side time stamps of the inspect phases on stderr (drains the stream)
 struct pb_tracer {
   bool on;
@@ -934,60 +889,66 @@ struct pb_tracer {
   }
 };
 
+
 template <typename T, typename O>
 static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const void* values_p,
                               bool auto_mode) {
   hipStream_t s = h->stream;
   const int64_t m = pl->m, n = pl->n, nnz = pl->nnz;
-  // the reduce addresses the product stream with 32-bit byte offsets
-  if (nnz > INT32_MAX - 8 || (uint64_t) (nnz + 64) * sizeof(T) >= ((uint64_t) 1 << 32))
+  if (nnz > INT32_MAX - 8)
     return SPBLAS_GFX950_STATUS_NOT_SUPPORTED;
   // x slice of the expand: 80 KiB for fp32 (two workgroups per CU); for fp64 the whole 160 KiB of a CU
-  // (one workgroup), which halves the number of slices and doubles the run length again
-  // (10M^2, 10/row: 755 -> 651 us; for fp32 the wider slice changed nothing)
-  // fp32 switches to 160 KiB slices as well from n = 8 M on: twice the run length for the reduce (with the
-  // equal-share expand: n = 6 M -5 %, 8 M +1 %, 10 M +2..5 %, 11 M +26 %, 40 M +17 %)
-  // ... provided a slice still carries enough entries to pay for its x load (row shards of a multi-GPU run
-  // have the columns of the whole matrix but a fraction of its entries: 2.5 M x 10 M rows ran 15 % slower)
+  // (one workgroup), which halves the number of slices and doubles the run length
+  // fp32 switches to 160 KiB slices as well from n = 8 M on, provided a slice still carries enough entries to
+  // pay for its x load (row shards of a multi-GPU run have the columns of the whole matrix but a fraction of
+  // its entries: 2.5 M x 10 M rows ran 15 % slower)
   const int64_t s80 = cdiv(n, PB_LDS_BYTES / 4);
   const bool wide32 = sizeof(T) == 4 && s80 >= 390 && nnz / s80 >= 75000;
   const int xlds = env_int("SPBLAS_GFX950_PB_XLDS_KB", (sizeof(T) == 8 || wide32) ? 160 : PB_LDS_BYTES / 1024) * 1024;
   int max_cols = xlds / (int) sizeof(T);
   if (max_cols > 65536)
     max_cols = 65536;  // 16-bit local column
-  // reduce shape: RW wave-bins per workgroup share the 80 KiB.  Fewer, taller bins make longer runs
-  // (less cache-line over-fetch at run boundaries) but leave fewer wavefronts to hide latency.
+  // reduce shape: RW wave-bins per workgroup share `rlds` bytes of LDS.  Fewer, taller bins make longer runs
+  // (less block padding) but leave fewer wavefronts to hide latency.
   int RW = env_int("SPBLAS_GFX950_PB_RWAVES", PB_RWAVES_DEFAULT);
   if (RW != 4 && RW != 8)
     RW = PB_RWAVES_DEFAULT;
   pl->rwaves = RW;
-  // per wave-bin; < 32768 (15-bit row + flag); 64 dummy slots per wave follow the accumulators
-  int max_rows = PB_LDS_BYTES / RW / (int) sizeof(T) - 64;
-  if (max_rows > 32767)
-    max_rows = 32767;
+  int rlds = env_int("SPBLAS_GFX950_PB_RLDS_KB", PB_LDS_BYTES / 1024) * 1024;
+  if (rlds < 16 * 1024 || rlds > 160 * 1024)
+    rlds = PB_LDS_BYTES;
+  // per wave-bin; < 32768 - 64 (15-bit row + flag, pads carry row = H); 64 dummy slots per wave follow the accumulators
+  int max_rows = rlds / RW / (int) sizeof(T) - 64;
+  if (max_rows > 32000)
+    max_rows = 32000;
   int S, W, NB, H;
   const int w_env = env_int("SPBLAS_GFX950_SLICE_COLS", 0);  // test hooks: force small tiles
   const int h_env = env_int("SPBLAS_GFX950_SLICE_ROWS", 0);
-  // Slices: as few (as wide) as LDS allows -- every extra slice shortens all runs of the reduce (293 slices
-  // at n = 6 M rounded up to 512 cost 10 %).  The expand gives every workgroup an equal share of A' whatever
-  // the slice count is, so the count needs no rounding to waves of workgroups (SPBLAS_GFX950_PB_XROUND is a
-  // test hook).
+  // Slices: as few (as wide) as LDS allows -- every extra slice shortens all runs.  The expand gives every
+  // workgroup an equal share of A' whatever the slice count is, so the count needs no rounding to waves of
+  // workgroups (SPBLAS_GFX950_PB_XROUND is a test hook).
   const int xround = env_int("SPBLAS_GFX950_PB_XROUND", 1);
   pick_tiling(n, w_env > 0 && w_env < max_cols ? w_env : max_cols, xround, xround, 4, &S, &W);
-  // Matrices with few slices (n of a few million) would get runs of many hundred entries with
-  // full-height bins: beyond the C prefetched chunks a run is read in a latency-exposed loop, and there
-  // are too few bins to fill the chip.  Shorter bins bring the average run back to ~128 entries.
-  int h_want = max_rows;
+  // Bins: enough wavefronts to fill the chip (8 per CU = 2 048), but never so many that the average run drops
+  // below ~4 blocks (half a block of padding per run), and never taller than the LDS budget allows.  Too few
+  // bins for the chip are made up for by the slice-free K split of the reduce (every bin's stream cut in K parts).
   {
-    const int64_t bins_full = cdiv(m, max_rows);
-    const int64_t run_full = nnz / (bins_full * S > 0 ? bins_full * S : 1);
-    if (run_full > 160) {
-      const int64_t h = (int64_t) ((double) m * 128.0 * (double) S / (double) (nnz > 0 ? nnz : 1));
-      h_want = (int) (h < 64 ? 64 : (h > max_rows ? max_rows : h));
-    }
+    const int64_t nb_min = cdiv(m, max_rows);
+    const int64_t nb_fill = env_int("SPBLAS_GFX950_PB_BINS", 2048);
+    const int64_t nb_run = nnz / ((int64_t) S * 128);
+    int64_t nb = std::max<int64_t>(nb_min, std::min<int64_t>(nb_fill, nb_run));
+    if (nb < 1)
+      nb = 1;
+    int64_t hh = cdiv(m > 0 ? m : 1, nb);
+    if (h_env > 0 && h_env < max_rows)
+      hh = h_env;
+    if (hh > max_rows)
+      hh = max_rows;
+    if (hh < 1)
+      hh = 1;
+    H = (int) hh;
+    NB = (int) cdiv(m > 0 ? m : 1, H);
   }
-  const int bround = env_int("SPBLAS_GFX950_PB_ROUND", 512) * RW;
-  pick_tiling(m, h_env > 0 && h_env < max_rows ? h_env : h_want, bround, bround / 2, 1, &NB, &H);
   if (h->bin_row_align > 1) {
     // caller wants bin boundaries on multiples of bin_row_align (stripe boundaries of the overlapped
     // multi-GPU step): use the largest divisor of it that fits the LDS budget, if a decent one exists
@@ -1004,34 +965,22 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
     }
   }
   const int64_t nseg = (int64_t) S * NB;
-  if (nseg > (int64_t) 64 << 20 || S > 16384)  // S ints of LDS per inspect workgroup
+  if (nseg > (int64_t) 64 << 20 || S > 16384)  // 2 * S ints of LDS per inspect workgroup
     return SPBLAS_GFX950_STATUS_NOT_SUPPORTED;
   pl->n_slices = S;
   pl->slice_cols = W;
   pl->n_rblk = NB;
   pl->rows_per_blk = H;
-  pl->n_ksplit = pick_ksplit(cdiv(NB, RW), S);
-  {
-    const int64_t avg_run = nnz / (nseg > 0 ? nseg : 1);
-    int C = env_int("SPBLAS_GFX950_PB_RCHUNKS", 0);
-    if (C != 1 && C != 2 && C != 4)
-      C = avg_run > 112 ? 4 : (avg_run > 48 ? 2 : 1);
-    pl->rchunks = C;
-    int GR = env_int("SPBLAS_GFX950_PB_RGROUP", 0);
-    if (GR != 1 && GR != 2 && GR != 4)
-      GR = 2;
-    pl->rgroup = GR;
-  }
 
   int rc;
   pb_tracer tr(s);
-  int32_t* seg = nullptr;
+  int32_t *cnt = nullptr, *aoff = nullptr, *prel = nullptr;
   long long* partials = nullptr;
-  if ((rc = dev_alloc((void**) &seg, (size_t) (nseg + 1) * 4, s)))
+  if ((rc = dev_alloc((void**) &cnt, (size_t) (nseg + 1) * 4, s)))
     return rc;
-  tr.mark("seg allocated");
-  pl->seg_ptr = seg;
-  SPB_HIP(hipMemsetAsync(seg, 0, (size_t) (nseg + 1) * 4, s));
+  pl->seg_ptr = cnt;
+  tr.mark("cnt allocated");
+  SPB_HIP(hipMemsetAsync(cnt, 0, (size_t) (nseg + 1) * 4, s));
   const O* rowptr = static_cast<const O*>(pl->rowptr);
   // rows longer than the nnz window (the plan's long_rows list) stay out of the tiles
   pl->hub_len = pl->n_long > 0 ? pl->win : 0;
@@ -1045,23 +994,54 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
       return rc_h;
   }
   hipLaunchKernelGGL((pb_count_kernel<O>), dim3((unsigned) NB), dim3(256), (size_t) S * 4, s, m, rowptr, pl->colind, W, H, S,
-                     NB, seg, pl->hub_len);
+                     NB, cnt, pl->hub_len);
   tr.mark("count kernel");
   // One probe pass over the counters, read back once: entries per slice, non-empty tiles per slice, entries
   // per bin group.  AUTO uses them to decline matrices the plan does not suit; the work lists below use them
   // to spot column / row skew, and their total is the number of entries placed in tiles.
   const int64_t ngroups = cdiv(NB, RW);
   std::vector<unsigned long long> h_sum((size_t) (2 * S + ngroups));
-  {
-    unsigned long long* d_sum = nullptr;
-    if ((rc = dev_alloc((void**) &d_sum, h_sum.size() * sizeof(unsigned long long), s)))
-      return rc;
-    hipLaunchKernelGGL(pb_balance_kernel, dim3((unsigned) (S + ngroups)), dim3(256), 0, s, S, NB, RW, seg, d_sum,
-                       d_sum + S, d_sum + 2 * S);
-    SPB_HIP(hipMemcpyAsync(h_sum.data(), d_sum, h_sum.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-    SPB_HIP(hipStreamSynchronize(s));
-    dev_free(d_sum, s);
-  }
+  unsigned long long* d_sum = nullptr;
+  if ((rc = dev_alloc((void**) &d_sum, h_sum.size() * sizeof(unsigned long long), s)))
+    return rc;
+  struct temp_guard {  // inspect temporaries are released on every exit path
+    hipStream_t s;
+    void* p[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    ~temp_guard() {
+      for (void* q : p)
+        dev_free(q, s);
+    }
+  } temps{s};
+  temps.p[0] = d_sum;
+  hipLaunchKernelGGL(pb_balance_kernel, dim3((unsigned) (S + ngroups)), dim3(256), 0, s, S, NB, RW, cnt, d_sum,
+                     d_sum + S, d_sum + 2 * S);
+  SPB_HIP(hipMemcpyAsync(h_sum.data(), d_sum, h_sum.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+  // the block offsets of both orders are computed meanwhile (the probe read-back below is the only wait)
+  if ((rc = dev_alloc((void**) &aoff, (size_t) (nseg + 1) * 4, s)))
+    return rc;
+  temps.p[1] = aoff;
+  if ((rc = dev_alloc((void**) &prel, (size_t) (nseg + 1) * 4, s)))
+    return rc;
+  temps.p[2] = prel;
+  if ((rc = dev_alloc((void**) &partials, (size_t) (cdiv(nseg, 2048) + 2) * sizeof(long long), s)))
+    return rc;
+  temps.p[3] = partials;
+  if ((rc = dev_alloc(&pl->s_binblk, (size_t) (NB + 1) * 4, s)))
+    return rc;
+  if ((rc = dev_alloc(&pl->s_sliceblk, (size_t) (S + 1) * 4, s)))
+    return rc;
+  int32_t* binblk = static_cast<int32_t*>(pl->s_binblk);
+  int32_t* sliceblk = static_cast<int32_t*>(pl->s_sliceblk);
+  hipLaunchKernelGGL(pb_nblk_kernel, dim3((unsigned) cdiv(nseg, 256)), dim3(256), 0, s, nseg, cnt, aoff);
+  (void) scan_counts_i32(s, nseg, aoff, partials);  // aoff[nseg] = blocks in A' order
+  hipLaunchKernelGGL(pb_bin_prefix_kernel, dim3((unsigned) NB), dim3(256), 0, s, S, NB, cnt, prel, binblk);
+  (void) scan_counts_i32(s, NB, binblk, partials);  // binblk[NB] = blocks in P order (bins padded to groups)
+  hipLaunchKernelGGL(pb_slice_blocks_kernel, dim3((unsigned) cdiv(S + 1, 256)), dim3(256), 0, s, S, NB, aoff, sliceblk);
+  std::vector<int32_t> h_sliceblk((size_t) S + 1);
+  int32_t h_pblocks = 0;
+  SPB_HIP(hipMemcpyAsync(h_sliceblk.data(), sliceblk, (size_t) (S + 1) * 4, hipMemcpyDeviceToHost, s));
+  SPB_HIP(hipMemcpyAsync(&h_pblocks, binblk + NB, 4, hipMemcpyDeviceToHost, s));
+  SPB_HIP(hipStreamSynchronize(s));
   unsigned long long placed_total = 0, max_slice = 0, max_group = 0, ne = 0;
   for (int i = 0; i < S; ++i) {
     placed_total += h_sum[(size_t) i];
@@ -1086,121 +1066,91 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
         ((double) max_slice > 6.0 * mean_slice + 65536.0 || (double) max_group > 6.0 * mean_group + 65536.0))
       return SPBLAS_GFX950_STATUS_NOT_SUPPORTED;
   }
-  tr.mark("probe read back");
-  if ((rc = dev_alloc((void**) &partials, (size_t) (cdiv(nseg, 2048) + 2) * sizeof(long long), s)))
+  tr.mark("probe + block offsets read back");
+  const int64_t a_blocks = h_sliceblk[(size_t) S], p_blocks = h_pblocks;
+  pl->a_blocks = a_blocks;
+  pl->p_blocks = p_blocks;
+  const int64_t a_pad = a_blocks * PB_BLK, p_pad = p_blocks * PB_BLK;
+  // 32-bit entry indices in the expand, 32-bit byte offsets into the product stream in the reduce; and the
+  // padded copy must stay a small multiple of the matrix (runs of a few entries pad to a whole block: a matrix
+  // that sparse per tile should not be tiled)
+  if (p_pad > INT32_MAX - 1024 || (uint64_t) (p_pad + 1024) * sizeof(T) >= ((uint64_t) 1 << 32) ||
+      (auto_mode && p_pad > 2 * nnz + 65536))
+    return SPBLAS_GFX950_STATUS_NOT_SUPPORTED;
+  if ((rc = dev_alloc((void**) &pl->s_values, (size_t) (a_pad + 8) * sizeof(T), s)))
     return rc;
-  if ((rc = dev_alloc((void**) &pl->s_values, (size_t) nnz * sizeof(T), s)))
+  if ((rc = dev_alloc((void**) &pl->s_colind, (size_t) (a_pad + 8) * 2, s)))
     return rc;
-  if ((rc = dev_alloc((void**) &pl->s_colind, (size_t) nnz * 2, s)))
+  if ((rc = dev_alloc((void**) &pl->s_perm, (size_t) (a_pad + 8) * 4, s)))
     return rc;
-  // the reduce kernel's unconditional (clamped) loads touch entry `start` of an EMPTY run, which is
-  // entry nnz for empty runs at the very end: keep one cache line of slack behind both streams
-  if ((rc = dev_alloc((void**) &pl->s_lrow, (size_t) (nnz + 64) * 2, s)))
+  if ((rc = dev_alloc((void**) &pl->s_blkdst, (size_t) (a_blocks + 8) * 4, s)))
     return rc;
-  if ((rc = dev_alloc((void**) &pl->s_perm, (size_t) nnz * 4, s)))
+  if ((rc = dev_alloc((void**) &pl->s_lrow, (size_t) (p_pad + PB_GRP) * 2, s)))
     return rc;
-  if ((rc = dev_alloc((void**) &pl->s_products, (size_t) (nnz + 64) * sizeof(T), s)))
+  if ((rc = dev_alloc((void**) &pl->s_products, (size_t) (p_pad + PB_GRP) * sizeof(T), s)))
     return rc;
-  if ((rc = dev_alloc((void**) &pl->s_segT, (size_t) nseg * sizeof(int2), s)))
-    return rc;
-  pl->device_bytes += (size_t) nnz * (2 * sizeof(T) + 8) + (size_t) nseg * 16;
-  tr.mark("plan arrays allocated");
-  (void) scan_counts_i32(s, nseg, seg, partials);  // the total is already known from the probe
+  pl->device_bytes += (size_t) a_pad * (sizeof(T) + 6) + (size_t) a_blocks * 4 + (size_t) p_pad * (sizeof(T) + 2) +
+                      (size_t) (NB + S + 2) * 4 + (size_t) nseg * 4;
+  // pads: value 0, column 0, no source position, row = H (a dummy accumulator); products start finite
+  SPB_HIP(hipMemsetAsync(pl->s_values, 0, (size_t) (a_pad + 8) * sizeof(T), s));
+  SPB_HIP(hipMemsetAsync(pl->s_colind, 0, (size_t) (a_pad + 8) * 2, s));
+  SPB_HIP(hipMemsetAsync(pl->s_perm, 0xFF, (size_t) (a_pad + 8) * 4, s));
+  SPB_HIP(hipMemsetAsync(pl->s_blkdst, 0, (size_t) (a_blocks + 8) * 4, s));
+  SPB_HIP(hipMemsetD16Async(reinterpret_cast<hipDeviceptr_t>(pl->s_lrow), (unsigned short) H, (size_t) (p_pad + PB_GRP), s));
+  SPB_HIP(hipMemsetAsync(pl->s_products, 0, (size_t) (p_pad + PB_GRP) * sizeof(T), s));
+  tr.mark("plan arrays allocated + cleared");
+  pl->n_ksplit = pick_ksplit(NB, NB > 0 ? p_blocks / PB_GBLK / NB : 0);
   {
-    // column skew: slice sizes from the segment offsets; when one slice is far above the average the
-    // expand gets an explicit work list with workgroups in proportion to the slice sizes
-    // A' is slice-major: a slice starts where the entries of the slices before it end
-    std::vector<int64_t> start((size_t) S + 1, 0);
-    for (int i = 0; i < S; ++i)
-      start[(size_t) i + 1] = start[(size_t) i] + (int64_t) h_sum[(size_t) i];
-    const int64_t max_len = (int64_t) max_slice;
-    const int64_t total = start[(size_t) S];
-    if (total > 0 && max_len * S > 3 * total) {
+    // column skew: when one slice is far above the average the expand gets an explicit work list with
+    // workgroups in proportion to the slice sizes (in blocks of A')
+    const int64_t total = (int64_t) placed_total;
+    if (total > 0 && (int64_t) max_slice * S > 3 * total) {
       const int cus = h->num_cus > 0 ? h->num_cus : 256;
-      const int64_t target = std::max<int64_t>(cdiv(total, 2 * cus), 4 * (int64_t) W);
+      const int64_t target = std::max<int64_t>(cdiv(a_blocks, 2 * cus), 4 * (int64_t) W / PB_BLK);
       std::vector<int4> items;
       for (int i = 0; i < S; ++i) {
-        const int64_t lo = start[(size_t) i], hi = start[(size_t) i + 1];
+        const int64_t lo = h_sliceblk[(size_t) i], hi = h_sliceblk[(size_t) i + 1];
+        if (hi <= lo)
+          continue;
         const int64_t np = std::max<int64_t>(1, cdiv(hi - lo, target));
-        const int64_t per = (cdiv(hi - lo, np) + 3) & ~(int64_t) 3;
+        const int64_t per = cdiv(hi - lo, np);
         for (int64_t k = 0; k < np; ++k) {
-          // cut on multiples of 4 entries (absolute), the vector body of the kernel relies on it
-          int64_t a = k == 0 ? lo : ((lo + k * per + 3) & ~(int64_t) 3);
-          int64_t b = k == np - 1 ? hi : ((lo + (k + 1) * per + 3) & ~(int64_t) 3);
-          a = std::min(a, hi);
-          b = std::min(b, hi);
-          if (b > a || (k == 0 && np == 1))
+          const int64_t a = std::min(lo + k * per, hi), b = std::min(lo + (k + 1) * per, hi);
+          if (b > a)
             items.push_back(make_int4(i, (int) a, (int) b, 0));
         }
       }
-      if ((rc = dev_alloc(&pl->s_xitems, items.size() * sizeof(int4), s)))
-        return rc;
-      SPB_HIP(hipMemcpyAsync(pl->s_xitems, items.data(), items.size() * sizeof(int4), hipMemcpyHostToDevice, s));
-      SPB_HIP(hipStreamSynchronize(s));
-      pl->n_xitems = (int64_t) items.size();
+      if (!items.empty()) {
+        if ((rc = dev_alloc(&pl->s_xitems, items.size() * sizeof(int4), s)))
+          return rc;
+        SPB_HIP(hipMemcpyAsync(pl->s_xitems, items.data(), items.size() * sizeof(int4), hipMemcpyHostToDevice, s));
+        SPB_HIP(hipStreamSynchronize(s));
+        pl->n_xitems = (int64_t) items.size();
+      }
     }
   }
   {
-    // row skew: entries per (bin group, slice).  When one group is far above the average the reduce gets a
-    // work list: every group is cut into as many slice ranges as its share of the entries asks for.
-    // (the group totals come from the probe; the per-slice breakdown is only fetched for skewed matrices)
-    const int64_t cells = ngroups * S;
-    std::vector<int64_t> tot((size_t) ngroups, 0);
+    // row skew: when one bin group is far above the average the reduce gets a work list: every group's wave-bin
+    // streams are cut into as many equal parts as its share of the entries asks for; split groups write partial
+    // rows into a compact buffer and pb_combine_items_kernel adds them in part order (bit reproducible).
     const int64_t total = (int64_t) placed_total, max_tot = (int64_t) max_group;
-    for (int64_t g = 0; g < ngroups; ++g)
-      tot[(size_t) g] = (int64_t) h_sum[(size_t) (2 * S + g)];
-    std::vector<int32_t> gs;
-    if (total > 0 && max_tot * ngroups > 3 * total && S >= 16) {
-      int32_t* d_gs = nullptr;
-      if ((rc = dev_alloc((void**) &d_gs, (size_t) cells * 4, s)))
-        return rc;
-      hipLaunchKernelGGL(pb_group_slice_kernel, dim3((unsigned) cdiv(cells, 256)), dim3(256), 0, s, S, NB, RW, ngroups,
-                         seg, d_gs);
-      gs.resize((size_t) cells);
-      SPB_HIP(hipMemcpyAsync(gs.data(), d_gs, (size_t) cells * 4, hipMemcpyDeviceToHost, s));
-      SPB_HIP(hipStreamSynchronize(s));
-      dev_free(d_gs, s);
-    }
-    if (total > 0 && max_tot * ngroups > 3 * total && S >= 16) {
+    if (total > 0 && max_tot * ngroups > 3 * total && ngroups > 1) {
       const int64_t target = std::max<int64_t>(total / 768, 16384);
       const int64_t block = (int64_t) RW * H;  // values per partial block
       std::vector<int4> items, split;
       int64_t poff = 0;
       for (int64_t g = 0; g < ngroups; ++g) {
-        int64_t K = (tot[(size_t) g] + target / 2) / target;
-        K = std::max<int64_t>(1, std::min<int64_t>(K, S / 8));
-        if (K == 1) {
-          items.push_back(make_int4((int) g, 0, S, -1));
-          continue;
-        }
-        if (poff + K * block > (int64_t) INT32_MAX) {  // offsets are 32-bit: stop splitting
-          items.push_back(make_int4((int) g, 0, S, -1));
-          continue;
-        }
-        // cut at multiples of 8 slices (the duplicate-flag groups of the reduce kernel) by cumulative count
-        const int64_t first = (int64_t) items.size();
-        int lo = 0;
-        int64_t run = 0, done = 0;
-        int made = 0;
-        for (int sl = 0; sl < S; ++sl) {
-          run += gs[(size_t) (g * S + sl)];
-          const bool boundary = ((sl + 1) % 8 == 0) || sl + 1 == S;
-          if (boundary && made + 1 < K && (done + run) * K >= (int64_t) (made + 1) * tot[(size_t) g] && sl + 1 < S) {
-            items.push_back(make_int4((int) g, lo, sl + 1, 0));
-            lo = sl + 1;
-            done += run;
-            run = 0;
-            ++made;
-          }
-        }
-        items.push_back(make_int4((int) g, lo, S, 0));
-        const int64_t Kg = (int64_t) items.size() - first;
-        if (Kg == 1) {
-          items.back().w = -1;
+        const int64_t tot_g = (int64_t) h_sum[(size_t) (2 * S + g)];
+        int64_t Kg = (tot_g + target / 2) / target;
+        // a part should still hold a few groups of every wave-bin's stream
+        Kg = std::max<int64_t>(1, std::min<int64_t>(Kg, std::max<int64_t>(1, tot_g / ((int64_t) RW * 4 * PB_GRP))));
+        Kg = std::min<int64_t>(Kg, 256);
+        if (Kg == 1 || poff + Kg * block > (int64_t) INT32_MAX) {  // offsets are 32-bit: stop splitting
+          items.push_back(make_int4((int) g, 0, 1, -1));
           continue;
         }
         for (int64_t k = 0; k < Kg; ++k)
-          items[(size_t) (first + k)].w = (int) (poff + k * block);
+          items.push_back(make_int4((int) g, (int) k, (int) Kg, (int) (poff + k * block)));
         split.push_back(make_int4((int) g, (int) Kg, (int) poff, 0));
         poff += Kg * block;
       }
@@ -1218,42 +1168,39 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
       }
     }
   }
-  tr.mark("scan + work lists");
+  tr.mark("work lists");
   if (S <= PB_STAGE_MAX_S && env_int("SPBLAS_GFX950_PB_STAGED_SCATTER", 1)) {
     // a quarter of the staging area at most goes to the row table (one entry per 64 matrix entries of a bin)
     const int rt_len = 2048;
-    const int cap = (int) (((size_t) PB_STAGE_LDS - (size_t) 12 * S - (size_t) 4 * (H + 1) - (size_t) 4 * rt_len - 128) /
+    const int cap = (int) (((size_t) PB_STAGE_LDS - (size_t) 16 * S - (size_t) 4 * (H + 1) - (size_t) 4 * rt_len - 128) /
                            (6 + sizeof(T))) & ~7;
     SPB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pb_scatter_staged_kernel<T, O>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, PB_STAGE_LDS - 64));
     hipLaunchKernelGGL((pb_scatter_staged_kernel<T, O>), dim3((unsigned) NB), dim3(PB_STAGE_THREADS),
                        (size_t) PB_STAGE_LDS - 64, s, m, rowptr, pl->colind, static_cast<const T*>(values_p), W, H, S,
-                       NB, seg, static_cast<T*>(pl->s_values), reinterpret_cast<uint16_t*>(pl->s_colind), pl->s_lrow,
-                       reinterpret_cast<int32_t*>(pl->s_perm), pl->hub_len, cap, rt_len);
-  } else
-  hipLaunchKernelGGL((pb_scatter_kernel<T, O>), dim3((unsigned) NB), dim3(256), (size_t) S * 4, s, m, rowptr,
-                     pl->colind, static_cast<const T*>(values_p), W, H, S, NB, seg, static_cast<T*>(pl->s_values),
-                     reinterpret_cast<uint16_t*>(pl->s_colind), pl->s_lrow, reinterpret_cast<int32_t*>(pl->s_perm),
-                     pl->hub_len);
+                       NB, cnt, aoff, prel, binblk, static_cast<T*>(pl->s_values),
+                       reinterpret_cast<uint16_t*>(pl->s_colind), pl->s_lrow, reinterpret_cast<int32_t*>(pl->s_perm),
+                       static_cast<int32_t*>(pl->s_blkdst), pl->hub_len, cap, rt_len);
+  } else {
+    SPB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pb_scatter_kernel<T, O>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8));
+    hipLaunchKernelGGL((pb_scatter_kernel<T, O>), dim3((unsigned) NB), dim3(256), (size_t) S * 8, s, m, rowptr,
+                       pl->colind, static_cast<const T*>(values_p), W, H, S, NB, aoff, prel, binblk,
+                       static_cast<T*>(pl->s_values), reinterpret_cast<uint16_t*>(pl->s_colind), pl->s_lrow,
+                       reinterpret_cast<int32_t*>(pl->s_perm), static_cast<int32_t*>(pl->s_blkdst), pl->hub_len);
+  }
   tr.mark("scatter");
-  hipLaunchKernelGGL(pb_transpose_seg_kernel, dim3((unsigned) cdiv(nseg, 256)), dim3(256), 0, s, S, NB, seg,
-                     static_cast<int2*>(pl->s_segT));
   SPB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pb_flag_dups_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, PB_LDS_BYTES));
-  hipLaunchKernelGGL(pb_flag_dups_kernel, dim3((unsigned) cdiv(NB, PB_RWAVES)), dim3(PB_RTHREADS),
-                     (size_t) PB_RWAVES * 2 * H, s, H, S, (int64_t) NB, pl->rchunks, pl->rgroup,
-                     static_cast<const int2*>(pl->s_segT), pl->s_lrow);
+                              hipFuncAttributeMaxDynamicSharedMemorySize, PB_LDS_BYTES + 16 * 1024));
+  hipLaunchKernelGGL(pb_flag_dups_kernel, dim3((unsigned) cdiv(NB, PB_FWAVES)), dim3(PB_FTHREADS),
+                     (size_t) PB_FWAVES * (size_t) ((H + 63) & ~63), s, H, (int64_t) NB, binblk, pl->s_lrow);
   SPB_HIP(hipGetLastError());
   SPB_HIP(hipStreamSynchronize(s));
   tr.mark("flags");
-  dev_free(partials, s);
-  // both kernels may use up to 80 KiB of dynamic LDS
   SPB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pb_expand_kernel<T>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, xlds > PB_LDS_BYTES ? xlds : PB_LDS_BYTES));
-  {
-    const void* fn = pb_reduce_fn<T>(pl->rwaves, pl->rchunks, pl->rgroup);
-    SPB_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, PB_LDS_BYTES));
-  }
+  for (int ub : {2, 4, 8})
+    SPB_HIP(hipFuncSetAttribute(pb_reduce_fn<T>(pl->rwaves, ub), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   return SPBLAS_GFX950_STATUS_SUCCESS;
 }
 
@@ -1269,10 +1216,11 @@ int spmv_sliced_build(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const 
 template <typename T>
 static int sliced_update_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const void* values) {
   pl->values_ptr = values;  // the hub rows read the caller's array directly
-  if (pl->s_placed == 0)
+  const int64_t a_pad = pl->a_blocks * PB_BLK;
+  if (pl->s_placed == 0 || a_pad == 0)
     return SPBLAS_GFX950_STATUS_SUCCESS;
-  hipLaunchKernelGGL((pb_update_values_kernel<T>), dim3((unsigned) cdiv(pl->s_placed, 256)), dim3(256), 0, h->stream,
-                     pl->s_placed, reinterpret_cast<const int32_t*>(pl->s_perm), static_cast<const T*>(values),
+  hipLaunchKernelGGL((pb_update_values_kernel<T>), dim3((unsigned) cdiv(a_pad, 256)), dim3(256), 0, h->stream, a_pad,
+                     reinterpret_cast<const int32_t*>(pl->s_perm), static_cast<const T*>(values),
                      static_cast<T*>(pl->s_values));
   SPB_HIP(hipGetLastError());
   return SPBLAS_GFX950_STATUS_SUCCESS;
@@ -1283,28 +1231,31 @@ int spmv_sliced_update(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const
                                              : sliced_update_typed<double>(h, pl, values);
 }
 
-static int pick_ksplit(int64_t groups, int S) {
+// parts every wave-bin's stream is cut into when there are too few wave-bins to fill the chip (a row shard of a
+// multi-GPU run): at least 4 wavefronts per CU in flight, but a part keeps >= 8 steps of 256 entries
+static int pick_ksplit(int64_t waves, int64_t steps_per_bin) {
   int K = env_int("SPBLAS_GFX950_PB_KSPLIT", 0);
   if (K <= 0) {
     K = 1;
-    while (groups * K < 384 && K < 32 && S / (2 * K) >= 8)
+    while (waves * K < 1024 && K < 32 && steps_per_bin / (2 * K) >= 8)
       K *= 2;
   }
-  return K > S ? S : (K < 1 ? 1 : K);
+  return K < 1 ? 1 : K;
 }
 
 template <typename T>
 static int sliced_expand_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const void* x) {
   pl->last_x = x;  // the hub rows are computed in the reduce stage and gather x themselves
-  const int32_t* seg = reinterpret_cast<const int32_t*>(pl->seg_ptr);
   // one wave of workgroups (2 per CU with 80 KiB slices, 1 with 160 KiB), but never shares so small that
   // re-loading the x slice dominates
   const int4* items = static_cast<const int4*>(pl->s_xitems);
   const int cus = h->num_cus > 0 ? h->num_cus : 256;
   const size_t xbytes = (size_t) pl->slice_cols * sizeof(T);
   int64_t nwg = (int64_t) cus * (xbytes > (size_t) PB_LDS_BYTES ? 1 : 2);
-  const int64_t total = pl->s_placed;
-  const int64_t min_share = 2 * (int64_t) pl->slice_cols;
+  const int64_t total = pl->a_blocks;
+  if (total == 0)
+    return SPBLAS_GFX950_STATUS_SUCCESS;
+  const int64_t min_share = std::max<int64_t>(1, 2 * (int64_t) pl->slice_cols / PB_BLK);
   if (nwg * min_share > total) {
     // ... but not fewer workgroups than slices (row shards: many slices with few entries each)
     const int64_t floor_wg = pl->n_slices < nwg ? pl->n_slices : nwg;
@@ -1314,12 +1265,14 @@ static int sliced_expand_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* p
   }
   if (nwg < 1)
     nwg = 1;
-  const int share = (int) ((cdiv(total > 0 ? total : 1, nwg) + 3) & ~(int64_t) 3);
-  const dim3 grid = items ? dim3((unsigned) pl->n_xitems) : dim3((unsigned) cdiv(total > 0 ? total : 1, share));
+  if (env_int("SPBLAS_GFX950_PB_DBG", 0) & 4)
+    return SPBLAS_GFX950_STATUS_SUCCESS;  // timing experiment: the reduce alone
+  const int share = (int) cdiv(total, nwg);
+  const dim3 grid = items ? dim3((unsigned) pl->n_xitems) : dim3((unsigned) cdiv(total, share));
   hipLaunchKernelGGL((pb_expand_kernel<T>), grid, dim3(PB_THREADS), xbytes, h->stream, pl->n, pl->slice_cols,
-                     (int) pl->n_rblk, seg, static_cast<const T*>(pl->s_values),
-                     reinterpret_cast<const uint16_t*>(pl->s_colind), static_cast<const T*>(x),
-                     static_cast<T*>(pl->s_products), items, (int) pl->n_slices, share);
+                     static_cast<const int32_t*>(pl->s_sliceblk), static_cast<const T*>(pl->s_values),
+                     reinterpret_cast<const uint16_t*>(pl->s_colind), static_cast<const int32_t*>(pl->s_blkdst),
+                     static_cast<const T*>(x), static_cast<T*>(pl->s_products), items, (int) pl->n_slices, share);
   SPB_HIP(hipGetLastError());
   return SPBLAS_GFX950_STATUS_SUCCESS;
 }
@@ -1336,18 +1289,17 @@ static int sliced_reduce_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* p
     return SPBLAS_GFX950_STATUS_NOT_SUPPORTED;  // the fused all-gather epilogue does not cover hub rows
   const T alpha = *static_cast<const T*>(alpha_p), beta = *static_cast<const T*>(beta_p);
   const int RW = pl->rwaves;
+  int UB = env_int("SPBLAS_GFX950_PB_RBATCH", 4);
+  if (UB != 2 && UB != 8)
+    UB = 4;
   const int64_t groups = cdiv(wb_end - wb_begin, RW);
-  // slices per split: whole batches of 8 runs, so the duplicate-flag groups stay aligned
-  int k_want = pick_ksplit(groups, pl->n_slices);
-  if (h->max_ksplit > 0 && k_want > h->max_ksplit)
-    k_want = (int) h->max_ksplit;  // striped callers run several reduces side by side
-  const int s_per = (int) cdiv(cdiv(pl->n_slices, k_want), 8) * 8;
-  const int K = (int) cdiv(pl->n_slices, s_per);
+  int K = pick_ksplit(wb_end - wb_begin, pl->n_rblk > 0 ? pl->p_blocks / PB_GBLK / pl->n_rblk : 0);
+  if (h->max_ksplit > 0 && K > h->max_ksplit)
+    K = (int) h->max_ksplit;  // striped callers run several reduces side by side
   const int64_t r_lo = wb_begin * pl->rows_per_blk;
   const int64_t r_hi = wb_end * pl->rows_per_blk < pl->m ? wb_end * pl->rows_per_blk : pl->m;
-  bool K_used_items = false;
-  const bool will_use_items = pl->s_ritems && !peers_p && wb_begin == 0 && wb_end == pl->n_rblk;
-  if (!will_use_items && K > 1 && pl->s_partial_k < K) {  // grow the partial-sum workspace (stream ordered)
+  const bool use_items = pl->s_ritems && !peers_p && wb_begin == 0 && wb_end == pl->n_rblk;
+  if (!use_items && K > 1 && pl->s_partial_k < K) {  // grow the partial-sum workspace (stream ordered)
     dev_free(pl->s_partial, s);
     pl->s_partial = nullptr;
     int rc = dev_alloc(&pl->s_partial, (size_t) K * pl->m * sizeof(T), s);
@@ -1356,39 +1308,39 @@ static int sliced_reduce_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* p
     pl->s_partial_k = K;
   }
   {
-    const int2* segT = static_cast<const int2*>(pl->s_segT);
+    const int32_t* binblk = static_cast<const int32_t*>(pl->s_binblk);
     const T* Pp = static_cast<const T*>(pl->s_products);
     const uint16_t* rowp = pl->s_lrow;
     T* yp = static_cast<T*>(y);
     T* part = K > 1 ? static_cast<T*>(pl->s_partial) : nullptr;
     int64_t mm = pl->m, pstride = pl->m;
-    int Hw = pl->rows_per_blk, S = pl->n_slices, sp = s_per;
+    int Hw = pl->rows_per_blk, Kk = K;
     T a = alpha, b = beta;
     T* const* peers = reinterpret_cast<T* const*>(peers_p);
     const int4* ritems = nullptr;
-    void* args[] = {&mm, &Hw, &S, &wb_begin, &wb_end, &segT, &Pp, &rowp, &yp, &a, &b, &sp, &part, &pstride,
-                    &peers, &n_peers, &peer_off, &ritems};
-    if (pl->s_ritems && !peers_p && wb_begin == 0 && wb_end == pl->n_rblk) {
+    int dbg = env_int("SPBLAS_GFX950_PB_DBG", 0);
+    void* args[] = {&mm, &Hw, &wb_begin, &wb_end, &binblk, &Pp, &rowp, &yp, &a, &b, &Kk, &part, &pstride,
+                    &peers, &n_peers, &peer_off, &ritems, &dbg};
+    const size_t lds = (size_t) RW * (pl->rows_per_blk + 64) * sizeof(T);
+    if (use_items) {
       // row-skewed matrix, whole range: explicit work list (built at inspect), compact partial sums
       ritems = static_cast<const int4*>(pl->s_ritems);
       part = static_cast<T*>(pl->s_rpartial);
       pstride = 0;
-      SPB_HIP(hipLaunchKernel(pb_reduce_fn<T>(RW, pl->rchunks, pl->rgroup), dim3((unsigned) pl->n_ritems), dim3(RW * 64),
-                              args, (size_t) RW * (pl->rows_per_blk + 64) * sizeof(T), s));
+      SPB_HIP(hipLaunchKernel(pb_reduce_fn<T>(RW, UB), dim3((unsigned) pl->n_ritems), dim3(RW * 64), args, lds, s));
       if (pl->n_rsplit > 0)
         hipLaunchKernelGGL((pb_combine_items_kernel<T>),
                            dim3((unsigned) pl->n_rsplit, (unsigned) cdiv((int64_t) RW * pl->rows_per_blk, 256)), dim3(256),
                            0, s, static_cast<const int4*>(pl->s_rsplit), (int64_t) RW * pl->rows_per_blk, pl->m,
                            static_cast<const T*>(pl->s_rpartial), static_cast<T*>(y), alpha, beta);
-      K_used_items = true;
-    } else
-    SPB_HIP(hipLaunchKernel(pb_reduce_fn<T>(RW, pl->rchunks, pl->rgroup), dim3((unsigned) groups, (unsigned) K), dim3(RW * 64), args,
-                            (size_t) RW * (pl->rows_per_blk + 64) * sizeof(T), s));
+    } else {
+      SPB_HIP(hipLaunchKernel(pb_reduce_fn<T>(RW, UB), dim3((unsigned) groups, (unsigned) K), dim3(RW * 64), args, lds, s));
+      if (K > 1 && r_hi > r_lo)
+        hipLaunchKernelGGL((pb_combine_kernel<T>), dim3((unsigned) cdiv(r_hi - r_lo, 256)), dim3(256), 0, s, r_lo, r_hi, K,
+                           static_cast<const T*>(pl->s_partial), pl->m, static_cast<T*>(y), alpha, beta,
+                           reinterpret_cast<T* const*>(peers_p), n_peers, peer_off);
+    }
   }
-  if (!K_used_items && K > 1 && r_hi > r_lo)
-    hipLaunchKernelGGL((pb_combine_kernel<T>), dim3((unsigned) cdiv(r_hi - r_lo, 256)), dim3(256), 0, s, r_lo, r_hi, K,
-                       static_cast<const T*>(pl->s_partial), pl->m, static_cast<T*>(y), alpha, beta,
-                       reinterpret_cast<T* const*>(peers_p), n_peers, peer_off);
   if (pl->hub_len > 0 && pl->n_long > 0) {
     // rows kept out of the tiles: y[row] += alpha * (row . x), for the rows of this bin range
     if (!pl->values_ptr || !pl->last_x)
@@ -1412,11 +1364,11 @@ static int sliced_reduce_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* p
   return SPBLAS_GFX950_STATUS_SUCCESS;
 }
 
-// slice split the reduce of the WHOLE row range would use, and the partial-sum workspace for it:
+// split the reduce of the WHOLE row range would use, and the partial-sum workspace for it:
 // callers that reduce stripe by stripe on several streams cap K with it (handle->max_ksplit) and
 // reserve the workspace before they fork, so no stripe allocates.
 int spmv_sliced_full_ksplit(spblas_gfx950_plan_s* pl) {
-  return pick_ksplit(cdiv(pl->n_rblk, pl->rwaves), pl->n_slices);
+  return pick_ksplit(pl->n_rblk, pl->n_rblk > 0 ? pl->p_blocks / PB_GBLK / pl->n_rblk : 0);
 }
 
 int spmv_sliced_reserve_partial(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, int K) {
@@ -1464,12 +1416,14 @@ int spmv_sliced_exec(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const v
 void spmv_sliced_free(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl) {
   hipStream_t s = h->stream;
   dev_free(pl->seg_ptr, s);
+  dev_free(pl->s_sliceblk, s);
+  dev_free(pl->s_binblk, s);
+  dev_free(pl->s_blkdst, s);
   dev_free(pl->s_colind, s);
   dev_free(pl->s_values, s);
   dev_free(pl->s_lrow, s);
   dev_free(pl->s_perm, s);
   dev_free(pl->s_products, s);
-  dev_free(pl->s_segT, s);
   dev_free(pl->s_partial, s);
   dev_free(pl->s_hub_part, s);
   dev_free(pl->s_xitems, s);
@@ -1483,8 +1437,10 @@ void spmv_sliced_free(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl) {
   pl->s_xitems = nullptr;
   pl->n_xitems = 0;
   pl->s_partial_k = 0;
-  pl->seg_ptr = pl->s_colind = pl->s_values = pl->s_products = pl->s_segT = pl->s_perm = nullptr;
+  pl->seg_ptr = pl->s_colind = pl->s_values = pl->s_products = pl->s_perm = nullptr;
+  pl->s_sliceblk = pl->s_binblk = pl->s_blkdst = nullptr;
   pl->s_lrow = nullptr;
+  pl->a_blocks = pl->p_blocks = 0;
   pl->n_slices = 0;
 }
 

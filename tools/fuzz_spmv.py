@@ -14,7 +14,7 @@ import util
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 HOOKS = ["SPBLAS_GFX950_SLICE_COLS", "SPBLAS_GFX950_SLICE_ROWS", "SPBLAS_GFX950_PB_KSPLIT", "SPBLAS_GFX950_PB_RWAVES",
-         "SPBLAS_GFX950_PB_RCHUNKS", "SPBLAS_GFX950_PB_RGROUP"]
+         "SPBLAS_GFX950_PB_RBATCH", "SPBLAS_GFX950_PB_RLDS_KB", "SPBLAS_GFX950_PB_BINS"]
 dev = torch.device("cuda:0")
 bad = 0
 for it in range(iters):
@@ -59,8 +59,9 @@ for it in range(iters):
             hooks["SPBLAS_GFX950_SLICE_ROWS"] = str(int(rng.choice([1, 16, 64, 700, 5000])))
         hooks["SPBLAS_GFX950_PB_KSPLIT"] = str(int(rng.choice([0, 1, 2, 8, 32])))
         hooks["SPBLAS_GFX950_PB_RWAVES"] = str(int(rng.choice([4, 8])))
-        hooks["SPBLAS_GFX950_PB_RCHUNKS"] = str(int(rng.choice([0, 1, 2, 4])))
-        hooks["SPBLAS_GFX950_PB_RGROUP"] = str(int(rng.choice([0, 1, 2, 4])))
+        hooks["SPBLAS_GFX950_PB_RBATCH"] = str(int(rng.choice([2, 4, 8])))
+        hooks["SPBLAS_GFX950_PB_RLDS_KB"] = str(int(rng.choice([40, 80, 160])))
+        hooks["SPBLAS_GFX950_PB_BINS"] = str(int(rng.choice([64, 512, 2048, 4096])))
     os.environ.update(hooks)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     rp_dev = t(rowptr.astype(np.int64 if off64 else np.int32))

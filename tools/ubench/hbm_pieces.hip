@@ -147,7 +147,7 @@ int main() {
   printf("%6s %5s %9s | %8s %8s %8s | %8s %8s   (GB/s; expand-like moves 10 B/entry, reduce-like 6 B/entry)\n", "L", "S",
          "entries", "lin", "wr_T", "wr_hash", "rd_lin", "rd_T");
   // S chosen so that S * NB * L ~ 1e8 entries
-  for (int L : {32, 64, 100, 128, 200, 256, 512, 1024, 4096}) {
+  for (int L : {8, 16, 32, 64, 100, 128}) {
     const int L4 = L / 4;
     int S = (int) (100000000L / ((long) NB * L));
     if (S < 1)
