@@ -448,6 +448,11 @@ static int plan_build(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, int al
   const int64_t long_cap = nnz / pl->win + 1;
   if ((rc = dev_alloc((void**) &d_stats, 4 * sizeof(unsigned long long), s)))
     return rc;
+  struct stats_guard {  // released on every exit path (plan-owned arrays are freed by plan_destroy)
+    void* p;
+    hipStream_t s;
+    ~stats_guard() { dev_free(p, s); }
+  } guard{d_stats, s};
   if ((rc = dev_alloc((void**) &pl->long_rows, (size_t) long_cap * 4, s)))
     return rc;
   if ((rc = dev_alloc((void**) &pl->win_row, (size_t) (pl->nwin + 1) * 4, s)))
@@ -463,7 +468,6 @@ static int plan_build(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, int al
   unsigned long long stats[4];
   SPB_HIP(hipMemcpyAsync(stats, d_stats, sizeof(stats), hipMemcpyDeviceToHost, s));
   SPB_HIP(hipStreamSynchronize(s));
-  dev_free(d_stats, s);
   pl->max_row_len = (int64_t) stats[0];
   pl->n_long = (int64_t) stats[1];
   pl->empty_rows = (int64_t) stats[2];
