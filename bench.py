@@ -8,7 +8,9 @@ Default (N=1): cfg2 = fp32 CSR SpMV, 10M x 10M, exactly 10 nnz/row, columns iid 
 (unsorted), values/x U[0,1), int32 indices, inputs resident in HBM before the timed region.
 A "step" = one multiply(info, A, x, y) (the inspect phase runs once, outside the timed
 region, and is reported separately).  N>1: the SAME global matrix row-sharded over N
-ranks (strong scaling), step = local SpMV + ONE RCCL all-gather of y (in the timed region).
+ranks (strong scaling), step = local SpMV + ONE all-gather of y (in the timed region); the JSON's
+"multi_gpu" object says where the step time goes (local kernels / gather / RCCL step / fused step).
+--workload spmv_rmat is BASELINE cfg4 on the same harness: fp64 R-MAT scale 24, rows sharded by nnz prefix.
 One JSON line on rank 0.  roofline.achieved = algorithmic bytes per launch (SURVEY.md
 section 8d: nnz*(sizeof(T)+4) + (m+1)*4 + n*sizeof(T) + m*sizeof(T)) / average kernel
 duration from HIP events recorded on the launch stream around the timed steps.
@@ -79,7 +81,7 @@ def spmv_bytes(m, n, nnz, tsize):
 
 
 def read_pmc_traffic(name):
-    """HBM bytes per launch from the committed PMC profile (profiles/<round>_pmc.json), or None."""
+    """HBM bytes per launch from the committed PMC profile (profiles/pmc_traffic.json), or None."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as f:
@@ -116,6 +118,84 @@ def cpu_baseline_spmv(values, rowptr, colind, shape, x, nnz):
                           "note": "OpenMP static row-parallel variant of the same loop"}}
 
 
+def measure(step, steps, warmup, multi, device):
+    """W untimed steps, then EXACTLY K steps between barrier + synchronize on both sides; ONE pair of HIP events on
+    the launch stream brackets the region (per-step event records were measured to cost up to 25 us per step).
+    Returns (wall seconds: max over ranks, average ms per step between the events)."""
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    if multi:
+        dist.barrier()
+    torch.cuda.synchronize()
+    region = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+    t0 = time.perf_counter()
+    region[0].record()
+    for _ in range(steps):
+        step()
+    region[1].record()
+    torch.cuda.synchronize()
+    if multi:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    el = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if multi:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    return float(el.item()), region[0].elapsed_time(region[1]) / steps
+
+
+def build_cfg2(args, world, rank, device, sharded, sp):
+    """cfg2: the SAME global 10M x 10M matrix for every N (generated per fixed row chunk), equal row shards."""
+    poisson = args.workload == "spmv_poisson"
+    m = n = args.rows or 10_000_000
+    if args.cols:
+        n = args.cols
+    dtype = torch.float32
+    chunks = args.chunks if args.chunks > 0 else 1
+    ranges = sharded.striped_row_ranges(m, world, chunks)
+    if ranges is None or poisson and world > 1:
+        chunks = 1
+        ranges = sharded.striped_row_ranges(m, world, 1)
+    if ranges is None:
+        sys.exit(f"rows={m} is not divisible by the number of ranks")
+    a_chunks, nnz_local = [], 0
+    for c in range(chunks):
+        lo, hi = ranges[c][rank]
+        v_c, rp_c, ci_c, nnz_c = gen_rows(lo, hi, n, 10, poisson, dtype, device)
+        a_chunks.append(sp.csr_view(v_c, rp_c, ci_c, (hi - lo, n), nnz_c))
+        nnz_local += nnz_c
+    label = (f"cfg2: fp32 CSR SpMV {m}x{n}, {'Poisson(10)' if poisson else 'exactly 10'} nnz/row, "
+             f"uniform random unsorted columns, int32 indices")
+    return {"m": m, "n": n, "dtype": dtype, "tsize": 4, "chunks": chunks, "ranges": ranges, "a_chunks": a_chunks,
+            "nnz_local": nnz_local, "label": label, "dtype_name": "f32", "bounds": [ranges[0][r][0] for r in range(world)] + [m],
+            "pmc_key": "spmv_cfg2" if (world == 1 and not poisson and args.rows is None and args.cols is None) else None}
+
+
+def build_rmat(args, world, rank, device, sharded, sp):
+    """cfg4: fp64 R-MAT scale 24 (edge factor 16, duplicates kept, 268 M entries), rows sharded by NNZ PREFIX on rowptr
+    (the shards differ several-fold in rows).  Every rank generates the same graph from the same seed on its own
+    GPU, keeps its row range and drops the rest; a checksum all-reduce confirms the ranks agree."""
+    from spblas_reference_amd import generate
+    scale = 24 if args.rows is None else int(np.log2(args.rows))
+    values, rowptr, colind, shape, nnz = generate.rmat_csr_device(scale, 16, dtype=torch.float64, seed=0, device=device)
+    m = n = shape[0]
+    if world > 1:
+        chk = torch.stack([rowptr.long().sum(), colind.long().sum()]).double()
+        lo_hi = torch.stack([chk, -chk])
+        dist.all_reduce(lo_hi, op=dist.ReduceOp.MAX)
+        if not bool((lo_hi[0] == -lo_hi[1]).all()):
+            sys.exit("ranks generated different R-MAT graphs")
+    bounds = sharded.partition_rows_by_nnz(rowptr, world)
+    a_local = sharded.shard_csr(values, rowptr, colind, shape, bounds[rank], bounds[rank + 1]) if world > 1 else \
+        sp.csr_view(values, rowptr, colind, shape, nnz)
+    del values, rowptr, colind
+    torch.cuda.empty_cache()
+    label = f"cfg4: fp64 CSR SpMV, R-MAT scale {scale}, edge factor 16, duplicates kept, rows sharded by nnz prefix"
+    return {"m": m, "n": n, "dtype": torch.float64, "tsize": 8, "chunks": 1, "ranges": None, "a_chunks": [a_local],
+            "nnz_local": a_local.size(), "label": label, "dtype_name": "f64", "bounds": bounds, "pmc_key": None}
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -137,51 +217,33 @@ def main():
     from spblas_reference_amd import _capi, sharded
     sp._capi.lib()  # fail loudly if the HIP library is missing
 
-    if args.workload in ("spmm", "spgemm", "spmv_rmat", "add", "transpose", "sptrsv"):
-        from bench_extra import run_extra  # secondary configs (cfg3/cfg4/cfg5), 1 GPU
+    if args.workload in ("spmm", "spgemm", "add", "transpose", "sptrsv"):
+        from bench_extra import run_extra  # secondary configs (cfg3 / cfg5 / 8f rows), 1 GPU
         return run_extra(args, device)
 
-    poisson = args.workload == "spmv_poisson"
-    m = n = args.rows or 10_000_000
-    if args.cols:
-        n = args.cols
-    per_row = 10
-    dtype, tsize = torch.float32, 4
+    rmat = args.workload == "spmv_rmat"
+    prob = (build_rmat if rmat else build_cfg2)(args, world, rank, device, sharded, sp)
+    m, n, dtype, tsize, chunks = prob["m"], prob["n"], prob["dtype"], prob["tsize"], prob["chunks"]
+    a_chunks, ranges, bounds, nnz_local = prob["a_chunks"], prob["ranges"], prob["bounds"], prob["nnz_local"]
+    rows_local = sum(a.shape()[0] for a in a_chunks)
     algs = {"auto": _capi.SPMV_AUTO, "vector": _capi.SPMV_VECTOR, "rowblock": _capi.SPMV_ROWBLOCK,
             "sliced": _capi.SPMV_SLICED}
     g = torch.Generator(device=device).manual_seed(7)
     x = torch.rand(n, dtype=dtype, device=device, generator=g)  # same on every rank (replicated)
-    # N = 1: one plan, no collective.  N > 1: `chunks` stripes, each split evenly over the ranks;
-    # stripe c's all-gather (RCCL, async) overlaps stripe c+1's kernels (sharded.PipelinedShardedSpMV).
-    # Default 1 stripe: measured on one GPU (row shards emulated with --rows/--cols/--overlap), every
-    # extra stripe costs ~20-30 us of launch/latency floor, more than the gather time it can hide
-    # at N = 4 and 8; --chunks C enables the overlapped variants.
-    chunks = args.chunks if args.chunks > 0 else 1
-    ranges = sharded.striped_row_ranges(m, world, chunks)
-    if ranges is None or poisson and world > 1:
-        chunks = 1
-        ranges = sharded.striped_row_ranges(m, world, 1)
-    if ranges is None:
-        sys.exit(f"rows={m} is not divisible by the number of ranks")
-    a_chunks, nnz_local = [], 0
-    for c in range(chunks):
-        lo, hi = ranges[c][rank]
-        v_c, rp_c, ci_c, nnz_c = gen_rows(lo, hi, n, per_row, poisson, dtype, device)
-        a_chunks.append(sp.csr_view(v_c, rp_c, ci_c, (hi - lo, n), nnz_c))
-        nnz_local += nnz_c
-    rows_local = sum(a.shape()[0] for a in a_chunks)
     nnz_t = torch.tensor([nnz_local], dtype=torch.int64, device=device)
     if multi:
         dist.all_reduce(nnz_t)
     nnz = int(nnz_t.item())
 
+    # N = 1: one plan, no collective.  N > 1: local SpMV of the rank's rows + ONE all-gather of y per step
+    # (RCCL; in place for equal shards, direct sends of the exact shard sizes for nnz-balanced ones), or -- when
+    # every rank can set it up and it reproduces the RCCL path bit for bit on four different vectors -- the
+    # all-gather fused into the reduce kernels (peer stores into hipIpc-mapped copies of y + device-side barrier).
+    # --chunks C > 1 enables the striped variants whose all-gathers overlap the next stripe's kernels.
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    mode = "plain"
-    op = None
-    if (multi or args.overlap) and chunks > 1 and args.alg in ("auto", "sliced"):
-        # preferred N > 1 path: ONE local plan (stripes back to back), expand once, reduce stripe by
-        # stripe with each stripe's all-gather overlapping the next reduce
+    mode, op, rccl_op, fused_op = "plain", None, None, None
+    if not rmat and (multi or args.overlap) and chunks > 1 and args.alg in ("auto", "sliced"):
         try:
             lens = torch.cat([a.rowptr()[1:].long() - a.rowptr()[:-1].long() for a in a_chunks])
             rp = torch.zeros(rows_local + 1, dtype=torch.int64, device=device)
@@ -194,52 +256,47 @@ def main():
         except RuntimeError:
             op = None
     if op is None:
-        op = sharded.PipelinedShardedSpMV(a_chunks, ranges, inspect=args.alg != "noplan",
+        if rmat:
+            rccl_op = sharded.ShardedSpMV(a_chunks[0], bounds, inspect=args.alg != "noplan",
                                           alg=None if args.alg == "noplan" else algs[args.alg])
+        else:
+            rccl_op = sharded.PipelinedShardedSpMV(a_chunks, ranges, inspect=args.alg != "noplan",
+                                                   alg=None if args.alg == "noplan" else algs[args.alg])
+        op = rccl_op
         mode = "pipelined" if chunks > 1 else "plain"
-    if multi and mode == "plain" and args.fused == "auto" and args.alg in ("auto", "sliced"):
-        # Preferred N > 1 path: no collective on the data path at all -- the reduce kernels store every
-        # finished row of y into all ranks' (IPC-mapped) copies, a device-side barrier ends the step.
-        # Adopted only if every rank can set it up AND its y is bit-identical to the RCCL path's.
-        bounds = [ranges[0][r][0] for r in range(world)] + [m]
-        fused = sharded.try_fused(a_chunks[0], bounds, x, lambda xk: op.step(xk), alg=algs[args.alg], info=op.infos[0],
-                                  log=(lambda msg: print(f"[bench] {msg}; using RCCL all-gather", file=sys.stderr))
-                                  if rank == 0 else None)
-        if fused is not None:
-            op, mode = fused, "fused"
+    if multi and mode == "plain" and args.fused == "auto" and args.alg in ("auto", "sliced") and \
+            len({bounds[r + 1] - bounds[r] for r in range(world)}) == 1:
+        fused_op = sharded.try_fused(a_chunks[0], bounds, x, lambda xk: rccl_op.step(xk), alg=algs[args.alg],
+                                     info=rccl_op.infos[0],
+                                     log=(lambda msg: print(f"[bench] {msg}; using RCCL all-gather", file=sys.stderr))
+                                     if rank == 0 else None)
+        if fused_op is not None:
+            op, mode = fused_op, "fused"
     torch.cuda.synchronize()
     inspect_ms = (time.perf_counter() - t0) * 1e3
     info0 = op.info if mode in ("overlapped", "fused") else op.infos[0]
     plan_info = info0.state_.info() if info0.state_ is not None else {"alg": "plan-free"}
 
-    for _ in range(args.warmup):
-        op.step(x)
-    torch.cuda.synchronize()
-    if multi:
-        dist.barrier()
-    torch.cuda.synchronize()
-    # Timed region: exactly K steps between barriers/synchronisations; ONE pair of HIP events on the launch
-    # stream brackets it (per-step event records were measured to cost up to 25 us per step: every record is
-    # a release point between the reduce of one step and the expand of the next).
-    region = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-    t0 = time.perf_counter()
-    region[0].record()
-    for i in range(args.steps):
-        op.step(x)
-    region[1].record()
-    torch.cuda.synchronize()
-    if multi:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    el = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    if multi:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    elapsed = float(el.item())
-    kern_avg_ms = region[0].elapsed_time(region[1]) / args.steps  # average launch(-pair) duration, HIP events
+    elapsed, kern_avg_ms = measure(lambda: op.step(x), args.steps, args.warmup, multi, device)
+
+    # Where the time of a multi-GPU step goes (outside the timed region, same K): the local kernels alone, the
+    # all-gather alone, the RCCL step and -- when it could be set up -- the fused step.
+    diag = None
+    if multi and rccl_op is not None:
+        k = max(5, min(args.steps, 50))
+        local_s, local_ev = measure(lambda: rccl_op.local(x), k, 2, multi, device)
+        gather_s, _ = measure(lambda: rccl_op.gather(), k, 2, multi, device)
+        rccl_s = (elapsed / args.steps * k) if mode != "fused" else measure(lambda: rccl_op.step(x), k, 2, multi, device)[0]
+        diag = {"mode_timed": mode, "local_spmv_ms": local_s / k * 1e3, "local_spmv_event_ms": local_ev,
+                "gather_ms": gather_s / k * 1e3, "rccl_step_ms": rccl_s / k * 1e3,
+                "fused_step_ms": elapsed / args.steps * 1e3 if mode == "fused" else None,
+                "gather": getattr(rccl_op, "gather_mode", "inplace"),
+                "rows_per_rank": [bounds[r + 1] - bounds[r] for r in range(world)],
+                "note": "each figure: K steps between barriers, max over ranks; local = kernels only, gather = "
+                        "collective only (y already computed), rccl_step = local + gather"}
     # Diagnostic pass outside the timed region: per-step events give the spread of single steps
     ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-           for _ in range(1 if mode in ("overlapped", "fused") else chunks)]
+           for _ in range(1 if mode in ("overlapped", "fused") or rmat else chunks)]
           for _ in range(args.steps)]
     for i in range(args.steps):
         op.step(x, events=ev[i])
@@ -248,38 +305,41 @@ def main():
         dist.barrier()
     kern_ms = sorted(sum(a.elapsed_time(b) for a, b in step_ev) for step_ev in ev)
     values, rowptr, colind = a_chunks[0].values(), a_chunks[0].rowptr(), a_chunks[0].colind()
-    r0, r1 = 0, rows_local
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         gflops = 2.0 * nnz / (elapsed / args.steps) / 1e9
-        local_bytes = spmv_bytes(r1 - r0, n, nnz_local, tsize)
+        local_bytes = spmv_bytes(rows_local, n, nnz_local, tsize)
         achieved = local_bytes / (kern_avg_ms * 1e-3) / 1e9
+        alg_id = plan_info.get("alg")
+        kernels = {3: f"pb_expand_kernel<{'float' if tsize == 4 else 'double'}> + pb_reduce_kernel<{'float' if tsize == 4 else 'double'},4,4> "
+                      "(one SpMV = this launch pair)",
+                   2: f"spmv_rowblock_kernel<{'float,int,2048' if tsize == 4 else 'double,int,1024'}> (+ spmv_long_fixup_kernel)",
+                   1: "spmv_vector_kernel<T,int,LPR>"}
         out = {
             "metric": "csr_spmv_gflops", "value": gflops, "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"cfg2: fp32 CSR SpMV {m}x{n}, {'Poisson(10)' if poisson else 'exactly 10'} nnz/row, "
-                                   f"uniform random unsorted columns, int32 indices, nnz={nnz}",
+            "vs_baseline": None, "dtype": prob["dtype_name"], "data": "synthetic",
+            "config": {"workload": f"{prob['label']}, nnz={nnz}",
                        "rows": m, "cols": n, "nnz": nnz, "index_type": "int32",
                        "parallelism": ("single GPU" if not multi else
                                        f"row-sharded x{world}, all-gather(y) fused into the reduce kernels (peer stores "
                                        "into hipIpc-mapped copies of y + device-side step barrier)" if mode == "fused" else
-                                       f"row-sharded x{world}, {chunks} stripes per step ({mode}), one RCCL all-gather(y) per "
-                                       "stripe overlapped with the next stripe's kernels"),
+                                       f"row-sharded x{world} ({'nnz-prefix' if rmat else 'equal'} shards), {chunks} stripe(s) per step "
+                                       f"({mode}), one RCCL all-gather(y) per stripe"),
                        "alg": args.alg, "plan": plan_info, "inspect_ms_untimed": inspect_ms},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
+                         # fraction of the rate a streaming copy reaches on this part (6.29 TB/s, MI355X_MICROARCH.md)
+                         "frac_of_achievable": achieved / 6290.0,
                          # PMC traffic was measured for the default cfg2 / 1 GPU / sliced plan only
-                         "traffic": read_pmc_traffic("spmv_cfg2") if (world == 1 and plan_info.get("alg") == 3
-                                                                     and not poisson and args.rows is None and args.cols is None) else None,
-                         "kernel": {3: "pb_expand_kernel<float> + pb_reduce_kernel<float,4,4> (one SpMV = this launch pair)",
-                                    2: "spmv_rowblock_kernel<float,int,2048>", 1: "spmv_vector_kernel<float,int,LPR>"
-                                    }.get(plan_info.get("alg"), "spmv_vector_kernel<float,int,LPR>"),
+                         "traffic": read_pmc_traffic(prob["pmc_key"]) if (prob["pmc_key"] and alg_id == 3) else None,
+                         "kernel": kernels.get(alg_id, kernels[1]),
                          "algorithmic_bytes_per_launch": local_bytes, "kernel_avg_ms": kern_avg_ms,
                          "step_events_pass": {"note": "separate untimed pass with one event pair per step", "min_ms": kern_ms[0],
                                               "median_ms": kern_ms[len(kern_ms) // 2], "avg_ms": sum(kern_ms) / len(kern_ms)},
                          "algorithmic_gbs_whole_step": spmv_bytes(m, n, nnz, tsize) / (elapsed / args.steps) / 1e9},
+            "multi_gpu": diag,
         }
         if world == 1 and chunks == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_spmv(values, rowptr, colind, (m, n), x, nnz)
@@ -287,9 +347,9 @@ def main():
             out["cpu_baseline"] = None
         print(json.dumps(out))
     if multi:
-        if mode == "fused":
-            op.check_status()
-            op.close()
+        if fused_op is not None:
+            fused_op.check_status()
+            fused_op.close()
         dist.destroy_process_group()
 
 

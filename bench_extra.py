@@ -1,7 +1,6 @@
 """Secondary BASELINE configs on one GPU (not the headline bench line):
   --workload spmm      cfg3: fp32 CSR x dense, A 2M x 2M 32 nnz/row, B 2M x 128 row-major
   --workload spgemm    cfg5: fp32 CSR x CSR, 1M x 1M, 16 nnz/row, multiply_compute + multiply_fill
-  --workload spmv_rmat cfg4 (single-GPU leg): fp64 CSR SpMV, R-MAT scale 24, edge factor 16
   --workload add | transpose | sptrsv   SURVEY 8f rows: CSR + CSR, CSR transpose, lower-triangular solve
 Same JSON contract as bench.py; `value` is GFLOP/s of the timed operation.  The CPU baseline
 (oracle, 1 core) is timed on a bounded row sample and scaled by nnz (stated in `sample`)."""
@@ -218,27 +217,4 @@ def run_extra(args, device):
                "triangular_solve_inspect_ms_untimed": inspect_ms}, cpu)
         return
 
-    # spmv_rmat: cfg4 single-GPU leg
-    scale = 24 if args.rows is None else int(np.log2(args.rows))
-    values, rowptr, colind, shape, nnz = generate.rmat_csr_device(scale, 16, dtype=torch.float64, seed=0, device=device)
-    m = shape[0]
-    a = sp.csr_view(values, rowptr, colind, shape, nnz)
-    g = torch.Generator(device=device).manual_seed(5)
-    x = torch.rand(m, dtype=torch.float64, device=device, generator=g)
-    y = torch.empty(m, dtype=torch.float64, device=device)
-    algs = {"auto": sp._capi.SPMV_AUTO, "vector": sp._capi.SPMV_VECTOR, "rowblock": sp._capi.SPMV_ROWBLOCK,
-            "sliced": sp._capi.SPMV_SLICED}
-    info = sp.multiply_inspect(a, x, y, alg=algs.get(getattr(args, "alg", "auto"), sp._capi.SPMV_AUTO))
-    elapsed, ms = _time_steps(lambda: sp.multiply(info, a, x, y), args.warmup, args.steps)
-    alg_bytes = nnz * 12 + (m + 1) * 4 + 2 * m * 8
-    cpu = None
-    if not args.no_cpu_baseline:
-        rp, ci, v, xh = rowptr.cpu().numpy(), colind.cpu().numpy(), values.cpu().numpy(), x.cpu().numpy()
-        t0 = time.perf_counter()
-        oracle.spmv(shape, rp, ci, v, xh)
-        dt = time.perf_counter() - t0
-        cpu = {"value": 2.0 * nnz / dt / 1e9, "unit": "GFLOP/s", "cores": 1, "kind": "port",
-               "sample": f"full workload ({nnz} nnz), 1 run of oracle_spmv_f64"}
-    _emit(args, "csr_spmv_gflops", 2.0 * nnz, alg_bytes, elapsed, ms,
-          f"cfg4 (1-GPU leg): fp64 CSR SpMV, R-MAT scale {scale}, edge factor 16, duplicates kept, nnz={nnz}",
-          {"dtype": "f64", "rows": m, "nnz": nnz, "plan": info.state_.info()}, cpu)
+    raise SystemExit(f"unknown workload {args.workload}")

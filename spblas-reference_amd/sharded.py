@@ -57,9 +57,16 @@ class ShardedSpMV:
     bounds    row boundaries b[0..P] shared by all ranks
     local_spmv(info, a_local, x, y_local): defaults to the HIP path; CPU (gloo) tests
               inject the oracle here to exercise the sharding/gather logic without a GPU.
+    gather    how unequal (nnz-balanced) shards are exchanged:
+              "p2p"     every rank sends its shard straight into the other ranks' y (one group of P-1 sends and
+                        P-1 receives, torch.distributed.batch_isend_irecv = one ncclGroup): each shard crosses each
+                        xGMI link once and nothing is padded -- the direct all-gather of SURVEY.md section 8e
+              "padded"  one all_gather_into_tensor of max-shard-sized slots, then P contiguous copies (R-MAT shards
+                        by nnz prefix differ several-fold in rows, so the padding can exceed the payload)
+              "auto"    = "p2p".  Equal shards always use ONE in-place all_gather_into_tensor.
     """
 
-    def __init__(self, a_local, bounds, group=None, local_spmv=None, inspect=True):
+    def __init__(self, a_local, bounds, group=None, local_spmv=None, inspect=True, gather="auto", alg=None):
         self.group = group
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -72,11 +79,13 @@ class ShardedSpMV:
         assert a_local.shape()[0] == counts[self.rank]
         self.counts = counts
         self.equal = len(set(counts)) == 1
+        assert gather in ("auto", "p2p", "padded")
+        self.gather_mode = "inplace" if self.equal else ("p2p" if gather == "auto" else gather)
         vals = a_local.values()
         self.y_full = torch.zeros(self.m, dtype=vals.dtype, device=vals.device)
-        if self.equal:
-            self.y_local = self.y_full[bounds[self.rank]:bounds[self.rank + 1]]  # in-place gather
-            self.pad = None
+        self.pad = None
+        if self.gather_mode in ("inplace", "p2p"):
+            self.y_local = self.y_full[bounds[self.rank]:bounds[self.rank + 1]]  # computed in place
         else:
             self.maxc = max(counts)
             self.pad = torch.zeros(self.world * self.maxc, dtype=vals.dtype, device=vals.device)
@@ -84,21 +93,36 @@ class ShardedSpMV:
         self.info = api.operation_info_t()
         if inspect and local_spmv is None:
             x_probe = torch.empty(a_local.shape()[1], dtype=vals.dtype, device=vals.device)
+            kw = {} if alg is None else {"alg": alg}
             # the operator owns its shard for its lifetime: matrix_opt lets inspect keep a re-tiled copy
-            self.info = api.multiply_inspect(api.matrix_opt(a_local), x_probe, self.y_local[:counts[self.rank]])
+            self.info = api.multiply_inspect(api.matrix_opt(a_local), x_probe, self.y_local[:counts[self.rank]], **kw)
+        self.infos = [self.info]
 
     def local(self, x):
         self.local_spmv(self.info, self.a_local, x, self.y_local[:self.counts[self.rank]])
 
     def gather(self):
         if self.world == 1:
-            if not self.equal:
+            if self.gather_mode == "padded":
                 self.y_full.copy_(self.y_local[:self.m])
             return self.y_full
-        if self.equal:
+        if self.gather_mode == "inplace":
             dist.all_gather_into_tensor(self.y_full, self.y_local, group=self.group)
+        elif self.gather_mode == "p2p":
+            ops = []
+            for g in range(self.world):
+                if g == self.rank:
+                    continue
+                peer = g if self.group is None else dist.get_global_rank(self.group, g)
+                if self.counts[self.rank]:
+                    ops.append(dist.P2POp(dist.isend, self.y_local, peer, self.group))
+                if self.counts[g]:
+                    ops.append(dist.P2POp(dist.irecv, self.y_full[self.bounds[g]:self.bounds[g + 1]], peer, self.group))
+            if ops:
+                for w in dist.batch_isend_irecv(ops):
+                    w.wait()
         else:
-            # unequal (nnz-balanced) shards: one padded all-gather, then P contiguous copies
+            # one padded all-gather, then P contiguous copies
             dist.all_gather_into_tensor(self.pad, self.y_local, group=self.group)
             for g in range(self.world):
                 c = self.counts[g]
@@ -106,9 +130,13 @@ class ShardedSpMV:
                     self.y_full[self.bounds[g]:self.bounds[g + 1]].copy_(self.pad[g * self.maxc:g * self.maxc + c])
         return self.y_full
 
-    def step(self, x):
+    def step(self, x, events=None):
         """One sharded SpMV: local rows, then all-gather(y).  Returns the full y."""
+        if events is not None:
+            events[0][0].record()
         self.local(x)
+        if events is not None:
+            events[0][1].record()
         return self.gather()
 
 
@@ -170,6 +198,22 @@ class PipelinedShardedSpMV:
                            for c in range(self.chunks)]
             self._bound_x = x
         return self._bound if self._bound_x is x else None
+
+    def local(self, x):
+        """The local SpMVs of every stripe, no collective (diagnostics)."""
+        bound = self._bind(x)
+        for c in range(self.chunks):
+            if bound is not None:
+                bound[c]()
+            else:
+                self.local_spmv(self.infos[c], self.a_chunks[c], x, self.y_local[c])
+
+    def gather(self):
+        """The all-gathers of every stripe alone (diagnostics)."""
+        if self.world > 1:
+            for c in range(self.chunks):
+                dist.all_gather_into_tensor(self.y_stripe[c], self.y_local[c], group=self.group)
+        return self.y_full
 
     def step(self, x, events=None):
         works = []

@@ -52,3 +52,23 @@ def test_bench_multi_gpu_code_path_with_one_rank(gpu, fused):
     out = json.loads(lines[0])
     assert out["value"] > 0 and out["steps"] == 5
     assert ("fused into the reduce kernels" in out["config"]["parallelism"]) == (fused == "auto")
+    mg = out["multi_gpu"]  # where the step time goes: one SCALE run must be diagnostic
+    assert mg["mode_timed"] == ("fused" if fused == "auto" else "plain")
+    assert mg["local_spmv_ms"] > 0 and mg["gather_ms"] >= 0 and mg["rccl_step_ms"] > 0
+    assert (mg["fused_step_ms"] is not None) == (fused == "auto")
+
+
+def test_bench_cfg4_rmat_multi_gpu_code_path_with_one_rank(gpu):
+    """BASELINE cfg4's multi-GPU leg (`bench.py --gpus N --workload spmv_rmat`: fp64 R-MAT, rows sharded by nnz
+    prefix, uneven all-gather) through the N > 1 code path with one rank, at scale 18."""
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr",
+           "127.0.0.1", "--master-port", "29679", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--debug-multi",
+           "--workload", "spmv_rmat", "--rows", str(1 << 18), "--steps", "5", "--warmup", "2", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.stdout[-2000:], r.stderr[-2000:])
+    out = json.loads(lines[0])
+    assert out["value"] > 0 and out["dtype"] == "f64" and out["config"]["nnz"] == 16 << 18
+    assert "R-MAT scale 18" in out["config"]["workload"] and out["multi_gpu"]["rccl_step_ms"] > 0

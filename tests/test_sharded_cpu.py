@@ -33,7 +33,8 @@ def _worker(rank, world, port, case, out_dir):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        m, n, nnz, by_nnz, dtype = case
+        m, n, nnz, by_nnz, dtype = case[:5]
+        gather = case[5] if len(case) > 5 else "auto"
         values, rowptr, colind, shape, _ = generate.generate_csr(m, n, nnz, seed=3, dtype=dtype)
         if by_nnz:  # skew the matrix: make the first rows heavy so nnz-balanced shards are unequal
             lens = np.diff(rowptr)
@@ -47,7 +48,9 @@ def _worker(rank, world, port, case, out_dir):
         bounds = sharded.partition_rows_by_nnz(rp_t, world) if by_nnz else sharded.partition_rows_even(m, world)
         a_local = sharded.shard_csr(t(values), rp_t, t(colind), shape, bounds[rank], bounds[rank + 1])
         assert int(a_local.rowptr()[0]) == 0 and a_local.shape() == (bounds[rank + 1] - bounds[rank], n)
-        op = sharded.ShardedSpMV(a_local, bounds, local_spmv=_oracle_local)
+        op = sharded.ShardedSpMV(a_local, bounds, local_spmv=_oracle_local, gather=gather)
+        assert op.gather_mode == ("inplace" if len({bounds[i + 1] - bounds[i] for i in range(world)}) == 1 else
+                                  ("p2p" if gather == "auto" else gather))
         x = t(np.random.default_rng(5).random(n).astype(dtype))
         y = op.step(x).numpy().copy()
         y2 = op.step(x).numpy().copy()  # a second step reuses the buffers
@@ -60,7 +63,8 @@ def _worker(rank, world, port, case, out_dir):
 
 
 @pytest.mark.parametrize("case", [(1000, 100, 100, False, np.float32), (100, 1000, 10000, False, np.float64),
-                                  (999, 640, 20000, True, np.float32), (40, 40, 1000, True, np.float64)])
+                                  (999, 640, 20000, True, np.float32), (40, 40, 1000, True, np.float64),
+                                  (999, 640, 20000, True, np.float32, "padded"), (40, 40, 1000, True, np.float64, "p2p")])
 def test_row_sharded_spmv_world2_gloo(case, tmp_path):
     port = _free_port()
     mp.spawn(_worker, args=(2, port, case, str(tmp_path)), nprocs=2, join=True)
