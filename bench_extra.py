@@ -56,10 +56,23 @@ def run_extra(args, device):
     from oracle import oracle
     from spblas_reference_amd import generate
 
-    if args.workload == "spmm":
+    if args.workload in ("spmm", "spmm_banded"):
         m = args.rows or 2_000_000
         ncols = 128
-        values, rowptr, colind, shape, nnz = generate.uniform_csr_device(m, m, 32, seed=0, device=device)
+        banded = args.workload == "spmm_banded"
+        if banded:
+            # cfg3's shape with 64 entries per row, all within 48 columns of the diagonal: neighbouring rows share B
+            # rows, every block of 32 rows is >= 1/5 dense over the 2-3 tiles of 64 columns it touches, and
+            # multiply_inspect hands it to the LDS-staged matrix-core kernel
+            g0 = torch.Generator(device=device).manual_seed(11)
+            per = 64
+            off = torch.randint(-48, 49, (m, per), device=device, generator=g0)
+            colind = ((torch.arange(m, device=device)[:, None] + off) % m).to(torch.int32).reshape(-1)
+            rowptr = (torch.arange(m + 1, device=device, dtype=torch.int64) * per).to(torch.int32)
+            values = torch.rand(m * per, device=device, generator=g0)
+            shape, nnz = (m, m), m * per
+        else:
+            values, rowptr, colind, shape, nnz = generate.uniform_csr_device(m, m, 32, seed=0, device=device)
         a = sp.csr_view(values, rowptr, colind, shape, nnz)
         g = torch.Generator(device=device).manual_seed(3)
         B = torch.rand((m, ncols), device=device, generator=g)
@@ -78,9 +91,14 @@ def run_extra(args, device):
             dt = time.perf_counter() - t0
             cpu = {"value": 2.0 * rp[-1] * ncols / dt / 1e9, "unit": "GFLOP/s", "cores": 1, "kind": "port",
                    "sample": f"first {rows} rows ({int(rp[-1])} nnz x {ncols} columns) of the same A and B, 1 run of oracle_spmm"}
+        mi = info.state_.spmm_info()
         _emit(args, "csr_spmm_gflops", 2.0 * nnz * ncols, alg_bytes, elapsed, ms,
-              f"cfg3: fp32 CSR x dense SpMM, A {m}x{m} 32 nnz/row uniform random, B {m}x{ncols} row-major",
-              {"dtype": "f32", "rows": m, "nnz": nnz, "ncols": ncols, "kernel": "spmm_rowgroup_kernel<float,int,4>"}, cpu)
+              (f"banded variant of cfg3: fp32 CSR x dense SpMM, A {m}x{m} 64 nnz/row within 48 columns of the diagonal, "
+               f"B {m}x{ncols} row-major" if banded else
+               f"cfg3: fp32 CSR x dense SpMM, A {m}x{m} 32 nnz/row uniform random, B {m}x{ncols} row-major"),
+              {"dtype": "f32", "rows": m, "nnz": nnz, "ncols": ncols, "spmm_inspect": mi,
+               "kernel": "spmm_panel_kernel<int> (v_mfma_f32_32x32x2_f32)" if mi["panel_blocks"] > 0 else
+                         "spmm_rowgroup_kernel<float,int,4>"}, cpu)
         return
 
     if args.workload == "spgemm":

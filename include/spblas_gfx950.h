@@ -200,7 +200,16 @@ int spblas_gfx950_step_wait(spblas_gfx950_handle_t handle, const void* flags, in
                             int64_t timeout_ms, int* status_dev);
 
 /* ---- SpMM:  C = alpha * A * B + beta * C,  B (k x n), C (m x n) row-major --- */
-/* ldb/ldc are row strides in elements (mdspan layout_right, test/gtest/spmm_test.cpp). */
+/* ldb/ldc are row strides in elements (mdspan layout_right, test/gtest/spmm_test.cpp).
+ * multiply_inspect(A, B, C) = spmv_plan_create (alg ROWBLOCK: row statistics, long-row list) followed by
+ * spmm_inspect, the counterpart of oneMKL's optimize_gemm (vendor/onemkl_sycl/spmm_impl.hpp:40-67): it probes every
+ * block of 32 rows for column locality and hands the blocks whose entries fall into <= 8 aligned tiles of 128
+ * columns (>= 1/5 dense: the measured crossover) to the LDS-staged matrix-core kernel (fp32; exact f32 MFMA).  spmm with such a plan
+ * also cuts rows longer than the plan's nnz window into parts (hub rows of power-law matrices).  plan = NULL:
+ * one lane group per row, no analysis.  spmm_plan_info: [0] inspected, [1] row blocks on the matrix cores,
+ * [2] entries inside them, [3] long rows. */
+int spblas_gfx950_spmm_inspect(spblas_gfx950_handle_t handle, spblas_gfx950_plan_t plan);
+int spblas_gfx950_spmm_plan_info(spblas_gfx950_plan_t plan, int64_t info[4]);
 int spblas_gfx950_spmm(spblas_gfx950_handle_t handle, spblas_gfx950_plan_t plan, int64_t m, int64_t k,
                        int64_t n, int64_t nnz, const void* alpha, const void* rowptr,
                        const int32_t* colind, const void* values, const void* B, int64_t ldb,

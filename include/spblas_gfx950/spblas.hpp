@@ -456,6 +456,7 @@ operation_info_t multiply_inspect(A&& a, X&& x, Y&& y) {
   using O = typename decltype(ab)::offset_type;
   info.spmv_state().template inspect<T, O>(ab.shape()[0], ab.shape()[1], ab.size(), ab.rowptr().data(),
                                            ab.colind().data(), ab.values().data(), SPBLAS_GFX950_SPMV_ROWBLOCK);
+  info.spmv_state().inspect_spmm();  // column-locality probe + long-row list (vendor/onemkl_sycl/spmm_impl.hpp:40-67)
   return info;
 }
 
@@ -471,7 +472,9 @@ void multiply(operation_info_t& info, A&& a, X&& x, Y&& y) {
     throw std::invalid_argument("multiply: matrix dimensions are incompatible.");  // multiply_impl.hpp:70-76
   }
   const T alpha = static_cast<T>(__detail::get_scaling_factor(a, x).value_or(1.0));
-  __gfx950::spmm<T, O>(info.spmv_state().handle(), ab.shape()[0], ab.shape()[1], y.extent(1), ab.size(), alpha,
+  auto plan = info.spmv_state().plan_for(ab.shape()[0], ab.shape()[1], ab.size(), ab.rowptr().data(), ab.colind().data(),
+                                         ab.values().data());
+  __gfx950::spmm<T, O>(info.spmv_state().handle(), plan, ab.shape()[0], ab.shape()[1], y.extent(1), ab.size(), alpha,
                        ab.rowptr().data(), ab.colind().data(), ab.values().data(), xb.data_handle(), xb.stride(0), T(0),
                        y.data_handle(), y.stride(0));
 }

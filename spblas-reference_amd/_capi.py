@@ -57,6 +57,8 @@ PROTOTYPES = [
     ("spblas_gfx950_spmm", c_int,
      [c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64,
       c_void_p, c_void_p, c_i64, c_int, c_int]),
+    ("spblas_gfx950_spmm_inspect", c_int, [c_void_p, c_void_p]),
+    ("spblas_gfx950_spmm_plan_info", c_int, [c_void_p, ctypes.POINTER(c_i64)]),
     ("spblas_gfx950_csr_transpose", c_int,
      [c_void_p, c_i64, c_i64, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int]),
     ("spblas_gfx950_scale", c_int, [c_void_p, c_i64, c_void_p, c_void_p, c_int]),

@@ -300,6 +300,17 @@ class _Plan:
 
         return expand, reduce_rows
 
+    def spmm_inspect(self):
+        """The SpMM part of multiply_inspect (spblas_gfx950_spmm_inspect): column-locality probe of every block of
+        32 rows; qualifying blocks go to the LDS-staged matrix-core kernel, long rows are cut into parts."""
+        check(_capi.lib().spblas_gfx950_spmm_inspect(self.handle.h, self.plan), "multiply_inspect")
+        return self
+
+    def spmm_info(self):
+        arr = (ctypes.c_int64 * 4)()
+        check(_capi.lib().spblas_gfx950_spmm_plan_info(self.plan, arr), "spblas_gfx950_spmm_plan_info")
+        return dict(zip(("inspected", "panel_blocks", "panel_nnz", "long_rows"), list(arr)))
+
     def update_values(self, values):
         """Refresh the plan after A's values changed in place (only the SLICED re-tiling keeps
         a copy of them; the other algorithms read the caller's array on every call)."""
@@ -603,14 +614,18 @@ class prepared_multiply:
 def _spmm(info, a, b, c):
     a_base, b_base = get_ultimate_base(a), get_ultimate_base(b)
     _reject_conjugated(a, b, c)
+    plan = None
     if isinstance(a_base, csc_view):
         # CSC operand (test/gtest/spmm_test.cpp:181): run the CSR kernel on the materialised row-major
         # form -- taken from the inspect result when there is one, otherwise transposed for this call
         if info is not None and isinstance(info.state_, _CscPlan) and info.state_.key == _csc_key(a_base):
             info.state_.refresh_if_stale(a_base)
+            plan = info.state_.plan
             a_base = info.state_.a_csr
         else:
             a_base = _CscPlan(a_base, _capi.SPMV_VECTOR).a_csr
+    elif isinstance(a_base, csr_view):
+        plan = _find_plan(info, a, a_base)  # what multiply_inspect(a, B, C) left in info / in the matrix_opt
     if not isinstance(a_base, csr_view):
         raise NotImplementedError("gfx950 SpMM: A must have a csr_view or csc_view base")
     if not _is_tensor(c) or c.dim() != 2:
@@ -632,7 +647,8 @@ def _spmm(info, a, b, c):
     n = c.shape[1]
     ldb = b_base.stride(0) if b_base.shape[0] > 1 else max(n, 1)
     ldc = c.stride(0) if c.shape[0] > 1 else max(n, 1)
-    check(_capi.lib().spblas_gfx950_spmm(hd.h, None, m, k, n, a_base.size(), ctypes.byref(alpha),
+    check(_capi.lib().spblas_gfx950_spmm(hd.h, plan.plan if plan is not None else None, m, k, n, a_base.size(),
+                                         ctypes.byref(alpha),
                                          _ptr(a_base.rowptr()), _ptr(a_base.colind()), _ptr(a_base.values()),
                                          _ptr(b_base), ldb, ctypes.byref(beta), _ptr(c), ldc,
                                          _OT[a_base.rowptr().dtype], vt), "multiply")
@@ -694,11 +710,16 @@ def multiply_inspect(*args, alg=_capi.SPMV_AUTO):
         mo = _get_matrix_opt(a)
         plan = _build_plan(a_base, _capi.SPMV_ROWBLOCK if is_spmm and alg == _capi.SPMV_AUTO else alg,
                            snapshot=mo is not None)
+        if is_spmm:
+            plan.spmm_inspect()
         info.state_ = plan
         if mo is not None:
             mo._plan = plan
     elif isinstance(a_base, csc_view) and _is_tensor(get_ultimate_base(b)):
-        info.state_ = _CscPlan(a_base, alg if get_ultimate_base(b).dim() == 1 else _capi.SPMV_ROWBLOCK)
+        is_spmm = get_ultimate_base(b).dim() == 2
+        info.state_ = _CscPlan(a_base, _capi.SPMV_ROWBLOCK if is_spmm else alg)
+        if is_spmm:
+            info.state_.plan.spmm_inspect()
     return info if ret else None
 
 

@@ -64,5 +64,18 @@ struct spblas_gfx950_plan_s {
   int s_partial_k = 0;
   int bin_aligned = 0;         // wave-bin height divides the handle's bin_row_align option
 
+  // SpMM inspect (spblas_gfx950_spmm_inspect, spmm.hip): row blocks of 32 rows whose entries fall into at most 16
+  // aligned tiles of 128 columns, densely enough, are multiplied from LDS-staged B tiles on the matrix cores
+  int mm_ready = 0;
+  int64_t mm_nblk = 0;              // row blocks of 32 rows
+  int64_t mm_npanel = 0;            // blocks taken by the panel kernel
+  int64_t mm_panel_nnz = 0;         // entries inside those blocks
+  unsigned char* mm_is_panel = nullptr;  // [mm_nblk] 1 = the panel kernel owns the block (the row kernel skips it)
+  int32_t* mm_panel_blocks = nullptr;    // [mm_npanel] block ids
+  int32_t* mm_tiles = nullptr;           // [mm_nblk * 9]: count + up to 8 ascending column-tile ids per block
+  void* mm_long_part = nullptr;          // T[n_long * mm_long_parts * n] partial rows of the long rows (grown on demand)
+  int64_t mm_long_cap = 0;               // elements held by mm_long_part
+  int mm_long_parts = 1;
+
   size_t device_bytes = 0;
 };

@@ -6,17 +6,35 @@
 // /root/reference/include/spblas/vendor/onemkl_sycl/spmm_impl.hpp:116-120 and the
 // maths is the CPU path include/spblas/algorithms/multiply_impl.hpp:66-92.
 //
-// spmm_rowgroup_kernel: a group of G lanes (power of two) owns one row of A and a
-// panel of G*V columns of B/C, V = elements per 16-byte (or narrower) lane access.
-// The group loads G (colind, value) pairs with one coalesced streaming access,
-// broadcasts them lane by lane and gathers whole B rows: every gather is one
-// contiguous G*V*sizeof(T)-byte segment (512 B for n = 128, fp32, V = 4, G = 32).
-// HBM/L2-bound on the B gathers; algorithmic bytes = nnz*(sizeof(T)+4) +
-// (m+1)*sizeof(O) + (k*n + m*n)*sizeof(T).
+// Three kernels; which rows go where is decided by multiply_inspect (spblas_gfx950_spmm_inspect, the counterpart of
+// oneMKL's optimize_gemm at vendor/onemkl_sycl/spmm_impl.hpp:40-67) -- without a plan only the first one runs:
+//   spmm_rowgroup_kernel   a group of G lanes (power of two) owns one row of A and a panel of G*V columns of
+//                          B/C, V = elements per 16-byte (or narrower) lane access.  The group loads G
+//                          (colind, value) pairs with one coalesced streaming access, broadcasts them lane by
+//                          lane and gathers whole B rows: every gather is one contiguous G*V*sizeof(T)-byte
+//                          segment (512 B for n = 128, fp32, V = 4, G = 32).  Bound by the B-row gathers.
+//   spmm_long_rows_kernel  rows longer than the plan's nnz window (hub rows of a power-law matrix: one lane group
+//                          would walk 1e5 entries) are cut into parts of ~4 K entries, one workgroup each; a
+//                          finish kernel adds the parts in order.
+//   spmm_panel_kernel      fp32: row blocks (32 rows) whose entries fall into <= 16 aligned tiles of 64 columns,
+//                          at >= 1/5 density: the B tile (128 x n) is staged in LDS ONCE for the block, the block
+//                          of A is scattered into a dense 32 x 128 LDS tile, and the contraction runs on the matrix
+//                          cores (v_mfma_f32_32x32x2_f32: exact f32, a k-ordered fma chain).  Banded / block
+//                          structured matrices; for uniform random columns no block qualifies and MFMA use is 0
+//                          by construction.
+// Algorithmic bytes = nnz*(sizeof(T)+4) + (m+1)*sizeof(O) + (k*n + m*n)*sizeof(T).
 #include "common.hpp"
 #include "plan.hpp"
+#include "scan.hpp"
+
+#include <cstdlib>
 
 namespace spb {
+
+static bool env_flag(const char* name) {
+  const char* v = std::getenv(name);
+  return v && *v && *v != '0';
+}
 
 template <typename T, int V>
 struct vec_of;
@@ -48,19 +66,29 @@ __global__ __launch_bounds__(256) void spmm_rowgroup_kernel(int64_t m, int64_t n
                                                             const T* __restrict__ values,
                                                             const T* __restrict__ B, int64_t ldb,
                                                             T* __restrict__ C, int64_t ldc, T alpha, T beta,
-                                                            int G) {
+                                                            int G, const unsigned char* __restrict__ is_panel,
+                                                            int long_len) {
+  // is_panel[row / 32] != 0: the panel kernel owns the row block; long_len > 0: rows longer than that belong to
+  // the long-row kernel
   typedef typename vec_of<T, V>::type vec_t;
   const int rows_per_block = 256 / G;
   const int64_t row = (int64_t) blockIdx.x * rows_per_block + threadIdx.x / G;
   const int lig = threadIdx.x % G;
   const int64_t panel_cols = (int64_t) G * V;
   O p0 = 0, p1 = 0;
-  if (row < m) {
+  bool mine = row < m;
+  if (mine && is_panel && is_panel[row >> 5])
+    mine = false;
+  if (mine) {
     p0 = rowptr[row];
     p1 = rowptr[row + 1];
+    if (long_len > 0 && p1 - p0 > (O) long_len)
+      mine = false;
   }
+  if (!mine)
+    p0 = p1 = 0;
   for (int64_t col0 = (int64_t) lig * V; col0 - (int64_t) lig * V < n; col0 += panel_cols) {
-    const bool active = row < m && col0 < n;
+    const bool active = mine && col0 < n;
     T acc[V];
 #pragma unroll
     for (int i = 0; i < V; ++i)
@@ -135,17 +163,340 @@ __global__ __launch_bounds__(256) void scale_matrix_kernel(int64_t m, int64_t n,
 
 template <typename T, typename O, int V>
 static void launch_spmm(hipStream_t s, int64_t m, int64_t n, const O* rowptr, const int32_t* colind,
-                        const T* values, const T* B, int64_t ldb, T* C, int64_t ldc, T alpha, T beta) {
+                        const T* values, const T* B, int64_t ldb, T* C, int64_t ldc, T alpha, T beta,
+                        const unsigned char* is_panel, int long_len) {
   int G = 1;
   while (G < 64 && (int64_t) G * V < n)
     G <<= 1;
   const int rows_per_block = 256 / G;
   hipLaunchKernelGGL((spmm_rowgroup_kernel<T, O, V>), dim3((unsigned) cdiv(m, rows_per_block)), dim3(256), 0, s,
-                     m, n, rowptr, colind, values, B, ldb, C, ldc, alpha, beta, G);
+                     m, n, rowptr, colind, values, B, ldb, C, ldc, alpha, beta, G, is_panel, long_len);
+}
+
+// ---- long rows ------------------------------------------------------------------------------------------
+// Workgroup (i, part) sums entries [lo, hi) of long row i for all n columns into part_buf[(i*parts + part)*n ..]:
+// thread t owns column t % cpp of the current pass of cpp = min(n, 256) columns and walks every eg-th entry
+// (eg = 256 / cpp entry groups); the groups' sums meet in LDS.
+template <typename T, typename O>
+__global__ __launch_bounds__(256) void spmm_long_rows_kernel(const int32_t* __restrict__ long_rows, int parts,
+                                                             int64_t n, const O* __restrict__ rowptr,
+                                                             const int32_t* __restrict__ colind,
+                                                             const T* __restrict__ values, const T* __restrict__ B,
+                                                             int64_t ldb, T* __restrict__ part_buf) {
+  __shared__ T red[256];
+  const int64_t i = blockIdx.x;
+  const int part = blockIdx.y;
+  const int64_t r = long_rows[i];
+  const O p0 = rowptr[r], p1 = rowptr[r + 1];
+  const O per = ((p1 - p0) + (O) parts - 1) / (O) parts;
+  const O lo = p0 + (O) part * per, hi = (lo + per) < p1 ? (lo + per) : p1;
+  const int cpp = n < 256 ? (int) n : 256;   // columns per pass
+  const int eg = 256 / cpp;                   // entry groups
+  const int j = threadIdx.x % cpp, e = threadIdx.x / cpp;
+  T* out = part_buf + ((int64_t) i * parts + part) * n;
+  for (int64_t c0 = 0; c0 < n; c0 += cpp) {
+    const bool col_ok = e < eg && c0 + j < n;
+    T acc = T(0);
+    if (col_ok) {
+      const T* Bc = B + c0 + j;
+      O p = lo + (O) e;
+      for (; p + (O) (3 * eg) < hi; p += (O) (4 * eg)) {  // four gathers in flight
+        const int64_t k0 = colind[p], k1 = colind[p + eg], k2 = colind[p + 2 * eg], k3 = colind[p + 3 * eg];
+        const T b0 = Bc[k0 * ldb], b1 = Bc[k1 * ldb], b2 = Bc[k2 * ldb], b3 = Bc[k3 * ldb];
+        acc += values[p] * b0;
+        acc += values[p + eg] * b1;
+        acc += values[p + 2 * eg] * b2;
+        acc += values[p + 3 * eg] * b3;
+      }
+      for (; p < hi; p += (O) eg)
+        acc += values[p] * Bc[(int64_t) colind[p] * ldb];
+    }
+    __syncthreads();
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (e == 0 && c0 + j < n) {
+      T sum = red[j];
+      for (int g = 1; g < eg; ++g)
+        sum += red[g * cpp + j];
+      out[c0 + j] = sum;
+    }
+  }
+}
+
+// C[row] = alpha * (parts in order) + beta * C[row] for every long row
+template <typename T>
+__global__ __launch_bounds__(256) void spmm_long_finish_kernel(const int32_t* __restrict__ long_rows, int parts,
+                                                               int64_t n, const T* __restrict__ part_buf,
+                                                               T* __restrict__ C, int64_t ldc, T alpha, T beta) {
+  const int64_t i = blockIdx.x;
+  const int64_t r = long_rows[i];
+  for (int64_t j = threadIdx.x; j < n; j += 256) {
+    T sum = T(0);
+    for (int q = 0; q < parts; ++q)
+      sum += part_buf[((int64_t) i * parts + q) * n + j];
+    T* cp = C + r * ldc + j;
+    *cp = beta == T(0) ? alpha * sum : alpha * sum + beta * *cp;
+  }
+}
+
+// ---- panel path (fp32, matrix cores) ---------------------------------------------------------------------
+static constexpr int MM_RB = 32;      // rows per block (the M of v_mfma_f32_32x32x2_f32)
+static constexpr int MM_KT = 64;      // columns of A / rows of B per tile (32 KiB of B + 8 KiB of A in LDS: 4 workgroups per CU)
+static constexpr int MM_MAXT = 16;    // tiles per block at most
+static constexpr int MM_NP = 128;     // columns of B / C per pass (4 wavefronts x 32)
+static constexpr int MM_TS = MM_MAXT + 1;  // ints per block in the tile table: count + ids
+
+// inspect: one wavefront per row block.  tiles[b*9] = number of distinct aligned column tiles of the block (9 = more
+// than MM_MAXT), tiles[b*9 + 1 ..] = their ids ascending; is_panel[b] = 1 when the block qualifies: <= MM_MAXT
+// tiles, >= min_per_tile entries per tile on average, no row longer than long_len.  flag32[b] repeats is_panel[b]
+// as an int for the scan that turns the flags into the ASCENDING list of qualifying blocks (neighbouring list
+// entries share B tiles, which the panel kernel's XCD mapping relies on).
+template <typename O>
+__global__ __launch_bounds__(64) void spmm_panel_probe_kernel(int64_t m, int64_t nblk, const O* __restrict__ rowptr,
+                                                              const int32_t* __restrict__ colind, int long_len,
+                                                              int min_per_tile, int32_t* __restrict__ tiles,
+                                                              unsigned char* __restrict__ is_panel,
+                                                              int32_t* __restrict__ flag32,
+                                                              unsigned long long* __restrict__ counters) {
+  __shared__ int slot[MM_MAXT];
+  __shared__ int overflow;
+  const int64_t b = blockIdx.x;
+  const int lane = threadIdx.x;
+  const int64_t r0 = b * MM_RB, r1 = (r0 + MM_RB) < m ? (r0 + MM_RB) : m;
+  if (lane < MM_MAXT)
+    slot[lane] = -1;
+  if (lane == 0)
+    overflow = 0;
+  __syncthreads();
+  const O p0 = rowptr[r0], p1 = rowptr[r1];
+  bool has_long = false;
+  if (long_len > 0 && r0 + lane < r1 && lane < MM_RB)
+    has_long = rowptr[r0 + lane + 1] - rowptr[r0 + lane] > (O) long_len;
+  has_long = __any(has_long);
+  // cheap reject before the scan: too few entries for even one tile
+  if (!has_long && p1 - p0 >= (O) min_per_tile) {
+    for (O p = p0 + lane; p < p1 && !overflow; p += 64) {
+      const int t = colind[p] / MM_KT;
+      bool placed = false;
+      for (int q = 0; q < MM_MAXT && !placed; ++q) {
+        const int old = atomicCAS(&slot[q], -1, t);
+        placed = old == -1 || old == t;
+      }
+      if (!placed)
+        overflow = 1;
+    }
+  }
+  __syncthreads();
+  if (lane == 0) {
+    int ids[MM_MAXT], nt = 0;
+    for (int q = 0; q < MM_MAXT; ++q)
+      if (slot[q] >= 0)
+        ids[nt++] = slot[q];
+    for (int a = 1; a < nt; ++a) {  // insertion sort: ascending tiles = ascending k order of the contraction
+      const int v = ids[a];
+      int c = a - 1;
+      while (c >= 0 && ids[c] > v) {
+        ids[c + 1] = ids[c];
+        --c;
+      }
+      ids[c + 1] = v;
+    }
+    const bool ok = !has_long && !overflow && nt > 0 && (int64_t) (p1 - p0) >= (int64_t) min_per_tile * nt;
+    tiles[b * MM_TS] = overflow ? MM_MAXT + 1 : nt;
+    for (int q = 0; q < nt; ++q)
+      tiles[b * MM_TS + 1 + q] = ids[q];
+    is_panel[b] = ok ? 1 : 0;
+    flag32[b] = ok ? 1 : 0;
+    if (ok)
+      atomicAdd(&counters[1], (unsigned long long) (p1 - p0));
+  }
+}
+
+// panel_blocks[offset[b]] = b for every qualifying block (offset = exclusive scan of the flags)
+__global__ __launch_bounds__(256) void spmm_panel_list_kernel(int64_t nblk, const unsigned char* __restrict__ is_panel,
+                                                              const int32_t* __restrict__ offset,
+                                                              int32_t* __restrict__ panel_blocks) {
+  const int64_t b = (int64_t) blockIdx.x * 256 + threadIdx.x;
+  if (b < nblk && is_panel[b])
+    panel_blocks[offset[b]] = (int32_t) b;
+}
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// One workgroup (4 wavefronts) per qualifying row block.  Per tile: A entries -> dense At[k][row] (k-major: the
+// MFMA A operand of lane l is At[2s + (l >> 5)][l & 31], consecutive lanes consecutive addresses), the B tile ->
+// Bt[k][col]; 64 MFMA steps of k = 2 contract it; wavefront w owns output columns [32w, 32w + 32) of the pass.
+// A B tile holding a non-finite value is contracted entry by entry instead (0 * inf would poison rows that do not
+// reference it; the reference only multiplies stored entries, multiply_impl.hpp:85-91).
+template <typename O>
+__global__ __launch_bounds__(256) void spmm_panel_kernel(int64_t m, int64_t k, int64_t n,
+                                                         const O* __restrict__ rowptr,
+                                                         const int32_t* __restrict__ colind,
+                                                         const float* __restrict__ values,
+                                                         const float* __restrict__ B, int64_t ldb,
+                                                         float* __restrict__ C, int64_t ldc, float alpha, float beta,
+                                                         const int32_t* __restrict__ panel_blocks,
+                                                         const int32_t* __restrict__ tiles, int64_t nlist_arg, int dbg) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* Bt = reinterpret_cast<float*>(smem);       // [MM_KT][MM_NP]
+  float* At = Bt + MM_KT * MM_NP;                   // [MM_KT][MM_RB]
+  int& nonfinite = *reinterpret_cast<int*>(At + MM_KT * MM_RB);  // (kept in the dynamic region: 16-byte aligned base)
+  int* rp_s = reinterpret_cast<int*>(At + MM_KT * MM_RB) + 4;      // [MM_RB + 1] row offsets relative to the block
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  // consecutive list entries share B tiles: keep them on ONE XCD (workgroup i runs on XCD i % 8; each XCD has its own
+  // L2) by giving XCD x the x-th contiguous eighth of the list -- 8.5 GB of fabric reads for 1 GB of B otherwise
+  const int64_t nlist = nlist_arg, per_xcd = (nlist + 7) / 8;
+  const int64_t li = (int64_t) (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+  if (li >= nlist)
+    return;
+  const int64_t b = panel_blocks[li];
+  const bool vec_ok = ((reinterpret_cast<uintptr_t>(B) | (uintptr_t) (ldb * 4)) & 15) == 0;
+  const int64_t r0 = b * MM_RB, r1 = (r0 + MM_RB) < m ? (r0 + MM_RB) : m;
+  const O p0 = rowptr[r0], p1 = rowptr[r1];
+  const int nt = tiles[b * MM_TS];
+  if (tid <= (int) (r1 - r0))
+    rp_s[tid] = (int) (rowptr[r0 + tid] - p0);
+  __syncthreads();
+  auto row_of = [&](int q) {  // last row of the block starting at or before entry q (offsets relative to the block)
+    int lo = 0, hi = (int) (r1 - r0);
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (rp_s[mid] <= q)
+        lo = mid;
+      else
+        hi = mid;
+    }
+    return lo;
+  };
+  // this thread's four of the block's first 1 024 entries: column (-1 = none), value, row inside the block
+  int64_t ec[4];
+  float ev[4];
+  int er[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const O p = p0 + (O) (u * 256 + tid);
+    const bool ok = p < p1;
+    const O pc = ok ? p : (p1 > p0 ? p1 - 1 : p0);
+    ec[u] = ok ? (int64_t) colind[pc] : -1;
+    ev[u] = ok ? values[pc] : 0.f;
+    er[u] = ok ? row_of((int) (p - p0)) : 0;
+  }
+  for (int64_t c0 = 0; c0 < n; c0 += MM_NP) {
+    const int ncol = (int) ((n - c0) < MM_NP ? (n - c0) : MM_NP);
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+      acc[q] = 0.f;
+    for (int ti = 0; ti < nt; ++ti) {
+      const int64_t kbase = (int64_t) tiles[b * MM_TS + 1 + ti] * MM_KT;
+      __syncthreads();  // the previous tile's operands are no longer read
+      for (int q = tid; q < MM_KT * MM_RB; q += 256)
+        At[q] = 0.f;
+      if (tid == 0)
+        nonfinite = 0;
+      // B tile: rows [kbase, kbase + 128) x columns [c0, c0 + ncol), zero elsewhere.  16 x 16-byte loads per thread,
+      // all issued before the first LDS write (one load at a time left the workgroup waiting 64 memory round trips)
+      bool bad = false;
+      if (dbg & 4) {
+      } else if (vec_ok && ncol == MM_NP) {
+        constexpr int PER = MM_KT * MM_NP / 4 / 256;  // 8 float4 per thread
+        f32x4 buf[PER];
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+          const int q4 = tid + u * 256, kk = q4 / (MM_NP / 4), j4 = q4 % (MM_NP / 4);
+          const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+          buf[u] = kbase + kk < k ? *reinterpret_cast<const f32x4*>(B + (kbase + kk) * ldb + c0 + 4 * j4) : zero;
+        }
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+          const int q4 = tid + u * 256;
+          bad |= !(__builtin_fabsf(buf[u].x) <= 3.402823466e38f) | !(__builtin_fabsf(buf[u].y) <= 3.402823466e38f) |
+                 !(__builtin_fabsf(buf[u].z) <= 3.402823466e38f) | !(__builtin_fabsf(buf[u].w) <= 3.402823466e38f);
+          reinterpret_cast<f32x4*>(Bt)[q4] = buf[u];
+        }
+      } else {
+        for (int q = tid; q < MM_KT * MM_NP; q += 256) {
+          const int kk = q / MM_NP, jj = q % MM_NP;
+          float v = 0.f;
+          if (kbase + kk < k && jj < ncol)
+            v = B[(kbase + kk) * ldb + c0 + jj];
+          bad |= !(__builtin_fabsf(v) <= 3.402823466e38f);  // NaN or infinity
+          Bt[q] = v;
+        }
+      }
+      __syncthreads();
+      if (bad)
+        nonfinite = 1;
+      // A block restricted to this tile (duplicates of one (row, column) accumulate: LDS float atomics, few entries).
+      // The first 1 024 entries of the block sit in registers (column, value, row) since before the tile loop; only
+      // larger blocks go back to memory for the rest.
+      if (!(dbg & 2)) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (ec[u] >= kbase && ec[u] < kbase + MM_KT)
+            unsafeAtomicAdd(&At[(int) (ec[u] - kbase) * MM_RB + er[u]], ev[u]);
+        for (O base = p0 + (O) 1024; base < p1; base += (O) (4 * 256)) {
+          int32_t cc[4];
+          float vv[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const O p = base + (O) (u * 256 + tid);
+            const O pc = p < p1 ? p : p1 - 1;
+            cc[u] = colind[pc];
+            vv[u] = values[pc];
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const O p = base + (O) (u * 256 + tid);
+            const int64_t c = cc[u];
+            if (p < p1 && c >= kbase && c < kbase + MM_KT)
+              unsafeAtomicAdd(&At[(int) (c - kbase) * MM_RB + row_of((int) (p - p0))], vv[u]);
+          }
+        }
+      }
+      __syncthreads();
+      if (!nonfinite) {
+        if (wave * 32 < ncol && !(dbg & 1)) {
+          const float* ap = At + (lane >> 5) * MM_RB + (lane & 31);
+          const float* bp = Bt + (lane >> 5) * MM_NP + wave * 32 + (lane & 31);
+#pragma unroll 8
+          for (int sidx = 0; sidx < MM_KT / 2; ++sidx)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[sidx * 2 * MM_RB], bp[sidx * 2 * MM_NP], acc, 0, 0, 0);
+        }
+      } else if (wave * 32 < ncol) {
+        // entry-by-entry contraction in the accumulator layout: D row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+        for (int kk = 0; kk < MM_KT; ++kk)
+          for (int rr = 0; rr < MM_RB; ++rr) {
+            const float a = At[kk * MM_RB + rr];
+            if (a != 0.f) {  // only stored entries contribute (an explicit zero entry times inf is lost here: see DESIGN)
+              const float prod = a * Bt[kk * MM_NP + wave * 32 + (lane & 31)];
+              const bool owner = ((rr >> 2) & 1) == (lane >> 5);
+              const int reg = (rr & 3) + 4 * (rr >> 3);
+#pragma unroll
+              for (int q = 0; q < 16; ++q)
+                if (owner && q == reg)
+                  acc[q] += prod;
+            }
+          }
+      }
+    }
+    // C block: lane holds column c0 + 32*wave + (lane & 31), rows (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    const int jj = wave * 32 + (lane & 31);
+    if (jj < ncol) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int64_t row = r0 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+        if (row < r1) {
+          float* cp = C + row * ldc + c0 + jj;
+          *cp = beta == 0.f ? alpha * acc[q] : alpha * acc[q] + beta * *cp;
+        }
+      }
+    }
+  }
 }
 
 template <typename T, typename O>
-static int spmm_typed(spblas_gfx950_handle_t h, int64_t m, int64_t k, int64_t n, int64_t nnz,
+static int spmm_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, int64_t m, int64_t k, int64_t n, int64_t nnz,
                       const void* alpha_p, const void* rowptr_p, const int32_t* colind, const void* values_p,
                       const void* B_p, int64_t ldb, const void* beta_p, void* C_p, int64_t ldc) {
   const T alpha = *static_cast<const T*>(alpha_p);
@@ -174,21 +525,130 @@ static int spmm_typed(spblas_gfx950_handle_t h, int64_t m, int64_t k, int64_t n,
       break;
     }
   }
-  if constexpr (sizeof(T) == 4) {
+  // what multiply_inspect decided: rows longer than the nnz window go to the long-row kernels, qualifying row
+  // blocks (fp32) to the panel kernel; everything else (and every row without a plan) to the row-group kernel
+  const bool planned = pl && pl->mm_ready;
+  const int long_len = planned && pl->n_long > 0 ? pl->win : 0;
+  const unsigned char* is_panel = planned && pl->mm_npanel > 0 && sizeof(T) == 4 ? pl->mm_is_panel : nullptr;
+  if (long_len > 0) {
+    // ~4 K entries per workgroup, at most 64 parts per row; the partial rows live in the plan (grown on demand)
+    int64_t parts = cdiv(pl->max_row_len, 4096);
+    parts = parts < 1 ? 1 : (parts > 64 ? 64 : parts);
+    const int64_t need = pl->n_long * parts * n;
+    if (pl->mm_long_cap < need || pl->mm_long_parts != (int) parts) {
+      dev_free(pl->mm_long_part, s);
+      pl->mm_long_part = nullptr;
+      pl->mm_long_cap = 0;
+      int rc = dev_alloc(&pl->mm_long_part, (size_t) need * sizeof(T), s);
+      if (rc)
+        return rc;
+      pl->mm_long_cap = need;
+      pl->mm_long_parts = (int) parts;
+    }
+  }
+  const bool all_panel = is_panel && pl->mm_npanel == pl->mm_nblk;  // nothing left for the row-group kernel
+  if (all_panel) {
+  } else if constexpr (sizeof(T) == 4) {
     if (V == 4)
-      launch_spmm<T, O, 4>(s, m, n, rowptr, colind, values, B, ldb, C, ldc, alpha, beta);
+      launch_spmm<T, O, 4>(s, m, n, rowptr, colind, values, B, ldb, C, ldc, alpha, beta, is_panel, long_len);
     else if (V == 2)
-      launch_spmm<T, O, 2>(s, m, n, rowptr, colind, values, B, ldb, C, ldc, alpha, beta);
+      launch_spmm<T, O, 2>(s, m, n, rowptr, colind, values, B, ldb, C, ldc, alpha, beta, is_panel, long_len);
     else
-      launch_spmm<T, O, 1>(s, m, n, rowptr, colind, values, B, ldb, C, ldc, alpha, beta);
+      launch_spmm<T, O, 1>(s, m, n, rowptr, colind, values, B, ldb, C, ldc, alpha, beta, is_panel, long_len);
   } else {
     if (V == 2)
-      launch_spmm<T, O, 2>(s, m, n, rowptr, colind, values, B, ldb, C, ldc, alpha, beta);
+      launch_spmm<T, O, 2>(s, m, n, rowptr, colind, values, B, ldb, C, ldc, alpha, beta, is_panel, long_len);
     else
-      launch_spmm<T, O, 1>(s, m, n, rowptr, colind, values, B, ldb, C, ldc, alpha, beta);
+      launch_spmm<T, O, 1>(s, m, n, rowptr, colind, values, B, ldb, C, ldc, alpha, beta, is_panel, long_len);
+  }
+  if constexpr (sizeof(T) == 4) {
+    if (is_panel) {
+      const size_t lds = (size_t) (MM_KT * MM_NP + MM_KT * MM_RB + 4 + MM_RB + 4) * sizeof(float);
+      hipLaunchKernelGGL((spmm_panel_kernel<O>), dim3((unsigned) (8 * cdiv(pl->mm_npanel, 8))), dim3(256), lds, s, m, k, n,
+                         rowptr, colind, values, B, ldb, C, ldc, alpha, beta, pl->mm_panel_blocks, pl->mm_tiles,
+                         pl->mm_npanel, env_flag("SPBLAS_GFX950_SPMM_DBG") ? std::atoi(std::getenv("SPBLAS_GFX950_SPMM_DBG")) : 0);
+    }
+  }
+  if (long_len > 0) {
+    T* part = static_cast<T*>(pl->mm_long_part);
+    hipLaunchKernelGGL((spmm_long_rows_kernel<T, O>), dim3((unsigned) pl->n_long, (unsigned) pl->mm_long_parts), dim3(256), 0,
+                       s, pl->long_rows, pl->mm_long_parts, n, rowptr, colind, values, B, ldb, part);
+    hipLaunchKernelGGL((spmm_long_finish_kernel<T>), dim3((unsigned) pl->n_long), dim3(256), 0, s, pl->long_rows,
+                       pl->mm_long_parts, n, part, C, ldc, alpha, beta);
   }
   SPB_HIP(hipGetLastError());
   return SPBLAS_GFX950_STATUS_SUCCESS;
+}
+
+template <typename O>
+static int spmm_inspect_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl) {
+  hipStream_t s = h->stream;
+  pl->mm_ready = 1;
+  pl->mm_nblk = cdiv(pl->m, MM_RB);
+  pl->mm_npanel = 0;
+  pl->mm_panel_nnz = 0;
+  // the panel kernel is fp32 only (v_mfma_f32_32x32x2_f32); a block needs >= 256 entries to qualify at all
+  if (pl->value_type != SPBLAS_GFX950_F32 || pl->mm_nblk == 0 || pl->nnz < 256 || env_flag("SPBLAS_GFX950_SPMM_NO_PANEL"))
+    return SPBLAS_GFX950_STATUS_SUCCESS;
+  int rc;
+  // entries a block must hold per 32 x 64 tile it touches: 1/5 dense, the measured crossover with the row-group
+  // kernel on banded matrices (tools/spmm_density.py: 1 M rows, n = 128 -- 0.94 vs 0.98 ms at 0.2, 1.49 vs 2.50 ms
+  // at 0.6, 0.78 vs 0.41 ms at 0.05); SPBLAS_GFX950_SPMM_PANEL_MIN overrides it (tests)
+  int min_per_tile = MM_RB * MM_KT / 5;
+  if (const char* e = std::getenv("SPBLAS_GFX950_SPMM_PANEL_MIN"))
+    min_per_tile = std::atoi(e) > 0 ? std::atoi(e) : min_per_tile;
+  unsigned long long* d_cnt = nullptr;
+  int32_t* flag32 = nullptr;
+  long long* partials = nullptr;
+  if ((rc = dev_alloc((void**) &pl->mm_is_panel, (size_t) pl->mm_nblk, s)) ||
+      (rc = dev_alloc((void**) &pl->mm_tiles, (size_t) pl->mm_nblk * MM_TS * 4, s)) ||
+      (rc = dev_alloc((void**) &pl->mm_panel_blocks, (size_t) pl->mm_nblk * 4, s)) ||
+      (rc = dev_alloc((void**) &d_cnt, 16, s)))
+    return rc;
+  if ((rc = dev_alloc((void**) &flag32, (size_t) (pl->mm_nblk + 1) * 4, s)) ||
+      (rc = dev_alloc((void**) &partials, (size_t) (cdiv(pl->mm_nblk, 2048) + 2) * sizeof(long long), s))) {
+    dev_free(d_cnt, s);
+    dev_free(flag32, s);
+    return rc;
+  }
+  SPB_HIP(hipMemsetAsync(d_cnt, 0, 16, s));
+  hipLaunchKernelGGL((spmm_panel_probe_kernel<O>), dim3((unsigned) pl->mm_nblk), dim3(64), 0, s, pl->m, pl->mm_nblk,
+                     static_cast<const O*>(pl->rowptr), pl->colind, pl->n_long > 0 ? pl->win : 0, min_per_tile,
+                     pl->mm_tiles, pl->mm_is_panel, flag32, d_cnt);
+  (void) scan_counts_i32(s, pl->mm_nblk, flag32, partials);  // flag32[nblk] = number of qualifying blocks
+  hipLaunchKernelGGL(spmm_panel_list_kernel, dim3((unsigned) cdiv(pl->mm_nblk, 256)), dim3(256), 0, s, pl->mm_nblk,
+                     pl->mm_is_panel, flag32, pl->mm_panel_blocks);
+  unsigned long long h_cnt[2] = {0, 0};
+  int32_t h_np = 0;
+  hipError_t e = hipMemcpyAsync(h_cnt, d_cnt, 16, hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess)
+    e = hipMemcpyAsync(&h_np, flag32 + pl->mm_nblk, 4, hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess)
+    e = hipStreamSynchronize(s);
+  dev_free(d_cnt, s);
+  dev_free(flag32, s);
+  dev_free(partials, s);
+  if (e != hipSuccess)
+    return hip_fail(e);
+  pl->mm_npanel = (int64_t) h_np;
+  pl->mm_panel_nnz = (int64_t) h_cnt[1];
+  pl->device_bytes += (size_t) pl->mm_nblk * (1 + 4 * MM_TS + 4);
+  SPB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(spmm_panel_kernel<O>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (MM_KT * MM_NP + MM_KT * MM_RB + 4 + MM_RB + 4) * (int) sizeof(float)));
+  return SPBLAS_GFX950_STATUS_SUCCESS;
+}
+
+void spmm_plan_free(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl) {
+  hipStream_t s = h->stream;
+  dev_free(pl->mm_is_panel, s);
+  dev_free(pl->mm_tiles, s);
+  dev_free(pl->mm_panel_blocks, s);
+  dev_free(pl->mm_long_part, s);
+  pl->mm_is_panel = nullptr;
+  pl->mm_tiles = pl->mm_panel_blocks = nullptr;
+  pl->mm_long_part = nullptr;
+  pl->mm_long_cap = 0;
+  pl->mm_ready = 0;
 }
 
 } // namespace spb
@@ -211,14 +671,35 @@ extern "C" int spblas_gfx950_spmm(spblas_gfx950_handle_t handle, spblas_gfx950_p
   if (!alpha || !beta || !rowptr || (nnz > 0 && (!colind || !values || !B)) || (m > 0 && n > 0 && !C))
     return SPBLAS_GFX950_STATUS_INVALID_POINTER;
   if (plan && (plan->m != m || plan->n != k || plan->nnz != nnz || plan->rowptr != rowptr ||
-               plan->colind != colind || plan->offset_type != offset_type))
+               plan->colind != colind || plan->offset_type != offset_type || plan->value_type != value_type))
     return SPBLAS_GFX950_STATUS_PLAN_MISMATCH;
   if (value_type == SPBLAS_GFX950_F32) {
     return offset_type == SPBLAS_GFX950_I32
-               ? spmm_typed<float, int32_t>(handle, m, k, n, nnz, alpha, rowptr, colind, values, B, ldb, beta, C, ldc)
-               : spmm_typed<float, int64_t>(handle, m, k, n, nnz, alpha, rowptr, colind, values, B, ldb, beta, C, ldc);
+               ? spmm_typed<float, int32_t>(handle, plan, m, k, n, nnz, alpha, rowptr, colind, values, B, ldb, beta, C, ldc)
+               : spmm_typed<float, int64_t>(handle, plan, m, k, n, nnz, alpha, rowptr, colind, values, B, ldb, beta, C, ldc);
   }
   return offset_type == SPBLAS_GFX950_I32
-             ? spmm_typed<double, int32_t>(handle, m, k, n, nnz, alpha, rowptr, colind, values, B, ldb, beta, C, ldc)
-             : spmm_typed<double, int64_t>(handle, m, k, n, nnz, alpha, rowptr, colind, values, B, ldb, beta, C, ldc);
+             ? spmm_typed<double, int32_t>(handle, plan, m, k, n, nnz, alpha, rowptr, colind, values, B, ldb, beta, C, ldc)
+             : spmm_typed<double, int64_t>(handle, plan, m, k, n, nnz, alpha, rowptr, colind, values, B, ldb, beta, C, ldc);
+}
+
+extern "C" int spblas_gfx950_spmm_inspect(spblas_gfx950_handle_t handle, spblas_gfx950_plan_t plan) {
+  if (!handle)
+    return SPBLAS_GFX950_STATUS_INVALID_HANDLE;
+  if (!plan)
+    return SPBLAS_GFX950_STATUS_INVALID_POINTER;
+  if (plan->mm_ready)
+    return SPBLAS_GFX950_STATUS_SUCCESS;
+  return plan->offset_type == SPBLAS_GFX950_I32 ? spmm_inspect_typed<int32_t>(handle, plan)
+                                                : spmm_inspect_typed<int64_t>(handle, plan);
+}
+
+extern "C" int spblas_gfx950_spmm_plan_info(spblas_gfx950_plan_t plan, int64_t info[4]) {
+  if (!plan || !info)
+    return SPBLAS_GFX950_STATUS_INVALID_POINTER;
+  info[0] = plan->mm_ready;
+  info[1] = plan->mm_npanel;      // row blocks (32 rows) multiplied on the matrix cores
+  info[2] = plan->mm_panel_nnz;   // entries inside them
+  info[3] = plan->mm_ready ? plan->n_long : 0;  // rows cut into parts by the long-row kernel
+  return SPBLAS_GFX950_STATUS_SUCCESS;
 }

@@ -380,6 +380,7 @@ int spmv_sliced_reserve_partial(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* 
 int spmv_sliced_build(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const void* values, bool auto_mode);
 int spmv_sliced_update(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const void* values);
 void spmv_sliced_free(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl);
+void spmm_plan_free(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl);
 
 template <typename T, typename O>
 static int spmv_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, int op, int64_t m, int64_t n,
@@ -693,6 +694,7 @@ int spblas_gfx950_plan_destroy(spblas_gfx950_handle_t handle, spblas_gfx950_plan
   dev_free(plan->part_head, s);
   dev_free(plan->part_tail, s);
   spmv_sliced_free(handle, plan);
+  spmm_plan_free(handle, plan);
   delete plan;
   return SPBLAS_GFX950_STATUS_SUCCESS;
 }

@@ -128,6 +128,7 @@ def test_cfg3_spmm_rmat_hub_rows(gpu):
     B = torch.rand((k, 128), device="cuda", generator=g)
     C = torch.full((m, 128), float("nan"), device="cuda")
     info = sp.multiply_inspect(sp.matrix_opt(a), B, C)
+    assert info.state_.spmm_info()["long_rows"] > 100  # the hubs go to the split long-row kernel
     sp.multiply(info, sp.scaled(0.5, a), B, C)
     assert bool(torch.isfinite(C).all())
     lens = (rowptr[1:].long() - rowptr[:-1].long())
@@ -143,7 +144,9 @@ def test_cfg3_spmm_rmat_hub_rows(gpu):
     # the plan-free path gives the same answer to rounding
     C2 = torch.full((m, 128), float("nan"), device="cuda")
     sp.multiply(sp.scaled(0.5, a), B, C2)
-    assert bool(((C - C2).abs() <= 2e-5 * C.abs() + 1e-30).all())
+    # (both sum positive terms; a k-entry row summed in sequence carries up to ~k*eps/2 of rounding, the split rows less)
+    tol = torch.clamp(lens.float() * 6e-8, min=2e-5)[:, None]
+    assert bool(((C - C2).abs() <= tol * C.abs() + 1e-30).all())
 
 
 # --------------------------------------------------------------------------------------------- cfg4

@@ -109,3 +109,111 @@ def test_spmm_cfg3_shape_properties(gpu):
     C_ref = oracle.spmm((len(rows), k), sub_rp, sub_c, sub_v, B_h)
     util.assert_parity(C1[torch.from_numpy(rows).cuda()].cpu().numpy(), C_ref,
                        absprod(sub_v, sub_rp, sub_c, (len(rows), k), B_h), np.float32, what="cfg3 sampled rows")
+
+
+def _banded(m, k, per_row, half_width, rng, clusters=(0,), dup=True):
+    """Rows whose columns cluster around the diagonal (and around diagonal + offset for every further cluster):
+    neighbouring rows share B rows -- the structure multiply_inspect hands to the LDS-staged matrix-core kernel."""
+    rowptr = np.arange(m + 1, dtype=np.int64) * per_row
+    centre = (np.arange(m) * (k / m)).astype(np.int64)
+    off = rng.integers(-half_width, half_width + 1, (m, per_row))
+    which = rng.integers(0, len(clusters), (m, per_row))
+    cols = (centre[:, None] + off + np.asarray(clusters)[which]) % k
+    if dup:
+        cols[:, 1] = cols[:, 0]  # one repeated (row, column) pair per row
+    return rowptr.astype(np.int32), cols.reshape(-1).astype(np.int32)
+
+
+@pytest.mark.parametrize("n", [32, 128, 200])
+@pytest.mark.parametrize("clusters", [(0,), (0, 5000, 11000)])
+def test_spmm_panel_path_matrix_cores(gpu, n, clusters, monkeypatch):
+    """SpMM inspect is consumed: row blocks whose entries fall into a few aligned 128-column tiles are multiplied
+    from LDS-staged B tiles on the matrix cores (spmm_panel_kernel, exact-f32 MFMA); the result must equal the
+    oracle like every other path, including repeated (row, column) pairs, unsorted columns, a ragged last block,
+    n that is not a multiple of 32 and n > 128 (two passes)."""
+    monkeypatch.setenv("SPBLAS_GFX950_SPMM_PANEL_MIN", "64")  # below the performance threshold: exercise the kernel
+    rng = np.random.default_rng(17)
+    m, k, per_row = 20011, 23000, 24 * len(clusters)
+    rowptr, colind = _banded(m, k, per_row, 40, rng, clusters)
+    nnz = len(colind)
+    values = (rng.random(nnz) - 0.3).astype(np.float32)
+    B = (rng.random((k, n)) - 0.5).astype(np.float32)
+    a = G.csr_on_device(values, rowptr, colind, (m, k), nnz)
+    Bd = G.dev(B)
+    C = torch.full((m, n), float("nan"), device="cuda")
+    info = sp.multiply_inspect(sp.matrix_opt(a), Bd, C)
+    mi = info.state_.spmm_info()
+    assert mi["inspected"] == 1 and mi["panel_blocks"] >= 0.9 * (m // 32), mi
+    sp.multiply(info, sp.scaled(-1.5, a), Bd, C)
+    C_ref = oracle.spmm((m, k), rowptr, colind, values, B, scale_a=-1.5)
+    util.assert_parity(G.host(C), C_ref, 1.5 * absprod(values, rowptr, colind, (m, k), B), np.float32,
+                       row_len=np.diff(rowptr), what=f"panel spmm n={n} clusters={clusters}")
+    # the plan-free path (one lane group per row) gives the same answer to rounding
+    C2 = torch.full((m, n), float("nan"), device="cuda")
+    sp.multiply(sp.scaled(-1.5, a), Bd, C2)
+    assert bool(((C - C2).abs() <= 1e-5 * (C.abs() + C2.abs()) + 1e-6).all())
+
+
+def test_spmm_panel_threshold_default(gpu):
+    """Default admission: >= 1/5 dense tiles go to the matrix cores, sparser banded blocks and uniform random
+    columns stay with the row-group kernel (MFMA use 0 by construction for cfg3-like inputs)."""
+    rng = np.random.default_rng(3)
+    m = k = 8192
+    x = torch.ones(k, 32, device="cuda")
+    C = torch.empty(m, 32, device="cuda")
+    for per_row, expect in ((64, True), (8, False)):
+        rowptr, colind = _banded(m, k, per_row, 40, rng, dup=False)
+        a = G.csr_on_device(np.ones(len(colind), np.float32), rowptr, colind, (m, k), len(colind))
+        info = sp.multiply_inspect(a, x, C)
+        assert (info.state_.spmm_info()["panel_blocks"] > 0.9 * (m // 32)) == expect, (per_row, info.state_.spmm_info())
+    values, rowptr, colind, shape, nnz = generate.uniform_csr_device(200_000, 200_000, 32, seed=0)
+    info = sp.multiply_inspect(sp.csr_view(values, rowptr, colind, shape, nnz), torch.ones(200_000, 32, device="cuda"),
+                               torch.empty(200_000, 32, device="cuda"))
+    assert info.state_.spmm_info() == {"inspected": 1, "panel_blocks": 0, "panel_nnz": 0, "long_rows": 0}
+
+
+def test_spmm_panel_path_nonfinite_b_rows(gpu, monkeypatch):
+    monkeypatch.setenv("SPBLAS_GFX950_SPMM_PANEL_MIN", "64")
+    """The dense tile holds zeros where A has no entry; 0 * inf must not leak into rows that do not reference the
+    non-finite B row (the reference multiplies stored entries only, multiply_impl.hpp:85-91)."""
+    rng = np.random.default_rng(5)
+    m, k, n, per_row = 4096, 4096, 64, 24
+    rowptr, colind = _banded(m, k, per_row, 30, rng, dup=False)
+    nnz = len(colind)
+    values = (rng.random(nnz) + 0.5).astype(np.float32)
+    B = (rng.random((k, n)) + 0.5).astype(np.float32)
+    B[1000, 3] = np.inf
+    B[2500, :] = np.nan
+    a = G.csr_on_device(values, rowptr, colind, (m, k), nnz)
+    C = torch.full((m, n), 7.0, device="cuda")
+    info = sp.multiply_inspect(a, G.dev(B), C)
+    assert info.state_.spmm_info()["panel_blocks"] > 100
+    sp.multiply(info, a, G.dev(B), C)
+    C_ref = oracle.spmm((m, k), rowptr, colind, values, B)
+    got = G.host(C)
+    assert np.array_equal(np.isnan(got), np.isnan(C_ref)) and np.array_equal(np.isinf(got), np.isinf(C_ref))
+    fin = np.isfinite(C_ref)
+    assert np.isnan(C_ref).any() and np.isinf(C_ref).any()
+    np.testing.assert_allclose(got[fin], C_ref[fin], rtol=2e-5)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_spmm_long_rows_are_split(gpu, dtype):
+    """Rows longer than the plan's nnz window (hub rows) are cut into parts by spmm_long_rows_kernel."""
+    rng = np.random.default_rng(9)
+    m, k, n = 3000, 5000, 72
+    lens = rng.integers(0, 20, m)
+    lens[17], lens[1500], lens[2999] = 30000, 9000, 2500
+    rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    nnz = int(rowptr[-1])
+    colind = rng.integers(0, k, nnz).astype(np.int32)
+    values = (rng.random(nnz) - 0.5).astype(dtype)
+    B = (rng.random((k, n)) - 0.5).astype(dtype)
+    a = G.csr_on_device(values, rowptr, colind, (m, k), nnz)
+    C = torch.full((m, n), float("nan"), dtype=G.dev(B).dtype, device="cuda")
+    info = sp.multiply_inspect(a, G.dev(B), C)
+    assert info.state_.spmm_info()["long_rows"] == (3 if dtype == np.float32 else 3)
+    sp.multiply(info, sp.scaled(2.0, a), G.dev(B), C)
+    C_ref = oracle.spmm((m, k), rowptr, colind, values, B, scale_a=2.0)
+    util.assert_parity(G.host(C), C_ref, 2.0 * absprod(values, rowptr, colind, (m, k), B), dtype,
+                       row_len=np.diff(rowptr), what="spmm long rows")
