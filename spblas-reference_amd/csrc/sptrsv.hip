@@ -13,15 +13,20 @@
 //   inspect   in-degree of every row + adjacency "row k -> rows that read x_k" (strict triangle
 //             transposed, built with atomics: order is irrelevant), then Kahn's algorithm: the
 //             frontier of rows whose in-degree dropped to zero becomes the next level.
-//   solve     one launch per WIDE level (rows spread over the chip, G lanes per row), and ONE
-//             single-workgroup launch per run of consecutive NARROW levels, which walks them with a
+//   solve     ONE launch per run of consecutive WIDE levels: a self-scheduling kernel whose wavefronts take
+//             chunks of rows in level order from a ticket counter and wait for the x entries they need on
+//             8-byte {value, solve number} granules published by the producing rows (one agent-scope store
+//             each; no kernel boundary, no grid barrier: a level costs one producer -> consumer hand-off,
+//             ~1 us, instead of a dependent launch of ~12 us -- 161 launches for 246 levels at 4 M rows before),
+//             and ONE single-workgroup launch per run of consecutive NARROW levels, which walks them with a
 //             workgroup barrier in between -- a chain-like matrix then costs a barrier per level
-//             instead of a kernel launch per level.  The same split is used inside inspect.
+//             instead of a hand-off per level.  Inspect splits its levels the same way.
 // Row sums are computed G lanes wide and tree-reduced, so they re-associate with respect to the
 // reference's sequential loop: parity is norm-wise, not bit-wise.
 #include "common.hpp"
 #include "scan.hpp"
 
+#include <algorithm>
 #include <cstdlib>
 #include <new>
 #include <vector>
@@ -33,6 +38,8 @@ static int env_int(const char* name, int def) {  // tuning / test hook
 
 #define TRSV_NARROW 2048       // inspect: frontiers with fewer rows are advanced by the single-workgroup kernel
 #define TRSV_BLOCK_THREADS 1024
+#define TRSV_SC_PASSES 2        // solve: wavefront passes per ticket of the self-scheduling kernel
+#define TRSV_SS_WAVES 16        // wavefronts per workgroup of the self-scheduling kernel (2 workgroups per CU fill it)
 
 struct spblas_gfx950_trsv_s {
   int64_t m = 0, nnz = 0;
@@ -47,6 +54,14 @@ struct spblas_gfx950_trsv_s {
   std::vector<group_t> groups;
   int64_t max_width = 0;
   int lanes = 8;  // lanes per row in the solve kernels
+  // self-scheduling solve of the wide runs: per wide group the cumulative chunk counts of its levels
+  // (chunk_ptr[group.cp0 .. group.cp0 + levels]), one ticket counter per group, and the granules
+  int32_t* chunk_ptr = nullptr;       // device
+  int32_t* tickets = nullptr;         // device [n_groups + 1] (+ 1 status word at the end)
+  unsigned long long* gran = nullptr; // device [2 * m]: {x bits (fp32) or half of them (fp64), solve number}
+  unsigned epoch = 0;                 // solve number (tags of earlier solves never match)
+  std::vector<int32_t> group_cp0;     // per group: first index into chunk_ptr (wide groups), -1 otherwise
+  std::vector<int32_t> group_chunks;  // per group: chunks in total
 };
 
 namespace spb {
@@ -87,6 +102,132 @@ __global__ __launch_bounds__(256) void trsv_fill_adj_kernel(int64_t m, const int
     const int c = colind[p];
     if (c >= 0 && c < m && trsv_strict(c, (int) row, upper))
       adj[adj_ptr[c] + atomicAdd(&cursor[c], 1)] = (int32_t) row;
+  }
+}
+
+// ---- levels by dependency polling (the default inspect) ---------------------------------------------------
+// level(r) = 1 + max level of the rows r reads (0 without dependencies).  For the lower triangle every dependency has
+// a smaller row index (larger for the upper one), so ONE self-scheduling kernel that hands out row blocks in index
+// order can compute all levels: a lane owns a row, polls lev[c] (level + 1; 0 = not yet known) of each strict entry
+// and publishes its own when all are known -- agent-scope 4-byte atomics, no adjacency lists, no transposed graph,
+// no launch per level (Kahn's algorithm above needs all three: 17 ms at 4 M rows / 246 levels).  Blocks go to
+// RUNNING workgroups in dependency order, so whatever a lane waits for is held by a running lane or already done;
+// lanes of one wavefront that depend on each other make progress because the wave-uniform outer loop lets the
+// producer store before the consumer polls again.  stat[0] = deepest level.
+__global__ __launch_bounds__(256) void trsv_levels_poll_kernel(int64_t m, const int32_t* __restrict__ rowptr,
+                                                               const int32_t* __restrict__ colind, int upper,
+                                                               int32_t* __restrict__ lev,
+                                                               int32_t* __restrict__ ticket, int32_t* __restrict__ stat,
+                                                               int spin_limit) {
+  // (four lanes per row instead of one -- a shorter hand-off chain through a row -- measured 4.2 vs 3.7 ms at 4 M
+  // rows: the kernel is bound by head-of-line blocking of the index-ordered tickets, not by the walk of a row)
+  __shared__ int s_ticket;
+  const int64_t nblk = (m + 255) / 256;
+  while (true) {
+    __syncthreads();
+    if (threadIdx.x == 0)
+      s_ticket = atomicAdd(ticket, 1);
+    __syncthreads();
+    const int64_t t = s_ticket;
+    if (t >= nblk)
+      return;
+    const int64_t blk = upper ? nblk - 1 - t : t;  // upper triangle: dependencies have larger indices
+    // inside a block, too, lanes take the rows in dependency order (irrelevant for correctness, shortens the waits)
+    const int64_t r = upper ? blk * 256 + 255 - threadIdx.x : blk * 256 + threadIdx.x;
+    const bool live = r < m;
+    int p = live ? rowptr[r] : 0;
+    const int p1 = live ? rowptr[r + 1] : 0;
+    int mx = 0;
+    bool done = !live;
+    int spins = 0;
+    while (__any(!done)) {
+      if (!done) {
+        while (p < p1) {
+          const int c = colind[p];
+          if (c >= 0 && c < m && trsv_strict(c, (int) r, upper)) {
+            const int v = __hip_atomic_load(&lev[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (v == 0)
+              break;  // not known yet: poll again on the next round
+            mx = v > mx ? v : mx;
+          }
+          ++p;
+        }
+        if (p >= p1) {
+          __hip_atomic_store(&lev[r], mx + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          done = true;
+        } else if (++spins > spin_limit) {
+          stat[1] = 1;  // gave up (corrupt input or a scheduling assumption broken): the host falls back to Kahn
+          done = true;
+        } else {
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
+    }
+    // deepest level: one atomic per wavefront (one per row on a single address took 20 ms at 4 M rows)
+    int wmax = live ? mx : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const int other = __shfl_xor(wmax, o, SPB_WAVE);
+      wmax = other > wmax ? other : wmax;
+    }
+    if ((threadIdx.x & 63) == 0)
+      atomicMax(&stat[0], wmax);
+  }
+}
+
+// rows per level: LDS histogram of the first 4 096 levels per workgroup (global atomics beyond), flushed once
+__global__ __launch_bounds__(256) void trsv_level_hist_kernel(int64_t m, const int32_t* __restrict__ lev,
+                                                              int32_t* __restrict__ hist) {
+  __shared__ int lh[4096];
+  for (int i = threadIdx.x; i < 4096; i += 256)
+    lh[i] = 0;
+  __syncthreads();
+  const int64_t per = (m + gridDim.x - 1) / gridDim.x;
+  const int64_t lo = (int64_t) blockIdx.x * per, hi = (lo + per) < m ? (lo + per) : m;
+  for (int64_t r = lo + threadIdx.x; r < hi; r += 256) {
+    const int l = lev[r] - 1;
+    if (l < 4096)
+      atomicAdd(&lh[l], 1);
+    else
+      atomicAdd(&hist[l], 1);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 4096; i += 256)
+    if (lh[i])
+      atomicAdd(&hist[i], lh[i]);
+}
+
+// order[level_ptr[level(r)] + k] = r: rows grouped by level (the order inside a level is irrelevant).  Every workgroup
+// counts its chunk of rows per level in LDS, reserves its share of each level with ONE global atomic, and places the
+// rows with LDS cursors (one global atomic per row on 246 hot counters took 11 ms at 4 M rows); levels beyond the
+// first 4 096 use the global cursors directly.
+__global__ __launch_bounds__(256) void trsv_place_rows_kernel(int64_t m, const int32_t* __restrict__ lev,
+                                                              const int32_t* __restrict__ level_ptr,
+                                                              int32_t* __restrict__ cursor, int32_t* __restrict__ order) {
+  __shared__ int lh[4096];
+  __shared__ int lbase[4096];
+  for (int i = threadIdx.x; i < 4096; i += 256)
+    lh[i] = 0;
+  __syncthreads();
+  const int64_t per = (m + gridDim.x - 1) / gridDim.x;
+  const int64_t lo = (int64_t) blockIdx.x * per, hi = (lo + per) < m ? (lo + per) : m;
+  for (int64_t r = lo + threadIdx.x; r < hi; r += 256) {
+    const int l = lev[r] - 1;
+    if (l < 4096)
+      atomicAdd(&lh[l], 1);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 4096; i += 256) {
+    const int c = lh[i];
+    if (c)
+      lbase[i] = level_ptr[i] + atomicAdd(&cursor[i], c);
+    lh[i] = 0;
+  }
+  __syncthreads();
+  for (int64_t r = lo + threadIdx.x; r < hi; r += 256) {
+    const int l = lev[r] - 1;
+    const int pos = l < 4096 ? lbase[l] + atomicAdd(&lh[l], 1) : level_ptr[l] + atomicAdd(&cursor[l], 1);
+    order[pos] = (int32_t) r;
   }
 }
 
@@ -208,17 +349,56 @@ __global__ __launch_bounds__(TRSV_BLOCK_THREADS) void trsv_bfs_block_kernel(cons
   }
 }
 
-// x_r for one row, computed by a group of G lanes (all lanes of the group return the same values)
+// ---- granules: x_r published for consumers INSIDE a running kernel ---------------------------------------
+// gran[2r] (fp32) / gran[2r], gran[2r+1] (fp64: low and high half) = {payload : 32, solve number : 32}, written by
+// ONE naturally aligned 8-byte agent-scope store each: the data is the flag (cdna_hip_programming.md, Guideline 16,
+// form R2) -- a consumer that reads the current solve number in the tag holds the value, no fence on either side.
+template <typename T>
+__device__ __forceinline__ void trsv_publish(unsigned long long* gran, int r, T v, unsigned epoch);
+template <>
+__device__ __forceinline__ void trsv_publish<float>(unsigned long long* gran, int r, float v, unsigned epoch) {
+  __hip_atomic_store(&gran[2 * (int64_t) r], ((unsigned long long) epoch << 32) | __float_as_uint(v), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
+}
+template <>
+__device__ __forceinline__ void trsv_publish<double>(unsigned long long* gran, int r, double v, unsigned epoch) {
+  const unsigned long long bits = (unsigned long long) __double_as_longlong(v);
+  __hip_atomic_store(&gran[2 * (int64_t) r], ((unsigned long long) epoch << 32) | (bits & 0xFFFFFFFFull), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(&gran[2 * (int64_t) r + 1], ((unsigned long long) epoch << 32) | (bits >> 32), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
+}
+// one poll: true when x_c of this solve has arrived (then *out holds it)
+template <typename T>
+__device__ __forceinline__ bool trsv_try_read(const unsigned long long* gran, int c, unsigned epoch, T* out);
+template <>
+__device__ __forceinline__ bool trsv_try_read<float>(const unsigned long long* gran, int c, unsigned epoch, float* out) {
+  const unsigned long long g = __hip_atomic_load(&gran[2 * (int64_t) c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  *out = __uint_as_float((unsigned) g);
+  return (unsigned) (g >> 32) == epoch;
+}
+template <>
+__device__ __forceinline__ bool trsv_try_read<double>(const unsigned long long* gran, int c, unsigned epoch, double* out) {
+  const unsigned long long lo = __hip_atomic_load(&gran[2 * (int64_t) c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned long long hi = __hip_atomic_load(&gran[2 * (int64_t) c + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  *out = __longlong_as_double((long long) ((hi << 32) | (lo & 0xFFFFFFFFull)));
+  return (unsigned) (lo >> 32) == epoch && (unsigned) (hi >> 32) == epoch;
+}
+
+// x_r for one row, computed by a group of G lanes (all lanes of the group return the same values).
+// Entries whose column lies outside [0, m) are ignored, as the inspect kernels ignore them; a row without a
+// stored diagonal divides by alpha * 0 (the reference would reuse the previous row's diagonal: undefined input).
 template <typename T, int G>
 __device__ __forceinline__ void trsv_row(int r, int lane, const int32_t* __restrict__ rowptr,
                                          const int32_t* __restrict__ colind, const T* __restrict__ values, T alpha,
-                                         const T* __restrict__ b, T* x, int upper, int unit) {
+                                         const T* __restrict__ b, T* x, int upper, int unit, int m,
+                                         unsigned long long* __restrict__ gran, unsigned epoch) {
   T dot = T(0);
   int dpos = -1;
   const int p1 = rowptr[r + 1];
   for (int p = rowptr[r] + lane; p < p1; p += G) {
     const int c = colind[p];
-    if (trsv_strict(c, r, upper))
+    if (c >= 0 && c < m && trsv_strict(c, r, upper))
       dot += values[p] * __hip_atomic_load(&x[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else if (c == r)
       dpos = p;  // the last stored diagonal entry wins (triangular_solve_impl.hpp:64-66,81-83)
@@ -234,6 +414,94 @@ __device__ __forceinline__ void trsv_row(int r, int lane, const int32_t* __restr
     if (!unit)
       v = v / (alpha * (dpos >= 0 ? values[dpos] : T(0)));
     __hip_atomic_store(&x[r], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    trsv_publish<T>(gran, r, v, epoch);  // consumers inside a later self-scheduling launch poll the granule
+  }
+}
+
+// A run of consecutive WIDE levels [l0, l0 + nlev) in one launch.  Work = chunks of 64 / G rows that never cross a
+// level boundary (rows of one level are independent); chunk_ptr[i] = chunks before level l0 + i.  A wavefront takes
+// the next chunk from the ticket counter, loads its rows (independent of x), and polls the granule of every x_c it
+// needs: chunks are handed out in level order to RUNNING wavefronts, so whatever a wavefront waits for belongs to a
+// ticket taken earlier by a wavefront that is running too -- no residency assumption, no grid barrier.  Every spin is
+// bounded: after `spin_limit` polls the wave raises status[0] and gives up (the host reports HIP_ERROR).
+template <typename T, int G>
+__global__ __launch_bounds__(TRSV_SS_WAVES * 64) void trsv_selfsched_kernel(int l0, int nlev, const int32_t* __restrict__ chunk_ptr,
+                                                             const int32_t* __restrict__ level_ptr,
+                                                             const int32_t* __restrict__ order,
+                                                             const int32_t* __restrict__ rowptr,
+                                                             const int32_t* __restrict__ colind,
+                                                             const T* __restrict__ values, T alpha,
+                                                             const T* __restrict__ b, T* x, int upper, int unit, int m,
+                                                             unsigned long long* __restrict__ gran, unsigned epoch,
+                                                             int* __restrict__ ticket, int* __restrict__ status,
+                                                             int spin_limit) {
+  constexpr int RPW = 64 / G;                 // rows per wavefront pass
+  constexpr int SC = TRSV_SC_PASSES * TRSV_SS_WAVES * RPW;  // rows per ticket: the workgroup's wavefronts x passes
+  __shared__ int s_ticket;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, gl = lane % G, grp = lane / G;
+  const int total = chunk_ptr[nlev];
+  while (true) {
+    // one ticket per workgroup and 32 * RPW rows: a single counter hands out ~90 tickets per microsecond
+    // (MI355X_MICROARCH.md, dequeue), 4 M rows in tickets of 8 would queue for milliseconds
+    __syncthreads();
+    if (threadIdx.x == 0)
+      s_ticket = atomicAdd(ticket, 1);
+    __syncthreads();
+    const int t = s_ticket;
+    if (t >= total)
+      return;
+    int lo = 0, hi = nlev;  // level of chunk t: last i with chunk_ptr[i] <= t
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (chunk_ptr[mid] <= t)
+        lo = mid;
+      else
+        hi = mid;
+    }
+    const int f0 = level_ptr[l0 + lo], f1 = level_ptr[l0 + lo + 1];
+    const int base = f0 + (t - chunk_ptr[lo]) * SC;
+   for (int pass = 0; pass < TRSV_SC_PASSES; ++pass) {
+    const int idx = base + (pass * TRSV_SS_WAVES + wave) * RPW + grp;
+    if (base + pass * TRSV_SS_WAVES * RPW >= f1)
+      break;
+    const bool live = idx < f1;
+    const int r = live ? order[idx] : 0;
+    T dot = T(0);
+    int dpos = -1;
+    const int p0 = live ? rowptr[r] : 0, p1 = live ? rowptr[r + 1] : 0;
+    for (int p = p0 + gl; p < p1; p += G) {
+      const int c = colind[p];
+      const T v = values[p];
+      if (c >= 0 && c < m && trsv_strict(c, r, upper)) {
+        T xc;
+        int spins = 0;
+        while (!trsv_try_read<T>(gran, c, epoch, &xc)) {
+          __builtin_amdgcn_s_sleep(2);
+          if (++spins > spin_limit) {
+            status[0] = 1;
+            xc = T(0);
+            break;
+          }
+        }
+        dot += v * xc;
+      } else if (c == r) {
+        dpos = p;
+      }
+    }
+#pragma unroll
+    for (int o = G >> 1; o > 0; o >>= 1) {
+      dot += __shfl_xor(dot, o, SPB_WAVE);
+      const int other = __shfl_xor(dpos, o, SPB_WAVE);
+      dpos = other > dpos ? other : dpos;
+    }
+    if (live && gl == 0) {
+      T v = b[r] - alpha * dot;
+      if (!unit)
+        v = v / (alpha * (dpos >= 0 ? values[dpos] : T(0)));
+      x[r] = v;
+      trsv_publish<T>(gran, r, v, epoch);
+    }
+   }
   }
 }
 
@@ -243,11 +511,12 @@ __global__ __launch_bounds__(256) void trsv_level_kernel(int f0, int f1, const i
                                                          const int32_t* __restrict__ rowptr,
                                                          const int32_t* __restrict__ colind,
                                                          const T* __restrict__ values, T alpha,
-                                                         const T* __restrict__ b, T* x, int upper, int unit) {
+                                                         const T* __restrict__ b, T* x, int upper, int unit, int m,
+                                                         unsigned long long* __restrict__ gran, unsigned epoch) {
   const int idx = f0 + blockIdx.x * (256 / G) + threadIdx.x / G;
   if (idx >= f1)
     return;
-  trsv_row<T, G>(order[idx], threadIdx.x % G, rowptr, colind, values, alpha, b, x, upper, unit);
+  trsv_row<T, G>(order[idx], threadIdx.x % G, rowptr, colind, values, alpha, b, x, upper, unit, m, gran, epoch);
 }
 
 // levels [l0, l1), all narrow: one workgroup, a barrier between levels
@@ -259,42 +528,75 @@ __global__ __launch_bounds__(TRSV_BLOCK_THREADS) void trsv_chain_kernel(int l0, 
                                                                        const int32_t* __restrict__ colind,
                                                                        const T* __restrict__ values, T alpha,
                                                                        const T* __restrict__ b, T* x, int upper,
-                                                                       int unit) {
+                                                                       int unit, int m,
+                                                                       unsigned long long* __restrict__ gran,
+                                                                       unsigned epoch) {
   for (int l = l0; l < l1; ++l) {
     const int f0 = level_ptr[l], f1 = level_ptr[l + 1];
     for (int idx = f0 + threadIdx.x / G; idx < f1; idx += TRSV_BLOCK_THREADS / G)
-      trsv_row<T, G>(order[idx], threadIdx.x % G, rowptr, colind, values, alpha, b, x, upper, unit);
+      trsv_row<T, G>(order[idx], threadIdx.x % G, rowptr, colind, values, alpha, b, x, upper, unit, m, gran, epoch);
     __threadfence();  // x of this level must be visible to the whole workgroup before the next one
     __syncthreads();
   }
 }
 
 template <typename T, int G>
-static int trsv_solve_typed(hipStream_t s, const spblas_gfx950_trsv_s* pl, const int32_t* rowptr,
+static int trsv_solve_typed(spblas_gfx950_handle_t h, spblas_gfx950_trsv_s* pl, const int32_t* rowptr,
                             const int32_t* colind, const T* values, T alpha, const T* b, T* x) {
+  hipStream_t s = h->stream;
   const int upper = pl->uplo == SPBLAS_GFX950_UPPER, unit = pl->diag == SPBLAS_GFX950_DIAG_UNIT;
-  for (const auto& g : pl->groups) {
-    if (g.wide) {
+  const int m = (int) pl->m;
+  const size_t ng = pl->groups.size();
+  if (!pl->gran) {  // first solve: granules (tag 0 = never written) and the ticket counters
+    int rc = dev_alloc((void**) &pl->gran, (size_t) pl->m * 16, s);
+    if (rc)
+      return rc;
+    if ((rc = dev_alloc((void**) &pl->tickets, (ng + 2) * 4, s)))
+      return rc;
+    SPB_HIP(hipMemsetAsync(pl->gran, 0, (size_t) pl->m * 16, s));
+  }
+  if (++pl->epoch == 0) {  // the solve number wrapped: start over with clean tags
+    SPB_HIP(hipMemsetAsync(pl->gran, 0, (size_t) pl->m * 16, s));
+    pl->epoch = 1;
+  }
+  SPB_HIP(hipMemsetAsync(pl->tickets, 0, (ng + 2) * 4, s));
+  int* status = pl->tickets + ng + 1;
+  const int cus = h->num_cus > 0 ? h->num_cus : 256;
+  const int spin_limit = env_int("SPBLAS_GFX950_TRSV_SPIN_LIMIT", 1 << 22);  // ~ a second of polling
+  bool used_selfsched = false;
+  for (size_t gi = 0; gi < ng; ++gi) {
+    const auto& g = pl->groups[gi];
+    if (g.wide && pl->group_cp0[gi] >= 0) {
+      const int chunks = pl->group_chunks[gi];
+      // 2 workgroups of 16 wavefronts per CU at most; fewer when the run is short
+      const int grid = (int) std::min<int64_t>((int64_t) cus * 2, chunks);
+      hipLaunchKernelGGL((trsv_selfsched_kernel<T, G>), dim3((unsigned) (grid > 0 ? grid : 1)), dim3(TRSV_SS_WAVES * 64), 0, s, g.l0,
+                         g.l1 - g.l0, pl->chunk_ptr + pl->group_cp0[gi], pl->level_ptr, pl->order, rowptr, colind, values,
+                         alpha, b, x, upper, unit, m, pl->gran, pl->epoch, pl->tickets + gi, status, spin_limit);
+      used_selfsched = true;
+    } else if (g.wide) {
       const int f0 = pl->h_level_ptr[g.l0], f1 = pl->h_level_ptr[g.l0 + 1];
       hipLaunchKernelGGL((trsv_level_kernel<T, G>), dim3((unsigned) cdiv(f1 - f0, 256 / G)), dim3(256), 0, s, f0, f1,
-                         pl->order, rowptr, colind, values, alpha, b, x, upper, unit);
+                         pl->order, rowptr, colind, values, alpha, b, x, upper, unit, m, pl->gran, pl->epoch);
     } else {
       hipLaunchKernelGGL((trsv_chain_kernel<T, G>), dim3(1), dim3(TRSV_BLOCK_THREADS), 0, s, g.l0, g.l1,
-                         pl->level_ptr, pl->order, rowptr, colind, values, alpha, b, x, upper, unit);
+                         pl->level_ptr, pl->order, rowptr, colind, values, alpha, b, x, upper, unit, m, pl->gran,
+                         pl->epoch);
     }
   }
+  (void) used_selfsched;
   SPB_HIP(hipGetLastError());
   return SPBLAS_GFX950_STATUS_SUCCESS;
 }
 
 template <typename T>
-static int trsv_solve_lanes(hipStream_t s, const spblas_gfx950_trsv_s* pl, const int32_t* rowptr,
+static int trsv_solve_lanes(spblas_gfx950_handle_t h, spblas_gfx950_trsv_s* pl, const int32_t* rowptr,
                             const int32_t* colind, const T* values, T alpha, const T* b, T* x) {
   switch (pl->lanes) {
-    case 4: return trsv_solve_typed<T, 4>(s, pl, rowptr, colind, values, alpha, b, x);
-    case 16: return trsv_solve_typed<T, 16>(s, pl, rowptr, colind, values, alpha, b, x);
-    case 64: return trsv_solve_typed<T, 64>(s, pl, rowptr, colind, values, alpha, b, x);
-    default: return trsv_solve_typed<T, 8>(s, pl, rowptr, colind, values, alpha, b, x);
+    case 4: return trsv_solve_typed<T, 4>(h, pl, rowptr, colind, values, alpha, b, x);
+    case 16: return trsv_solve_typed<T, 16>(h, pl, rowptr, colind, values, alpha, b, x);
+    case 64: return trsv_solve_typed<T, 64>(h, pl, rowptr, colind, values, alpha, b, x);
+    default: return trsv_solve_typed<T, 8>(h, pl, rowptr, colind, values, alpha, b, x);
   }
 }
 
@@ -344,6 +646,8 @@ int spblas_gfx950_sptrsv_create(spblas_gfx950_handle_t handle, spblas_gfx950_trs
     dev_free(partials, s);
     dev_free(level_ptr, s);
     dev_free(pl->order, s);
+    dev_free(pl->level_ptr, s);
+    dev_free(pl->chunk_ptr, s);
     delete pl;
     *plan_out = nullptr;
     return code;
@@ -356,7 +660,50 @@ int spblas_gfx950_sptrsv_create(spblas_gfx950_handle_t handle, spblas_gfx950_trs
       (rc = dev_alloc((void**) &level_ptr, (size_t) (m + 1) * 4, s)) ||
       (rc = dev_alloc((void**) &pl->order, (size_t) m * 4, s)))
     return fail(rc);
-  hipError_t e = hipMemsetAsync(adj_ptr, 0, (size_t) (m + 1) * 4, s);
+  std::vector<int32_t>& lp = pl->h_level_ptr;
+  int32_t n_levels = 0;
+  hipError_t e = hipSuccess;
+  bool have_levels = false;
+  if (env_int("SPBLAS_GFX950_TRSV_KAHN", 0) == 0) {
+    // default: levels by dependency polling.  indeg doubles as lev[], adj_ptr as hist[], cursor as the placement
+    // cursors, state = {ticket, -, -, -, deepest level, gave-up flag}
+    e = hipMemsetAsync(indeg, 0, (size_t) m * 4, s);
+    if (e == hipSuccess)
+      e = hipMemsetAsync(adj_ptr, 0, (size_t) (m + 1) * 4, s);
+    if (e == hipSuccess)
+      e = hipMemsetAsync(cursor, 0, (size_t) m * 4, s);
+    if (e == hipSuccess)
+      e = hipMemsetAsync(state, 0, 32, s);
+    if (e != hipSuccess)
+      return fail(hip_fail(e));
+    const int cus = handle->num_cus > 0 ? handle->num_cus : 256;
+    const int grid = (int) std::min<int64_t>((int64_t) cus * 8, cdiv(m, 256));
+    hipLaunchKernelGGL(trsv_levels_poll_kernel, dim3((unsigned) grid), dim3(256), 0, s, m, rowptr, colind, upper, indeg,
+                       state, state + 4, env_int("SPBLAS_GFX950_TRSV_SPIN_LIMIT", 1 << 22));
+    hipLaunchKernelGGL(trsv_level_hist_kernel, dim3((unsigned) std::min<int64_t>(1024, cdiv(m, 256))), dim3(256), 0, s, m,
+                       indeg, adj_ptr);
+    int32_t st2[2] = {0, 0};
+    if ((e = hipMemcpyAsync(st2, state + 4, 8, hipMemcpyDeviceToHost, s)) != hipSuccess ||
+        (e = hipStreamSynchronize(s)) != hipSuccess)
+      return fail(hip_fail(e));
+    if (st2[1] == 0) {
+      n_levels = st2[0] + 1;
+      // hist -> level_ptr (exclusive scan over the levels), then the rows are placed level by level
+      scan_counts_i32(s, n_levels, adj_ptr, partials);
+      hipLaunchKernelGGL(trsv_place_rows_kernel, dim3((unsigned) std::min<int64_t>(1024, cdiv(m, 256))), dim3(256), 0, s, m,
+                         indeg, adj_ptr, cursor, pl->order);
+      lp.resize((size_t) n_levels + 1);
+      if ((e = hipMemcpyAsync(lp.data(), adj_ptr, (size_t) (n_levels + 1) * 4, hipMemcpyDeviceToHost, s)) != hipSuccess ||
+          (e = hipMemcpyAsync(level_ptr, adj_ptr, (size_t) (n_levels + 1) * 4, hipMemcpyDeviceToDevice, s)) != hipSuccess ||
+          (e = hipStreamSynchronize(s)) != hipSuccess)
+        return fail(hip_fail(e));
+      if (lp[(size_t) n_levels] != (int32_t) m)
+        return fail(SPBLAS_GFX950_STATUS_INVALID_VALUE);
+      have_levels = true;
+    }
+  }
+  if (!have_levels) {
+  e = hipMemsetAsync(adj_ptr, 0, (size_t) (m + 1) * 4, s);
   if (e == hipSuccess)
     e = hipMemsetAsync(cursor, 0, (size_t) m * 4, s);
   if (e == hipSuccess)
@@ -380,7 +727,6 @@ int spblas_gfx950_sptrsv_create(spblas_gfx950_handle_t handle, spblas_gfx950_trs
   st[1] = 0;
   st[2] = st[0];
   st[3] = 0;
-  std::vector<int32_t>& lp = pl->h_level_ptr;
   // Wide levels are enqueued in batches (the kernels find the frontier in `state` themselves), narrow ones go
   // to the single-workgroup kernel; the host looks at the state once per batch instead of once per level
   // (246 levels at 4 M rows: 104 synchronisations before, 18.8 ms of inspect).
@@ -401,7 +747,7 @@ int spblas_gfx950_sptrsv_create(spblas_gfx950_handle_t handle, spblas_gfx950_trs
         (e = hipStreamSynchronize(s)) != hipSuccess)
       return fail(hip_fail(e));
   }
-  const int32_t n_levels = st[3];
+  n_levels = st[3];
   if (st[0] != (int32_t) m)  // cannot happen for a strict triangle; guards against corrupt input
     return fail(SPBLAS_GFX950_STATUS_INVALID_VALUE);
   lp.resize((size_t) n_levels + 1);
@@ -413,27 +759,51 @@ int spblas_gfx950_sptrsv_create(spblas_gfx950_handle_t handle, spblas_gfx950_trs
   if ((e = hipMemcpyAsync(level_ptr, lp.data(), (size_t) (n_levels + 1) * 4, hipMemcpyHostToDevice, s)) != hipSuccess ||
       (e = hipStreamSynchronize(s)) != hipSuccess)
     return fail(hip_fail(e));
+  }  // Kahn fallback
   pl->level_ptr = level_ptr;
   level_ptr = nullptr;
-  // launch groups of the solve: a level of >= `narrow` rows gets its own chip-wide launch, runs of
-  // narrower levels share one single-workgroup launch
+  // launch groups of the solve: a run of consecutive levels of >= `narrow` rows is ONE self-scheduling launch,
+  // a run of narrower levels ONE single-workgroup launch (SPBLAS_GFX950_TRSV_SELFSCHED=0: one launch per wide level)
   const int narrow = env_int("SPBLAS_GFX950_TRSV_NARROW", 128);
+  // measured at 4 M rows / 246 levels: 2.59 ms self-scheduling (5 launches) vs 2.00 ms with one launch per wide level
+  // (161 launches) -- a producer -> consumer hand-off through L2 / fabric costs ~3 us under load and a 512-workgroup
+  // grid keeps fewer rows in flight than a launch per level does, so the launch-per-level solve stays the default
+  const bool selfsched = env_int("SPBLAS_GFX950_TRSV_SELFSCHED", 0) != 0;
+  const int rpw = TRSV_SC_PASSES * TRSV_SS_WAVES * (64 / pl->lanes);  // rows per ticket of the self-scheduling kernel
+  std::vector<int32_t> h_chunk_ptr;
   for (int32_t l = 0; l < n_levels;) {
-    const int64_t w = lp[l + 1] - lp[l];
-    pl->max_width = w > pl->max_width ? w : pl->max_width;
-    if (w >= narrow) {
-      pl->groups.push_back({l, l + 1, 1});
-      ++l;
+    const bool wide = lp[l + 1] - lp[l] >= narrow;
+    int32_t e1 = l + 1;
+    if (wide && !selfsched) {
+      pl->max_width = std::max<int64_t>(pl->max_width, lp[l + 1] - lp[l]);
     } else {
-      int32_t e1 = l + 1;
-      while (e1 < n_levels && lp[e1 + 1] - lp[e1] < narrow) {
-        const int64_t w2 = lp[e1 + 1] - lp[e1];
-        pl->max_width = w2 > pl->max_width ? w2 : pl->max_width;
+      while (e1 < n_levels && ((lp[e1 + 1] - lp[e1] >= narrow) == wide))
         ++e1;
-      }
-      pl->groups.push_back({l, e1, 0});
-      l = e1;
+      for (int32_t q = l; q < e1; ++q)
+        pl->max_width = std::max<int64_t>(pl->max_width, lp[q + 1] - lp[q]);
     }
+    pl->groups.push_back({l, e1, wide ? 1 : 0});
+    if (wide && selfsched) {
+      pl->group_cp0.push_back((int32_t) h_chunk_ptr.size());
+      int32_t acc = 0;
+      for (int32_t q = l; q < e1; ++q) {
+        h_chunk_ptr.push_back(acc);
+        acc += (int32_t) cdiv(lp[q + 1] - lp[q], rpw);
+      }
+      h_chunk_ptr.push_back(acc);
+      pl->group_chunks.push_back(acc);
+    } else {
+      pl->group_cp0.push_back(-1);
+      pl->group_chunks.push_back(0);
+    }
+    l = e1;
+  }
+  if (!h_chunk_ptr.empty()) {
+    if ((rc = dev_alloc((void**) &pl->chunk_ptr, h_chunk_ptr.size() * 4, s)))
+      return fail(rc);
+    if ((e = hipMemcpyAsync(pl->chunk_ptr, h_chunk_ptr.data(), h_chunk_ptr.size() * 4, hipMemcpyHostToDevice, s)) != hipSuccess ||
+        (e = hipStreamSynchronize(s)) != hipSuccess)
+      return fail(hip_fail(e));
   }
   dev_free(indeg, s);
   dev_free(adj_ptr, s);
@@ -451,6 +821,9 @@ int spblas_gfx950_sptrsv_destroy(spblas_gfx950_handle_t handle, spblas_gfx950_tr
     return SPBLAS_GFX950_STATUS_SUCCESS;
   dev_free(plan->order, handle->stream);
   dev_free(plan->level_ptr, handle->stream);
+  dev_free(plan->chunk_ptr, handle->stream);
+  dev_free(plan->tickets, handle->stream);
+  dev_free(plan->gran, handle->stream);
   delete plan;
   return SPBLAS_GFX950_STATUS_SUCCESS;
 }
@@ -479,10 +852,10 @@ int spblas_gfx950_sptrsv_solve(spblas_gfx950_handle_t handle, spblas_gfx950_trsv
   if (m == 0)
     return SPBLAS_GFX950_STATUS_SUCCESS;
   if (value_type == SPBLAS_GFX950_F32)
-    return trsv_solve_lanes<float>(handle->stream, plan, rowptr, colind, static_cast<const float*>(values),
+    return trsv_solve_lanes<float>(handle, plan, rowptr, colind, static_cast<const float*>(values),
                                    *static_cast<const float*>(alpha), static_cast<const float*>(b),
                                    static_cast<float*>(x));
-  return trsv_solve_lanes<double>(handle->stream, plan, rowptr, colind, static_cast<const double*>(values),
+  return trsv_solve_lanes<double>(handle, plan, rowptr, colind, static_cast<const double*>(values),
                                   *static_cast<const double*>(alpha), static_cast<const double*>(b),
                                   static_cast<double*>(x));
 }

@@ -215,3 +215,27 @@ def test_trsv_golden_bit_exact(gpu, upper, unit):
     sp.triangular_solve(d_a, uplo, diag, d_b, d_x)
     key = f"x_{'upper' if upper else 'lower'}_{'unit' if unit else 'explicit'}"
     assert np.array_equal(G.host(d_x), g[key])
+
+
+@pytest.mark.parametrize("mode", ["kahn_inspect", "selfsched_solve"])
+@pytest.mark.parametrize("upper", [False, True])
+def test_alternative_inspect_and_solve_paths(gpu, monkeypatch, mode, upper):
+    """The default is: levels by dependency polling (one self-scheduling kernel), solve with one launch per wide
+    level.  The other two paths stay in the library -- Kahn's algorithm as the fallback of the polling inspect, the
+    self-scheduling solve (granule hand-offs inside one launch) as an option -- and must give the same answers:
+    a random triangular system with a few hundred wide levels, fp32 and fp64."""
+    monkeypatch.setenv("SPBLAS_GFX950_TRSV_KAHN" if mode == "kahn_inspect" else "SPBLAS_GFX950_TRSV_SELFSCHED", "1")
+    rng = np.random.default_rng(8)
+    n, k = 60000, 6
+    rows = np.repeat(np.arange(n), k)
+    cols = (rng.random(n * k) * rows).astype(np.int64)
+    keep = cols < rows
+    S = sps.csr_matrix(((rng.random(keep.sum()) - 0.5) * (0.5 / k), (rows[keep], cols[keep])), shape=(n, n))
+    M = (S + sps.diags(1.0 + rng.random(n))).tocsr()
+    if upper:
+        M = M.T.tocsr()
+    for dtype in (np.float32, np.float64):
+        x, info = check(M, rng.random(n) + 0.5, upper, False, dtype)
+        assert info["levels"] > 20 and info["max_level_width"] > 128
+        if mode == "selfsched_solve":
+            assert info["launches_per_solve"] < info["levels"] / 4
