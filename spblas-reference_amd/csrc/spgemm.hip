@@ -30,6 +30,7 @@
 #include "common.hpp"
 #include "scan.hpp"
 
+#include <cstdlib>
 #include <new>
 
 #define SPG_NBINS 6
@@ -50,6 +51,15 @@ struct spblas_gfx950_spgemm_s {
   uint32_t* dense_bits = nullptr;  // [dense_blocks * ceil(n/32)]
   void* dense_vals = nullptr;      // [dense_blocks * n] T
   int dense_vals_type = -1;
+  // numeric reuse (multiply_numeric after the first fill; vendor/rocsparse/multiply_spgemm.hpp:178-214): the first
+  // numeric pass of a symbolic result records, for every product of the rows in the LDS-hash bins 1-2, the rank of
+  // its column in the (sorted) output row; later passes accumulate by rank -- no hash, no compaction, no sort
+  int32_t* r_pbase = nullptr;   // [m + 1] first product of every row in the enumeration order
+  uint16_t* r_rank = nullptr;   // [products] rank of the product's column in its output row
+  int32_t* r_cols = nullptr;    // [nnz(C)] the sorted column indices (the caller may pass other arrays later)
+  const int32_t* r_last_colind = nullptr;  // the caller's column array the last numeric pass filled
+  bool r_ready = false;
+  int numeric_calls = 0;        // numeric passes since the symbolic one (the SECOND records: a one-shot fill pays nothing)
 };
 
 namespace spb {
@@ -475,6 +485,118 @@ __global__ __launch_bounds__(256) void spg_dense_kernel(
   }
 }
 
+// products per row (0 for rows outside the LDS-hash bins 1-2: they keep the hash path), scanned into r_pbase
+__global__ __launch_bounds__(256) void spg_products_kernel(int64_t m, const int32_t* __restrict__ a_rowptr,
+                                                           const int32_t* __restrict__ a_colind,
+                                                           const int32_t* __restrict__ b_rowptr,
+                                                           int32_t* __restrict__ prod) {
+  const int64_t row = (int64_t) blockIdx.x * 32 + threadIdx.x / 8;
+  const int lane = threadIdx.x % 8;
+  int64_t ub = 0;
+  if (row < m)
+    for (int p = a_rowptr[row] + lane; p < a_rowptr[row + 1]; p += 8) {
+      const int kk = a_colind[p];
+      ub += b_rowptr[kk + 1] - b_rowptr[kk];
+    }
+  ub = group_sum_c<8>(ub);
+  if (row < m && lane == 0)
+    prod[row] = ub <= 256 ? (int32_t) ub : 0;
+}
+
+// MODE 0: record the rank of every product's column in its output row (binary search in the row's sorted columns,
+// held in LDS).  MODE 1: numeric pass by rank: vals[rank] += a * b in LDS, then one coalesced write of the row's
+// values and columns.  Both walk the products of a row in the same order: A entries in storage order, the entries
+// of each B row in storage order; product index = r_pbase[row] + (entries of the earlier B rows) + offset.
+// Teams of TPR <= 64 lanes inside one wavefront (bins 1-2), SUB lanes per B row, as in spg_hash_kernel.
+template <typename T, int TPR, int CAP, int MODE>
+__global__ __launch_bounds__(256) void spg_ranked_kernel(
+    int64_t count, const int32_t* __restrict__ perm, const int32_t* __restrict__ a_rowptr,
+    const int32_t* __restrict__ a_colind, const T* __restrict__ a_values, const int32_t* __restrict__ b_rowptr,
+    const int32_t* __restrict__ b_colind, const T* __restrict__ b_values, const int32_t* __restrict__ c_rowptr,
+    const int32_t* __restrict__ cols_sorted, int32_t* __restrict__ c_colind, T* __restrict__ c_values, T alpha,
+    int sub, const int32_t* __restrict__ pbase, uint16_t* __restrict__ prank, int copy_cols) {
+  constexpr int RPB = 256 / TPR;
+  __shared__ int s_keys[MODE == 0 ? RPB * CAP : 1];
+  __shared__ T s_vals[MODE == 1 ? RPB * CAP : 1];
+  const int team = threadIdx.x / TPR, lt = threadIdx.x % TPR;
+  const int64_t idx = (int64_t) blockIdx.x * RPB + team;
+  const bool live = idx < count;
+  const int row = live ? perm[idx] : 0;
+  const int out0 = live ? c_rowptr[row] : 0;
+  const int d = live ? c_rowptr[row + 1] - out0 : 0;
+  int* tkeys = s_keys + (MODE == 0 ? team * CAP : 0);
+  T* tvals = s_vals + (MODE == 1 ? team * CAP : 0);
+  for (int i = lt; i < d; i += TPR) {
+    if (MODE == 0)
+      tkeys[i] = cols_sorted[out0 + i];
+    else
+      tvals[i] = T(0);
+  }
+  spg_team_sync<TPR>();
+  if (live) {
+    const int p0 = a_rowptr[row], p1 = a_rowptr[row + 1];
+    const int sg = lt / sub, sl = lt % sub, nsg = TPR / sub;
+    const int tbase = (threadIdx.x & 63) - lt;  // first lane of the team in its wave
+    int running = pbase[row];
+    for (int pc = p0; pc < p1; pc += TPR) {
+      int qb = 0, len = 0;
+      T av = T(0);
+      if (pc + lt < p1) {
+        const int kk = a_colind[pc + lt];
+        qb = b_rowptr[kk];
+        len = b_rowptr[kk + 1] - qb;
+        if (MODE == 1)
+          av = alpha * a_values[pc + lt];
+      }
+      // exclusive scan of the B-row lengths over the team's lanes (team-uniform trip count)
+      int incl = len;
+      for (int o = 1; o < TPR; o <<= 1) {
+        const int t = __shfl_up(incl, o, TPR);
+        if (lt >= o)
+          incl += t;
+      }
+      const int excl = incl - len;
+      const int total = __shfl(incl, tbase + TPR - 1);
+      const int cnt = (p1 - pc) < TPR ? (p1 - pc) : TPR;
+      for (int j0 = 0; j0 < cnt; j0 += nsg) {
+        const int j = j0 + sg;
+        const int src = tbase + (j < cnt ? j : 0);
+        const int q0 = __shfl(qb, src);
+        const int ln = __shfl(len, src);
+        const int off = __shfl(excl, src);
+        const T a = MODE == 1 ? __shfl(av, src) : T(0);
+        if (j < cnt)
+          for (int q = sl; q < ln; q += sub) {
+            const int pidx = running + off + q;
+            if (MODE == 0) {
+              const int col = b_colind[q0 + q];
+              int lo = 0, hi = d;  // first position with tkeys[pos] >= col (the column is present by construction)
+              while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (tkeys[mid] <= col)
+                  lo = mid;
+                else
+                  hi = mid;
+              }
+              prank[pidx] = (uint16_t) lo;
+            } else {
+              spg_lds_add(&tvals[prank[pidx]], a * b_values[q0 + q]);
+            }
+          }
+      }
+      running += total;
+    }
+  }
+  if (MODE == 1) {
+    spg_team_sync<TPR>();
+    for (int i = lt; i < d; i += TPR) {
+      c_values[out0 + i] = tvals[i];
+      if (copy_cols)
+        c_colind[out0 + i] = cols_sorted[out0 + i];
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void spg_zero_rows_kernel(int64_t count, const int32_t* __restrict__ perm,
                                                             int32_t* __restrict__ c_rowptr) {
   const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
@@ -519,13 +641,16 @@ static int launch_hash(hipStream_t s, const spblas_gfx950_spgemm_s* st, int bin,
 template <typename T, bool NUMERIC>
 static int run_bins(spblas_gfx950_handle_t h, spblas_gfx950_spgemm_s* st, const T* a_values, const T* b_values,
                     int32_t* c_rowptr, int32_t* c_colind, T* c_values, T alpha, const T* d_values = nullptr,
-                    T beta = T(0)) {
+                    T beta = T(0), bool skip_small_bins = false) {
   hipStream_t s = h->stream;
   int rc;
-  if ((rc = launch_hash<T, 7, 16, NUMERIC>(s, st, 1, a_values, b_values, c_rowptr, c_colind, c_values, alpha,
+  // skip_small_bins: bins 1-2 were done by the rank-based reuse pass
+  if (!skip_small_bins &&
+      (rc = launch_hash<T, 7, 16, NUMERIC>(s, st, 1, a_values, b_values, c_rowptr, c_colind, c_values, alpha,
                                            d_values, beta)))
     return rc;
-  if ((rc = launch_hash<T, 9, 64, NUMERIC>(s, st, 2, a_values, b_values, c_rowptr, c_colind, c_values, alpha,
+  if (!skip_small_bins &&
+      (rc = launch_hash<T, 9, 64, NUMERIC>(s, st, 2, a_values, b_values, c_rowptr, c_colind, c_values, alpha,
                                            d_values, beta)))
     return rc;
   if ((rc = launch_hash<T, 11, 128, NUMERIC>(s, st, 3, a_values, b_values, c_rowptr, c_colind, c_values, alpha,
@@ -560,11 +685,94 @@ static int run_bins(spblas_gfx950_handle_t h, spblas_gfx950_spgemm_s* st, const 
   return SPBLAS_GFX950_STATUS_SUCCESS;
 }
 
+template <typename T, int MODE>
+static void launch_ranked(hipStream_t s, const spblas_gfx950_spgemm_s* st, const T* a_values, const T* b_values,
+                          int32_t* c_colind, T* c_values, T alpha, int copy_cols) {
+  const int64_t c1 = st->bin_off[2] - st->bin_off[1], c2 = st->bin_off[3] - st->bin_off[2];
+  const int sub1 = st->sub < 16 ? st->sub : 16, sub2 = st->sub < 64 ? st->sub : 64;
+  if (c1 > 0)
+    hipLaunchKernelGGL((spg_ranked_kernel<T, 16, 64, MODE>), dim3((unsigned) cdiv(c1, 16)), dim3(256), 0, s, c1,
+                       st->perm + st->bin_off[1], st->a_rowptr, st->a_colind, a_values, st->b_rowptr, st->b_colind, b_values,
+                       st->rowptr, st->r_cols, c_colind, c_values, alpha, sub1, st->r_pbase, st->r_rank, copy_cols);
+  if (c2 > 0)
+    hipLaunchKernelGGL((spg_ranked_kernel<T, 64, 256, MODE>), dim3((unsigned) cdiv(c2, 4)), dim3(256), 0, s, c2,
+                       st->perm + st->bin_off[2], st->a_rowptr, st->a_colind, a_values, st->b_rowptr, st->b_colind, b_values,
+                       st->rowptr, st->r_cols, c_colind, c_values, alpha, sub2, st->r_pbase, st->r_rank, copy_cols);
+}
+
+// numeric pass.  Plain three-argument products (no addend, real B) whose rows sit in the LDS-hash bins 1-2 are
+// eligible for reuse: the SECOND pass on a symbolic result runs the hash kernels and then records the rank of every
+// product (SPBLAS_GFX950_SPGEMM_REUSE=0 turns the recording off, =2 records in the first pass already); every later
+// pass accumulates by rank.  Rows in the other bins always take the hash / dense kernels.
+template <typename T>
+static int spgemm_numeric_typed(spblas_gfx950_handle_t h, spblas_gfx950_spgemm_s* st, const T* a_values,
+                                const T* b_values, int32_t* c_colind, T* c_values, T alpha, const T* d_values, T beta) {
+  hipStream_t s = h->stream;
+  if (st->r_ready) {
+    // the column indices of an array this state filled before are still in place (the reference's reuse contract:
+    // multiply_numeric recomputes values, multiply_spgemm.hpp:195-213); another array gets them copied
+    launch_ranked<T, 1>(s, st, a_values, b_values, c_colind, c_values, alpha, c_colind != st->r_last_colind);
+    SPB_HIP(hipGetLastError());
+    st->r_last_colind = c_colind;
+    return run_bins<T, true>(h, st, a_values, b_values, st->rowptr, c_colind, c_values, alpha, d_values, beta, true);
+  }
+  int rc = run_bins<T, true>(h, st, a_values, b_values, st->rowptr, c_colind, c_values, alpha, d_values, beta);
+  if (rc)
+    return rc;
+  // the first fill of a symbolic result stays a plain hash pass; a second one shows that the structure is being
+  // reused and records the ranks (hash pass + 1.3 ms once at cfg5), the third and later ones take the rank path
+  const char* env = std::getenv("SPBLAS_GFX950_SPGEMM_REUSE");
+  const bool want = !(env && env[0] == '0') && ++st->numeric_calls >= (env && env[0] == '2' ? 1 : 2);
+  const int64_t small_rows = st->bin_off[3] - st->bin_off[1];
+  if (!want || st->has_addend || st->identity_b || small_rows == 0 || st->m == 0)
+    return SPBLAS_GFX950_STATUS_SUCCESS;
+  // record: products per row -> r_pbase, a copy of the sorted columns, then the ranks
+  const int64_t m = st->m, nb = cdiv(m, 2048);
+  long long* partials = nullptr;
+  if ((rc = dev_alloc((void**) &st->r_pbase, (size_t) (m + 1) * 4, s)) ||
+      (rc = dev_alloc((void**) &partials, (size_t) (nb + 2) * sizeof(long long), s)))
+    return SPBLAS_GFX950_STATUS_SUCCESS;  // out of memory for the optional fast path: keep the hash path
+  hipLaunchKernelGGL(spg_products_kernel, dim3((unsigned) cdiv(m, 32)), dim3(256), 0, s, m, st->a_rowptr, st->a_colind,
+                     st->b_rowptr, st->r_pbase);
+  long long* total_dev = scan_counts_i32(s, m, st->r_pbase, partials);
+  long long total = 0;
+  hipError_t e = hipMemcpyAsync(&total, total_dev, sizeof(total), hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess)
+    e = hipStreamSynchronize(s);
+  dev_free(partials, s);
+  if (e != hipSuccess)
+    return hip_fail(e);
+  if (total <= 0 || total > INT32_MAX ||
+      dev_alloc((void**) &st->r_rank, (size_t) total * 2, s) != SPBLAS_GFX950_STATUS_SUCCESS ||
+      dev_alloc((void**) &st->r_cols, (size_t) st->c_nnz * 4, s) != SPBLAS_GFX950_STATUS_SUCCESS) {
+    dev_free(st->r_pbase, s);
+    dev_free(st->r_rank, s);
+    st->r_pbase = nullptr;
+    st->r_rank = nullptr;
+    return SPBLAS_GFX950_STATUS_SUCCESS;
+  }
+  SPB_HIP(hipMemcpyAsync(st->r_cols, c_colind, (size_t) st->c_nnz * 4, hipMemcpyDeviceToDevice, s));
+  launch_ranked<T, 0>(s, st, a_values, b_values, c_colind, c_values, alpha, 0);
+  SPB_HIP(hipGetLastError());
+  st->r_last_colind = c_colind;
+  st->r_ready = true;
+  return SPBLAS_GFX950_STATUS_SUCCESS;
+}
+
 static void spgemm_release(spblas_gfx950_spgemm_s* st, hipStream_t s) {
   dev_free(st->rowptr, s);
   dev_free(st->perm, s);
   dev_free(st->dense_bits, s);
   dev_free(st->dense_vals, s);
+  dev_free(st->r_pbase, s);
+  dev_free(st->r_rank, s);
+  dev_free(st->r_cols, s);
+  st->r_pbase = nullptr;
+  st->r_rank = nullptr;
+  st->r_cols = nullptr;
+  st->r_last_colind = nullptr;
+  st->r_ready = false;
+  st->numeric_calls = 0;
   st->rowptr = nullptr;
   st->perm = nullptr;
   st->dense_bits = nullptr;
@@ -759,14 +967,14 @@ static int spgemm_numeric_impl(spblas_gfx950_handle_t handle, spblas_gfx950_spge
   if (st->c_nnz == 0)
     return SPBLAS_GFX950_STATUS_SUCCESS;
   if (value_type == SPBLAS_GFX950_F32)
-    return run_bins<float, true>(handle, st, static_cast<const float*>(a_values),
-                                 static_cast<const float*>(b_values), st->rowptr, c_colind,
-                                 static_cast<float*>(c_values), *static_cast<const float*>(alpha),
-                                 static_cast<const float*>(d_values), beta ? *static_cast<const float*>(beta) : 0.f);
-  return run_bins<double, true>(handle, st, static_cast<const double*>(a_values),
-                                static_cast<const double*>(b_values), st->rowptr, c_colind,
-                                static_cast<double*>(c_values), *static_cast<const double*>(alpha),
-                                static_cast<const double*>(d_values), beta ? *static_cast<const double*>(beta) : 0.0);
+    return spgemm_numeric_typed<float>(handle, st, static_cast<const float*>(a_values),
+                                       static_cast<const float*>(b_values), c_colind, static_cast<float*>(c_values),
+                                       *static_cast<const float*>(alpha), static_cast<const float*>(d_values),
+                                       beta ? *static_cast<const float*>(beta) : 0.f);
+  return spgemm_numeric_typed<double>(handle, st, static_cast<const double*>(a_values),
+                                      static_cast<const double*>(b_values), c_colind, static_cast<double*>(c_values),
+                                      *static_cast<const double*>(alpha), static_cast<const double*>(d_values),
+                                      beta ? *static_cast<const double*>(beta) : 0.0);
 }
 
 int spblas_gfx950_spgemm_numeric(spblas_gfx950_handle_t handle, spblas_gfx950_spgemm_t st, const void* alpha,

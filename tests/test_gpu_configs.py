@@ -244,3 +244,21 @@ def test_cfg5_spgemm_full_size(gpu):
     got_rp, got_c, got_v = _rows_subproblem(rows, d_rp, d_c.colind(), d_c.values())
     assert np.array_equal(got_rp, cr) and np.array_equal(got_c, cc)
     np.testing.assert_allclose(got_v, cv, rtol=2e-5)
+    # numeric reuse (multiply_numeric after the first fill, vendor/rocsparse/multiply_spgemm.hpp:178-214): the second
+    # pass accumulates by the product ranks recorded during the first one -- new values, fresh output arrays, same
+    # structure; indices identical, values = 6 x the first result (A scaled by 2, B by 3: exact in binary)
+    first_vals = d_c.values().clone()
+    first_cols = d_c.colind().clone()
+    av.mul_(2.0)
+    bv.mul_(3.0)
+    d_c.update(torch.full((cn,), float("nan"), device="cuda"), d_rp,
+               torch.full((cn,), -1, dtype=torch.int32, device="cuda"), (m, m), cn)
+    for attempt in range(3):  # 2nd pass: hash + recording; 3rd and 4th: by rank (4th into the array the 3rd filled)
+        if attempt < 2:
+            d_c.update(torch.full((cn,), float("nan"), device="cuda"), d_rp,
+                       torch.full((cn,), -1, dtype=torch.int32, device="cuda"), (m, m), cn)
+        else:
+            d_c.values().fill_(float("nan"))
+        sp.multiply_fill(info, d_a, d_b, d_c)
+        assert torch.equal(d_c.colind(), first_cols), attempt
+        assert bool(((d_c.values() - 6.0 * first_vals).abs() <= 1e-5 * (6.0 * first_vals).abs() + 1e-30).all()), attempt
