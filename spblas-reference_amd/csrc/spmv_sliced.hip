@@ -929,6 +929,22 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
   // workgroups (SPBLAS_GFX950_PB_XROUND is a test hook).
   const int xround = env_int("SPBLAS_GFX950_PB_XROUND", 1);
   pick_tiling(n, w_env > 0 && w_env < max_cols ? w_env : max_cols, xround, xround, 4, &S, &W);
+  // One slice per expand workgroup when that costs little: with 160 KiB slices the expand runs one workgroup per CU, and
+  // a slice count just below the CU count (cfg2: 245 of 256) makes every equal share straddle two slices -- two x-slice
+  // loads and two barriers per workgroup, 80 MB of x reads instead of 40.  Rounding the count up to the CU count
+  // narrows the slices by < 10 % and lets workgroup i take exactly slice i (SPBLAS_GFX950_PB_SLICE_ALIGN=0: off).
+  bool slice_aligned = false;
+  {
+    const int cus = h->num_cus > 0 ? h->num_cus : 256;
+    if (env_int("SPBLAS_GFX950_PB_SLICE_ALIGN", 1) && w_env <= 0 && xlds > PB_LDS_BYTES && S <= cus && S * 10 >= cus * 9) {
+      const int64_t w2 = cdiv(cdiv(n, cus), 4) * 4;
+      if (w2 <= max_cols && cdiv(n, w2) <= cus) {
+        W = (int) w2;
+        S = (int) cdiv(n, w2);
+        slice_aligned = true;
+      }
+    }
+  }
   // Bins: enough wavefronts to fill the chip (8 per CU = 2 048), but never so many that the average run drops
   // below ~4 blocks (half a block of padding per run), and never taller than the LDS budget allows.  Too few
   // bins for the chip are made up for by the slice-free K split of the reduce (every bin's stream cut in K parts).
@@ -1104,7 +1120,20 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
     // column skew: when one slice is far above the average the expand gets an explicit work list with
     // workgroups in proportion to the slice sizes (in blocks of A')
     const int64_t total = (int64_t) placed_total;
-    if (total > 0 && (int64_t) max_slice * S > 3 * total) {
+    const bool one_item_per_slice = slice_aligned && total > 0 && (double) max_slice * S <= 1.05 * (double) total;
+    if (one_item_per_slice) {
+      std::vector<int4> items;
+      for (int i = 0; i < S; ++i)
+        if (h_sliceblk[(size_t) i + 1] > h_sliceblk[(size_t) i])
+          items.push_back(make_int4(i, h_sliceblk[(size_t) i], h_sliceblk[(size_t) i + 1], 0));
+      if (!items.empty()) {
+        if ((rc = dev_alloc(&pl->s_xitems, items.size() * sizeof(int4), s)))
+          return rc;
+        SPB_HIP(hipMemcpyAsync(pl->s_xitems, items.data(), items.size() * sizeof(int4), hipMemcpyHostToDevice, s));
+        SPB_HIP(hipStreamSynchronize(s));
+        pl->n_xitems = (int64_t) items.size();
+      }
+    } else if (total > 0 && (int64_t) max_slice * S > 3 * total) {
       const int cus = h->num_cus > 0 ? h->num_cus : 256;
       const int64_t target = std::max<int64_t>(cdiv(a_blocks, 2 * cus), 4 * (int64_t) W / PB_BLK);
       std::vector<int4> items;
