@@ -10,17 +10,19 @@
 //
 // The reference walks the rows sequentially.  Here triangular_solve_inspect builds LEVEL SETS on the
 // device (rows of one level depend only on rows of earlier levels) and the solve runs level by level:
-//   inspect   in-degree of every row + adjacency "row k -> rows that read x_k" (strict triangle
-//             transposed, built with atomics: order is irrelevant), then Kahn's algorithm: the
-//             frontier of rows whose in-degree dropped to zero becomes the next level.
-//   solve     ONE launch per run of consecutive WIDE levels: a self-scheduling kernel whose wavefronts take
-//             chunks of rows in level order from a ticket counter and wait for the x entries they need on
-//             8-byte {value, solve number} granules published by the producing rows (one agent-scope store
-//             each; no kernel boundary, no grid barrier: a level costs one producer -> consumer hand-off,
-//             ~1 us, instead of a dependent launch of ~12 us -- 161 launches for 246 levels at 4 M rows before),
-//             and ONE single-workgroup launch per run of consecutive NARROW levels, which walks them with a
-//             workgroup barrier in between -- a chain-like matrix then costs a barrier per level
-//             instead of a hand-off per level.  Inspect splits its levels the same way.
+//   inspect   levels by dependency polling: one self-scheduling kernel hands rows out in index order, a row's level is
+//             1 + the deepest level among the rows it reads (polled until known; bounded spins), then a histogram
+//             of the levels and a placement pass sort the rows by level.  Fallback (a wave gave up polling, or
+//             SPBLAS_GFX950_TRSV_KAHN=1): in-degrees + transposed adjacency + Kahn's algorithm, frontier by frontier.
+//   solve     ONE cooperative launch (trsv_coop_kernel): a grid barrier per wide level, a workgroup barrier per level
+//             inside a run of NARROW levels (workgroup 0 alone), the loads that do not depend on x pipelined three
+//             levels ahead.  Where a cooperative launch is not possible (stream capture, device attribute missing,
+//             a narrow run longer than 4096 levels, SPBLAS_GFX950_TRSV_COOP=0): one launch per wide level and one
+//             single-workgroup launch per narrow run.  SPBLAS_GFX950_TRSV_SELFSCHED=1 selects a third form, one
+//             self-scheduling launch per run of wide levels with {value, solve number} granules as the hand-off.
+//             Measured at 4 M rows / 246 levels / 36 M entries: 1.70 ms cooperative, 1.86 ms launch per level,
+//             2.59 ms self-scheduling; the floor is the x gather (32 M agent-scope 64-byte fetches, ~0.5 ms) plus
+//             one store -> load hand-off per level.
 // Row sums are computed G lanes wide and tree-reduced, so they re-associate with respect to the
 // reference's sequential loop: parity is norm-wise, not bit-wise.
 #include "common.hpp"
@@ -54,6 +56,8 @@ struct spblas_gfx950_trsv_s {
   std::vector<group_t> groups;
   int64_t max_width = 0;
   int lanes = 8;  // lanes per row in the solve kernels
+  int narrow = 128;      // levels with fewer rows are "narrow": walked by one workgroup
+  bool coop_ok = false;  // the solve is ONE cooperative launch (trsv_coop_kernel)
   // self-scheduling solve of the wide runs: per wide group the cumulative chunk counts of its levels
   // (chunk_ptr[group.cp0 .. group.cp0 + levels]), one ticket counter per group, and the granules
   int32_t* chunk_ptr = nullptr;       // device
@@ -414,7 +418,8 @@ __device__ __forceinline__ void trsv_row(int r, int lane, const int32_t* __restr
     if (!unit)
       v = v / (alpha * (dpos >= 0 ? values[dpos] : T(0)));
     __hip_atomic_store(&x[r], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    trsv_publish<T>(gran, r, v, epoch);  // consumers inside a later self-scheduling launch poll the granule
+    if (gran)
+      trsv_publish<T>(gran, r, v, epoch);  // consumers inside a later self-scheduling launch poll the granule
   }
 }
 
@@ -505,6 +510,215 @@ __global__ __launch_bounds__(TRSV_SS_WAVES * 64) void trsv_selfsched_kernel(int 
   }
 }
 
+// ---- the whole solve in ONE cooperative launch ------------------------------------------------------------
+// Every level in one kernel, a grid barrier between levels (a workgroup barrier inside a run of NARROW levels,
+// which workgroup 0 walks alone while the others wait at the next grid barrier).  What a launch per level pays
+// per level -- drain, dispatch, then FOUR dependent loads (order -> rowptr -> colind/values -> x) -- becomes one
+// barrier and ONE load latency: the three loads that do not depend on x are software-pipelined across levels
+// (while the barrier after level l is pending a lane group loads colind/values for its rows of level l + 1, rowptr
+// for level l + 2 and order for level l + 3; after the barrier only the x gather is left).  A lane group owns R row
+// slots per level, so one pipelined pass covers gridDim * (1024 / G) * R rows; wider levels take further plain passes.
+// x crosses workgroups (and XCDs, whose L2s are not coherent) through agent-scope stores and loads only.
+// Launched with hipLaunchCooperativeKernel: all workgroups are resident, so the barrier cannot deadlock; the
+// spin is bounded all the same (status[0] = 1 and every workgroup leaves).
+// Measured, 4 M rows / 246 levels (158 grid barriers): barrier 2.3 us (two-level arrival; all-to-all flags 4.1 us,
+// acq_rel arrivals or a release fence per wavefront 10-60 us: every one is an L2 write-back), pipeline loads 1.9 us
+// per level when not overlapped with the barrier, x gather + store 2.2 us.
+#define TRSV_COOP_THREADS 1024
+
+// Grid barrier number n, first half.  x is written with agent-scope (write-through) stores: once a wavefront's
+// stores are acknowledged (vmcnt = 0) they are at the coherent level, and the consumers read x with agent-scope
+// loads, so the arrival itself needs no cache maintenance (relaxed).  Two-level arrival: 8 group counters
+// (workgroup w -> group w % 8, the XCD it runs on; bar[32 * (1 + g)]), the last of a group arrives at bar[0].
+__device__ __forceinline__ void trsv_barrier_arrive(unsigned* bar, unsigned n, int* s_flags) {
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned gid = blockIdx.x & 7u, ngroups = gridDim.x < 8u ? gridDim.x : 8u;
+    const unsigned gsize = (gridDim.x - gid + 7u) >> 3;
+    unsigned last = 0;
+    if (__hip_atomic_fetch_add(&bar[32 * (1 + gid)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 == n * gsize)
+      last = __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 == n * ngroups;
+    s_flags[1] = (int) last;
+  }
+}
+// Second half: the last workgroup to arrive releases the others through one flag LINE per workgroup
+// (bar[32 * (9 + w)]): 256 workgroups polling one address saturate its memory channel (measured 45 us per barrier).
+__device__ __forceinline__ bool trsv_barrier_wait(unsigned* bar, unsigned n, int spin_limit, int* status, int* s_flags) {
+  __syncthreads();
+  if (s_flags[1]) {
+    for (unsigned w = threadIdx.x; w < gridDim.x; w += blockDim.x)
+      __hip_atomic_store(&bar[32 * (9 + w)], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else if (threadIdx.x == 0) {
+    int spins = 0;
+    while (__hip_atomic_load(&bar[32 * (9 + blockIdx.x)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > spin_limit) {
+        status[0] = 1;
+        s_flags[0] = 1;
+        break;
+      }
+    }
+  }
+  __syncthreads();
+  return s_flags[0] == 0;
+}
+
+template <typename T, int G, int R>
+__global__ __launch_bounds__(TRSV_COOP_THREADS) void trsv_coop_kernel(int n_levels, int narrow,
+                                                                      const int32_t* __restrict__ level_ptr,
+                                                                      const int32_t* __restrict__ order,
+                                                                      const int32_t* __restrict__ rowptr,
+                                                                      const int32_t* __restrict__ colind,
+                                                                      const T* __restrict__ values, T alpha,
+                                                                      const T* __restrict__ b, T* x, int upper,
+                                                                      int unit, int m, unsigned* bar, int* status,
+                                                                      int spin_limit, int dbg) {
+  constexpr int RPB = TRSV_COOP_THREADS / G;  // rows per workgroup and slot
+  const int gl = threadIdx.x % G, grp = threadIdx.x / G;
+  __shared__ int s_flags[2];  // {abort, last arrival}
+  if (threadIdx.x == 0)
+    s_flags[0] = 0;
+  __syncthreads();
+  // first row position of this lane group in level L (>= the level's end: none), the level's end and slot stride
+  auto first_slot = [&](int L, int* f1, int* stride) -> int {
+    if (L < 0 || L >= n_levels) {
+      *f1 = 0;
+      *stride = 1;
+      return 0;
+    }
+    const int f0 = level_ptr[L];
+    *f1 = level_ptr[L + 1];
+    if (*f1 - f0 >= narrow) {
+      *stride = (int) gridDim.x * RPB;
+      return f0 + (int) blockIdx.x * RPB + grp;
+    }
+    *stride = RPB;
+    return blockIdx.x == 0 ? f0 + grp : *f1;
+  };
+  // pipeline registers per slot: A = row known, B = row + entry range, C = first two entries per lane loaded
+  int rA[R], rB[R], pB[R], qB[R], rC[R], pC[R], qC[R], c0[R], c1[R];
+  T v0[R], v1[R];
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    rA[k] = rB[k] = rC[k] = -1;
+    pB[k] = qB[k] = pC[k] = qC[k] = 0;
+    c0[k] = c1[k] = -1;
+    v0[k] = v1[k] = T(0);
+  }
+  // one pipeline step: C <- entries of B's rows, B <- entry range of A's rows, A <- rows of level L (all loads
+  // independent of each other and of x)
+  auto advance = [&](int L) {
+    int f1, stride;
+    const int slot = first_slot(L, &f1, &stride);
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      rC[k] = rB[k];
+      pC[k] = pB[k];
+      qC[k] = qB[k];
+      c0[k] = c1[k] = -1;
+      v0[k] = v1[k] = T(0);
+      if (rB[k] >= 0) {
+        if (pB[k] < qB[k]) {
+          c0[k] = colind[pB[k]];
+          v0[k] = values[pB[k]];
+        }
+        if (pB[k] + G < qB[k]) {
+          c1[k] = colind[pB[k] + G];
+          v1[k] = values[pB[k] + G];
+        }
+      }
+      rB[k] = rA[k];
+      pB[k] = qB[k] = 0;
+      if (rA[k] >= 0) {
+        pB[k] = rowptr[rA[k]] + gl;
+        qB[k] = rowptr[rA[k] + 1];
+      }
+      const int idx = slot + k * stride;
+      rA[k] = idx < f1 ? order[idx] : -1;
+    }
+  };
+  advance(0);
+  advance(1);
+  advance(2);
+  unsigned n_bar = 0;
+  for (int l = 0; l < n_levels; ++l) {
+    // ---- level l: gather x for the pipelined rows, finish them ----
+    if (!(dbg & 4)) {
+      bool s0[R], s1[R];
+      T x0[R], x1[R];
+#pragma unroll
+      for (int k = 0; k < R; ++k) {
+        s0[k] = rC[k] >= 0 && c0[k] >= 0 && c0[k] < m && trsv_strict(c0[k], rC[k], upper);
+        s1[k] = rC[k] >= 0 && c1[k] >= 0 && c1[k] < m && trsv_strict(c1[k], rC[k], upper);
+        x0[k] = x1[k] = T(0);
+        if (s0[k])
+          x0[k] = __hip_atomic_load(&x[c0[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (s1[k])
+          x1[k] = __hip_atomic_load(&x[c1[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+#pragma unroll
+      for (int k = 0; k < R; ++k) {
+        T dot = T(0);
+        int dpos = -1;
+        if (s0[k])
+          dot += v0[k] * x0[k];
+        else if (rC[k] >= 0 && c0[k] == rC[k])
+          dpos = pC[k];
+        if (s1[k])
+          dot += v1[k] * x1[k];
+        else if (rC[k] >= 0 && c1[k] == rC[k])
+          dpos = pC[k] + G;
+        for (int p = pC[k] + 2 * G; p < qC[k]; p += G) {  // rows longer than 2 G entries
+          const int c = colind[p];
+          if (c >= 0 && c < m && trsv_strict(c, rC[k], upper))
+            dot += values[p] * __hip_atomic_load(&x[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          else if (c == rC[k])
+            dpos = p;
+        }
+#pragma unroll
+        for (int o = G >> 1; o > 0; o >>= 1) {
+          dot += __shfl_xor(dot, o, SPB_WAVE);
+          const int other = __shfl_xor(dpos, o, SPB_WAVE);
+          dpos = other > dpos ? other : dpos;
+        }
+        if (rC[k] >= 0 && gl == 0) {
+          T v = b[rC[k]] - alpha * dot;
+          if (!unit)
+            v = v / (alpha * (dpos >= 0 ? values[dpos] : T(0)));
+          __hip_atomic_store(&x[rC[k]], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+    }
+    {  // rows of a level wider than the pipelined pass
+      int f1, stride;
+      const int slot = first_slot(l, &f1, &stride);
+      if (!(dbg & 8))
+      for (int idx = slot + R * stride; idx < f1; idx += stride)
+        trsv_row<T, G>(order[idx], gl, rowptr, colind, values, alpha, b, x, upper, unit, m, nullptr, 0u);
+    }
+    if (l + 1 == n_levels)
+      break;
+    // ---- hand level l over to level l + 1; the pipeline advances while the barrier is pending ----
+    const int w0 = level_ptr[l + 1] - level_ptr[l], w1 = level_ptr[l + 2] - level_ptr[l + 1];
+    if (w0 < narrow && w1 < narrow) {  // inside a narrow run: workgroup 0 alone
+      advance(l + 3);
+      if (blockIdx.x == 0) {
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this lane's write-through x stores are acknowledged
+        __syncthreads();
+      }
+    } else if (dbg & 2) {
+      advance(l + 3);
+    } else {
+      ++n_bar;
+      trsv_barrier_arrive(bar, n_bar, s_flags);
+      advance(l + 3);
+      if (!trsv_barrier_wait(bar, n_bar, spin_limit, status, s_flags))
+        return;
+    }
+  }
+}
+
 // one wide level: rows order[f0..f1), G lanes per row
 template <typename T, int G>
 __global__ __launch_bounds__(256) void trsv_level_kernel(int f0, int f1, const int32_t* __restrict__ order,
@@ -547,22 +761,62 @@ static int trsv_solve_typed(spblas_gfx950_handle_t h, spblas_gfx950_trsv_s* pl, 
   const int upper = pl->uplo == SPBLAS_GFX950_UPPER, unit = pl->diag == SPBLAS_GFX950_DIAG_UNIT;
   const int m = (int) pl->m;
   const size_t ng = pl->groups.size();
-  if (!pl->gran) {  // first solve: granules (tag 0 = never written) and the ticket counters
-    int rc = dev_alloc((void**) &pl->gran, (size_t) pl->m * 16, s);
+  bool any_selfsched = false;
+  for (size_t gi = 0; gi < ng; ++gi)
+    any_selfsched = any_selfsched || (pl->groups[gi].wide && pl->group_cp0[gi] >= 0);
+  const int cus = h->num_cus > 0 ? h->num_cus : 256;
+  // ticket counters, [ng] unused, [ng + 1] = status word, then (32-int aligned) the grid barrier: one line for the
+  // arrival counter and one release flag line per workgroup
+  const size_t bar_off = (ng + 2 + 31) / 32 * 32, ctl_ints = bar_off + 32 * (size_t) (9 + 2 * cus);
+  if (!pl->tickets) {
+    int rc = dev_alloc((void**) &pl->tickets, ctl_ints * 4, s);
     if (rc)
       return rc;
-    if ((rc = dev_alloc((void**) &pl->tickets, (ng + 2) * 4, s)))
+  }
+  if (any_selfsched && !pl->gran) {  // granules (tag 0 = never written)
+    int rc = dev_alloc((void**) &pl->gran, (size_t) pl->m * 16, s);
+    if (rc)
       return rc;
     SPB_HIP(hipMemsetAsync(pl->gran, 0, (size_t) pl->m * 16, s));
   }
   if (++pl->epoch == 0) {  // the solve number wrapped: start over with clean tags
-    SPB_HIP(hipMemsetAsync(pl->gran, 0, (size_t) pl->m * 16, s));
+    if (pl->gran)
+      SPB_HIP(hipMemsetAsync(pl->gran, 0, (size_t) pl->m * 16, s));
     pl->epoch = 1;
   }
-  SPB_HIP(hipMemsetAsync(pl->tickets, 0, (ng + 2) * 4, s));
+  SPB_HIP(hipMemsetAsync(pl->tickets, 0, ctl_ints * 4, s));
   int* status = pl->tickets + ng + 1;
-  const int cus = h->num_cus > 0 ? h->num_cus : 256;
-  const int spin_limit = env_int("SPBLAS_GFX950_TRSV_SPIN_LIMIT", 1 << 22);  // ~ a second of polling
+  const int spin_limit = env_int("SPBLAS_GFX950_TRSV_SPIN_LIMIT", 1 << 22);  // ~ seconds of polling
+  // the whole solve as one cooperative launch (default when the device offers it and no narrow run is so long
+  // that the waiting workgroups could exhaust their bounded spin: 4096 levels ~ 10 ms)
+  if (pl->coop_ok && !any_selfsched && ng > 1) {
+    int n_levels = (int) pl->h_level_ptr.size() - 1, narrow = pl->narrow;
+    int wgs = env_int("SPBLAS_GFX950_TRSV_COOP_WGS", 1);
+    int occ = 0;
+    constexpr int R = G <= 8 ? 4 : (G <= 16 ? 2 : 1);  // row slots per lane group in the pipelined pass
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, trsv_coop_kernel<T, G, R>, TRSV_COOP_THREADS, 0) != hipSuccess || occ < 1)
+      occ = 0;
+    if (wgs > occ)
+      wgs = occ;
+    if (wgs > 2)
+      wgs = 2;
+    if (wgs >= 1) {
+      unsigned* bar = reinterpret_cast<unsigned*>(pl->tickets + bar_off);
+      const int32_t* lp = pl->level_ptr;
+      const int32_t* ord = pl->order;
+      int mm = m, up = upper, un = unit, sl = spin_limit, bm = env_int("SPBLAS_GFX950_TRSV_DBG", 0);
+      void* args[] = {&n_levels, &narrow, (void*) &lp, (void*) &ord, (void*) &rowptr, (void*) &colind, (void*) &values,
+                      &alpha, (void*) &b, (void*) &x, &up, &un, &mm, &bar, &status, &sl, &bm};
+      int grid = env_int("SPBLAS_GFX950_TRSV_COOP_GRID", 0);
+      if (grid < 1 || grid > cus * wgs)
+        grid = cus * wgs;
+      const hipError_t ce = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(&trsv_coop_kernel<T, G, R>), dim3((unsigned) grid),
+                                                       dim3(TRSV_COOP_THREADS), args, 0, s);
+      if (ce == hipSuccess)
+        return SPBLAS_GFX950_STATUS_SUCCESS;
+      (void) hipGetLastError();  // not launched (e.g. the stream is being captured): one launch per group below
+    }
+  }
   bool used_selfsched = false;
   for (size_t gi = 0; gi < ng; ++gi) {
     const auto& g = pl->groups[gi];
@@ -798,6 +1052,18 @@ int spblas_gfx950_sptrsv_create(spblas_gfx950_handle_t handle, spblas_gfx950_trs
     }
     l = e1;
   }
+  pl->narrow = narrow;
+  {
+    int longest_run = 0, coop_attr = 0, dev = 0;
+    for (const auto& g : pl->groups)
+      if (!g.wide)
+        longest_run = std::max(longest_run, g.l1 - g.l0);
+    (void) hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&coop_attr, hipDeviceAttributeCooperativeLaunch, dev) != hipSuccess)
+      coop_attr = 0;
+    pl->coop_ok = coop_attr != 0 && !selfsched && env_int("SPBLAS_GFX950_TRSV_COOP", 1) != 0 &&
+                  longest_run <= env_int("SPBLAS_GFX950_TRSV_COOP_MAX_RUN", 4096);
+  }
   if (!h_chunk_ptr.empty()) {
     if ((rc = dev_alloc((void**) &pl->chunk_ptr, h_chunk_ptr.size() * 4, s)))
       return fail(rc);
@@ -833,7 +1099,7 @@ int spblas_gfx950_sptrsv_info(spblas_gfx950_trsv_t plan, int64_t info[4]) {
     return SPBLAS_GFX950_STATUS_INVALID_POINTER;
   info[0] = plan->h_level_ptr.empty() ? 0 : (int64_t) plan->h_level_ptr.size() - 1;  // levels
   info[1] = plan->max_width;                                                         // widest level
-  info[2] = (int64_t) plan->groups.size();                                           // kernel launches per solve
+  info[2] = plan->coop_ok && plan->groups.size() > 1 ? 1 : (int64_t) plan->groups.size();  // kernel launches per solve
   info[3] = plan->lanes;                                                             // lanes per row
   return SPBLAS_GFX950_STATUS_SUCCESS;
 }

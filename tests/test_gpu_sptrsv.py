@@ -217,14 +217,22 @@ def test_trsv_golden_bit_exact(gpu, upper, unit):
     assert np.array_equal(G.host(d_x), g[key])
 
 
-@pytest.mark.parametrize("mode", ["kahn_inspect", "selfsched_solve"])
+@pytest.mark.parametrize("mode", ["default", "kahn_inspect", "selfsched_solve", "launch_per_level", "coop_small_grid",
+                                  "coop_one_slot_pass"])
 @pytest.mark.parametrize("upper", [False, True])
 def test_alternative_inspect_and_solve_paths(gpu, monkeypatch, mode, upper):
-    """The default is: levels by dependency polling (one self-scheduling kernel), solve with one launch per wide
-    level.  The other two paths stay in the library -- Kahn's algorithm as the fallback of the polling inspect, the
+    """The default is: levels by dependency polling (one self-scheduling kernel), solve = ONE cooperative launch with
+    a grid barrier per level.  The other paths stay in the library -- Kahn's algorithm as the fallback of the polling
+    inspect, one launch per wide level (what a stream capture or a device without cooperative launches gets), the
     self-scheduling solve (granule hand-offs inside one launch) as an option -- and must give the same answers:
-    a random triangular system with a few hundred wide levels, fp32 and fp64."""
-    monkeypatch.setenv("SPBLAS_GFX950_TRSV_KAHN" if mode == "kahn_inspect" else "SPBLAS_GFX950_TRSV_SELFSCHED", "1")
+    a random triangular system with a few hundred wide levels, fp32 and fp64.  The two coop_* modes push the
+    cooperative kernel off its comfortable shape: 3 workgroups (every wide level needs the plain extra passes behind
+    the pipelined one) and a `narrow` threshold above the widest level (workgroup 0 walks everything alone)."""
+    env = {"kahn_inspect": ("SPBLAS_GFX950_TRSV_KAHN", "1"), "selfsched_solve": ("SPBLAS_GFX950_TRSV_SELFSCHED", "1"),
+           "launch_per_level": ("SPBLAS_GFX950_TRSV_COOP", "0"), "coop_small_grid": ("SPBLAS_GFX950_TRSV_COOP_GRID", "3"),
+           "coop_one_slot_pass": ("SPBLAS_GFX950_TRSV_NARROW", "100000")}.get(mode)
+    if env:
+        monkeypatch.setenv(*env)
     rng = np.random.default_rng(8)
     n, k = 60000, 6
     rows = np.repeat(np.arange(n), k)
@@ -239,3 +247,7 @@ def test_alternative_inspect_and_solve_paths(gpu, monkeypatch, mode, upper):
         assert info["levels"] > 20 and info["max_level_width"] > 128
         if mode == "selfsched_solve":
             assert info["launches_per_solve"] < info["levels"] / 4
+        elif mode == "launch_per_level":
+            assert info["launches_per_solve"] > 20
+        elif mode in ("default", "coop_small_grid"):
+            assert info["launches_per_solve"] == 1
