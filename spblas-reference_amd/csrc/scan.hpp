@@ -55,8 +55,10 @@ static __global__ __launch_bounds__(256) void scan_partials_kernel(int64_t nb, l
 }
 
 // data[0..n) counts -> exclusive offsets, data[n] = total (n+1 entries written)
+// (`copy`, when given, receives the same n+1 offsets: the caller's row pointer array next to the plan's own)
 static __global__ __launch_bounds__(256) void scan_apply_kernel(int64_t n, int32_t* __restrict__ data,
-                                                         const long long* __restrict__ partials) {
+                                                         const long long* __restrict__ partials,
+                                                         int32_t* __restrict__ copy = nullptr) {
   __shared__ int sm[256];
   const int64_t base = (int64_t) blockIdx.x * 2048;
   // each thread owns 8 consecutive entries
@@ -80,12 +82,18 @@ static __global__ __launch_bounds__(256) void scan_apply_kernel(int64_t n, int32
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const int64_t i = base + threadIdx.x * 8 + j;
-    if (i < n)
+    if (i < n) {
       data[i] = (int32_t) off;
+      if (copy)
+        copy[i] = (int32_t) off;
+    }
     off += v[j];
   }
-  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0)
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
     data[n] = (int32_t) partials[gridDim.x];
+    if (copy)
+      copy[n] = (int32_t) partials[gridDim.x];
+  }
 }
 
 
@@ -96,7 +104,7 @@ static inline long long* scan_counts_i32(hipStream_t s, int64_t n, int32_t* data
   const int64_t nb = cdiv(n, 2048);
   hipLaunchKernelGGL(scan_block_sums_kernel, dim3((unsigned) nb), dim3(256), 0, s, n, data, partials);
   hipLaunchKernelGGL(scan_partials_kernel, dim3(1), dim3(256), 0, s, nb, partials);
-  hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned) nb), dim3(256), 0, s, n, data, partials);
+  hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned) nb), dim3(256), 0, s, n, data, partials, (int32_t*) nullptr);
   return partials + nb;
 }
 
