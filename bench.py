@@ -276,6 +276,8 @@ def main():
     inspect_ms = (time.perf_counter() - t0) * 1e3
     info0 = op.info if mode in ("overlapped", "fused") else op.infos[0]
     plan_info = info0.state_.info() if info0.state_ is not None else {"alg": "plan-free"}
+    if info0.state_ is not None and hasattr(info0.state_, "sliced_info") and plan_info.get("alg") == 3:
+        plan_info["sliced"] = info0.state_.sliced_info()
 
     elapsed, kern_avg_ms = measure(lambda: op.step(x), args.steps, args.warmup, multi, device)
 

@@ -148,6 +148,11 @@ int spblas_gfx950_plan_destroy(spblas_gfx950_handle_t handle, spblas_gfx950_plan
  * [7]=#empty rows, [8]=rows per row-bin (SLICED), [9]=1 if the bins honour BIN_ROW_ALIGN,
  * [10]=#expand work items, [11]=#reduce work items (SLICED plans of skewed matrices; else 0). */
 int spblas_gfx950_plan_info(spblas_gfx950_plan_t plan, int64_t info[12]);
+/* More of a SLICED plan (zeros for other plans): info[0]=#row-bins, [1]=1 if the bins have variable heights (row-skewed
+ * matrix: a new bin every [8] rows and every ~nnz/2048 entries), [2]=blocks of 32 entries in expand order,
+ * [3]=blocks in reduce order (bins padded to groups of 8 blocks), [4]=entries placed in tiles, [5]=#rows kept out of
+ * the tiles (hub rows), [6]=hub threshold (row length), [7]=reduce K split. */
+int spblas_gfx950_plan_info_sliced(spblas_gfx950_plan_t plan, int64_t info[8]);
 
 /* Two-stage execution of a SLICED plan (other plans: STATUS_NOT_SUPPORTED), used to overlap the
  * multi-GPU all-gather of finished y rows with the rest of the SpMV:

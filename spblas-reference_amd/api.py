@@ -281,6 +281,13 @@ class _Plan:
                  "empty_rows", "rows_per_bin", "bin_aligned", "expand_items", "reduce_items"]
         return dict(zip(names, list(arr)))
 
+    def sliced_info(self):
+        arr = (ctypes.c_int64 * 8)()
+        check(_capi.lib().spblas_gfx950_plan_info_sliced(self.plan, arr), "spblas_gfx950_plan_info_sliced")
+        names = ["n_bins", "variable_bins", "expand_blocks", "reduce_blocks", "placed_entries", "hub_rows", "hub_len",
+                 "ksplit"]
+        return dict(zip(names, list(arr)))
+
     # two-stage execution of a SLICED plan (include/spblas_gfx950.h: spmv_expand / spmv_reduce_rows)
     def bind_stages(self, x, y_base_ptr, dtype, alpha=1.0, beta=0.0):
         """Returns (expand, reduce_rows) callables with every argument pre-bound; reduce_rows(lo, hi)

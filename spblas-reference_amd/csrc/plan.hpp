@@ -63,6 +63,13 @@ struct spblas_gfx950_plan_s {
   void* s_partial = nullptr;   // T[s_partial_k][m] partial sums (grown on demand)
   int s_partial_k = 0;
   int bin_aligned = 0;         // wave-bin height divides the handle's bin_row_align option
+  // row-skewed matrices: wave-bins of variable height (<= rows_per_blk rows, ~equal entries); nullptr = bin b
+  // holds the rows [b * rows_per_blk, (b + 1) * rows_per_blk)
+  void* s_binrow = nullptr;    // int32[NB + 1] first row of every wave-bin (device)
+  int32_t* h_binrow = nullptr; // host copy (new[])
+  void* s_hub_rows = nullptr;  // int32[n_hub] rows kept out of the tiles (== long_rows unless variable bins raise the threshold)
+  int64_t n_hub = 0;
+  bool hub_rows_owned = false;
 
   // SpMM inspect (spblas_gfx950_spmm_inspect, spmm.hip): row blocks of 32 rows whose entries fall into at most 16
   // aligned tiles of 128 columns, densely enough, are multiplied from LDS-staged B tiles on the matrix cores

@@ -647,7 +647,7 @@ int spblas_gfx950_spmv_step_bcast(spblas_gfx950_handle_t handle, spblas_gfx950_p
   int64_t per = cdiv(cdiv(NB, RW), stripes) * RW;  // bins per stripe: whole workgroups
   if (per < RW)
     per = RW;
-  const int n_str = (int) cdiv(NB, per);
+  const int n_str = plan->s_binrow ? 1 : (int) cdiv(NB, per);  // stripes are cut on the arithmetic bin grid only
   hipStream_t main_s = handle->stream;
   int rc;
   if (n_str <= 1) {
@@ -714,6 +714,21 @@ int spblas_gfx950_plan_info(spblas_gfx950_plan_t plan, int64_t info[12]) {
   info[9] = plan->bin_aligned;
   info[10] = plan->n_xitems;
   info[11] = plan->n_ritems;
+  return SPBLAS_GFX950_STATUS_SUCCESS;
+}
+
+int spblas_gfx950_plan_info_sliced(spblas_gfx950_plan_t plan, int64_t info[8]) {
+  if (!plan || !info)
+    return SPBLAS_GFX950_STATUS_INVALID_POINTER;
+  const bool sl = plan->alg == SPBLAS_GFX950_SPMV_SLICED;
+  info[0] = sl ? plan->n_rblk : 0;
+  info[1] = sl && plan->s_binrow ? 1 : 0;
+  info[2] = sl ? plan->a_blocks : 0;
+  info[3] = sl ? plan->p_blocks : 0;
+  info[4] = sl ? plan->s_placed : 0;
+  info[5] = sl && plan->hub_len > 0 ? plan->n_hub : 0;
+  info[6] = sl ? plan->hub_len : 0;
+  info[7] = sl ? plan->n_ksplit : 0;
   return SPBLAS_GFX950_STATUS_SUCCESS;
 }
 

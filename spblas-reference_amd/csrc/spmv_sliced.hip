@@ -60,9 +60,17 @@ static constexpr int PB_FTHREADS = 512;         // inspect (flag kernel): 8 wave
 static constexpr int PB_FWAVES = PB_FTHREADS / 64;
 static constexpr int PB_RWAVES_DEFAULT = 4;     // reduce: wave-bins per workgroup (plan->rwaves)
 static constexpr int PB_LDS_BYTES = 80 * 1024;  // two workgroups per CU (160 KiB LDS)
-static constexpr int PB_BLK = 32;               // entries per block: the padding unit of a run (128 B of fp32 products)
+// entries per block -- the padding unit of a run: 128 B of products (32 fp32, 16 fp64), so the expand's scattered
+// product stores are whole aligned 128-byte pieces for either type (smaller or unaligned pieces write 28-30 % slower,
+// tools/ubench/hbm_pieces.hip) and an fp64 run pads to 16 entries, not 32 (R-MAT scale 24: 47 % -> 25 % padding)
+template <typename T>
+struct pb_geom {
+  static constexpr int BLK = 128 / (int) sizeof(T);
+  static constexpr int GBLK = 256 / BLK;  // blocks per reduce group (PB_GRP entries): the padding unit of a bin
+};
+static inline int pb_blk_of(int value_type) { return value_type == SPBLAS_GFX950_F32 ? 32 : 16; }
 static constexpr int PB_GRP = 256;              // entries per reduce step: 64 lanes x 4
-static constexpr int PB_GBLK = PB_GRP / PB_BLK; // blocks per group: the padding unit of a bin
+
 
 // ---- inspect --------------------------------------------------------------------------
 // One workgroup per wave-bin: all entries of the bin's rows share wb, so the per-slice counts
@@ -81,18 +89,75 @@ __device__ __forceinline__ int64_t pb_row_of(const O* __restrict__ rowptr, int64
   return lo;
 }
 
+// rows [*r0, *r1) of wave-bin wb: equal heights, or -- row-skewed matrices -- the variable heights of binrow[]
+__device__ __forceinline__ void pb_bin_rows(const int32_t* __restrict__ binrow, int64_t wb, int H, int64_t m,
+                                            int64_t* r0, int64_t* r1) {
+  if (binrow) {
+    *r0 = binrow[wb];
+    *r1 = binrow[wb + 1];
+  } else {
+    *r0 = wb * H;
+    *r1 = (*r0 + H) < m ? (*r0 + H) : m;
+  }
+}
+
+// Variable-height bins: row r starts a bin when it lies on the H-row grid (no bin is taller than the LDS
+// accumulators allow) or when the entry count before it crosses a multiple of E (no bin holds much more than E
+// entries plus one row).  flag[] is scanned into bin numbers; pb_bin_rows_kernel writes the boundaries.
+template <typename O>
+__global__ __launch_bounds__(256) void pb_bin_flags_kernel(int64_t m, int H, int64_t E, const O* __restrict__ rowptr,
+                                                           int32_t* __restrict__ flag) {
+  const int64_t r = (int64_t) blockIdx.x * 256 + threadIdx.x;
+  if (r >= m)
+    return;
+  flag[r] = (r % H == 0) || ((int64_t) rowptr[r] / E != (int64_t) rowptr[r - 1] / E);
+}
+// rows longer than `thr` entries, appended to rows[] in arbitrary order (wave-aggregated append)
+template <typename O>
+__global__ __launch_bounds__(256) void pb_hub_list_kernel(int64_t m, int thr, const O* __restrict__ rowptr,
+                                                          unsigned long long* __restrict__ count,
+                                                          int32_t* __restrict__ rows) {
+  const int lane = threadIdx.x & 63;
+  for (int64_t r0 = (int64_t) blockIdx.x * 256; r0 < m; r0 += (int64_t) gridDim.x * 256) {
+    const int64_t r = r0 + threadIdx.x;
+    const bool hub = r < m && (int64_t) (rowptr[r + 1] - rowptr[r]) > (int64_t) thr;
+    const unsigned long long mask = __ballot(hub);
+    if (mask == 0)
+      continue;
+    unsigned long long base = 0;
+    const int leader = __builtin_ctzll(mask);
+    if (lane == leader)
+      base = atomicAdd(count, (unsigned long long) __popcll(mask));
+    base = __shfl(base, leader);
+    if (hub)
+      rows[base + __popcll(mask & ((1ull << lane) - 1ull))] = (int32_t) r;
+  }
+}
+__global__ __launch_bounds__(256) void pb_bin_rows_kernel(int64_t m, const int32_t* __restrict__ pos,
+                                                          int32_t* __restrict__ binrow) {
+  const int64_t r = (int64_t) blockIdx.x * 256 + threadIdx.x;
+  if (r > m)
+    return;
+  if (r == m)
+    binrow[pos[m]] = (int32_t) m;
+  else if (pos[r + 1] != pos[r])
+    binrow[pos[r]] = (int32_t) r;
+}
+
 // hub_len > 0: entries of rows longer than hub_len are left out of the tiles (a run that repeats one
 // row hundreds of times would serialise on the LDS atomic); pb_hub_rows_kernel adds those rows.
 template <typename O>
 __global__ __launch_bounds__(256) void pb_count_kernel(int64_t m, const O* __restrict__ rowptr,
                                                        const int32_t* __restrict__ colind, int W, int H, int S, int NB,
-                                                       int32_t* __restrict__ cnt, int hub_len) {
+                                                       int32_t* __restrict__ cnt, int hub_len,
+                                                       const int32_t* __restrict__ binrow) {
   extern __shared__ int hist[];  // [S]
   const int wb = blockIdx.x;
   for (int i = threadIdx.x; i < S; i += 256)
     hist[i] = 0;
   __syncthreads();
-  const int64_t r0 = (int64_t) wb * H, r1 = (r0 + H) < m ? (r0 + H) : m;
+  int64_t r0, r1;
+  pb_bin_rows(binrow, wb, H, m, &r0, &r1);
   if (r0 < m) {
     const O p0 = rowptr[r0], p1 = rowptr[r1];
     for (O p = p0 + threadIdx.x; p < p1; p += 256) {
@@ -111,16 +176,18 @@ __global__ __launch_bounds__(256) void pb_count_kernel(int64_t m, const O* __res
 
 // blocks per run, in A' order (key = s*NB + b); scanned in place into the block offsets aoff[]
 __global__ __launch_bounds__(256) void pb_nblk_kernel(int64_t nseg, const int32_t* __restrict__ cnt,
-                                                      int32_t* __restrict__ aoff) {
+                                                      int32_t* __restrict__ aoff, int blk) {
   const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
   if (i < nseg)
-    aoff[i] = (cnt[i] + PB_BLK - 1) / PB_BLK;
+    aoff[i] = (cnt[i] + blk - 1) / blk;
 }
 
 // P order: one workgroup per wave-bin b scans the block counts of its S runs: prel[b*S + s] = blocks of the bin
 // before slice s; bintot[b] = the bin's blocks rounded up to whole groups (scanned afterwards into binblk[]).
 __global__ __launch_bounds__(256) void pb_bin_prefix_kernel(int S, int NB, const int32_t* __restrict__ cnt,
-                                                            int32_t* __restrict__ prel, int32_t* __restrict__ bintot) {
+                                                            int32_t* __restrict__ prel, int32_t* __restrict__ bintot,
+                                                            int blk) {
+  const int gblk = PB_GRP / blk;
   __shared__ int sm[256];
   __shared__ int carry;
   const int b = blockIdx.x, tid = threadIdx.x;
@@ -129,7 +196,7 @@ __global__ __launch_bounds__(256) void pb_bin_prefix_kernel(int S, int NB, const
   __syncthreads();
   for (int s0 = 0; s0 < S; s0 += 256) {
     const int s = s0 + tid;
-    const int v = s < S ? (cnt[(int64_t) s * NB + b] + PB_BLK - 1) / PB_BLK : 0;
+    const int v = s < S ? (cnt[(int64_t) s * NB + b] + blk - 1) / blk : 0;
     sm[tid] = v;
     __syncthreads();
     for (int o = 1; o < 256; o <<= 1) {
@@ -147,7 +214,7 @@ __global__ __launch_bounds__(256) void pb_bin_prefix_kernel(int S, int NB, const
     __syncthreads();
   }
   if (tid == 0)
-    bintot[b] = (carry + PB_GBLK - 1) / PB_GBLK * PB_GBLK;
+    bintot[b] = (carry + gblk - 1) / gblk * gblk;
 }
 
 // sliceblk[s] = aoff[s*NB] (first A'-order block of slice s), sliceblk[S] = all blocks
@@ -170,7 +237,8 @@ __global__ __launch_bounds__(256) void pb_scatter_kernel(int64_t m, const O* __r
                                                          const int32_t* __restrict__ binblk, T* __restrict__ s_val,
                                                          uint16_t* __restrict__ s_col, uint16_t* __restrict__ s_row,
                                                          int32_t* __restrict__ perm, int32_t* __restrict__ blkdst,
-                                                         int hub_len) {
+                                                         int hub_len, const int32_t* __restrict__ binrow) {
+  constexpr int PB_BLK = pb_geom<T>::BLK;
   extern __shared__ int smem_i[];
   int* cursor = smem_i;    // [S] next A' position of the run
   int* pdelta = smem_i + S;  // [S] P position minus A' position of the run's entries
@@ -192,7 +260,8 @@ __global__ __launch_bounds__(256) void pb_scatter_kernel(int64_t m, const O* __r
       blkdst[a0 + k] = p0b + k;
   }
   __syncthreads();
-  const int64_t r0 = (int64_t) wb * H, r1 = (r0 + H) < m ? (r0 + H) : m;
+  int64_t r0, r1;
+  pb_bin_rows(binrow, wb, H, m, &r0, &r1);
   if (r0 >= m)
     return;
   const O p0 = rowptr[r0], p1 = rowptr[r1];
@@ -227,7 +296,8 @@ __global__ __launch_bounds__(PB_STAGE_THREADS) void pb_scatter_staged_kernel(
     int H, int S, int NB, const int32_t* __restrict__ cnt, const int32_t* __restrict__ aoff,
     const int32_t* __restrict__ prel, const int32_t* __restrict__ binblk, T* __restrict__ s_val,
     uint16_t* __restrict__ s_col, uint16_t* __restrict__ s_row, int32_t* __restrict__ perm,
-    int32_t* __restrict__ blkdst, int hub_len, int cap, int rt_len) {
+    int32_t* __restrict__ blkdst, int hub_len, int cap, int rt_len, const int32_t* __restrict__ binrow) {
+  constexpr int PB_BLK = pb_geom<T>::BLK;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   int* lcnt = reinterpret_cast<int*>(smem);  // [S] entries of this bin per slice
   int* gdst = lcnt + S;                      // [S] first A' position of the run
@@ -240,7 +310,8 @@ __global__ __launch_bounds__(PB_STAGE_THREADS) void pb_scatter_staged_kernel(
   uint16_t* stc = reinterpret_cast<uint16_t*>(stv + cap);  // [cap] column inside the slice
   __shared__ int pass_end, pass_direct;
   const int wb = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int64_t r0 = (int64_t) wb * H, r1 = (r0 + H) < m ? (r0 + H) : m;
+  int64_t r0, r1;
+  pb_bin_rows(binrow, wb, H, m, &r0, &r1);
   if (r0 >= m)
     return;
   const int nr = (int) (r1 - r0);
@@ -493,12 +564,13 @@ __global__ __launch_bounds__(PB_THREADS) void pb_expand_kernel(int64_t n, int W,
                                                                const int32_t* __restrict__ blkdst,
                                                                const T* __restrict__ x, T* __restrict__ P,
                                                                const int4* __restrict__ items, int S, int share) {
+  constexpr int PB_BLK = pb_geom<T>::BLK, LPB = PB_BLK / 4;  // lanes per block: 8 (fp32) / 4 (fp64)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   T* xs = reinterpret_cast<T*>(smem);
   const int tid = threadIdx.x;
-  const int sub = (tid & 7) * 4;  // first of this lane's 4 entries inside its block
-  const int bsel = tid >> 3;      // block inside the workgroup's pass of PB_THREADS / 8 blocks
-  constexpr int PASS = PB_THREADS / 8;
+  const int sub = (tid & (LPB - 1)) * 4;  // first of this lane's 4 entries inside its block
+  const int bsel = tid / LPB;             // block inside the workgroup's pass of PB_THREADS / LPB blocks
+  constexpr int PASS = PB_THREADS / LPB;
   auto load_x = [&](int s) {
     const int64_t c0 = (int64_t) s * W;
     const int cw = (int) ((n - c0) < W ? (n - c0) : W);
@@ -582,7 +654,7 @@ __global__ __launch_bounds__(PB_THREADS) void pb_expand_kernel(int64_t n, int W,
 // flag (bit 15) and take the atomic path there.  tag[row] = id (0..255) of the last entry that claimed the row.
 __global__ __launch_bounds__(PB_FTHREADS) void pb_flag_dups_kernel(int Hw, int64_t NBw,
                                                                    const int32_t* __restrict__ binblk,
-                                                                   uint16_t* __restrict__ s_row) {
+                                                                   uint16_t* __restrict__ s_row, int PB_GBLK) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   unsigned char* tag = smem + (size_t) wave * (size_t) ((Hw + 63) & ~63);
@@ -634,7 +706,8 @@ __global__ __launch_bounds__(RW * 64) void pb_reduce_kernel(int64_t m, int Hw, i
                                                             T alpha, T beta, int K, T* __restrict__ partial,
                                                             int64_t pstride, T* const* __restrict__ peers,
                                                             int n_peers, int64_t peer_off,
-                                                            const int4* __restrict__ ritems, int dbg) {
+                                                            const int4* __restrict__ ritems, int dbg,
+                                                            const int32_t* __restrict__ binrow) {
   // dbg (SPBLAS_GFX950_PB_DBG, timing experiments only -- results are wrong): 1 = skip the atomic path of flagged
   // entries, 2 = no LDS traffic at all (the stream alone)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -646,10 +719,12 @@ __global__ __launch_bounds__(RW * 64) void pb_reduce_kernel(int64_t m, int Hw, i
     partial = item.w >= 0 ? partial + item.w + (int64_t) wave * Hw : nullptr;
   if (wb >= NBw)
     return;
-  const int64_t r0 = wb * Hw;
-  const int rh = (int) ((m - r0) < Hw ? (m - r0) : Hw);
+  int64_t r0, r1;
+  pb_bin_rows(binrow, wb, Hw, m, &r0, &r1);
+  const int rh = (int) (r1 - r0);
   for (int i = lane; i < rh; i += 64)
     acc[i] = T(0);
+  constexpr int PB_GBLK = pb_geom<T>::GBLK;
   const int gb0 = binblk[wb] / PB_GBLK, ng = binblk[wb + 1] / PB_GBLK - gb0;
   const int g_lo = gb0 + (int) ((int64_t) ng * item.y / item.z);
   const int g_hi = gb0 + (int) ((int64_t) ng * (item.y + 1) / item.z);
@@ -817,11 +892,23 @@ __global__ __launch_bounds__(256) void pb_hub_finish_kernel(int64_t n_hub, int p
 template <typename T>
 __global__ __launch_bounds__(256) void pb_combine_items_kernel(const int4* __restrict__ cg, int64_t group_rows,
                                                                int64_t m, const T* __restrict__ partial,
-                                                               T* __restrict__ y, T alpha, T beta) {
+                                                               T* __restrict__ y, T alpha, T beta, int Hw,
+                                                               const int32_t* __restrict__ binrow, int64_t NB) {
   const int4 g = cg[blockIdx.x];
   const int64_t i = (int64_t) blockIdx.y * 256 + threadIdx.x;
-  const int64_t row = (int64_t) g.x * group_rows + i;
-  if (i >= group_rows || row >= m)
+  if (i >= group_rows)
+    return;
+  int64_t row = (int64_t) g.x * group_rows + i;
+  if (binrow) {  // slot i of the group's partial block = row (i % Hw) of its wave-bin (i / Hw)
+    const int64_t wb = (int64_t) g.x * (group_rows / Hw) + i / Hw;
+    if (wb >= NB)
+      return;
+    const int64_t r0 = binrow[wb], off = i % Hw;
+    if (off >= binrow[wb + 1] - r0)
+      return;
+    row = r0 + off;
+  }
+  if (row >= m)
     return;
   const T* src = partial + (int64_t) g.z + i;
   T s = src[0];
@@ -980,6 +1067,66 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
       pl->bin_aligned = 1;
     }
   }
+  int rc;
+  pb_tracer tr(s);
+  const O* rowptr = static_cast<const O*>(pl->rowptr);
+  // Row-skewed matrices (power-law graphs: most entries in a few thousand rows, half the rows empty) get wave-bins
+  // of VARIABLE height: a new bin every H rows and wherever the entry count crosses a multiple of E, so no bin is
+  // taller than the LDS accumulators allow and none carries much more than E entries.  With equal heights the
+  // R-MAT scale-24 matrix puts 8.9 M entries into one bin (average 39 k): one inspect workgroup and one reduce
+  // wavefront per such bin (inspect 310 ms).  Uniform matrices keep the arithmetic bins (binrow = nullptr).
+  const double avg_len = m > 0 ? (double) nnz / (double) m : 0.0;
+  int varbins = env_int("SPBLAS_GFX950_PB_VARBINS", -1);
+  if (varbins < 0)
+    varbins = (double) pl->max_row_len > 16.0 * avg_len + 64.0 || pl->empty_rows * 4 > m;
+  if (h->bin_row_align > 1 || m < 2 || NB < 2)
+    varbins = 0;
+  const int32_t* binrow = nullptr;
+  if (varbins) {
+    int64_t E = nnz / env_int("SPBLAS_GFX950_PB_BINS", 2048);
+    E = std::max<int64_t>(8192, std::min<int64_t>(E, 98304));
+    int32_t* flag = nullptr;
+    long long* fpart = nullptr;
+    if ((rc = dev_alloc((void**) &flag, (size_t) (m + 1) * 4, s)))
+      return rc;
+    if ((rc = dev_alloc((void**) &fpart, (size_t) (cdiv(m, 2048) + 2) * sizeof(long long), s))) {
+      dev_free(flag, s);
+      return rc;
+    }
+    hipLaunchKernelGGL((pb_bin_flags_kernel<O>), dim3((unsigned) cdiv(m, 256)), dim3(256), 0, s, m, H, E, rowptr, flag);
+    long long* total_dev = scan_counts_i32(s, m, flag, fpart);
+    long long nb_var = 0;
+    hipError_t e = hipMemcpyAsync(&nb_var, total_dev, sizeof(nb_var), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess)
+      e = hipStreamSynchronize(s);
+    if (e == hipSuccess && nb_var > 0 && nb_var < ((int64_t) 1 << 24)) {
+      NB = (int) nb_var;
+      rc = dev_alloc(&pl->s_binrow, (size_t) (NB + 1) * 4, s);
+      if (!rc) {
+        hipLaunchKernelGGL(pb_bin_rows_kernel, dim3((unsigned) cdiv(m + 1, 256)), dim3(256), 0, s, m, flag,
+                           static_cast<int32_t*>(pl->s_binrow));
+        pl->h_binrow = new (std::nothrow) int32_t[(size_t) NB + 1];
+        if (!pl->h_binrow)
+          rc = SPBLAS_GFX950_STATUS_ALLOC_FAILED;
+        else {
+          e = hipMemcpyAsync(pl->h_binrow, pl->s_binrow, (size_t) (NB + 1) * 4, hipMemcpyDeviceToHost, s);
+          if (e == hipSuccess)
+            e = hipStreamSynchronize(s);
+        }
+      }
+    }
+    dev_free(flag, s);
+    dev_free(fpart, s);
+    if (e != hipSuccess)
+      return hip_fail(e);
+    if (rc)
+      return rc;
+    binrow = static_cast<const int32_t*>(pl->s_binrow);
+    if (!binrow)
+      varbins = 0;
+    pl->device_bytes += (size_t) (NB + 1) * 4;
+    tr.mark("variable bins");
+  }
   const int64_t nseg = (int64_t) S * NB;
   if (nseg > (int64_t) 64 << 20 || S > 16384)  // 2 * S ints of LDS per inspect workgroup
     return SPBLAS_GFX950_STATUS_NOT_SUPPORTED;
@@ -988,8 +1135,6 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
   pl->n_rblk = NB;
   pl->rows_per_blk = H;
 
-  int rc;
-  pb_tracer tr(s);
   int32_t *cnt = nullptr, *aoff = nullptr, *prel = nullptr;
   long long* partials = nullptr;
   if ((rc = dev_alloc((void**) &cnt, (size_t) (nseg + 1) * 4, s)))
@@ -997,20 +1142,59 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
   pl->seg_ptr = cnt;
   tr.mark("cnt allocated");
   SPB_HIP(hipMemsetAsync(cnt, 0, (size_t) (nseg + 1) * 4, s));
-  const O* rowptr = static_cast<const O*>(pl->rowptr);
   // rows longer than the nnz window (the plan's long_rows list) stay out of the tiles
   pl->hub_len = pl->n_long > 0 ? pl->win : 0;
+  pl->s_hub_rows = pl->long_rows;
+  pl->n_hub = pl->n_long;
+  pl->hub_rows_owned = false;
+  if (varbins && pl->n_long > 0) {
+    // variable bins keep all but the very longest rows in the tiles (a row of 16 k entries leaves ~20 entries in
+    // each of its runs: duplicates the reduce adds atomically, not a serial chain): own list, higher threshold
+    const int hub2 = std::max<int>(pl->win, env_int("SPBLAS_GFX950_PB_HUB_LEN", 16384));
+    if (pl->max_row_len <= hub2) {
+      pl->hub_len = 0;
+      pl->s_hub_rows = nullptr;
+      pl->n_hub = 0;
+    } else if (hub2 > pl->win) {
+      unsigned long long* st2 = nullptr;
+      int32_t* rows2 = nullptr;
+      if ((rc = dev_alloc((void**) &st2, 4 * sizeof(unsigned long long), s)))
+        return rc;
+      if ((rc = dev_alloc((void**) &rows2, (size_t) (nnz / hub2 + 1) * 4, s))) {
+        dev_free(st2, s);
+        return rc;
+      }
+      unsigned long long hst[4] = {0, 0, 0, 0};
+      hipError_t e = hipMemsetAsync(st2, 0, 4 * sizeof(unsigned long long), s);
+      if (e == hipSuccess) {
+        hipLaunchKernelGGL((pb_hub_list_kernel<O>), dim3((unsigned) (cdiv(m, 256) < 2048 ? cdiv(m, 256) : 2048)), dim3(256),
+                           0, s, m, hub2, rowptr, st2 + 1, rows2);
+        e = hipMemcpyAsync(hst, st2, sizeof(hst), hipMemcpyDeviceToHost, s);
+      }
+      if (e == hipSuccess)
+        e = hipStreamSynchronize(s);
+      dev_free(st2, s);
+      if (e != hipSuccess) {
+        dev_free(rows2, s);
+        return hip_fail(e);
+      }
+      pl->hub_len = hub2;
+      pl->s_hub_rows = rows2;
+      pl->n_hub = (int64_t) hst[1];
+      pl->hub_rows_owned = true;
+    }
+  }
   pl->values_ptr = values_p;
   if (pl->hub_len > 0) {
     // workgroups per hub row: ~16K entries each, at most 64
     int64_t parts = cdiv(pl->max_row_len, 16384);
     pl->hub_parts = (int) (parts < 1 ? 1 : (parts > 64 ? 64 : parts));
-    int rc_h = dev_alloc(&pl->s_hub_part, (size_t) pl->n_long * pl->hub_parts * sizeof(T), s);
+    int rc_h = dev_alloc(&pl->s_hub_part, (size_t) pl->n_hub * pl->hub_parts * sizeof(T), s);
     if (rc_h)
       return rc_h;
   }
   hipLaunchKernelGGL((pb_count_kernel<O>), dim3((unsigned) NB), dim3(256), (size_t) S * 4, s, m, rowptr, pl->colind, W, H, S,
-                     NB, cnt, pl->hub_len);
+                     NB, cnt, pl->hub_len, binrow);
   tr.mark("count kernel");
   // One probe pass over the counters, read back once: entries per slice, non-empty tiles per slice, entries
   // per bin group.  AUTO uses them to decline matrices the plan does not suit; the work lists below use them
@@ -1048,9 +1232,9 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
     return rc;
   int32_t* binblk = static_cast<int32_t*>(pl->s_binblk);
   int32_t* sliceblk = static_cast<int32_t*>(pl->s_sliceblk);
-  hipLaunchKernelGGL(pb_nblk_kernel, dim3((unsigned) cdiv(nseg, 256)), dim3(256), 0, s, nseg, cnt, aoff);
+  hipLaunchKernelGGL(pb_nblk_kernel, dim3((unsigned) cdiv(nseg, 256)), dim3(256), 0, s, nseg, cnt, aoff, pb_geom<T>::BLK);
   (void) scan_counts_i32(s, nseg, aoff, partials);  // aoff[nseg] = blocks in A' order
-  hipLaunchKernelGGL(pb_bin_prefix_kernel, dim3((unsigned) NB), dim3(256), 0, s, S, NB, cnt, prel, binblk);
+  hipLaunchKernelGGL(pb_bin_prefix_kernel, dim3((unsigned) NB), dim3(256), 0, s, S, NB, cnt, prel, binblk, pb_geom<T>::BLK);
   (void) scan_counts_i32(s, NB, binblk, partials);  // binblk[NB] = blocks in P order (bins padded to groups)
   hipLaunchKernelGGL(pb_slice_blocks_kernel, dim3((unsigned) cdiv(S + 1, 256)), dim3(256), 0, s, S, NB, aoff, sliceblk);
   std::vector<int32_t> h_sliceblk((size_t) S + 1);
@@ -1086,6 +1270,7 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
   const int64_t a_blocks = h_sliceblk[(size_t) S], p_blocks = h_pblocks;
   pl->a_blocks = a_blocks;
   pl->p_blocks = p_blocks;
+  constexpr int PB_BLK = pb_geom<T>::BLK, PB_GBLK = pb_geom<T>::GBLK;
   const int64_t a_pad = a_blocks * PB_BLK, p_pad = p_blocks * PB_BLK;
   // 32-bit entry indices in the expand, 32-bit byte offsets into the product stream in the reduce; and the
   // padded copy must stay a small multiple of the matrix (runs of a few entries pad to a whole block: a matrix
@@ -1209,20 +1394,20 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
                        (size_t) PB_STAGE_LDS - 64, s, m, rowptr, pl->colind, static_cast<const T*>(values_p), W, H, S,
                        NB, cnt, aoff, prel, binblk, static_cast<T*>(pl->s_values),
                        reinterpret_cast<uint16_t*>(pl->s_colind), pl->s_lrow, reinterpret_cast<int32_t*>(pl->s_perm),
-                       static_cast<int32_t*>(pl->s_blkdst), pl->hub_len, cap, rt_len);
+                       static_cast<int32_t*>(pl->s_blkdst), pl->hub_len, cap, rt_len, binrow);
   } else {
     SPB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pb_scatter_kernel<T, O>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8));
     hipLaunchKernelGGL((pb_scatter_kernel<T, O>), dim3((unsigned) NB), dim3(256), (size_t) S * 8, s, m, rowptr,
                        pl->colind, static_cast<const T*>(values_p), W, H, S, NB, aoff, prel, binblk,
                        static_cast<T*>(pl->s_values), reinterpret_cast<uint16_t*>(pl->s_colind), pl->s_lrow,
-                       reinterpret_cast<int32_t*>(pl->s_perm), static_cast<int32_t*>(pl->s_blkdst), pl->hub_len);
+                       reinterpret_cast<int32_t*>(pl->s_perm), static_cast<int32_t*>(pl->s_blkdst), pl->hub_len, binrow);
   }
   tr.mark("scatter");
   SPB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pb_flag_dups_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, PB_LDS_BYTES + 16 * 1024));
   hipLaunchKernelGGL(pb_flag_dups_kernel, dim3((unsigned) cdiv(NB, PB_FWAVES)), dim3(PB_FTHREADS),
-                     (size_t) PB_FWAVES * (size_t) ((H + 63) & ~63), s, H, (int64_t) NB, binblk, pl->s_lrow);
+                     (size_t) PB_FWAVES * (size_t) ((H + 63) & ~63), s, H, (int64_t) NB, binblk, pl->s_lrow, PB_GBLK);
   SPB_HIP(hipGetLastError());
   SPB_HIP(hipStreamSynchronize(s));
   tr.mark("flags");
@@ -1245,7 +1430,7 @@ int spmv_sliced_build(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const 
 template <typename T>
 static int sliced_update_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const void* values) {
   pl->values_ptr = values;  // the hub rows read the caller's array directly
-  const int64_t a_pad = pl->a_blocks * PB_BLK;
+  const int64_t a_pad = pl->a_blocks * pb_geom<T>::BLK;
   if (pl->s_placed == 0 || a_pad == 0)
     return SPBLAS_GFX950_STATUS_SUCCESS;
   hipLaunchKernelGGL((pb_update_values_kernel<T>), dim3((unsigned) cdiv(a_pad, 256)), dim3(256), 0, h->stream, a_pad,
@@ -1284,7 +1469,7 @@ static int sliced_expand_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* p
   const int64_t total = pl->a_blocks;
   if (total == 0)
     return SPBLAS_GFX950_STATUS_SUCCESS;
-  const int64_t min_share = std::max<int64_t>(1, 2 * (int64_t) pl->slice_cols / PB_BLK);
+  const int64_t min_share = std::max<int64_t>(1, 2 * (int64_t) pl->slice_cols / pb_geom<T>::BLK);
   if (nwg * min_share > total) {
     // ... but not fewer workgroups than slices (row shards: many slices with few entries each)
     const int64_t floor_wg = pl->n_slices < nwg ? pl->n_slices : nwg;
@@ -1314,7 +1499,7 @@ static int sliced_reduce_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* p
   hipStream_t s = h->stream;
   if (wb_end <= wb_begin)
     return SPBLAS_GFX950_STATUS_SUCCESS;
-  if (peers_p && pl->hub_len > 0 && pl->n_long > 0)
+  if (peers_p && pl->hub_len > 0 && pl->n_hub > 0)
     return SPBLAS_GFX950_STATUS_NOT_SUPPORTED;  // the fused all-gather epilogue does not cover hub rows
   const T alpha = *static_cast<const T*>(alpha_p), beta = *static_cast<const T*>(beta_p);
   const int RW = pl->rwaves;
@@ -1322,11 +1507,12 @@ static int sliced_reduce_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* p
   if (UB != 2 && UB != 8)
     UB = 4;
   const int64_t groups = cdiv(wb_end - wb_begin, RW);
-  int K = pick_ksplit(wb_end - wb_begin, pl->n_rblk > 0 ? pl->p_blocks / PB_GBLK / pl->n_rblk : 0);
+  int K = pick_ksplit(wb_end - wb_begin, pl->n_rblk > 0 ? pl->p_blocks / pb_geom<T>::GBLK / pl->n_rblk : 0);
   if (h->max_ksplit > 0 && K > h->max_ksplit)
     K = (int) h->max_ksplit;  // striped callers run several reduces side by side
-  const int64_t r_lo = wb_begin * pl->rows_per_blk;
-  const int64_t r_hi = wb_end * pl->rows_per_blk < pl->m ? wb_end * pl->rows_per_blk : pl->m;
+  const int64_t r_lo = pl->h_binrow ? pl->h_binrow[wb_begin] : wb_begin * pl->rows_per_blk;
+  const int64_t r_hi = pl->h_binrow ? pl->h_binrow[wb_end]
+                                    : (wb_end * pl->rows_per_blk < pl->m ? wb_end * pl->rows_per_blk : pl->m);
   const bool use_items = pl->s_ritems && !peers_p && wb_begin == 0 && wb_end == pl->n_rblk;
   if (!use_items && K > 1 && pl->s_partial_k < K) {  // grow the partial-sum workspace (stream ordered)
     dev_free(pl->s_partial, s);
@@ -1348,8 +1534,9 @@ static int sliced_reduce_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* p
     T* const* peers = reinterpret_cast<T* const*>(peers_p);
     const int4* ritems = nullptr;
     int dbg = env_int("SPBLAS_GFX950_PB_DBG", 0);
+    const int32_t* binrow = static_cast<const int32_t*>(pl->s_binrow);
     void* args[] = {&mm, &Hw, &wb_begin, &wb_end, &binblk, &Pp, &rowp, &yp, &a, &b, &Kk, &part, &pstride,
-                    &peers, &n_peers, &peer_off, &ritems, &dbg};
+                    &peers, &n_peers, &peer_off, &ritems, &dbg, &binrow};
     const size_t lds = (size_t) RW * (pl->rows_per_blk + 64) * sizeof(T);
     if (use_items) {
       // row-skewed matrix, whole range: explicit work list (built at inspect), compact partial sums
@@ -1361,7 +1548,8 @@ static int sliced_reduce_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* p
         hipLaunchKernelGGL((pb_combine_items_kernel<T>),
                            dim3((unsigned) pl->n_rsplit, (unsigned) cdiv((int64_t) RW * pl->rows_per_blk, 256)), dim3(256),
                            0, s, static_cast<const int4*>(pl->s_rsplit), (int64_t) RW * pl->rows_per_blk, pl->m,
-                           static_cast<const T*>(pl->s_rpartial), static_cast<T*>(y), alpha, beta);
+                           static_cast<const T*>(pl->s_rpartial), static_cast<T*>(y), alpha, beta, pl->rows_per_blk,
+                           binrow, pl->n_rblk);
     } else {
       SPB_HIP(hipLaunchKernel(pb_reduce_fn<T>(RW, UB), dim3((unsigned) groups, (unsigned) K), dim3(RW * 64), args, lds, s));
       if (K > 1 && r_hi > r_lo)
@@ -1370,24 +1558,25 @@ static int sliced_reduce_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* p
                            reinterpret_cast<T* const*>(peers_p), n_peers, peer_off);
     }
   }
-  if (pl->hub_len > 0 && pl->n_long > 0) {
+  if (pl->hub_len > 0 && pl->n_hub > 0) {
     // rows kept out of the tiles: y[row] += alpha * (row . x), for the rows of this bin range
     if (!pl->values_ptr || !pl->last_x)
       return SPBLAS_GFX950_STATUS_INVALID_VALUE;
     if (!pl->s_hub_part)
       return SPBLAS_GFX950_STATUS_INVALID_VALUE;
-    const dim3 grid((unsigned) pl->n_long, (unsigned) pl->hub_parts);
+    const dim3 grid((unsigned) pl->n_hub, (unsigned) pl->hub_parts);
     T* part = static_cast<T*>(pl->s_hub_part);
+    const int32_t* hub_rows = static_cast<const int32_t*>(pl->s_hub_rows);
     if (pl->offset_type == SPBLAS_GFX950_I32)
-      hipLaunchKernelGGL((pb_hub_rows_kernel<T, int32_t>), grid, dim3(256), 0, s, pl->n_long, pl->long_rows,
+      hipLaunchKernelGGL((pb_hub_rows_kernel<T, int32_t>), grid, dim3(256), 0, s, pl->n_hub, hub_rows,
                          static_cast<const int32_t*>(pl->rowptr), pl->colind, static_cast<const T*>(pl->values_ptr),
                          static_cast<const T*>(pl->last_x), part, r_lo, r_hi);
     else
-      hipLaunchKernelGGL((pb_hub_rows_kernel<T, int64_t>), grid, dim3(256), 0, s, pl->n_long, pl->long_rows,
+      hipLaunchKernelGGL((pb_hub_rows_kernel<T, int64_t>), grid, dim3(256), 0, s, pl->n_hub, hub_rows,
                          static_cast<const int64_t*>(pl->rowptr), pl->colind, static_cast<const T*>(pl->values_ptr),
                          static_cast<const T*>(pl->last_x), part, r_lo, r_hi);
-    hipLaunchKernelGGL((pb_hub_finish_kernel<T>), dim3((unsigned) cdiv(pl->n_long, 256)), dim3(256), 0, s, pl->n_long,
-                       pl->hub_parts, pl->long_rows, part, static_cast<T*>(y), alpha, r_lo, r_hi);
+    hipLaunchKernelGGL((pb_hub_finish_kernel<T>), dim3((unsigned) cdiv(pl->n_hub, 256)), dim3(256), 0, s, pl->n_hub,
+                       pl->hub_parts, hub_rows, part, static_cast<T*>(y), alpha, r_lo, r_hi);
   }
   SPB_HIP(hipGetLastError());
   return SPBLAS_GFX950_STATUS_SUCCESS;
@@ -1397,7 +1586,7 @@ static int sliced_reduce_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* p
 // callers that reduce stripe by stripe on several streams cap K with it (handle->max_ksplit) and
 // reserve the workspace before they fork, so no stripe allocates.
 int spmv_sliced_full_ksplit(spblas_gfx950_plan_s* pl) {
-  return pick_ksplit(pl->n_rblk, pl->n_rblk > 0 ? pl->p_blocks / PB_GBLK / pl->n_rblk : 0);
+  return pick_ksplit(pl->n_rblk, pl->n_rblk > 0 ? pl->p_blocks / (PB_GRP / pb_blk_of(pl->value_type)) / pl->n_rblk : 0);
 }
 
 int spmv_sliced_reserve_partial(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, int K) {
@@ -1425,8 +1614,13 @@ int spmv_sliced_reduce_rows(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, 
                             void* y, int64_t row_begin, int64_t row_end, void* const* peers, int n_peers,
                             int64_t peer_off) {
   const int64_t H = pl->rows_per_blk;
-  const int64_t wb0 = cdiv(row_begin, H);
+  int64_t wb0 = cdiv(row_begin, H);
   int64_t wb1 = cdiv(row_end, H);
+  if (pl->h_binrow) {  // variable bins: first bin whose first row is >= the bound
+    const int32_t* br = pl->h_binrow;
+    wb0 = std::lower_bound(br, br + pl->n_rblk, (int32_t) std::min<int64_t>(row_begin, pl->m)) - br;
+    wb1 = std::lower_bound(br, br + pl->n_rblk, (int32_t) std::min<int64_t>(row_end, pl->m)) - br;
+  }
   if (wb1 > pl->n_rblk)
     wb1 = pl->n_rblk;
   return pl->value_type == SPBLAS_GFX950_F32
@@ -1455,6 +1649,15 @@ void spmv_sliced_free(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl) {
   dev_free(pl->s_products, s);
   dev_free(pl->s_partial, s);
   dev_free(pl->s_hub_part, s);
+  dev_free(pl->s_binrow, s);
+  pl->s_binrow = nullptr;
+  delete[] pl->h_binrow;
+  pl->h_binrow = nullptr;
+  if (pl->hub_rows_owned)
+    dev_free(pl->s_hub_rows, s);
+  pl->s_hub_rows = nullptr;
+  pl->n_hub = 0;
+  pl->hub_rows_owned = false;
   dev_free(pl->s_xitems, s);
   dev_free(pl->s_ritems, s);
   dev_free(pl->s_rsplit, s);

@@ -18,6 +18,10 @@ from oracle import oracle
 from spblas_reference_amd import _capi, generate
 
 pytestmark = pytest.mark.gpu
+
+
+def cdiv(a, b):
+    return -(-a // b)
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 ALGS = {"noplan": None, "auto": _capi.SPMV_AUTO, "vector": _capi.SPMV_VECTOR, "rowblock": _capi.SPMV_ROWBLOCK,
         "sliced": _capi.SPMV_SLICED}
@@ -412,10 +416,14 @@ def test_spmv_sliced_with_a_few_dense_rows(gpu):
           ref_cmp=False)
 
 
-def test_spmv_auto_declines_sliced_for_skewed_matrices(gpu):
+@pytest.mark.parametrize("varbins", ["0", "1"])
+def test_spmv_auto_declines_sliced_for_skewed_matrices(gpu, monkeypatch, varbins):
     """Hot columns (one slice carries most entries) or a heavy block of rows (one bin group does): the
     sliced plan would leave the chip waiting for a single workgroup, so AUTO must keep the row-block
-    kernel; a forced SLICED plan must still be correct."""
+    kernel; a forced SLICED plan must still be correct.  With variable-height bins (the default for row-skewed
+    matrices; SPBLAS_GFX950_PB_VARBINS=0 keeps the arithmetic bins and their reduce work list under test) the
+    heavy block of rows is spread over many bins and AUTO may take either plan."""
+    monkeypatch.setenv("SPBLAS_GFX950_PB_VARBINS", varbins)
     rng = np.random.default_rng(33)
     m, n, per = 400000, 2000000, 8
     rowptr = (np.arange(m + 1, dtype=np.int64) * per).astype(np.int32)
@@ -447,13 +455,18 @@ def test_spmv_auto_declines_sliced_for_skewed_matrices(gpu):
     xd = G.dev(x)
     y = torch.full((m,), float("nan"), device="cuda")
     info = sp.multiply_inspect(sp.matrix_opt(a), xd, y)
-    assert info.state_.info()["alg"] == _capi.SPMV_ROWBLOCK
+    if varbins == "0":
+        assert info.state_.info()["alg"] == _capi.SPMV_ROWBLOCK
     sp.multiply(info, a, xd, y)
     check(val2, rowptr2, col2, (m, n), x, G.host(y), what="heavy row block (auto)", ref_cmp=False)
     # forced SLICED: the reduce runs from its work list (heavy bin groups split over several workgroups,
     # pb_combine_items_kernel sums their partial rows); a row-range call takes the uniform path instead
     info = sp.multiply_inspect(a, xd, y, alg=_capi.SPMV_SLICED)
-    assert info.state_.info()["reduce_items"] > 0
+    if varbins == "0":
+        assert info.state_.info()["reduce_items"] > 0 and info.state_.sliced_info()["variable_bins"] == 0
+    else:
+        si = info.state_.sliced_info()
+        assert si["variable_bins"] == 1 and si["n_bins"] > cdiv(m, info.state_.info()["rows_per_bin"])
     y.fill_(float("nan"))
     sp.multiply(info, sp.scaled(0.5, a), xd, y)
     check(val2, rowptr2, col2, (m, n), x, G.host(y), scale=0.5, what="heavy row block (forced sliced)",
