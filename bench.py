@@ -193,7 +193,8 @@ def build_rmat(args, world, rank, device, sharded, sp):
     torch.cuda.empty_cache()
     label = f"cfg4: fp64 CSR SpMV, R-MAT scale {scale}, edge factor 16, duplicates kept, rows sharded by nnz prefix"
     return {"m": m, "n": n, "dtype": torch.float64, "tsize": 8, "chunks": 1, "ranges": None, "a_chunks": [a_local],
-            "nnz_local": a_local.size(), "label": label, "dtype_name": "f64", "bounds": bounds, "pmc_key": None}
+            "nnz_local": a_local.size(), "label": label, "dtype_name": "f64", "bounds": bounds,
+            "pmc_key": "spmv_rmat" if world == 1 else None}
 
 
 def main():

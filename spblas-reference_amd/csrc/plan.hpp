@@ -70,6 +70,9 @@ struct spblas_gfx950_plan_s {
   void* s_hub_rows = nullptr;  // int32[n_hub] rows kept out of the tiles (== long_rows unless variable bins raise the threshold)
   int64_t n_hub = 0;
   bool hub_rows_owned = false;
+  // AUTO: the static rules could not tell which plan is faster (hot columns / heavy rows): plan_create times both
+  int s_uncertain = 0;
+  float trial_ms[2] = {0.f, 0.f};  // {row-block, sliced} when the trial ran
 
   // SpMM inspect (spblas_gfx950_spmm_inspect, spmm.hip): row blocks of 32 rows whose entries fall into at most 16
   // aligned tiles of 128 columns, densely enough, are multiplied from LDS-staged B tiles on the matrix cores

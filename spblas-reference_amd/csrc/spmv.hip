@@ -17,6 +17,8 @@
 #include "common.hpp"
 #include "plan.hpp"
 
+#include <cstdlib>
+
 namespace spb {
 
 // ---------------------------------------------------------------------------
@@ -496,15 +498,76 @@ static int plan_build(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, int al
 // crossover on square 10-per-row matrices: n between 0.5M and 1M columns, tools/auto_sweep.sh), the
 // matrix is big enough to amortise two launches, rows are short (LDS atomics serialise on
 // hub rows) and the average (slice, bin) segment keeps a wavefront busy.
+static int env_int_spmv(const char* name, int def) {
+  const char* v = std::getenv(name);
+  return v && *v ? std::atoi(v) : def;
+}
+
 static bool sliced_candidate(const spblas_gfx950_plan_s* pl) {
   const size_t tsz = pl->value_type == SPBLAS_GFX950_F32 ? 4 : 8;
   const double tile = 80.0 * 1024 / tsz;
   const double nseg = (pl->n / tile + 1) * (pl->m / tile + 1);
   return (size_t) pl->n * tsz >= ((size_t) 3 << 20) && pl->nnz >= ((int64_t) 2 << 20) &&
          pl->nnz < INT32_MAX - 8 && (double) pl->nnz / nseg >= 48.0 &&
-         // rows longer than the window are kept out of the tiles and handled by pb_hub_rows_kernel; a few
-         // dense rows are fine, a matrix living in its hub rows (power law) is not
-         (pl->max_row_len <= 4096 || (pl->n_long <= 65536 && pl->long_nnz * 4 <= pl->nnz));
+         // rows longer than the window: a few dense rows are fine; a matrix living in its long rows (power law) gets
+         // variable-height bins and is decided by the timed trial (below) -- unless trials are switched off
+         (pl->max_row_len <= 4096 || (pl->n_long <= 65536 && pl->long_nnz * 4 <= pl->nnz) ||
+          env_int_spmv("SPBLAS_GFX950_AUTO_TRIAL", 1) != 0);
+}
+
+// AUTO trial: both plans exist; multiply a zero vector twice with each (the traffic does not depend on the values of x)
+// and keep the faster.  *sliced_wins is left true when anything about the trial itself fails.
+static int auto_trial(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const void* values, bool* sliced_wins) {
+  *sliced_wins = true;
+  hipStream_t s = h->stream;
+  const size_t tsz = pl->value_type == SPBLAS_GFX950_F32 ? 4 : 8;
+  void *x = nullptr, *y = nullptr;
+  if (dev_alloc(&x, (size_t) pl->n * tsz, s) != SPBLAS_GFX950_STATUS_SUCCESS)
+    return SPBLAS_GFX950_STATUS_SUCCESS;
+  if (dev_alloc(&y, (size_t) pl->m * tsz, s) != SPBLAS_GFX950_STATUS_SUCCESS) {
+    dev_free(x, s);
+    return SPBLAS_GFX950_STATUS_SUCCESS;
+  }
+  hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+  bool ok = hipMemsetAsync(x, 0, (size_t) pl->n * tsz, s) == hipSuccess;
+  for (int i = 0; i < 3 && ok; ++i)
+    ok = hipEventCreate(&ev[i]) == hipSuccess;
+  const double one = 1.0, zero = 0.0;
+  const float onef = 1.f, zerof = 0.f;
+  const void* alpha = tsz == 4 ? (const void*) &onef : (const void*) &one;
+  const void* beta = tsz == 4 ? (const void*) &zerof : (const void*) &zero;
+  auto run = [&](int alg) {
+    const int saved = pl->alg;
+    pl->alg = alg;
+    const int rc = spblas_gfx950_spmv(h, pl, SPBLAS_GFX950_OP_N, pl->m, pl->n, pl->nnz, alpha, pl->rowptr, pl->colind, values, x,
+                                      beta, y, pl->offset_type, pl->value_type);
+    pl->alg = saved;
+    return rc;
+  };
+  float best[2] = {1e30f, 1e30f};
+  const int algs[2] = {SPBLAS_GFX950_SPMV_ROWBLOCK, SPBLAS_GFX950_SPMV_SLICED};
+  for (int a = 0; a < 2 && ok; ++a) {
+    ok = run(algs[a]) == SPBLAS_GFX950_STATUS_SUCCESS;  // warm-up (first launch of the kernels, workspace growth)
+    for (int rep = 0; rep < 2 && ok; ++rep) {
+      ok = hipEventRecord(ev[0], s) == hipSuccess && run(algs[a]) == SPBLAS_GFX950_STATUS_SUCCESS &&
+           hipEventRecord(ev[1], s) == hipSuccess && hipEventSynchronize(ev[1]) == hipSuccess;
+      float ms = 0.f;
+      if (ok && hipEventElapsedTime(&ms, ev[0], ev[1]) == hipSuccess && ms < best[a])
+        best[a] = ms;
+    }
+  }
+  (void) hipStreamSynchronize(s);
+  for (int i = 0; i < 3; ++i)
+    if (ev[i])
+      (void) hipEventDestroy(ev[i]);
+  dev_free(x, s);
+  dev_free(y, s);
+  if (ok) {
+    pl->trial_ms[0] = best[0];
+    pl->trial_ms[1] = best[1];
+    *sliced_wins = best[1] < 0.95f * best[0];  // the re-tiled copy costs memory: it has to win clearly
+  }
+  return SPBLAS_GFX950_STATUS_SUCCESS;
 }
 
 } // namespace spb
@@ -556,7 +619,13 @@ int spblas_gfx950_spmv_plan_create(spblas_gfx950_handle_t handle, spblas_gfx950_
     // declines (NOT_SUPPORTED) when the entries cluster in few tiles.
     const int rc2 = spmv_sliced_build(handle, pl, values, true);
     if (rc2 == SPBLAS_GFX950_STATUS_SUCCESS) {
-      pl->alg = SPBLAS_GFX950_SPMV_SLICED;
+      bool keep = true;
+      if (pl->s_uncertain)
+        (void) auto_trial(handle, pl, values, &keep);
+      if (keep)
+        pl->alg = SPBLAS_GFX950_SPMV_SLICED;
+      else
+        spmv_sliced_free(handle, pl);
     } else {
       spmv_sliced_free(handle, pl);
       if (rc2 != SPBLAS_GFX950_STATUS_NOT_SUPPORTED)

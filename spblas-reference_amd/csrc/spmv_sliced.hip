@@ -1263,8 +1263,15 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
     // workgroup: decline when the heaviest slice or group carries more than 6x the average.
     const double mean_slice = (double) placed_total / (double) S, mean_group = (double) placed_total / (double) ngroups;
     if (placed_total > 0 &&
-        ((double) max_slice > 6.0 * mean_slice + 65536.0 || (double) max_group > 6.0 * mean_group + 65536.0))
-      return SPBLAS_GFX950_STATUS_NOT_SUPPORTED;
+        ((double) max_slice > 6.0 * mean_slice + 65536.0 || (double) max_group > 6.0 * mean_group + 65536.0)) {
+      // Round 2: the expand spreads a heavy slice over as many workgroups as its share asks for and variable-height
+      // bins flatten heavy rows, so such a matrix CAN run well here (R-MAT scale 24 fp64: 2.4 vs 3.4 ms) -- but hot
+      // columns also serve the row-block kernel from L2.  No static rule separates the two: the plan is finished
+      // and plan_create times it against the row-block kernel.
+      if (!env_int("SPBLAS_GFX950_AUTO_TRIAL", 1))
+        return SPBLAS_GFX950_STATUS_NOT_SUPPORTED;
+      pl->s_uncertain = 1;
+    }
   }
   tr.mark("probe + block offsets read back");
   const int64_t a_blocks = h_sliceblk[(size_t) S], p_blocks = h_pblocks;
@@ -1348,8 +1355,9 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
     // streams are cut into as many equal parts as its share of the entries asks for; split groups write partial
     // rows into a compact buffer and pb_combine_items_kernel adds them in part order (bit reproducible).
     const int64_t total = (int64_t) placed_total, max_tot = (int64_t) max_group;
-    if (total > 0 && max_tot * ngroups > 3 * total && ngroups > 1) {
-      const int64_t target = std::max<int64_t>(total / 768, 16384);
+    const int force_items = env_int("SPBLAS_GFX950_PB_RITEMS", 0);  // experiment: work list whatever the skew; value = parts per 1/768 of the entries
+    if (total > 0 && (max_tot * ngroups > 3 * total || force_items > 0) && ngroups > 1) {
+      const int64_t target = std::max<int64_t>(total / (768 * (force_items > 0 ? force_items : 1)), 16384);
       const int64_t block = (int64_t) RW * H;  // values per partial block
       std::vector<int4> items, split;
       int64_t poff = 0;

@@ -150,7 +150,7 @@ def test_cfg3_spmm_rmat_hub_rows(gpu):
 
 
 # --------------------------------------------------------------------------------------------- cfg4
-@pytest.mark.parametrize("alg", ["auto", "sliced"])
+@pytest.mark.parametrize("alg", ["auto", "rowblock", "sliced"])
 def test_cfg4_spmv_rmat_scale24_f64(gpu, alg):
     """BASELINE cfg4 (single-GPU leg; the row-sharded leg is bench.py --gpus N --workload spmv_rmat and
     tests/test_sharded_cpu.py): fp64 CSR SpMV on an R-MAT graph of 2^24 vertices, edge factor 16, 268 M
@@ -165,8 +165,15 @@ def test_cfg4_spmv_rmat_scale24_f64(gpu, alg):
     x2 = torch.rand(n, dtype=torch.float64, device="cuda", generator=g)
     y1, y2, y3 = (torch.full((m,), float("nan"), dtype=torch.float64, device="cuda") for _ in range(3))
     if alg == "auto":
+        # power-law rows and hot columns: no static rule -- AUTO builds the sliced plan (variable-height bins) and
+        # keeps whichever of it and the row-block kernel was faster in its timed trial
         info = sp.multiply_inspect(sp.matrix_opt(a), x1, y1)
-        # power-law rows: AUTO keeps the row-block kernel with long-row splitting
+        pi = info.state_.info()
+        assert pi["alg"] in (_capi.SPMV_ROWBLOCK, _capi.SPMV_SLICED) and pi["n_long_rows"] > 1000
+        if pi["alg"] == _capi.SPMV_SLICED:
+            assert info.state_.sliced_info()["variable_bins"] == 1
+    elif alg == "rowblock":
+        info = sp.multiply_inspect(a, x1, y1, alg=_capi.SPMV_ROWBLOCK)
         assert info.state_.info()["alg"] == _capi.SPMV_ROWBLOCK and info.state_.info()["n_long_rows"] > 1000
     else:
         info = sp.multiply_inspect(a, x1, y1, alg=_capi.SPMV_SLICED)
