@@ -142,6 +142,8 @@ int spblas_gfx950_spmv_plan_create(spblas_gfx950_handle_t handle, spblas_gfx950_
                                    int value_type, int alg);
 int spblas_gfx950_spmv_plan_update_values(spblas_gfx950_handle_t handle, spblas_gfx950_plan_t plan,
                                           const void* values);
+/* A plan carries workspaces (products, partial sums): it must not run on two streams at once.  plan_destroy frees on
+ * the handle's current stream, ordered behind the last launch that used the plan on whichever stream that was. */
 int spblas_gfx950_plan_destroy(spblas_gfx950_handle_t handle, spblas_gfx950_plan_t plan);
 /* Introspection for tests/bench: info[0]=alg, [1]=window nnz, [2]=#windows,
  * [3]=#long rows, [4]=max row length, [5]=device bytes held, [6]=#column slices,

@@ -297,11 +297,17 @@ class _Plan:
         a, b = ct(alpha), ct(beta)
         h, p, xp, yp = self.handle.h, self.plan, ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(y_base_ptr)
         keep = (a, b, x)
+        # the stream that is current NOW: every other API call re-binds the handle to the then-current stream, so
+        # the bound callables put the handle back on theirs before they launch
+        stream = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+        set_stream = lib.spblas_gfx950_set_stream
 
         def expand():
+            set_stream(h, stream)
             check(lib.spblas_gfx950_spmv_expand(h, p, xp), "spmv_expand")
 
         def reduce_rows(lo, hi, _keep=keep):
+            set_stream(h, stream)
             check(lib.spblas_gfx950_spmv_reduce_rows(h, p, ctypes.byref(a), ctypes.byref(b), yp, lo, hi),
                   "spmv_reduce_rows")
 
@@ -599,13 +605,17 @@ def _spmv(info, a, b, c, prepare_only=False):
 
 class prepared_multiply:
     """multiply(info, a, x, y) validated and bound ONCE; calling the object re-issues the same
-    SpMV on the stream that was current at construction.  For solver-style loops where the Python
-    host layer (view unwrapping, checks: tens of microseconds) would otherwise cost more than the
-    kernel.  The operands must stay the same tensors; their contents may change between calls."""
+    SpMV on the stream that was current at construction (the handle is put back on that stream before every
+    launch: other API calls re-bind it to whatever stream is current when they run).  For solver-style loops
+    where the Python host layer (view unwrapping, checks: tens of microseconds) would otherwise cost more than the
+    kernel.  The operands must stay the same tensors; their contents may change between calls.  A plan carries
+    workspaces and must not run on two streams at once."""
 
     def __init__(self, info, a, x, y):
         self._args, self._keep = _spmv(info, a, x, y, prepare_only=True)
         self._fn = _capi.lib().spblas_gfx950_spmv
+        self._set_stream = _capi.lib().spblas_gfx950_set_stream
+        self._stream = ctypes.c_void_p(torch.cuda.current_stream(y.device).cuda_stream)
         a_base = get_ultimate_base(a)
         self._plan = self._keep[2]
         self._values = a_base.values() if isinstance(a_base, csr_view) else None
@@ -613,6 +623,7 @@ class prepared_multiply:
     def __call__(self):
         if self._plan is not None and self._plan.snapshot and self._values is not None:
             self._plan.refresh_if_stale(self._values)
+        self._set_stream(self._args[0], self._stream)
         rc = self._fn(*self._args)
         if rc:
             check(rc, "multiply")

@@ -70,6 +70,10 @@ struct spblas_gfx950_plan_s {
   void* s_hub_rows = nullptr;  // int32[n_hub] rows kept out of the tiles (== long_rows unless variable bins raise the threshold)
   int64_t n_hub = 0;
   bool hub_rows_owned = false;
+  // the stream of the last launch that used the plan's workspaces: plan_destroy orders its frees behind it.  (A plan
+  // carries mutable workspaces -- products, partial sums, long-row partials -- and must not run on two streams at once.)
+  hipStream_t last_stream = nullptr;
+  bool used = false;
   // AUTO: the static rules could not tell which plan is faster (hot columns / heavy rows): plan_create times both
   int s_uncertain = 0;
   float trial_ms[2] = {0.f, 0.f};  // {row-block, sliced} when the trial ran

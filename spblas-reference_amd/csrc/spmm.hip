@@ -673,6 +673,10 @@ extern "C" int spblas_gfx950_spmm(spblas_gfx950_handle_t handle, spblas_gfx950_p
   if (plan && (plan->m != m || plan->n != k || plan->nnz != nnz || plan->rowptr != rowptr ||
                plan->colind != colind || plan->offset_type != offset_type || plan->value_type != value_type))
     return SPBLAS_GFX950_STATUS_PLAN_MISMATCH;
+  if (plan) {  // the long-row partials are the plan's
+    plan->last_stream = handle->stream;
+    plan->used = true;
+  }
   if (value_type == SPBLAS_GFX950_F32) {
     return offset_type == SPBLAS_GFX950_I32
                ? spmm_typed<float, int32_t>(handle, plan, m, k, n, nnz, alpha, rowptr, colind, values, B, ldb, beta, C, ldc)

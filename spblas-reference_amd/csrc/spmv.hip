@@ -420,6 +420,8 @@ static int spmv_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, int op
     return spmv_sliced_exec(h, pl, alpha_p, x_p, beta_p, y_p);
 
   if (pl && pl->alg == SPBLAS_GFX950_SPMV_ROWBLOCK) {
+    pl->last_stream = s;  // part_head / part_tail are the plan's
+    pl->used = true;
     if (pl->n_long > 0) {
       launch_rowblock<T, O, true>(s, pl, rowptr, colind, values, x, y, alpha, beta);
       hipLaunchKernelGGL((spmv_long_fixup_kernel<T, O>), dim3((unsigned) pl->n_long), dim3(64), 0, s,
@@ -758,6 +760,18 @@ int spblas_gfx950_plan_destroy(spblas_gfx950_handle_t handle, spblas_gfx950_plan
   if (!plan)
     return SPBLAS_GFX950_STATUS_SUCCESS;
   hipStream_t s = handle->stream;
+  if (plan->used && plan->last_stream != s) {
+    // the frees below are ordered on the handle's stream: put them behind the last launch that used the plan
+    hipEvent_t ev = nullptr;
+    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess) {
+      if (hipEventRecord(ev, plan->last_stream) != hipSuccess || hipStreamWaitEvent(s, ev, 0) != hipSuccess)
+        (void) hipStreamSynchronize(plan->last_stream);
+      (void) hipEventDestroy(ev);
+    } else {
+      (void) hipStreamSynchronize(plan->last_stream);
+    }
+    (void) hipGetLastError();
+  }
   dev_free(plan->win_row, s);
   dev_free(plan->long_rows, s);
   dev_free(plan->part_head, s);

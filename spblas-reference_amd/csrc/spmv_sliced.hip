@@ -1468,6 +1468,8 @@ static int pick_ksplit(int64_t waves, int64_t steps_per_bin) {
 template <typename T>
 static int sliced_expand_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const void* x) {
   pl->last_x = x;  // the hub rows are computed in the reduce stage and gather x themselves
+  pl->last_stream = h->stream;
+  pl->used = true;
   // one wave of workgroups (2 per CU with 80 KiB slices, 1 with 160 KiB), but never shares so small that
   // re-loading the x slice dominates
   const int4* items = static_cast<const int4*>(pl->s_xitems);
@@ -1507,6 +1509,8 @@ static int sliced_reduce_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* p
   hipStream_t s = h->stream;
   if (wb_end <= wb_begin)
     return SPBLAS_GFX950_STATUS_SUCCESS;
+  pl->last_stream = s;
+  pl->used = true;
   if (peers_p && pl->hub_len > 0 && pl->n_hub > 0)
     return SPBLAS_GFX950_STATUS_NOT_SUPPORTED;  // the fused all-gather epilogue does not cover hub rows
   const T alpha = *static_cast<const T*>(alpha_p), beta = *static_cast<const T*>(beta_p);

@@ -253,6 +253,43 @@ def test_spmv_values_changed_in_place(gpu):
                   ref_cmp=False)
 
 
+def test_prepared_calls_keep_their_stream_and_plans_die_in_stream_order(gpu):
+    """prepared_multiply / bind_stages launch on the stream that was current when they were made, although every other
+    API call re-binds the handle to the stream current at ITS call; a plan destroyed while the handle sits on another
+    stream frees its workspaces behind the last launch that used them (spblas_gfx950_plan_destroy)."""
+    rng = np.random.default_rng(17)
+    m, n, per = 300000, 1_200_000, 8
+    rowptr = (np.arange(m + 1, dtype=np.int64) * per).astype(np.int32)
+    nnz = m * per
+    colind = rng.integers(0, n, nnz).astype(np.int32)
+    values = (rng.random(nnz) + 0.5).astype(np.float32)
+    x = (rng.random(n) + 0.5).astype(np.float32)
+    a = G.csr_on_device(values, rowptr, colind, (m, n), nnz)
+    xd = G.dev(x)
+    y = torch.full((m,), float("nan"), device="cuda")
+    y2 = torch.full((m,), float("nan"), device="cuda")
+    small = G.csr_on_device(values[:80], rowptr[:11], (colind[:80] % 50).astype(np.int32), (10, 50), 80)
+    xs, ys = G.dev(x[:50]), torch.empty(10, device="cuda")
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        info = sp.multiply_inspect(a, xd, y, alg=_capi.SPMV_SLICED)
+        run = sp.prepared_multiply(info, a, xd, y)
+        expand, reduce_rows = info.state_.bind_stages(xd, y2.data_ptr(), torch.float32)
+    for _ in range(3):
+        sp.multiply(small, xs, ys)       # the handle now sits on the default stream
+        run()                            # ... and goes back to `side` for the prepared call
+        sp.multiply(small, xs, ys)
+        expand()
+        reduce_rows(0, m)
+    sp.multiply(small, xs, ys)
+    del run, expand, reduce_rows, info    # plan destroyed with the handle on the default stream, work pending on `side`
+    side.synchronize()
+    torch.cuda.synchronize()
+    check(values, rowptr, colind, (m, n), x, G.host(y), what="prepared on a side stream", ref_cmp=False)
+    check(values, rowptr, colind, (m, n), x, G.host(y2), what="bound stages on a side stream", ref_cmp=False)
+
+
 def test_spmv_csc_and_transposed_operand(gpu):
     # y = A x with A given as csc_view, and y = A^T x via transposed(csr)
     # (vendor/rocsparse/detail/get_transpose.hpp:19-29; test/gtest/spmv_test.cpp:110-208)
