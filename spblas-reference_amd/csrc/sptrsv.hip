@@ -1061,7 +1061,14 @@ int spblas_gfx950_sptrsv_create(spblas_gfx950_handle_t handle, spblas_gfx950_trs
     (void) hipGetDevice(&dev);
     if (hipDeviceGetAttribute(&coop_attr, hipDeviceAttributeCooperativeLaunch, dev) != hipSuccess)
       coop_attr = 0;
-    pl->coop_ok = coop_attr != 0 && !selfsched && env_int("SPBLAS_GFX950_TRSV_COOP", 1) != 0 &&
+    // An HSA tool that intercepts queues (rocprofv3 of ROCm 7.2) crashes in its exit handlers once the process has
+    // used the cooperative queue (SIGSEGV after the tool has written its output): with such a tool loaded the
+    // default falls back to one launch per level; SPBLAS_GFX950_TRSV_COOP=1 forces the cooperative kernel anyway
+    // (that is how profiles/ shows it), =0 switches it off.
+    const char* tool = std::getenv("ROCP_TOOL_LIBRARIES");
+    const char* tool2 = std::getenv("HSA_TOOLS_LIB");
+    const bool intercepted = (tool && *tool) || (tool2 && *tool2);
+    pl->coop_ok = coop_attr != 0 && !selfsched && env_int("SPBLAS_GFX950_TRSV_COOP", intercepted ? 0 : 1) != 0 &&
                   longest_run <= env_int("SPBLAS_GFX950_TRSV_COOP_MAX_RUN", 4096);
   }
   if (!h_chunk_ptr.empty()) {

@@ -250,4 +250,6 @@ def test_alternative_inspect_and_solve_paths(gpu, monkeypatch, mode, upper):
         elif mode == "launch_per_level":
             assert info["launches_per_solve"] > 20
         elif mode in ("default", "coop_small_grid"):
-            assert info["launches_per_solve"] == 1
+            # (under an HSA tool such as rocprofv3 the default falls back to one launch per level, sptrsv.hip)
+            if not (os.environ.get("ROCP_TOOL_LIBRARIES") or os.environ.get("HSA_TOOLS_LIB")):
+                assert info["launches_per_solve"] == 1
