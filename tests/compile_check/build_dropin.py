@@ -1,0 +1,107 @@
+"""Compile-check / run-check infrastructure for the drop-in backend headers (include/spblas/vendor/gfx950/*.hpp).
+
+patched_reference_headers(dst)  applies INTEGRATION.md section 2's edits to a scratch copy of the six reference
+                                headers it names (nothing under /root/reference is written).
+build_dropin_run()              compiles tests/compile_check/dropin_run.cpp -- the reference's own <spblas/spblas.hpp>
+                                with -DSPBLAS_ENABLE_GFX950 -- and links it to libspblas_gfx950.so.  Only where the
+                                reference tree exists (the build container); the binary
+                                (tests/compile_check/_build/dropin_run, git-ignored) travels to the GPU box with the
+                                snapshot and tests/test_gpu_dropin.py runs it there.
+The stubs under tests/compile_check/stubs/ stand in for range-v3's views::zip and for mdspan ONLY so that the
+reference's views and concepts parse; with a vendor backend selected none of the reference's algorithms is compiled in,
+and every expected value in dropin_run.cpp comes from host loops written in that file.  This is not a build of the
+reference, and it pins nothing for the oracle.
+"""
+import os
+import shutil
+import subprocess
+import tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference/include"
+OUT_DIR = os.path.join(HERE, "_build")
+DROPIN_RUN = os.path.join(OUT_DIR, "dropin_run")
+
+
+def _edit(text, anchor, addition, after=True, count=1):
+    assert anchor in text, f"anchor not found: {anchor!r}"
+    return text.replace(anchor, anchor + addition if after else addition + anchor, count)
+
+
+def patched_reference_headers(dst):
+    """INTEGRATION.md section 2, applied to a scratch copy."""
+    def load(rel):
+        with open(os.path.join(REF, rel)) as f:
+            return f.read()
+
+    def store(rel, text):
+        path = os.path.join(dst, rel)
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as f:
+            f.write(text)
+
+    guard_old = "defined(SPBLAS_ENABLE_CUSPARSE)\n#define SPBLAS_VENDOR_BACKEND"
+    guard_new = "defined(SPBLAS_ENABLE_CUSPARSE) || defined(SPBLAS_ENABLE_GFX950)\n#define SPBLAS_VENDOR_BACKEND"
+    # spblas.hpp:3-7 -- the SPBLAS_VENDOR_BACKEND guard
+    t = load("spblas/spblas.hpp")
+    assert guard_old in t
+    store("spblas/spblas.hpp", t.replace(guard_old, guard_new))
+    # algorithms/algorithms.hpp: the CPU multiply / triangular_solve are already excluded by SPBLAS_VENDOR_BACKEND
+    # (:8-11); the CPU scale / add / transpose loops cannot dereference device memory and their signatures are the
+    # ones this backend provides for device operands, so they are excluded for this backend as well
+    t = load("spblas/algorithms/algorithms.hpp")
+    for impl in ("scale_impl", "add_impl", "transpose_impl"):
+        t = t.replace(f"#include <spblas/algorithms/{impl}.hpp>\n",
+                      f"#ifndef SPBLAS_ENABLE_GFX950\n#include <spblas/algorithms/{impl}.hpp>\n#endif\n")
+    assert t.count("#ifndef SPBLAS_ENABLE_GFX950") == 3
+    store("spblas/algorithms/algorithms.hpp", t)
+    # backend/backend.hpp:9-27
+    t = load("spblas/backend/backend.hpp")
+    t = _edit(t, "#ifdef SPBLAS_ENABLE_CUSPARSE\n#include <spblas/vendor/cusparse/cusparse.hpp>\n#endif\n",
+              "\n#ifdef SPBLAS_ENABLE_GFX950\n#include <spblas/vendor/gfx950/gfx950.hpp>\n#endif\n")
+    store("spblas/backend/backend.hpp", t)
+    # detail/types.hpp:6-24
+    t = load("spblas/detail/types.hpp")
+    t = _edit(t, "#ifdef SPBLAS_ENABLE_CUSPARSE\n#include <spblas/vendor/cusparse/types.hpp>\n#endif\n",
+              "\n#ifdef SPBLAS_ENABLE_GFX950\n#include <spblas/vendor/gfx950/index_types.hpp>\n#endif\n")
+    store("spblas/detail/types.hpp", t)
+    # detail/operation_info_t.hpp:22-24 and :100-103
+    t = load("spblas/detail/operation_info_t.hpp")
+    t = _edit(t, "#ifdef SPBLAS_ENABLE_ROCSPARSE\n#include <spblas/vendor/rocsparse/operation_state_t.hpp>\n#endif\n",
+              "\n#ifdef SPBLAS_ENABLE_GFX950\n#include <spblas/vendor/gfx950/detail/backend_calls.hpp>\n#endif\n")
+    t = _edit(t, "#ifdef SPBLAS_ENABLE_ROCSPARSE\npublic:\n  __rocsparse::operation_state_t state_;\n#endif\n",
+              "\n#ifdef SPBLAS_ENABLE_GFX950\npublic:\n  __gfx950::operation_state_t state_;\n#endif\n")
+    store("spblas/detail/operation_info_t.hpp", t)
+    # views/matrix_opt_impl.hpp (optional edit of INTEGRATION.md section 2: plan cache in the matrix_opt)
+    return dst
+
+
+def compile_flags(scratch):
+    return ["-std=c++20", "-Wall", "-Wno-unused-variable", "-DSPBLAS_ENABLE_GFX950", "-D__HIP_PLATFORM_AMD__",
+            "-I", scratch,                                  # the edited copies shadow the originals
+            "-I", os.path.join(ROOT, "include"),             # spblas/vendor/gfx950/*.hpp, spblas_gfx950.h
+            "-I", REF,                                      # the rest of the reference tree, untouched
+            "-I", os.path.join(HERE, "stubs"),               # <range/v3/all.hpp>, <experimental/mdspan> stand-ins
+            "-I", os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "include")]
+
+
+def build_dropin_run(libdir):
+    """Returns the binary's path, or None where the reference tree does not exist."""
+    if not os.path.isdir(REF):
+        return None
+    gxx = shutil.which("g++")
+    if not gxx:
+        raise RuntimeError("g++ not found")
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    os.makedirs(OUT_DIR, exist_ok=True)
+    with tempfile.TemporaryDirectory() as tmp:
+        scratch = patched_reference_headers(os.path.join(tmp, "patched"))
+        cmd = [gxx, "-O1"] + compile_flags(scratch) + [
+            os.path.join(HERE, "dropin_run.cpp"), "-L", libdir, "-lspblas_gfx950", "-L", os.path.join(rocm, "lib"),
+            "-lamdhip64", "-Wl,-rpath,$ORIGIN/../../../spblas-reference_amd/lib", "-Wl,-rpath," + os.path.join(rocm, "lib"),
+            "-o", DROPIN_RUN]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("g++ failed on dropin_run.cpp:\n" + r.stderr[-8000:])
+    return DROPIN_RUN

@@ -1,0 +1,29 @@
+"""-m gpu: the drop-in backend headers RUNNING behind the reference's own API (SURVEY.md section 8 rows a10 / b).
+
+tests/compile_check/_build/dropin_run is tests/compile_check/dropin_run.cpp compiled in the build container against
+the reference tree's <spblas/spblas.hpp> with -DSPBLAS_ENABLE_GFX950 (INTEGRATION.md section 2's edits applied to a
+scratch copy; tests/compile_check/build_dropin.py, called from __graft_entry__.build()).  It calls
+spblas::multiply / multiply_inspect / multiply_compute / multiply_fill / multiply_symbolic_* / multiply_numeric /
+add_inspect / add_compute / transpose / scale / triangular_solve[_inspect] on spblas::csr_view, csc_view,
+transposed(), scaled(), matrix_opt and row-major mdspans over device pointers, exactly as a user of the reference
+would, and checks every result against host loops.  The GPU box has no reference tree: only the binary travels."""
+import os
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "tests", "compile_check", "_build", "dropin_run")
+
+
+def test_dropin_backend_runs_behind_the_reference_api(gpu):
+    if not os.path.exists(BIN):
+        pytest.skip("tests/compile_check/_build/dropin_run was not built (it needs the reference tree: run "
+                    "__graft_entry__.build() in the build container before the snapshot is taken)")
+    r = subprocess.run([BIN], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, f"dropin_run failed:\n{r.stdout[-2000:]}\n{r.stderr[-4000:]}"
+    assert "checks, 0 failed" in r.stdout, r.stdout
+    n = int(r.stdout.split("dropin_run:")[1].split("checks")[0])
+    assert n >= 25, r.stdout
