@@ -121,7 +121,13 @@ typedef enum spblas_gfx950_option {
    * matrix_opt (views/matrix_opt_impl.hpp: the view that owns a vendor-optimised form of the matrix), the
    * same opt-in oneMKL's optimize_* stage gets in vendor/onemkl_sycl/spmm_impl.hpp:48-61.  Asking for
    * alg = SLICED explicitly needs no option. */
-  SPBLAS_GFX950_OPT_VALUE_SNAPSHOT = 3
+  SPBLAS_GFX950_OPT_VALUE_SNAPSHOT = 3,
+  /* value = 1: the caller GUARANTEES that a c_colind array it passes to spblas_gfx950_spgemm_numeric[_addend] still
+   * holds what the previous numeric call on the same state wrote there whenever it is the same address; repeated
+   * fills of one result then leave the column indices alone (cfg5: 1.40 -> 0.94 ms per fill).  Default 0: every
+   * numeric call writes c_colind -- an equal address proves nothing (allocators hand freed addresses out again:
+   * the reference's SpGEMMReuseAndChangePointer test does exactly that, test/gtest/device/spgemm_reuse_test.cpp:325). */
+  SPBLAS_GFX950_OPT_SPGEMM_KEEP_COLIND = 4
 } spblas_gfx950_option;
 int spblas_gfx950_set_option(spblas_gfx950_handle_t handle, int option, int64_t value);
 

@@ -667,7 +667,9 @@ void multiply_symbolic_compute(spgemm_state_t& s, A&& a, B&& b, C&& c) {
 }
 template <typename A, typename B, typename C>
   requires(__detail::has_csr_base<A> && __detail::has_csr_base<B> && __detail::is_csr<std::remove_cvref_t<C>>::value)
-void multiply_symbolic_fill(spgemm_state_t&, A&&, B&&, C&&) {}
+void multiply_symbolic_fill(spgemm_state_t& s, A&& a, B&& b, C&& c) {
+  s.numeric(a, b, c);  // leaves C's structure (rowptr + colind) in the caller's arrays, multiply_spgemm.hpp:147-176
+}
 template <typename A, typename B, typename C>
   requires(__detail::has_csr_base<A> && __detail::has_csr_base<B> && __detail::is_csr<std::remove_cvref_t<C>>::value)
 void multiply_numeric(spgemm_state_t& s, A&& a, B&& b, C&& c) {
@@ -696,7 +698,9 @@ void multiply_symbolic_compute(spgemm_state_t& s, A&& a, B&& b, C&& c, D&& d) {
 template <typename A, typename B, typename C, typename D>
   requires(__detail::has_csr_base<A> && __detail::has_csr_base<B> && __detail::is_csr<std::remove_cvref_t<C>>::value &&
            __detail::has_csr_base<D>)
-void multiply_symbolic_fill(spgemm_state_t&, A&&, B&&, C&&, D&&) {}
+void multiply_symbolic_fill(spgemm_state_t& s, A&& a, B&& b, C&& c, D&& d) {
+  s.numeric(a, b, c, d);
+}
 template <typename A, typename B, typename C, typename D>
   requires(__detail::has_csr_base<A> && __detail::has_csr_base<B> && __detail::is_csr<std::remove_cvref_t<C>>::value &&
            __detail::has_csr_base<D>)

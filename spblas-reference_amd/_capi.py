@@ -33,6 +33,7 @@ SPMV_AUTO, SPMV_VECTOR, SPMV_ROWBLOCK, SPMV_SLICED = 0, 1, 2, 3
 OPT_BIN_ROW_ALIGN = 1
 OPT_MAX_KSPLIT = 2
 OPT_VALUE_SNAPSHOT = 3
+OPT_SPGEMM_KEEP_COLIND = 4
 
 # every symbol include/spblas_gfx950.h declares: (name, restype, argtypes)
 PROTOTYPES = [

@@ -18,6 +18,7 @@ struct spblas_gfx950_handle_s {
   int64_t bin_row_align = 0;  // SPBLAS_GFX950_OPT_BIN_ROW_ALIGN
   int64_t max_ksplit = 0;     // SPBLAS_GFX950_OPT_MAX_KSPLIT (0 = no cap)
   int64_t value_snapshot = 0; // SPBLAS_GFX950_OPT_VALUE_SNAPSHOT: AUTO may pick a plan that copies A's values
+  int64_t spgemm_keep_colind = 0;  // SPBLAS_GFX950_OPT_SPGEMM_KEEP_COLIND: same c_colind address = same contents
   // second stream + fork/join events of the striped fused step (created on first use)
   hipStream_t aux_stream = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;

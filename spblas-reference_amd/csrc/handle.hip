@@ -99,6 +99,12 @@ int spblas_gfx950_set_option(spblas_gfx950_handle_t handle, int option, int64_t 
     handle->value_snapshot = value;
     return SPBLAS_GFX950_STATUS_SUCCESS;
   }
+  if (option == SPBLAS_GFX950_OPT_SPGEMM_KEEP_COLIND) {
+    if (value != 0 && value != 1)
+      return SPBLAS_GFX950_STATUS_INVALID_VALUE;
+    handle->spgemm_keep_colind = value;
+    return SPBLAS_GFX950_STATUS_SUCCESS;
+  }
   return SPBLAS_GFX950_STATUS_INVALID_VALUE;
 }
 

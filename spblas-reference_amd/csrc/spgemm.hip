@@ -722,9 +722,10 @@ static int spgemm_numeric_typed(spblas_gfx950_handle_t h, spblas_gfx950_spgemm_s
                                 const T* b_values, int32_t* c_colind, T* c_values, T alpha, const T* d_values, T beta) {
   hipStream_t s = h->stream;
   if (st->r_ready) {
-    // the column indices of an array this state filled before are still in place (the reference's reuse contract:
-    // multiply_numeric recomputes values, multiply_spgemm.hpp:195-213); another array gets them copied
-    launch_ranked<T, 1>(s, st, a_values, b_values, c_colind, c_values, alpha, c_colind != st->r_last_colind);
+    // columns: rewritten unless the caller vouches for the array's contents (OPT_SPGEMM_KEEP_COLIND) and it is the
+    // array the previous pass filled -- the address alone proves nothing, allocators hand freed addresses out again
+    launch_ranked<T, 1>(s, st, a_values, b_values, c_colind, c_values, alpha,
+                        !(h->spgemm_keep_colind != 0 && c_colind == st->r_last_colind));
     SPB_HIP(hipGetLastError());
     st->r_last_colind = c_colind;
     return run_bins<T, true>(h, st, a_values, b_values, st->rowptr, c_colind, c_values, alpha, d_values, beta, true);

@@ -22,6 +22,11 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 REF = "/root/reference/include"
 OUT_DIR = os.path.join(HERE, "_build")
 DROPIN_RUN = os.path.join(OUT_DIR, "dropin_run")
+REF_DEVICE_TESTS = os.path.join(OUT_DIR, "reference_device_tests")
+# the reference's own device tests, compiled UNMODIFIED from where they lie (never copied into this repository)
+REF_TEST_DIR = "/root/reference/test/gtest"
+REF_TEST_SOURCES = ["device/spmv_test.cpp", "device/spgemm_test.cpp", "device/spgemm_reuse_test.cpp",
+                    "device/rocsparse/spgemm_4args_test.cpp"]
 
 
 def _edit(text, anchor, addition, after=True, count=1):
@@ -105,3 +110,37 @@ def build_dropin_run(libdir):
     if r.returncode != 0:
         raise RuntimeError("g++ failed on dropin_run.cpp:\n" + r.stderr[-8000:])
     return DROPIN_RUN
+
+
+def build_reference_device_tests(libdir, jobs=4):
+    """The reference's device test files (test/gtest/device/*.cpp: thrust device vectors + GoogleTest macros)
+    compiled as they are against the patched tree with -DSPBLAS_ENABLE_GFX950 -- i.e. with THIS backend behind
+    spblas::multiply & co. -- by hipcc (thrust needs a device compiler), with stubs/gtest/gtest.h standing in for
+    GoogleTest (TEST / EXPECT_EQ / EXPECT_NEAR + a main that runs the registry).  Their expected values are the
+    loops those test files contain.  Returns the binary's path, or None where the reference tree does not exist."""
+    if not os.path.isdir(REF) or not os.path.isdir(REF_TEST_DIR):
+        return None
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    hipcc = os.path.join(rocm, "bin", "hipcc")
+    os.makedirs(OUT_DIR, exist_ok=True)
+    from concurrent.futures import ThreadPoolExecutor
+    with tempfile.TemporaryDirectory() as tmp:
+        scratch = patched_reference_headers(os.path.join(tmp, "patched"))
+        flags = [f for f in compile_flags(scratch) if f != "-D__HIP_PLATFORM_AMD__"]  # hipcc defines it
+        common = [hipcc, "--offload-arch=gfx950", "-O1", "-Wno-reorder-ctor", "-Wno-unused-but-set-variable"] + flags
+        sources = [os.path.join(REF_TEST_DIR, s) for s in REF_TEST_SOURCES] + [os.path.join(HERE, "gtest_main.cpp")]
+        objs = [os.path.join(tmp, f"t{i}.o") for i in range(len(sources))]
+
+        def compile_one(i):
+            return subprocess.run(common + ["-c", sources[i], "-o", objs[i]], capture_output=True, text=True)
+
+        with ThreadPoolExecutor(max_workers=jobs) as pool:
+            for i, r in enumerate(pool.map(compile_one, range(len(sources)))):
+                if r.returncode != 0:
+                    raise RuntimeError(f"hipcc failed on {sources[i]}:\n" + r.stderr[-8000:])
+        r = subprocess.run([hipcc, "--offload-arch=gfx950"] + objs + [
+            "-L", libdir, "-lspblas_gfx950", "-Wl,-rpath,$ORIGIN/../../../spblas-reference_amd/lib",
+            "-Wl,-rpath," + os.path.join(rocm, "lib"), "-o", REF_DEVICE_TESTS], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("link of reference_device_tests failed:\n" + r.stderr[-8000:])
+    return REF_DEVICE_TESTS

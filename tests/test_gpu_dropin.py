@@ -27,3 +27,22 @@ def test_dropin_backend_runs_behind_the_reference_api(gpu):
     assert "checks, 0 failed" in r.stdout, r.stdout
     n = int(r.stdout.split("dropin_run:")[1].split("checks")[0])
     assert n >= 25, r.stdout
+
+
+REF_BIN = os.path.join(ROOT, "tests", "compile_check", "_build", "reference_device_tests")
+
+
+def test_reference_device_tests_pass_on_this_backend(gpu):
+    """The reference's OWN device tests -- test/gtest/device/{spmv,spgemm,spgemm_reuse}_test.cpp and
+    device/rocsparse/spgemm_4args_test.cpp, 14 TESTs -- compiled unmodified from the reference tree (never copied
+    here) against <spblas/spblas.hpp> with -DSPBLAS_ENABLE_GFX950, i.e. with this backend behind spblas::multiply,
+    multiply_compute / multiply_fill, multiply_symbolic_* / multiply_numeric and the four-argument forms
+    (tests/compile_check/build_dropin.py: hipcc, thrust device vectors, a stand-in for the GoogleTest macros).
+    Their expected values are the host loops those files contain (spa_accumulator over __backend::rows)."""
+    if not os.path.exists(REF_BIN):
+        pytest.skip("tests/compile_check/_build/reference_device_tests was not built (needs the reference tree: "
+                    "__graft_entry__.build() in the build container)")
+    r = subprocess.run([REF_BIN], capture_output=True, text=True, timeout=600)
+    tail = r.stdout[-3000:] + "\n" + r.stderr[-3000:]
+    assert r.returncode == 0, tail
+    assert "14 tests ran, 0 failed" in r.stdout, tail

@@ -152,6 +152,61 @@ def test_spgemm_reuse_changed_values_and_pointers(gpu):
         check_against_oracle(tuple(a_h), tuple(b_h), got, np.float32)
 
 
+def test_spgemm_numeric_into_recycled_addresses(gpu):
+    """device/spgemm_reuse_test.cpp:325-448 (SpGEMMReuseAndChangePointer): every numeric pass gets fresh copies of all
+    nine arrays, and the allocator hands the addresses of the previous iteration's copies out again.  An equal
+    c_colind address therefore proves nothing about its contents: numeric must (re)write the column indices unless
+    it is provably the array the previous pass filled.  Six passes, so that the rank-reuse path (third pass on) is
+    exercised; pass 4 poisons the recycled column array instead of copying the structure into it, pass 5 passes the
+    SAME tensors again (the one case where the columns may stay untouched)."""
+    m, k, nnz = 1000, 100, 10000
+    a_h = list(generate.generate_csr(m, k, nnz)[:4])
+    b_h = list(generate.generate_csr(k, m, nnz, seed=1)[:4])
+    d_a = G.csr_on_device(*a_h, nnz)
+    d_b = G.csr_on_device(*b_h, nnz)
+    d_rp = torch.zeros(m + 1, dtype=torch.int32, device="cuda")
+    d_c = sp.csr_view(None, d_rp, None, (m, m), 0)
+    state = sp.spgemm_state_t()
+    sp.multiply_symbolic_compute(state, d_a, d_b, d_c)
+    cn = state.result_nnz()
+    c_val, c_col = torch.zeros(cn, device="cuda"), torch.full((cn,), -7, dtype=torch.int32, device="cuda")
+    d_c.update(c_val, d_rp, c_col, (m, m), cn)
+    sp.multiply_symbolic_fill(state, d_a, d_b, d_c)
+    # the symbolic stage leaves the structure in the caller's arrays (multiply_spgemm.hpp:147-176)
+    ref_nnz, ref_rp, ref_ci, _ = util_spgemm_reference(a_h, b_h)
+    assert np.array_equal(G.host(d_rp), ref_rp) and np.array_equal(G.host(c_col), ref_ci)
+    rng = np.random.default_rng(0)
+    seen = set()
+    cur = None
+    for it in range(6):
+        a_h[0] = (rng.random(nnz) * 100).astype(np.float32)
+        b_h[0] = (rng.random(nnz) * 100).astype(np.float32)
+        if it != 5:
+            cur = None                                          # drop the previous copies: their addresses are free again
+            na = G.csr_on_device(*a_h, nnz)
+            nb = G.csr_on_device(*b_h, nnz)
+            n_col = torch.full((cn,), 123456, dtype=torch.int32, device="cuda") if it == 4 else c_col.clone()
+            n_val, n_rp = torch.full((cn,), float("nan"), device="cuda"), d_rp.clone()
+            nc = sp.csr_view(n_val, n_rp, n_col, (m, m), cn)
+            cur = (na, nb, nc)
+        else:
+            cur[0].values().copy_(G.dev(a_h[0]))
+            cur[1].values().copy_(G.dev(b_h[0]))
+        seen.add(cur[2].colind().data_ptr())
+        sp.multiply_numeric(state, cur[0], cur[1], cur[2])
+        got = (cn, G.host(cur[2].rowptr()), G.host(cur[2].colind()), G.host(cur[2].values()))
+        check_against_oracle(tuple(a_h), tuple(b_h), got, np.float32)
+    assert len(seen) < 5, "the allocator was expected to recycle at least one address (the scenario under test)"
+
+
+def util_spgemm_reference(a_h, b_h):
+    """(nnz, rowptr, colind, values) of A * B from the oracle."""
+    (av, ar, ac, ash), (bv, br, bc, bsh) = a_h, b_h
+    n_ref, _ = oracle.spgemm_symbolic(ash, ar, ac, bsh, br, bc)
+    cr, cc, cv = oracle.spgemm_numeric(ash, ar, ac, av, bsh, br, bc, bv, capacity=n_ref)
+    return n_ref, cr, cc, cv
+
+
 def test_spgemm_errors(gpu):
     a_h = generate.generate_csr(40, 40, 1000)[:4]
     d_a = G.csr_on_device(*a_h, 1000)
