@@ -6,6 +6,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 #include "spblas_gfx950.h"
 
@@ -27,6 +28,15 @@ struct spblas_gfx950_handle_s {
   void* scratch = nullptr;
   size_t scratch_bytes = 0;
   hipStream_t scratch_stream = nullptr;
+  // pinned, device-visible host buffer for small read-backs (spb::readback_*), and the copies staged in it
+  void* pinned = nullptr;
+  size_t pinned_bytes = 0, pinned_used = 0;
+  struct pending_copy {
+    void* dst;
+    size_t off, bytes;
+  };
+  pending_copy pending[8];
+  int n_pending = 0;
 };
 
 namespace spb {
@@ -101,6 +111,79 @@ inline int handle_scratch(spblas_gfx950_handle_s* h, size_t bytes, void** out) {
   h->scratch_stream = h->stream;
   *out = h->scratch;
   return SPBLAS_GFX950_STATUS_SUCCESS;
+}
+
+// Small device -> host read-backs WITHOUT the SDMA engine: a copy kernel writes into the handle's pinned host buffer
+// (device-mapped), readback_flush drains the stream and hands the bytes out.  The first hipMemcpy of more than a few KB
+// in a process sets up an SDMA queue (12-15 ms measured inside an inspect of 38 ms); counters and offset tables of an
+// inspect are a few dozen KB.  Larger or unaligned requests take hipMemcpyAsync.
+static __global__ __launch_bounds__(256) void spb_readback_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst,
+                                                                  size_t n) {
+  for (size_t i = (size_t) blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t) gridDim.x * 256)
+    dst[i] = src[i];
+}
+inline int readback_add(spblas_gfx950_handle_s* h, void* host_dst, const void* dev_src, size_t bytes) {
+  constexpr size_t cap = (size_t) 1 << 20;
+  if (bytes == 0)
+    return SPBLAS_GFX950_STATUS_SUCCESS;
+  const bool fits = (bytes & 3) == 0 && (reinterpret_cast<uintptr_t>(dev_src) & 3) == 0 && h->n_pending < 8 &&
+                    h->pinned_used + bytes <= cap;
+  if (fits && !h->pinned) {
+    if (hipHostMalloc(&h->pinned, cap, hipHostMallocDefault) != hipSuccess) {
+      (void) hipGetLastError();
+      h->pinned = nullptr;
+    } else {
+      h->pinned_bytes = cap;
+    }
+  }
+  if (!fits || !h->pinned) {
+    const hipError_t e = hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, h->stream);
+    return e == hipSuccess ? SPBLAS_GFX950_STATUS_SUCCESS : hip_fail(e);
+  }
+  uint32_t* dst = reinterpret_cast<uint32_t*>(static_cast<char*>(h->pinned) + h->pinned_used);
+  const size_t n = bytes / 4;
+  const unsigned grid = (unsigned) (n / 256 + 1 < 64 ? n / 256 + 1 : 64);
+  hipLaunchKernelGGL(spb_readback_kernel, dim3(grid), dim3(256), 0, h->stream, static_cast<const uint32_t*>(dev_src), dst, n);
+  h->pending[h->n_pending++] = {host_dst, h->pinned_used, bytes};
+  h->pinned_used += (bytes + 63) & ~(size_t) 63;
+  return SPBLAS_GFX950_STATUS_SUCCESS;
+}
+// The mirror image for small host -> device uploads (work lists): the bytes are staged in the pinned buffer and a
+// kernel copies them to their place.  The staging space is recycled by readback_flush (which drains the stream).
+inline int upload_add(spblas_gfx950_handle_s* h, void* dev_dst, const void* host_src, size_t bytes) {
+  constexpr size_t cap = (size_t) 1 << 20;
+  if (bytes == 0)
+    return SPBLAS_GFX950_STATUS_SUCCESS;
+  const bool fits = (bytes & 3) == 0 && (reinterpret_cast<uintptr_t>(dev_dst) & 3) == 0 && h->pinned_used + bytes <= cap;
+  if (fits && !h->pinned) {
+    if (hipHostMalloc(&h->pinned, cap, hipHostMallocDefault) != hipSuccess) {
+      (void) hipGetLastError();
+      h->pinned = nullptr;
+    } else {
+      h->pinned_bytes = cap;
+    }
+  }
+  if (!fits || !h->pinned) {
+    const hipError_t e = hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, h->stream);
+    return e == hipSuccess ? SPBLAS_GFX950_STATUS_SUCCESS : hip_fail(e);
+  }
+  char* stage = static_cast<char*>(h->pinned) + h->pinned_used;
+  std::memcpy(stage, host_src, bytes);
+  const size_t n = bytes / 4;
+  const unsigned grid = (unsigned) (n / 256 + 1 < 64 ? n / 256 + 1 : 64);
+  hipLaunchKernelGGL(spb_readback_kernel, dim3(grid), dim3(256), 0, h->stream, reinterpret_cast<const uint32_t*>(stage),
+                     static_cast<uint32_t*>(dev_dst), n);
+  h->pinned_used += (bytes + 63) & ~(size_t) 63;
+  return SPBLAS_GFX950_STATUS_SUCCESS;
+}
+inline int readback_flush(spblas_gfx950_handle_s* h) {
+  const hipError_t e = hipStreamSynchronize(h->stream);
+  for (int i = 0; i < h->n_pending; ++i)
+    if (e == hipSuccess)
+      std::memcpy(h->pending[i].dst, static_cast<char*>(h->pinned) + h->pending[i].off, h->pending[i].bytes);
+  h->n_pending = 0;
+  h->pinned_used = 0;
+  return e == hipSuccess ? SPBLAS_GFX950_STATUS_SUCCESS : hip_fail(e);
 }
 
 template <typename T>

@@ -4,6 +4,8 @@
 //  vendor/rocsparse/multiply_spgemm.hpp:34-43).
 #include "common.hpp"
 
+#include <cstdlib>
+
 #include <new>
 
 namespace spb {
@@ -67,6 +69,8 @@ int spblas_gfx950_destroy(spblas_gfx950_handle_t handle) {
     (void) hipStreamSynchronize(handle->scratch_stream);
     (void) hipFree(handle->scratch);
   }
+  if (handle->pinned)
+    (void) hipHostFree(handle->pinned);
   delete handle;
   return SPBLAS_GFX950_STATUS_SUCCESS;
 }

@@ -66,7 +66,7 @@ struct spblas_gfx950_plan_s {
   // row-skewed matrices: wave-bins of variable height (<= rows_per_blk rows, ~equal entries); nullptr = bin b
   // holds the rows [b * rows_per_blk, (b + 1) * rows_per_blk)
   void* s_binrow = nullptr;    // int32[NB + 1] first row of every wave-bin (device)
-  int32_t* h_binrow = nullptr; // host copy (new[])
+  int32_t* h_binrow = nullptr; // host copy (malloc; fetched on first partial-range reduce)
   void* s_hub_rows = nullptr;  // int32[n_hub] rows kept out of the tiles (== long_rows unless variable bins raise the threshold)
   int64_t n_hub = 0;
   bool hub_rows_owned = false;

@@ -1093,26 +1093,21 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
       dev_free(flag, s);
       return rc;
     }
+    tr.mark("variable bins: temporaries allocated");
     hipLaunchKernelGGL((pb_bin_flags_kernel<O>), dim3((unsigned) cdiv(m, 256)), dim3(256), 0, s, m, H, E, rowptr, flag);
     long long* total_dev = scan_counts_i32(s, m, flag, fpart);
+    tr.mark("variable bins: flags + scan");
     long long nb_var = 0;
     hipError_t e = hipMemcpyAsync(&nb_var, total_dev, sizeof(nb_var), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess)
       e = hipStreamSynchronize(s);
+    tr.mark("variable bins: total read back");
     if (e == hipSuccess && nb_var > 0 && nb_var < ((int64_t) 1 << 24)) {
       NB = (int) nb_var;
       rc = dev_alloc(&pl->s_binrow, (size_t) (NB + 1) * 4, s);
       if (!rc) {
         hipLaunchKernelGGL(pb_bin_rows_kernel, dim3((unsigned) cdiv(m + 1, 256)), dim3(256), 0, s, m, flag,
                            static_cast<int32_t*>(pl->s_binrow));
-        pl->h_binrow = new (std::nothrow) int32_t[(size_t) NB + 1];
-        if (!pl->h_binrow)
-          rc = SPBLAS_GFX950_STATUS_ALLOC_FAILED;
-        else {
-          e = hipMemcpyAsync(pl->h_binrow, pl->s_binrow, (size_t) (NB + 1) * 4, hipMemcpyDeviceToHost, s);
-          if (e == hipSuccess)
-            e = hipStreamSynchronize(s);
-        }
       }
     }
     dev_free(flag, s);
@@ -1215,7 +1210,8 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
   temps.p[0] = d_sum;
   hipLaunchKernelGGL(pb_balance_kernel, dim3((unsigned) (S + ngroups)), dim3(256), 0, s, S, NB, RW, cnt, d_sum,
                      d_sum + S, d_sum + 2 * S);
-  SPB_HIP(hipMemcpyAsync(h_sum.data(), d_sum, h_sum.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+  if ((rc = readback_add(h, h_sum.data(), d_sum, h_sum.size() * sizeof(unsigned long long))))
+    return rc;
   // the block offsets of both orders are computed meanwhile (the probe read-back below is the only wait)
   if ((rc = dev_alloc((void**) &aoff, (size_t) (nseg + 1) * 4, s)))
     return rc;
@@ -1239,9 +1235,9 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
   hipLaunchKernelGGL(pb_slice_blocks_kernel, dim3((unsigned) cdiv(S + 1, 256)), dim3(256), 0, s, S, NB, aoff, sliceblk);
   std::vector<int32_t> h_sliceblk((size_t) S + 1);
   int32_t h_pblocks = 0;
-  SPB_HIP(hipMemcpyAsync(h_sliceblk.data(), sliceblk, (size_t) (S + 1) * 4, hipMemcpyDeviceToHost, s));
-  SPB_HIP(hipMemcpyAsync(&h_pblocks, binblk + NB, 4, hipMemcpyDeviceToHost, s));
-  SPB_HIP(hipStreamSynchronize(s));
+  if ((rc = readback_add(h, h_sliceblk.data(), sliceblk, (size_t) (S + 1) * 4)) ||
+      (rc = readback_add(h, &h_pblocks, binblk + NB, 4)) || (rc = readback_flush(h)))
+    return rc;
   unsigned long long placed_total = 0, max_slice = 0, max_group = 0, ne = 0;
   for (int i = 0; i < S; ++i) {
     placed_total += h_sum[(size_t) i];
@@ -1321,8 +1317,8 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
       if (!items.empty()) {
         if ((rc = dev_alloc(&pl->s_xitems, items.size() * sizeof(int4), s)))
           return rc;
-        SPB_HIP(hipMemcpyAsync(pl->s_xitems, items.data(), items.size() * sizeof(int4), hipMemcpyHostToDevice, s));
-        SPB_HIP(hipStreamSynchronize(s));
+        if ((rc = upload_add(h, pl->s_xitems, items.data(), items.size() * sizeof(int4))) || (rc = readback_flush(h)))
+          return rc;
         pl->n_xitems = (int64_t) items.size();
       }
     } else if (total > 0 && (int64_t) max_slice * S > 3 * total) {
@@ -1344,8 +1340,8 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
       if (!items.empty()) {
         if ((rc = dev_alloc(&pl->s_xitems, items.size() * sizeof(int4), s)))
           return rc;
-        SPB_HIP(hipMemcpyAsync(pl->s_xitems, items.data(), items.size() * sizeof(int4), hipMemcpyHostToDevice, s));
-        SPB_HIP(hipStreamSynchronize(s));
+        if ((rc = upload_add(h, pl->s_xitems, items.data(), items.size() * sizeof(int4))) || (rc = readback_flush(h)))
+          return rc;
         pl->n_xitems = (int64_t) items.size();
       }
     }
@@ -1381,9 +1377,9 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
             (rc = dev_alloc(&pl->s_rsplit, split.size() * sizeof(int4), s)) ||
             (rc = dev_alloc(&pl->s_rpartial, (size_t) poff * sizeof(T), s)))
           return rc;
-        SPB_HIP(hipMemcpyAsync(pl->s_ritems, items.data(), items.size() * sizeof(int4), hipMemcpyHostToDevice, s));
-        SPB_HIP(hipMemcpyAsync(pl->s_rsplit, split.data(), split.size() * sizeof(int4), hipMemcpyHostToDevice, s));
-        SPB_HIP(hipStreamSynchronize(s));
+        if ((rc = upload_add(h, pl->s_ritems, items.data(), items.size() * sizeof(int4))) ||
+            (rc = upload_add(h, pl->s_rsplit, split.data(), split.size() * sizeof(int4))) || (rc = readback_flush(h)))
+          return rc;
         pl->n_ritems = (int64_t) items.size();
         pl->n_rsplit = (int64_t) split.size();
         pl->device_bytes += (size_t) poff * sizeof(T);
@@ -1501,6 +1497,26 @@ static int sliced_expand_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* p
   return SPBLAS_GFX950_STATUS_SUCCESS;
 }
 
+// Host copy of binrow[] for callers that reduce a PART of the rows (the whole-range path never needs it).  Fetched on
+// first use: a 38 KB device-to-host copy is the first SDMA transfer of many processes and cost 15 ms inside inspect.
+static int ensure_host_binrow(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl) {
+  if (!pl->s_binrow || pl->h_binrow)
+    return SPBLAS_GFX950_STATUS_SUCCESS;
+  const size_t bytes = (size_t) (pl->n_rblk + 1) * 4;
+  int32_t* hb = static_cast<int32_t*>(std::malloc(bytes));
+  if (!hb)
+    return SPBLAS_GFX950_STATUS_ALLOC_FAILED;
+  int rc = readback_add(h, hb, pl->s_binrow, bytes);
+  if (!rc)
+    rc = readback_flush(h);
+  if (rc) {
+    std::free(hb);
+    return rc;
+  }
+  pl->h_binrow = hb;
+  return SPBLAS_GFX950_STATUS_SUCCESS;
+}
+
 // rows of the wave-bins [wb_begin, wb_end):  y = alpha * (products of the last expand) + beta * y
 template <typename T>
 static int sliced_reduce_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const void* alpha_p,
@@ -1522,9 +1538,20 @@ static int sliced_reduce_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* p
   int K = pick_ksplit(wb_end - wb_begin, pl->n_rblk > 0 ? pl->p_blocks / pb_geom<T>::GBLK / pl->n_rblk : 0);
   if (h->max_ksplit > 0 && K > h->max_ksplit)
     K = (int) h->max_ksplit;  // striped callers run several reduces side by side
-  const int64_t r_lo = pl->h_binrow ? pl->h_binrow[wb_begin] : wb_begin * pl->rows_per_blk;
-  const int64_t r_hi = pl->h_binrow ? pl->h_binrow[wb_end]
-                                    : (wb_end * pl->rows_per_blk < pl->m ? wb_end * pl->rows_per_blk : pl->m);
+  int64_t r_lo = wb_begin * pl->rows_per_blk;
+  int64_t r_hi = wb_end * pl->rows_per_blk < pl->m ? wb_end * pl->rows_per_blk : pl->m;
+  if (pl->s_binrow) {  // variable bins
+    if (wb_begin == 0 && wb_end == pl->n_rblk) {
+      r_lo = 0;
+      r_hi = pl->m;
+    } else {
+      const int rc_b = ensure_host_binrow(h, pl);
+      if (rc_b)
+        return rc_b;
+      r_lo = pl->h_binrow[wb_begin];
+      r_hi = pl->h_binrow[wb_end];
+    }
+  }
   const bool use_items = pl->s_ritems && !peers_p && wb_begin == 0 && wb_end == pl->n_rblk;
   if (!use_items && K > 1 && pl->s_partial_k < K) {  // grow the partial-sum workspace (stream ordered)
     dev_free(pl->s_partial, s);
@@ -1628,7 +1655,13 @@ int spmv_sliced_reduce_rows(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, 
   const int64_t H = pl->rows_per_blk;
   int64_t wb0 = cdiv(row_begin, H);
   int64_t wb1 = cdiv(row_end, H);
-  if (pl->h_binrow) {  // variable bins: first bin whose first row is >= the bound
+  if (pl->s_binrow && row_begin <= 0 && row_end >= pl->m) {
+    wb0 = 0;
+    wb1 = pl->n_rblk;
+  } else if (pl->s_binrow) {  // variable bins: first bin whose first row is >= the bound
+    const int rc_b = ensure_host_binrow(h, pl);
+    if (rc_b)
+      return rc_b;
     const int32_t* br = pl->h_binrow;
     wb0 = std::lower_bound(br, br + pl->n_rblk, (int32_t) std::min<int64_t>(row_begin, pl->m)) - br;
     wb1 = std::lower_bound(br, br + pl->n_rblk, (int32_t) std::min<int64_t>(row_end, pl->m)) - br;
@@ -1663,7 +1696,7 @@ void spmv_sliced_free(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl) {
   dev_free(pl->s_hub_part, s);
   dev_free(pl->s_binrow, s);
   pl->s_binrow = nullptr;
-  delete[] pl->h_binrow;
+  std::free(pl->h_binrow);
   pl->h_binrow = nullptr;
   if (pl->hub_rows_owned)
     dev_free(pl->s_hub_rows, s);
