@@ -67,6 +67,15 @@ struct spblas_gfx950_plan_s {
   // holds the rows [b * rows_per_blk, (b + 1) * rows_per_blk)
   void* s_binrow = nullptr;    // int32[NB + 1] first row of every wave-bin (device)
   int32_t* h_binrow = nullptr; // host copy (malloc; fetched on first partial-range reduce)
+  // matrices with many empty rows (graphs): the tiles are built over the NON-EMPTY rows only (same colind / values, a
+  // compacted row pointer array); s_m = rows of that compacted matrix, nzrow[i] = original row of compact row i,
+  // zrow[] = the empty rows (y = beta * y there)
+  int64_t s_m = 0;
+  void* s_rowptr_c = nullptr;  // O[s_m + 1]
+  void* s_nzrow = nullptr;     // int32[s_m]; nullptr = no compaction (s_m == m)
+  void* s_zrow = nullptr;      // int32[n_zero]
+  int64_t n_zero = 0;
+  int32_t* h_binrow_orig = nullptr;  // host: ORIGINAL first row of every wave-bin (compaction; fetched lazily)
   void* s_hub_rows = nullptr;  // int32[n_hub] rows kept out of the tiles (== long_rows unless variable bins raise the threshold)
   int64_t n_hub = 0;
   bool hub_rows_owned = false;

@@ -112,6 +112,55 @@ __global__ __launch_bounds__(256) void pb_bin_flags_kernel(int64_t m, int H, int
     return;
   flag[r] = (r % H == 0) || ((int64_t) rowptr[r] / E != (int64_t) rowptr[r - 1] / E);
 }
+// Row compaction: flag[r] = row r is non-empty; after the scan pos[r] = non-empty rows before r.
+template <typename O>
+__global__ __launch_bounds__(256) void pb_nonempty_flags_kernel(int64_t m, const O* __restrict__ rowptr,
+                                                                int32_t* __restrict__ flag) {
+  const int64_t r = (int64_t) blockIdx.x * 256 + threadIdx.x;
+  if (r < m)
+    flag[r] = rowptr[r + 1] > rowptr[r];
+}
+template <typename O>
+__global__ __launch_bounds__(256) void pb_compact_rows_kernel(int64_t m, const O* __restrict__ rowptr,
+                                                              const int32_t* __restrict__ pos, O* __restrict__ rowptr_c,
+                                                              int32_t* __restrict__ nzrow, int32_t* __restrict__ zrow) {
+  const int64_t r = (int64_t) blockIdx.x * 256 + threadIdx.x;
+  if (r > m)
+    return;
+  if (r == m) {
+    rowptr_c[pos[m]] = rowptr[m];
+    return;
+  }
+  const int32_t i = pos[r];
+  if (pos[r + 1] != i) {
+    nzrow[i] = (int32_t) r;
+    rowptr_c[i] = rowptr[r];
+  } else {
+    zrow[r - i] = (int32_t) r;
+  }
+}
+// y = beta * y on the empty rows inside [row_begin, row_end)
+template <typename T>
+__global__ __launch_bounds__(256) void pb_empty_rows_kernel(int64_t n_zero, const int32_t* __restrict__ zrow,
+                                                            T* __restrict__ y, T beta, int64_t row_begin, int64_t row_end) {
+  const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_zero)
+    return;
+  const int64_t r = zrow[i];
+  if (r >= row_begin && r < row_end)
+    y[r] = beta == T(0) ? T(0) : beta * y[r];
+}
+// out[b] = original row of the first (compact) row of wave-bin b; out[NB] = m
+__global__ __launch_bounds__(256) void pb_bin_orig_rows_kernel(int64_t NB, int64_t s_m, int64_t m,
+                                                               const int32_t* __restrict__ binrow,
+                                                               const int32_t* __restrict__ nzrow, int32_t* __restrict__ out) {
+  const int64_t b = (int64_t) blockIdx.x * 256 + threadIdx.x;
+  if (b > NB)
+    return;
+  const int64_t c = binrow[b];
+  out[b] = c < s_m ? nzrow[c] : (int32_t) m;
+}
+
 // rows longer than `thr` entries, appended to rows[] in arbitrary order (wave-aggregated append)
 template <typename O>
 __global__ __launch_bounds__(256) void pb_hub_list_kernel(int64_t m, int thr, const O* __restrict__ rowptr,
@@ -707,7 +756,8 @@ __global__ __launch_bounds__(RW * 64) void pb_reduce_kernel(int64_t m, int Hw, i
                                                             int64_t pstride, T* const* __restrict__ peers,
                                                             int n_peers, int64_t peer_off,
                                                             const int4* __restrict__ ritems, int dbg,
-                                                            const int32_t* __restrict__ binrow) {
+                                                            const int32_t* __restrict__ binrow,
+                                                            const int32_t* __restrict__ rowmap) {
   // dbg (SPBLAS_GFX950_PB_DBG, timing experiments only -- results are wrong): 1 = skip the atomic path of flagged
   // entries, 2 = no LDS traffic at all (the stream alone)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -812,6 +862,14 @@ __global__ __launch_bounds__(RW * 64) void pb_reduce_kernel(int64_t m, int Hw, i
     }
     return;
   }
+  if (rowmap) {  // tiles built over the non-empty rows only: compact row -> row of y
+    for (int i = lane; i < rh; i += 64) {
+      const T v = alpha * acc[i];
+      const int64_t r = rowmap[r0 + i];
+      y[r] = beta == T(0) ? v : v + beta * y[r];
+    }
+    return;
+  }
   for (int i = lane; i < rh; i += 64) {
     const T v = alpha * acc[i];
     y[r0 + i] = beta == T(0) ? v : v + beta * y[r0 + i];
@@ -824,13 +882,15 @@ __global__ __launch_bounds__(256) void pb_combine_kernel(int64_t r_lo, int64_t r
                                                          const T* __restrict__ partial, int64_t pstride,
                                                          T* __restrict__ y, T alpha, T beta,
                                                          T* const* __restrict__ peers, int n_peers,
-                                                         int64_t peer_off) {
-  const int64_t i = r_lo + (int64_t) blockIdx.x * 256 + threadIdx.x;
+                                                         int64_t peer_off, const int32_t* __restrict__ rowmap) {
+  int64_t i = r_lo + (int64_t) blockIdx.x * 256 + threadIdx.x;
   if (i >= r_hi)
     return;
   T s = partial[i];
   for (int k = 1; k < K; ++k)
     s += partial[(int64_t) k * pstride + i];
+  if (rowmap)
+    i = rowmap[i];
   if (peers) {
     for (int p = 0; p < n_peers; ++p)
       peers[p][peer_off + i] = alpha * s;
@@ -873,7 +933,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void pb_hub_finish_kernel(int64_t n_hub, int parts,
                                                             const int32_t* __restrict__ hub_rows,
                                                             const T* __restrict__ part, T* __restrict__ y, T alpha,
-                                                            int64_t row_begin, int64_t row_end) {
+                                                            int64_t row_begin, int64_t row_end,
+                                                            const int32_t* __restrict__ rowmap) {
   const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
   if (i >= n_hub)
     return;
@@ -883,7 +944,7 @@ __global__ __launch_bounds__(256) void pb_hub_finish_kernel(int64_t n_hub, int p
   T s = T(0);
   for (int k = 0; k < parts; ++k)
     s += part[i * parts + k];
-  y[r] += alpha * s;
+  y[rowmap ? rowmap[r] : r] += alpha * s;
 }
 
 // Work-item variant of the combine: one entry of `cg` per SPLIT bin group = (group, K_g, offset of its
@@ -893,7 +954,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void pb_combine_items_kernel(const int4* __restrict__ cg, int64_t group_rows,
                                                                int64_t m, const T* __restrict__ partial,
                                                                T* __restrict__ y, T alpha, T beta, int Hw,
-                                                               const int32_t* __restrict__ binrow, int64_t NB) {
+                                                               const int32_t* __restrict__ binrow, int64_t NB,
+                                                               const int32_t* __restrict__ rowmap) {
   const int4 g = cg[blockIdx.x];
   const int64_t i = (int64_t) blockIdx.y * 256 + threadIdx.x;
   if (i >= group_rows)
@@ -910,6 +972,8 @@ __global__ __launch_bounds__(256) void pb_combine_items_kernel(const int4* __res
   }
   if (row >= m)
     return;
+  if (rowmap)
+    row = rowmap[row];
   const T* src = partial + (int64_t) g.z + i;
   T s = src[0];
   for (int k = 1; k < g.y; ++k)
@@ -981,9 +1045,52 @@ template <typename T, typename O>
 static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const void* values_p,
                               bool auto_mode) {
   hipStream_t s = h->stream;
-  const int64_t m = pl->m, n = pl->n, nnz = pl->nnz;
+  const int64_t n = pl->n, nnz = pl->nnz;
+  int64_t m = pl->m;
   if (nnz > INT32_MAX - 8)
     return SPBLAS_GFX950_STATUS_NOT_SUPPORTED;
+  int rc;
+  pb_tracer tr(s);
+  const O* rowptr = static_cast<const O*>(pl->rowptr);
+  // Matrices with many empty rows (graphs: 56 % of the rows of R-MAT scale 24) are tiled over their NON-EMPTY rows
+  // only: same colind / values, a compacted row pointer array, and the reduce writes row nzrow[i] of y for compact
+  // row i.  Empty rows cost accumulator slots and whole wave-bins otherwise (cfg4: 9 445 -> 5 680 bins, padding
+  // 21 % -> 15 %, 2.53 -> 2.32 ms).  Needs variable-height bins (the boundaries live in binrow[]).
+  int compact = env_int("SPBLAS_GFX950_PB_COMPACT", -1);
+  if (compact < 0)
+    compact = pl->empty_rows * 4 > m;
+  if (h->bin_row_align > 1 || env_int("SPBLAS_GFX950_PB_VARBINS", -1) == 0 || pl->empty_rows == 0 || m - pl->empty_rows < 2)
+    compact = 0;
+  pl->s_m = m;
+  if (compact) {
+    int32_t* flag = nullptr;
+    long long* fpart = nullptr;
+    const int64_t m_eff = m - pl->empty_rows;
+    if ((rc = dev_alloc((void**) &flag, (size_t) (m + 1) * 4, s)))
+      return rc;
+    if ((rc = dev_alloc((void**) &fpart, (size_t) (cdiv(m, 2048) + 2) * sizeof(long long), s)) ||
+        (rc = dev_alloc(&pl->s_rowptr_c, (size_t) (m_eff + 1) * sizeof(O), s)) ||
+        (rc = dev_alloc(&pl->s_nzrow, (size_t) m_eff * 4, s)) ||
+        (rc = dev_alloc(&pl->s_zrow, (size_t) pl->empty_rows * 4, s))) {
+      dev_free(flag, s);
+      dev_free(fpart, s);
+      return rc;
+    }
+    hipLaunchKernelGGL((pb_nonempty_flags_kernel<O>), dim3((unsigned) cdiv(m, 256)), dim3(256), 0, s, m, rowptr, flag);
+    (void) scan_counts_i32(s, m, flag, fpart);
+    hipLaunchKernelGGL((pb_compact_rows_kernel<O>), dim3((unsigned) cdiv(m + 1, 256)), dim3(256), 0, s, m, rowptr, flag,
+                       static_cast<O*>(pl->s_rowptr_c), static_cast<int32_t*>(pl->s_nzrow),
+                       static_cast<int32_t*>(pl->s_zrow));
+    dev_free(flag, s);
+    dev_free(fpart, s);
+    SPB_HIP(hipGetLastError());
+    pl->n_zero = pl->empty_rows;
+    pl->s_m = m_eff;
+    pl->device_bytes += (size_t) (m_eff + 1) * sizeof(O) + (size_t) m * 4;
+    m = m_eff;
+    rowptr = static_cast<const O*>(pl->s_rowptr_c);
+    tr.mark("empty rows compacted");
+  }
   // x slice of the expand: 80 KiB for fp32 (two workgroups per CU); for fp64 the whole 160 KiB of a CU
   // (one workgroup), which halves the number of slices and doubles the run length
   // fp32 switches to 160 KiB slices as well from n = 8 M on, provided a slice still carries enough entries to
@@ -1067,9 +1174,6 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
       pl->bin_aligned = 1;
     }
   }
-  int rc;
-  pb_tracer tr(s);
-  const O* rowptr = static_cast<const O*>(pl->rowptr);
   // Row-skewed matrices (power-law graphs: most entries in a few thousand rows, half the rows empty) get wave-bins
   // of VARIABLE height: a new bin every H rows and wherever the entry count crosses a multiple of E, so no bin is
   // taller than the LDS accumulators allow and none carries much more than E entries.  With equal heights the
@@ -1078,9 +1182,11 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
   const double avg_len = m > 0 ? (double) nnz / (double) m : 0.0;
   int varbins = env_int("SPBLAS_GFX950_PB_VARBINS", -1);
   if (varbins < 0)
-    varbins = (double) pl->max_row_len > 16.0 * avg_len + 64.0 || pl->empty_rows * 4 > m;
-  if (h->bin_row_align > 1 || m < 2 || NB < 2)
+    varbins = (double) pl->max_row_len > 16.0 * avg_len + 64.0 || pl->empty_rows * 4 > pl->m;
+  if (h->bin_row_align > 1 || m < 2 || (NB < 2 && !compact))
     varbins = 0;
+  if (compact)
+    varbins = 1;  // the reduce maps compact rows through binrow[] + nzrow[]
   const int32_t* binrow = nullptr;
   if (varbins) {
     int64_t E = nnz / env_int("SPBLAS_GFX950_PB_BINS", 2048);
@@ -1117,6 +1223,8 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
     if (rc)
       return rc;
     binrow = static_cast<const int32_t*>(pl->s_binrow);
+    if (!binrow && compact)
+      return SPBLAS_GFX950_STATUS_NOT_SUPPORTED;  // the compacted rows are addressed through binrow[]
     if (!binrow)
       varbins = 0;
     pl->device_bytes += (size_t) (NB + 1) * 4;
@@ -1150,7 +1258,7 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
       pl->hub_len = 0;
       pl->s_hub_rows = nullptr;
       pl->n_hub = 0;
-    } else if (hub2 > pl->win) {
+    } else if (hub2 > pl->win || compact) {  // (compaction: the list holds COMPACT row numbers)
       unsigned long long* st2 = nullptr;
       int32_t* rows2 = nullptr;
       if ((rc = dev_alloc((void**) &st2, 4 * sizeof(unsigned long long), s)))
@@ -1504,16 +1612,33 @@ static int ensure_host_binrow(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
     return SPBLAS_GFX950_STATUS_SUCCESS;
   const size_t bytes = (size_t) (pl->n_rblk + 1) * 4;
   int32_t* hb = static_cast<int32_t*>(std::malloc(bytes));
-  if (!hb)
+  int32_t* ho = pl->s_nzrow ? static_cast<int32_t*>(std::malloc(bytes)) : nullptr;
+  int32_t* d_orig = nullptr;
+  if (!hb || (pl->s_nzrow && !ho)) {
+    std::free(hb);
+    std::free(ho);
     return SPBLAS_GFX950_STATUS_ALLOC_FAILED;
+  }
   int rc = readback_add(h, hb, pl->s_binrow, bytes);
+  if (!rc && pl->s_nzrow) {  // compaction: the original row every bin starts at
+    rc = dev_alloc((void**) &d_orig, bytes, h->stream);
+    if (!rc) {
+      hipLaunchKernelGGL(pb_bin_orig_rows_kernel, dim3((unsigned) cdiv(pl->n_rblk + 1, 256)), dim3(256), 0, h->stream,
+                         pl->n_rblk, pl->s_m, pl->m, static_cast<const int32_t*>(pl->s_binrow),
+                         static_cast<const int32_t*>(pl->s_nzrow), d_orig);
+      rc = readback_add(h, ho, d_orig, bytes);
+    }
+  }
   if (!rc)
     rc = readback_flush(h);
+  dev_free(d_orig, h->stream);
   if (rc) {
     std::free(hb);
+    std::free(ho);
     return rc;
   }
   pl->h_binrow = hb;
+  pl->h_binrow_orig = ho;
   return SPBLAS_GFX950_STATUS_SUCCESS;
 }
 
@@ -1538,25 +1663,36 @@ static int sliced_reduce_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* p
   int K = pick_ksplit(wb_end - wb_begin, pl->n_rblk > 0 ? pl->p_blocks / pb_geom<T>::GBLK / pl->n_rblk : 0);
   if (h->max_ksplit > 0 && K > h->max_ksplit)
     K = (int) h->max_ksplit;  // striped callers run several reduces side by side
+  // [r_lo, r_hi): the rows of these bins in the index space the tiles were built over (compact rows when the empty
+  // rows were taken out); [o_lo, o_hi): the same range in rows of y (hub rows and empty rows are listed by those)
   int64_t r_lo = wb_begin * pl->rows_per_blk;
-  int64_t r_hi = wb_end * pl->rows_per_blk < pl->m ? wb_end * pl->rows_per_blk : pl->m;
+  int64_t r_hi = wb_end * pl->rows_per_blk < pl->s_m ? wb_end * pl->rows_per_blk : pl->s_m;
+  int64_t o_lo = r_lo, o_hi = r_hi;
   if (pl->s_binrow) {  // variable bins
     if (wb_begin == 0 && wb_end == pl->n_rblk) {
-      r_lo = 0;
-      r_hi = pl->m;
+      r_lo = o_lo = 0;
+      r_hi = pl->s_m;
+      o_hi = pl->m;
     } else {
       const int rc_b = ensure_host_binrow(h, pl);
       if (rc_b)
         return rc_b;
-      r_lo = pl->h_binrow[wb_begin];
-      r_hi = pl->h_binrow[wb_end];
+      r_lo = o_lo = pl->h_binrow[wb_begin];
+      r_hi = o_hi = pl->h_binrow[wb_end];
+      if (pl->h_binrow_orig) {  // (empty rows ahead of the first non-empty row belong to the first bin)
+        o_lo = wb_begin == 0 ? 0 : pl->h_binrow_orig[wb_begin];
+        o_hi = pl->h_binrow_orig[wb_end];
+      }
     }
   }
+  const int32_t* rowmap = static_cast<const int32_t*>(pl->s_nzrow);
+  if (peers_p && rowmap)
+    return SPBLAS_GFX950_STATUS_NOT_SUPPORTED;  // the fused all-gather epilogue writes contiguous rows
   const bool use_items = pl->s_ritems && !peers_p && wb_begin == 0 && wb_end == pl->n_rblk;
   if (!use_items && K > 1 && pl->s_partial_k < K) {  // grow the partial-sum workspace (stream ordered)
     dev_free(pl->s_partial, s);
     pl->s_partial = nullptr;
-    int rc = dev_alloc(&pl->s_partial, (size_t) K * pl->m * sizeof(T), s);
+    int rc = dev_alloc(&pl->s_partial, (size_t) K * pl->s_m * sizeof(T), s);
     if (rc)
       return rc;
     pl->s_partial_k = K;
@@ -1567,7 +1703,7 @@ static int sliced_reduce_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* p
     const uint16_t* rowp = pl->s_lrow;
     T* yp = static_cast<T*>(y);
     T* part = K > 1 ? static_cast<T*>(pl->s_partial) : nullptr;
-    int64_t mm = pl->m, pstride = pl->m;
+    int64_t mm = pl->s_m, pstride = pl->s_m;
     int Hw = pl->rows_per_blk, Kk = K;
     T a = alpha, b = beta;
     T* const* peers = reinterpret_cast<T* const*>(peers_p);
@@ -1575,7 +1711,7 @@ static int sliced_reduce_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* p
     int dbg = env_int("SPBLAS_GFX950_PB_DBG", 0);
     const int32_t* binrow = static_cast<const int32_t*>(pl->s_binrow);
     void* args[] = {&mm, &Hw, &wb_begin, &wb_end, &binblk, &Pp, &rowp, &yp, &a, &b, &Kk, &part, &pstride,
-                    &peers, &n_peers, &peer_off, &ritems, &dbg, &binrow};
+                    &peers, &n_peers, &peer_off, &ritems, &dbg, &binrow, &rowmap};
     const size_t lds = (size_t) RW * (pl->rows_per_blk + 64) * sizeof(T);
     if (use_items) {
       // row-skewed matrix, whole range: explicit work list (built at inspect), compact partial sums
@@ -1586,17 +1722,20 @@ static int sliced_reduce_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* p
       if (pl->n_rsplit > 0)
         hipLaunchKernelGGL((pb_combine_items_kernel<T>),
                            dim3((unsigned) pl->n_rsplit, (unsigned) cdiv((int64_t) RW * pl->rows_per_blk, 256)), dim3(256),
-                           0, s, static_cast<const int4*>(pl->s_rsplit), (int64_t) RW * pl->rows_per_blk, pl->m,
+                           0, s, static_cast<const int4*>(pl->s_rsplit), (int64_t) RW * pl->rows_per_blk, pl->s_m,
                            static_cast<const T*>(pl->s_rpartial), static_cast<T*>(y), alpha, beta, pl->rows_per_blk,
-                           binrow, pl->n_rblk);
+                           binrow, pl->n_rblk, rowmap);
     } else {
       SPB_HIP(hipLaunchKernel(pb_reduce_fn<T>(RW, UB), dim3((unsigned) groups, (unsigned) K), dim3(RW * 64), args, lds, s));
       if (K > 1 && r_hi > r_lo)
         hipLaunchKernelGGL((pb_combine_kernel<T>), dim3((unsigned) cdiv(r_hi - r_lo, 256)), dim3(256), 0, s, r_lo, r_hi, K,
-                           static_cast<const T*>(pl->s_partial), pl->m, static_cast<T*>(y), alpha, beta,
-                           reinterpret_cast<T* const*>(peers_p), n_peers, peer_off);
+                           static_cast<const T*>(pl->s_partial), pl->s_m, static_cast<T*>(y), alpha, beta,
+                           reinterpret_cast<T* const*>(peers_p), n_peers, peer_off, rowmap);
     }
   }
+  if (rowmap && pl->n_zero > 0 && o_hi > o_lo)  // the empty rows inside the range: y = beta * y
+    hipLaunchKernelGGL((pb_empty_rows_kernel<T>), dim3((unsigned) cdiv(pl->n_zero, 256)), dim3(256), 0, s, pl->n_zero,
+                       static_cast<const int32_t*>(pl->s_zrow), static_cast<T*>(y), beta, o_lo, o_hi);
   if (pl->hub_len > 0 && pl->n_hub > 0) {
     // rows kept out of the tiles: y[row] += alpha * (row . x), for the rows of this bin range
     if (!pl->values_ptr || !pl->last_x)
@@ -1606,16 +1745,19 @@ static int sliced_reduce_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* p
     const dim3 grid((unsigned) pl->n_hub, (unsigned) pl->hub_parts);
     T* part = static_cast<T*>(pl->s_hub_part);
     const int32_t* hub_rows = static_cast<const int32_t*>(pl->s_hub_rows);
+    // (hub rows are numbered like the rows of the tiles: compact numbers and the compacted row pointers when the
+    // empty rows were taken out)
+    const void* hub_rowptr = rowmap ? pl->s_rowptr_c : pl->rowptr;
     if (pl->offset_type == SPBLAS_GFX950_I32)
       hipLaunchKernelGGL((pb_hub_rows_kernel<T, int32_t>), grid, dim3(256), 0, s, pl->n_hub, hub_rows,
-                         static_cast<const int32_t*>(pl->rowptr), pl->colind, static_cast<const T*>(pl->values_ptr),
+                         static_cast<const int32_t*>(hub_rowptr), pl->colind, static_cast<const T*>(pl->values_ptr),
                          static_cast<const T*>(pl->last_x), part, r_lo, r_hi);
     else
       hipLaunchKernelGGL((pb_hub_rows_kernel<T, int64_t>), grid, dim3(256), 0, s, pl->n_hub, hub_rows,
-                         static_cast<const int64_t*>(pl->rowptr), pl->colind, static_cast<const T*>(pl->values_ptr),
+                         static_cast<const int64_t*>(hub_rowptr), pl->colind, static_cast<const T*>(pl->values_ptr),
                          static_cast<const T*>(pl->last_x), part, r_lo, r_hi);
     hipLaunchKernelGGL((pb_hub_finish_kernel<T>), dim3((unsigned) cdiv(pl->n_hub, 256)), dim3(256), 0, s, pl->n_hub,
-                       pl->hub_parts, hub_rows, part, static_cast<T*>(y), alpha, r_lo, r_hi);
+                       pl->hub_parts, hub_rows, part, static_cast<T*>(y), alpha, r_lo, r_hi, rowmap);
   }
   SPB_HIP(hipGetLastError());
   return SPBLAS_GFX950_STATUS_SUCCESS;
@@ -1636,7 +1778,7 @@ int spmv_sliced_reserve_partial(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* 
   pl->s_partial = nullptr;
   pl->s_partial_k = 0;
   const size_t tsz = pl->value_type == SPBLAS_GFX950_F32 ? 4 : 8;
-  int rc = dev_alloc(&pl->s_partial, (size_t) K * pl->m * tsz, s);
+  int rc = dev_alloc(&pl->s_partial, (size_t) K * pl->s_m * tsz, s);
   if (rc)
     return rc;
   pl->s_partial_k = K;
@@ -1662,7 +1804,7 @@ int spmv_sliced_reduce_rows(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, 
     const int rc_b = ensure_host_binrow(h, pl);
     if (rc_b)
       return rc_b;
-    const int32_t* br = pl->h_binrow;
+    const int32_t* br = pl->h_binrow_orig ? pl->h_binrow_orig : pl->h_binrow;  // first row of y of every bin
     wb0 = std::lower_bound(br, br + pl->n_rblk, (int32_t) std::min<int64_t>(row_begin, pl->m)) - br;
     wb1 = std::lower_bound(br, br + pl->n_rblk, (int32_t) std::min<int64_t>(row_end, pl->m)) - br;
   }
@@ -1698,6 +1840,14 @@ void spmv_sliced_free(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl) {
   pl->s_binrow = nullptr;
   std::free(pl->h_binrow);
   pl->h_binrow = nullptr;
+  std::free(pl->h_binrow_orig);
+  pl->h_binrow_orig = nullptr;
+  dev_free(pl->s_rowptr_c, s);
+  dev_free(pl->s_nzrow, s);
+  dev_free(pl->s_zrow, s);
+  pl->s_rowptr_c = pl->s_nzrow = pl->s_zrow = nullptr;
+  pl->n_zero = 0;
+  pl->s_m = 0;
   if (pl->hub_rows_owned)
     dev_free(pl->s_hub_rows, s);
   pl->s_hub_rows = nullptr;

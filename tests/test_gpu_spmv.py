@@ -253,6 +253,50 @@ def test_spmv_values_changed_in_place(gpu):
                   ref_cmp=False)
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_spmv_sliced_compacts_empty_rows(gpu, dtype):
+    """Graph-like matrix: 70 % of the rows empty (in stretches, at both ends and scattered), a few hub rows, hot
+    columns.  The SLICED plan tiles the non-empty rows only (variable-height bins over compact row numbers); y of an
+    empty row must come out as beta * y, alpha / beta forms and row-range reduces must agree with the oracle."""
+    rng = np.random.default_rng(41)
+    m, n = 300000, 900000
+    lens = np.where(rng.random(m) < 0.3, rng.integers(1, 40, m), 0)
+    lens[:5000] = 0
+    lens[-777:] = 0
+    lens[120000:150000] = 0
+    hubs = rng.choice(np.flatnonzero(lens), 6, replace=False)
+    lens[hubs] = [30000, 20000, 2500, 1800, 1200, 70000]
+    rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    nnz = int(rowptr[-1])
+    colind = np.where(rng.random(nnz) < 0.4, rng.integers(0, 2000, nnz), rng.integers(0, n, nnz)).astype(np.int32)
+    values = (rng.random(nnz) - 0.5).astype(dtype)
+    x = (rng.random(n) - 0.5).astype(dtype)
+    a = G.csr_on_device(values, rowptr, colind, (m, n), nnz)
+    xd = G.dev(x)
+    y = torch.full((m,), float("nan"), dtype=xd.dtype, device="cuda")
+    info = sp.multiply_inspect(a, xd, y, alg=_capi.SPMV_SLICED)
+    si = info.state_.sliced_info()
+    assert si["variable_bins"] == 1 and si["hub_rows"] >= 2
+    assert si["n_bins"] < cdiv(m, info.state_.info()["rows_per_bin"]) + 2100     # far fewer than a bin per H rows of y
+    sp.multiply(info, a, xd, y)
+    yh = G.host(y)
+    assert not np.isnan(yh).any() and not yh[lens == 0].any()
+    check(values, rowptr, colind, (m, n), x, yh, what="compacted rows", ref_cmp=False)
+    sp.multiply(info, sp.scaled(-1.5, a), xd, y)
+    check(values, rowptr, colind, (m, n), x, G.host(y), scale=-1.5, what="compacted rows, alpha", ref_cmp=False)
+    # two-stage form with beta: y2 = 0.5 * A x + 2 * y2, the rows reduced in three ranges cut at arbitrary rows
+    y2 = torch.full((m,), 3.0, dtype=xd.dtype, device="cuda")
+    expand, reduce_rows = info.state_.bind_stages(xd, y2.data_ptr(), xd.dtype, alpha=0.5, beta=2.0)
+    expand()
+    for lo, hi in ((0, 100001), (100001, 234567), (234567, m)):
+        reduce_rows(lo, hi)
+    want = 0.5 * np.asarray(oracle.spmv((m, n), rowptr, colind, values.astype(np.float64), x.astype(np.float64))) + 6.0
+    got = G.host(y2).astype(np.float64)
+    assert np.array_equal(got[lens == 0], np.full(int((lens == 0).sum()), 6.0))
+    absrow = 0.5 * oracle.spmv_absrow(rowptr, colind, values.astype(np.float64), x.astype(np.float64)) + 6.0
+    util.assert_parity(got.astype(dtype), want, absrow, dtype, row_len=lens, what="compacted rows, beta + row ranges")
+
+
 def test_prepared_calls_keep_their_stream_and_plans_die_in_stream_order(gpu):
     """prepared_multiply / bind_stages launch on the stream that was current when they were made, although every other
     API call re-binds the handle to the stream current at ITS call; a plan destroyed while the handle sits on another

@@ -15,7 +15,7 @@ iters = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 HOOKS = ["SPBLAS_GFX950_SLICE_COLS", "SPBLAS_GFX950_SLICE_ROWS", "SPBLAS_GFX950_PB_KSPLIT", "SPBLAS_GFX950_PB_RWAVES",
          "SPBLAS_GFX950_PB_RBATCH", "SPBLAS_GFX950_PB_RLDS_KB", "SPBLAS_GFX950_PB_BINS", "SPBLAS_GFX950_PB_VARBINS",
-         "SPBLAS_GFX950_PB_HUB_LEN"]
+         "SPBLAS_GFX950_PB_HUB_LEN", "SPBLAS_GFX950_PB_COMPACT"]
 dev = torch.device("cuda:0")
 bad = 0
 for it in range(iters):
@@ -65,6 +65,7 @@ for it in range(iters):
         hooks["SPBLAS_GFX950_PB_BINS"] = str(int(rng.choice([64, 512, 2048, 4096])))
         hooks["SPBLAS_GFX950_PB_VARBINS"] = str(int(rng.choice([-1, 0, 1])))   # variable-height bins: auto / off / forced
         hooks["SPBLAS_GFX950_PB_HUB_LEN"] = str(int(rng.choice([1, 300, 16384])))
+        hooks["SPBLAS_GFX950_PB_COMPACT"] = str(int(rng.choice([-1, 0, 1])))    # tiles over the non-empty rows only
     os.environ.update(hooks)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     rp_dev = t(rowptr.astype(np.int64 if off64 else np.int32))
