@@ -277,8 +277,12 @@ def main():
     inspect_ms = (time.perf_counter() - t0) * 1e3
     info0 = op.info if mode in ("overlapped", "fused") else op.infos[0]
     plan_info = info0.state_.info() if info0.state_ is not None else {"alg": "plan-free"}
-    if info0.state_ is not None and hasattr(info0.state_, "sliced_info") and plan_info.get("alg") == 3:
-        plan_info["sliced"] = info0.state_.sliced_info()
+    if info0.state_ is not None and hasattr(info0.state_, "sliced_info"):
+        si = info0.state_.sliced_info()
+        if plan_info.get("alg") == 3:
+            plan_info["sliced"] = si
+        elif si.get("auto_trial"):
+            plan_info["auto_trial"] = {k: si[k] for k in ("trial_rowblock_ns", "trial_sliced_ns")}
 
     elapsed, kern_avg_ms = measure(lambda: op.step(x), args.steps, args.warmup, multi, device)
 

@@ -159,8 +159,10 @@ int spblas_gfx950_plan_info(spblas_gfx950_plan_t plan, int64_t info[12]);
 /* More of a SLICED plan (zeros for other plans): info[0]=#row-bins, [1]=1 if the bins have variable heights (row-skewed
  * matrix: a new bin every [8] rows and every ~nnz/2048 entries), [2]=blocks of 32 entries in expand order,
  * [3]=blocks in reduce order (bins padded to groups of 8 blocks), [4]=entries placed in tiles, [5]=#rows kept out of
- * the tiles (hub rows), [6]=hub threshold (row length), [7]=reduce K split. */
-int spblas_gfx950_plan_info_sliced(spblas_gfx950_plan_t plan, int64_t info[8]);
+ * the tiles (hub rows), [6]=hub threshold (row length), [7]=reduce K split, [8]=rows the tiles are built over (fewer
+ * than m when the empty rows were taken out).  For ANY plan: [9]=1 if AUTO decided by a timed trial, [10]/[11]=time
+ * of the row-block / the sliced plan in that trial, nanoseconds. */
+int spblas_gfx950_plan_info_sliced(spblas_gfx950_plan_t plan, int64_t info[12]);
 
 /* Two-stage execution of a SLICED plan (other plans: STATUS_NOT_SUPPORTED), used to overlap the
  * multi-GPU all-gather of finished y rows with the rest of the SpMV:

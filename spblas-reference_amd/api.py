@@ -282,10 +282,10 @@ class _Plan:
         return dict(zip(names, list(arr)))
 
     def sliced_info(self):
-        arr = (ctypes.c_int64 * 8)()
+        arr = (ctypes.c_int64 * 12)()
         check(_capi.lib().spblas_gfx950_plan_info_sliced(self.plan, arr), "spblas_gfx950_plan_info_sliced")
         names = ["n_bins", "variable_bins", "expand_blocks", "reduce_blocks", "placed_entries", "hub_rows", "hub_len",
-                 "ksplit"]
+                 "ksplit", "tiled_rows", "auto_trial", "trial_rowblock_ns", "trial_sliced_ns"]
         return dict(zip(names, list(arr)))
 
     # two-stage execution of a SLICED plan (include/spblas_gfx950.h: spmv_expand / spmv_reduce_rows)

@@ -800,7 +800,7 @@ int spblas_gfx950_plan_info(spblas_gfx950_plan_t plan, int64_t info[12]) {
   return SPBLAS_GFX950_STATUS_SUCCESS;
 }
 
-int spblas_gfx950_plan_info_sliced(spblas_gfx950_plan_t plan, int64_t info[8]) {
+int spblas_gfx950_plan_info_sliced(spblas_gfx950_plan_t plan, int64_t info[12]) {
   if (!plan || !info)
     return SPBLAS_GFX950_STATUS_INVALID_POINTER;
   const bool sl = plan->alg == SPBLAS_GFX950_SPMV_SLICED;
@@ -812,6 +812,10 @@ int spblas_gfx950_plan_info_sliced(spblas_gfx950_plan_t plan, int64_t info[8]) {
   info[5] = sl && plan->hub_len > 0 ? plan->n_hub : 0;
   info[6] = sl ? plan->hub_len : 0;
   info[7] = sl ? plan->n_ksplit : 0;
+  info[8] = sl ? plan->s_m : 0;
+  info[9] = plan->trial_ms[0] > 0.f ? 1 : 0;
+  info[10] = (int64_t) (plan->trial_ms[0] * 1e6f);
+  info[11] = (int64_t) (plan->trial_ms[1] * 1e6f);
   return SPBLAS_GFX950_STATUS_SUCCESS;
 }
 
