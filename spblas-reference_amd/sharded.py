@@ -542,3 +542,98 @@ def try_fused(a_local, bounds, x, reference_step, alg=None, group=None, log=None
     if fused is not None:
         fused.close()
     return None
+
+
+# --------------------------------------------------------------------------- SpMM and SpGEMM over row shards
+def _hip_local_spmm(info, a_local, b, c_local):
+    api.multiply(info, a_local, b, c_local)
+
+
+class ShardedSpMM:
+    """C = A B with A row-sharded, B (k x n, row-major) replicated, C row-sharded (SURVEY.md section 8e,
+    "Partitioning": rows of multiply_impl.hpp:85-91 are independent).  No collective on the data path: every rank
+    owns the rows [bounds[r], bounds[r+1]) of C.  gather_c() assembles the full C on every rank when a caller needs it
+    (one all-gather of the row blocks, in place for equal shards, direct sends for nnz-balanced ones)."""
+
+    def __init__(self, a_local, bounds, ncols, group=None, local_spmm=None, inspect=True):
+        self.group = group
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        assert len(bounds) == self.world + 1 and a_local.shape()[0] == bounds[self.rank + 1] - bounds[self.rank]
+        self.bounds, self.m, self.ncols = list(bounds), bounds[-1], int(ncols)
+        self.a_local = a_local
+        self.local_spmm = local_spmm or _hip_local_spmm
+        vals = a_local.values()
+        self.c_full = torch.zeros((self.m, self.ncols), dtype=vals.dtype, device=vals.device)
+        self.c_local = self.c_full[bounds[self.rank]:bounds[self.rank + 1]]
+        self.info = api.operation_info_t()
+        if inspect and local_spmm is None:
+            b_probe = torch.empty((a_local.shape()[1], self.ncols), dtype=vals.dtype, device=vals.device)
+            self.info = api.multiply_inspect(api.matrix_opt(a_local), b_probe, self.c_local)
+
+    def local(self, b):
+        """This rank's rows of C (a view into its full-size buffer)."""
+        self.local_spmm(self.info, self.a_local, b, self.c_local)
+        return self.c_local
+
+    def gather_c(self):
+        if self.world == 1:
+            return self.c_full
+        counts = [self.bounds[g + 1] - self.bounds[g] for g in range(self.world)]
+        if len(set(counts)) == 1:
+            dist.all_gather_into_tensor(self.c_full, self.c_local, group=self.group)
+            return self.c_full
+        ops = []
+        for g in range(self.world):
+            if g == self.rank:
+                continue
+            peer = g if self.group is None else dist.get_global_rank(self.group, g)
+            if counts[self.rank]:
+                ops.append(dist.P2POp(dist.isend, self.c_local, peer, self.group))
+            if counts[g]:
+                ops.append(dist.P2POp(dist.irecv, self.c_full[self.bounds[g]:self.bounds[g + 1]], peer, self.group))
+        for w in (dist.batch_isend_irecv(ops) if ops else []):
+            w.wait()
+        return self.c_full
+
+
+def _hip_local_spgemm(a_local, b):
+    """(rowptr, colind, values) of a_local * b through multiply_compute / multiply_fill."""
+    m, n = a_local.shape()[0], b.shape()[1]
+    dev = a_local.values().device
+    rp = torch.zeros(m + 1, dtype=torch.int32, device=dev)
+    c = api.csr_view(None, rp, None, (m, n), 0)
+    info = api.multiply_compute(a_local, b, c)
+    nnz = info.result_nnz()
+    c.update(torch.empty(nnz, dtype=a_local.values().dtype, device=dev), rp,
+             torch.empty(nnz, dtype=torch.int32, device=dev), (m, n), nnz)
+    api.multiply_fill(info, a_local, b, c)
+    return c.rowptr(), c.colind(), c.values()
+
+
+class ShardedSpGEMM:
+    """C = A B with A row-sharded and B replicated: every rank computes its block of rows of C with the single-GPU
+    SpGEMM; C's row blocks are disjoint, so the only exchange is the block sizes -- nnz offsets of the global C are an
+    exclusive scan over the ranks.  compute() returns this rank's block as
+    (rowptr rebased to 0, colind, values) together with (nnz_offset, nnz_total) of the global matrix."""
+
+    def __init__(self, a_local, b, bounds, group=None, local_spgemm=None):
+        self.group = group
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        assert len(bounds) == self.world + 1 and a_local.shape()[0] == bounds[self.rank + 1] - bounds[self.rank]
+        self.a_local, self.b, self.bounds = a_local, b, list(bounds)
+        self.local_spgemm = local_spgemm or _hip_local_spgemm
+
+    def compute(self):
+        rowptr, colind, values = self.local_spgemm(self.a_local, self.b)
+        nnz_local = int(rowptr[-1].item()) if rowptr.numel() else 0
+        sizes = [nnz_local]
+        if self.world > 1:
+            on_gpu = dist.get_backend(self.group) == "nccl"
+            mine = torch.tensor([nnz_local], dtype=torch.int64, device=values.device if on_gpu else "cpu")
+            every = torch.zeros(self.world, dtype=torch.int64, device=mine.device)
+            dist.all_gather_into_tensor(every, mine, group=self.group)
+            sizes = [int(v) for v in every.tolist()]
+        offset = sum(sizes[:self.rank])
+        return (rowptr, colind, values), (offset, sum(sizes))

@@ -217,3 +217,26 @@ def test_spmm_long_rows_are_split(gpu, dtype):
     C_ref = oracle.spmm((m, k), rowptr, colind, values, B, scale_a=2.0)
     util.assert_parity(G.host(C), C_ref, 2.0 * absprod(values, rowptr, colind, (m, k), B), dtype,
                        row_len=np.diff(rowptr), what="spmm long rows")
+
+
+def test_row_sharded_spmm_and_spgemm_single_rank_hip_path(gpu):
+    """sharded.ShardedSpMM / ShardedSpGEMM with their default (HIP) local operators, one rank: the multi-rank logic
+    is covered on CPU by tests/test_sharded_cpu.py (gloo, world size 2) with the oracle injected."""
+    from spblas_reference_amd import sharded
+    m, k, n, nnz = 3000, 2000, 24, 40000
+    values, rowptr, colind, shape, _ = generate.generate_csr(m, k, nnz, seed=7)
+    a = G.csr_on_device(values, rowptr, colind, shape, nnz)
+    b_h = np.random.default_rng(9).random((k, n)).astype(np.float32)
+    op = sharded.ShardedSpMM(a, [0, m], n)
+    c = op.local(G.dev(b_h))
+    assert op.gather_c().data_ptr() == c.data_ptr()
+    ref = np.asarray(oracle.spmm(shape, rowptr, colind, values, b_h)).reshape(m, n)
+    absr = np.asarray(oracle.spmm(shape, rowptr, colind, np.abs(values), np.abs(b_h))).reshape(m, n)
+    util.assert_parity(G.host(c).ravel(), ref.ravel(), absr.ravel(), np.float32, row_len=np.full(m * n, 64), what="sharded SpMM")
+    bv, br, bc, bsh, _ = generate.generate_csr(k, m, nnz, seed=8)
+    g = sharded.ShardedSpGEMM(a, G.csr_on_device(bv, br, bc, bsh, nnz), [0, m])
+    (cr, cc, cv), (off, total) = g.compute()
+    n_ref, _ = oracle.spgemm_symbolic(shape, rowptr, colind, bsh, br, bc)
+    fr, fc, fv = oracle.spgemm_numeric(shape, rowptr, colind, values, bsh, br, bc, bv, capacity=n_ref)
+    assert (off, total) == (0, n_ref) and np.array_equal(G.host(cr), fr) and np.array_equal(G.host(cc), fc[:n_ref])
+    assert np.allclose(G.host(cv), fv[:n_ref], rtol=1e-5, atol=1e-3)

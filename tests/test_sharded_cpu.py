@@ -162,3 +162,59 @@ def test_sharded_default_compute_is_the_hip_path():
     op = sharded.ShardedSpMV(a, [0, 1], inspect=False)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         op.step(torch.ones(1))
+
+
+# --------------------------------------------------------------------------- SpMM / SpGEMM over row shards
+def _oracle_local_spmm(info, a_local, b, c_local):
+    c = oracle.spmm(tuple(a_local.shape()), a_local.rowptr().numpy(), a_local.colind().numpy(), a_local.values().numpy(),
+                    b.numpy())
+    c_local.copy_(torch.from_numpy(np.asarray(c).reshape(c_local.shape)))
+
+
+def _oracle_local_spgemm(a_local, b):
+    ash, bsh = tuple(a_local.shape()), tuple(b.shape())
+    ar, ac, av = a_local.rowptr().numpy(), a_local.colind().numpy(), a_local.values().numpy()
+    br, bc, bv = b.rowptr().numpy(), b.colind().numpy(), b.values().numpy()
+    n_ref, _ = oracle.spgemm_symbolic(ash, ar, ac, bsh, br, bc)
+    cr, cc, cv = oracle.spgemm_numeric(ash, ar, ac, av, bsh, br, bc, bv, capacity=n_ref)
+    return torch.from_numpy(cr), torch.from_numpy(cc[:n_ref].copy()), torch.from_numpy(cv[:n_ref].copy())
+
+
+def _worker_spmm_spgemm(rank, world, port, by_nnz, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        m, k, n, nnz = 300, 200, 12, 4000
+        values, rowptr, colind, shape, _ = generate.generate_csr(m, k, nnz, seed=7)
+        t = torch.from_numpy
+        rp_t = t(rowptr)
+        bounds = sharded.partition_rows_by_nnz(rp_t, world) if by_nnz else sharded.partition_rows_even(m, world)
+        a_local = sharded.shard_csr(t(values), rp_t, t(colind), shape, bounds[rank], bounds[rank + 1])
+        # SpMM: B replicated, C row blocks, optional gather
+        b = t(np.random.default_rng(9).random((k, n)).astype(np.float32))
+        op = sharded.ShardedSpMM(a_local, bounds, n, local_spmm=_oracle_local_spmm)
+        c_loc = op.local(b).numpy().copy()
+        c_ref = np.asarray(oracle.spmm(shape, rowptr, colind, values, b.numpy())).reshape(m, n)
+        assert np.array_equal(c_loc, c_ref[bounds[rank]:bounds[rank + 1]])
+        assert np.array_equal(op.gather_c().numpy(), c_ref)
+        # SpGEMM: A row-sharded, B (k x m) replicated, C blocks disjoint, nnz offsets by exclusive scan
+        bv, br, bc, bsh, _ = generate.generate_csr(k, m, nnz, seed=8)
+        b_csr = sp.csr_view(t(bv), t(br), t(bc), bsh, nnz)
+        g = sharded.ShardedSpGEMM(a_local, b_csr, bounds, local_spgemm=_oracle_local_spgemm)
+        (cr, cc, cv), (off, total) = g.compute()
+        n_ref, _ = oracle.spgemm_symbolic(shape, rowptr, colind, bsh, br, bc)
+        fr, fc, fv = oracle.spgemm_numeric(shape, rowptr, colind, values, bsh, br, bc, bv, capacity=n_ref)
+        lo, hi = int(fr[bounds[rank]]), int(fr[bounds[rank + 1]])
+        assert total == n_ref and off == lo
+        assert np.array_equal(cr.numpy(), fr[bounds[rank]:bounds[rank + 1] + 1] - lo)
+        assert np.array_equal(cc.numpy(), fc[lo:hi]) and np.array_equal(cv.numpy(), fv[lo:hi])
+        np.save(os.path.join(out_dir, f"ok_mm_{rank}.npy"), np.array(bounds))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("by_nnz", [False, True])
+def test_row_sharded_spmm_and_spgemm_world2_gloo(by_nnz, tmp_path):
+    mp.spawn(_worker_spmm_spgemm, args=(2, _free_port(), by_nnz, str(tmp_path)), nprocs=2, join=True)
+    assert all(os.path.exists(os.path.join(str(tmp_path), f"ok_mm_{r}.npy")) for r in range(2))
