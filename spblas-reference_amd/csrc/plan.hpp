@@ -76,6 +76,13 @@ struct spblas_gfx950_plan_s {
   void* s_zrow = nullptr;      // int32[n_zero]
   int64_t n_zero = 0;
   int32_t* h_binrow_orig = nullptr;  // host: ORIGINAL first row of every wave-bin (compaction; fetched lazily)
+  // rows longer than split_len entries are cut into PIECES of split_len entries, each a row of the compacted matrix
+  // (bit 31 of its nzrow entry set): no tile then sees one row hundreds of times.  A piece's sum goes to
+  // piece_out[compact row]; pb_split_finish_kernel adds the pieces of a row in order.
+  int split_len = 0;
+  void* s_piece_out = nullptr;   // T[s_m]
+  void* s_split_rows = nullptr;  // int4[n_split]: (row of y, first compact row, pieces, 0)
+  int64_t n_split = 0;
   void* s_hub_rows = nullptr;  // int32[n_hub] rows kept out of the tiles (== long_rows unless variable bins raise the threshold)
   int64_t n_hub = 0;
   bool hub_rows_owned = false;

@@ -112,18 +112,27 @@ __global__ __launch_bounds__(256) void pb_bin_flags_kernel(int64_t m, int H, int
     return;
   flag[r] = (r % H == 0) || ((int64_t) rowptr[r] / E != (int64_t) rowptr[r - 1] / E);
 }
-// Row compaction: flag[r] = row r is non-empty; after the scan pos[r] = non-empty rows before r.
+// The row map of a plan whose tiles are NOT built over the rows of y one to one.  pieces[r] = compact rows that row r
+// of y becomes: 0 for an empty row that is taken out, 1 for an ordinary row, cdiv(len, L) for a row longer than L
+// entries (L = 0: no splitting).  After the scan pos[r] = compact rows before row r.
+static constexpr int32_t PB_PIECE_BIT = (int32_t) 0x80000000;
 template <typename O>
-__global__ __launch_bounds__(256) void pb_nonempty_flags_kernel(int64_t m, const O* __restrict__ rowptr,
-                                                                int32_t* __restrict__ flag) {
+__global__ __launch_bounds__(256) void pb_row_pieces_kernel(int64_t m, const O* __restrict__ rowptr, int drop_empty, int L,
+                                                            int32_t* __restrict__ pieces) {
   const int64_t r = (int64_t) blockIdx.x * 256 + threadIdx.x;
-  if (r < m)
-    flag[r] = rowptr[r + 1] > rowptr[r];
+  if (r >= m)
+    return;
+  const int64_t len = (int64_t) (rowptr[r + 1] - rowptr[r]);
+  pieces[r] = len == 0 ? (drop_empty ? 0 : 1) : (L > 0 && len > L ? (int32_t) ((len + L - 1) / L) : 1);
 }
+// rowptr_c / nzrow of the compact rows (nzrow = row of y, PB_PIECE_BIT set on the pieces of a split row), the list of
+// empty rows that were taken out and the list of split rows (both appended in arbitrary order)
 template <typename O>
-__global__ __launch_bounds__(256) void pb_compact_rows_kernel(int64_t m, const O* __restrict__ rowptr,
-                                                              const int32_t* __restrict__ pos, O* __restrict__ rowptr_c,
-                                                              int32_t* __restrict__ nzrow, int32_t* __restrict__ zrow) {
+__global__ __launch_bounds__(256) void pb_row_map_kernel(int64_t m, const O* __restrict__ rowptr,
+                                                         const int32_t* __restrict__ pos, int L, O* __restrict__ rowptr_c,
+                                                         int32_t* __restrict__ nzrow, int32_t* __restrict__ zrow,
+                                                         int4* __restrict__ split_rows,
+                                                         unsigned long long* __restrict__ counters) {
   const int64_t r = (int64_t) blockIdx.x * 256 + threadIdx.x;
   if (r > m)
     return;
@@ -131,13 +140,35 @@ __global__ __launch_bounds__(256) void pb_compact_rows_kernel(int64_t m, const O
     rowptr_c[pos[m]] = rowptr[m];
     return;
   }
-  const int32_t i = pos[r];
-  if (pos[r + 1] != i) {
+  const int32_t i = pos[r], k = pos[r + 1] - i;
+  if (k == 0) {
+    zrow[atomicAdd(&counters[0], 1ull)] = (int32_t) r;
+  } else if (k == 1) {
     nzrow[i] = (int32_t) r;
     rowptr_c[i] = rowptr[r];
   } else {
-    zrow[r - i] = (int32_t) r;
+    split_rows[atomicAdd(&counters[1], 1ull)] = make_int4((int) r, i, k, 0);
+    for (int j = 0; j < k; ++j) {
+      nzrow[i + j] = (int32_t) r | PB_PIECE_BIT;
+      rowptr_c[i + j] = rowptr[r] + (O) j * (O) L;
+    }
   }
+}
+// y[row] = (sum of the row's pieces, in order) + beta * y[row]: one wavefront per split row
+template <typename T>
+__global__ __launch_bounds__(256) void pb_split_finish_kernel(int64_t n_split, const int4* __restrict__ split_rows,
+                                                              const T* __restrict__ piece_out, T* __restrict__ y, T beta) {
+  const int64_t i = (int64_t) blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (i >= n_split)
+    return;
+  const int4 e = split_rows[i];
+  T s = T(0);
+  for (int j = lane; j < e.z; j += 64)
+    s += piece_out[(int64_t) e.y + j];
+  s = group_sum_c<64>(s);
+  if (lane == 0)
+    y[e.x] = beta == T(0) ? s : s + beta * y[e.x];
 }
 // y = beta * y on the empty rows inside [row_begin, row_end)
 template <typename T>
@@ -158,7 +189,7 @@ __global__ __launch_bounds__(256) void pb_bin_orig_rows_kernel(int64_t NB, int64
   if (b > NB)
     return;
   const int64_t c = binrow[b];
-  out[b] = c < s_m ? nzrow[c] : (int32_t) m;
+  out[b] = c < s_m ? (nzrow[c] & ~PB_PIECE_BIT) : (int32_t) m;
 }
 
 // rows longer than `thr` entries, appended to rows[] in arbitrary order (wave-aggregated append)
@@ -739,6 +770,9 @@ __global__ __launch_bounds__(PB_FTHREADS) void pb_flag_dups_kernel(int Hw, int64
   }
 }
 
+// (Duplicates are added with the native LDS float atomic.  A compare-and-swap loop -- 12x the rate per operation,
+// tools/ubench/lds_atomic.hip -- was tried in its place: 10-20 % faster where two or three lanes share a row, 4x slower
+// where dozens do (R-MAT with whole rows: 3.5 vs 0.8 ms), 35 % slower for fp64, and the larger kernel cost cfg2 6 %.)
 // reduce: RW wavefronts per workgroup, one wave-bin each.  The bin's entries are ONE contiguous stream of
 // groups (256 entries: lane l holds entries 4l..4l+3 -- a 16-byte product load and an 8-byte row load).
 // The loop is software-pipelined by hand: the loads of batch k+1 (UB groups) are issued before batch k is
@@ -757,7 +791,8 @@ __global__ __launch_bounds__(RW * 64) void pb_reduce_kernel(int64_t m, int Hw, i
                                                             int n_peers, int64_t peer_off,
                                                             const int4* __restrict__ ritems, int dbg,
                                                             const int32_t* __restrict__ binrow,
-                                                            const int32_t* __restrict__ rowmap) {
+                                                            const int32_t* __restrict__ rowmap,
+                                                            T* __restrict__ piece_out) {
   // dbg (SPBLAS_GFX950_PB_DBG, timing experiments only -- results are wrong): 1 = skip the atomic path of flagged
   // entries, 2 = no LDS traffic at all (the stream alone)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -862,11 +897,14 @@ __global__ __launch_bounds__(RW * 64) void pb_reduce_kernel(int64_t m, int Hw, i
     }
     return;
   }
-  if (rowmap) {  // tiles built over the non-empty rows only: compact row -> row of y
+  if (rowmap) {  // compact row -> row of y, or (a piece of a split row) -> its slot of piece_out
     for (int i = lane; i < rh; i += 64) {
       const T v = alpha * acc[i];
-      const int64_t r = rowmap[r0 + i];
-      y[r] = beta == T(0) ? v : v + beta * y[r];
+      const int32_t r = rowmap[r0 + i];
+      if (r < 0)
+        piece_out[r0 + i] = v;
+      else
+        y[r] = beta == T(0) ? v : v + beta * y[r];
     }
     return;
   }
@@ -882,15 +920,22 @@ __global__ __launch_bounds__(256) void pb_combine_kernel(int64_t r_lo, int64_t r
                                                          const T* __restrict__ partial, int64_t pstride,
                                                          T* __restrict__ y, T alpha, T beta,
                                                          T* const* __restrict__ peers, int n_peers,
-                                                         int64_t peer_off, const int32_t* __restrict__ rowmap) {
+                                                         int64_t peer_off, const int32_t* __restrict__ rowmap,
+                                                         T* __restrict__ piece_out) {
   int64_t i = r_lo + (int64_t) blockIdx.x * 256 + threadIdx.x;
   if (i >= r_hi)
     return;
   T s = partial[i];
   for (int k = 1; k < K; ++k)
     s += partial[(int64_t) k * pstride + i];
-  if (rowmap)
-    i = rowmap[i];
+  if (rowmap) {
+    const int32_t r = rowmap[i];
+    if (r < 0) {
+      piece_out[i] = alpha * s;
+      return;
+    }
+    i = r;
+  }
   if (peers) {
     for (int p = 0; p < n_peers; ++p)
       peers[p][peer_off + i] = alpha * s;
@@ -944,7 +989,7 @@ __global__ __launch_bounds__(256) void pb_hub_finish_kernel(int64_t n_hub, int p
   T s = T(0);
   for (int k = 0; k < parts; ++k)
     s += part[i * parts + k];
-  y[rowmap ? rowmap[r] : r] += alpha * s;
+  y[rowmap ? (rowmap[r] & ~PB_PIECE_BIT) : r] += alpha * s;
 }
 
 // Work-item variant of the combine: one entry of `cg` per SPLIT bin group = (group, K_g, offset of its
@@ -955,7 +1000,8 @@ __global__ __launch_bounds__(256) void pb_combine_items_kernel(const int4* __res
                                                                int64_t m, const T* __restrict__ partial,
                                                                T* __restrict__ y, T alpha, T beta, int Hw,
                                                                const int32_t* __restrict__ binrow, int64_t NB,
-                                                               const int32_t* __restrict__ rowmap) {
+                                                               const int32_t* __restrict__ rowmap,
+                                                               T* __restrict__ piece_out) {
   const int4 g = cg[blockIdx.x];
   const int64_t i = (int64_t) blockIdx.y * 256 + threadIdx.x;
   if (i >= group_rows)
@@ -972,12 +1018,18 @@ __global__ __launch_bounds__(256) void pb_combine_items_kernel(const int4* __res
   }
   if (row >= m)
     return;
-  if (rowmap)
-    row = rowmap[row];
   const T* src = partial + (int64_t) g.z + i;
   T s = src[0];
   for (int k = 1; k < g.y; ++k)
     s += src[(int64_t) k * group_rows];
+  if (rowmap) {
+    const int32_t r = rowmap[row];
+    if (r < 0) {
+      piece_out[row] = alpha * s;
+      return;
+    }
+    row = r;
+  }
   y[row] = beta == T(0) ? alpha * s : alpha * s + beta * y[row];
 }
 
@@ -1055,41 +1107,86 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
   // Matrices with many empty rows (graphs: 56 % of the rows of R-MAT scale 24) are tiled over their NON-EMPTY rows
   // only: same colind / values, a compacted row pointer array, and the reduce writes row nzrow[i] of y for compact
   // row i.  Empty rows cost accumulator slots and whole wave-bins otherwise (cfg4: 9 445 -> 5 680 bins, padding
-  // 21 % -> 15 %, 2.53 -> 2.32 ms).  Needs variable-height bins (the boundaries live in binrow[]).
+  // 21 % -> 15 %, 2.53 -> 2.32 ms).  In the same row map, rows LONGER than split_len entries become several compact rows
+  // ("pieces"): a row of 16 k entries otherwise leaves ~80 entries in each of its runs, which the reduce has to add
+  // with LDS float atomics -- 0.47 of 0.80 ms on R-MAT scale 22 fp32 (SPBLAS_GFX950_PB_DBG=1).  Pieces are ordinary rows
+  // to every kernel; their sums meet in pb_split_finish_kernel.  Needs variable-height bins (the boundaries live in
+  // binrow[], in compact rows).
   int compact = env_int("SPBLAS_GFX950_PB_COMPACT", -1);
   if (compact < 0)
     compact = pl->empty_rows * 4 > m;
-  if (h->bin_row_align > 1 || env_int("SPBLAS_GFX950_PB_VARBINS", -1) == 0 || pl->empty_rows == 0 || m - pl->empty_rows < 2)
+  if (pl->empty_rows == 0 || m - pl->empty_rows < 2)
     compact = 0;
+  // piece length: the fp32 LDS add is the slow one (0.33 lanes per clock and CU), so fp32 wants pieces short enough that
+  // two entries of a piece rarely meet in one group of the reduce (measured on R-MAT scale 22 / 24: 32 beats 16, 64, 128 and
+  // 512); fp64 is nearly insensitive and prefers fewer compact rows (2048)
+  int split_len = env_int("SPBLAS_GFX950_PB_SPLIT_LEN", sizeof(T) == 4 ? 32 : 2048);
+  {
+    const double avg0 = m > 0 ? (double) nnz / (double) m : 0.0;
+    if (split_len < 8 || pl->max_row_len <= 2 * (int64_t) split_len || (double) pl->max_row_len <= 16.0 * avg0 + 64.0)
+      split_len = 0;  // no row is long enough to matter
+  }
+  if (h->bin_row_align > 1 || env_int("SPBLAS_GFX950_PB_VARBINS", -1) == 0 || m < 2)
+    compact = split_len = 0;
   pl->s_m = m;
-  if (compact) {
-    int32_t* flag = nullptr;
+  pl->split_len = 0;
+  if (compact || split_len > 0) {
+    int32_t* pieces = nullptr;
     long long* fpart = nullptr;
-    const int64_t m_eff = m - pl->empty_rows;
-    if ((rc = dev_alloc((void**) &flag, (size_t) (m + 1) * 4, s)))
+    unsigned long long* counters = nullptr;
+    struct guard_t {
+      hipStream_t s;
+      void* p[3] = {nullptr, nullptr, nullptr};
+      ~guard_t() {
+        for (void* q : p)
+          dev_free(q, s);
+      }
+    } g{s};
+    if ((rc = dev_alloc((void**) &pieces, (size_t) (m + 1) * 4, s)))
       return rc;
-    if ((rc = dev_alloc((void**) &fpart, (size_t) (cdiv(m, 2048) + 2) * sizeof(long long), s)) ||
-        (rc = dev_alloc(&pl->s_rowptr_c, (size_t) (m_eff + 1) * sizeof(O), s)) ||
-        (rc = dev_alloc(&pl->s_nzrow, (size_t) m_eff * 4, s)) ||
-        (rc = dev_alloc(&pl->s_zrow, (size_t) pl->empty_rows * 4, s))) {
-      dev_free(flag, s);
-      dev_free(fpart, s);
+    g.p[0] = pieces;
+    if ((rc = dev_alloc((void**) &fpart, (size_t) (cdiv(m, 2048) + 2) * sizeof(long long), s)))
       return rc;
-    }
-    hipLaunchKernelGGL((pb_nonempty_flags_kernel<O>), dim3((unsigned) cdiv(m, 256)), dim3(256), 0, s, m, rowptr, flag);
-    (void) scan_counts_i32(s, m, flag, fpart);
-    hipLaunchKernelGGL((pb_compact_rows_kernel<O>), dim3((unsigned) cdiv(m + 1, 256)), dim3(256), 0, s, m, rowptr, flag,
+    g.p[1] = fpart;
+    if ((rc = dev_alloc((void**) &counters, 2 * sizeof(unsigned long long), s)))
+      return rc;
+    g.p[2] = counters;
+    SPB_HIP(hipMemsetAsync(counters, 0, 2 * sizeof(unsigned long long), s));
+    hipLaunchKernelGGL((pb_row_pieces_kernel<O>), dim3((unsigned) cdiv(m, 256)), dim3(256), 0, s, m, rowptr, compact,
+                       split_len, pieces);
+    long long* total_dev = scan_counts_i32(s, m, pieces, fpart);
+    long long m_c = 0;
+    if ((rc = readback_add(h, &m_c, total_dev, sizeof(m_c))) || (rc = readback_flush(h)))
+      return rc;
+    if (m_c < 2 || m_c >= INT32_MAX)
+      return SPBLAS_GFX950_STATUS_NOT_SUPPORTED;
+    const int64_t split_cap = split_len > 0 ? nnz / split_len + 1 : 1;
+    if ((rc = dev_alloc(&pl->s_rowptr_c, (size_t) (m_c + 1) * sizeof(O), s)) ||
+        (rc = dev_alloc(&pl->s_nzrow, (size_t) m_c * 4, s)) ||
+        (rc = dev_alloc(&pl->s_zrow, (size_t) (compact ? pl->empty_rows : 1) * 4, s)) ||
+        (rc = dev_alloc(&pl->s_split_rows, (size_t) split_cap * sizeof(int4), s)))
+      return rc;
+    hipLaunchKernelGGL((pb_row_map_kernel<O>), dim3((unsigned) cdiv(m + 1, 256)), dim3(256), 0, s, m, rowptr, pieces, split_len,
                        static_cast<O*>(pl->s_rowptr_c), static_cast<int32_t*>(pl->s_nzrow),
-                       static_cast<int32_t*>(pl->s_zrow));
-    dev_free(flag, s);
-    dev_free(fpart, s);
+                       static_cast<int32_t*>(pl->s_zrow), static_cast<int4*>(pl->s_split_rows), counters);
+    unsigned long long h_cnt[2] = {0, 0};
+    if ((rc = readback_add(h, h_cnt, counters, sizeof(h_cnt))) || (rc = readback_flush(h)))
+      return rc;
     SPB_HIP(hipGetLastError());
-    pl->n_zero = pl->empty_rows;
-    pl->s_m = m_eff;
-    pl->device_bytes += (size_t) (m_eff + 1) * sizeof(O) + (size_t) m * 4;
-    m = m_eff;
+    pl->n_zero = (int64_t) h_cnt[0];
+    pl->n_split = (int64_t) h_cnt[1];
+    if (pl->n_split > 0) {
+      if ((rc = dev_alloc(&pl->s_piece_out, (size_t) m_c * sizeof(T), s)))
+        return rc;
+      pl->split_len = split_len;
+    }
+    pl->s_m = m_c;
+    pl->device_bytes += (size_t) (m_c + 1) * sizeof(O) + (size_t) m_c * 4 + (size_t) pl->n_zero * 4 +
+                        (size_t) pl->n_split * 16 + (pl->n_split > 0 ? (size_t) m_c * sizeof(T) : 0);
+    m = m_c;
     rowptr = static_cast<const O*>(pl->s_rowptr_c);
-    tr.mark("empty rows compacted");
+    compact = 1;  // from here on: "the tiles are built over a row map"
+    tr.mark("row map (empty rows out, long rows split)");
   }
   // x slice of the expand: 80 KiB for fp32 (two workgroups per CU); for fp64 the whole 160 KiB of a CU
   // (one workgroup), which halves the number of slices and doubles the run length
@@ -1250,7 +1347,11 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
   pl->s_hub_rows = pl->long_rows;
   pl->n_hub = pl->n_long;
   pl->hub_rows_owned = false;
-  if (varbins && pl->n_long > 0) {
+  if (pl->split_len > 0) {  // every row of the tiles is at most split_len entries long
+    pl->hub_len = 0;
+    pl->s_hub_rows = nullptr;
+    pl->n_hub = 0;
+  } else if (varbins && pl->n_long > 0) {
     // variable bins keep all but the very longest rows in the tiles (a row of 16 k entries leaves ~20 entries in
     // each of its runs: duplicates the reduce adds atomically, not a serial chain): own list, higher threshold
     const int hub2 = std::max<int>(pl->win, env_int("SPBLAS_GFX950_PB_HUB_LEN", 16384));
@@ -1688,6 +1789,10 @@ static int sliced_reduce_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* p
   const int32_t* rowmap = static_cast<const int32_t*>(pl->s_nzrow);
   if (peers_p && rowmap)
     return SPBLAS_GFX950_STATUS_NOT_SUPPORTED;  // the fused all-gather epilogue writes contiguous rows
+  // the pieces of a split row may lie in different bins: their sums only meet when every bin has been reduced
+  if (pl->n_split > 0 && !(wb_begin == 0 && wb_end == pl->n_rblk))
+    return SPBLAS_GFX950_STATUS_NOT_SUPPORTED;
+  T* piece_out = static_cast<T*>(pl->s_piece_out);
   const bool use_items = pl->s_ritems && !peers_p && wb_begin == 0 && wb_end == pl->n_rblk;
   if (!use_items && K > 1 && pl->s_partial_k < K) {  // grow the partial-sum workspace (stream ordered)
     dev_free(pl->s_partial, s);
@@ -1711,7 +1816,7 @@ static int sliced_reduce_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* p
     int dbg = env_int("SPBLAS_GFX950_PB_DBG", 0);
     const int32_t* binrow = static_cast<const int32_t*>(pl->s_binrow);
     void* args[] = {&mm, &Hw, &wb_begin, &wb_end, &binblk, &Pp, &rowp, &yp, &a, &b, &Kk, &part, &pstride,
-                    &peers, &n_peers, &peer_off, &ritems, &dbg, &binrow, &rowmap};
+                    &peers, &n_peers, &peer_off, &ritems, &dbg, &binrow, &rowmap, &piece_out};
     const size_t lds = (size_t) RW * (pl->rows_per_blk + 64) * sizeof(T);
     if (use_items) {
       // row-skewed matrix, whole range: explicit work list (built at inspect), compact partial sums
@@ -1724,15 +1829,18 @@ static int sliced_reduce_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* p
                            dim3((unsigned) pl->n_rsplit, (unsigned) cdiv((int64_t) RW * pl->rows_per_blk, 256)), dim3(256),
                            0, s, static_cast<const int4*>(pl->s_rsplit), (int64_t) RW * pl->rows_per_blk, pl->s_m,
                            static_cast<const T*>(pl->s_rpartial), static_cast<T*>(y), alpha, beta, pl->rows_per_blk,
-                           binrow, pl->n_rblk, rowmap);
+                           binrow, pl->n_rblk, rowmap, piece_out);
     } else {
       SPB_HIP(hipLaunchKernel(pb_reduce_fn<T>(RW, UB), dim3((unsigned) groups, (unsigned) K), dim3(RW * 64), args, lds, s));
       if (K > 1 && r_hi > r_lo)
         hipLaunchKernelGGL((pb_combine_kernel<T>), dim3((unsigned) cdiv(r_hi - r_lo, 256)), dim3(256), 0, s, r_lo, r_hi, K,
                            static_cast<const T*>(pl->s_partial), pl->s_m, static_cast<T*>(y), alpha, beta,
-                           reinterpret_cast<T* const*>(peers_p), n_peers, peer_off, rowmap);
+                           reinterpret_cast<T* const*>(peers_p), n_peers, peer_off, rowmap, piece_out);
     }
   }
+  if (pl->n_split > 0)  // rows that were cut into pieces: y = (sum of the pieces) + beta * y
+    hipLaunchKernelGGL((pb_split_finish_kernel<T>), dim3((unsigned) cdiv(pl->n_split, 4)), dim3(256), 0, s, pl->n_split,
+                       static_cast<const int4*>(pl->s_split_rows), static_cast<const T*>(piece_out), static_cast<T*>(y), beta);
   if (rowmap && pl->n_zero > 0 && o_hi > o_lo)  // the empty rows inside the range: y = beta * y
     hipLaunchKernelGGL((pb_empty_rows_kernel<T>), dim3((unsigned) cdiv(pl->n_zero, 256)), dim3(256), 0, s, pl->n_zero,
                        static_cast<const int32_t*>(pl->s_zrow), static_cast<T*>(y), beta, o_lo, o_hi);
@@ -1845,6 +1953,11 @@ void spmv_sliced_free(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl) {
   dev_free(pl->s_rowptr_c, s);
   dev_free(pl->s_nzrow, s);
   dev_free(pl->s_zrow, s);
+  dev_free(pl->s_piece_out, s);
+  dev_free(pl->s_split_rows, s);
+  pl->s_piece_out = pl->s_split_rows = nullptr;
+  pl->n_split = 0;
+  pl->split_len = 0;
   pl->s_rowptr_c = pl->s_nzrow = pl->s_zrow = nullptr;
   pl->n_zero = 0;
   pl->s_m = 0;

@@ -5,6 +5,7 @@ SpMV_Ascaled, SpMV_BScaled on util::dims with alpha in {-10,1,5}) and add the ed
 SURVEY.md section 8c lists (empty/ragged rows, unsorted + duplicate columns, one very long
 row, int64 offsets, fp64, inspect/execute, matrix_opt reuse, CSC/transposed operand).
 """
+import ctypes
 import os
 
 import numpy as np
@@ -254,7 +255,7 @@ def test_spmv_values_changed_in_place(gpu):
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
-def test_spmv_sliced_compacts_empty_rows(gpu, dtype):
+def test_spmv_sliced_compacts_empty_rows(gpu, monkeypatch, dtype):
     """Graph-like matrix: 70 % of the rows empty (in stretches, at both ends and scattered), a few hub rows, hot
     columns.  The SLICED plan tiles the non-empty rows only (variable-height bins over compact row numbers); y of an
     empty row must come out as beta * y, alpha / beta forms and row-range reduces must agree with the oracle."""
@@ -274,9 +275,39 @@ def test_spmv_sliced_compacts_empty_rows(gpu, dtype):
     a = G.csr_on_device(values, rowptr, colind, (m, n), nnz)
     xd = G.dev(x)
     y = torch.full((m,), float("nan"), dtype=xd.dtype, device="cuda")
+    # default: empty rows out AND every row longer than L entries cut into pieces of L entries (no hub rows left);
+    # L = 32 for fp32, 2048 for fp64 (csrc/spmv_sliced.hip)
     info = sp.multiply_inspect(a, xd, y, alg=_capi.SPMV_SLICED)
     si = info.state_.sliced_info()
-    assert si["variable_bins"] == 1 and si["hub_rows"] >= 2
+    assert si["variable_bins"] == 1 and si["hub_rows"] == 0
+    L = 32 if dtype == np.float32 else 2048
+    assert si["tiled_rows"] == int((lens > 0).sum()) + int(sum(-(-int(v) // L) - 1 for v in lens if v > L))
+    sp.multiply(info, a, xd, y)
+    yh = G.host(y)
+    assert not np.isnan(yh).any() and not yh[lens == 0].any()
+    check(values, rowptr, colind, (m, n), x, yh, what="compacted + split rows", ref_cmp=False)
+    y.fill_(1.0)   # beta path of the split rows and of the empty rows, through the C ABI
+    alpha_c, beta_c = (ctypes.c_float if dtype == np.float32 else ctypes.c_double)(0.5), \
+        (ctypes.c_float if dtype == np.float32 else ctypes.c_double)(2.0)
+    api_h = sp.api._Handle.current(y.device)
+    assert _capi.lib().spblas_gfx950_spmv(api_h.h, info.state_.plan, _capi.OP_N, m, n, nnz, ctypes.byref(alpha_c),
+                                         ctypes.c_void_p(a.rowptr().data_ptr()), ctypes.c_void_p(a.colind().data_ptr()),
+                                         ctypes.c_void_p(a.values().data_ptr()), ctypes.c_void_p(xd.data_ptr()),
+                                         ctypes.byref(beta_c), ctypes.c_void_p(y.data_ptr()), _capi.I32,
+                                         _capi.F32 if dtype == np.float32 else _capi.F64) == 0
+    want = 0.5 * np.asarray(oracle.spmv((m, n), rowptr, colind, values.astype(np.float64), x.astype(np.float64))) + 2.0
+    absrow = 0.5 * oracle.spmv_absrow(rowptr, colind, values.astype(np.float64), x.astype(np.float64)) + 2.0
+    util.assert_parity(G.host(y), want, absrow, dtype, row_len=lens, what="compacted + split rows, alpha and beta")
+    expand, reduce_rows = info.state_.bind_stages(xd, y.data_ptr(), xd.dtype)
+    expand()
+    with pytest.raises(RuntimeError):      # pieces of one row lie in different bins: no partial row ranges
+        reduce_rows(0, m // 2)
+    del info
+    # rows kept whole (hub rows go through their own kernel): row ranges work
+    monkeypatch.setenv("SPBLAS_GFX950_PB_SPLIT_LEN", "0")
+    info = sp.multiply_inspect(a, xd, y, alg=_capi.SPMV_SLICED)
+    si = info.state_.sliced_info()
+    assert si["variable_bins"] == 1 and si["hub_rows"] >= 2 and si["tiled_rows"] == int((lens > 0).sum())
     assert si["n_bins"] < cdiv(m, info.state_.info()["rows_per_bin"]) + 2100     # far fewer than a bin per H rows of y
     sp.multiply(info, a, xd, y)
     yh = G.host(y)
@@ -457,10 +488,14 @@ def test_spmv_two_stage_and_overlapped_sharding_single_rank(gpu):
         info_rb.state_.bind_stages(x, y2.data_ptr(), torch.float32)[0]()
 
 
-def test_spmv_sliced_with_a_few_dense_rows(gpu):
-    """A uniform matrix with a handful of very long rows: AUTO must still pick the LDS-sliced plan -- the
-    long rows stay out of the tiles and are added by pb_hub_rows_kernel -- and the two-stage entry points
-    must cover them as well."""
+@pytest.mark.parametrize("split", ["pieces", "hub_rows"])
+def test_spmv_sliced_with_a_few_dense_rows(gpu, monkeypatch, split):
+    """A uniform matrix with a handful of very long rows: AUTO must still pick the LDS-sliced plan.  By default the long
+    rows are cut into pieces that the tiles treat as rows ("pieces"; such a plan reduces all rows at once); with
+    SPBLAS_GFX950_PB_SPLIT_LEN=0 they stay out of the tiles and are added by pb_hub_rows_kernel ("hub_rows"), and the
+    two-stage entry points must cover them as well."""
+    if split == "hub_rows":
+        monkeypatch.setenv("SPBLAS_GFX950_PB_SPLIT_LEN", "0")
     rng = np.random.default_rng(21)
     m, n = 300000, 1500000
     lens = np.full(m, 8, np.int64)
@@ -480,14 +515,20 @@ def test_spmv_sliced_with_a_few_dense_rows(gpu):
     assert pi["alg"] == _capi.SPMV_SLICED and pi["n_long_rows"] == 3
     sp.multiply(info, sp.scaled(-1.5, a), xd, y)
     check(values, rowptr, colind, (m, n), x, G.host(y), scale=-1.5, what="sliced + hub rows", ref_cmp=False)
+    si = info.state_.sliced_info()
+    # ("hub_rows": the 120 000- and the 30 000-entry row exceed the 16 384-entry hub threshold, the 5 000-entry row stays)
+    assert (si["hub_rows"], si["tiled_rows"] > m) == ((0, True) if split == "pieces" else (2, False))
     # beta != 0 through the C ABI path of prepared_multiply is covered elsewhere; here: two-stage execution
     y2 = torch.full((m,), float("nan"), device="cuda")
     expand, reduce_rows = info.state_.bind_stages(xd, y2.data_ptr(), torch.float32, alpha=-1.5)
     expand()
-    H = pi["rows_per_bin"]
-    cut = (m // 2 // H) * H
-    reduce_rows(cut, m)
-    reduce_rows(0, cut)
+    if split == "pieces":
+        reduce_rows(0, m)
+    else:
+        H = pi["rows_per_bin"]
+        cut = (m // 2 // H) * H
+        reduce_rows(cut, m)
+        reduce_rows(0, cut)
     assert torch.equal(y, y2)
     # values change in place: update_values refreshes the tiles, the hub rows read the caller's array
     a.values().mul_(2.0)
@@ -508,6 +549,9 @@ def test_spmv_auto_declines_sliced_for_skewed_matrices(gpu, monkeypatch, varbins
     # the static rules ("0": no variable bins, no timed trial -- AUTO must decline) and the round-2 default ("1": the plan
     # is built and AUTO keeps whichever of the two was faster in the trial)
     monkeypatch.setenv("SPBLAS_GFX950_AUTO_TRIAL", varbins)
+    # (rows stay whole here: a plan that cuts long rows into pieces reduces all rows at once, and this test also drives
+    # the two-stage row-range form; test_spmv_sliced_compacts_empty_rows covers the pieces)
+    monkeypatch.setenv("SPBLAS_GFX950_PB_SPLIT_LEN", "0")
     rng = np.random.default_rng(33)
     m, n, per = 400000, 2000000, 8
     rowptr = (np.arange(m + 1, dtype=np.int64) * per).astype(np.int32)
