@@ -169,7 +169,11 @@ int spblas_gfx950_plan_info_sliced(spblas_gfx950_plan_t plan, int64_t info[12]);
  *   expand       products of every stored entry with x (x read once, LDS-resident slices)
  *   reduce_rows  y[r] = alpha * (A x)[r] + beta * y[r] for the row-bins that START in
  *                [row_begin, row_end), from the products of the last expand.  `y` is the base of
- *                the full local y (entry r at y[r]).  spblas_gfx950_spmv == expand + reduce_rows(0, m). */
+ *                the full local y (entry r at y[r]).  spblas_gfx950_spmv == expand + reduce_rows(0, m).
+ *                A plan of a row-skewed matrix that cuts its long rows into pieces (plan_info_sliced[8] > m or the
+ *                plan was made without SPBLAS_GFX950_OPT_BIN_ROW_ALIGN on such a matrix) reduces all rows in ONE call:
+ *                a proper sub-range returns STATUS_NOT_SUPPORTED there.  Plans created under OPT_BIN_ROW_ALIGN > 1 (what
+ *                the striped multi-GPU step sets) never cut rows. */
 int spblas_gfx950_spmv_expand(spblas_gfx950_handle_t handle, spblas_gfx950_plan_t plan, const void* x);
 int spblas_gfx950_spmv_reduce_rows(spblas_gfx950_handle_t handle, spblas_gfx950_plan_t plan, const void* alpha,
                                    const void* beta, void* y, int64_t row_begin, int64_t row_end);
