@@ -25,6 +25,10 @@ DROPIN_RUN = os.path.join(OUT_DIR, "dropin_run")
 REF_DEVICE_TESTS = os.path.join(OUT_DIR, "reference_device_tests")
 # the reference's own device tests, compiled UNMODIFIED from where they lie (never copied into this repository)
 REF_TEST_DIR = "/root/reference/test/gtest"
+# ... and its two device examples (they print a banner and "Example is completed!"; fmt comes header-only from the
+# copy that ships inside the image's PyTorch)
+REF_EXAMPLES = {"ref_example_device_spmv": "/root/reference/examples/device/device_spmv.cpp",
+                "ref_example_rocsparse_simple_spmv": "/root/reference/examples/rocsparse/rocsparse_simple_spmv.cpp"}
 REF_TEST_SOURCES = ["device/spmv_test.cpp", "device/spgemm_test.cpp", "device/spgemm_reuse_test.cpp",
                     "device/rocsparse/spgemm_4args_test.cpp"]
 
@@ -144,3 +148,39 @@ def build_reference_device_tests(libdir, jobs=4):
     if r.returncode != 0:
         raise RuntimeError("link of reference_device_tests failed:\n" + r.stderr[-8000:])
     return REF_DEVICE_TESTS
+
+
+def _fmt_include():
+    try:
+        import torch
+        inc = os.path.join(os.path.dirname(torch.__file__), "include")
+        return inc if os.path.exists(os.path.join(inc, "fmt", "core.h")) else None
+    except Exception:  # noqa: BLE001
+        return None
+
+
+def build_reference_examples(libdir):
+    """The reference's device examples (examples/device/device_spmv.cpp, examples/rocsparse/rocsparse_simple_spmv.cpp),
+    compiled unmodified against this backend.  Returns the binaries' paths ([] where the reference tree or a fmt header
+    is missing)."""
+    fmt = _fmt_include()
+    if not os.path.isdir(REF) or fmt is None or not all(os.path.exists(p) for p in REF_EXAMPLES.values()):
+        return []
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    hipcc = os.path.join(rocm, "bin", "hipcc")
+    os.makedirs(OUT_DIR, exist_ok=True)
+    out = []
+    with tempfile.TemporaryDirectory() as tmp:
+        scratch = patched_reference_headers(os.path.join(tmp, "patched"))
+        flags = [f for f in compile_flags(scratch) if f != "-D__HIP_PLATFORM_AMD__"]
+        for name, src in REF_EXAMPLES.items():
+            binp = os.path.join(OUT_DIR, name)
+            r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O1", "-Wno-reorder-ctor", "-DFMT_HEADER_ONLY", "-I", fmt] +
+                               flags + [src, "-L", libdir, "-lspblas_gfx950",
+                                        "-Wl,-rpath,$ORIGIN/../../../spblas-reference_amd/lib",
+                                        "-Wl,-rpath," + os.path.join(rocm, "lib"), "-o", binp],
+                               capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError(f"hipcc failed on {src}:\n" + r.stderr[-6000:])
+            out.append(binp)
+    return out

@@ -46,3 +46,15 @@ def test_reference_device_tests_pass_on_this_backend(gpu):
     tail = r.stdout[-3000:] + "\n" + r.stderr[-3000:]
     assert r.returncode == 0, tail
     assert "14 tests ran, 0 failed" in r.stdout, tail
+
+
+@pytest.mark.parametrize("name", ["ref_example_device_spmv", "ref_example_rocsparse_simple_spmv"])
+def test_reference_device_examples_run_on_this_backend(gpu, name):
+    """examples/device/device_spmv.cpp and examples/rocsparse/rocsparse_simple_spmv.cpp of the reference, compiled
+    unmodified against this backend (tests/compile_check/build_dropin.py): they run spblas::multiply on device arrays
+    and end with "Example is completed!"."""
+    binp = os.path.join(ROOT, "tests", "compile_check", "_build", name)
+    if not os.path.exists(binp):
+        pytest.skip(f"{name} was not built (needs the reference tree and a fmt header: __graft_entry__.build())")
+    r = subprocess.run([binp], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "Example is completed!" in r.stdout, r.stdout[-1000:] + r.stderr[-2000:]
