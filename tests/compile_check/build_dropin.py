@@ -29,6 +29,11 @@ REF_TEST_DIR = "/root/reference/test/gtest"
 # copy that ships inside the image's PyTorch)
 REF_EXAMPLES = {"ref_example_device_spmv": "/root/reference/examples/device/device_spmv.cpp",
                 "ref_example_rocsparse_simple_spmv": "/root/reference/examples/rocsparse/rocsparse_simple_spmv.cpp"}
+# its HOST tests (the ones the reference builds for CPU backends, test/gtest/CMakeLists.txt:7-15; conjugate_test.cpp is
+# complex-only and built for two backends only, :17-19), run against this DEVICE backend through gtest_main_pinned.cpp
+REF_HOST_TESTS = os.path.join(OUT_DIR, "reference_host_tests")
+REF_HOST_TEST_SOURCES = ["spmv_test.cpp", "spmm_test.cpp", "spgemm_test.cpp", "spgemm_csr_csc.cpp", "add_test.cpp",
+                         "transpose_test.cpp", "triangular_solve_test.cpp", "mdspan_overlays.cpp"]
 REF_TEST_SOURCES = ["device/spmv_test.cpp", "device/spgemm_test.cpp", "device/spgemm_reuse_test.cpp",
                     "device/rocsparse/spgemm_4args_test.cpp"]
 
@@ -184,3 +189,37 @@ def build_reference_examples(libdir):
                 raise RuntimeError(f"hipcc failed on {src}:\n" + r.stderr[-6000:])
             out.append(binp)
     return out
+
+
+def build_reference_host_tests(libdir, jobs=4):
+    """The reference's HOST test files (std::vector operands, no synchronisation) compiled unmodified against this
+    device backend and linked with gtest_main_pinned.cpp, which makes every heap allocation of the test binary
+    pinned, device-visible memory.  Returns the binary's path, or None where the reference tree / a fmt header is
+    missing."""
+    fmt = _fmt_include()
+    if not os.path.isdir(REF) or not os.path.isdir(REF_TEST_DIR) or fmt is None:
+        return None
+    gxx = shutil.which("g++")
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    os.makedirs(OUT_DIR, exist_ok=True)
+    from concurrent.futures import ThreadPoolExecutor
+    with tempfile.TemporaryDirectory() as tmp:
+        scratch = patched_reference_headers(os.path.join(tmp, "patched"))
+        common = [gxx, "-O1", "-DFMT_HEADER_ONLY", "-I", fmt] + compile_flags(scratch)
+        sources = [os.path.join(REF_TEST_DIR, s) for s in REF_HOST_TEST_SOURCES] + [os.path.join(HERE, "gtest_main_pinned.cpp")]
+        objs = [os.path.join(tmp, f"h{i}.o") for i in range(len(sources))]
+
+        def compile_one(i):
+            return subprocess.run(common + ["-c", sources[i], "-o", objs[i]], capture_output=True, text=True)
+
+        with ThreadPoolExecutor(max_workers=jobs) as pool:
+            for i, r in enumerate(pool.map(compile_one, range(len(sources)))):
+                if r.returncode != 0:
+                    raise RuntimeError(f"g++ failed on {sources[i]}:\n" + r.stderr[-8000:])
+        r = subprocess.run([gxx] + objs + ["-L", libdir, "-lspblas_gfx950", "-L", os.path.join(rocm, "lib"), "-lamdhip64",
+                                           "-Wl,-rpath,$ORIGIN/../../../spblas-reference_amd/lib",
+                                           "-Wl,-rpath," + os.path.join(rocm, "lib"), "-o", REF_HOST_TESTS],
+                           capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("link of reference_host_tests failed:\n" + r.stderr[-8000:])
+    return REF_HOST_TESTS

@@ -1,6 +1,6 @@
 // TEST-RUN INFRASTRUCTURE ONLY (tests/compile_check/build_dropin.py: build_reference_device_tests()).
 // The image has no GoogleTest.  This is the handful of macros the reference's device tests use -- TEST,
-// EXPECT_EQ, EXPECT_NEAR -- with a registry and a main() (gtest_main.cpp), so that those test files can be compiled
+// EXPECT_EQ, EXPECT_NE, EXPECT_LE, EXPECT_NEAR -- with a registry and a main() (gtest_main.cpp), so that those test files can be compiled
 // UNMODIFIED from the reference tree against the gfx950 backend.  Not GoogleTest, pins nothing.
 #pragma once
 #include <cmath>
@@ -51,6 +51,22 @@ void report(const char* kind, const char* ea, const char* eb, const A& a, const 
     auto&& vb_ = (b);                                                                         \
     if (!(va_ == vb_))                                                                        \
       ::testing_stub::report("EXPECT_EQ", #a, #b, va_, vb_, __FILE__, __LINE__);              \
+  } while (0)
+
+#define EXPECT_NE(a, b)                                                                       \
+  do {                                                                                        \
+    auto&& va_ = (a);                                                                         \
+    auto&& vb_ = (b);                                                                         \
+    if (!(va_ != vb_))                                                                        \
+      ::testing_stub::report("EXPECT_NE", #a, #b, va_, vb_, __FILE__, __LINE__);              \
+  } while (0)
+
+#define EXPECT_LE(a, b)                                                                       \
+  do {                                                                                        \
+    auto&& va_ = (a);                                                                         \
+    auto&& vb_ = (b);                                                                         \
+    if (!(va_ <= vb_))                                                                        \
+      ::testing_stub::report("EXPECT_LE", #a, #b, va_, vb_, __FILE__, __LINE__);              \
   } while (0)
 
 #define EXPECT_NEAR(a, b, tol)                                                                \

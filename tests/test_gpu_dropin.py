@@ -58,3 +58,22 @@ def test_reference_device_examples_run_on_this_backend(gpu, name):
         pytest.skip(f"{name} was not built (needs the reference tree and a fmt header: __graft_entry__.build())")
     r = subprocess.run([binp], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "Example is completed!" in r.stdout, r.stdout[-1000:] + r.stderr[-2000:]
+
+
+def test_reference_host_tests_pass_on_this_backend(gpu):
+    """The reference's HOST tests -- test/gtest/{spmv,spmm,spgemm,spgemm_csr_csc,add,transpose,triangular_solve}_test.cpp
+    and mdspan_overlays.cpp, the list its CMake builds for CPU backends (test/gtest/CMakeLists.txt:7-15), 28 TESTs --
+    compiled UNMODIFIED against this device backend.  They keep their operands in std::vector and never synchronise;
+    tests/compile_check/gtest_main_pinned.cpp gives the test binary a heap of pinned, device-visible memory
+    (operator new -> one hipHostMalloc slab) and the binary runs with AMD_SERIALIZE_KERNEL / AMD_SERIALIZE_COPY = 3 so
+    that every launch has finished when the call returns.  Neither the tests nor the backend are changed for it.
+    Covers what the device tests do not: SpMM (n = 1 ... 512, csr and csc A), csc / transposed SpMV with scaling, all
+    CSR / CSC combinations of SpGEMM, add, transpose, both triangular solves, the mdspan overlays."""
+    binp = os.path.join(ROOT, "tests", "compile_check", "_build", "reference_host_tests")
+    if not os.path.exists(binp):
+        pytest.skip("reference_host_tests was not built (needs the reference tree and a fmt header: __graft_entry__.build())")
+    env = dict(os.environ, AMD_SERIALIZE_KERNEL="3", AMD_SERIALIZE_COPY="3")
+    r = subprocess.run([binp], capture_output=True, text=True, timeout=900, env=env)
+    tail = r.stdout[-3000:] + "\n" + r.stderr[-3000:]
+    assert r.returncode == 0, tail
+    assert "28 tests ran, 0 failed" in r.stdout, tail
