@@ -37,6 +37,7 @@ void dropin_instantiations(spblas::csr_view<T, I, O> a, spblas::csr_view<T, I, O
   multiply(scaled(3.0f, a), B, C);
   operation_info_t info_mm = multiply_inspect(a, B, C);
   multiply(info_mm, a, B, C);
+  multiply(a_csc, B, C);  // csc_view A (test/gtest/spmm_test.cpp:181)
   // SpGEMM: vendor/rocsparse/multiply_spgemm.hpp:232-317
   operation_info_t info_g = multiply_compute(a, b, c);
   multiply_compute(info_g, a, b, c);
@@ -47,6 +48,12 @@ void dropin_instantiations(spblas::csr_view<T, I, O> a, spblas::csr_view<T, I, O
   multiply_symbolic_compute(state, a, b, c);
   multiply_symbolic_fill(state, a, b, c);
   multiply_numeric(state, scaled(2.0f, a), b, c);
+  // CSR / CSC operand combinations (test/gtest/spgemm_test.cpp:205, spgemm_csr_csc.cpp)
+  spblas::csc_view<T, I, O> c_csc(static_cast<T*>(nullptr), static_cast<O*>(nullptr), static_cast<I*>(nullptr), {0, 0}, 0);
+  operation_info_t info_gc = multiply_compute(a_csc, a_csc, c_csc);
+  multiply_fill(info_gc, a_csc, a_csc, c_csc);
+  operation_info_t info_gm = multiply_compute(a, a_csc, c);
+  multiply_fill(info_gm, a, a_csc, c);
   // four-argument forms  C = alpha*A*B + beta*D  (multiply_spgemm.hpp:237-274)
   multiply_compute(state, a, b, c, d);
   multiply_fill(state, a, b, c, d);
