@@ -34,6 +34,9 @@ REF_EXAMPLES = {"ref_example_device_spmv": "/root/reference/examples/device/devi
 REF_HOST_TESTS = os.path.join(OUT_DIR, "reference_host_tests")
 REF_HOST_TEST_SOURCES = ["spmv_test.cpp", "spmm_test.cpp", "spgemm_test.cpp", "spgemm_csr_csc.cpp", "add_test.cpp",
                          "transpose_test.cpp", "triangular_solve_test.cpp", "mdspan_overlays.cpp"]
+# ... and its eight host examples (their own main(): linked with pinned_heap.cpp)
+REF_HOST_EXAMPLES = ["simple_spmv", "simple_spmm", "simple_spgemm", "simple_sptrsv", "spmm_csc", "spmm_csr", "sptrsv_csr",
+                     "matrix_opt_example"]
 REF_TEST_SOURCES = ["device/spmv_test.cpp", "device/spgemm_test.cpp", "device/spgemm_reuse_test.cpp",
                     "device/rocsparse/spgemm_4args_test.cpp"]
 
@@ -223,3 +226,33 @@ def build_reference_host_tests(libdir, jobs=4):
     if r.returncode != 0:
         raise RuntimeError("link of reference_host_tests failed:\n" + r.stderr[-8000:])
     return REF_HOST_TESTS
+
+
+def build_reference_host_examples(libdir, jobs=4):
+    """examples/*.cpp of the reference (host vectors, fmt output) against this device backend, each linked with
+    pinned_heap.cpp (the pinned, device-visible heap set up before main()).  Returns the binaries' paths."""
+    fmt = _fmt_include()
+    if not os.path.isdir(REF) or fmt is None:
+        return []
+    gxx = shutil.which("g++")
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    os.makedirs(OUT_DIR, exist_ok=True)
+    from concurrent.futures import ThreadPoolExecutor
+    with tempfile.TemporaryDirectory() as tmp:
+        scratch = patched_reference_headers(os.path.join(tmp, "patched"))
+        common = [gxx, "-O1", "-DFMT_HEADER_ONLY", "-I", fmt] + compile_flags(scratch)
+        tail = [os.path.join(HERE, "pinned_heap.cpp"), "-L", libdir, "-lspblas_gfx950", "-L", os.path.join(rocm, "lib"),
+                "-lamdhip64", "-Wl,-rpath,$ORIGIN/../../../spblas-reference_amd/lib", "-Wl,-rpath," + os.path.join(rocm, "lib")]
+
+        def build_one(name):
+            binp = os.path.join(OUT_DIR, "ref_host_example_" + name)
+            return binp, subprocess.run(common + [os.path.join("/root/reference/examples", name + ".cpp")] + tail + ["-o", binp],
+                                        capture_output=True, text=True)
+
+        out = []
+        with ThreadPoolExecutor(max_workers=jobs) as pool:
+            for binp, r in pool.map(build_one, REF_HOST_EXAMPLES):
+                if r.returncode != 0:
+                    raise RuntimeError(f"g++ failed on {binp}:\n" + r.stderr[-6000:])
+                out.append(binp)
+    return out

@@ -391,6 +391,15 @@ int main() {
     operation_info_t info = triangular_solve_inspect(l, lower_triangle_t{}, explicit_diagonal_t{}, db.span(), dx.span());
     triangular_solve(info, l, lower_triangle_t{}, explicit_diagonal_t{}, db.span(), dx.span());
     expect(close_vec(dx.host(), want, sc), "triangular_solve(info, L, lower, explicit, b, x)");
+    {  // scaled right-hand side (examples/simple_sptrsv.cpp:49-53): x = inv(L) (3 b) = 3 inv(L) b
+      std::vector<double> want3(want), sc3(sc);
+      for (std::size_t i = 0; i < want3.size(); ++i) {
+        want3[i] *= 3.0;
+        sc3[i] *= 3.0;
+      }
+      triangular_solve(l, lower_triangle_t{}, explicit_diagonal_t{}, scaled(3.0f, db.span()), dx.span());
+      expect(close_vec(dx.host(), want3, sc3), "triangular_solve(L, lower, explicit, scaled(3, b), x)");
+    }
     // U = L^T as CSR, unit diagonal: x_i = b_i - sum_{k > i} u_ik x_k
     const host_csr hu = host_transpose(hl);
     for (I r = m - 1; r >= 0; --r) {

@@ -77,3 +77,16 @@ def test_reference_host_tests_pass_on_this_backend(gpu):
     tail = r.stdout[-3000:] + "\n" + r.stderr[-3000:]
     assert r.returncode == 0, tail
     assert "28 tests ran, 0 failed" in r.stdout, tail
+
+
+@pytest.mark.parametrize("name", ["simple_spmv", "simple_spmm", "simple_spgemm", "simple_sptrsv", "spmm_csc", "spmm_csr",
+                                  "sptrsv_csr", "matrix_opt_example"])
+def test_reference_host_examples_run_on_this_backend(gpu, name):
+    """examples/*.cpp of the reference (host vectors), compiled unmodified against this device backend and linked with
+    tests/compile_check/pinned_heap.cpp (pinned, device-visible heap before main()); serialised launches as above."""
+    binp = os.path.join(ROOT, "tests", "compile_check", "_build", "ref_host_example_" + name)
+    if not os.path.exists(binp):
+        pytest.skip(f"{name} was not built (needs the reference tree and a fmt header: __graft_entry__.build())")
+    env = dict(os.environ, AMD_SERIALIZE_KERNEL="3", AMD_SERIALIZE_COPY="3")
+    r = subprocess.run([binp], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode == 0 and "Example is completed!" in r.stdout, r.stdout[-1000:] + r.stderr[-2000:]
