@@ -1051,8 +1051,9 @@ def _trsv_operands(a, uplo, diag, b, x):
         raise TypeError("triangular_solve: uplo must be upper_triangle_t or lower_triangle_t")  # :48-49 static_assert
     if not isinstance(diag, (implicit_unit_diagonal_t, explicit_diagonal_t)):
         raise TypeError("triangular_solve: diag must be implicit_unit_diagonal_t or explicit_diagonal_t")
-    if get_scaling_factor(b) is not None or get_scaling_factor(x) is not None:
-        raise NotImplementedError("gfx950 triangular_solve: scaled b / x views are not supported")
+    if get_scaling_factor(x) is not None:
+        raise NotImplementedError("gfx950 triangular_solve: x must be a plain vector")
+    b = get_ultimate_base(b)  # scaled(alpha, b) is allowed (examples/simple_sptrsv.cpp:49-53): applied to x afterwards
     m, n = a_base.shape()
     # the reference asserts squareness and matching vector lengths (triangular_solve_impl.hpp:50-53)
     if m != n or not _is_tensor(b) or not _is_tensor(x) or b.dim() != 1 or x.dim() != 1 or x.numel() != n or \
@@ -1118,6 +1119,11 @@ def triangular_solve(*args):
     vt, ct = _vtype(a_base.values(), "triangular_solve")
     sa = get_scaling_factor(a)
     alpha = ct(1 if sa is None else sa)
+    sb = get_scaling_factor(b)
     check(_capi.lib().spblas_gfx950_sptrsv_solve(hd.h, plan.plan, a_base.shape()[0], a_base.size(),
                                                  ctypes.byref(alpha), _ptr(a_base.rowptr()), _ptr(a_base.colind()),
-                                                 _ptr(a_base.values()), _ptr(b), _ptr(x), vt), "triangular_solve")
+                                                 _ptr(a_base.values()), _ptr(get_ultimate_base(b)), _ptr(x), vt),
+          "triangular_solve")
+    if sb is not None:  # the solve is linear in b: x = inv(A) (s b) = s inv(A) b
+        beta = ct(sb)
+        check(_capi.lib().spblas_gfx950_scale(hd.h, x.numel(), ctypes.byref(beta), _ptr(x), vt), "triangular_solve")

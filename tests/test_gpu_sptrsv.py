@@ -127,6 +127,19 @@ def test_other_triangle_is_ignored_and_last_diagonal_wins(gpu):
     assert np.array_equal(x, ref) and np.array_equal(ref, np.array([2.0, 2.0]))
 
 
+def test_scaled_right_hand_side(gpu):
+    """examples/simple_sptrsv.cpp:49-53 passes scaled(alpha, b): x = inv(T) (alpha b)."""
+    rng = np.random.default_rng(13)
+    n = 1500
+    M = tri_system(n, 0.01, False, rng)
+    b = rng.random(n) + 0.5
+    d_a = G.csr_on_device(M.data.astype(np.float64), M.indptr.astype(np.int32), M.indices.astype(np.int32), M.shape, M.nnz)
+    d_b, d_x = G.dev(b), torch.full((n,), float("nan"), dtype=torch.float64, device="cuda")
+    sp.triangular_solve(d_a, sp.lower_triangle, sp.explicit_diagonal, sp.scaled(-3.0, d_b), d_x)
+    ref = oracle.triangular_solve(M.shape, M.indptr, M.indices, M.data, -3.0 * b, upper=False, unit=False)
+    assert np.allclose(G.host(d_x), ref, rtol=1e-11, atol=1e-13)
+
+
 @pytest.mark.parametrize("alpha", [2.0, -0.5])
 def test_scaled_matrix_view(gpu, alpha):
     rng = np.random.default_rng(3)
