@@ -256,3 +256,45 @@ def build_reference_host_examples(libdir, jobs=4):
                     raise RuntimeError(f"g++ failed on {binp}:\n" + r.stderr[-6000:])
                 out.append(binp)
     return out
+
+
+ORACLE_HOST_TESTS = os.path.join(OUT_DIR, "reference_host_tests_on_oracle")
+
+
+def build_reference_host_tests_on_oracle(jobs=4):
+    """The same eight host test files of the reference, behind the same drop-in header layer, but linked to
+    oracle_shim.c + oracle/spblas_oracle.c instead of the GPU library: spblas::multiply & co. end in the CPU oracle, on
+    ordinary host memory, no GPU involved.  Passing = the oracle reproduces every known answer the reference's tests
+    hold for this path (tests/test_oracle_reference_tests.py).  Returns the binary's path or None."""
+    fmt = _fmt_include()
+    if not os.path.isdir(REF) or not os.path.isdir(REF_TEST_DIR) or fmt is None:
+        return None
+    gxx, gcc = shutil.which("g++"), shutil.which("gcc")
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    os.makedirs(OUT_DIR, exist_ok=True)
+    shim = os.path.join(OUT_DIR, "liboracle_shim.so")
+    r = subprocess.run([gcc, "-O2", "-fPIC", "-shared", "-I", os.path.join(ROOT, "include"), os.path.join(HERE, "oracle_shim.c"),
+                        os.path.join(ROOT, "oracle", "spblas_oracle.c"), "-o", shim], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("gcc failed on oracle_shim.c:\n" + r.stderr[-4000:])
+    from concurrent.futures import ThreadPoolExecutor
+    with tempfile.TemporaryDirectory() as tmp:
+        scratch = patched_reference_headers(os.path.join(tmp, "patched"))
+        common = [gxx, "-O1", "-DFMT_HEADER_ONLY", "-I", fmt] + compile_flags(scratch)
+        sources = [os.path.join(REF_TEST_DIR, s) for s in REF_HOST_TEST_SOURCES] + [os.path.join(HERE, "gtest_main.cpp")]
+        objs = [os.path.join(tmp, f"o{i}.o") for i in range(len(sources))]
+
+        def compile_one(i):
+            return subprocess.run(common + ["-c", sources[i], "-o", objs[i]], capture_output=True, text=True)
+
+        with ThreadPoolExecutor(max_workers=jobs) as pool:
+            for i, r in enumerate(pool.map(compile_one, range(len(sources)))):
+                if r.returncode != 0:
+                    raise RuntimeError(f"g++ failed on {sources[i]}:\n" + r.stderr[-8000:])
+        # (libamdhip64 only satisfies the inline stream helpers of stream_memory.hpp; nothing calls into it)
+        r = subprocess.run([gxx] + objs + [shim, "-L", os.path.join(rocm, "lib"), "-lamdhip64", "-Wl,-rpath,$ORIGIN",
+                                           "-Wl,-rpath," + os.path.join(rocm, "lib"), "-o", ORACLE_HOST_TESTS],
+                           capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("link of reference_host_tests_on_oracle failed:\n" + r.stderr[-8000:])
+    return ORACLE_HOST_TESTS

@@ -1,0 +1,42 @@
+"""The CPU oracle pinned by the reference's OWN tests ("check it against every ... known-answer test
+... the reference's own tests hold for this path").
+
+The reference stores no golden vectors: its known answers are the comparator loops inside its test files.  Here the eight
+host test files its CMake builds for CPU backends (test/gtest/CMakeLists.txt:7-15: spmv, spmm, spgemm, spgemm_csr_csc,
+add, transpose, triangular_solve, mdspan_overlays -- 28 TESTs) are compiled UNMODIFIED, from where they lie in the
+reference tree, behind the drop-in header layer, and linked to tests/compile_check/oracle_shim.c, which implements the C
+ABI those headers call with oracle/spblas_oracle.c on ordinary host memory (no GPU).  So spblas::multiply,
+multiply_compute / multiply_fill, add, transpose and triangular_solve of those tests END IN THE ORACLE, and the
+reference's own EXPECT_EQ_ comparators (test/gtest/util.hpp:7-23) judge it.
+
+What this is not: a build of the reference's algorithms (with a vendor backend selected none of them is compiled in; the
+stand-in headers under tests/compile_check/stubs/ only let its views, generators and test macros parse).  The binary is
+built where the reference tree exists (this container); where it does not (the GPU box) the prebuilt binary still runs.
+"""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from compile_check import build_dropin  # noqa: E402
+
+
+def test_oracle_passes_the_reference_host_tests():
+    binp = build_dropin.ORACLE_HOST_TESTS
+    if os.path.isdir(build_dropin.REF):
+        built = build_dropin.build_reference_host_tests_on_oracle()
+        assert built, "could not build the reference's host tests against the oracle (fmt header missing?)"
+        binp = built
+    elif not os.path.exists(binp):
+        pytest.skip("no reference tree here and no prebuilt reference_host_tests_on_oracle")
+    r = subprocess.run([binp], capture_output=True, text=True, timeout=900)
+    tail = r.stdout[-3000:] + "\n" + r.stderr[-3000:]
+    assert r.returncode == 0, tail
+    assert "28 tests ran, 0 failed" in r.stdout, tail
+    ran = [line.split("]", 1)[1].strip() for line in r.stdout.splitlines() if line.startswith("[       OK ]")]
+    for must in ("CsrView.SpMV", "CscView.SpMV", "CsrView.SpMM", "CscView.SpMM", "CsrView.SpGEMM", "CscView.SpGEMM",
+                 "CsrView.Add_CSR_CSR_CSR", "CsrView.Transpose", "CsrView.TriangularSolveLowerImplicit"):
+        assert must in ran, (must, ran)
