@@ -12,8 +12,9 @@
  * (test/gtest/CMakeLists.txt:7-15 -- spmv, spmm, spgemm, spgemm_csr_csc, add, transpose, triangular_solve,
  * mdspan_overlays: 28 TESTs) are compiled UNMODIFIED from the reference tree and linked, through the drop-in
  * header layer and tests/compile_check/oracle_shim.c, to THIS file: spblas::multiply & co. of those tests end in the
- * functions below and the reference's own EXPECT_EQ_ comparators judge them -- 28 tests, 0 failures
- * (tests/test_oracle_reference_tests.py, part of the CPU suite).  What remains unpinned: the reference's CPU
+ * functions below and the reference's own EXPECT_EQ_ comparators judge them -- 28 tests, 0 failures; its four
+ * device test files (reuse family, four-argument SpGEMM; thrust::device_vector as a host vector) do the same --
+ * 14 tests, 0 failures (tests/test_oracle_reference_tests.py, part of the CPU suite).  What remains unpinned: the reference's CPU
  * ALGORITHMS themselves are not built here (header-only C++23 that needs range-v3 / kokkos-mdspan via CMake
  * FetchContent, CMakeLists.txt:120-124,143-147; neither is in the image and the rules of this build forbid a
  * reference build on stand-in headers), so no bitwise comparison "oracle vs reference multiply()" exists; the

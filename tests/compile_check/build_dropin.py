@@ -298,3 +298,42 @@ def build_reference_host_tests_on_oracle(jobs=4):
     if r.returncode != 0:
         raise RuntimeError("link of reference_host_tests_on_oracle failed:\n" + r.stderr[-8000:])
     return ORACLE_HOST_TESTS
+
+
+ORACLE_DEVICE_TESTS = os.path.join(OUT_DIR, "reference_device_tests_on_oracle")
+
+
+def build_reference_device_tests_on_oracle(jobs=4):
+    """The reference's four DEVICE test files linked to the oracle shim as well: stubs_host/thrust/device_vector.h makes
+    thrust::device_vector a host vector, g++ compiles them, and the symbolic / numeric reuse family and the four-argument
+    SpGEMM of those tests end in oracle_spgemm_* (tests/test_oracle_reference_tests.py).  Returns the path or None."""
+    if not os.path.isdir(REF) or not os.path.isdir(REF_TEST_DIR):
+        return None
+    gxx, gcc = shutil.which("g++"), shutil.which("gcc")
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    os.makedirs(OUT_DIR, exist_ok=True)
+    shim = os.path.join(OUT_DIR, "liboracle_shim.so")
+    r = subprocess.run([gcc, "-O2", "-fPIC", "-shared", "-I", os.path.join(ROOT, "include"), os.path.join(HERE, "oracle_shim.c"),
+                        os.path.join(ROOT, "oracle", "spblas_oracle.c"), "-o", shim], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("gcc failed on oracle_shim.c:\n" + r.stderr[-4000:])
+    from concurrent.futures import ThreadPoolExecutor
+    with tempfile.TemporaryDirectory() as tmp:
+        scratch = patched_reference_headers(os.path.join(tmp, "patched"))
+        common = [gxx, "-O1", "-I", os.path.join(HERE, "stubs_host")] + compile_flags(scratch)
+        sources = [os.path.join(REF_TEST_DIR, s) for s in REF_TEST_SOURCES] + [os.path.join(HERE, "gtest_main.cpp")]
+        objs = [os.path.join(tmp, f"d{i}.o") for i in range(len(sources))]
+
+        def compile_one(i):
+            return subprocess.run(common + ["-c", sources[i], "-o", objs[i]], capture_output=True, text=True)
+
+        with ThreadPoolExecutor(max_workers=jobs) as pool:
+            for i, r in enumerate(pool.map(compile_one, range(len(sources)))):
+                if r.returncode != 0:
+                    raise RuntimeError(f"g++ failed on {sources[i]}:\n" + r.stderr[-8000:])
+        r = subprocess.run([gxx] + objs + [shim, "-L", os.path.join(rocm, "lib"), "-lamdhip64", "-Wl,-rpath,$ORIGIN",
+                                           "-Wl,-rpath," + os.path.join(rocm, "lib"), "-o", ORACLE_DEVICE_TESTS],
+                           capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("link of reference_device_tests_on_oracle failed:\n" + r.stderr[-8000:])
+    return ORACLE_DEVICE_TESTS

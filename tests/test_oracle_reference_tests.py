@@ -40,3 +40,22 @@ def test_oracle_passes_the_reference_host_tests():
     for must in ("CsrView.SpMV", "CscView.SpMV", "CsrView.SpMM", "CscView.SpMM", "CsrView.SpGEMM", "CscView.SpGEMM",
                  "CsrView.Add_CSR_CSR_CSR", "CsrView.Transpose", "CsrView.TriangularSolveLowerImplicit"):
         assert must in ran, (must, ran)
+
+
+def test_oracle_passes_the_reference_device_tests():
+    """The four DEVICE test files of the reference (test/gtest/CMakeLists.txt:24-26: spmv, spgemm, spgemm_reuse,
+    rocsparse/spgemm_4args -- 14 TESTs) judge the oracle as well: thrust::device_vector is a host vector here
+    (tests/compile_check/stubs_host/thrust/device_vector.h), everything else as above.  This is what pins
+    oracle_spgemm_symbolic_d / oracle_spgemm_numeric_d_* (C = alpha A B + beta D has no CPU implementation in the
+    reference: its known answers are spgemm_4args_test.cpp:78-108) and the symbolic / numeric reuse family."""
+    binp = build_dropin.ORACLE_DEVICE_TESTS
+    if os.path.isdir(build_dropin.REF):
+        built = build_dropin.build_reference_device_tests_on_oracle()
+        assert built
+        binp = built
+    elif not os.path.exists(binp):
+        pytest.skip("no reference tree here and no prebuilt reference_device_tests_on_oracle")
+    r = subprocess.run([binp], capture_output=True, text=True, timeout=900)
+    tail = r.stdout[-3000:] + "\n" + r.stderr[-3000:]
+    assert r.returncode == 0, tail
+    assert "14 tests ran, 0 failed" in r.stdout, tail
