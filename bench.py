@@ -285,6 +285,25 @@ def main():
             plan_info["auto_trial"] = {k: si[k] for k in ("trial_rowblock_ns", "trial_sliced_ns")}
 
     elapsed, kern_avg_ms = measure(lambda: op.step(x), args.steps, args.warmup, multi, device)
+    fused_post_check = None
+    if multi and mode == "fused" and rccl_op is not None:
+        # The fused exchange was validated against the RCCL path before the timed loop (sharded.try_fused); check it once
+        # more AFTER hundreds of steps, with vectors it has not seen, so that a peer store that only goes stale under
+        # load cannot publish a number: any mismatch on any rank and the RCCL path is timed instead.
+        ok = 1
+        for x_k in (1.25 * x + 0.5, 0.75 * x - 0.25):
+            y_f = op.step(x_k).clone()
+            y_r = rccl_op.step(x_k)
+            torch.cuda.synchronize()
+            ok &= int(torch.equal(y_f, y_r))
+        flag = torch.tensor([ok], dtype=torch.int32, device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        fused_post_check = bool(int(flag.item()))
+        if not fused_post_check:
+            if rank == 0:
+                print("[bench] fused all-gather failed its post-check; timing the RCCL all-gather path instead", file=sys.stderr)
+            op, mode = rccl_op, "plain"
+            elapsed, kern_avg_ms = measure(lambda: op.step(x), args.steps, args.warmup, multi, device)
 
     # Where the time of a multi-GPU step goes (outside the timed region, same K): the local kernels alone, the
     # all-gather alone, the RCCL step and -- when it could be set up -- the fused step.
@@ -297,6 +316,7 @@ def main():
         diag = {"mode_timed": mode, "local_spmv_ms": local_s / k * 1e3, "local_spmv_event_ms": local_ev,
                 "gather_ms": gather_s / k * 1e3, "rccl_step_ms": rccl_s / k * 1e3,
                 "fused_step_ms": elapsed / args.steps * 1e3 if mode == "fused" else None,
+                "fused_post_check": fused_post_check,
                 "gather": getattr(rccl_op, "gather_mode", "inplace"),
                 "rows_per_rank": [bounds[r + 1] - bounds[r] for r in range(world)],
                 "note": "each figure: K steps between barriers, max over ranks; local = kernels only, gather = "

@@ -56,6 +56,7 @@ def test_bench_multi_gpu_code_path_with_one_rank(gpu, fused):
     assert mg["mode_timed"] == ("fused" if fused == "auto" else "plain")
     assert mg["local_spmv_ms"] > 0 and mg["gather_ms"] >= 0 and mg["rccl_step_ms"] > 0
     assert (mg["fused_step_ms"] is not None) == (fused == "auto")
+    assert mg["fused_post_check"] is (True if fused == "auto" else None)   # fused results re-checked after the timed loop
 
 
 def test_bench_cfg4_rmat_multi_gpu_code_path_with_one_rank(gpu):
