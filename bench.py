@@ -333,6 +333,18 @@ def main():
     kern_ms = sorted(sum(a.elapsed_time(b) for a, b in step_ev) for step_ev in ev)
     values, rowptr, colind = a_chunks[0].values(), a_chunks[0].rowptr(), a_chunks[0].colind()
 
+    # a second inspect of the same matrix (N = 1 only): the first one of a process also loads the code objects and
+    # first-touches the pool, this one is what a caller pays from then on
+    inspect_warm_ms = None
+    if not multi and args.alg != "noplan" and mode == "plain":
+        y_tmp = torch.empty(rows_local, dtype=dtype, device=device)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        info_w = sp.multiply_inspect(sp.matrix_opt(a_chunks[0]), x, y_tmp, alg=algs[args.alg])
+        torch.cuda.synchronize()
+        inspect_warm_ms = (time.perf_counter() - t1) * 1e3
+        del info_w, y_tmp
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         gflops = 2.0 * nnz / (elapsed / args.steps) / 1e9
@@ -354,7 +366,8 @@ def main():
                                        "into hipIpc-mapped copies of y + device-side step barrier)" if mode == "fused" else
                                        f"row-sharded x{world} ({'nnz-prefix' if rmat else 'equal'} shards), {chunks} stripe(s) per step "
                                        f"({mode}), one RCCL all-gather(y) per stripe"),
-                       "alg": args.alg, "plan": plan_info, "inspect_ms_untimed": inspect_ms},
+                       "alg": args.alg, "plan": plan_info, "inspect_ms_untimed": inspect_ms,
+                       "inspect_warm_ms_untimed": inspect_warm_ms},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          # fraction of the rate a streaming copy reaches on this part (6.29 TB/s, MI355X_MICROARCH.md)
