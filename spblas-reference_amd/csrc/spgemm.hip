@@ -55,9 +55,15 @@ struct spblas_gfx950_spgemm_s {
   // numeric pass of a symbolic result records, for every product of the rows in the LDS-hash bins 1-2, the rank of
   // its column in the (sorted) output row; later passes accumulate by rank -- no hash, no compaction, no sort
   int32_t* r_pbase = nullptr;   // [m + 1] first product of every row in the enumeration order
-  uint16_t* r_rank = nullptr;   // [products] rank of the product's column in its output row
+  uint8_t* r_rank = nullptr;    // [products] rank of the product's column in its output row (rows of <= 256 products)
   int32_t* r_cols = nullptr;    // [nnz(C)] the sorted column indices (the caller may pass other arrays later)
   const int32_t* r_last_colind = nullptr;  // the caller's column array the last numeric pass filled
+  // (start, length) of the B row every entry of A selects, written once by the symbolic pass: every later kernel
+  // streams 8 B per A entry instead of chasing a_colind -> b_rowptr[.], b_rowptr[. + 1].  Under the B-row gathers of
+  // a fill b_rowptr (4 MB at cfg5) does not stay in the L2s, and those lookups were 1.35 of the 4.08 GB a fill by
+  // rank read (profiles/r02e_spgemm_pmc.md).  nullptr (no B, out of memory, SPBLAS_GFX950_SPG_ADESC=0): the kernels
+  // look the rows up themselves.
+  int2* r_adesc = nullptr;      // [a_nnz]
   bool r_ready = false;
   int numeric_calls = 0;        // numeric passes since the symbolic one (the SECOND records: a one-shot fill pays nothing)
 };
@@ -83,28 +89,35 @@ __global__ __launch_bounds__(256) void spg_bound_kernel(int64_t m, const int32_t
                                                         const int32_t* __restrict__ a_colind,
                                                         const int32_t* __restrict__ b_rowptr,
                                                         const int32_t* __restrict__ d_rowptr,
+                                                        const int2* __restrict__ adesc,
                                                         int32_t* __restrict__ bin_of_row,
                                                         unsigned long long* __restrict__ bin_count) {
+  // grid-stride over groups of 32 rows: the bin histogram stays in LDS for the whole workgroup and reaches the
+  // global counters once per workgroup -- with one workgroup per 32 rows the 31 k same-address atomics of a
+  // 1 M-row matrix (~11 ns each, serialised) were the whole 0.38 ms of this kernel
   __shared__ unsigned int hist[SPG_NBINS];
   if (threadIdx.x < SPG_NBINS)
     hist[threadIdx.x] = 0;
   __syncthreads();
-  const int64_t row = (int64_t) blockIdx.x * 32 + threadIdx.x / 8;
   const int lane = threadIdx.x % 8;
-  int64_t ub = 0;
-  if (row < m) {
+  for (int64_t row = (int64_t) blockIdx.x * 32 + threadIdx.x / 8; row < m; row += (int64_t) gridDim.x * 32) {
+    int64_t ub = 0;
     for (int p = a_rowptr[row] + lane; p < a_rowptr[row + 1]; p += 8) {
+      if (adesc) {
+        ub += adesc[p].y;
+        continue;
+      }
       const int kk = a_colind[p];
       ub += b_rowptr ? b_rowptr[kk + 1] - b_rowptr[kk] : 1;  // no B: identity (add(), see below)
     }
-  }
-  ub = group_sum_c<8>(ub);
-  if (row < m && d_rowptr)
-    ub += d_rowptr[row + 1] - d_rowptr[row];
-  if (row < m && lane == 0) {
-    const int b = spg_bin_of(ub);
-    bin_of_row[row] = b;
-    atomicAdd(&hist[b], 1u);
+    ub = group_sum_c<8>(ub);
+    if (d_rowptr)
+      ub += d_rowptr[row + 1] - d_rowptr[row];
+    if (lane == 0) {
+      const int b = spg_bin_of(ub);
+      bin_of_row[row] = b;
+      atomicAdd(&hist[b], 1u);
+    }
   }
   __syncthreads();
   if (threadIdx.x < SPG_NBINS && hist[threadIdx.x])
@@ -201,7 +214,8 @@ __global__ __launch_bounds__(256) void spg_hash_kernel(
     const int32_t* __restrict__ b_colind, const T* __restrict__ b_values, int32_t* __restrict__ c_rowptr,
     int32_t* __restrict__ c_colind, T* __restrict__ c_values, T alpha, int sub, long long ncols,
     const int32_t* __restrict__ d_rowptr, const int32_t* __restrict__ d_colind, const T* __restrict__ d_values,
-    T beta, int b_has_entries) {
+    T beta, int b_has_entries, const int2* __restrict__ adesc) {
+  // adesc != nullptr: (start, length) of the B row of every A entry (then a_colind / b_rowptr are not read)
   constexpr int HS = 1 << LOG2HS;
   constexpr int RPB = 256 / TPR;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -267,9 +281,15 @@ __global__ __launch_bounds__(256) void spg_hash_kernel(
         int qb = 0, qe = 0;
         T av = T(0);
         if (pc + lt < p1) {
-          const int kk = a_colind[pc + lt];
-          qb = b_rowptr ? b_rowptr[kk] : kk;
-          qe = b_rowptr ? b_rowptr[kk + 1] : kk + 1;
+          if (adesc) {
+            const int2 dd = adesc[pc + lt];
+            qb = dd.x;
+            qe = dd.x + dd.y;
+          } else {
+            const int kk = a_colind[pc + lt];
+            qb = b_rowptr ? b_rowptr[kk] : kk;
+            qe = b_rowptr ? b_rowptr[kk + 1] : kk + 1;
+          }
           if (NUMERIC)
             av = alpha * a_values[pc + lt];
         }
@@ -310,10 +330,18 @@ __global__ __launch_bounds__(256) void spg_hash_kernel(
       }
     } else {
       for (int p = p0 + sg; p < p1; p += nsg) {
-        const int kk = a_colind[p];
         const T av = NUMERIC ? alpha * a_values[p] : T(0);
-        const int q1 = b_rowptr ? b_rowptr[kk + 1] : kk + 1;
-        for (int q = (b_rowptr ? b_rowptr[kk] : kk) + sl; q < q1; q += sub)
+        int qs, q1;
+        if (adesc) {
+          const int2 dd = adesc[p];
+          qs = dd.x;
+          q1 = dd.x + dd.y;
+        } else {
+          const int kk = a_colind[p];
+          qs = b_rowptr ? b_rowptr[kk] : kk;
+          q1 = b_rowptr ? b_rowptr[kk + 1] : kk + 1;
+        }
+        for (int q = qs + sl; q < q1; q += sub)
           insert(b_rowptr ? b_colind[q] : q, NUMERIC ? (b_rowptr ? av * b_values[q] : av) : T(0));
       }
     }
@@ -502,12 +530,17 @@ __global__ __launch_bounds__(256) void spg_dense_kernel(
 __global__ __launch_bounds__(256) void spg_products_kernel(int64_t m, const int32_t* __restrict__ a_rowptr,
                                                            const int32_t* __restrict__ a_colind,
                                                            const int32_t* __restrict__ b_rowptr,
+                                                           const int2* __restrict__ adesc,
                                                            int32_t* __restrict__ prod) {
   const int64_t row = (int64_t) blockIdx.x * 32 + threadIdx.x / 8;
   const int lane = threadIdx.x % 8;
   int64_t ub = 0;
   if (row < m)
     for (int p = a_rowptr[row] + lane; p < a_rowptr[row + 1]; p += 8) {
+      if (adesc) {
+        ub += adesc[p].y;
+        continue;
+      }
       const int kk = a_colind[p];
       ub += b_rowptr[kk + 1] - b_rowptr[kk];
     }
@@ -516,52 +549,146 @@ __global__ __launch_bounds__(256) void spg_products_kernel(int64_t m, const int3
     prod[row] = ub <= 256 ? (int32_t) ub : 0;
 }
 
-// MODE 0: record the rank of every product's column in its output row (binary search in the row's sorted columns,
-// held in LDS).  MODE 1: numeric pass by rank: vals[rank] += a * b in LDS, then one coalesced write of the row's
-// values and columns.  Both walk the products of a row in the same order: A entries in storage order, the entries
-// of each B row in storage order; product index = r_pbase[row] + (entries of the earlier B rows) + offset.
-// Teams of TPR <= 64 lanes inside one wavefront (bins 1-2), SUB lanes per B row, as in spg_hash_kernel.
-template <typename T, int TPR, int CAP, int MODE>
-__global__ __launch_bounds__(256) void spg_ranked_kernel(
+// Numeric reuse, recording pass: the rank of every product's column in its (sorted) output row -- a binary search in
+// the row's columns, held in LDS.  The products of a row are enumerated in a fixed order that the fills by rank
+// (spg_ranked_fill_kernel) repeat: A entries in storage order, the entries of each B row in storage order; product
+// index = r_pbase[row] + (entries of the earlier B rows) + offset.  Rows of bins 1-2 have <= 256 products, hence
+// <= 256 output entries: a rank fits one byte.
+// Teams of TPR <= 64 lanes inside one wavefront, SUB lanes per B row, as in spg_hash_kernel.
+template <int TPR, int CAP>
+__global__ __launch_bounds__(256) void spg_rank_record_kernel(
     int64_t count, const int32_t* __restrict__ perm, const int32_t* __restrict__ a_rowptr,
-    const int32_t* __restrict__ a_colind, const T* __restrict__ a_values, const int32_t* __restrict__ b_rowptr,
-    const int32_t* __restrict__ b_colind, const T* __restrict__ b_values, const int32_t* __restrict__ c_rowptr,
-    const int32_t* __restrict__ cols_sorted, int32_t* __restrict__ c_colind, T* __restrict__ c_values, T alpha,
-    int sub, const int32_t* __restrict__ pbase, uint16_t* __restrict__ prank, int copy_cols) {
+    const int32_t* __restrict__ a_colind, const int32_t* __restrict__ b_rowptr, const int2* __restrict__ adesc,
+    const int32_t* __restrict__ b_colind, const int32_t* __restrict__ c_rowptr,
+    const int32_t* __restrict__ cols_sorted, int sub, const int32_t* __restrict__ pbase,
+    uint8_t* __restrict__ prank) {
   constexpr int RPB = 256 / TPR;
-  __shared__ int s_keys[MODE == 0 ? RPB * CAP : 1];
-  __shared__ T s_vals[MODE == 1 ? RPB * CAP : 1];
+  __shared__ int s_keys[RPB * CAP];
   const int team = threadIdx.x / TPR, lt = threadIdx.x % TPR;
   const int64_t idx = (int64_t) blockIdx.x * RPB + team;
   const bool live = idx < count;
   const int row = live ? perm[idx] : 0;
   const int out0 = live ? c_rowptr[row] : 0;
   const int d = live ? c_rowptr[row + 1] - out0 : 0;
-  int* tkeys = s_keys + (MODE == 0 ? team * CAP : 0);
-  T* tvals = s_vals + (MODE == 1 ? team * CAP : 0);
-  for (int i = lt; i < d; i += TPR) {
-    if (MODE == 0)
-      tkeys[i] = cols_sorted[out0 + i];
-    else
-      tvals[i] = T(0);
+  int* tkeys = s_keys + team * CAP;
+  for (int i = lt; i < d; i += TPR)
+    tkeys[i] = cols_sorted[out0 + i];
+  spg_team_sync<TPR>();
+  if (!live)
+    return;
+  const int p0 = a_rowptr[row], p1 = a_rowptr[row + 1];
+  const int sg = lt / sub, sl = lt % sub, nsg = TPR / sub;
+  const int tbase = (threadIdx.x & 63) - lt;  // first lane of the team in its wave
+  int running = pbase[row];
+  for (int pc = p0; pc < p1; pc += TPR) {
+    int qb = 0, len = 0;
+    if (pc + lt < p1) {
+      if (adesc) {
+        const int2 dd = adesc[pc + lt];
+        qb = dd.x;
+        len = dd.y;
+      } else {
+        const int kk = a_colind[pc + lt];
+        qb = b_rowptr[kk];
+        len = b_rowptr[kk + 1] - qb;
+      }
+    }
+    // exclusive scan of the B-row lengths over the team's lanes (team-uniform trip count)
+    int incl = len;
+    for (int o = 1; o < TPR; o <<= 1) {
+      const int t = __shfl_up(incl, o, TPR);
+      if (lt >= o)
+        incl += t;
+    }
+    const int excl = incl - len;
+    const int total = __shfl(incl, tbase + TPR - 1);
+    const int cnt = (p1 - pc) < TPR ? (p1 - pc) : TPR;
+    for (int j0 = 0; j0 < cnt; j0 += nsg) {
+      const int j = j0 + sg;
+      const int src = tbase + (j < cnt ? j : 0);
+      const int q0 = __shfl(qb, src);
+      const int ln = __shfl(len, src);
+      const int off = __shfl(excl, src);
+      if (j < cnt)
+        for (int q = sl; q < ln; q += sub) {
+          const int col = b_colind[q0 + q];
+          int lo = 0, hi = d;  // last position with tkeys[pos] <= col (the column is present by construction)
+          while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (tkeys[mid] <= col)
+              lo = mid;
+            else
+              hi = mid;
+          }
+          prank[running + off + q] = (uint8_t) lo;
+        }
+    }
+    running += total;
   }
+}
+
+__global__ __launch_bounds__(256) void spg_adesc_kernel(int64_t a_nnz, const int32_t* __restrict__ a_colind,
+                                                        const int32_t* __restrict__ b_rowptr,
+                                                        int2* __restrict__ adesc) {
+  const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
+  if (i < a_nnz) {
+    const int kk = a_colind[i];
+    struct __attribute__((packed, aligned(4))) pair_t {
+      int lo, hi;
+    };
+    const pair_t r = *reinterpret_cast<const pair_t*>(b_rowptr + kk);  // one 8-byte load, 4-byte aligned
+    adesc[i] = make_int2(r.lo, r.hi - r.lo);
+  }
+}
+// Numeric pass by rank: vals[rank] += a * b in LDS, then one coalesced write of the row's values (and columns).
+//  * U entries of the A row per sub-group are taken up together, so that the rank and B-value loads of U B rows are in
+//    flight before the first LDS update;
+//  * a row whose product count equals its number of output entries has no two products on the same column: every
+//    product then owns its slot, so the slots are written with plain LDS stores -- no zero fill, no read-modify-write
+//    (cfg5: 96.6 % of the rows).  Rows with repeated columns accumulate as before.
+// Same product enumeration as the recording kernel: r_rank does not depend on TPR, SUB or U.
+template <typename T, int TPR, int CAP, int U>
+__global__ __launch_bounds__(256) void spg_ranked_fill_kernel(
+    int64_t count, const int32_t* __restrict__ perm, const int32_t* __restrict__ a_rowptr,
+    const int32_t* __restrict__ a_colind, const T* __restrict__ a_values, const int32_t* __restrict__ b_rowptr,
+    const int2* __restrict__ adesc, const T* __restrict__ b_values, const int32_t* __restrict__ c_rowptr,
+    const int32_t* __restrict__ cols_sorted, int32_t* __restrict__ c_colind, T* __restrict__ c_values, T alpha,
+    int sub, const int32_t* __restrict__ pbase, const uint8_t* __restrict__ prank, int copy_cols) {
+  // adesc != nullptr: (start, length) in b_values of the B row of every A entry (a_colind / b_rowptr are not read)
+  constexpr int RPB = 256 / TPR;
+  __shared__ T s_vals[RPB * CAP];
+  const int team = threadIdx.x / TPR, lt = threadIdx.x % TPR;
+  const int64_t idx = (int64_t) blockIdx.x * RPB + team;
+  const bool live = idx < count;
+  const int row = live ? perm[idx] : 0;
+  const int out0 = live ? c_rowptr[row] : 0;
+  const int d = live ? c_rowptr[row + 1] - out0 : 0;
+  int running = live ? pbase[row] : 0;
+  const bool plain = live && pbase[row + 1] - running == d;
+  T* tvals = s_vals + team * CAP;
+  if (!plain)
+    for (int i = lt; i < d; i += TPR)
+      tvals[i] = T(0);
   spg_team_sync<TPR>();
   if (live) {
     const int p0 = a_rowptr[row], p1 = a_rowptr[row + 1];
     const int sg = lt / sub, sl = lt % sub, nsg = TPR / sub;
     const int tbase = (threadIdx.x & 63) - lt;  // first lane of the team in its wave
-    int running = pbase[row];
     for (int pc = p0; pc < p1; pc += TPR) {
       int qb = 0, len = 0;
       T av = T(0);
       if (pc + lt < p1) {
-        const int kk = a_colind[pc + lt];
-        qb = b_rowptr[kk];
-        len = b_rowptr[kk + 1] - qb;
-        if (MODE == 1)
-          av = alpha * a_values[pc + lt];
+        if (adesc) {
+          const int2 dd = adesc[pc + lt];
+          qb = dd.x;
+          len = dd.y;
+        } else {
+          const int kk = a_colind[pc + lt];
+          qb = b_rowptr[kk];
+          len = b_rowptr[kk + 1] - qb;
+        }
+        av = alpha * a_values[pc + lt];
       }
-      // exclusive scan of the B-row lengths over the team's lanes (team-uniform trip count)
       int incl = len;
       for (int o = 1; o < TPR; o <<= 1) {
         const int t = __shfl_up(incl, o, TPR);
@@ -571,42 +698,57 @@ __global__ __launch_bounds__(256) void spg_ranked_kernel(
       const int excl = incl - len;
       const int total = __shfl(incl, tbase + TPR - 1);
       const int cnt = (p1 - pc) < TPR ? (p1 - pc) : TPR;
-      for (int j0 = 0; j0 < cnt; j0 += nsg) {
-        const int j = j0 + sg;
-        const int src = tbase + (j < cnt ? j : 0);
-        const int q0 = __shfl(qb, src);
-        const int ln = __shfl(len, src);
-        const int off = __shfl(excl, src);
-        const T a = MODE == 1 ? __shfl(av, src) : T(0);
-        if (j < cnt)
-          for (int q = sl; q < ln; q += sub) {
-            const int pidx = running + off + q;
-            if (MODE == 0) {
-              const int col = b_colind[q0 + q];
-              int lo = 0, hi = d;  // first position with tkeys[pos] >= col (the column is present by construction)
-              while (hi - lo > 1) {
-                const int mid = (lo + hi) >> 1;
-                if (tkeys[mid] <= col)
-                  lo = mid;
-                else
-                  hi = mid;
-              }
-              prank[pidx] = (uint16_t) lo;
-            } else {
-              spg_lds_add(&tvals[prank[pidx]], a * b_values[q0 + q]);
-            }
+      for (int j0 = 0; j0 < cnt; j0 += U * nsg) {
+        int q0[U], ln[U], pb[U], rk[U];
+        T a[U], bv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int j = j0 + u * nsg + sg;
+          const int src = tbase + (j < cnt ? j : 0);
+          q0[u] = __shfl(qb, src);
+          ln[u] = __shfl(len, src);
+          pb[u] = running + __shfl(excl, src);
+          a[u] = __shfl(av, src);
+          if (j >= cnt)
+            ln[u] = 0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          rk[u] = 0;
+          bv[u] = T(0);
+          if (sl < ln[u]) {
+            rk[u] = prank[pb[u] + sl];
+            bv[u] = b_values[q0[u] + sl];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          if (sl < ln[u]) {
+            if (plain)
+              tvals[rk[u]] = a[u] * bv[u];
+            else
+              spg_lds_add(&tvals[rk[u]], a[u] * bv[u]);
+          }
+        // B rows longer than the sub-group: the rest of their entries, one round at a time
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          for (int q = sl + sub; q < ln[u]; q += sub) {
+            const T v = a[u] * b_values[q0[u] + q];
+            const int r = prank[pb[u] + q];
+            if (plain)
+              tvals[r] = v;
+            else
+              spg_lds_add(&tvals[r], v);
           }
       }
       running += total;
     }
   }
-  if (MODE == 1) {
-    spg_team_sync<TPR>();
-    for (int i = lt; i < d; i += TPR) {
-      c_values[out0 + i] = tvals[i];
-      if (copy_cols)
-        c_colind[out0 + i] = cols_sorted[out0 + i];
-    }
+  spg_team_sync<TPR>();
+  for (int i = lt; i < d; i += TPR) {
+    c_values[out0 + i] = tvals[i];
+    if (copy_cols)
+      c_colind[out0 + i] = cols_sorted[out0 + i];
   }
 }
 
@@ -646,7 +788,7 @@ static int launch_hash(hipStream_t s, const spblas_gfx950_spgemm_s* st, int bin,
   hipLaunchKernelGGL(kern, dim3((unsigned) cdiv(count, RPB)), dim3(256), smem, s, count,
                      st->perm + st->bin_off[bin], st->a_rowptr, st->a_colind, a_values, st->b_rowptr,
                      st->b_colind, b_values, c_rowptr, c_colind, c_values, alpha, sub, (long long) (st->n > 0 ? st->n : 1),
-                     st->d_rowptr, st->d_colind, d_values, beta, (int) (st->b_nnz > 0));
+                     st->d_rowptr, st->d_colind, d_values, beta, (int) (st->b_nnz > 0), st->r_adesc);
   SPB_HIP(hipGetLastError());
   return SPBLAS_GFX950_STATUS_SUCCESS;
 }
@@ -698,19 +840,57 @@ static int run_bins(spblas_gfx950_handle_t h, spblas_gfx950_spgemm_s* st, const 
   return SPBLAS_GFX950_STATUS_SUCCESS;
 }
 
-template <typename T, int MODE>
-static void launch_ranked(hipStream_t s, const spblas_gfx950_spgemm_s* st, const T* a_values, const T* b_values,
-                          int32_t* c_colind, T* c_values, T alpha, int copy_cols) {
+template <typename T, int TPR, int CAP>
+static void launch_ranked_fill(hipStream_t s, const spblas_gfx950_spgemm_s* st, int64_t cnt, int64_t first,
+                               const T* a_values, const T* b_values, int32_t* c_colind, T* c_values, T alpha,
+                               int copy_cols) {
+  const int sub = st->sub < TPR ? st->sub : TPR;
+  constexpr int RPB = 256 / TPR;
+  hipLaunchKernelGGL((spg_ranked_fill_kernel<T, TPR, CAP, 4>), dim3((unsigned) cdiv(cnt, RPB)), dim3(256), 0, s, cnt,
+                     st->perm + first, st->a_rowptr, st->a_colind, a_values, st->b_rowptr, st->r_adesc, b_values,
+                     st->rowptr, st->r_cols, c_colind, c_values, alpha, sub, st->r_pbase, st->r_rank, copy_cols);
+}
+
+// the recording pass for the rows of bins 1-2 ...
+static void launch_rank_record(hipStream_t s, const spblas_gfx950_spgemm_s* st) {
   const int64_t c1 = st->bin_off[2] - st->bin_off[1], c2 = st->bin_off[3] - st->bin_off[2];
   const int sub1 = st->sub < 16 ? st->sub : 16, sub2 = st->sub < 64 ? st->sub : 64;
   if (c1 > 0)
-    hipLaunchKernelGGL((spg_ranked_kernel<T, 16, 64, MODE>), dim3((unsigned) cdiv(c1, 16)), dim3(256), 0, s, c1,
-                       st->perm + st->bin_off[1], st->a_rowptr, st->a_colind, a_values, st->b_rowptr, st->b_colind, b_values,
-                       st->rowptr, st->r_cols, c_colind, c_values, alpha, sub1, st->r_pbase, st->r_rank, copy_cols);
+    hipLaunchKernelGGL((spg_rank_record_kernel<16, 64>), dim3((unsigned) cdiv(c1, 16)), dim3(256), 0, s, c1,
+                       st->perm + st->bin_off[1], st->a_rowptr, st->a_colind, st->b_rowptr, st->r_adesc, st->b_colind,
+                       st->rowptr, st->r_cols, sub1, st->r_pbase, st->r_rank);
   if (c2 > 0)
-    hipLaunchKernelGGL((spg_ranked_kernel<T, 64, 256, MODE>), dim3((unsigned) cdiv(c2, 4)), dim3(256), 0, s, c2,
-                       st->perm + st->bin_off[2], st->a_rowptr, st->a_colind, a_values, st->b_rowptr, st->b_colind, b_values,
-                       st->rowptr, st->r_cols, c_colind, c_values, alpha, sub2, st->r_pbase, st->r_rank, copy_cols);
+    hipLaunchKernelGGL((spg_rank_record_kernel<64, 256>), dim3((unsigned) cdiv(c2, 4)), dim3(256), 0, s, c2,
+                       st->perm + st->bin_off[2], st->a_rowptr, st->a_colind, st->b_rowptr, st->r_adesc, st->b_colind,
+                       st->rowptr, st->r_cols, sub2, st->r_pbase, st->r_rank);
+}
+
+// ... and their fills by rank.  Team width of a bin-2 row: the A entries of a row are walked TPR at a time, and a
+// 64-lane team on a 16-entry row leaves the wave with one row's dependent loads in flight; narrower teams put 2-4
+// rows into every wave (cfg5: 0.93 -> 0.78 ms; SPBLAS_GFX950_SPG_RANKED_TPR=16/32/64 overrides the choice).
+template <typename T>
+static void launch_ranked(hipStream_t s, const spblas_gfx950_spgemm_s* st, const T* a_values, const T* b_values,
+                          int32_t* c_colind, T* c_values, T alpha, int copy_cols) {
+  const int64_t c1 = st->bin_off[2] - st->bin_off[1], c2 = st->bin_off[3] - st->bin_off[2];
+  static const int tpr_env = [] {
+    const char* e = std::getenv("SPBLAS_GFX950_SPG_RANKED_TPR");
+    return e ? std::atoi(e) : 0;
+  }();
+  const double avg_a = st->m > 0 ? (double) st->a_nnz / (double) st->m : 0.0;
+  const int tpr2 = tpr_env ? tpr_env : avg_a <= 16.0 ? 16 : avg_a <= 32.0 ? 32 : 64;
+  if (c1 > 0)
+    launch_ranked_fill<T, 16, 64>(s, st, c1, st->bin_off[1], a_values, b_values, c_colind, c_values, alpha, copy_cols);
+  if (c2 > 0) {
+    if (tpr2 == 16)
+      launch_ranked_fill<T, 16, 256>(s, st, c2, st->bin_off[2], a_values, b_values, c_colind, c_values, alpha,
+                                     copy_cols);
+    else if (tpr2 == 32)
+      launch_ranked_fill<T, 32, 256>(s, st, c2, st->bin_off[2], a_values, b_values, c_colind, c_values, alpha,
+                                     copy_cols);
+    else
+      launch_ranked_fill<T, 64, 256>(s, st, c2, st->bin_off[2], a_values, b_values, c_colind, c_values, alpha,
+                                     copy_cols);
+  }
 }
 
 // numeric pass.  Plain three-argument products (no addend, real B) whose rows sit in the LDS-hash bins 1-2 are
@@ -724,7 +904,7 @@ static int spgemm_numeric_typed(spblas_gfx950_handle_t h, spblas_gfx950_spgemm_s
   if (st->r_ready) {
     // columns: rewritten unless the caller vouches for the array's contents (OPT_SPGEMM_KEEP_COLIND) and it is the
     // array the previous pass filled -- the address alone proves nothing, allocators hand freed addresses out again
-    launch_ranked<T, 1>(s, st, a_values, b_values, c_colind, c_values, alpha,
+    launch_ranked<T>(s, st, a_values, b_values, c_colind, c_values, alpha,
                         !(h->spgemm_keep_colind != 0 && c_colind == st->r_last_colind));
     SPB_HIP(hipGetLastError());
     st->r_last_colind = c_colind;
@@ -747,7 +927,7 @@ static int spgemm_numeric_typed(spblas_gfx950_handle_t h, spblas_gfx950_spgemm_s
       (rc = dev_alloc((void**) &partials, (size_t) (nb + 2) * sizeof(long long), s)))
     return SPBLAS_GFX950_STATUS_SUCCESS;  // out of memory for the optional fast path: keep the hash path
   hipLaunchKernelGGL(spg_products_kernel, dim3((unsigned) cdiv(m, 32)), dim3(256), 0, s, m, st->a_rowptr, st->a_colind,
-                     st->b_rowptr, st->r_pbase);
+                     st->b_rowptr, st->r_adesc, st->r_pbase);
   long long* total_dev = scan_counts_i32(s, m, st->r_pbase, partials);
   long long total = 0;
   hipError_t e = hipMemcpyAsync(&total, total_dev, sizeof(total), hipMemcpyDeviceToHost, s);
@@ -757,7 +937,7 @@ static int spgemm_numeric_typed(spblas_gfx950_handle_t h, spblas_gfx950_spgemm_s
   if (e != hipSuccess)
     return hip_fail(e);
   if (total <= 0 || total > INT32_MAX ||
-      dev_alloc((void**) &st->r_rank, (size_t) total * 2, s) != SPBLAS_GFX950_STATUS_SUCCESS ||
+      dev_alloc((void**) &st->r_rank, (size_t) total, s) != SPBLAS_GFX950_STATUS_SUCCESS ||
       dev_alloc((void**) &st->r_cols, (size_t) st->c_nnz * 4, s) != SPBLAS_GFX950_STATUS_SUCCESS) {
     dev_free(st->r_pbase, s);
     dev_free(st->r_rank, s);
@@ -766,7 +946,7 @@ static int spgemm_numeric_typed(spblas_gfx950_handle_t h, spblas_gfx950_spgemm_s
     return SPBLAS_GFX950_STATUS_SUCCESS;
   }
   SPB_HIP(hipMemcpyAsync(st->r_cols, c_colind, (size_t) st->c_nnz * 4, hipMemcpyDeviceToDevice, s));
-  launch_ranked<T, 0>(s, st, a_values, b_values, c_colind, c_values, alpha, 0);
+  launch_rank_record(s, st);
   SPB_HIP(hipGetLastError());
   st->r_last_colind = c_colind;
   st->r_ready = true;
@@ -781,6 +961,8 @@ static void spgemm_release(spblas_gfx950_spgemm_s* st, hipStream_t s) {
   dev_free(st->r_pbase, s);
   dev_free(st->r_rank, s);
   dev_free(st->r_cols, s);
+  dev_free(st->r_adesc, s);
+  st->r_adesc = nullptr;
   st->r_pbase = nullptr;
   st->r_rank = nullptr;
   st->r_cols = nullptr;
@@ -886,8 +1068,17 @@ static int spgemm_symbolic_impl(spblas_gfx950_handle_t handle, spblas_gfx950_spg
   unsigned long long* d_cnt = reinterpret_cast<unsigned long long*>(static_cast<char*>(scratch) + bin_bytes);
   long long* partials = reinterpret_cast<long long*>(static_cast<char*>(scratch) + bin_bytes + cnt_bytes);
   SPB_HIP(hipMemsetAsync(d_cnt, 0, 2 * SPG_NBINS * sizeof(unsigned long long), s));
-  hipLaunchKernelGGL(spg_bound_kernel, dim3((unsigned) cdiv(m, 32)), dim3(256), 0, s, m, a_rowptr, a_colind,
-                     b_rowptr, st->d_rowptr, bin_of_row, d_cnt);
+  // (start, length) of the B row of every A entry, one coalesced pass while b_rowptr still has the L2s to itself
+  {
+    const char* env = std::getenv("SPBLAS_GFX950_SPG_ADESC");
+    if (b_rowptr && a_nnz > 0 && !(env && env[0] == '0') &&
+        dev_alloc((void**) &st->r_adesc, (size_t) a_nnz * sizeof(int2), s) == SPBLAS_GFX950_STATUS_SUCCESS)
+      hipLaunchKernelGGL(spg_adesc_kernel, dim3((unsigned) cdiv(a_nnz, 256)), dim3(256), 0, s, a_nnz, a_colind, b_rowptr,
+                         st->r_adesc);
+  }
+  const int64_t bound_wgs = cdiv(m, 32) < 8 * (int64_t) handle->num_cus ? cdiv(m, 32) : 8 * (int64_t) handle->num_cus;
+  hipLaunchKernelGGL(spg_bound_kernel, dim3((unsigned) bound_wgs), dim3(256), 0, s, m, a_rowptr, a_colind,
+                     b_rowptr, st->d_rowptr, st->r_adesc, bin_of_row, d_cnt);
   SPB_HIP(hipGetLastError());
   unsigned long long counts[SPG_NBINS];
   SPB_HIP(hipMemcpyAsync(counts, d_cnt, sizeof(counts), hipMemcpyDeviceToHost, s));
