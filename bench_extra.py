@@ -155,7 +155,7 @@ def run_extra(args, device):
               "filled structure (numeric reuse: accumulation by recorded product ranks)",
               {"dtype": "f32", "rows": m, "products": products, "nnz_c": cn, "multiply_compute_ms_untimed": compute_warm_ms,
                "multiply_compute_first_call_ms": compute_ms, "first_fill_ms_untimed": fills[0], "second_fill_ms_untimed_records_ranks": fills[1],
-               "kernel": "spg_ranked_fill_kernel<float,16,256,4> (first fill: spg_hash_kernel<float,9,64,true>; recording fill: + spg_rank_record_kernel<64,256>)"}, cpu)
+               "kernel": "spg_ranked_fill_kernel<float,16,256,4,false> (first fill: spg_hash_kernel<float,9,64,true>; recording fill: + spg_rank_record_kernel<64,256>)"}, cpu)
         return
 
     if args.workload == "add":  # C = A + B, timed step = add_compute (numeric)

@@ -526,11 +526,13 @@ __global__ __launch_bounds__(256) void spg_dense_kernel(
   }
 }
 
-// products per row (0 for rows outside the LDS-hash bins 1-2: they keep the hash path), scanned into r_pbase
+// products per row, the addend's entries included (0 for rows outside the LDS-hash bins 1-2: they keep the hash
+// path), scanned into r_pbase
 __global__ __launch_bounds__(256) void spg_products_kernel(int64_t m, const int32_t* __restrict__ a_rowptr,
                                                            const int32_t* __restrict__ a_colind,
                                                            const int32_t* __restrict__ b_rowptr,
                                                            const int2* __restrict__ adesc,
+                                                           const int32_t* __restrict__ d_rowptr,
                                                            int32_t* __restrict__ prod) {
   const int64_t row = (int64_t) blockIdx.x * 32 + threadIdx.x / 8;
   const int lane = threadIdx.x % 8;
@@ -542,9 +544,11 @@ __global__ __launch_bounds__(256) void spg_products_kernel(int64_t m, const int3
         continue;
       }
       const int kk = a_colind[p];
-      ub += b_rowptr[kk + 1] - b_rowptr[kk];
+      ub += b_rowptr ? b_rowptr[kk + 1] - b_rowptr[kk] : 1;  // no B: identity (add())
     }
   ub = group_sum_c<8>(ub);
+  if (row < m && d_rowptr)
+    ub += d_rowptr[row + 1] - d_rowptr[row];  // the addend's entries follow the products of the row
   if (row < m && lane == 0)
     prod[row] = ub <= 256 ? (int32_t) ub : 0;
 }
@@ -561,7 +565,9 @@ __global__ __launch_bounds__(256) void spg_rank_record_kernel(
     const int32_t* __restrict__ a_colind, const int32_t* __restrict__ b_rowptr, const int2* __restrict__ adesc,
     const int32_t* __restrict__ b_colind, const int32_t* __restrict__ c_rowptr,
     const int32_t* __restrict__ cols_sorted, int sub, const int32_t* __restrict__ pbase,
-    uint8_t* __restrict__ prank) {
+    uint8_t* __restrict__ prank, const int32_t* __restrict__ d_rowptr, const int32_t* __restrict__ d_colind) {
+  // b_rowptr == nullptr: B is the identity (add()): every A entry is one product on its own column.
+  // d_rowptr != nullptr: the entries of the addend's row are enumerated after the products.
   constexpr int RPB = 256 / TPR;
   __shared__ int s_keys[RPB * CAP];
   const int team = threadIdx.x / TPR, lt = threadIdx.x % TPR;
@@ -579,6 +585,17 @@ __global__ __launch_bounds__(256) void spg_rank_record_kernel(
   const int p0 = a_rowptr[row], p1 = a_rowptr[row + 1];
   const int sg = lt / sub, sl = lt % sub, nsg = TPR / sub;
   const int tbase = (threadIdx.x & 63) - lt;  // first lane of the team in its wave
+  auto rank_of = [&](int col) {
+    int lo = 0, hi = d;  // last position with tkeys[pos] <= col (the column is present by construction)
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (tkeys[mid] <= col)
+        lo = mid;
+      else
+        hi = mid;
+    }
+    return lo;
+  };
   int running = pbase[row];
   for (int pc = p0; pc < p1; pc += TPR) {
     int qb = 0, len = 0;
@@ -589,8 +606,8 @@ __global__ __launch_bounds__(256) void spg_rank_record_kernel(
         len = dd.y;
       } else {
         const int kk = a_colind[pc + lt];
-        qb = b_rowptr[kk];
-        len = b_rowptr[kk + 1] - qb;
+        qb = b_rowptr ? b_rowptr[kk] : kk;
+        len = b_rowptr ? b_rowptr[kk + 1] - qb : 1;
       }
     }
     // exclusive scan of the B-row lengths over the team's lanes (team-uniform trip count)
@@ -610,20 +627,15 @@ __global__ __launch_bounds__(256) void spg_rank_record_kernel(
       const int ln = __shfl(len, src);
       const int off = __shfl(excl, src);
       if (j < cnt)
-        for (int q = sl; q < ln; q += sub) {
-          const int col = b_colind[q0 + q];
-          int lo = 0, hi = d;  // last position with tkeys[pos] <= col (the column is present by construction)
-          while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (tkeys[mid] <= col)
-              lo = mid;
-            else
-              hi = mid;
-          }
-          prank[running + off + q] = (uint8_t) lo;
-        }
+        for (int q = sl; q < ln; q += sub)
+          prank[running + off + q] = (uint8_t) rank_of(b_rowptr ? b_colind[q0 + q] : q0 + q);
     }
     running += total;
+  }
+  if (d_rowptr) {
+    const int q0 = d_rowptr[row], q1 = d_rowptr[row + 1];
+    for (int q = q0 + lt; q < q1; q += TPR)
+      prank[running + (q - q0)] = (uint8_t) rank_of(d_colind[q]);
   }
 }
 
@@ -647,13 +659,16 @@ __global__ __launch_bounds__(256) void spg_adesc_kernel(int64_t a_nnz, const int
 //    product then owns its slot, so the slots are written with plain LDS stores -- no zero fill, no read-modify-write
 //    (cfg5: 96.6 % of the rows).  Rows with repeated columns accumulate as before.
 // Same product enumeration as the recording kernel: r_rank does not depend on TPR, SUB or U.
-template <typename T, int TPR, int CAP, int U>
+template <typename T, int TPR, int CAP, int U, bool GENERAL>
 __global__ __launch_bounds__(256) void spg_ranked_fill_kernel(
     int64_t count, const int32_t* __restrict__ perm, const int32_t* __restrict__ a_rowptr,
     const int32_t* __restrict__ a_colind, const T* __restrict__ a_values, const int32_t* __restrict__ b_rowptr,
     const int2* __restrict__ adesc, const T* __restrict__ b_values, const int32_t* __restrict__ c_rowptr,
     const int32_t* __restrict__ cols_sorted, int32_t* __restrict__ c_colind, T* __restrict__ c_values, T alpha,
-    int sub, const int32_t* __restrict__ pbase, const uint8_t* __restrict__ prank, int copy_cols) {
+    int sub, const int32_t* __restrict__ pbase, const uint8_t* __restrict__ prank, int copy_cols,
+    const int32_t* __restrict__ d_rowptr, const T* __restrict__ d_values, T beta) {
+  // GENERAL: b_rowptr == nullptr means B is the identity (add()), d_rowptr != nullptr adds beta * (row of the addend).
+  // The plain three-argument product has its own instantiation: the extra tests in the load batch cost it 10 %.
   // adesc != nullptr: (start, length) in b_values of the B row of every A entry (a_colind / b_rowptr are not read)
   constexpr int RPB = 256 / TPR;
   __shared__ T s_vals[RPB * CAP];
@@ -684,8 +699,8 @@ __global__ __launch_bounds__(256) void spg_ranked_fill_kernel(
           len = dd.y;
         } else {
           const int kk = a_colind[pc + lt];
-          qb = b_rowptr[kk];
-          len = b_rowptr[kk + 1] - qb;
+          qb = (!GENERAL || b_rowptr) ? b_rowptr[kk] : kk;
+          len = (!GENERAL || b_rowptr) ? b_rowptr[kk + 1] - qb : 1;
         }
         av = alpha * a_values[pc + lt];
       }
@@ -718,7 +733,7 @@ __global__ __launch_bounds__(256) void spg_ranked_fill_kernel(
           bv[u] = T(0);
           if (sl < ln[u]) {
             rk[u] = prank[pb[u] + sl];
-            bv[u] = b_values[q0[u] + sl];
+            bv[u] = (!GENERAL || b_rowptr) ? b_values[q0[u] + sl] : T(1);
           }
         }
 #pragma unroll
@@ -732,7 +747,7 @@ __global__ __launch_bounds__(256) void spg_ranked_fill_kernel(
         // B rows longer than the sub-group: the rest of their entries, one round at a time
 #pragma unroll
         for (int u = 0; u < U; ++u)
-          for (int q = sl + sub; q < ln[u]; q += sub) {
+          for (int q = sl + sub; q < ln[u]; q += sub) {  // (never with the identity: its rows have one entry)
             const T v = a[u] * b_values[q0[u] + q];
             const int r = prank[pb[u] + q];
             if (plain)
@@ -742,6 +757,17 @@ __global__ __launch_bounds__(256) void spg_ranked_fill_kernel(
           }
       }
       running += total;
+    }
+    if (GENERAL && d_rowptr) {
+      const int q0 = d_rowptr[row], q1 = d_rowptr[row + 1];
+      for (int q = q0 + lt; q < q1; q += TPR) {
+        const T v = beta * d_values[q];
+        const int r = prank[running + (q - q0)];
+        if (plain)
+          tvals[r] = v;
+        else
+          spg_lds_add(&tvals[r], v);
+      }
     }
   }
   spg_team_sync<TPR>();
@@ -843,26 +869,34 @@ static int run_bins(spblas_gfx950_handle_t h, spblas_gfx950_spgemm_s* st, const 
 template <typename T, int TPR, int CAP>
 static void launch_ranked_fill(hipStream_t s, const spblas_gfx950_spgemm_s* st, int64_t cnt, int64_t first,
                                const T* a_values, const T* b_values, int32_t* c_colind, T* c_values, T alpha,
-                               int copy_cols) {
-  const int sub = st->sub < TPR ? st->sub : TPR;
+                               int copy_cols, const T* d_values, T beta) {
+  const int sub = st->identity_b ? 1 : st->sub < TPR ? st->sub : TPR;  // identity B: one lane per A entry
   constexpr int RPB = 256 / TPR;
-  hipLaunchKernelGGL((spg_ranked_fill_kernel<T, TPR, CAP, 4>), dim3((unsigned) cdiv(cnt, RPB)), dim3(256), 0, s, cnt,
-                     st->perm + first, st->a_rowptr, st->a_colind, a_values, st->b_rowptr, st->r_adesc, b_values,
-                     st->rowptr, st->r_cols, c_colind, c_values, alpha, sub, st->r_pbase, st->r_rank, copy_cols);
+  if (st->identity_b || st->d_rowptr)
+    hipLaunchKernelGGL((spg_ranked_fill_kernel<T, TPR, CAP, 4, true>), dim3((unsigned) cdiv(cnt, RPB)), dim3(256), 0, s,
+                       cnt, st->perm + first, st->a_rowptr, st->a_colind, a_values, st->b_rowptr, st->r_adesc, b_values,
+                       st->rowptr, st->r_cols, c_colind, c_values, alpha, sub, st->r_pbase, st->r_rank, copy_cols,
+                       st->d_rowptr, d_values, beta);
+  else
+    hipLaunchKernelGGL((spg_ranked_fill_kernel<T, TPR, CAP, 4, false>), dim3((unsigned) cdiv(cnt, RPB)), dim3(256), 0, s,
+                       cnt, st->perm + first, st->a_rowptr, st->a_colind, a_values, st->b_rowptr, st->r_adesc, b_values,
+                       st->rowptr, st->r_cols, c_colind, c_values, alpha, sub, st->r_pbase, st->r_rank, copy_cols,
+                       st->d_rowptr, d_values, beta);
 }
 
 // the recording pass for the rows of bins 1-2 ...
 static void launch_rank_record(hipStream_t s, const spblas_gfx950_spgemm_s* st) {
   const int64_t c1 = st->bin_off[2] - st->bin_off[1], c2 = st->bin_off[3] - st->bin_off[2];
-  const int sub1 = st->sub < 16 ? st->sub : 16, sub2 = st->sub < 64 ? st->sub : 64;
+  const int sub1 = st->identity_b ? 1 : st->sub < 16 ? st->sub : 16;
+  const int sub2 = st->identity_b ? 1 : st->sub < 64 ? st->sub : 64;
   if (c1 > 0)
     hipLaunchKernelGGL((spg_rank_record_kernel<16, 64>), dim3((unsigned) cdiv(c1, 16)), dim3(256), 0, s, c1,
                        st->perm + st->bin_off[1], st->a_rowptr, st->a_colind, st->b_rowptr, st->r_adesc, st->b_colind,
-                       st->rowptr, st->r_cols, sub1, st->r_pbase, st->r_rank);
+                       st->rowptr, st->r_cols, sub1, st->r_pbase, st->r_rank, st->d_rowptr, st->d_colind);
   if (c2 > 0)
     hipLaunchKernelGGL((spg_rank_record_kernel<64, 256>), dim3((unsigned) cdiv(c2, 4)), dim3(256), 0, s, c2,
                        st->perm + st->bin_off[2], st->a_rowptr, st->a_colind, st->b_rowptr, st->r_adesc, st->b_colind,
-                       st->rowptr, st->r_cols, sub2, st->r_pbase, st->r_rank);
+                       st->rowptr, st->r_cols, sub2, st->r_pbase, st->r_rank, st->d_rowptr, st->d_colind);
 }
 
 // ... and their fills by rank.  Team width of a bin-2 row: the A entries of a row are walked TPR at a time, and a
@@ -870,33 +904,46 @@ static void launch_rank_record(hipStream_t s, const spblas_gfx950_spgemm_s* st) 
 // rows into every wave (cfg5: 0.93 -> 0.78 ms; SPBLAS_GFX950_SPG_RANKED_TPR=16/32/64 overrides the choice).
 template <typename T>
 static void launch_ranked(hipStream_t s, const spblas_gfx950_spgemm_s* st, const T* a_values, const T* b_values,
-                          int32_t* c_colind, T* c_values, T alpha, int copy_cols) {
+                          int32_t* c_colind, T* c_values, T alpha, int copy_cols, const T* d_values, T beta) {
   const int64_t c1 = st->bin_off[2] - st->bin_off[1], c2 = st->bin_off[3] - st->bin_off[2];
   static const int tpr_env = [] {
     const char* e = std::getenv("SPBLAS_GFX950_SPG_RANKED_TPR");
     return e ? std::atoi(e) : 0;
   }();
+  static const int tpr1_env = [] {
+    const char* e = std::getenv("SPBLAS_GFX950_SPG_RANKED_TPR1");
+    return e ? std::atoi(e) : 0;
+  }();
   const double avg_a = st->m > 0 ? (double) st->a_nnz / (double) st->m : 0.0;
   const int tpr2 = tpr_env ? tpr_env : avg_a <= 16.0 ? 16 : avg_a <= 32.0 ? 32 : 64;
-  if (c1 > 0)
-    launch_ranked_fill<T, 16, 64>(s, st, c1, st->bin_off[1], a_values, b_values, c_colind, c_values, alpha, copy_cols);
+  // bin 1 (<= 64 products): 8-lane teams when the rows are that short (add(): 16 + 16 entries per row at the 8f size)
+  const int tpr1 = tpr1_env ? tpr1_env : (st->identity_b || avg_a <= 8.0) ? 8 : 16;
+  if (c1 > 0) {
+    if (tpr1 == 8)
+      launch_ranked_fill<T, 8, 64>(s, st, c1, st->bin_off[1], a_values, b_values, c_colind, c_values, alpha, copy_cols,
+                                   d_values, beta);
+    else
+      launch_ranked_fill<T, 16, 64>(s, st, c1, st->bin_off[1], a_values, b_values, c_colind, c_values, alpha,
+                                    copy_cols, d_values, beta);
+  }
   if (c2 > 0) {
     if (tpr2 == 16)
       launch_ranked_fill<T, 16, 256>(s, st, c2, st->bin_off[2], a_values, b_values, c_colind, c_values, alpha,
-                                     copy_cols);
+                                     copy_cols, d_values, beta);
     else if (tpr2 == 32)
       launch_ranked_fill<T, 32, 256>(s, st, c2, st->bin_off[2], a_values, b_values, c_colind, c_values, alpha,
-                                     copy_cols);
+                                     copy_cols, d_values, beta);
     else
       launch_ranked_fill<T, 64, 256>(s, st, c2, st->bin_off[2], a_values, b_values, c_colind, c_values, alpha,
-                                     copy_cols);
+                                     copy_cols, d_values, beta);
   }
 }
 
-// numeric pass.  Plain three-argument products (no addend, real B) whose rows sit in the LDS-hash bins 1-2 are
-// eligible for reuse: the SECOND pass on a symbolic result runs the hash kernels and then records the rank of every
-// product (SPBLAS_GFX950_SPGEMM_REUSE=0 turns the recording off, =2 records in the first pass already); every later
-// pass accumulates by rank.  Rows in the other bins always take the hash / dense kernels.
+// numeric pass.  Rows that sit in the LDS-hash bins 1-2 are eligible for reuse -- three- and four-argument products and
+// add() (identity B + addend) alike: the SECOND pass on a symbolic result runs the hash kernels and then records the
+// rank of every product and addend entry (SPBLAS_GFX950_SPGEMM_REUSE=0 turns the recording off, =2 records in the
+// first pass already); every later pass accumulates by rank.  Rows in the other bins always take the hash / dense
+// kernels.
 template <typename T>
 static int spgemm_numeric_typed(spblas_gfx950_handle_t h, spblas_gfx950_spgemm_s* st, const T* a_values,
                                 const T* b_values, int32_t* c_colind, T* c_values, T alpha, const T* d_values, T beta) {
@@ -905,7 +952,7 @@ static int spgemm_numeric_typed(spblas_gfx950_handle_t h, spblas_gfx950_spgemm_s
     // columns: rewritten unless the caller vouches for the array's contents (OPT_SPGEMM_KEEP_COLIND) and it is the
     // array the previous pass filled -- the address alone proves nothing, allocators hand freed addresses out again
     launch_ranked<T>(s, st, a_values, b_values, c_colind, c_values, alpha,
-                        !(h->spgemm_keep_colind != 0 && c_colind == st->r_last_colind));
+                     !(h->spgemm_keep_colind != 0 && c_colind == st->r_last_colind), d_values, beta);
     SPB_HIP(hipGetLastError());
     st->r_last_colind = c_colind;
     return run_bins<T, true>(h, st, a_values, b_values, st->rowptr, c_colind, c_values, alpha, d_values, beta, true);
@@ -918,7 +965,7 @@ static int spgemm_numeric_typed(spblas_gfx950_handle_t h, spblas_gfx950_spgemm_s
   const char* env = std::getenv("SPBLAS_GFX950_SPGEMM_REUSE");
   const bool want = !(env && env[0] == '0') && ++st->numeric_calls >= (env && env[0] == '2' ? 1 : 2);
   const int64_t small_rows = st->bin_off[3] - st->bin_off[1];
-  if (!want || st->has_addend || st->identity_b || small_rows == 0 || st->m == 0)
+  if (!want || small_rows == 0 || st->m == 0)
     return SPBLAS_GFX950_STATUS_SUCCESS;
   // record: products per row -> r_pbase, a copy of the sorted columns, then the ranks
   const int64_t m = st->m, nb = cdiv(m, 2048);
@@ -927,7 +974,7 @@ static int spgemm_numeric_typed(spblas_gfx950_handle_t h, spblas_gfx950_spgemm_s
       (rc = dev_alloc((void**) &partials, (size_t) (nb + 2) * sizeof(long long), s)))
     return SPBLAS_GFX950_STATUS_SUCCESS;  // out of memory for the optional fast path: keep the hash path
   hipLaunchKernelGGL(spg_products_kernel, dim3((unsigned) cdiv(m, 32)), dim3(256), 0, s, m, st->a_rowptr, st->a_colind,
-                     st->b_rowptr, st->r_adesc, st->r_pbase);
+                     st->b_rowptr, st->r_adesc, st->d_rowptr, st->r_pbase);
   long long* total_dev = scan_counts_i32(s, m, st->r_pbase, partials);
   long long total = 0;
   hipError_t e = hipMemcpyAsync(&total, total_dev, sizeof(total), hipMemcpyDeviceToHost, s);

@@ -272,3 +272,110 @@ def test_spgemm_with_empty_operands(gpu):
     d_h = _csr(m, n, 4000, 2, np.float32)
     check_spgemm4(a_h, e_kn, d_h, device_spgemm4(a_h, e_kn, d_h, sd=-2.0)[0], np.float32, 1.0, -2.0)
     check_spgemm4(e_mk, b_h, d_h, device_spgemm4(e_mk, b_h, d_h)[0], np.float32)
+
+
+# ------------------------------------------------------------------ repeated fills: the rank path
+def _with_duplicates(h, rng, every=7):
+    """Repeat a column inside some rows (csr_view allows unsorted / repeated columns)."""
+    v, rp, ci, sh = h
+    ci = ci.copy()
+    for r in range(0, len(rp) - 1, every):
+        if rp[r + 1] - rp[r] >= 2:
+            ci[rp[r] + 1] = ci[rp[r]]
+    return (v, rp, ci, sh)
+
+
+@pytest.mark.parametrize("record_at", ["second", "first"])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_add_repeated_compute_by_rank(gpu, monkeypatch, dtype, record_at):
+    """add_compute again and again on one add_inspect result (add_impl.hpp:110-113 allows it): the second call records
+    the rank of every entry of A and B in its output row, later calls accumulate by rank.  Values and scale factors
+    change between the calls; columns are poisoned before each call."""
+    if record_at == "first":
+        monkeypatch.setenv("SPBLAS_GFX950_SPGEMM_REUSE", "2")
+    rng = np.random.default_rng(5)
+    m, n = 700, 900
+    a_h = _with_duplicates(_csr(m, n, 9000, 0, dtype), rng)
+    b_h = _with_duplicates(_csr(m, n, 12000, 1, dtype), rng, every=5)
+    # one long row on each side (falls outside the rank bins) and a few empty ones come with the generator
+    (av, ar, ac, ash), (bv, br, bc, bsh) = a_h, b_h
+    d_a, d_b = G.csr_on_device(av, ar, ac, ash, len(av)), G.csr_on_device(bv, br, bc, bsh, len(bv))
+    d_rowptr = torch.full((m + 1,), -1, dtype=torch.int32, device="cuda")
+    d_c = sp.csr_view(None, d_rowptr, None, (m, n), 0)
+    info = sp.add_inspect(d_a, d_b, d_c)
+    nnz = info.result_nnz()
+    d_vals = torch.full((nnz,), float("nan"), dtype=G.dev(av).dtype, device="cuda")
+    d_cols = torch.full((nnz,), -1, dtype=torch.int32, device="cuda")
+    d_c.update(d_vals, d_rowptr, d_cols)
+    for it, (sa, sb) in enumerate([(None, None), (2.0, None), (None, -0.5), (1.5, 3.0), (None, None)]):
+        av2, bv2 = rng.random(len(av)).astype(dtype), rng.random(len(bv)).astype(dtype)
+        d_a.values().copy_(G.dev(av2))
+        d_b.values().copy_(G.dev(bv2))
+        d_vals.fill_(float("nan"))
+        d_cols.fill_(-1)
+        A = sp.scaled(sa, d_a) if sa is not None else d_a
+        B = sp.scaled(sb, d_b) if sb is not None else d_b
+        sp.add_compute(info, A, B, d_c)
+        got = (nnz, G.host(d_rowptr), G.host(d_cols), G.host(d_vals))
+        check_add((av2, ar, ac, ash), (bv2, br, bc, bsh), got, dtype, sa, sb)
+
+
+@pytest.mark.parametrize("record_at", ["second", "first"])
+def test_spgemm_4args_repeated_fills_by_rank(gpu, monkeypatch, record_at):
+    """multiply_numeric(state, A, B, C, D) five times with new values and factors: hash pass, recording pass, then the
+    fills by rank with the addend's entries enumerated after the products (multiply_spgemm.hpp:178-214)."""
+    if record_at == "first":
+        monkeypatch.setenv("SPBLAS_GFX950_SPGEMM_REUSE", "2")
+    rng = np.random.default_rng(9)
+    dtype = np.float32
+    a_h, b_h, d_h = _csr(500, 400, 5000, 0, dtype), _csr(400, 600, 7000, 1, dtype), _csr(500, 600, 6000, 2, dtype)
+    d_h = _with_duplicates(d_h, rng)
+    (av, ar, ac, ash), (bv, br, bc, bsh), (dv, dr, dc, dsh) = a_h, b_h, d_h
+    d_a, d_b, d_d = (G.csr_on_device(v, r, c, s, len(v)) for v, r, c, s in (a_h, b_h, d_h))
+    m, n = ash[0], bsh[1]
+    d_rowptr = torch.full((m + 1,), -1, dtype=torch.int32, device="cuda")
+    d_c = sp.csr_view(None, d_rowptr, None, (m, n), 0)
+    state = sp.spgemm_state_t()
+    sp.multiply_compute(state, d_a, d_b, d_c, d_d)
+    nnz = state.result_nnz()
+    d_vals = torch.full((nnz,), float("nan"), dtype=torch.float32, device="cuda")
+    d_cols = torch.full((nnz,), -1, dtype=torch.int32, device="cuda")
+    d_c.update(d_vals, d_rowptr, d_cols, (m, n), nnz)
+    for it, (sa, sd) in enumerate([(None, None), (2.0, None), (None, -0.25), (0.5, 3.0), (None, None)]):
+        new = [rng.random(len(x)).astype(dtype) for x in (av, bv, dv)]
+        for t, x in zip((d_a, d_b, d_d), new):
+            t.values().copy_(G.dev(x))
+        d_vals.fill_(float("nan"))
+        d_cols.fill_(-1)
+        A = sp.scaled(sa, d_a) if sa is not None else d_a
+        D = sp.scaled(sd, d_d) if sd is not None else d_d
+        sp.multiply_numeric(state, A, d_b, d_c, D)
+        got = (nnz, G.host(d_rowptr), G.host(d_cols), G.host(d_vals))
+        check_spgemm4((new[0], ar, ac, ash), (new[1], br, bc, bsh), (new[2], dr, dc, dsh), got, dtype,
+                      sa or 1.0, sd or 1.0)
+
+
+def test_add_golden_bit_exact_by_rank(gpu, monkeypatch):
+    """The golden add fixtures again with the ranks recorded in the first pass: the second pass IS the rank path."""
+    monkeypatch.setenv("SPBLAS_GFX950_SPGEMM_REUSE", "2")
+    for name in ("add_plain.npz", "add_scaled.npz"):
+        g = np.load(os.path.join(GOLDEN, name))
+        shape = tuple(int(v) for v in g["shape"])
+        (av, ar, ac), (bv, br, bc) = (g["a_values"], g["a_rowptr"], g["a_colind"]), \
+            (g["b_values"], g["b_rowptr"], g["b_colind"])
+        sa, sb = float(g["scale_a"]), float(g["scale_b"])
+        d_a, d_b = G.csr_on_device(av, ar, ac, shape, len(av)), G.csr_on_device(bv, br, bc, shape, len(bv))
+        A = sp.scaled(sa, d_a) if sa != 1 else d_a
+        B = sp.scaled(sb, d_b) if sb != 1 else d_b
+        rp = torch.full((shape[0] + 1,), -1, dtype=torch.int32, device="cuda")
+        d_c = sp.csr_view(None, rp, None, shape, 0)
+        info = sp.add_inspect(A, B, d_c)
+        nnz = info.result_nnz()
+        vals = torch.full((nnz,), float("nan"), dtype=G.dev(av).dtype, device="cuda")
+        cols = torch.full((nnz,), -1, dtype=torch.int32, device="cuda")
+        d_c.update(vals, rp, cols)
+        for _ in range(3):
+            vals.fill_(float("nan"))
+            cols.fill_(-1)
+            sp.add_compute(info, A, B, d_c)
+            assert np.array_equal(G.host(cols), g["c_colind"]) and np.array_equal(G.host(vals), g["c_values"])
