@@ -830,9 +830,11 @@ static int run_bins(spblas_gfx950_handle_t h, spblas_gfx950_spgemm_s* st, const 
       (rc = launch_hash<T, 7, 16, NUMERIC>(s, st, 1, a_values, b_values, c_rowptr, c_colind, c_values, alpha,
                                            d_values, beta)))
     return rc;
+  // bin 2: a wave per row for the numeric pass (its rank sort works on TPR buckets: 32-lane teams take 3.2 instead of
+  // 2.1 ms at cfg5), two rows per wave for the symbolic one (0.61 -> 0.56 ms: more rows' loads in flight)
   if (!skip_small_bins &&
-      (rc = launch_hash<T, 9, 64, NUMERIC>(s, st, 2, a_values, b_values, c_rowptr, c_colind, c_values, alpha,
-                                           d_values, beta)))
+      (rc = launch_hash<T, 9, NUMERIC ? 64 : 32, NUMERIC>(s, st, 2, a_values, b_values, c_rowptr, c_colind, c_values,
+                                                          alpha, d_values, beta)))
     return rc;
   if ((rc = launch_hash<T, 11, 128, NUMERIC>(s, st, 3, a_values, b_values, c_rowptr, c_colind, c_values, alpha,
                                            d_values, beta)))

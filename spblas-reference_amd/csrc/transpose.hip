@@ -3,110 +3,403 @@
 // Result identical to the reference's counting sort
 // (/root/reference/include/spblas/algorithms/transpose_impl.hpp:14-53): entries of every output row
 // are in source order (ascending original row, ties in storage order), i.e. a STABLE sort of the
-// entries by column.  Steps, all on the handle's stream:
-//   1. payload of every entry = (row id, value)                    -- spt_payload_kernel (expand rowptr)
-//   2. stable LSD radix sort of (column, payload) pairs            -- rocprim::radix_sort_pairs
-//   3. t_rowptr[j] = first sorted position with column >= j        -- spt_rowptr_kernel
-//   4. t_colind[k], t_values[k] = sorted payload k                 -- spt_split_kernel (streaming)
-// The payload travels with the key, so no pass gathers from a permutation (the first version sorted
-// (column, position) pairs and gathered rows / values afterwards: 3.8 of 6.6 ms at 1e8 entries were that
-// random gather).  The device-wide radix sort is the one generic primitive taken from rocPRIM
-// (header-only, part of ROCm); it runs at inspect time only.  Everything on the multiply() hot path is
-// hand-written.  Used by multiply_inspect on csc_view / transposed(csr) operands, which then run the
+// entries by column -- done here by hand-written LSD radix passes of 8 bits (spt_count_kernel, scan.hpp,
+// spt_scatter_kernel) followed by one streaming pass that turns the sorted columns into t_rowptr
+// (spt_rowptr_fill_kernel).  No library primitive: round 1 and most of round 2 used rocprim::radix_sort_pairs on
+// (column, (row, value)) pairs between a payload pass, a binary-search pass and a split pass (3.45 ms at 1e8
+// entries); the passes below take 2.6 ms.
+// Used by transpose() itself and by multiply_inspect on csc_view / transposed(csr) operands, which then run the
 // regular (row-block or LDS-sliced) SpMV kernels on the materialised transpose instead of the atomic
 // scatter kernel.
+#include <cstdlib>
 #include <cstring>
 
 #include "common.hpp"
-
-#include <rocprim/rocprim.hpp>
+#include "scan.hpp"
 
 namespace spb {
 
-template <typename T>
-struct spt_payload {
-  int32_t row;
-  T val;
-};
+// ---------------------------------------------------------------------------------------------------------------
+// Hand-written stable LSD radix sort of the entries by column, 8 bits per pass, specialised for the transpose:
+//   * the first pass builds the (row, value) payload on the fly (row of entry i = binary search in the tile's slice
+//     of rowptr, held in LDS) -- no payload pass;
+//   * the last pass writes t_colind / t_values directly -- no split pass;
+//   * keys, rows and values travel as three arrays (three coalesced streams per piece);
+//   * a tile is 8 waves x SPT_ROUNDS x 64 = 4096 entries per workgroup of 512 lanes (58 / 74 KiB of LDS: two
+//     workgroups per CU), so a tile's piece of one of the 256 buckets averages 16 entries; tiles of 8192 (one
+//     workgroup per CU) and of 3072 / 2048 entries were measured and are slower or equal;
+//   * every XCD works on a contiguous range of tiles, so the pieces of neighbouring tiles, adjacent in memory, are
+//     merged into whole lines by one L2.
+// Per pass: spt_count_kernel (digit histogram of every tile) -> exclusive scan of counts[digit][tile] (scan.hpp; the
+// flattened digit-major order IS the stable output order) -> spt_scatter_kernel.
+// Stability inside a tile: wave w owns the contiguous entries [(w*R)*64, (w*R+R)*64) of the tile and walks them 64 at a
+// time; the rank of a lane among the lanes of its round with the same digit comes from eight ballots, the running
+// count of the digit over the wave's earlier rounds from an LDS counter that only this wave touches.
+constexpr int SPT_WAVES = 8;
 
-template <typename T>
-__global__ __launch_bounds__(256) void spt_payload_kernel(int64_t m, const int32_t* __restrict__ rowptr,
-                                                          const T* __restrict__ values,
-                                                          spt_payload<T>* __restrict__ out) {
-  const int64_t row = (int64_t) blockIdx.x * 32 + threadIdx.x / 8;
-  const int lane = threadIdx.x % 8;
-  if (row >= m)
-    return;
-  for (int p = rowptr[row] + lane; p < rowptr[row + 1]; p += 8) {
-    spt_payload<T> e;
-    e.row = (int32_t) row;
-    e.val = values[p];
-    out[p] = e;
+__global__ __launch_bounds__(512) void spt_count_kernel(int64_t nnz, int shift, int tile_size,
+                                                        const int32_t* __restrict__ keys, int64_t ntiles,
+                                                        int32_t* __restrict__ counts) {
+  // (one histogram per wave instead: no faster; 16-byte key loads: 172 -> 104 us per pass at 1e8 entries)
+  __shared__ int hist[256];
+  if (threadIdx.x < 256)
+    hist[threadIdx.x] = 0;
+  __syncthreads();
+  const int64_t base = (int64_t) blockIdx.x * tile_size;
+  int* mine = hist;
+  const int tile_n = (int) (nnz - base < tile_size ? nnz - base : tile_size);
+  if (tile_n == tile_size && (reinterpret_cast<uintptr_t>(keys + base) & 15) == 0) {
+    const int4* k4 = reinterpret_cast<const int4*>(keys + base);
+    for (int q = threadIdx.x; q < tile_size / 4; q += 512) {
+      const int4 k = k4[q];
+      atomicAdd(&mine[(k.x >> shift) & 255], 1);
+      atomicAdd(&mine[(k.y >> shift) & 255], 1);
+      atomicAdd(&mine[(k.z >> shift) & 255], 1);
+      atomicAdd(&mine[(k.w >> shift) & 255], 1);
+    }
+  } else {
+    for (int li = threadIdx.x; li < tile_n; li += 512)
+      atomicAdd(&mine[(keys[base + li] >> shift) & 255], 1);
   }
+  __syncthreads();
+  if (threadIdx.x < 256)
+    counts[(int64_t) threadIdx.x * ntiles + blockIdx.x] = hist[threadIdx.x];
 }
 
-__global__ __launch_bounds__(256) void spt_rowptr_kernel(int64_t n, int64_t nnz, const int32_t* __restrict__ sorted_cols,
-                                                         int32_t* __restrict__ t_rowptr) {
-  const int64_t j = (int64_t) blockIdx.x * 256 + threadIdx.x;
-  if (j > n)
+// tile_row[t] = row that owns entry t * tile_size (the last r with rowptr[r] <= it), tile_row[ntiles] = the row of the
+// last entry: the rows of tile t lie in [tile_row[t], tile_row[t + 1]]
+__global__ __launch_bounds__(256) void spt_tile_rows_kernel(int64_t ntiles, int tile_size, int64_t nnz, int64_t m,
+                                                            const int32_t* __restrict__ rowptr,
+                                                            int32_t* __restrict__ tile_row) {
+  const int64_t t = (int64_t) blockIdx.x * 256 + threadIdx.x;
+  if (t > ntiles)
     return;
-  int64_t lo = 0, hi = nnz;  // first k with sorted_cols[k] >= j
+  const int64_t target = t * tile_size < nnz ? t * tile_size : nnz - 1;
+  int64_t lo = 0, hi = m;  // first r in [0, m] with rowptr[r] > target
   while (lo < hi) {
     const int64_t mid = (lo + hi) >> 1;
-    if (sorted_cols[mid] < j)
+    if (rowptr[mid] <= target)
       lo = mid + 1;
     else
       hi = mid;
   }
-  t_rowptr[j] = (int32_t) lo;
+  tile_row[t] = (int32_t) (lo - 1);
+}
+
+template <typename T, int SPT_ROUNDS, bool FIRST>
+__global__ __launch_bounds__(512) void spt_scatter_kernel(int64_t nnz, int shift, const int32_t* __restrict__ in_keys,
+                                                          const int32_t* __restrict__ in_rows,
+                                                          const T* __restrict__ in_vals, int64_t m,
+                                                          const int32_t* __restrict__ rowptr, int64_t ntiles,
+                                                          const int32_t* __restrict__ offsets,
+                                                          int32_t* __restrict__ out_keys,
+                                                          int32_t* __restrict__ out_rows, T* __restrict__ out_vals,
+                                                          int xcd_map, const int32_t* __restrict__ tile_row) {
+  constexpr int SPT_TILE = SPT_WAVES * SPT_ROUNDS * 64;
+  extern __shared__ __attribute__((aligned(16))) unsigned char spt_smem[];
+  T* stage_val = reinterpret_cast<T*>(spt_smem);                    // [TILE]
+  int* stage_key = reinterpret_cast<int*>(stage_val + SPT_TILE);    // [TILE]
+  int* stage_row = stage_key + SPT_TILE;                            // [TILE]
+  volatile int* cnt = stage_row + SPT_TILE;                         // [WAVES][256] running counts -> wave offsets
+  int* lstart = const_cast<int*>(cnt) + SPT_WAVES * 256;            // [256] first local position of a bucket
+  int* delta = lstart + 256;                                        // [256] global - local position of a bucket
+  int* misc = delta + 256;                                          // [8]
+
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+  // workgroups are dealt round-robin to the 8 XCDs: give every XCD a contiguous range of tiles, so that the pieces
+  // of neighbouring tiles (adjacent in memory, bucket by bucket) meet in ONE L2 and leave it as whole lines
+  // (4.0 -> 3.3 ms at 1e8 entries; SPBLAS_GFX950_TRANSPOSE_XCD=0 switches the mapping off)
+  int64_t tile = blockIdx.x;
+  if (xcd_map) {
+    const int64_t per = ntiles / 8, body = per * 8;
+    if (tile < body)
+      tile = (tile & 7) * per + (tile >> 3);
+  }
+  const int64_t base = tile * SPT_TILE;
+  const int tile_n = (int) (nnz - base < SPT_TILE ? nnz - base : SPT_TILE);
+  for (int i = tid; i < SPT_WAVES * 256; i += 512)
+    cnt[i] = 0;
+
+  __syncthreads();
+
+  int key[SPT_ROUNDS], row[SPT_ROUNDS], rank[SPT_ROUNDS];
+  T val[SPT_ROUNDS];
+#pragma unroll
+  for (int r = 0; r < SPT_ROUNDS; ++r) {
+    const int li = (w * SPT_ROUNDS + r) * 64 + lane;
+    const bool valid = li < tile_n;
+    key[r] = valid ? in_keys[base + li] : 0;
+    val[r] = valid ? in_vals[base + li] : T(0);
+    if (!FIRST)
+      row[r] = valid ? in_rows[base + li] : 0;
+  }
+  if (FIRST) {
+    // row of every entry of the tile (the (row, value) payload is built here, no separate pass): the rows
+    // r_lo + 1 .. r_hi that start inside the tile leave their number at their first entry (LDS max: of several rows
+    // starting at one position -- empty ones -- the last owns the entry), and an inclusive running maximum over the
+    // tile's positions turns the marks into "row of entry".  Wave scans side by side for the ROUNDS of a lane, a carry
+    // along the wave's rounds, one maximum per earlier wave.  (A binary search per entry in an LDS copy of the row
+    // offsets took 0.34 ms more per pass at 1e8 entries, one search at a time 0.9 ms.)
+    int* mark = stage_row;  // free until the staging phase
+    const int r_lo = tile_row[tile], r_hi = tile_row[tile + 1];
+    for (int i = tid; i < SPT_TILE; i += 512)
+      mark[i] = 0;
+    __syncthreads();
+    for (int j = 1 + tid; j <= r_hi - r_lo; j += 512) {
+      const int64_t pos = (int64_t) rowptr[r_lo + j] - base;
+      if (pos >= 0 && pos < tile_n)
+        atomicMax(&mark[pos], j);
+    }
+    __syncthreads();
+    int x[SPT_ROUNDS];
+#pragma unroll
+    for (int r = 0; r < SPT_ROUNDS; ++r)
+      x[r] = mark[(w * SPT_ROUNDS + r) * 64 + lane];
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+#pragma unroll
+      for (int r = 0; r < SPT_ROUNDS; ++r) {
+        const int t = __shfl_up(x[r], o, 64);
+        if (lane >= o)
+          x[r] = x[r] > t ? x[r] : t;
+      }
+    }
+    int carry = 0;
+#pragma unroll
+    for (int r = 0; r < SPT_ROUNDS; ++r) {
+      x[r] = x[r] > carry ? x[r] : carry;
+      carry = __shfl(x[r], 63);
+    }
+    if (lane == 0)
+      misc[2 + w] = carry;
+    __syncthreads();
+    int pre = 0;
+    for (int q = 0; q < w; ++q)
+      pre = misc[2 + q] > pre ? misc[2 + q] : pre;
+#pragma unroll
+    for (int r = 0; r < SPT_ROUNDS; ++r)
+      row[r] = r_lo + (x[r] > pre ? x[r] : pre);
+  }
+  // ranks inside the wave's chunk
+  const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+  for (int r = 0; r < SPT_ROUNDS; ++r) {
+    const int li = (w * SPT_ROUNDS + r) * 64 + lane;
+    const bool valid = li < tile_n;
+    const int d = (key[r] >> shift) & 255;
+    unsigned long long same = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const bool bit = (d >> b) & 1;
+      const unsigned long long bal = __ballot(bit);
+      same &= bit ? bal : ~bal;
+    }
+    const int before = (int) __popcll(same & lt_mask);
+    const int prev = valid ? cnt[w * 256 + d] : 0;
+    __builtin_amdgcn_wave_barrier();
+    if (valid && before == 0)
+      cnt[w * 256 + d] = prev + (int) __popcll(same);
+    __builtin_amdgcn_wave_barrier();
+    rank[r] = prev + before;
+  }
+  __syncthreads();
+  int run = 0, incl = 0;
+  if (tid < 256) {
+    for (int q = 0; q < SPT_WAVES; ++q) {
+      const int c = cnt[q * 256 + tid];
+      cnt[q * 256 + tid] = run;
+      run += c;
+    }
+    incl = run;
+    for (int o = 1; o < 64; o <<= 1) {
+      const int v = __shfl_up(incl, o, 64);
+      if (lane >= o)
+        incl += v;
+    }
+    if (lane == 63)
+      misc[2 + w] = incl;
+  }
+  __syncthreads();
+  if (tid < 256) {
+    int ls = incl - run;
+    for (int q = 0; q < w; ++q)
+      ls += misc[2 + q];
+    lstart[tid] = ls;
+    delta[tid] = offsets[(int64_t) tid * ntiles + tile] - ls;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < SPT_ROUNDS; ++r) {
+    const int li = (w * SPT_ROUNDS + r) * 64 + lane;
+    if (li < tile_n) {
+      const int d = (key[r] >> shift) & 255;
+      const int lp = lstart[d] + cnt[w * 256 + d] + rank[r];
+      stage_key[lp] = key[r];
+      stage_row[lp] = row[r];
+      stage_val[lp] = val[r];
+    }
+  }
+  __syncthreads();
+  for (int j = tid; j < tile_n; j += 512) {
+    const int k = stage_key[j];
+    const int64_t g = (int64_t) j + delta[(k >> shift) & 255];
+    out_keys[g] = k;
+    out_rows[g] = stage_row[j];
+    out_vals[g] = stage_val[j];
+  }
+}
+
+// t_rowptr from the sorted columns, one streaming pass: entry k-1 is the last entry of its column c when the next
+// entry has another column c'; then t_rowptr[c + 1 .. c'] = k.  Work item 0 covers the columns up to the first entry's.
+// A lane fills short gaps itself, the wave fills gaps up to 4096 columns together, longer ones (at most n / 4096 of
+// them) go to a list that spt_rowptr_long_kernel fills with the whole grid.
+__global__ __launch_bounds__(256) void spt_rowptr_fill_kernel(int64_t n, int64_t nnz,
+                                                              const int32_t* __restrict__ sorted_cols,
+                                                              int32_t* __restrict__ t_rowptr, int4* __restrict__ longs,
+                                                              unsigned* __restrict__ n_longs) {
+  // four work items per lane (one 16-byte load of sorted columns): items 4q .. 4q + 3 of 0 .. nnz
+  const int64_t q = (int64_t) blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int64_t t0 = 4 * q;
+  int k[4] = {0, 0, 0, 0};
+  int prev = -1;
+  if (t0 <= nnz) {
+    if (t0 > 0)
+      prev = sorted_cols[t0 - 1];
+    if (t0 + 4 <= nnz && (reinterpret_cast<uintptr_t>(sorted_cols + t0) & 15) == 0) {
+      const int4 v4 = *reinterpret_cast<const int4*>(sorted_cols + t0);
+      k[0] = v4.x, k[1] = v4.y, k[2] = v4.z, k[3] = v4.w;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        k[e] = t0 + e < nnz ? sorted_cols[t0 + e] : (int) n;
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int64_t t = t0 + e;
+    int lo = 0, hi = -1;
+    const int v = (int) t;
+    if (t <= nnz) {
+      lo = prev + 1;
+      hi = t < nnz ? k[e] : (int) n;
+      prev = k[e];
+    }
+    const int len = hi - lo + 1;
+    if (len > 0 && len <= 8)
+      for (int j = lo; j <= hi; ++j)
+        t_rowptr[j] = v;
+    if (len > 4096) {
+      const unsigned slot = atomicAdd(n_longs, 1u);
+      longs[slot] = make_int4(lo, hi, v, 0);
+    }
+    unsigned long long mid = __ballot(len > 8 && len <= 4096);
+    while (mid) {
+      const int src = __ffsll((long long) mid) - 1;
+      const int slo = __shfl(lo, src), shi = __shfl(hi, src), sv = __shfl(v, src);
+      for (int j = slo + lane; j <= shi; j += 64)
+        t_rowptr[j] = sv;
+      mid &= mid - 1;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void spt_rowptr_long_kernel(const int4* __restrict__ longs,
+                                                              const unsigned* __restrict__ n_longs,
+                                                              int32_t* __restrict__ t_rowptr) {
+  const unsigned cnt = *n_longs;
+  for (unsigned it = 0; it < cnt; ++it) {
+    const int4 e = longs[it];
+    const int64_t len = (int64_t) e.y - e.x + 1;
+    const int64_t per = (len + gridDim.x - 1) / gridDim.x;
+    const int64_t j0 = e.x + (int64_t) blockIdx.x * per;
+    const int64_t j1 = j0 + per - 1 < e.y ? j0 + per - 1 : e.y;
+    for (int64_t j = j0 + threadIdx.x; j <= j1; j += 256)
+      t_rowptr[j] = e.z;
+  }
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void spt_split_kernel(int64_t nnz, const spt_payload<T>* __restrict__ sorted,
-                                                        int32_t* __restrict__ t_colind, T* __restrict__ t_values) {
-  const int64_t k = (int64_t) blockIdx.x * 256 + threadIdx.x;
-  if (k >= nnz)
-    return;
-  const spt_payload<T> e = sorted[k];
-  t_colind[k] = e.row;
-  t_values[k] = e.val;
-}
-
-template <typename T>
-static int transpose_typed(spblas_gfx950_handle_t handle, int64_t m, int64_t n, int64_t nnz, const int32_t* rowptr,
+static int transpose_radix(spblas_gfx950_handle_t handle, int64_t m, int64_t n, int64_t nnz, const int32_t* rowptr,
                            const int32_t* colind, const T* values, int32_t* t_rowptr, int32_t* t_colind,
                            T* t_values) {
   hipStream_t s = handle->stream;
-  using P = spt_payload<T>;
   int bits = 1;
   while (bits < 32 && ((int64_t) 1 << bits) < n)
     ++bits;
-  // scratch: payload in / out, sorted keys and the sort's temporary storage, carved out of the handle's
-  // grow-only buffer (no allocation on repeated calls, nothing handed back to an allocator while
-  // kernels may still be using it)
-  size_t tmp_bytes = 0;
-  hipError_t e = rocprim::radix_sort_pairs(nullptr, tmp_bytes, colind, (int32_t*) nullptr, (P*) nullptr, (P*) nullptr,
-                                           (size_t) nnz, 0, bits, s);
-  if (e != hipSuccess)
-    return hip_fail(e);
-  const size_t pay = (((size_t) nnz * sizeof(P)) + 255) & ~(size_t) 255;
-  const size_t keys = (((size_t) nnz * 4) + 255) & ~(size_t) 255;
-  void* base = nullptr;
-  int rc = handle_scratch(handle, 2 * pay + keys + tmp_bytes + 256, &base);
+  const int passes = (bits + 7) / 8;
+  static const int xcd_map = [] {
+    const char* e = std::getenv("SPBLAS_GFX950_TRANSPOSE_XCD");
+    return e ? std::atoi(e) : 1;
+  }();
+  constexpr int SPT_ROUNDS = 8;
+  constexpr int SPT_TILE = SPT_WAVES * SPT_ROUNDS * 64;
+  const int64_t ntiles = cdiv(nnz, SPT_TILE);
+  const int64_t nscan = 256 * ntiles, nb = cdiv(nscan, 2048);
+  auto al = [](size_t b) { return (b + 255) & ~(size_t) 255; };
+  const size_t key_b = al((size_t) nnz * 4), val_b = al((size_t) nnz * sizeof(T));
+  const size_t cnt_b = al((size_t) (nscan + 1) * 4), part_b = al((size_t) (nb + 2) * sizeof(long long));
+  const size_t long_b = al((size_t) (n / 4096 + 4) * sizeof(int4)) + 256;
+  const size_t trow_b = al((size_t) (ntiles + 1) * 4);
+  // two intermediate (key, row, value) sets -- a one- or two-pass sort needs none or one -- and the sorted keys
+  const int nsets = passes >= 3 ? 2 : passes - 1;
+  void* basep = nullptr;
+  int rc = handle_scratch(handle, (size_t) nsets * (2 * key_b + val_b) + key_b + cnt_b + part_b + long_b + trow_b + 256,
+                          &basep);
   if (rc)
     return rc;
-  char* bp = static_cast<char*>(base);
-  P* pay_in = reinterpret_cast<P*>(bp);
-  P* pay_out = reinterpret_cast<P*>(bp + pay);
-  int32_t* sorted_cols = reinterpret_cast<int32_t*>(bp + 2 * pay);
-  void* tmp = bp + 2 * pay + keys;
-  hipLaunchKernelGGL((spt_payload_kernel<T>), dim3((unsigned) cdiv(m, 32)), dim3(256), 0, s, m, rowptr, values, pay_in);
-  e = rocprim::radix_sort_pairs(tmp, tmp_bytes, colind, sorted_cols, pay_in, pay_out, (size_t) nnz, 0, bits, s);
-  if (e != hipSuccess)
-    return hip_fail(e);
-  hipLaunchKernelGGL(spt_rowptr_kernel, dim3((unsigned) cdiv(n + 1, 256)), dim3(256), 0, s, n, nnz, sorted_cols, t_rowptr);
-  hipLaunchKernelGGL((spt_split_kernel<T>), dim3((unsigned) cdiv(nnz, 256)), dim3(256), 0, s, nnz, pay_out, t_colind,
-                     t_values);
+  char* bp = static_cast<char*>(basep);
+  int32_t* set_keys[2];
+  int32_t* set_rows[2];
+  T* set_vals[2];
+  for (int i = 0; i < 2; ++i) {
+    char* q = bp + (size_t) (i < nsets ? i : 0) * (2 * key_b + val_b);
+    set_keys[i] = reinterpret_cast<int32_t*>(q);
+    set_rows[i] = reinterpret_cast<int32_t*>(q + key_b);
+    set_vals[i] = reinterpret_cast<T*>(q + 2 * key_b);
+  }
+  char* q = bp + (size_t) nsets * (2 * key_b + val_b);
+  int32_t* sorted_cols = reinterpret_cast<int32_t*>(q);
+  int32_t* counts = reinterpret_cast<int32_t*>(q + key_b);
+  long long* partials = reinterpret_cast<long long*>(q + key_b + cnt_b);
+  int4* longs = reinterpret_cast<int4*>(q + key_b + cnt_b + part_b);
+  unsigned* n_longs = reinterpret_cast<unsigned*>(q + key_b + cnt_b + part_b + long_b - 256);
+  int32_t* tile_row = reinterpret_cast<int32_t*>(q + key_b + cnt_b + part_b + long_b);
+
+  const size_t smem = (size_t) SPT_TILE * (8 + sizeof(T)) + (size_t) (SPT_WAVES * 256 + 512 + 16) * 4;
+  auto k_first = spt_scatter_kernel<T, SPT_ROUNDS, true>;
+  auto k_next = spt_scatter_kernel<T, SPT_ROUNDS, false>;
+  SPB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_first), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int) smem));
+  SPB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_next), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int) smem));
+  hipLaunchKernelGGL(spt_tile_rows_kernel, dim3((unsigned) cdiv(ntiles + 1, 256)), dim3(256), 0, s, ntiles, SPT_TILE, nnz,
+                     m, rowptr, tile_row);
+  const int32_t* in_keys = colind;
+  const int32_t* in_rows = nullptr;
+  const T* in_vals = values;
+  for (int p = 0; p < passes; ++p) {
+    const bool last = p == passes - 1;
+    int32_t* out_keys = last ? sorted_cols : set_keys[p & 1];
+    int32_t* out_rows = last ? t_colind : set_rows[p & 1];
+    T* out_vals = last ? t_values : set_vals[p & 1];
+    hipLaunchKernelGGL(spt_count_kernel, dim3((unsigned) ntiles), dim3(512), 0, s, nnz, 8 * p, SPT_TILE, in_keys, ntiles,
+                       counts);
+    scan_counts_i32(s, nscan, counts, partials);
+    if (p == 0)
+      hipLaunchKernelGGL(k_first, dim3((unsigned) ntiles), dim3(512), smem, s, nnz, 8 * p, in_keys, in_rows, in_vals, m,
+                         rowptr, ntiles, counts, out_keys, out_rows, out_vals, xcd_map, tile_row);
+    else
+      hipLaunchKernelGGL(k_next, dim3((unsigned) ntiles), dim3(512), smem, s, nnz, 8 * p, in_keys, in_rows, in_vals, m,
+                         rowptr, ntiles, counts, out_keys, out_rows, out_vals, xcd_map, tile_row);
+    in_keys = out_keys;
+    in_rows = out_rows;
+    in_vals = out_vals;
+  }
+  SPB_HIP(hipMemsetAsync(n_longs, 0, 4, s));
+  hipLaunchKernelGGL(spt_rowptr_fill_kernel, dim3((unsigned) cdiv(nnz + 1, 1024)), dim3(256), 0, s, n, nnz, sorted_cols,
+                     t_rowptr, longs, n_longs);
+  hipLaunchKernelGGL(spt_rowptr_long_kernel, dim3(512), dim3(256), 0, s, longs, n_longs, t_rowptr);
   SPB_HIP(hipGetLastError());
   return SPBLAS_GFX950_STATUS_SUCCESS;
 }
@@ -150,9 +443,9 @@ extern "C" int spblas_gfx950_csr_transpose(spblas_gfx950_handle_t handle, int64_
     return SPBLAS_GFX950_STATUS_SUCCESS;
   }
   if (value_type == SPBLAS_GFX950_F32)
-    return transpose_typed<float>(handle, m, n, nnz, rowptr, colind, static_cast<const float*>(values), t_rowptr,
+    return transpose_radix<float>(handle, m, n, nnz, rowptr, colind, static_cast<const float*>(values), t_rowptr,
                                   t_colind, static_cast<float*>(t_values));
-  return transpose_typed<double>(handle, m, n, nnz, rowptr, colind, static_cast<const double*>(values), t_rowptr,
+  return transpose_radix<double>(handle, m, n, nnz, rowptr, colind, static_cast<const double*>(values), t_rowptr,
                                  t_colind, static_cast<double*>(t_values));
 }
 

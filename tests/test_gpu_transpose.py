@@ -54,6 +54,59 @@ def test_transpose_duplicates_empty_and_errors(gpu):
                                     torch.zeros(6, dtype=torch.int32, device="cuda"), (6, 4), 6))
 
 
+def _structured(m, n, row_len, cols_of, rng, dtype=np.float32):
+    rowptr = np.zeros(m + 1, np.int64)
+    rowptr[1:] = np.cumsum(row_len)
+    colind = np.concatenate([cols_of(r, int(l)) for r, l in enumerate(row_len)] or [np.zeros(0)]).astype(np.int32)
+    return rng.random(len(colind)).astype(dtype), rowptr.astype(np.int32), colind, (m, n), len(colind)
+
+
+@pytest.mark.parametrize("case", ["one_pass", "two_passes", "four_passes_long_gaps", "mostly_empty_rows",
+                                  "one_hot_column", "partial_last_tile_f64"])
+def test_transpose_radix_passes_corner_cases(gpu, case):
+    """The hand-written radix passes of csrc/transpose.hip against the oracle, bit for bit: 1 / 2 / 4 passes (n <= 256,
+    <= 65 536, > 16 M columns), column gaps of every class of the row-offset pass (lane, wave, whole-grid list), tiles
+    whose rows are almost all empty (thousands of row starts on one entry), one column that takes everything (a single
+    bucket per pass), several tiles with a partial last one, repeated columns inside rows (stability)."""
+    rng = np.random.default_rng(17)
+    dtype = np.float32
+    if case == "one_pass":
+        m, n = 3000, 200
+        lens = rng.integers(0, 12, m)
+        cols = lambda r, l: rng.integers(0, n, l)                      # repeated columns inside a row
+    elif case == "two_passes":
+        m, n = 2500, 40_000
+        lens = rng.integers(0, 15, m)
+        cols = lambda r, l: rng.integers(0, n, l)
+    elif case == "four_passes_long_gaps":
+        m, n = 4000, 20_000_000
+        lens = rng.integers(0, 8, m)
+        pool = np.concatenate([rng.integers(0, 50, 40), rng.integers(5_000, 9_000, 40),
+                               rng.integers(17_000_000, 17_000_300, 60), [n - 1]])
+        cols = lambda r, l: rng.choice(pool, l)
+    elif case == "mostly_empty_rows":
+        m, n = 200_000, 5000
+        lens = np.zeros(m, np.int64)
+        busy = rng.choice(m, 900, replace=False)
+        lens[busy] = rng.integers(1, 30, len(busy))
+        lens[:5000] = 0
+        lens[-7000:] = 0
+        cols = lambda r, l: rng.integers(0, n, l)
+    elif case == "one_hot_column":
+        m, n = 9000, 70_000
+        lens = np.full(m, 2)
+        cols = lambda r, l: np.array([4321, 4321 if r % 3 else 69_999])
+    else:
+        m, n, dtype = 1300, 3000, np.float64
+        lens = rng.integers(5, 12, m)                                   # ~ 11 000 entries: three tiles of 4096
+        cols = lambda r, l: rng.integers(0, n, l)
+    values, rowptr, colind, shape, nnz = _structured(m, n, lens, cols, rng, dtype)
+    got = device_transpose(values, rowptr, colind, shape, nnz)
+    ref = oracle.transpose(shape, rowptr, colind, values)
+    for g, r, what in zip(got, ref, ("rowptr", "colind", "values")):
+        assert np.array_equal(g, r), f"{case}: {what} differs"
+
+
 def test_transpose_large_is_an_involution(gpu):
     m, n = 300_000, 200_000
     values, rowptr, colind, shape, nnz = generate.uniform_csr_device(m, n, 12, seed=4)

@@ -16,7 +16,7 @@ for f in glob.glob("$OUT/p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         acc[r["Kernel_Name"].split("(")[0][-60:]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, c in acc.items():
-    if not any(x in k for x in ("spb::spmv", "spb::pb_", "spb::spmm", "spb::spg", "spb::trsv")): continue
+    if not any(x in k for x in ("spb::spmv", "spb::pb_", "spb::spmm", "spb::spg", "spb::trsv", "spb::spt", "spb::scan")): continue
     m = {n: sum(v) / len(v) for n, v in c.items()}
     rd = 32 * m.get("TCC_EA0_RDREQ_32B_sum", 0) + 64 * m.get("TCC_EA0_RDREQ_64B_sum", 0) + 128 * m.get("TCC_EA0_RDREQ_128B_sum", 0)
     w64 = m.get("TCC_EA0_WRREQ_64B_sum", 0); wr = 64 * w64 + 32 * max(m.get("TCC_EA0_WRREQ_sum", 0) - w64, 0)

@@ -1,13 +1,8 @@
 #!/bin/bash
-# same-box A/B: previous library (tools/tmp_old) vs the current one on the cfg5 fill
+# team width of the bin-2 hash kernels (symbolic + first fill) on cfg5
 mkdir -p gpurun_out
-L=spblas-reference_amd/lib/libspblas_gfx950.so
-cp $L /tmp/new.so
-one() { timeout 600 python bench.py --workload $1 --no-cpu-baseline --steps 20 --warmup 5 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['roofline']['kernel_avg_ms'])"; }
-for rep in 1 2; do
-  cp tools/tmp_old/libspblas_gfx950.so $L; echo -n "old spgemm: "; one spgemm
-  cp /tmp/new.so $L; echo -n "new spgemm: "; one spgemm
+for t in 64 32 16; do
+  echo -n "hash2 TPR $t: "
+  SPBLAS_GFX950_SPG_HASH2_TPR=$t timeout 600 python bench.py --workload spgemm --no-cpu-baseline --steps 5 --warmup 2 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); c=d['config']; print(d['ms_per_step'], c['multiply_compute_ms_untimed'], c['first_fill_ms_untimed'], c['second_fill_ms_untimed_records_ranks'])"
 done
-echo -n "add: "; one add
-timeout 900 python -m pytest tests/test_gpu_add.py tests/test_gpu_spgemm.py tests/test_gpu_configs.py tests/test_gpu_dropin.py -x -q 2>&1 | tail -2
-timeout 600 python tools/fuzz_spgemm.py 2>&1 | tail -2
+for t in 32 16; do SPBLAS_GFX950_SPG_HASH2_TPR=$t timeout 900 python -m pytest tests/test_gpu_add.py tests/test_gpu_spgemm.py -x -q 2>&1 | tail -2; done
