@@ -793,8 +793,9 @@ void trsv_prepare(trsv_state_t& st, A&& a, Triangle, DiagonalStorage, B&& b, X&&
   auto ab = __detail::get_ultimate_base(a);
   reject_conjugated(__detail::is_conjugated(a));
   // the reference asserts these (triangular_solve_impl.hpp:50-53); a device backend has to refuse
+  auto bb = __detail::get_ultimate_base(b);  // b may be scaled(beta, b) (examples/simple_sptrsv.cpp:49-53)
   if (ab.shape()[0] != ab.shape()[1] || static_cast<std::int64_t>(std::ranges::size(x)) != ab.shape()[1] ||
-      static_cast<std::int64_t>(std::ranges::size(b)) != ab.shape()[0]) {
+      static_cast<std::int64_t>(std::ranges::size(bb)) != ab.shape()[0]) {
     throw std::invalid_argument("triangular_solve: matrix and vector dimensions are incompatible.");
   }
   const int uplo = std::is_same_v<Triangle, upper_triangle_t> ? SPBLAS_GFX950_UPPER : SPBLAS_GFX950_LOWER;
@@ -834,8 +835,16 @@ void triangular_solve(operation_info_t& info, A&& a, Triangle t, DiagonalStorage
   auto ab = __detail::get_ultimate_base(a);
   using T = typename decltype(ab)::scalar_type;
   const T alpha = static_cast<T>(__detail::get_scaling_factor(a).value_or(1.0));
-  st.template solve<T>(alpha, ab.rowptr().data(), ab.colind().data(), ab.values().data(), std::ranges::data(b),
+  // a scaled right-hand side: the solve is linear in b, so the factor is applied to x afterwards
+  auto bb = __detail::get_ultimate_base(b);
+  const auto beta = __detail::get_scaling_factor(b);
+  st.template solve<T>(alpha, ab.rowptr().data(), ab.colind().data(), ab.values().data(), std::ranges::data(bb),
                        std::ranges::data(x));
+  if (beta.has_value()) {
+    __gfx950::handle_t h;
+    __gfx950::scale_values<T>(h, static_cast<std::int64_t>(std::ranges::size(x)), static_cast<T>(*beta),
+                              std::ranges::data(x));
+  }
 }
 template <typename A, typename Triangle, typename DiagonalStorage, typename B, typename X>
   requires(__detail::has_csr_base<A>)

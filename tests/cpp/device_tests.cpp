@@ -477,6 +477,15 @@ static void trsv_case(int n, int nnz, Triangle t, Diag d, bool zero_b) {
   std::span<value_t> xs2(d_x2.p, n);
   spblas::triangular_solve(a.view, t, d, bs, xs2);
   CHECK(d_x2.download() == x);
+  // scaled right-hand side (examples/simple_sptrsv.cpp:49-53): the solve is linear in b
+  dvec<value_t> d_x3(std::vector<value_t>(n, 1.0f));
+  std::span<value_t> xs3(d_x3.p, n);
+  spblas::triangular_solve(a.view, t, d, spblas::scaled(2.0f, bs), xs3);
+  auto x3 = d_x3.download();
+  bool ok3 = true;
+  for (int i = 0; i < n; i++)
+    ok3 &= near_ref(2.0f * x_ref[i], x3[i]);
+  CHECK(ok3);
 }
 
 static void test_triangular_solve() {
