@@ -56,6 +56,8 @@ struct spblas_gfx950_spgemm_s {
   // its column in the (sorted) output row; later passes accumulate by rank -- no hash, no compaction, no sort
   int32_t* r_pbase = nullptr;   // [m + 1] first product of every row in the enumeration order
   uint8_t* r_rank = nullptr;    // [products] rank of the product's column in its output row (rows of <= 256 products)
+  int32_t* r_pbase3 = nullptr;  // the same pair for the rows of bin 3 (257 .. 1024 products: two-byte ranks), e.g. the
+  uint16_t* r_rank3 = nullptr;  // 27-point stencil times itself or a Galerkin product
   int32_t* r_cols = nullptr;    // [nnz(C)] the sorted column indices (the caller may pass other arrays later)
   const int32_t* r_last_colind = nullptr;  // the caller's column array the last numeric pass filled
   // (start, length) of the B row every entry of A selects, written once by the symbolic pass: every later kernel
@@ -533,7 +535,7 @@ __global__ __launch_bounds__(256) void spg_products_kernel(int64_t m, const int3
                                                            const int32_t* __restrict__ b_rowptr,
                                                            const int2* __restrict__ adesc,
                                                            const int32_t* __restrict__ d_rowptr,
-                                                           int32_t* __restrict__ prod) {
+                                                           int32_t* __restrict__ prod, int32_t* __restrict__ prod3) {
   const int64_t row = (int64_t) blockIdx.x * 32 + threadIdx.x / 8;
   const int lane = threadIdx.x % 8;
   int64_t ub = 0;
@@ -549,23 +551,26 @@ __global__ __launch_bounds__(256) void spg_products_kernel(int64_t m, const int3
   ub = group_sum_c<8>(ub);
   if (row < m && d_rowptr)
     ub += d_rowptr[row + 1] - d_rowptr[row];  // the addend's entries follow the products of the row
-  if (row < m && lane == 0)
+  if (row < m && lane == 0) {
     prod[row] = ub <= 256 ? (int32_t) ub : 0;
+    prod3[row] = ub > 256 && ub <= 1024 ? (int32_t) ub : 0;
+  }
 }
 
 // Numeric reuse, recording pass: the rank of every product's column in its (sorted) output row -- a binary search in
 // the row's columns, held in LDS.  The products of a row are enumerated in a fixed order that the fills by rank
 // (spg_ranked_fill_kernel) repeat: A entries in storage order, the entries of each B row in storage order; product
 // index = r_pbase[row] + (entries of the earlier B rows) + offset.  Rows of bins 1-2 have <= 256 products, hence
+// (bin 3: <= 1024 products, RT = uint16_t)
 // <= 256 output entries: a rank fits one byte.
 // Teams of TPR <= 64 lanes inside one wavefront, SUB lanes per B row, as in spg_hash_kernel.
-template <int TPR, int CAP>
+template <int TPR, int CAP, typename RT>
 __global__ __launch_bounds__(256) void spg_rank_record_kernel(
     int64_t count, const int32_t* __restrict__ perm, const int32_t* __restrict__ a_rowptr,
     const int32_t* __restrict__ a_colind, const int32_t* __restrict__ b_rowptr, const int2* __restrict__ adesc,
     const int32_t* __restrict__ b_colind, const int32_t* __restrict__ c_rowptr,
     const int32_t* __restrict__ cols_sorted, int sub, const int32_t* __restrict__ pbase,
-    uint8_t* __restrict__ prank, const int32_t* __restrict__ d_rowptr, const int32_t* __restrict__ d_colind) {
+    RT* __restrict__ prank, const int32_t* __restrict__ d_rowptr, const int32_t* __restrict__ d_colind) {
   // b_rowptr == nullptr: B is the identity (add()): every A entry is one product on its own column.
   // d_rowptr != nullptr: the entries of the addend's row are enumerated after the products.
   constexpr int RPB = 256 / TPR;
@@ -628,14 +633,14 @@ __global__ __launch_bounds__(256) void spg_rank_record_kernel(
       const int off = __shfl(excl, src);
       if (j < cnt)
         for (int q = sl; q < ln; q += sub)
-          prank[running + off + q] = (uint8_t) rank_of(b_rowptr ? b_colind[q0 + q] : q0 + q);
+          prank[running + off + q] = (RT) rank_of(b_rowptr ? b_colind[q0 + q] : q0 + q);
     }
     running += total;
   }
   if (d_rowptr) {
     const int q0 = d_rowptr[row], q1 = d_rowptr[row + 1];
     for (int q = q0 + lt; q < q1; q += TPR)
-      prank[running + (q - q0)] = (uint8_t) rank_of(d_colind[q]);
+      prank[running + (q - q0)] = (RT) rank_of(d_colind[q]);
   }
 }
 
@@ -659,13 +664,13 @@ __global__ __launch_bounds__(256) void spg_adesc_kernel(int64_t a_nnz, const int
 //    product then owns its slot, so the slots are written with plain LDS stores -- no zero fill, no read-modify-write
 //    (cfg5: 96.6 % of the rows).  Rows with repeated columns accumulate as before.
 // Same product enumeration as the recording kernel: r_rank does not depend on TPR, SUB or U.
-template <typename T, int TPR, int CAP, int U, bool GENERAL>
+template <typename T, int TPR, int CAP, int U, bool GENERAL, typename RT>
 __global__ __launch_bounds__(256) void spg_ranked_fill_kernel(
     int64_t count, const int32_t* __restrict__ perm, const int32_t* __restrict__ a_rowptr,
     const int32_t* __restrict__ a_colind, const T* __restrict__ a_values, const int32_t* __restrict__ b_rowptr,
     const int2* __restrict__ adesc, const T* __restrict__ b_values, const int32_t* __restrict__ c_rowptr,
     const int32_t* __restrict__ cols_sorted, int32_t* __restrict__ c_colind, T* __restrict__ c_values, T alpha,
-    int sub, const int32_t* __restrict__ pbase, const uint8_t* __restrict__ prank, int copy_cols,
+    int sub, const int32_t* __restrict__ pbase, const RT* __restrict__ prank, int copy_cols,
     const int32_t* __restrict__ d_rowptr, const T* __restrict__ d_values, T beta) {
   // GENERAL: b_rowptr == nullptr means B is the identity (add()), d_rowptr != nullptr adds beta * (row of the addend).
   // The plain three-argument product has its own instantiation: the extra tests in the load batch cost it 10 %.
@@ -822,21 +827,22 @@ static int launch_hash(hipStream_t s, const spblas_gfx950_spgemm_s* st, int bin,
 template <typename T, bool NUMERIC>
 static int run_bins(spblas_gfx950_handle_t h, spblas_gfx950_spgemm_s* st, const T* a_values, const T* b_values,
                     int32_t* c_rowptr, int32_t* c_colind, T* c_values, T alpha, const T* d_values = nullptr,
-                    T beta = T(0), bool skip_small_bins = false) {
+                    T beta = T(0), int skip_upto = 0) {
   hipStream_t s = h->stream;
   int rc;
-  // skip_small_bins: bins 1-2 were done by the rank-based reuse pass
-  if (!skip_small_bins &&
+  // skip_upto = 2 / 3: bins 1-2 / 1-3 were done by the rank-based reuse pass
+  if (skip_upto < 2 &&
       (rc = launch_hash<T, 7, 16, NUMERIC>(s, st, 1, a_values, b_values, c_rowptr, c_colind, c_values, alpha,
                                            d_values, beta)))
     return rc;
   // bin 2: a wave per row for the numeric pass (its rank sort works on TPR buckets: 32-lane teams take 3.2 instead of
   // 2.1 ms at cfg5), two rows per wave for the symbolic one (0.61 -> 0.56 ms: more rows' loads in flight)
-  if (!skip_small_bins &&
+  if (skip_upto < 2 &&
       (rc = launch_hash<T, 9, NUMERIC ? 64 : 32, NUMERIC>(s, st, 2, a_values, b_values, c_rowptr, c_colind, c_values,
                                                           alpha, d_values, beta)))
     return rc;
-  if ((rc = launch_hash<T, 11, 128, NUMERIC>(s, st, 3, a_values, b_values, c_rowptr, c_colind, c_values, alpha,
+  if (skip_upto < 3 &&
+      (rc = launch_hash<T, 11, 128, NUMERIC>(s, st, 3, a_values, b_values, c_rowptr, c_colind, c_values, alpha,
                                            d_values, beta)))
     return rc;
   if ((rc = launch_hash<T, 13, 256, NUMERIC>(s, st, 4, a_values, b_values, c_rowptr, c_colind, c_values, alpha,
@@ -868,37 +874,42 @@ static int run_bins(spblas_gfx950_handle_t h, spblas_gfx950_spgemm_s* st, const 
   return SPBLAS_GFX950_STATUS_SUCCESS;
 }
 
-template <typename T, int TPR, int CAP>
+template <typename T, int TPR, int CAP, typename RT>
 static void launch_ranked_fill(hipStream_t s, const spblas_gfx950_spgemm_s* st, int64_t cnt, int64_t first,
                                const T* a_values, const T* b_values, int32_t* c_colind, T* c_values, T alpha,
-                               int copy_cols, const T* d_values, T beta) {
+                               int copy_cols, const T* d_values, T beta, const int32_t* pbase, const RT* ranks) {
   const int sub = st->identity_b ? 1 : st->sub < TPR ? st->sub : TPR;  // identity B: one lane per A entry
   constexpr int RPB = 256 / TPR;
   if (st->identity_b || st->d_rowptr)
-    hipLaunchKernelGGL((spg_ranked_fill_kernel<T, TPR, CAP, 4, true>), dim3((unsigned) cdiv(cnt, RPB)), dim3(256), 0, s,
-                       cnt, st->perm + first, st->a_rowptr, st->a_colind, a_values, st->b_rowptr, st->r_adesc, b_values,
-                       st->rowptr, st->r_cols, c_colind, c_values, alpha, sub, st->r_pbase, st->r_rank, copy_cols,
+    hipLaunchKernelGGL((spg_ranked_fill_kernel<T, TPR, CAP, 4, true, RT>), dim3((unsigned) cdiv(cnt, RPB)), dim3(256), 0,
+                       s, cnt, st->perm + first, st->a_rowptr, st->a_colind, a_values, st->b_rowptr, st->r_adesc,
+                       b_values, st->rowptr, st->r_cols, c_colind, c_values, alpha, sub, pbase, ranks, copy_cols,
                        st->d_rowptr, d_values, beta);
   else
-    hipLaunchKernelGGL((spg_ranked_fill_kernel<T, TPR, CAP, 4, false>), dim3((unsigned) cdiv(cnt, RPB)), dim3(256), 0, s,
-                       cnt, st->perm + first, st->a_rowptr, st->a_colind, a_values, st->b_rowptr, st->r_adesc, b_values,
-                       st->rowptr, st->r_cols, c_colind, c_values, alpha, sub, st->r_pbase, st->r_rank, copy_cols,
+    hipLaunchKernelGGL((spg_ranked_fill_kernel<T, TPR, CAP, 4, false, RT>), dim3((unsigned) cdiv(cnt, RPB)), dim3(256), 0,
+                       s, cnt, st->perm + first, st->a_rowptr, st->a_colind, a_values, st->b_rowptr, st->r_adesc,
+                       b_values, st->rowptr, st->r_cols, c_colind, c_values, alpha, sub, pbase, ranks, copy_cols,
                        st->d_rowptr, d_values, beta);
 }
 
-// the recording pass for the rows of bins 1-2 ...
+// the recording pass for the rows of bins 1-3 ...
 static void launch_rank_record(hipStream_t s, const spblas_gfx950_spgemm_s* st) {
   const int64_t c1 = st->bin_off[2] - st->bin_off[1], c2 = st->bin_off[3] - st->bin_off[2];
+  const int64_t c3 = st->bin_off[4] - st->bin_off[3];
   const int sub1 = st->identity_b ? 1 : st->sub < 16 ? st->sub : 16;
   const int sub2 = st->identity_b ? 1 : st->sub < 64 ? st->sub : 64;
   if (c1 > 0)
-    hipLaunchKernelGGL((spg_rank_record_kernel<16, 64>), dim3((unsigned) cdiv(c1, 16)), dim3(256), 0, s, c1,
+    hipLaunchKernelGGL((spg_rank_record_kernel<16, 64, uint8_t>), dim3((unsigned) cdiv(c1, 16)), dim3(256), 0, s, c1,
                        st->perm + st->bin_off[1], st->a_rowptr, st->a_colind, st->b_rowptr, st->r_adesc, st->b_colind,
                        st->rowptr, st->r_cols, sub1, st->r_pbase, st->r_rank, st->d_rowptr, st->d_colind);
   if (c2 > 0)
-    hipLaunchKernelGGL((spg_rank_record_kernel<64, 256>), dim3((unsigned) cdiv(c2, 4)), dim3(256), 0, s, c2,
+    hipLaunchKernelGGL((spg_rank_record_kernel<64, 256, uint8_t>), dim3((unsigned) cdiv(c2, 4)), dim3(256), 0, s, c2,
                        st->perm + st->bin_off[2], st->a_rowptr, st->a_colind, st->b_rowptr, st->r_adesc, st->b_colind,
                        st->rowptr, st->r_cols, sub2, st->r_pbase, st->r_rank, st->d_rowptr, st->d_colind);
+  if (c3 > 0 && st->r_rank3)
+    hipLaunchKernelGGL((spg_rank_record_kernel<64, 1024, uint16_t>), dim3((unsigned) cdiv(c3, 4)), dim3(256), 0, s, c3,
+                       st->perm + st->bin_off[3], st->a_rowptr, st->a_colind, st->b_rowptr, st->r_adesc, st->b_colind,
+                       st->rowptr, st->r_cols, sub2, st->r_pbase3, st->r_rank3, st->d_rowptr, st->d_colind);
 }
 
 // ... and their fills by rank.  Team width of a bin-2 row: the A entries of a row are walked TPR at a time, and a
@@ -922,23 +933,28 @@ static void launch_ranked(hipStream_t s, const spblas_gfx950_spgemm_s* st, const
   const int tpr1 = tpr1_env ? tpr1_env : (st->identity_b || avg_a <= 8.0) ? 8 : 16;
   if (c1 > 0) {
     if (tpr1 == 8)
-      launch_ranked_fill<T, 8, 64>(s, st, c1, st->bin_off[1], a_values, b_values, c_colind, c_values, alpha, copy_cols,
-                                   d_values, beta);
+      launch_ranked_fill<T, 8, 64, uint8_t>(s, st, c1, st->bin_off[1], a_values, b_values, c_colind, c_values, alpha,
+                                            copy_cols, d_values, beta, st->r_pbase, st->r_rank);
     else
-      launch_ranked_fill<T, 16, 64>(s, st, c1, st->bin_off[1], a_values, b_values, c_colind, c_values, alpha,
-                                    copy_cols, d_values, beta);
+      launch_ranked_fill<T, 16, 64, uint8_t>(s, st, c1, st->bin_off[1], a_values, b_values, c_colind, c_values, alpha,
+                                             copy_cols, d_values, beta, st->r_pbase, st->r_rank);
   }
   if (c2 > 0) {
     if (tpr2 == 16)
-      launch_ranked_fill<T, 16, 256>(s, st, c2, st->bin_off[2], a_values, b_values, c_colind, c_values, alpha,
-                                     copy_cols, d_values, beta);
+      launch_ranked_fill<T, 16, 256, uint8_t>(s, st, c2, st->bin_off[2], a_values, b_values, c_colind, c_values, alpha,
+                                              copy_cols, d_values, beta, st->r_pbase, st->r_rank);
     else if (tpr2 == 32)
-      launch_ranked_fill<T, 32, 256>(s, st, c2, st->bin_off[2], a_values, b_values, c_colind, c_values, alpha,
-                                     copy_cols, d_values, beta);
+      launch_ranked_fill<T, 32, 256, uint8_t>(s, st, c2, st->bin_off[2], a_values, b_values, c_colind, c_values, alpha,
+                                              copy_cols, d_values, beta, st->r_pbase, st->r_rank);
     else
-      launch_ranked_fill<T, 64, 256>(s, st, c2, st->bin_off[2], a_values, b_values, c_colind, c_values, alpha,
-                                     copy_cols, d_values, beta);
+      launch_ranked_fill<T, 64, 256, uint8_t>(s, st, c2, st->bin_off[2], a_values, b_values, c_colind, c_values, alpha,
+                                              copy_cols, d_values, beta, st->r_pbase, st->r_rank);
   }
+  // bin 3 (257 .. 1024 products): a wave per row, 4 KiB (fp32) of LDS accumulators per row
+  const int64_t c3 = st->bin_off[4] - st->bin_off[3];
+  if (c3 > 0 && st->r_rank3)
+    launch_ranked_fill<T, 64, 1024, uint16_t>(s, st, c3, st->bin_off[3], a_values, b_values, c_colind, c_values, alpha,
+                                              copy_cols, d_values, beta, st->r_pbase3, st->r_rank3);
 }
 
 // numeric pass.  Rows that sit in the LDS-hash bins 1-2 are eligible for reuse -- three- and four-argument products and
@@ -957,7 +973,8 @@ static int spgemm_numeric_typed(spblas_gfx950_handle_t h, spblas_gfx950_spgemm_s
                      !(h->spgemm_keep_colind != 0 && c_colind == st->r_last_colind), d_values, beta);
     SPB_HIP(hipGetLastError());
     st->r_last_colind = c_colind;
-    return run_bins<T, true>(h, st, a_values, b_values, st->rowptr, c_colind, c_values, alpha, d_values, beta, true);
+    return run_bins<T, true>(h, st, a_values, b_values, st->rowptr, c_colind, c_values, alpha, d_values, beta,
+                             st->r_rank3 ? 3 : 2);
   }
   int rc = run_bins<T, true>(h, st, a_values, b_values, st->rowptr, c_colind, c_values, alpha, d_values, beta);
   if (rc)
@@ -966,34 +983,46 @@ static int spgemm_numeric_typed(spblas_gfx950_handle_t h, spblas_gfx950_spgemm_s
   // reused and records the ranks (hash pass + 1.3 ms once at cfg5), the third and later ones take the rank path
   const char* env = std::getenv("SPBLAS_GFX950_SPGEMM_REUSE");
   const bool want = !(env && env[0] == '0') && ++st->numeric_calls >= (env && env[0] == '2' ? 1 : 2);
-  const int64_t small_rows = st->bin_off[3] - st->bin_off[1];
+  const int64_t small_rows = st->bin_off[4] - st->bin_off[1];  // bins 1-3
   if (!want || small_rows == 0 || st->m == 0)
     return SPBLAS_GFX950_STATUS_SUCCESS;
-  // record: products per row -> r_pbase, a copy of the sorted columns, then the ranks
+  // record: products per row -> r_pbase (bins 1-2) / r_pbase3 (bin 3), a copy of the sorted columns, then the ranks
   const int64_t m = st->m, nb = cdiv(m, 2048);
-  long long* partials = nullptr;
-  if ((rc = dev_alloc((void**) &st->r_pbase, (size_t) (m + 1) * 4, s)) ||
-      (rc = dev_alloc((void**) &partials, (size_t) (nb + 2) * sizeof(long long), s)))
-    return SPBLAS_GFX950_STATUS_SUCCESS;  // out of memory for the optional fast path: keep the hash path
+  long long *partials = nullptr, *partials3 = nullptr;
+  auto drop = [&]() {  // out of memory for the optional fast path: keep the hash path
+    dev_free(st->r_pbase, s);
+    dev_free(st->r_pbase3, s);
+    dev_free(st->r_rank, s);
+    dev_free(st->r_rank3, s);
+    dev_free(st->r_cols, s);
+    st->r_pbase = st->r_pbase3 = nullptr;
+    st->r_rank = nullptr;
+    st->r_rank3 = nullptr;
+    st->r_cols = nullptr;
+    return SPBLAS_GFX950_STATUS_SUCCESS;
+  };
+  if (dev_alloc((void**) &st->r_pbase, (size_t) (m + 1) * 4, s) || dev_alloc((void**) &st->r_pbase3, (size_t) (m + 1) * 4, s) ||
+      dev_alloc((void**) &partials, (size_t) 2 * (nb + 2) * sizeof(long long), s))
+    return drop();
+  partials3 = partials + (nb + 2);
   hipLaunchKernelGGL(spg_products_kernel, dim3((unsigned) cdiv(m, 32)), dim3(256), 0, s, m, st->a_rowptr, st->a_colind,
-                     st->b_rowptr, st->r_adesc, st->d_rowptr, st->r_pbase);
+                     st->b_rowptr, st->r_adesc, st->d_rowptr, st->r_pbase, st->r_pbase3);
   long long* total_dev = scan_counts_i32(s, m, st->r_pbase, partials);
-  long long total = 0;
+  long long* total3_dev = scan_counts_i32(s, m, st->r_pbase3, partials3);
+  long long total = 0, total3 = 0;
   hipError_t e = hipMemcpyAsync(&total, total_dev, sizeof(total), hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess)
+    e = hipMemcpyAsync(&total3, total3_dev, sizeof(total3), hipMemcpyDeviceToHost, s);
   if (e == hipSuccess)
     e = hipStreamSynchronize(s);
   dev_free(partials, s);
   if (e != hipSuccess)
     return hip_fail(e);
-  if (total <= 0 || total > INT32_MAX ||
-      dev_alloc((void**) &st->r_rank, (size_t) total, s) != SPBLAS_GFX950_STATUS_SUCCESS ||
-      dev_alloc((void**) &st->r_cols, (size_t) st->c_nnz * 4, s) != SPBLAS_GFX950_STATUS_SUCCESS) {
-    dev_free(st->r_pbase, s);
-    dev_free(st->r_rank, s);
-    st->r_pbase = nullptr;
-    st->r_rank = nullptr;
-    return SPBLAS_GFX950_STATUS_SUCCESS;
-  }
+  if (total + total3 <= 0 || total > INT32_MAX || total3 > INT32_MAX ||
+      (total > 0 && dev_alloc((void**) &st->r_rank, (size_t) total, s) != SPBLAS_GFX950_STATUS_SUCCESS) ||
+      (total3 > 0 && dev_alloc((void**) &st->r_rank3, (size_t) total3 * 2, s) != SPBLAS_GFX950_STATUS_SUCCESS) ||
+      dev_alloc((void**) &st->r_cols, (size_t) st->c_nnz * 4, s) != SPBLAS_GFX950_STATUS_SUCCESS)
+    return drop();
   SPB_HIP(hipMemcpyAsync(st->r_cols, c_colind, (size_t) st->c_nnz * 4, hipMemcpyDeviceToDevice, s));
   launch_rank_record(s, st);
   SPB_HIP(hipGetLastError());
@@ -1009,6 +1038,10 @@ static void spgemm_release(spblas_gfx950_spgemm_s* st, hipStream_t s) {
   dev_free(st->dense_vals, s);
   dev_free(st->r_pbase, s);
   dev_free(st->r_rank, s);
+  dev_free(st->r_pbase3, s);
+  dev_free(st->r_rank3, s);
+  st->r_pbase3 = nullptr;
+  st->r_rank3 = nullptr;
   dev_free(st->r_cols, s);
   dev_free(st->r_adesc, s);
   st->r_adesc = nullptr;

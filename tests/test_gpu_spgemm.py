@@ -118,6 +118,50 @@ def test_spgemm_all_bins_including_dense_rows(gpu):
     check_against_oracle(a_h, b_h, device_spgemm(a_h, b_h, True), np.float32)
 
 
+@pytest.mark.parametrize("record_at", ["second", "first"])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_spgemm_repeated_fills_every_bin_by_rank(gpu, monkeypatch, dtype, record_at):
+    """Five numeric passes on one symbolic result whose rows sit in every accumulator bin: <= 64 and <= 256 products
+    (one-byte ranks), 257 .. 1024 (two-byte ranks, e.g. a 27-point stencil times itself), and the larger hash / dense
+    bins that keep the hash kernels.  New values and a new factor every pass, columns poisoned before each."""
+    if record_at == "first":
+        monkeypatch.setenv("SPBLAS_GFX950_SPGEMM_REUSE", "2")
+    rng = np.random.default_rng(21)
+    m, k, n = 400, 700, 20000
+    a_lens = rng.integers(0, 6, m)
+    a_lens[10:90] = rng.integers(12, 30, 80)     # x B rows of ~30: 360 .. 900 products -> bin 3
+    a_lens[5] = 60                               # ~1800 products -> bin 4
+    a_lens[6] = 300                              # dense accumulator
+    a_lens[7] = 0
+    ar = np.concatenate([[0], np.cumsum(a_lens)]).astype(np.int32)
+    ac = np.concatenate([rng.choice(k, L, replace=False) for L in a_lens]).astype(np.int32)
+    b_lens = rng.integers(20, 40, k)
+    b_lens[ac[ar[6]]] = 5000
+    br = np.concatenate([[0], np.cumsum(b_lens)]).astype(np.int32)
+    bc = np.concatenate([rng.choice(n, L, replace=False) for L in b_lens]).astype(np.int32)
+    bc[br[3] + 1] = bc[br[3]]                    # a repeated column inside a B row
+    d_a = G.csr_on_device(np.zeros(len(ac), dtype), ar, ac, (m, k), len(ac))
+    d_b = G.csr_on_device(np.zeros(len(bc), dtype), br, bc, (k, n), len(bc))
+    d_rp = torch.full((m + 1,), -1, dtype=torch.int32, device="cuda")
+    d_c = sp.csr_view(None, d_rp, None, (m, n), 0)
+    state = sp.spgemm_state_t()
+    sp.multiply_compute(state, d_a, d_b, d_c)
+    cn = state.result_nnz()
+    d_vals = torch.full((cn,), float("nan"), dtype=G.dev(np.zeros(1, dtype)).dtype, device="cuda")
+    d_cols = torch.full((cn,), -1, dtype=torch.int32, device="cuda")
+    d_c.update(d_vals, d_rp, d_cols, (m, n), cn)
+    for it, scale in enumerate([None, 2.0, None, -0.5, None]):
+        av = (rng.random(len(ac)) + 0.5).astype(dtype)
+        bv = (rng.random(len(bc)) + 0.5).astype(dtype)
+        d_a.values().copy_(G.dev(av))
+        d_b.values().copy_(G.dev(bv))
+        d_vals.fill_(float("nan"))
+        d_cols.fill_(-1)
+        sp.multiply_numeric(state, sp.scaled(scale, d_a) if scale is not None else d_a, d_b, d_c)
+        got = (cn, G.host(d_rp), G.host(d_cols), G.host(d_vals))
+        check_against_oracle((av, ar, ac, (m, k)), (bv, br, bc, (k, n)), got, dtype, scale or 1.0)
+
+
 def test_spgemm_reuse_changed_values_and_pointers(gpu):
     # device/spgemm_reuse_test.cpp:12-114,326-399: symbolic once, numeric 3x with new values,
     # then with re-allocated (different pointer) value arrays

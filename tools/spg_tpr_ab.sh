@@ -1,8 +1,8 @@
 #!/bin/bash
-# team width of the bin-2 hash kernels (symbolic + first fill) on cfg5
+# SpGEMM family after a change: tests, fuzz, bench lines (spgemm, add), bin-3 timing
 mkdir -p gpurun_out
-for t in 64 32 16; do
-  echo -n "hash2 TPR $t: "
-  SPBLAS_GFX950_SPG_HASH2_TPR=$t timeout 600 python bench.py --workload spgemm --no-cpu-baseline --steps 5 --warmup 2 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); c=d['config']; print(d['ms_per_step'], c['multiply_compute_ms_untimed'], c['first_fill_ms_untimed'], c['second_fill_ms_untimed_records_ranks'])"
-done
-for t in 32 16; do SPBLAS_GFX950_SPG_HASH2_TPR=$t timeout 900 python -m pytest tests/test_gpu_add.py tests/test_gpu_spgemm.py -x -q 2>&1 | tail -2; done
+timeout 900 python -m pytest tests/test_gpu_add.py tests/test_gpu_spgemm.py tests/test_gpu_configs.py tests/test_gpu_dropin.py -x -q 2>&1 | tail -3
+timeout 600 python tools/fuzz_spgemm.py 2>&1 | tail -2
+timeout 600 python bench.py --workload spgemm --no-cpu-baseline --steps 20 --warmup 5 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); c=d['config']; print('fill', d['ms_per_step'], 'compute', c['multiply_compute_ms_untimed'], 'first fill', c['first_fill_ms_untimed'], 'recording fill', c['second_fill_ms_untimed_records_ranks'])"
+timeout 600 python tools/spg_bin3.py 2>&1 | tail -2
+timeout 600 python tools/spg_bin3.py 300000 32 2>&1 | tail -2
