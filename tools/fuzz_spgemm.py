@@ -43,6 +43,32 @@ for it in range(iters):
         al, be = float(rng.choice([1.0, 2.0])), float(rng.choice([1.0, -0.5]))
         TA.check_spgemm4(a, b, d, TA.device_spgemm4(a, b, d, sa=None if al == 1.0 else al, sd=None if be == 1.0 else be)[0],
                          dtype, al, be)
+        # repeated numeric passes: with SPBLAS_GFX950_SPGEMM_REUSE=2 the first pass records the ranks and the second
+        # one IS the rank path (bins 1-3, addend entries included); new values in between
+        os.environ["SPBLAS_GFX950_SPGEMM_REUSE"] = "2" if it & 1 else "1"
+        new_vals = tuple((rng.random(len(t[0])) + 0.25).astype(dtype) for t in (a, b, d))
+        first, second = TA.device_spgemm4(a, b, d, sa=None if al == 1.0 else al, sd=None if be == 1.0 else be,
+                                          reuse_values=new_vals)
+        TA.check_spgemm4(a, b, d, first, dtype, al, be)
+        a2, b2, d2 = ((new_vals[i],) + t[1:] for i, t in enumerate((a, b, d)))
+        TA.check_spgemm4(a2, b2, d2, second, dtype, al, be)
+        d_a3, d_b3 = G.csr_on_device(*a, len(a[0])), G.csr_on_device(*b, len(b[0]))
+        rp3 = torch.full((m + 1,), -1, dtype=torch.int32, device="cuda")
+        c3 = sp.csr_view(None, rp3, None, (m, n), 0)
+        st3 = sp.spgemm_state_t()
+        sp.multiply_compute(st3, d_a3, d_b3, c3)
+        cn3 = st3.result_nnz()
+        v3 = torch.full((cn3,), float("nan"), dtype=G.dev(a[0]).dtype, device="cuda")
+        k3 = torch.full((cn3,), -1, dtype=torch.int32, device="cuda")
+        c3.update(v3, rp3, k3, (m, n), cn3)
+        for rep, (va, vb) in enumerate([(a[0], b[0]), (new_vals[0], new_vals[1]), (a[0], b[0])]):
+            d_a3.values().copy_(G.dev(va))
+            d_b3.values().copy_(G.dev(vb))
+            v3.fill_(float("nan"))
+            k3.fill_(-1)
+            sp.multiply_fill(st3, d_a3, d_b3, c3)
+            TS.check_against_oracle((va,) + a[1:], (vb,) + b[1:], (cn3, G.host(rp3), G.host(k3), G.host(v3)), dtype)
+        os.environ.pop("SPBLAS_GFX950_SPGEMM_REUSE", None)
         e = rcsr(rng, m, n, kinds[0], dtype)
         TA.check_add(d, e, TA.device_add(d, e, None if al == 1.0 else al, None if be == 1.0 else be), dtype,
                      None if al == 1.0 else al, None if be == 1.0 else be)
