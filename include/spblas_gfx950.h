@@ -252,7 +252,13 @@ int spblas_gfx950_spgemm_symbolic(spblas_gfx950_handle_t handle, spblas_gfx950_s
  * STATUS_INSUFFICIENT_SPACE (csr_builder.hpp:18-22).  c_rowptr is rewritten from
  * the state's copy, so a different buffer than the one passed to symbolic is fine
  * (test/gtest/device/spgemm_reuse_test.cpp).  a_values/b_values may change between
- * calls; the pattern may not. */
+ * calls; the pattern may not.
+ * Memory held by the state: 8 bytes per entry of A from the symbolic pass on (the bounds of the B row
+ * every A entry selects); from the SECOND numeric pass on -- a one-shot fill pays nothing -- also one
+ * byte per product of the rows with at most 256 products, two per product of the rows with 257..1024,
+ * and 4 bytes per entry of C: later passes accumulate by recorded rank (SPBLAS_GFX950_SPGEMM_REUSE=0
+ * in the environment keeps every pass on the hash kernels).  All of it is optional: an allocation
+ * failure leaves the hash path in place. */
 int spblas_gfx950_spgemm_numeric(spblas_gfx950_handle_t handle, spblas_gfx950_spgemm_t state, const void* alpha,
                                  const int32_t* a_rowptr, const int32_t* a_colind, const void* a_values,
                                  const int32_t* b_rowptr, const int32_t* b_colind, const void* b_values,
