@@ -37,7 +37,7 @@ static __global__ __launch_bounds__(256) void scan_partials_kernel(int64_t nb, l
     sm[threadIdx.x] = v;
     __syncthreads();
     for (int o = 1; o < 256; o <<= 1) {
-      const long long t = threadIdx.x >= o ? sm[threadIdx.x - o] : 0;
+      const long long t = (int) threadIdx.x >= o ? sm[threadIdx.x - o] : 0;
       __syncthreads();
       sm[threadIdx.x] += t;
       __syncthreads();
@@ -73,7 +73,7 @@ static __global__ __launch_bounds__(256) void scan_apply_kernel(int64_t n, int32
   sm[threadIdx.x] = s;
   __syncthreads();
   for (int o = 1; o < 256; o <<= 1) {
-    const int t = threadIdx.x >= o ? sm[threadIdx.x - o] : 0;
+    const int t = (int) threadIdx.x >= o ? sm[threadIdx.x - o] : 0;
     __syncthreads();
     sm[threadIdx.x] += t;
     __syncthreads();
