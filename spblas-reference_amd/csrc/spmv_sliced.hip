@@ -1203,11 +1203,13 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
   }
   // x slice of the expand: 80 KiB for fp32 (two workgroups per CU); for fp64 the whole 160 KiB of a CU
   // (one workgroup), which halves the number of slices and doubles the run length
-  // fp32 switches to 160 KiB slices as well from n = 8 M on, provided a slice still carries enough entries to
-  // pay for its x load (row shards of a multi-GPU run have the columns of the whole matrix but a fraction of
-  // its entries: 2.5 M x 10 M rows ran 15 % slower)
+  // fp32 switches to 160 KiB slices as well from n = 8 M on.  (Until the slice count was aligned to the CU count --
+  // one expand workgroup per slice, x read once -- row shards of a multi-GPU run, which have the columns of the
+  // whole matrix but a fraction of its entries, were kept on 80 KiB slices; with the alignment the wide slices win
+  // at every shard size: 10 M columns x 2.5 M / 1.25 M / 0.625 M rows 111 -> 100, 77 -> 62, 60 -> 45 us,
+  // tools/shard_sweep.sh.)
   const int64_t s80 = cdiv(n, PB_LDS_BYTES / 4);
-  const bool wide32 = sizeof(T) == 4 && s80 >= 390 && nnz / s80 >= 75000;
+  const bool wide32 = sizeof(T) == 4 && s80 >= 390;
   const int xlds = env_int("SPBLAS_GFX950_PB_XLDS_KB", (sizeof(T) == 8 || wide32) ? 160 : PB_LDS_BYTES / 1024) * 1024;
   int max_cols = xlds / (int) sizeof(T);
   if (max_cols > 65536)
@@ -1677,7 +1679,9 @@ static int pick_ksplit(int64_t waves, int64_t steps_per_bin) {
   int K = env_int("SPBLAS_GFX950_PB_KSPLIT", 0);
   if (K <= 0) {
     K = 1;
-    while (waves * K < 1024 && K < 32 && steps_per_bin / (2 * K) >= 8)
+    // ~700 wavefronts fill the chip for this kernel; more parts only add partial sums to combine (row shards of
+    // cfg2, tools/shard_sweep.sh: 190 bins K = 4 / 8: 40.9 / 44.5 us, 248 bins: 69.0 / 77.0 us)
+    while (waves * K < 700 && K < 32 && steps_per_bin / (2 * K) >= 8)
       K *= 2;
   }
   return K < 1 ? 1 : K;
