@@ -1252,12 +1252,14 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
     }
   }
   // Bins: enough wavefronts to fill the chip (8 per CU = 2 048), but never so many that the average run drops
-  // below ~4 blocks (half a block of padding per run), and never taller than the LDS budget allows.  Too few
+  // below ~3 blocks (half a block of padding per run), and never taller than the LDS budget allows.  Too few
   // bins for the chip are made up for by the slice-free K split of the reduce (every bin's stream cut in K parts).
   {
     const int64_t nb_min = cdiv(m, max_rows);
     const int64_t nb_fill = env_int("SPBLAS_GFX950_PB_BINS", 2048);
-    const int64_t nb_run = nnz / ((int64_t) S * 128);
+    // (3 blocks per run: row shards of cfg2 2.5 M / 1.25 M rows 99.6 -> 93.2 / 61.3 -> 58.4 us against 4 blocks, 2 blocks
+    // no better, square matrices of 1-6 M rows unchanged; tools/shard_run_sweep.sh, tools/run_min_mid.sh)
+    const int64_t nb_run = nnz / ((int64_t) S * env_int("SPBLAS_GFX950_PB_RUN_MIN", 96));
     int64_t nb = std::max<int64_t>(nb_min, std::min<int64_t>(nb_fill, nb_run));
     if (nb < 1)
       nb = 1;
