@@ -1203,13 +1203,15 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
   }
   // x slice of the expand: 80 KiB for fp32 (two workgroups per CU); for fp64 the whole 160 KiB of a CU
   // (one workgroup), which halves the number of slices and doubles the run length
-  // fp32 switches to 160 KiB slices as well from n = 8 M on.  (Until the slice count was aligned to the CU count --
-  // one expand workgroup per slice, x read once -- row shards of a multi-GPU run, which have the columns of the
-  // whole matrix but a fraction of its entries, were kept on 80 KiB slices; with the alignment the wide slices win
-  // at every shard size: 10 M columns x 2.5 M / 1.25 M / 0.625 M rows 111 -> 100, 77 -> 62, 60 -> 45 us,
-  // tools/shard_sweep.sh.)
+  // fp32 switches to 160 KiB slices as well from n = 2 M on: half the slices, twice the run length (square
+  // matrices with 10 entries per row, tools/xlds_mid.sh: n = 3 M 109 -> 101 us, 6 M 203 -> 193, 7.9 M 285 -> 248;
+  // even at 1-2 M, 8 us slower at 0.5 M where 13 slices cannot feed the chip).  Row shards of a multi-GPU run -- the
+  // columns of the whole matrix but a fraction of its entries -- were kept on 80 KiB slices until the slice count
+  // was aligned to the CU count (one expand workgroup per slice, x read once); with the alignment the wide slices
+  // win at every shard size: 10 M columns x 2.5 M / 1.25 M / 0.625 M rows 111 -> 100, 77 -> 62, 60 -> 45 us
+  // (tools/shard_sweep.sh).
   const int64_t s80 = cdiv(n, PB_LDS_BYTES / 4);
-  const bool wide32 = sizeof(T) == 4 && s80 >= 390;
+  const bool wide32 = sizeof(T) == 4 && s80 >= 100;
   const int xlds = env_int("SPBLAS_GFX950_PB_XLDS_KB", (sizeof(T) == 8 || wide32) ? 160 : PB_LDS_BYTES / 1024) * 1024;
   int max_cols = xlds / (int) sizeof(T);
   if (max_cols > 65536)
