@@ -54,6 +54,21 @@ def parse():
     return p.parse_args()
 
 
+def launch_ranks(nproc):
+    """One rank per GPU under torch.distributed.run on a free loopback port; stdout/stderr pass straight through."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL and hipIpc across processes need it here
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def gen_rows(row_begin, row_end, n, per_row, poisson, dtype, device):
     """Rows [row_begin,row_end) of the global cfg matrix, generated chunk by chunk with
     seed = chunk index so that every world size sees the same matrix."""
@@ -90,6 +105,17 @@ def read_pmc_traffic(name):
         return None
 
 
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline_spmv(values, rowptr, colind, shape, x, nnz):
     """Reference CPU path restated (oracle, kind 'port'): 1 core, reference flags
     (-O3 -march=native, built on THIS host), best of 3 on the full workload."""
@@ -103,7 +129,7 @@ def cpu_baseline_spmv(values, rowptr, colind, shape, x, nnz):
     best = float("inf")
     for _ in range(3):
         t0 = time.perf_counter()
-        oracle.spmv(shape, rp, ci, v, xh, native=native)
+        y_ref = oracle.spmv(shape, rp, ci, v, xh, native=native)
         best = min(best, time.perf_counter() - t0)
     best_omp = float("inf")
     for _ in range(3):
@@ -111,11 +137,23 @@ def cpu_baseline_spmv(values, rowptr, colind, shape, x, nnz):
         oracle.spmv_omp(rp, ci, v, xh, native=native)
         best_omp = min(best_omp, time.perf_counter() - t0)
     ncpu = os.cpu_count()
-    return {"value": 2.0 * nnz / best / 1e9, "unit": "GFLOP/s", "cores": 1, "kind": "port",
+    absrow = oracle.spmv_absrow(rp, ci, v, xh)
+    return y_ref, absrow, {"value": 2.0 * nnz / best / 1e9, "unit": "GFLOP/s", "cores": 1, "kind": "port", "cpu_model": cpu_model(),
             "sample": f"full workload ({nnz} nnz), best of 3 runs of oracle_spmv (-O3 -march={'native' if native else 'x86-64-v3'})",
             "seconds": best,
             "all_cores": {"value": 2.0 * nnz / best_omp / 1e9, "cores": ncpu, "seconds": best_omp,
                           "note": "OpenMP static row-parallel variant of the same loop"}}
+
+
+def parity_spmv(y, y_ref, absrow, tol):
+    """Norm-wise parity of SURVEY.md section 8c (tests/util.py:assert_parity): |y - y_ref| <= tol * sum_p |a_p x_p| per row.
+    numpy arrays in, a small report out."""
+    err = np.abs(y.astype(np.float64) - y_ref.astype(np.float64))
+    bound = tol * absrow.astype(np.float64) + float(np.finfo(y.dtype).tiny)
+    bad = ~(err <= bound)  # NaN must fail
+    ratio = float((err / np.maximum(absrow.astype(np.float64), 1e-300)).max()) if err.size else 0.0
+    return {"status": "pass" if not bad.any() else "fail", "rows": int(err.size), "rows_out_of_bound": int(bad.sum()),
+            "tol": tol, "worst_err_over_rownorm": ratio}
 
 
 def measure(step, steps, warmup, multi, device):
@@ -199,13 +237,16 @@ def build_rmat(args, world, rank, device, sharded, sp):
 
 def main():
     args = parse()
+    exit_code = 0
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.debug_multi):
+        # Plain `python bench.py --gpus N`: start the N ranks ourselves as a CHILD torch.distributed.run -- this
+        # parent has not touched the GPU (no HIP call, no torch.cuda query so far) and never does; it relays the
+        # ranks' output (rank 0 prints the ONE JSON line) and exits with the child's code.
+        return launch_ranks(max(1, args.gpus))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
-                     "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
         args.gpus = world
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
@@ -345,6 +386,39 @@ def main():
         inspect_warm_ms = (time.perf_counter() - t1) * 1e3
         del info_w, y_tmp
 
+    # What was timed is also what is checked (outside the timed region): y of the timed operator for this x.
+    y_timed = op.step(x)
+    torch.cuda.synchronize()
+    if fused_op is not None and mode == "fused":
+        fused_op.check_status()
+    y_timed = y_timed.clone()
+    parity = None
+    tol = 1e-6 if tsize == 4 else 1e-12
+    if multi:
+        # N > 1: the gathered y of the timed path against PLAN-FREE local SpMVs (spmv_vector_kernel on the caller's own
+        # arrays: no re-tiled copy, no plan) gathered by the plain RCCL path.  Both sides re-associate the row sums, so
+        # the bound is 2 * tol * sum |a x| (the row norms come from the same plan-free kernel on |A|, |x|).
+        if rmat:
+            mk = lambda chunks_: sharded.ShardedSpMV(chunks_[0], bounds, inspect=False)
+        else:
+            mk = lambda chunks_: sharded.PipelinedShardedSpMV(chunks_, ranges, inspect=False)
+        if mode == "overlapped":
+            parity = {"status": "skipped", "why": "striped ownership: covered by tests/test_sharded_cpu.py"}
+        else:
+            y_ref = mk(a_chunks).step(x).clone()
+            abs_chunks = [sp.csr_view(a.values().abs(), a.rowptr(), a.colind(), a.shape(), a.size()) for a in a_chunks]
+            y_abs = mk(abs_chunks).step(x.abs()).clone()
+            torch.cuda.synchronize()
+            err = (y_timed.double() - y_ref.double()).abs()
+            bad = ~(err <= 2.0 * tol * y_abs.double() + float(np.finfo(np.float32 if tsize == 4 else np.float64).tiny))
+            stat = torch.stack([bad.sum().double(), (err / y_abs.double().clamp_min(1e-300)).max()])
+            dist.all_reduce(stat, op=dist.ReduceOp.MAX)
+            parity = {"status": "pass" if int(stat[0].item()) == 0 else "fail", "rows": int(y_timed.numel()),
+                      "rows_out_of_bound": int(stat[0].item()), "tol": 2.0 * tol,
+                      "worst_err_over_rownorm": float(stat[1].item()),
+                      "against": "plan-free local SpMV (spmv_vector_kernel) + RCCL all-gather, every row, every rank"}
+            del y_ref, y_abs, abs_chunks, err, bad
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         gflops = 2.0 * nnz / (elapsed / args.steps) / 1e9
@@ -382,16 +456,26 @@ def main():
             "multi_gpu": diag,
         }
         if world == 1 and chunks == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline_spmv(values, rowptr, colind, (m, n), x, nnz)
+            # the cpu_baseline leg computes the oracle's y for the same inputs; the timed plan's y is held to it
+            y_ref, absrow, out["cpu_baseline"] = cpu_baseline_spmv(values, rowptr, colind, (m, n), x, nnz)
+            if parity is None:
+                parity = parity_spmv(y_timed.cpu().numpy(), y_ref, absrow, tol)
+                parity["against"] = "oracle_spmv (CPU restatement of multiply_impl.hpp:33-53), every row"
         else:
             out["cpu_baseline"] = None
+        out["parity_check"] = parity["status"] if parity else "not run (--no-cpu-baseline)"
+        out["parity"] = parity
         print(json.dumps(out))
+        if parity and parity["status"] == "fail":
+            sys.stderr.write("[bench] PARITY CHECK FAILED: the timed operator's y is outside the parity bound\n")
+            exit_code = 3
     if multi:
         if fused_op is not None:
             fused_op.check_status()
             fused_op.close()
         dist.destroy_process_group()
+    return exit_code
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -242,9 +242,17 @@ class _Handle:
         return hd
 
 
-# In-place changes to a value array made through this module's own scale() (a raw kernel, invisible to
-# torch's version counter) are recorded here: data_ptr -> number of such changes.
+# In-place changes to an array made through this module's own raw kernels (invisible to torch's version
+# counter) are recorded here: data_ptr -> number of such writes.  Every API entry that writes a value or column
+# array through the C ABI -- scale(), multiply_fill / multiply_numeric, add, transpose -- bumps the epoch, so a
+# SLICED plan's value snapshot and the "colind provably untouched" test of repeated SpGEMM fills see them.
 _value_epochs = {}
+
+
+def _note_write(*tensors):
+    for t in tensors:
+        if t is not None:
+            _value_epochs[t.data_ptr()] = _value_epochs.get(t.data_ptr(), 0) + 1
 
 
 def _values_stamp(values):
@@ -528,6 +536,7 @@ def transpose(*args):
                                                   _ptr(a.colind()), _ptr(a.values()), _ptr(b.rowptr()),
                                                   _ptr(b.colind()), _ptr(b.values()),
                                                   _vtype(a.values(), "transpose")[0]), "transpose")
+    _note_write(b.values(), b.colind())
     b.update(b.values(), b.rowptr(), b.colind(), b.shape(), nnz)  # transpose_impl.hpp:54
 
 
@@ -545,7 +554,7 @@ def scale(alpha, t):
     hd = _Handle.current(vals.device)
     check(_capi.lib().spblas_gfx950_scale(hd.h, nvals, ctypes.byref(a), _ptr(vals), vt), "scale")
     if not _is_tensor(base):  # plans holding a copy of these values see the change (_Plan.refresh_if_stale)
-        _value_epochs[vals.data_ptr()] = _value_epochs.get(vals.data_ptr(), 0) + 1
+        _note_write(vals)
 
 
 def _find_plan(info, a, a_base):
@@ -843,13 +852,17 @@ def _numeric(state, a, b, c_user, d=None):
             _ptr(b_base.rowptr()), _ptr(b_base.colind()), _ptr(b_base.values()), ctypes.byref(beta),
             _ptr(d_base.rowptr()), _ptr(d_base.colind()), _ptr(d_base.values()), _ptr(c.rowptr()),
             _ptr(c.colind()), _ptr(c.values()), cap, vt), "multiply_fill")
+        _note_write(c.values(), c.colind())
     else:
         # Repeated fills of ONE result may leave its column indices alone (OPT_SPGEMM_KEEP_COLIND) -- but only when
         # this is provably the array the previous fill wrote and nobody touched it since: the same tensor object
         # (which this state keeps alive, so its address cannot have been recycled) with an unchanged version counter.
+        # Writes made through this library's own kernels (another state filling the same arrays, add, transpose)
+        # do not move torch's counter; the module-level write epoch of the address covers those.
         ci = c.colind()
         last = getattr(state, "_last_colind", None)
-        keep = last is not None and last[0] is ci and last[1] == ci._version and last[2] == ci.data_ptr()
+        keep = last is not None and last[0] is ci and last[1] == ci._version and last[2] == ci.data_ptr() and \
+            last[3] == _value_epochs.get(ci.data_ptr(), 0)
         if keep:
             hd.set_option(_capi.OPT_SPGEMM_KEEP_COLIND, 1)
         try:
@@ -861,7 +874,10 @@ def _numeric(state, a, b, c_user, d=None):
         finally:
             if keep:
                 hd.set_option(_capi.OPT_SPGEMM_KEEP_COLIND, 0)
-        state._last_colind = (ci, ci._version, ci.data_ptr())
+        _note_write(c.values())
+        if not keep:
+            _note_write(ci)
+        state._last_colind = (ci, ci._version, ci.data_ptr(), _value_epochs.get(ci.data_ptr(), 0))
     if isinstance(c_user, csr_view):
         c_user.update(c.values(), c.rowptr(), c.colind(), state._result_shape, nnz)  # spgemm_gustavsons.hpp:50-51
     else:
@@ -966,6 +982,7 @@ def _add_numeric(state, a, b, c):
                                                     _ptr(b_base.rowptr()), _ptr(b_base.colind()),
                                                     _ptr(b_base.values()), _ptr(c.rowptr()), _ptr(c.colind()),
                                                     _ptr(c.values()), cap, vt), "add")
+    _note_write(c.values(), c.colind())
     c.update(c.values(), c.rowptr(), c.colind(), state._result_shape, nnz)  # add_impl.hpp:75-76
 
 

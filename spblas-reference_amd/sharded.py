@@ -493,7 +493,8 @@ def try_fused(a_local, bounds, x, reference_step, alg=None, group=None, log=None
     """Collective.  Returns a FusedShardedSpMV if EVERY rank could set it up and its full y agrees with
     `reference_step(x_k)` (the RCCL all-gather path) on every rank for FOUR different vectors x_k; otherwise
     None, with everything the attempt allocated released again.  Never raises: any failure means "keep the
-    reference path".
+    reference path".  The collective sequence is identical on every rank (constructor agreements, the reference
+    steps, one final all-reduce), whichever rank fails where.
 
     The vectors differ from step to step (x, 2x, x + 1, 0.5x - 1) so that a stale or missing peer store cannot
     hide: y of step k lives in buffer k & 1, so both copies are written twice with different contents and a
@@ -513,17 +514,26 @@ def try_fused(a_local, bounds, x, reference_step, alg=None, group=None, log=None
         fused = FusedShardedSpMV(a_local, bounds, group=group, alg=alg, info=info, timeout_ms=3000, stripes=stripes)
         takes_x = len(_inspect.signature(reference_step).parameters) >= 1
         xs = [x, 2.0 * x, x + 1.0, 0.5 * x - 1.0] if takes_x else [x, x, x]
+        # Every rank issues the SAME collective sequence whatever happens locally: all reference steps (RCCL
+        # all-gathers) first, then the fused steps, which contain no collective -- a rank whose barrier times out
+        # (the missing-peer-store case this validation exists to catch) must not skip an all-gather its peers are
+        # still inside.  Local failures only clear `same`; the outcome is agreed in the all-reduce below.
+        y_refs = [(reference_step(x_k) if takes_x else reference_step()).clone() for x_k in xs]
         same = 1
-        for x_k in xs:
-            y_ref = (reference_step(x_k) if takes_x else reference_step()).clone()
-            y_fused = fused.step(x_k)
-            torch.cuda.synchronize()
-            fused.check_status()
-            if info is not None:
-                ok = torch.equal(y_ref, y_fused)
-            else:
-                tol = 1e-4 if y_ref.dtype == torch.float32 else 1e-10
-                ok = torch.allclose(y_fused, y_ref, rtol=tol, atol=tol * float(y_ref.abs().max()))
+        for x_k, y_ref in zip(xs, y_refs):
+            try:
+                y_fused = fused.step(x_k)
+                torch.cuda.synchronize()
+                fused.check_status()
+                if info is not None:
+                    ok = torch.equal(y_ref, y_fused)
+                else:
+                    tol = 1e-4 if y_ref.dtype == torch.float32 else 1e-10
+                    ok = torch.allclose(y_fused, y_ref, rtol=tol, atol=tol * float(y_ref.abs().max()))
+            except Exception as e:  # noqa: BLE001 - keep stepping so the peers' barriers are not left short
+                ok = False
+                if log:
+                    log(f"fused step failed: {e}")
             same &= int(ok)
         fused._timeout = 20000
         if not same and log:

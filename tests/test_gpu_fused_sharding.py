@@ -73,3 +73,35 @@ def test_bench_cfg4_rmat_multi_gpu_code_path_with_one_rank(gpu):
     out = json.loads(lines[0])
     assert out["value"] > 0 and out["dtype"] == "f64" and out["config"]["nnz"] == 16 << 18
     assert "R-MAT scale 18" in out["config"]["workload"] and out["multi_gpu"]["rccl_step_ms"] > 0
+
+
+@pytest.mark.parametrize("workload", ["spmv", "spmv_rmat"])
+def test_bench_launches_its_own_ranks_and_checks_what_it_timed(gpu, workload):
+    """`python3 bench.py --gpus N` WITHOUT an outer torch.distributed.run (the shape of the driver's N = 1 command):
+    the parent starts the ranks as a child process before touching the GPU, relays rank 0's one JSON line and the
+    exit code; the line carries `multi_gpu` and a `parity_check` of the timed operator's y (round-2 VERDICT item 1)."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--debug-multi", "--steps", "5", "--warmup", "2",
+           "--no-cpu-baseline", "--workload", workload, "--rows", "2000000" if workload == "spmv" else str(1 << 18)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.stdout[-2000:], r.stderr[-2000:])
+    out = json.loads(lines[0])
+    assert out["multi_gpu"]["rccl_step_ms"] > 0
+    assert out["parity_check"] == "pass" and out["parity"]["rows_out_of_bound"] == 0, out["parity"]
+    assert out["parity"]["rows"] == out["config"]["rows"]
+
+
+def test_bench_single_gpu_line_is_self_checking(gpu):
+    """N = 1 (a reduced cfg2 so the test stays short): the y of the timed plan is compared with the oracle's y that the
+    cpu_baseline leg computes anyway -- the published number and the checked number come from one process."""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--rows", "1000000", "--steps", "5", "--warmup", "2"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.stdout[-2000:], r.stderr[-2000:])
+    out = json.loads(lines[0])
+    assert out["parity_check"] == "pass" and out["parity"]["rows"] == 1000000
+    assert out["cpu_baseline"]["cores"] == 1 and out["cpu_baseline"]["cpu_model"]
+    assert out["multi_gpu"] is None

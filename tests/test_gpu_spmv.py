@@ -254,6 +254,62 @@ def test_spmv_values_changed_in_place(gpu):
                   ref_cmp=False)
 
 
+def test_spmv_snapshot_sees_values_rewritten_by_the_librarys_own_kernels(gpu):
+    """the sliced plan's value snapshot must also notice writes made through this library's own raw
+    kernels -- multiply_fill refilling C's values (an AMG re-setup: inspect matrix_opt(C) once, refill C before every
+    multiply), add() and transpose() writing into an inspected matrix's arrays -- none of which moves torch's version
+    counter.  Reference behaviour: the values are read on every multiply (multiply_impl.hpp:48-52)."""
+    from oracle import oracle
+    rng = np.random.default_rng(11)
+    m = k = 300000
+    per = 3
+    def rand_csr(seed_vals):
+        rp = (np.arange(m + 1, dtype=np.int64) * per).astype(np.int32)
+        ci = rng.integers(0, k, m * per).astype(np.int32)
+        return rp, ci, (rng.random(m * per) + 0.5).astype(np.float32)
+    arp, aci, av = rand_csr(0)
+    brp, bci, bv = rand_csr(1)
+    a = G.csr_on_device(av, arp, aci, (m, k), m * per)
+    b = G.csr_on_device(bv, brp, bci, (k, k), k * per)
+    c_rp = torch.zeros(m + 1, dtype=torch.int32, device="cuda")
+    c = sp.csr_view(None, c_rp, None, (m, k), 0)
+    info_c = sp.multiply_compute(a, b, c)
+    cn = info_c.result_nnz()
+    c.update(torch.zeros(cn, device="cuda"), c_rp, torch.zeros(cn, dtype=torch.int32, device="cuda"), (m, k), cn)
+    sp.multiply_fill(info_c, a, b, c)
+    x = (rng.random(k) + 0.5).astype(np.float32)
+    xd = G.dev(x)
+    y = torch.full((m,), float("nan"), device="cuda")
+    info = sp.multiply_inspect(sp.matrix_opt(c), xd, y, alg=_capi.SPMV_SLICED)
+    assert info.state_.info()["alg"] == _capi.SPMV_SLICED
+    sp.multiply(info, sp.matrix_opt(c), xd, y)
+    crp, cci = G.host(c.rowptr()), G.host(c.colind())
+    check(G.host(c.values()), crp, cci, (m, k), x, G.host(y), what="C as inspected", ref_cmp=False)
+    # refill C in place with new A values (same structure, same arrays, torch's counter does not move)
+    a.values().mul_(3.0)
+    ver = c.values()._version
+    sp.multiply_fill(info_c, a, b, c)
+    assert c.values()._version == ver  # the write is invisible to torch: only the module's write epoch sees it
+    sp.multiply(info, sp.matrix_opt(c), xd, y)
+    check(G.host(c.values()), crp, cci, (m, k), x, G.host(y), what="C refilled by multiply_fill", ref_cmp=False)
+    y1 = G.host(y).copy()
+    # transpose() writing into an inspected matrix's value array
+    t_src = G.csr_on_device(*[arr for arr in (av * np.float32(0.5), arp, aci)], (m, k), m * per)
+    t = sp.csr_view(torch.zeros(m * per, device="cuda"), torch.zeros(k + 1, dtype=torch.int32, device="cuda"),
+                    torch.zeros(m * per, dtype=torch.int32, device="cuda"), (k, m), m * per)
+    sp.transpose(t_src, t)
+    yt = torch.full((k,), float("nan"), device="cuda")
+    xm = G.dev((rng.random(m) + 0.5).astype(np.float32))
+    info_t = sp.multiply_inspect(sp.matrix_opt(t), xm, yt, alg=_capi.SPMV_SLICED)
+    sp.multiply(info_t, sp.matrix_opt(t), xm, yt)
+    t_src.values().mul_(4.0)
+    sp.transpose(t_src, t)       # same structure, new values, same output arrays
+    sp.multiply(info_t, sp.matrix_opt(t), xm, yt)
+    check(G.host(t.values()), G.host(t.rowptr()), G.host(t.colind()), (k, m), G.host(xm), G.host(yt),
+          what="matrix rewritten by transpose()", ref_cmp=False)
+    assert not np.array_equal(y1, np.zeros_like(y1))
+
+
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_spmv_sliced_compacts_empty_rows(gpu, monkeypatch, dtype):
     """Graph-like matrix: 70 % of the rows empty (in stretches, at both ends and scattered), a few hub rows, hot
