@@ -96,13 +96,22 @@ def spmv_bytes(m, n, nnz, tsize):
 
 
 def read_pmc_traffic(name):
-    """HBM bytes per launch from the committed PMC profile (profiles/pmc_traffic.json), or None."""
+    """(HBM bytes per launch, provenance) from the committed PMC profile (profiles/pmc_traffic.json), or (None, None).
+    The provenance names the profile and the hash of csrc/spmv_sliced.hip it was measured on, and says whether the
+    kernels have changed since (a stale constant must be visible in the JSON line)."""
+    import hashlib
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as f:
-            return json.load(f).get(name)
+            d = json.load(f)
+        stamp = dict((d.get("_stamp") or {}).get(name) or {})
+        with open(os.path.join(ROOT, "spblas-reference_amd", "csrc", "spmv_sliced.hip"), "rb") as f:
+            now = hashlib.sha256(f.read()).hexdigest()[:16]
+        stamp["spmv_sliced_hip_sha256_16_now"] = now
+        stamp["stale"] = stamp.get("spmv_sliced_hip_sha256_16") != now
+        return d.get(name), stamp
     except Exception:
-        return None
+        return None, None
 
 
 def cpu_model():
@@ -248,6 +257,11 @@ def main():
         return launch_ranks(max(1, args.gpus))
     if args.gpus != world:
         args.gpus = world
+    # stdout carries exactly ONE line (the JSON, rank 0): libraries that print banners to fd 1 (RCCL announces its
+    # version there when the first communicator is created) are sent to stderr for the duration of the run
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     multi = world > 1 or args.debug_multi
@@ -261,6 +275,8 @@ def main():
 
     if args.workload in ("spmm", "spmm_banded", "spgemm", "add", "transpose", "sptrsv"):
         from bench_extra import run_extra  # secondary configs (cfg3 / cfg5 / 8f rows), 1 GPU
+        sys.stdout.flush()
+        os.dup2(json_fd, 1)  # single-GPU secondary workloads print their own line
         return run_extra(args, device)
 
     rmat = args.workload == "spmv_rmat"
@@ -425,7 +441,9 @@ def main():
         local_bytes = spmv_bytes(rows_local, n, nnz_local, tsize)
         achieved = local_bytes / (kern_avg_ms * 1e-3) / 1e9
         alg_id = plan_info.get("alg")
-        kernels = {3: f"pb_expand_kernel<{'float' if tsize == 4 else 'double'}> + pb_reduce_kernel<{'float' if tsize == 4 else 'double'},4,4> "
+        traffic, traffic_src = read_pmc_traffic(prob["pmc_key"]) if (prob["pmc_key"] and alg_id == 3) else (None, None)
+        u8 = plan_info.get("sliced", {}).get("row_code_u8")
+        kernels = {3: f"pb_expand_kernel<{'float' if tsize == 4 else 'double'}> + pb_reduce_kernel<{'float' if tsize == 4 else 'double'},4,{'2,true' if u8 else '4,false'}> "
                       "(one SpMV = this launch pair)",
                    2: f"spmv_rowblock_kernel<{'float,int,2048' if tsize == 4 else 'double,int,1024'}> (+ spmv_long_fixup_kernel)",
                    1: "spmv_vector_kernel<T,int,LPR>"}
@@ -447,7 +465,7 @@ def main():
                          # fraction of the rate a streaming copy reaches on this part (6.29 TB/s, MI355X_MICROARCH.md)
                          "frac_of_achievable": achieved / 6290.0,
                          # PMC traffic was measured for the default cfg2 / 1 GPU / sliced plan only
-                         "traffic": read_pmc_traffic(prob["pmc_key"]) if (prob["pmc_key"] and alg_id == 3) else None,
+                         "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": kernels.get(alg_id, kernels[1]),
                          "algorithmic_bytes_per_launch": local_bytes, "kernel_avg_ms": kern_avg_ms,
                          "step_events_pass": {"note": "separate untimed pass with one event pair per step", "min_ms": kern_ms[0],
@@ -465,7 +483,8 @@ def main():
             out["cpu_baseline"] = None
         out["parity_check"] = parity["status"] if parity else "not run (--no-cpu-baseline)"
         out["parity"] = parity
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
         if parity and parity["status"] == "fail":
             sys.stderr.write("[bench] PARITY CHECK FAILED: the timed operator's y is outside the parity bound\n")
             exit_code = 3

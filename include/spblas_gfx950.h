@@ -160,7 +160,8 @@ int spblas_gfx950_plan_info(spblas_gfx950_plan_t plan, int64_t info[12]);
  * matrix: a new bin every [8] rows and every ~nnz/2048 entries), [2]=blocks of 32 entries in expand order,
  * [3]=blocks in reduce order (bins padded to groups of 8 blocks), [4]=entries placed in tiles, [5]=#rows kept out of
  * the tiles (hub rows), [6]=hub threshold (row length), [7]=reduce K split, [8]=rows the tiles are built over (fewer
- * than m when the empty rows were taken out).  For ANY plan: [9]=1 if AUTO decided by a timed trial, [10]/[11]=time
+ * than m when the empty rows were taken out).  For ANY plan: [9] bit 0 = AUTO decided by a timed trial, bit 1 = the
+ * reduce streams one-byte row codes (runs sorted by row) instead of 16-bit rows, [10]/[11]=time
  * of the row-block / the sliced plan in that trial, nanoseconds. */
 int spblas_gfx950_plan_info_sliced(spblas_gfx950_plan_t plan, int64_t info[12]);
 

@@ -116,7 +116,8 @@ class BackendError(RuntimeError):
 
 
 def library_path():
-    return _build.LIBPATH
+    # SPBLAS_GFX950_LIB: another build of the same library (tools/build_variant.sh: same-box A/B measurements only)
+    return os.environ.get("SPBLAS_GFX950_LIB") or _build.LIBPATH
 
 
 def lib():

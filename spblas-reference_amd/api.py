@@ -294,7 +294,10 @@ class _Plan:
         check(_capi.lib().spblas_gfx950_plan_info_sliced(self.plan, arr), "spblas_gfx950_plan_info_sliced")
         names = ["n_bins", "variable_bins", "expand_blocks", "reduce_blocks", "placed_entries", "hub_rows", "hub_len",
                  "ksplit", "tiled_rows", "auto_trial", "trial_rowblock_ns", "trial_sliced_ns"]
-        return dict(zip(names, list(arr)))
+        d = dict(zip(names, list(arr)))
+        d["row_code_u8"] = (d["auto_trial"] >> 1) & 1  # one-byte row codes in the reduce's stream (runs sorted by row)
+        d["auto_trial"] &= 1
+        return d
 
     # two-stage execution of a SLICED plan (include/spblas_gfx950.h: spmv_expand / spmv_reduce_rows)
     def bind_stages(self, x, y_base_ptr, dtype, alpha=1.0, beta=0.0):

@@ -44,6 +44,14 @@ struct spblas_gfx950_plan_s {
   void* s_values = nullptr;    // T[a_blocks*32] (A' order; pads 0)
   void* s_perm = nullptr;      // int32[a_blocks*32] source position in the caller's CSR arrays (pads -1)
   uint16_t* s_lrow = nullptr;  // uint16[p_blocks*32] row inside the bin | bit 15 = duplicate flag (P order; pads = H)
+  // one-byte row codes instead of s_lrow (spmv_sliced.hip, "enc8"): runs sorted by row, the row advance per entry
+  int enc8 = 0;
+  unsigned char* s_code = nullptr;  // uint8[p_blocks*BLK]: advance since the previous entry of the block; 255 = left out
+  void* s_hdr = nullptr;            // per P block: base row + duplicate flags (8 B per 32 fp32 / 4 B per 16 fp64 entries)
+  unsigned* s_exc_idx = nullptr;    // [NB * exc_cap] P index of the entries the codes cannot reach ...
+  uint16_t* s_exc_row = nullptr;    // [NB * exc_cap] ... and their row inside the bin
+  int32_t* s_exc_cnt = nullptr;     // [NB] exceptions per wave-bin; [NB] = "encoding failed" flag of the build
+  int exc_cap = 0;
   void* s_products = nullptr;  // T[p_blocks*32] workspace: expanded products (P order)
   int64_t a_blocks = 0, p_blocks = 0;
   int n_ksplit = 1;            // reduce workgroups per bin group (every wave-bin's stream cut into K parts)

@@ -813,7 +813,7 @@ int spblas_gfx950_plan_info_sliced(spblas_gfx950_plan_t plan, int64_t info[12]) 
   info[6] = sl ? plan->hub_len : 0;
   info[7] = sl ? plan->n_ksplit : 0;
   info[8] = sl ? plan->s_m : 0;
-  info[9] = plan->trial_ms[0] > 0.f ? 1 : 0;
+  info[9] = (plan->trial_ms[0] > 0.f ? 1 : 0) | (sl && plan->enc8 ? 2 : 0);  // bit 0: AUTO ran its trial, bit 1: one-byte row codes
   info[10] = (int64_t) (plan->trial_ms[0] * 1e6f);
   info[11] = (int64_t) (plan->trial_ms[1] * 1e6f);
   return SPBLAS_GFX950_STATUS_SUCCESS;

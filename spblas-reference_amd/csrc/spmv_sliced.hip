@@ -71,6 +71,74 @@ struct pb_geom {
 static inline int pb_blk_of(int value_type) { return value_type == SPBLAS_GFX950_F32 ? 32 : 16; }
 static constexpr int PB_GRP = 256;              // entries per reduce step: 64 lanes x 4
 
+// ---- one-byte row codes (round 3) -----------------------------------------------------------------------------
+// The reduce streams 4 B of product + 2 B of row word per padded entry; with the runs sorted by row the row word
+// shrinks to ONE byte (tools/build_variant.sh u8rows, cfg2: reduce 140.6 -> 118.1 us).  Encoding ("enc8"), P order:
+//   s_code[e]   u8 per entry: the row advance since the previous entry of the same BLOCK (0..254), or 255 =
+//               "advance 255 rows and leave this entry out of the main pass" (a pad, or an EXCEPTION: an entry whose
+//               row lies >= 255 rows beyond the decoder's position -- 3e-5 of the entries at cfg2's tile density)
+//   s_hdr[blk]  per block: row of the block's first entry (u16) + one duplicate flag per entry (the bit the u16
+//               encoding keeps in bit 15 of the row word); 8 B per 32 fp32 entries, 4 B per 16 fp64 entries
+//   exceptions  per wave-bin, at most exc_cap of them: (P index, row); the reduce adds them with the LDS float atomic
+//               after its main pass.  A bin with more exceptions, or a run too long to sort in registers, sets
+//               enc_fail and the plan is rebuilt with the 16-bit rows.
+// The decoder's row D of entry j of a block is base + code_1 + ... + code_j: D_j = min(r_j, D_{j-1} + 255), i.e.
+// D_j = 255 j + min_{k <= j} (r_k - 255 k) -- a prefix minimum at inspect, a prefix sum in the reduce.
+// Bytes per padded entry in the reduce: 4 + 1 + 0.25 = 5.25 (was 6); nothing changes for the expand.
+template <typename T>
+struct pb_hdr;
+template <>
+struct pb_hdr<float> {
+  typedef unsigned long long type;  // bits 0..31 duplicate flags, 32..47 base row
+  static __host__ __device__ __forceinline__ type make(unsigned base, unsigned flags) {
+    return ((type) base << 32) | flags;
+  }
+  static __device__ __forceinline__ unsigned base(type h) { return (unsigned) (h >> 32) & 0xffffu; }
+  static __device__ __forceinline__ unsigned flags(type h) { return (unsigned) h; }
+};
+template <>
+struct pb_hdr<double> {
+  typedef unsigned type;  // bits 0..15 duplicate flags, 16..31 base row
+  static __host__ __device__ __forceinline__ type make(unsigned base, unsigned flags) { return (base << 16) | flags; }
+  static __device__ __forceinline__ unsigned base(type h) { return h >> 16; }
+  static __device__ __forceinline__ unsigned flags(type h) { return h & 0xffffu; }
+};
+static constexpr int PB_SORT_MAX = 512;  // longest run the inspect sorts in registers (8 entries per lane)
+static constexpr int PB_EXC_CAP = 128;   // exceptions a wave-bin may hold
+
+// value of lane - o (o = 1, 2, 4) inside the 16-lane DPP row; lanes without a source get 0
+template <int O>
+__device__ __forceinline__ unsigned pb_row_shr(unsigned v) {
+  return (unsigned) __builtin_amdgcn_update_dpp(0, (int) v, 0x110 + O, 0xf, 0xf, true);
+}
+// rows of a lane's 4 consecutive entries from their packed codes: row[j] = base + (codes of the block's earlier
+// lanes) + c0 + ... + cj, clamped to Hw (tail pads may run past the bin); LPB = lanes per block (8 fp32 / 4 fp64)
+template <int LPB>
+__device__ __forceinline__ void pb_decode_rows(unsigned cw, unsigned base, int lane, unsigned Hw, unsigned (&row)[4],
+                                               bool (&skip)[4]) {
+  const unsigned c0 = cw & 0xffu, c1 = (cw >> 8) & 0xffu, c2 = (cw >> 16) & 0xffu, c3 = cw >> 24;
+  const unsigned s1 = c0 + c1, s2 = s1 + c2, s3 = s2 + c3;
+  const unsigned li = (unsigned) lane & (LPB - 1);
+  unsigned t = s3, u;
+  u = pb_row_shr<1>(t);
+  t += li >= 1 ? u : 0u;
+  u = pb_row_shr<2>(t);
+  t += li >= 2 ? u : 0u;
+  if (LPB > 4) {
+    u = pb_row_shr<4>(t);
+    t += li >= 4 ? u : 0u;
+  }
+  const unsigned b = base + t - s3;
+  row[0] = min(b + c0, Hw);
+  row[1] = min(b + s1, Hw);
+  row[2] = min(b + s2, Hw);
+  row[3] = min(b + s3, Hw);
+  skip[0] = c0 == 255u;
+  skip[1] = c1 == 255u;
+  skip[2] = c2 == 255u;
+  skip[3] = c3 == 255u;
+}
+
 
 // ---- inspect --------------------------------------------------------------------------
 // One workgroup per wave-bin: all entries of the bin's rows share wb, so the per-slice counts
@@ -383,14 +451,98 @@ static constexpr int PB_STAGE_THREADS = 1024;
 static constexpr int PB_STAGE_LDS = 160 * 1024;
 static constexpr int PB_STAGE_MAX_S = 2048;
 
-template <typename T, typename O>
+// enc8 write-out of one staged run by one wavefront: sort the run by source position (= by row: positions grow with the
+// row), then emit values / columns / source positions in that order and the one-byte row codes, block bases and
+// exceptions.  R = entries a lane holds while ranking (the run has at most 64 R entries).
+template <typename T, int R, typename RowOf>
+__device__ __forceinline__ void pb_emit_sorted_run(int n, int lo, int g, int gp, int p0, int lane, int* __restrict__ st,
+                                                   T* __restrict__ stv, uint16_t* __restrict__ stc, RowOf row_of,
+                                                   T* __restrict__ s_val, uint16_t* __restrict__ s_col,
+                                                   int32_t* __restrict__ perm, unsigned char* __restrict__ s_code,
+                                                   typename pb_hdr<T>::type* __restrict__ s_hdr, int* exc_n, int exc_cap,
+                                                   unsigned* __restrict__ exc_idx, uint16_t* __restrict__ exc_row) {
+  constexpr int PB_BLK = pb_geom<T>::BLK;
+  int q[R], rank[R];
+  T v[R];
+  uint16_t c[R];
+#pragma unroll
+  for (int t = 0; t < R; ++t) {
+    const int i = lane + 64 * t;
+    const bool in = i < n;
+    q[t] = in ? st[lo + i] : 0x7fffffff;
+    v[t] = in ? stv[lo + i] : T(0);
+    c[t] = in ? stc[lo + i] : (uint16_t) 0;
+    rank[t] = 0;
+  }
+  // rank = entries of the run with a smaller source position (positions are unique): broadcast reads of the run
+  for (int k = 0; k < n; k += 4) {
+    int qk[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      qk[j] = k + j < n ? st[lo + k + j] : 0x7fffffff;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int t = 0; t < R; ++t)
+        rank[t] += qk[j] < q[t] ? 1 : 0;
+  }
+  // in place: every lane has read all it needs (LDS operations of one wavefront complete in order)
+#pragma unroll
+  for (int t = 0; t < R; ++t)
+    if (lane + 64 * t < n) {
+      st[lo + rank[t]] = q[t];
+      stv[lo + rank[t]] = v[t];
+      stc[lo + rank[t]] = c[t];
+    }
+  const int nb = (n + PB_BLK - 1) / PB_BLK;
+  for (int j0 = 0; j0 < nb * PB_BLK; j0 += 64) {
+    const int j = j0 + lane;
+    const bool valid = j < n;
+    const int qq = valid ? st[lo + j] : 0;
+    const int r = valid ? row_of(qq) : 0;
+    const int bi = lane & (PB_BLK - 1);  // j0 is a multiple of 64, 64 a multiple of the block
+    // D_j = 255 bi + min over the block's entries k <= j of (r_k - 255 k): the decoder's position after entry j
+    int M = valid ? r - 255 * bi : 0x3fffffff;
+#pragma unroll
+    for (int o = 1; o < PB_BLK; o <<= 1) {
+      const int u = __shfl_up(M, o, 64);
+      if (bi >= o)
+        M = u < M ? u : M;
+    }
+    const int D = M + 255 * bi;
+    const int Dp = __shfl_up(D, 1, 64);
+    const bool exc = valid && bi > 0 && r - Dp >= 255;
+    if (valid) {
+      s_val[g + j] = stv[lo + j];
+      s_col[g + j] = stc[lo + j];
+      perm[g + j] = (int32_t) (p0 + qq);
+      s_code[gp + j] = (unsigned char) (bi == 0 ? 0 : (exc ? 255 : r - Dp));
+      if (bi == 0)
+        s_hdr[(gp + j) / PB_BLK] = pb_hdr<T>::make((unsigned) r, 0u);
+    }
+    if (exc) {
+      const int k = atomicAdd(exc_n, 1);
+      if (k < exc_cap) {
+        exc_idx[k] = (unsigned) (gp + j);
+        exc_row[k] = (uint16_t) r;
+      }
+    }
+  }
+}
+
+template <typename T, typename O, bool ENC8>
 __global__ __launch_bounds__(PB_STAGE_THREADS) void pb_scatter_staged_kernel(
     int64_t m, const O* __restrict__ rowptr, const int32_t* __restrict__ colind, const T* __restrict__ values, int W,
     int H, int S, int NB, const int32_t* __restrict__ cnt, const int32_t* __restrict__ aoff,
     const int32_t* __restrict__ prel, const int32_t* __restrict__ binblk, T* __restrict__ s_val,
     uint16_t* __restrict__ s_col, uint16_t* __restrict__ s_row, int32_t* __restrict__ perm,
-    int32_t* __restrict__ blkdst, int hub_len, int cap, int rt_len, const int32_t* __restrict__ binrow) {
+    int32_t* __restrict__ blkdst, int hub_len, int cap, int rt_len, const int32_t* __restrict__ binrow,
+    unsigned char* __restrict__ s_code, typename pb_hdr<T>::type* __restrict__ s_hdr, unsigned* __restrict__ exc_idx,
+    uint16_t* __restrict__ exc_row, int32_t* __restrict__ exc_cnt, int exc_cap, int32_t* __restrict__ enc_fail) {
   constexpr int PB_BLK = pb_geom<T>::BLK;
+  __shared__ int exc_n;
+  if (ENC8 && threadIdx.x == 0)
+    exc_n = 0;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   int* lcnt = reinterpret_cast<int*>(smem);  // [S] entries of this bin per slice
   int* gdst = lcnt + S;                      // [S] first A' position of the run
@@ -520,6 +672,8 @@ __global__ __launch_bounds__(PB_STAGE_THREADS) void pb_scatter_staged_kernel(
       }
       const int pos = atomicAdd(&lcur[sl], 1);
       if (direct) {
+        if (ENC8)
+          continue;  // a run larger than the staging area cannot be sorted here: the plan falls back (flag below)
         const int i = gdst[sl] + pos;
         s_val[i] = values[p0 + q];
         s_col[i] = (uint16_t) (c - sl * W);
@@ -533,6 +687,8 @@ __global__ __launch_bounds__(PB_STAGE_THREADS) void pb_scatter_staged_kernel(
       }
     }
     __syncthreads();
+    if (ENC8 && direct && tid == 0)
+      atomicExch(enc_fail, 1);
     if (!direct) {
       // every wave writes whole runs from the staging area (contiguous stores, no global gathers: fetching
       // value and column again by position cost 2.4 of the kernel's 2.75 ms -- random 4-byte reads, even
@@ -540,6 +696,24 @@ __global__ __launch_bounds__(PB_STAGE_THREADS) void pb_scatter_staged_kernel(
       constexpr int NW = PB_STAGE_THREADS / 64;
       for (int sl = s0 + wave; sl < s1; sl += NW) {
         const int n = lcnt[sl], lo = lcur[sl] - n, g = gdst[sl], gp = pdst[sl];
+        if (ENC8) {
+          unsigned* ei = exc_idx + (size_t) wb * exc_cap;
+          uint16_t* er = exc_row + (size_t) wb * exc_cap;
+          if (n > PB_SORT_MAX) {
+            if (lane == 0)
+              atomicExch(enc_fail, 1);
+          } else if (n > 256) {
+            pb_emit_sorted_run<T, 8>(n, lo, g, gp, (int) p0, lane, st, stv, stc, row_of, s_val, s_col, perm, s_code, s_hdr,
+                                     &exc_n, exc_cap, ei, er);
+          } else if (n > 128) {
+            pb_emit_sorted_run<T, 4>(n, lo, g, gp, (int) p0, lane, st, stv, stc, row_of, s_val, s_col, perm, s_code, s_hdr,
+                                     &exc_n, exc_cap, ei, er);
+          } else if (n > 0) {
+            pb_emit_sorted_run<T, 2>(n, lo, g, gp, (int) p0, lane, st, stv, stc, row_of, s_val, s_col, perm, s_code, s_hdr,
+                                     &exc_n, exc_cap, ei, er);
+          }
+          continue;
+        }
         for (int j = lane; j < n; j += 64) {
           const int q = st[lo + j];
           s_val[g + j] = stv[lo + j];
@@ -554,6 +728,12 @@ __global__ __launch_bounds__(PB_STAGE_THREADS) void pb_scatter_staged_kernel(
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     s0 = s1;
   }
+  if (ENC8 && tid == 0) {  // (every wave's exception appends are LDS operations completed before the last barrier)
+    const int k = exc_n;
+    exc_cnt[wb] = k < exc_cap ? k : exc_cap;
+    if (k > exc_cap)
+      atomicExch(enc_fail, 1);
+  }
 }
 
 // balance probe: entries per slice and per bin group (RW bins = one reduce workgroup).  Workgroups
@@ -563,16 +743,19 @@ __global__ __launch_bounds__(PB_STAGE_THREADS) void pb_scatter_staged_kernel(
 __global__ __launch_bounds__(256) void pb_balance_kernel(int S, int NB, int RW, const int32_t* __restrict__ cnt,
                                                          unsigned long long* __restrict__ slice_sum,
                                                          unsigned long long* __restrict__ slice_ne,
-                                                         unsigned long long* __restrict__ group_sum) {
+                                                         unsigned long long* __restrict__ group_sum,
+                                                         unsigned long long* __restrict__ slice_max) {
   __shared__ unsigned long long red[4];
   __shared__ unsigned long long red_ne[4];
-  unsigned long long tot = 0, ne = 0;  // ne: non-empty (slice, bin) tiles -- the locality probe
+  __shared__ unsigned long long red_mx[4];
+  unsigned long long tot = 0, ne = 0, mx = 0;  // ne: non-empty (slice, bin) tiles -- the locality probe; mx: longest run
   if ((int) blockIdx.x < S) {
     const int sl = blockIdx.x;
     for (int b = threadIdx.x; b < NB; b += 256) {
       const unsigned long long c = (unsigned long long) cnt[(int64_t) sl * NB + b];
       tot += c;
       ne += c != 0;
+      mx = c > mx ? c : mx;
     }
   } else {
     const int64_t g = (int64_t) blockIdx.x - S;
@@ -583,9 +766,14 @@ __global__ __launch_bounds__(256) void pb_balance_kernel(int S, int NB, int RW, 
   }
   tot = group_sum_c<64>(tot);
   ne = group_sum_c<64>(ne);
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned long long u = __shfl_xor(mx, o, 64);
+    mx = u > mx ? u : mx;
+  }
   if ((threadIdx.x & 63) == 0) {
     red[threadIdx.x >> 6] = tot;
     red_ne[threadIdx.x >> 6] = ne;
+    red_mx[threadIdx.x >> 6] = mx;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -593,6 +781,7 @@ __global__ __launch_bounds__(256) void pb_balance_kernel(int S, int NB, int RW, 
     if ((int) blockIdx.x < S) {
       slice_sum[blockIdx.x] = t;
       slice_ne[blockIdx.x] = red_ne[0] + red_ne[1] + red_ne[2] + red_ne[3];
+      slice_max[blockIdx.x] = std::max(std::max(red_mx[0], red_mx[1]), std::max(red_mx[2], red_mx[3]));
     } else {
       group_sum[blockIdx.x - S] = t;
     }
@@ -783,6 +972,50 @@ __global__ __launch_bounds__(PB_FTHREADS) void pb_flag_dups_kernel(int Hw, int64
   }
 }
 
+// The same for the one-byte row codes: rows come from pb_decode_rows, entries with code 255 (pads, exceptions) take no
+// part, and the four flag bits of a lane are gathered into the block's header word.
+template <typename T>
+__global__ __launch_bounds__(PB_FTHREADS) void pb_flag_dups8_kernel(int Hw, int64_t NBw,
+                                                                    const int32_t* __restrict__ binblk,
+                                                                    const unsigned char* __restrict__ s_code,
+                                                                    typename pb_hdr<T>::type* __restrict__ s_hdr) {
+  constexpr int PB_BLK = pb_geom<T>::BLK, PB_GBLK = pb_geom<T>::GBLK, LPB = PB_BLK / 4;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  unsigned char* tag = smem + (size_t) wave * (size_t) ((Hw + 64 + 63) & ~63);
+  const int64_t wb = (int64_t) blockIdx.x * PB_FWAVES + wave;
+  if (wb >= NBw)
+    return;
+  const int g0 = binblk[wb] / PB_GBLK, g1 = binblk[wb + 1] / PB_GBLK;
+  for (int g = g0; g < g1; ++g) {
+    const unsigned cw = *reinterpret_cast<const unsigned*>(s_code + (int64_t) g * PB_GRP + 4 * lane);
+    const int64_t blk = (int64_t) g * PB_GBLK + lane / LPB;
+    const typename pb_hdr<T>::type hd = s_hdr[blk];
+    unsigned row[4];
+    bool skip[4];
+    pb_decode_rows<LPB>(cw, pb_hdr<T>::base(hd), lane, (unsigned) Hw, row, skip);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (!skip[j])
+        tag[row[j]] = (unsigned char) (4 * lane + j);
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the tag stores have landed
+    unsigned fl = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (!skip[j] && tag[row[j]] != (unsigned char) (4 * lane + j))
+        fl |= 1u << j;
+    fl <<= 4 * (lane & (LPB - 1));
+#pragma unroll
+    for (int o = 1; o < LPB; o <<= 1)
+      fl |= (unsigned) __shfl_xor((int) fl, o, 64);
+    if ((lane & (LPB - 1)) == 0 && fl != 0)
+      s_hdr[blk] = pb_hdr<T>::make(pb_hdr<T>::base(hd), fl);
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // the tag reads are done before the next group's stores
+  }
+}
+
 // (Duplicates are added with the native LDS float atomic.  A compare-and-swap loop -- 12x the rate per operation,
 // tools/ubench/lds_atomic.hip -- was tried in its place: 10-20 % faster where two or three lanes share a row, 4x slower
 // where dozens do (R-MAT with whole rows: 3.5 vs 0.8 ms), 35 % slower for fp64, and the larger kernel cost cfg2 6 %.)
@@ -794,7 +1027,8 @@ __global__ __launch_bounds__(PB_FTHREADS) void pb_flag_dups_kernel(int Hw, int64
 //   item (ritems != nullptr: row-skewed matrices; else blockIdx): .x = bin group, .y / .z = this workgroup reduces
 //   part y of z equal parts of every wave-bin's stream, .w >= 0 = offset of its partial sums (RW*Hw values,
 //   pb_combine_items_kernel adds them), .w < 0 = the group is not split and y is written directly.
-template <typename T, int RW, int UB>
+//   ENC8: the row stream is s_code (one byte per entry) + s_hdr (per block); `s_row` then points at the codes
+template <typename T, int RW, int UB, bool ENC8>
 __global__ __launch_bounds__(RW * 64) void pb_reduce_kernel(int64_t m, int Hw, int64_t wb_begin, int64_t NBw,
                                                             const int32_t* __restrict__ binblk,
                                                             const T* __restrict__ P,
@@ -805,7 +1039,11 @@ __global__ __launch_bounds__(RW * 64) void pb_reduce_kernel(int64_t m, int Hw, i
                                                             const int4* __restrict__ ritems, int dbg,
                                                             const int32_t* __restrict__ binrow,
                                                             const int32_t* __restrict__ rowmap,
-                                                            T* __restrict__ piece_out) {
+                                                            T* __restrict__ piece_out,
+                                                            const typename pb_hdr<T>::type* __restrict__ s_hdr,
+                                                            const unsigned* __restrict__ exc_idx,
+                                                            const uint16_t* __restrict__ exc_row,
+                                                            const int32_t* __restrict__ exc_cnt, int exc_cap) {
   // dbg (SPBLAS_GFX950_PB_DBG, timing experiments only -- results are wrong): 1 = skip the atomic path of flagged
   // entries, 2 = no LDS traffic at all (the stream alone)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -826,9 +1064,13 @@ __global__ __launch_bounds__(RW * 64) void pb_reduce_kernel(int64_t m, int Hw, i
   const int gb0 = binblk[wb] / PB_GBLK, ng = binblk[wb + 1] / PB_GBLK - gb0;
   const int g_lo = gb0 + (int) ((int64_t) ng * item.y / item.z);
   const int g_hi = gb0 + (int) ((int64_t) ng * (item.y + 1) / item.z);
+  constexpr int LPB = pb_geom<T>::BLK / 4;  // lanes per block
+  typedef typename pb_hdr<T>::type hdr_t;
   struct batch_t {
     T p[UB][4];
-    u16x4 r[UB];
+    u16x4 r[UB];   // 16-bit rows
+    unsigned cw[UB];  // enc8: four row codes
+    hdr_t hd[UB];     // enc8: the header of the lane's block
   };
   // flagged entries store to a per-lane dummy slot behind the accumulators instead of sitting in an
   // exec-masked block (the instruction count per group is what the kernel time follows once the stream is linear)
@@ -842,7 +1084,20 @@ __global__ __launch_bounds__(RW * 64) void pb_reduce_kernel(int64_t m, int Hw, i
       const unsigned offR = ((unsigned) gg * PB_GRP + 4u * (unsigned) lane) * 2u;
       const unsigned offP = offR * (unsigned) (sizeof(T) / 2);
       pack4<T>::load(reinterpret_cast<const T*>(reinterpret_cast<const char*>(P) + offP), q.p[u]);
+      if (ENC8) {
+        q.cw[u] = stream_load(reinterpret_cast<const unsigned*>(reinterpret_cast<const char*>(s_row) + (offR >> 1)));
+        q.hd[u] = stream_load(s_hdr + ((unsigned) gg * (unsigned) PB_GBLK + (unsigned) lane / LPB));
+        continue;
+      }
+#ifdef PB_EXP_U8ROWS  // timing experiment (tools/build_variant.sh): one byte of row stream per entry; results are wrong
+      const unsigned w8 = stream_load(reinterpret_cast<const unsigned*>(reinterpret_cast<const char*>(s_row) + (offR >> 1)));
+      q.r[u][0] = (unsigned short) ((w8 & 0xffu) << 3);
+      q.r[u][1] = (unsigned short) (((w8 >> 8) & 0xffu) << 3);
+      q.r[u][2] = (unsigned short) (((w8 >> 16) & 0xffu) << 3);
+      q.r[u][3] = (unsigned short) ((w8 >> 24) << 3);
+#else
       q.r[u] = stream_load(reinterpret_cast<const u16x4*>(reinterpret_cast<const char*>(s_row) + offR));
+#endif
     }
   };
   auto consume = [&](int g, const batch_t& q) {
@@ -851,31 +1106,46 @@ __global__ __launch_bounds__(RW * 64) void pb_reduce_kernel(int64_t m, int Hw, i
       if (g + u >= g_hi)
         break;
       if (dbg & 2) {
-        dbg_sum += q.p[u][0] + q.p[u][1] + q.p[u][2] + q.p[u][3] + T(q.r[u][0] ^ q.r[u][1] ^ q.r[u][2] ^ q.r[u][3]);
+        dbg_sum += q.p[u][0] + q.p[u][1] + q.p[u][2] + q.p[u][3] +
+                   (ENC8 ? T(q.cw[u] ^ (unsigned) q.hd[u]) : T(q.r[u][0] ^ q.r[u][1] ^ q.r[u][2] ^ q.r[u][3]));
         continue;
       }
       // one group: all LDS reads, then all writes.  Rows of unflagged entries are distinct inside a
       // group (pb_flag_dups_kernel), flagged ones are added atomically afterwards.
       T v[4];
       T* slot[4];
-      bool flagged[4];
+      bool flagged[4], atomic[4];
+      if (ENC8) {
+        unsigned row[4];
+        bool skip[4];
+        pb_decode_rows<LPB>(q.cw[u], pb_hdr<T>::base(q.hd[u]), lane, (unsigned) Hw, row, skip);
+        const unsigned fl = pb_hdr<T>::flags(q.hd[u]) >> (4 * (lane & (LPB - 1)));
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        unsigned r = q.r[u][j];
-        asm("" : "+v"(r));  // keep the row word a 32-bit value (the 16-bit forms cost extra masking)
-        flagged[j] = r > 0x7FFFu;
-        slot[j] = acc + (r & 0x7FFFu);
-        v[j] = *slot[j];
+        for (int j = 0; j < 4; ++j) {
+          atomic[j] = ((fl >> j) & 1u) != 0 && !skip[j];  // duplicates; pads and exceptions take no part here
+          flagged[j] = atomic[j] || skip[j];
+          slot[j] = acc + row[j];
+          v[j] = *slot[j];
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          unsigned r = q.r[u][j];
+          asm("" : "+v"(r));  // keep the row word a 32-bit value (the 16-bit forms cost extra masking)
+          flagged[j] = atomic[j] = r > 0x7FFFu;
+          slot[j] = acc + (r & 0x7FFFu);
+          v[j] = *slot[j];
+        }
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         T* w = flagged[j] ? dummy : slot[j];
         *w = v[j] + q.p[u][j];
       }
-      if (!(dbg & 1) && __builtin_amdgcn_ballot_w64(flagged[0] | flagged[1] | flagged[2] | flagged[3]) != 0) {
+      if (!(dbg & 1) && __builtin_amdgcn_ballot_w64(atomic[0] | atomic[1] | atomic[2] | atomic[3]) != 0) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          if (flagged[j])
+          if (atomic[j])
             unsafeAtomicAdd(slot[j], q.p[u][j]);
       }
     }
@@ -892,6 +1162,14 @@ __global__ __launch_bounds__(RW * 64) void pb_reduce_kernel(int64_t m, int Hw, i
   }
   if (dbg & 2)
     *dummy = dbg_sum;
+  if (ENC8 && item.y == 0 && !(dbg & 3)) {
+    // exceptions of this wave-bin (entries the one-byte codes could not reach): added once, by the first part
+    const int ne = exc_cnt[wb];
+    for (int i = lane; i < ne; i += 64) {
+      const unsigned e = exc_idx[(size_t) wb * exc_cap + i];
+      unsafeAtomicAdd(acc + exc_row[(size_t) wb * exc_cap + i], P[e]);
+    }
+  }
   if (partial) {
     // uniform split: slot k of the [K][m] array; work items: this wave's part of the item's own RW*Hw block
     T* dst = ritems ? partial : partial + (int64_t) blockIdx.y * pstride + r0;
@@ -1047,8 +1325,18 @@ __global__ __launch_bounds__(256) void pb_combine_items_kernel(const int4* __res
 }
 
 template <typename T>
-static const void* pb_reduce_fn(int rw, int ub) {
-#define SPB_RK(RW_, UB_) reinterpret_cast<const void*>(pb_reduce_kernel<T, RW_, UB_>)
+static const void* pb_reduce_fn(int rw, int ub, bool enc8 = false) {
+  if (enc8) {
+    if (rw == 8)
+      return ub == 2 ? (const void*) pb_reduce_kernel<T, 8, 2, true>
+                     : ub == 8 ? (const void*) pb_reduce_kernel<T, 8, 8, true> : (const void*) pb_reduce_kernel<T, 8, 4, true>;
+    return ub == 1 ? (const void*) pb_reduce_kernel<T, 4, 1, true>
+           : ub == 2 ? (const void*) pb_reduce_kernel<T, 4, 2, true>
+                     : ub == 8 ? (const void*) pb_reduce_kernel<T, 4, 8, true> : (const void*) pb_reduce_kernel<T, 4, 4, true>;
+  }
+  if (ub == 1 && rw == 4)
+    return (const void*) pb_reduce_kernel<T, 4, 1, false>;
+#define SPB_RK(RW_, UB_) reinterpret_cast<const void*>(pb_reduce_kernel<T, RW_, UB_, false>)
   if (rw == 8)
     return ub == 2 ? SPB_RK(8, 2) : (ub == 8 ? SPB_RK(8, 8) : SPB_RK(8, 4));
   return ub == 2 ? SPB_RK(4, 2) : (ub == 8 ? SPB_RK(4, 8) : SPB_RK(4, 4));
@@ -1423,7 +1711,7 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
   // per bin group.  AUTO uses them to decline matrices the plan does not suit; the work lists below use them
   // to spot column / row skew, and their total is the number of entries placed in tiles.
   const int64_t ngroups = cdiv(NB, RW);
-  std::vector<unsigned long long> h_sum((size_t) (2 * S + ngroups));
+  std::vector<unsigned long long> h_sum((size_t) (2 * S + ngroups + S));  // ..., then the longest run per slice
   unsigned long long* d_sum = nullptr;
   if ((rc = dev_alloc((void**) &d_sum, h_sum.size() * sizeof(unsigned long long), s)))
     return rc;
@@ -1437,7 +1725,7 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
   } temps{s};
   temps.p[0] = d_sum;
   hipLaunchKernelGGL(pb_balance_kernel, dim3((unsigned) (S + ngroups)), dim3(256), 0, s, S, NB, RW, cnt, d_sum,
-                     d_sum + S, d_sum + 2 * S);
+                     d_sum + S, d_sum + 2 * S, d_sum + 2 * S + ngroups);
   if ((rc = readback_add(h, h_sum.data(), d_sum, h_sum.size() * sizeof(unsigned long long))))
     return rc;
   // the block offsets of both orders are computed meanwhile (the probe read-back below is the only wait)
@@ -1466,11 +1754,12 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
   if ((rc = readback_add(h, h_sliceblk.data(), sliceblk, (size_t) (S + 1) * 4)) ||
       (rc = readback_add(h, &h_pblocks, binblk + NB, 4)) || (rc = readback_flush(h)))
     return rc;
-  unsigned long long placed_total = 0, max_slice = 0, max_group = 0, ne = 0;
+  unsigned long long placed_total = 0, max_slice = 0, max_group = 0, ne = 0, max_run = 0;
   for (int i = 0; i < S; ++i) {
     placed_total += h_sum[(size_t) i];
     max_slice = std::max(max_slice, h_sum[(size_t) i]);
     ne += h_sum[(size_t) (S + i)];
+    max_run = std::max(max_run, h_sum[(size_t) (2 * S + ngroups + i)]);
   }
   for (int64_t g = 0; g < ngroups; ++g)
     max_group = std::max(max_group, h_sum[(size_t) (2 * S + g)]);
@@ -1517,18 +1806,44 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
     return rc;
   if ((rc = dev_alloc((void**) &pl->s_blkdst, (size_t) (a_blocks + 8) * 4, s)))
     return rc;
-  if ((rc = dev_alloc((void**) &pl->s_lrow, (size_t) (p_pad + PB_GRP) * 2, s)))
+  // Row stream of the reduce: one-byte codes when the tiles are dense enough for them (the average row advance inside
+  // a run is H * (non-empty tiles) / entries: beyond ~40 rows too many entries become exceptions), no run is too long
+  // to be sorted in registers and the staged scatter (which sorts) is in use; otherwise 16-bit rows.
+  typedef typename pb_hdr<T>::type hdr_t;
+  const bool staged = S <= PB_STAGE_MAX_S && env_int("SPBLAS_GFX950_PB_STAGED_SCATTER", 1);
+  int enc8 = env_int("SPBLAS_GFX950_PB_ENC8", 1);
+  if (!staged || max_run > (unsigned long long) PB_SORT_MAX || placed_total == 0 ||
+      (enc8 == 1 && (double) H * (double) ne > 40.0 * (double) placed_total))
+    enc8 = 0;
+  pl->enc8 = enc8 ? 1 : 0;
+  pl->exc_cap = PB_EXC_CAP;
+  const size_t hdr_bytes = (size_t) (p_blocks + PB_GBLK) * sizeof(hdr_t);
+  if (enc8) {
+    if ((rc = dev_alloc((void**) &pl->s_code, (size_t) (p_pad + PB_GRP), s)) || (rc = dev_alloc(&pl->s_hdr, hdr_bytes, s)) ||
+        (rc = dev_alloc((void**) &pl->s_exc_idx, (size_t) NB * PB_EXC_CAP * 4, s)) ||
+        (rc = dev_alloc((void**) &pl->s_exc_row, (size_t) NB * PB_EXC_CAP * 2, s)) ||
+        (rc = dev_alloc((void**) &pl->s_exc_cnt, (size_t) (NB + 1) * 4, s)))  // [NB] = enc_fail
+      return rc;
+  } else if ((rc = dev_alloc((void**) &pl->s_lrow, (size_t) (p_pad + PB_GRP) * 2, s))) {
     return rc;
+  }
   if ((rc = dev_alloc((void**) &pl->s_products, (size_t) (p_pad + PB_GRP) * sizeof(T), s)))
     return rc;
-  pl->device_bytes += (size_t) a_pad * (sizeof(T) + 6) + (size_t) a_blocks * 4 + (size_t) p_pad * (sizeof(T) + 2) +
+  pl->device_bytes += (size_t) a_pad * (sizeof(T) + 6) + (size_t) a_blocks * 4 + (size_t) p_pad * sizeof(T) +
+                      (enc8 ? (size_t) p_pad + hdr_bytes + (size_t) NB * PB_EXC_CAP * 6 : (size_t) p_pad * 2) +
                       (size_t) (NB + S + 2) * 4 + (size_t) nseg * 4;
   // pads: value 0, column 0, no source position, row = H (a dummy accumulator); products start finite
   SPB_HIP(hipMemsetAsync(pl->s_values, 0, (size_t) (a_pad + 8) * sizeof(T), s));
   SPB_HIP(hipMemsetAsync(pl->s_colind, 0, (size_t) (a_pad + 8) * 2, s));
   SPB_HIP(hipMemsetAsync(pl->s_perm, 0xFF, (size_t) (a_pad + 8) * 4, s));
   SPB_HIP(hipMemsetAsync(pl->s_blkdst, 0, (size_t) (a_blocks + 8) * 4, s));
-  SPB_HIP(hipMemsetD16Async(reinterpret_cast<hipDeviceptr_t>(pl->s_lrow), (unsigned short) H, (size_t) (p_pad + PB_GRP), s));
+  if (enc8) {  // pads: code 255 (left out of the main pass); headers and exception counts start at 0
+    SPB_HIP(hipMemsetAsync(pl->s_code, 0xFF, (size_t) (p_pad + PB_GRP), s));
+    SPB_HIP(hipMemsetAsync(pl->s_hdr, 0, hdr_bytes, s));
+    SPB_HIP(hipMemsetAsync(pl->s_exc_cnt, 0, (size_t) (NB + 1) * 4, s));
+  } else {
+    SPB_HIP(hipMemsetD16Async(reinterpret_cast<hipDeviceptr_t>(pl->s_lrow), (unsigned short) H, (size_t) (p_pad + PB_GRP), s));
+  }
   SPB_HIP(hipMemsetAsync(pl->s_products, 0, (size_t) (p_pad + PB_GRP) * sizeof(T), s));
   tr.mark("plan arrays allocated + cleared");
   pl->n_ksplit = pick_ksplit(NB, NB > 0 ? p_blocks / PB_GBLK / NB : 0);
@@ -1615,18 +1930,35 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
     }
   }
   tr.mark("work lists");
-  if (S <= PB_STAGE_MAX_S && env_int("SPBLAS_GFX950_PB_STAGED_SCATTER", 1)) {
-    // a quarter of the staging area at most goes to the row table (one entry per 64 matrix entries of a bin)
-    const int rt_len = 2048;
-    const int cap = (int) (((size_t) PB_STAGE_LDS - (size_t) 16 * S - (size_t) 4 * (H + 1) - (size_t) 4 * rt_len - 128) /
-                           (6 + sizeof(T))) & ~7;
-    SPB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pb_scatter_staged_kernel<T, O>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, PB_STAGE_LDS - 64));
-    hipLaunchKernelGGL((pb_scatter_staged_kernel<T, O>), dim3((unsigned) NB), dim3(PB_STAGE_THREADS),
-                       (size_t) PB_STAGE_LDS - 64, s, m, rowptr, pl->colind, static_cast<const T*>(values_p), W, H, S,
-                       NB, cnt, aoff, prel, binblk, static_cast<T*>(pl->s_values),
-                       reinterpret_cast<uint16_t*>(pl->s_colind), pl->s_lrow, reinterpret_cast<int32_t*>(pl->s_perm),
-                       static_cast<int32_t*>(pl->s_blkdst), pl->hub_len, cap, rt_len, binrow);
+  // a quarter of the staging area at most goes to the row table (one entry per 64 matrix entries of a bin)
+  const int rt_len = 2048;
+  const int cap = (int) (((size_t) PB_STAGE_LDS - (size_t) 16 * S - (size_t) 4 * (H + 1) - (size_t) 4 * rt_len - 128) /
+                         (6 + sizeof(T))) & ~7;
+  auto launch_staged = [&](bool e8) {
+    const void* fn = e8 ? reinterpret_cast<const void*>(pb_scatter_staged_kernel<T, O, true>)
+                        : reinterpret_cast<const void*>(pb_scatter_staged_kernel<T, O, false>);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, PB_STAGE_LDS - 64);
+    if (e != hipSuccess)
+      return e;
+    int64_t mm = m;
+    const int32_t* ci = pl->colind;
+    const T* vp = static_cast<const T*>(values_p);
+    T* sv = static_cast<T*>(pl->s_values);
+    uint16_t *sc = reinterpret_cast<uint16_t*>(pl->s_colind), *sr = pl->s_lrow;
+    int32_t *pm = reinterpret_cast<int32_t*>(pl->s_perm), *bd = static_cast<int32_t*>(pl->s_blkdst);
+    int hub = pl->hub_len, cap_ = cap, rt_ = rt_len, W_ = W, H_ = H, S_ = S, NB_ = NB, ecap = PB_EXC_CAP;
+    unsigned char* code = pl->s_code;
+    hdr_t* hdr = static_cast<hdr_t*>(pl->s_hdr);
+    unsigned* ei = pl->s_exc_idx;
+    uint16_t* er = pl->s_exc_row;
+    int32_t *ec = pl->s_exc_cnt, *fail = pl->s_exc_cnt ? pl->s_exc_cnt + NB : nullptr;
+    const int32_t *cnt_ = cnt, *aoff_ = aoff, *prel_ = prel, *binblk_ = binblk;
+    void* args[] = {&mm, &rowptr, &ci, &vp, &W_, &H_, &S_, &NB_, &cnt_, &aoff_, &prel_, &binblk_, &sv, &sc, &sr, &pm, &bd,
+                    &hub, &cap_, &rt_, &binrow, &code, &hdr, &ei, &er, &ec, &ecap, &fail};
+    return hipLaunchKernel(fn, dim3((unsigned) NB), dim3(PB_STAGE_THREADS), args, (size_t) PB_STAGE_LDS - 64, s);
+  };
+  if (staged) {
+    SPB_HIP(launch_staged(enc8 != 0));
   } else {
     SPB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pb_scatter_kernel<T, O>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8));
@@ -1638,15 +1970,55 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
   tr.mark("scatter");
   SPB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pb_flag_dups_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, PB_LDS_BYTES + 16 * 1024));
-  hipLaunchKernelGGL(pb_flag_dups_kernel, dim3((unsigned) cdiv(NB, PB_FWAVES)), dim3(PB_FTHREADS),
-                     (size_t) PB_FWAVES * (size_t) ((H + 63) & ~63), s, H, (int64_t) NB, binblk, pl->s_lrow, PB_GBLK);
+  SPB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pb_flag_dups8_kernel<T>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, PB_LDS_BYTES + 16 * 1024));
+  auto launch_flags = [&]() {
+    if (pl->enc8)
+      hipLaunchKernelGGL((pb_flag_dups8_kernel<T>), dim3((unsigned) cdiv(NB, PB_FWAVES)), dim3(PB_FTHREADS),
+                         (size_t) PB_FWAVES * (size_t) ((H + 64 + 63) & ~63), s, H, (int64_t) NB, binblk, pl->s_code,
+                         static_cast<hdr_t*>(pl->s_hdr));
+    else
+      hipLaunchKernelGGL(pb_flag_dups_kernel, dim3((unsigned) cdiv(NB, PB_FWAVES)), dim3(PB_FTHREADS),
+                         (size_t) PB_FWAVES * (size_t) ((H + 63) & ~63), s, H, (int64_t) NB, binblk, pl->s_lrow, PB_GBLK);
+  };
+  launch_flags();
   SPB_HIP(hipGetLastError());
-  SPB_HIP(hipStreamSynchronize(s));
+  int32_t enc_fail = 0;
+  if (pl->enc8) {
+    if ((rc = readback_add(h, &enc_fail, pl->s_exc_cnt + NB, 4)) || (rc = readback_flush(h)))
+      return rc;
+  } else {
+    SPB_HIP(hipStreamSynchronize(s));
+  }
+  if (enc_fail || env_int("SPBLAS_GFX950_PB_ENC8_FAIL", 0)) {
+    // a wave-bin with more exceptions than its list holds, or a run that could not be sorted: the same plan with
+    // 16-bit rows (the tiles, offsets and work lists stay; the scatter and the duplicate flags run again)
+    dev_free(pl->s_code, s);
+    dev_free(pl->s_hdr, s);
+    dev_free(pl->s_exc_idx, s);
+    dev_free(pl->s_exc_row, s);
+    dev_free(pl->s_exc_cnt, s);
+    pl->s_code = nullptr;
+    pl->s_hdr = nullptr;
+    pl->s_exc_idx = nullptr;
+    pl->s_exc_row = nullptr;
+    pl->s_exc_cnt = nullptr;
+    pl->enc8 = 0;
+    if ((rc = dev_alloc((void**) &pl->s_lrow, (size_t) (p_pad + PB_GRP) * 2, s)))
+      return rc;
+    SPB_HIP(hipMemsetD16Async(reinterpret_cast<hipDeviceptr_t>(pl->s_lrow), (unsigned short) H, (size_t) (p_pad + PB_GRP), s));
+    SPB_HIP(launch_staged(false));
+    launch_flags();
+    SPB_HIP(hipGetLastError());
+    SPB_HIP(hipStreamSynchronize(s));
+    tr.mark("fallback to 16-bit rows");
+  }
   tr.mark("flags");
   SPB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pb_expand_kernel<T>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, xlds > PB_LDS_BYTES ? xlds : PB_LDS_BYTES));
-  for (int ub : {2, 4, 8})
-    SPB_HIP(hipFuncSetAttribute(pb_reduce_fn<T>(pl->rwaves, ub), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  for (int ub : {1, 2, 4, 8})
+    SPB_HIP(hipFuncSetAttribute(pb_reduce_fn<T>(pl->rwaves, ub, pl->enc8 != 0), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024));
   return SPBLAS_GFX950_STATUS_SUCCESS;
 }
 
@@ -1778,8 +2150,10 @@ static int sliced_reduce_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* p
     return SPBLAS_GFX950_STATUS_NOT_SUPPORTED;  // the fused all-gather epilogue does not cover hub rows
   const T alpha = *static_cast<const T*>(alpha_p), beta = *static_cast<const T*>(beta_p);
   const int RW = pl->rwaves;
-  int UB = env_int("SPBLAS_GFX950_PB_RBATCH", 4);
-  if (UB != 2 && UB != 8)
+  // groups per batch (two batches in flight): 4 for the 16-bit rows; the one-byte codes run best with 2 (cfg2, same box:
+  // reduce 118.4 / 124.6 / 129.5 us for 2 / 4 / 8)
+  int UB = env_int("SPBLAS_GFX950_PB_RBATCH", pl->enc8 ? 2 : 4);
+  if (UB != 1 && UB != 2 && UB != 8)
     UB = 4;
   const int64_t groups = cdiv(wb_end - wb_begin, RW);
   int K = pick_ksplit(wb_end - wb_begin, pl->n_rblk > 0 ? pl->p_blocks / pb_geom<T>::GBLK / pl->n_rblk : 0);
@@ -1826,7 +2200,14 @@ static int sliced_reduce_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* p
   {
     const int32_t* binblk = static_cast<const int32_t*>(pl->s_binblk);
     const T* Pp = static_cast<const T*>(pl->s_products);
-    const uint16_t* rowp = pl->s_lrow;
+    const uint16_t* rowp = pl->enc8 ? reinterpret_cast<const uint16_t*>(pl->s_code) : pl->s_lrow;
+    typedef typename pb_hdr<T>::type hdr_t;
+    const hdr_t* hdr = static_cast<const hdr_t*>(pl->s_hdr);
+    const unsigned* exc_idx = pl->s_exc_idx;
+    const uint16_t* exc_row = pl->s_exc_row;
+    const int32_t* exc_cnt = pl->s_exc_cnt;
+    int exc_cap = pl->exc_cap;
+    const bool e8 = pl->enc8 != 0;
     T* yp = static_cast<T*>(y);
     T* part = K > 1 ? static_cast<T*>(pl->s_partial) : nullptr;
     int64_t mm = pl->s_m, pstride = pl->s_m;
@@ -1837,14 +2218,15 @@ static int sliced_reduce_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* p
     int dbg = env_int("SPBLAS_GFX950_PB_DBG", 0);
     const int32_t* binrow = static_cast<const int32_t*>(pl->s_binrow);
     void* args[] = {&mm, &Hw, &wb_begin, &wb_end, &binblk, &Pp, &rowp, &yp, &a, &b, &Kk, &part, &pstride,
-                    &peers, &n_peers, &peer_off, &ritems, &dbg, &binrow, &rowmap, &piece_out};
+                    &peers, &n_peers, &peer_off, &ritems, &dbg, &binrow, &rowmap, &piece_out, &hdr, &exc_idx,
+                    &exc_row, &exc_cnt, &exc_cap};
     const size_t lds = (size_t) RW * (pl->rows_per_blk + 64) * sizeof(T);
     if (use_items) {
       // row-skewed matrix, whole range: explicit work list (built at inspect), compact partial sums
       ritems = static_cast<const int4*>(pl->s_ritems);
       part = static_cast<T*>(pl->s_rpartial);
       pstride = 0;
-      SPB_HIP(hipLaunchKernel(pb_reduce_fn<T>(RW, UB), dim3((unsigned) pl->n_ritems), dim3(RW * 64), args, lds, s));
+      SPB_HIP(hipLaunchKernel(pb_reduce_fn<T>(RW, UB, e8), dim3((unsigned) pl->n_ritems), dim3(RW * 64), args, lds, s));
       if (pl->n_rsplit > 0)
         hipLaunchKernelGGL((pb_combine_items_kernel<T>),
                            dim3((unsigned) pl->n_rsplit, (unsigned) cdiv((int64_t) RW * pl->rows_per_blk, 256)), dim3(256),
@@ -1852,7 +2234,7 @@ static int sliced_reduce_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* p
                            static_cast<const T*>(pl->s_rpartial), static_cast<T*>(y), alpha, beta, pl->rows_per_blk,
                            binrow, pl->n_rblk, rowmap, piece_out);
     } else {
-      SPB_HIP(hipLaunchKernel(pb_reduce_fn<T>(RW, UB), dim3((unsigned) groups, (unsigned) K), dim3(RW * 64), args, lds, s));
+      SPB_HIP(hipLaunchKernel(pb_reduce_fn<T>(RW, UB, e8), dim3((unsigned) groups, (unsigned) K), dim3(RW * 64), args, lds, s));
       if (K > 1 && r_hi > r_lo)
         hipLaunchKernelGGL((pb_combine_kernel<T>), dim3((unsigned) cdiv(r_hi - r_lo, 256)), dim3(256), 0, s, r_lo, r_hi, K,
                            static_cast<const T*>(pl->s_partial), pl->s_m, static_cast<T*>(y), alpha, beta,
@@ -1961,6 +2343,17 @@ void spmv_sliced_free(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl) {
   dev_free(pl->s_colind, s);
   dev_free(pl->s_values, s);
   dev_free(pl->s_lrow, s);
+  dev_free(pl->s_code, s);
+  dev_free(pl->s_hdr, s);
+  dev_free(pl->s_exc_idx, s);
+  dev_free(pl->s_exc_row, s);
+  dev_free(pl->s_exc_cnt, s);
+  pl->s_code = nullptr;
+  pl->s_hdr = nullptr;
+  pl->s_exc_idx = nullptr;
+  pl->s_exc_row = nullptr;
+  pl->s_exc_cnt = nullptr;
+  pl->enc8 = 0;
   dev_free(pl->s_perm, s);
   dev_free(pl->s_products, s);
   dev_free(pl->s_partial, s);

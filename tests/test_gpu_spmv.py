@@ -180,6 +180,85 @@ def test_spmv_sliced_empty_trailing_runs_on_allocation_boundary(gpu, dtype):
     check(values, rowptr, colind, (m, n), x, G.host(y), what="sliced, empty trailing runs")
 
 
+def _enc8_exceptions(rowptr, colind, W, H, blk):
+    """Entries the one-byte row codes cannot reach, per wave-bin (the rule of spmv_sliced.hip, restated): runs sorted by
+    row, cut into blocks of `blk`; inside a block the decoder follows D_j = min(r_j, D_{j-1} + 255) and entry j is an
+    exception iff r_j - D_{j-1} >= 255."""
+    m = len(rowptr) - 1
+    rows = np.repeat(np.arange(m), np.diff(rowptr))
+    out = {}
+    for b in range((m + H - 1) // H):
+        sel = (rows >= b * H) & (rows < (b + 1) * H)
+        r, c = rows[sel] - b * H, colind[sel]
+        n_exc = 0
+        for s in np.unique(c // W):
+            rr = r[c // W == s]                   # storage order = row order: already sorted
+            for k0 in range(0, len(rr), blk):
+                d = rr[k0]
+                for rj in rr[k0 + 1:k0 + blk]:
+                    if rj - d >= 255:
+                        n_exc += 1
+                        d += 255
+                    else:
+                        d = rj
+        out[b] = n_exc
+    return out
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("enc,per_row", [("0", 2), ("2", 2), ("2", 1), ("1", 1), ("fail", 2)])
+def test_spmv_sliced_row_encodings(gpu, monkeypatch, dtype, enc, per_row):
+    """Round 3: the reduce streams ONE byte of row code per entry (runs sorted by row, block bases, exception lists)
+    instead of 16-bit rows.  Sparse tiles on purpose: 2 entries per row leave ~50 rows between the entries of a run, so
+    some entries lie >= 255 rows beyond the decoder and go through the per-bin exception lists; with 1 entry per row the
+    lists overflow and the build falls back to 16-bit rows by itself.  Every variant against the oracle; forced
+    encodings through SPBLAS_GFX950_PB_ENC8 (0 = 16-bit rows, 2 = one-byte codes whatever the tile density, 1 = the
+    density rule decides), the fallback also through SPBLAS_GFX950_PB_ENC8_FAIL."""
+    W, H = 64, 4000
+    monkeypatch.setenv("SPBLAS_GFX950_SLICE_COLS", str(W))
+    monkeypatch.setenv("SPBLAS_GFX950_SLICE_ROWS", str(H))
+    monkeypatch.setenv("SPBLAS_GFX950_PB_ENC8", "2" if enc == "fail" else enc)
+    if enc == "fail":
+        monkeypatch.setenv("SPBLAS_GFX950_PB_ENC8_FAIL", "1")
+    rng = np.random.default_rng(23)
+    m, n = 8000, 6400
+    lens = np.full(m, per_row)
+    lens[rng.random(m) < 0.1] = 0
+    lens[4321] = 300                                  # a row that repeats inside runs (duplicate flags)
+    rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    nnz = int(rowptr[-1])
+    colind = rng.integers(0, n, nnz).astype(np.int32)
+    values = (rng.random(nnz) - 0.5).astype(dtype)
+    x = (rng.random(n) - 0.5).astype(dtype)
+    exc = _enc8_exceptions(rowptr, colind, W, H, 32 if dtype == np.float32 else 16)
+    if per_row == 2:
+        assert 0 < max(exc.values()) <= 128, exc      # the exception lists are used and suffice
+    else:
+        assert max(exc.values()) > 128, exc           # more than a list holds: the build must fall back
+    a = G.csr_on_device(values, rowptr, colind, (m, n), nnz)
+    xd = G.dev(x)
+    y = torch.full((m,), float("nan"), dtype=xd.dtype, device="cuda")
+    info = sp.multiply_inspect(a, xd, y, alg=_capi.SPMV_SLICED)
+    assert info.state_.info()["alg"] == _capi.SPMV_SLICED and info.state_.info()["n_slices"] == 100
+    want_u8 = enc == "2" and per_row == 2
+    assert info.state_.sliced_info()["row_code_u8"] == int(want_u8)
+    sp.multiply(info, sp.scaled(-1.5, a), xd, y)
+    check(values, rowptr, colind, (m, n), x, G.host(y), scale=-1.5, what=f"rows enc={enc}", ref_cmp=False)
+    y.fill_(1.0)                                      # alpha / beta form, values refreshed in place
+    a.values().mul_(2.0)
+    info.state_.update_values(a.values())
+    alpha, beta = (ctypes.c_float if dtype == np.float32 else ctypes.c_double)(0.5), \
+        (ctypes.c_float if dtype == np.float32 else ctypes.c_double)(2.0)
+    hd = sp.api._Handle.current(xd.device)
+    sp.api.check(_capi.lib().spblas_gfx950_spmv(hd.h, info.state_.plan, _capi.OP_N, m, n, nnz, ctypes.byref(alpha),
+                                                sp.api._ptr(a.rowptr()), sp.api._ptr(a.colind()), sp.api._ptr(a.values()),
+                                                sp.api._ptr(xd), ctypes.byref(beta), sp.api._ptr(y), _capi.I32,
+                                                _capi.F32 if dtype == np.float32 else _capi.F64), "spmv")
+    y_ref = oracle.spmv((m, n), rowptr, colind, values * dtype(2), x).astype(np.float64) * 0.5 + 2.0
+    absrow = oracle.spmv_absrow(rowptr, colind, values * dtype(2), x) * 0.5 + 2.0
+    util.assert_parity(G.host(y), y_ref.astype(dtype), absrow, dtype, row_len=np.diff(rowptr), what=f"alpha/beta enc={enc}")
+
+
 def test_spmv_plan_introspection_and_long_rows(gpu):
     lens = np.full(500, 3, np.int64)
     lens[100] = 10000

@@ -36,12 +36,16 @@ __device__ __forceinline__ long piece_pos(long q4, int L4, int S, int NB, int mo
   return dst * L4 + off;
 }
 
-template <int MODE_W>
+template <int MODE_W, int XCD = 0>
 __global__ __launch_bounds__(1024) void expand_like(const f32x4* __restrict__ val, const u16x4* __restrict__ col,
                                                     f32x4* __restrict__ P, long n4, int L4, int S, int NB) {
   const long stride = (long) gridDim.x * 1024;
   const long per = (n4 + gridDim.x - 1) / gridDim.x;  // contiguous share per workgroup, like the real expand
-  const long lo = (long) blockIdx.x * per, hi = lo + per < n4 ? lo + per : n4;
+  // XCD = 1 (r03): workgroup i runs on XCD i % 8; give every XCD a CONTIGUOUS range of shares, so that the pieces of
+  // neighbouring shares -- adjacent in memory under wr_T -- are written through ONE L2 at about the same time and the
+  // partial lines at their ends can merge there before they reach HBM
+  const int bid = XCD ? (int) ((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) : (int) blockIdx.x;
+  const long lo = (long) bid * per, hi = lo + per < n4 ? lo + per : n4;
   (void) stride;
   for (long q = lo + threadIdx.x; q < hi; q += 2048) {
     const long q2 = q + 1024 < hi ? q + 1024 : q;
@@ -144,10 +148,10 @@ int main() {
   CHECK(hipMemset(val, 0, cap * 4));
   CHECK(hipMemset(col, 0, cap * 2));
   CHECK(hipMemset(P, 0, cap * 4));
-  printf("%6s %5s %9s | %8s %8s %8s | %8s %8s   (GB/s; expand-like moves 10 B/entry, reduce-like 6 B/entry)\n", "L", "S",
-         "entries", "lin", "wr_T", "wr_hash", "rd_lin", "rd_T");
+  printf("%6s %5s %9s | %8s %8s %8s %8s | %8s %8s   (GB/s; expand-like moves 10 B/entry, reduce-like 6 B/entry)\n", "L", "S",
+         "entries", "lin", "wr_T", "wr_Txcd", "wr_hash", "rd_lin", "rd_T");
   // S chosen so that S * NB * L ~ 1e8 entries
-  for (int L : {8, 16, 32, 64, 100, 128}) {
+  for (int L : {8, 16, 32, 64, 100, 128, 200, 204, 196, 256}) {
     const int L4 = L / 4;
     int S = (int) (100000000L / ((long) NB * L));
     if (S < 1)
@@ -162,12 +166,13 @@ int main() {
     const int G = 256;
     float t0 = time_ms([&] { hipLaunchKernelGGL(expand_like<0>, dim3(G), dim3(1024), 0, 0, val, col, P, n4, L4, S, NB); });
     float t1 = time_ms([&] { hipLaunchKernelGGL(expand_like<1>, dim3(G), dim3(1024), 0, 0, val, col, P, n4, L4, S, NB); });
+    float t1x = time_ms([&] { hipLaunchKernelGGL((expand_like<1, 1>), dim3(G), dim3(1024), 0, 0, val, col, P, n4, L4, S, NB); });
     float t2 = time_ms([&] { hipLaunchKernelGGL(expand_like<2>, dim3(G), dim3(1024), 0, 0, val, col, P, n4, L4, S, NB); });
     float t3 = time_ms([&] { hipLaunchKernelGGL(reduce_like<0>, dim3(NB / 4), dim3(256), 0, 0, P, col, out, L4, S, NB); });
     float t4 = time_ms([&] { hipLaunchKernelGGL(reduce_like<1>, dim3(NB / 4), dim3(256), 0, 0, P, col, out, L4, S, NB); });
     const double gb10 = n * 10.0 / 1e6, gb6 = n * 6.0 / 1e6;
-    printf("%6d %5d %9ld | %8.0f %8.0f %8.0f | %8.0f %8.0f   us: %.0f %.0f %.0f | %.0f %.0f\n", L, S, n, gb10 / t0, gb10 / t1,
-           gb10 / t2, gb6 / t3, gb6 / t4, t0 * 1e3, t1 * 1e3, t2 * 1e3, t3 * 1e3, t4 * 1e3);
+    printf("%6d %5d %9ld | %8.0f %8.0f %8.0f %8.0f | %8.0f %8.0f   us: %.0f %.0f %.0f %.0f | %.0f %.0f\n", L, S, n, gb10 / t0, gb10 / t1,
+           gb10 / t1x, gb10 / t2, gb6 / t3, gb6 / t4, t0 * 1e3, t1 * 1e3, t1x * 1e3, t2 * 1e3, t3 * 1e3, t4 * 1e3);
   }
   CHECK(hipDeviceSynchronize());
   return 0;
