@@ -261,7 +261,10 @@ def build_reference_host_examples(libdir, jobs=4):
 ORACLE_HOST_TESTS = os.path.join(OUT_DIR, "reference_host_tests_on_oracle")
 
 
-def build_reference_host_tests_on_oracle(jobs=4):
+SANITIZE_FLAGS = ["-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer", "-g"]
+
+
+def build_reference_host_tests_on_oracle(jobs=4, sanitize=False):
     """The same eight host test files of the reference, behind the same drop-in header layer, but linked to
     oracle_shim.c + oracle/spblas_oracle.c instead of the GPU library: spblas::multiply & co. end in the CPU oracle, on
     ordinary host memory, no GPU involved.  Passing = the oracle reproduces every known answer the reference's tests
@@ -272,15 +275,21 @@ def build_reference_host_tests_on_oracle(jobs=4):
     gxx, gcc = shutil.which("g++"), shutil.which("gcc")
     rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
     os.makedirs(OUT_DIR, exist_ok=True)
-    shim = os.path.join(OUT_DIR, "liboracle_shim.so")
-    r = subprocess.run([gcc, "-O2", "-fPIC", "-shared", "-I", os.path.join(ROOT, "include"), os.path.join(HERE, "oracle_shim.c"),
+    # sanitize=True: the reference's -DENABLE_SANITIZERS build (/root/reference/CMakeLists.txt:9,113-117:
+    # -fsanitize=address,undefined) of the whole CPU-only stack -- test files, drop-in headers, backend_calls.hpp state
+    # lifetimes, the shim and the oracle -- as a second binary next to the plain one
+    san = SANITIZE_FLAGS if sanitize else []
+    sfx = "_asan" if sanitize else ""
+    shim = os.path.join(OUT_DIR, f"liboracle_shim{sfx}.so")
+    r = subprocess.run([gcc, "-O1" if sanitize else "-O2", "-fPIC", "-shared"] + san +
+                       ["-I", os.path.join(ROOT, "include"), os.path.join(HERE, "oracle_shim.c"),
                         os.path.join(ROOT, "oracle", "spblas_oracle.c"), "-o", shim], capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("gcc failed on oracle_shim.c:\n" + r.stderr[-4000:])
     from concurrent.futures import ThreadPoolExecutor
     with tempfile.TemporaryDirectory() as tmp:
         scratch = patched_reference_headers(os.path.join(tmp, "patched"))
-        common = [gxx, "-O1", "-DFMT_HEADER_ONLY", "-I", fmt] + compile_flags(scratch)
+        common = [gxx, "-O1", "-DFMT_HEADER_ONLY", "-I", fmt] + san + compile_flags(scratch)
         sources = [os.path.join(REF_TEST_DIR, s) for s in REF_HOST_TEST_SOURCES] + [os.path.join(HERE, "gtest_main.cpp")]
         objs = [os.path.join(tmp, f"o{i}.o") for i in range(len(sources))]
 
@@ -292,18 +301,18 @@ def build_reference_host_tests_on_oracle(jobs=4):
                 if r.returncode != 0:
                     raise RuntimeError(f"g++ failed on {sources[i]}:\n" + r.stderr[-8000:])
         # (libamdhip64 only satisfies the inline stream helpers of stream_memory.hpp; nothing calls into it)
-        r = subprocess.run([gxx] + objs + [shim, "-L", os.path.join(rocm, "lib"), "-lamdhip64", "-Wl,-rpath,$ORIGIN",
-                                           "-Wl,-rpath," + os.path.join(rocm, "lib"), "-o", ORACLE_HOST_TESTS],
+        r = subprocess.run([gxx] + san + objs + [shim, "-L", os.path.join(rocm, "lib"), "-lamdhip64", "-Wl,-rpath,$ORIGIN",
+                                                 "-Wl,-rpath," + os.path.join(rocm, "lib"), "-o", ORACLE_HOST_TESTS + sfx],
                            capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("link of reference_host_tests_on_oracle failed:\n" + r.stderr[-8000:])
-    return ORACLE_HOST_TESTS
+    return ORACLE_HOST_TESTS + sfx
 
 
 ORACLE_DEVICE_TESTS = os.path.join(OUT_DIR, "reference_device_tests_on_oracle")
 
 
-def build_reference_device_tests_on_oracle(jobs=4):
+def build_reference_device_tests_on_oracle(jobs=4, sanitize=False):
     """The reference's four DEVICE test files linked to the oracle shim as well: stubs_host/thrust/device_vector.h makes
     thrust::device_vector a host vector, g++ compiles them, and the symbolic / numeric reuse family and the four-argument
     SpGEMM of those tests end in oracle_spgemm_* (tests/test_oracle_reference_tests.py).  Returns the path or None."""
@@ -312,15 +321,18 @@ def build_reference_device_tests_on_oracle(jobs=4):
     gxx, gcc = shutil.which("g++"), shutil.which("gcc")
     rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
     os.makedirs(OUT_DIR, exist_ok=True)
-    shim = os.path.join(OUT_DIR, "liboracle_shim.so")
-    r = subprocess.run([gcc, "-O2", "-fPIC", "-shared", "-I", os.path.join(ROOT, "include"), os.path.join(HERE, "oracle_shim.c"),
+    san = SANITIZE_FLAGS if sanitize else []
+    sfx = "_asan" if sanitize else ""
+    shim = os.path.join(OUT_DIR, f"liboracle_shim{sfx}.so")
+    r = subprocess.run([gcc, "-O1" if sanitize else "-O2", "-fPIC", "-shared"] + san +
+                       ["-I", os.path.join(ROOT, "include"), os.path.join(HERE, "oracle_shim.c"),
                         os.path.join(ROOT, "oracle", "spblas_oracle.c"), "-o", shim], capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("gcc failed on oracle_shim.c:\n" + r.stderr[-4000:])
     from concurrent.futures import ThreadPoolExecutor
     with tempfile.TemporaryDirectory() as tmp:
         scratch = patched_reference_headers(os.path.join(tmp, "patched"))
-        common = [gxx, "-O1", "-I", os.path.join(HERE, "stubs_host")] + compile_flags(scratch)
+        common = [gxx, "-O1", "-I", os.path.join(HERE, "stubs_host")] + san + compile_flags(scratch)
         sources = [os.path.join(REF_TEST_DIR, s) for s in REF_TEST_SOURCES] + [os.path.join(HERE, "gtest_main.cpp")]
         objs = [os.path.join(tmp, f"d{i}.o") for i in range(len(sources))]
 
@@ -331,9 +343,9 @@ def build_reference_device_tests_on_oracle(jobs=4):
             for i, r in enumerate(pool.map(compile_one, range(len(sources)))):
                 if r.returncode != 0:
                     raise RuntimeError(f"g++ failed on {sources[i]}:\n" + r.stderr[-8000:])
-        r = subprocess.run([gxx] + objs + [shim, "-L", os.path.join(rocm, "lib"), "-lamdhip64", "-Wl,-rpath,$ORIGIN",
-                                           "-Wl,-rpath," + os.path.join(rocm, "lib"), "-o", ORACLE_DEVICE_TESTS],
+        r = subprocess.run([gxx] + san + objs + [shim, "-L", os.path.join(rocm, "lib"), "-lamdhip64", "-Wl,-rpath,$ORIGIN",
+                                                 "-Wl,-rpath," + os.path.join(rocm, "lib"), "-o", ORACLE_DEVICE_TESTS + sfx],
                            capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("link of reference_device_tests_on_oracle failed:\n" + r.stderr[-8000:])
-    return ORACLE_DEVICE_TESTS
+    return ORACLE_DEVICE_TESTS + sfx

@@ -59,3 +59,28 @@ def test_oracle_passes_the_reference_device_tests():
     tail = r.stdout[-3000:] + "\n" + r.stderr[-3000:]
     assert r.returncode == 0, tail
     assert "14 tests ran, 0 failed" in r.stdout, tail
+
+
+@pytest.mark.parametrize("which", ["host", "device"])
+def test_cpu_stack_is_clean_under_asan_and_ubsan(which):
+    """The reference's -DENABLE_SANITIZERS configuration (/root/reference/CMakeLists.txt:9,113-117:
+    -fsanitize=address,undefined) applied to everything of this build that runs on the CPU: the reference's unmodified
+    test files, the drop-in overloads (include/spblas/vendor/gfx950/*.hpp), the state objects and lifetimes of
+    detail/backend_calls.hpp, tests/compile_check/oracle_shim.c and oracle/spblas_oracle.c -- 28 host + 14 device tests
+    with -fno-sanitize-recover=all, so any heap / stack error, leak or undefined operation fails the run.  (CPU only: GPU
+    sanitizers are not available on this pool.)"""
+    build = build_dropin.build_reference_host_tests_on_oracle if which == "host" else \
+        build_dropin.build_reference_device_tests_on_oracle
+    binp = (build_dropin.ORACLE_HOST_TESTS if which == "host" else build_dropin.ORACLE_DEVICE_TESTS) + "_asan"
+    if os.path.isdir(build_dropin.REF):
+        binp = build(sanitize=True)
+        assert binp
+    elif not os.path.exists(binp):
+        pytest.skip("no reference tree here and no prebuilt sanitizer binary")
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0:halt_on_error=1",
+               UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
+    r = subprocess.run([binp], capture_output=True, text=True, timeout=900, env=env)
+    tail = r.stdout[-2000:] + "\n" + r.stderr[-4000:]
+    assert r.returncode == 0, tail
+    assert ("28 tests ran, 0 failed" if which == "host" else "14 tests ran, 0 failed") in r.stdout, tail
+    assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error:" not in r.stderr, tail
