@@ -186,6 +186,23 @@ inline int readback_flush(spblas_gfx950_handle_s* h) {
   return e == hipSuccess ? SPBLAS_GFX950_STATUS_SUCCESS : hip_fail(e);
 }
 
+// Every function that queues read-backs holds one of these: whatever path it leaves by, nothing stays queued that
+// points at its stack frame or at memory it frees (readback_flush hands bytes out to the queued destinations; an error
+// return between readback_add and readback_flush used to leave them behind for the NEXT flush of the handle).
+struct readback_scope {
+  spblas_gfx950_handle_s* h;
+  explicit readback_scope(spblas_gfx950_handle_s* handle) : h(handle) {}
+  readback_scope(const readback_scope&) = delete;
+  readback_scope& operator=(const readback_scope&) = delete;
+  ~readback_scope() {
+    if (h && (h->n_pending != 0 || h->pinned_used != 0)) {
+      (void) hipStreamSynchronize(h->stream);  // the copy kernels may still be using the staging buffer
+      h->n_pending = 0;
+      h->pinned_used = 0;
+    }
+  }
+};
+
 template <typename T>
 struct scalar_of;
 template <>

@@ -694,8 +694,11 @@ extern "C" int spblas_gfx950_spmm_inspect(spblas_gfx950_handle_t handle, spblas_
     return SPBLAS_GFX950_STATUS_INVALID_POINTER;
   if (plan->mm_ready)
     return SPBLAS_GFX950_STATUS_SUCCESS;
-  return plan->offset_type == SPBLAS_GFX950_I32 ? spmm_inspect_typed<int32_t>(handle, plan)
-                                                : spmm_inspect_typed<int64_t>(handle, plan);
+  const int rc = plan->offset_type == SPBLAS_GFX950_I32 ? spmm_inspect_typed<int32_t>(handle, plan)
+                                                         : spmm_inspect_typed<int64_t>(handle, plan);
+  if (rc != SPBLAS_GFX950_STATUS_SUCCESS)
+    spmm_plan_free(handle, plan);  // a failed inspect leaves no half-built panel tables behind and is retried (mm_ready = 0)
+  return rc;
 }
 
 extern "C" int spblas_gfx950_spmm_plan_info(spblas_gfx950_plan_t plan, int64_t info[4]) {

@@ -1403,6 +1403,7 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
   if (nnz > INT32_MAX - 8)
     return SPBLAS_GFX950_STATUS_NOT_SUPPORTED;
   int rc;
+  readback_scope rb_scope(h);  // several read-backs below land in locals of this frame
   pb_tracer tr(s);
   const O* rowptr = static_cast<const O*>(pl->rowptr);
   // Matrices with many empty rows (graphs: 56 % of the rows of R-MAT scale 24) are tiled over their NON-EMPTY rows
@@ -1812,8 +1813,11 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
   typedef typename pb_hdr<T>::type hdr_t;
   const bool staged = S <= PB_STAGE_MAX_S && env_int("SPBLAS_GFX950_PB_STAGED_SCATTER", 1);
   int enc8 = env_int("SPBLAS_GFX950_PB_ENC8", 1);
+  // ... and only when the wave-bins alone fill the chip: with fewer wavefronts in flight (row shards of a multi-GPU run,
+  // K-split plans) the longer decode chain per group is no longer hidden -- cfg2 shards on one box, one-byte codes vs
+  // 16-bit rows: 5 M rows (2 034 bins) 156.9 vs 162.8 us, 2.5 M (1 017 bins) 103.3 vs 93.1, 1.25 M 63.2 vs 58.3.
   if (!staged || max_run > (unsigned long long) PB_SORT_MAX || placed_total == 0 ||
-      (enc8 == 1 && (double) H * (double) ne > 40.0 * (double) placed_total))
+      (enc8 == 1 && ((double) H * (double) ne > 40.0 * (double) placed_total || NB < 1536)))
     enc8 = 0;
   pl->enc8 = enc8 ? 1 : 0;
   pl->exc_cap = PB_EXC_CAP;
@@ -2105,6 +2109,7 @@ static int ensure_host_binrow(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
   if (!pl->s_binrow || pl->h_binrow)
     return SPBLAS_GFX950_STATUS_SUCCESS;
   const size_t bytes = (size_t) (pl->n_rblk + 1) * 4;
+  readback_scope rb_scope(h);  // hb / ho are freed on the error paths below
   int32_t* hb = static_cast<int32_t*>(std::malloc(bytes));
   int32_t* ho = pl->s_nzrow ? static_cast<int32_t*>(std::malloc(bytes)) : nullptr;
   int32_t* d_orig = nullptr;

@@ -90,7 +90,15 @@ def patched_reference_headers(dst):
     t = _edit(t, "#ifdef SPBLAS_ENABLE_ROCSPARSE\npublic:\n  __rocsparse::operation_state_t state_;\n#endif\n",
               "\n#ifdef SPBLAS_ENABLE_GFX950\npublic:\n  __gfx950::operation_state_t state_;\n#endif\n")
     store("spblas/detail/operation_info_t.hpp", t)
-    # views/matrix_opt_impl.hpp (optional edit of INTEGRATION.md section 2: plan cache in the matrix_opt)
+    # views/matrix_opt_impl.hpp:25-28,90-92 -- the plan cache of a matrix_opt (oneMKL keeps its optimised handle the same way)
+    t = load("spblas/views/matrix_opt_impl.hpp")
+    t = _edit(t, "#include <spblas/concepts.hpp>\n",
+              "\n#ifdef SPBLAS_ENABLE_GFX950\n#include <memory>\n#include <spblas/vendor/gfx950/detail/backend_calls.hpp>\n#endif\n")
+    t = _edit(t, "  matrix_opt(M matrix) : matrix_(matrix) {\n",
+              "#ifdef SPBLAS_ENABLE_GFX950\n    gfx950_state_ = std::make_shared<__gfx950::opt_cache_t>();\n#endif\n")
+    t = _edit(t, "public:\n  M matrix_;\n",
+              "\n#ifdef SPBLAS_ENABLE_GFX950\n  std::shared_ptr<__gfx950::opt_cache_t> gfx950_state_;  // shared by the copies of the view\n#endif\n")
+    store("spblas/views/matrix_opt_impl.hpp", t)
     return dst
 
 

@@ -193,6 +193,24 @@ int main() {
     operation_info_t info_opt = multiply_inspect(a_opt, x, y);
     multiply(info_opt, a_opt, x, y);
     expect(close_vec(dy.host(), want, absrow), "multiply(info, matrix_opt(a), x, y)");
+    {
+      // the plan lives in the matrix_opt (views/matrix_opt_impl.hpp:25-28,90-92 is where oneMKL keeps its handle): a
+      // multiply WITHOUT info, also through a view stacked on a copy of a_opt, reuses it -- one plan built, ever
+      auto* cached = a_opt.gfx950_state_->get<__gfx950::spmv_state_t>();
+      expect(cached != nullptr && cached->plans_built() == 1 && cached->plan() != nullptr,
+             "multiply_inspect(matrix_opt(a), ...) keeps the plan in the view");
+      HIP_OK(hipMemset(dy.p, 0xFF, m * sizeof(T)));
+      multiply(a_opt, x, y);
+      expect(close_vec(dy.host(), want, absrow), "multiply(matrix_opt(a), x, y) without info");
+      std::vector<double> want2, abs2;
+      host_spmv(ha, hx, 3.0, want2, abs2);
+      multiply(scaled(3.0f, a_opt), x, y);
+      expect(close_vec(dy.host(), want2, abs2), "multiply(scaled(alpha, matrix_opt(a)), x, y) without info");
+      std::int64_t pinfo[12] = {0};
+      expect(spblas_gfx950_plan_info(cached->plan(), pinfo) == SPBLAS_GFX950_STATUS_SUCCESS && pinfo[0] != 0 &&
+                 a_opt.gfx950_state_->get<__gfx950::spmv_state_t>() == cached && cached->plans_built() == 1,
+             "second and third call did not plan again (spblas_gfx950_plan_info on the cached plan)");
+    }
     host_spmv(ha, hx, -2.5, want, absrow);
     multiply(scaled(-2.5f, a), x, y);
     expect(close_vec(dy.host(), want, absrow), "multiply(scaled(alpha, a), x, y)");
@@ -205,6 +223,30 @@ int main() {
     host_spmv(ha, hx, 1.0, want, absrow);
     multiply(a_csc, x, y);
     expect(close_vec(dy.host(), want, absrow), "multiply(csc_view, x, y)");
+    {
+      // inspected csc_view: the row-major form is materialised once (csc_spmv_state_t) and the regular kernels run;
+      // the result equals the atomics path above to rounding (vendor/rocsparse/detail/get_transpose.hpp:19-29 semantics)
+      const std::vector<T> y_atomics = dy.host();
+      HIP_OK(hipMemset(dy.p, 0xFF, m * sizeof(T)));
+      operation_info_t info_csc = multiply_inspect(a_csc, x, y);
+      auto* st = info_csc.state_.get_state<__gfx950::csc_spmv_state_t<T>>();
+      expect(st != nullptr && st->inspections() == 1, "multiply_inspect(csc_view, ...) materialises the transpose once");
+      multiply(info_csc, a_csc, x, y);
+      multiply(info_csc, a_csc, x, y);
+      const std::vector<T> y_insp = dy.host();
+      expect(close_vec(y_insp, want, absrow) && st->inspections() == 1, "multiply(info, csc_view, x, y) after multiply_inspect");
+      bool same = true;
+      for (std::size_t i = 0; i < y_insp.size(); ++i)
+        same = same && std::fabs(static_cast<double>(y_insp[i]) - y_atomics[i]) <= 2e-6 * absrow[i] + 1e-30;
+      expect(same, "inspected csc_view result equals the atomics path to rounding");
+      // ... and through a matrix_opt over the csc_view, without info
+      matrix_opt c_opt(a_csc);
+      multiply_inspect(c_opt, x, y);
+      HIP_OK(hipMemset(dy.p, 0xFF, m * sizeof(T)));
+      multiply(c_opt, x, y);
+      expect(close_vec(dy.host(), want, absrow) && c_opt.gfx950_state_->get<__gfx950::csc_spmv_state_t<T>>() != nullptr,
+             "multiply(matrix_opt(csc_view), x, y) without info");
+    }
     // y2 = A^T x2 through transposed(a)
     std::vector<T> hx2(m);
     for (auto& v : hx2)
