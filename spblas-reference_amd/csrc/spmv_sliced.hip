@@ -80,7 +80,7 @@ static constexpr int PB_GRP = 256;              // entries per reduce step: 64 l
 //   s_hdr[blk]  per block: row of the block's first entry (u16) + one duplicate flag per entry (the bit the u16
 //               encoding keeps in bit 15 of the row word); 8 B per 32 fp32 entries, 4 B per 16 fp64 entries
 //   exceptions  per wave-bin, at most exc_cap of them: (P index, row); the reduce adds them with the LDS float atomic
-//               after its main pass.  A bin with more exceptions, or a run too long to sort in registers, sets
+//               after its main pass.  A bin with more exceptions, or a run larger than the inspect's staging area, sets
 //               enc_fail and the plan is rebuilt with the 16-bit rows.
 // The decoder's row D of entry j of a block is base + code_1 + ... + code_j: D_j = min(r_j, D_{j-1} + 255), i.e.
 // D_j = 255 j + min_{k <= j} (r_k - 255 k) -- a prefix minimum at inspect, a prefix sum in the reduce.
@@ -103,7 +103,6 @@ struct pb_hdr<double> {
   static __device__ __forceinline__ unsigned base(type h) { return h >> 16; }
   static __device__ __forceinline__ unsigned flags(type h) { return h & 0xffffu; }
 };
-static constexpr int PB_SORT_MAX = 512;  // longest run the inspect sorts in registers (8 entries per lane)
 static constexpr int PB_EXC_CAP = 128;   // exceptions a wave-bin may hold
 
 // value of lane - o (o = 1, 2, 4) inside the 16-lane DPP row; lanes without a source get 0
@@ -450,50 +449,77 @@ __global__ __launch_bounds__(256) void pb_scatter_kernel(int64_t m, const O* __r
 static constexpr int PB_STAGE_THREADS = 1024;
 static constexpr int PB_STAGE_LDS = 160 * 1024;
 static constexpr int PB_STAGE_MAX_S = 2048;
+static constexpr int PB_STAGE_SP = 256;  // enc8: at most this many slices (per-wave, per-slice cursors in LDS)
 
-// enc8 write-out of one staged run by one wavefront: sort the run by source position (= by row: positions grow with the
-// row), then emit values / columns / source positions in that order and the one-byte row codes, block bases and
-// exceptions.  R = entries a lane holds while ranking (the run has at most 64 R entries).
-template <typename T, int R, typename RowOf>
-__device__ __forceinline__ void pb_emit_sorted_run(int n, int lo, int g, int gp, int p0, int lane, int* __restrict__ st,
-                                                   T* __restrict__ stv, uint16_t* __restrict__ stc, RowOf row_of,
+// A staged run of the ordered staging is sorted except inside ROUNDS: the entries one wavefront staged from one round of
+// 64 consecutive source positions (equal q >> 6, adjacent in the run, a handful at most) took their places in the
+// order the LDS atomic served the lanes.  Sort every such group in place by position: each lane ranks its entry inside
+// its group (a walk to both ends of the group) and the chunk is rewritten one chunk behind the reads, so that a group
+// straddling two chunks of 64 is read whole before any of it is overwritten (a group has at most 64 entries).
+template <typename T>
+__device__ __forceinline__ void pb_sort_rounds(int n, int lo, int lane, int* __restrict__ st, T* __restrict__ stv,
+                                               uint16_t* __restrict__ stc) {
+  struct item_t {
+    int q, np;
+    T v;
+    uint16_t c;
+  };
+  auto load = [&](int ch) {
+    item_t it;
+    const int j = ch * 64 + lane;
+    it.q = -1;
+    it.np = -1;
+    it.v = T(0);
+    it.c = 0;
+    if (j < n) {
+      it.q = st[lo + j];
+      it.v = stv[lo + j];
+      it.c = stc[lo + j];
+      const int gid = it.q >> 6;
+      int start = j, smaller = 0;
+      for (int k = j - 1; k >= 0; --k) {
+        const int qk = st[lo + k];
+        if ((qk >> 6) != gid)
+          break;
+        start = k;
+        smaller += qk < it.q ? 1 : 0;
+      }
+      for (int k = j + 1; k < n; ++k) {
+        const int qk = st[lo + k];
+        if ((qk >> 6) != gid)
+          break;
+        smaller += qk < it.q ? 1 : 0;
+      }
+      it.np = start + smaller;
+    }
+    return it;
+  };
+  const int nch = (n + 63) >> 6;
+  item_t cur = load(0);
+  for (int ch = 0; ch < nch; ++ch) {
+    item_t nxt = cur;
+    if (ch + 1 < nch)
+      nxt = load(ch + 1);
+    if (cur.np >= 0 && cur.np != ch * 64 + lane) {
+      st[lo + cur.np] = cur.q;
+      stv[lo + cur.np] = cur.v;
+      stc[lo + cur.np] = cur.c;
+    }
+    cur = nxt;
+  }
+}
+
+// enc8 write-out of one staged run by one wavefront.  The run lies in the staging area sorted by source position (= by
+// row: positions grow with the row; the ordered staging of pb_scatter_staged_kernel sees to that): emit values /
+// columns / source positions in that order and the one-byte row codes, block bases and exceptions.
+template <typename T, typename RowOf>
+__device__ __forceinline__ void pb_emit_sorted_run(int n, int lo, int g, int gp, int p0, int lane, const int* __restrict__ st,
+                                                   const T* __restrict__ stv, const uint16_t* __restrict__ stc, RowOf row_of,
                                                    T* __restrict__ s_val, uint16_t* __restrict__ s_col,
                                                    int32_t* __restrict__ perm, unsigned char* __restrict__ s_code,
                                                    typename pb_hdr<T>::type* __restrict__ s_hdr, int* exc_n, int exc_cap,
                                                    unsigned* __restrict__ exc_idx, uint16_t* __restrict__ exc_row) {
   constexpr int PB_BLK = pb_geom<T>::BLK;
-  int q[R], rank[R];
-  T v[R];
-  uint16_t c[R];
-#pragma unroll
-  for (int t = 0; t < R; ++t) {
-    const int i = lane + 64 * t;
-    const bool in = i < n;
-    q[t] = in ? st[lo + i] : 0x7fffffff;
-    v[t] = in ? stv[lo + i] : T(0);
-    c[t] = in ? stc[lo + i] : (uint16_t) 0;
-    rank[t] = 0;
-  }
-  // rank = entries of the run with a smaller source position (positions are unique): broadcast reads of the run
-  for (int k = 0; k < n; k += 4) {
-    int qk[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      qk[j] = k + j < n ? st[lo + k + j] : 0x7fffffff;
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int t = 0; t < R; ++t)
-        rank[t] += qk[j] < q[t] ? 1 : 0;
-  }
-  // in place: every lane has read all it needs (LDS operations of one wavefront complete in order)
-#pragma unroll
-  for (int t = 0; t < R; ++t)
-    if (lane + 64 * t < n) {
-      st[lo + rank[t]] = q[t];
-      stv[lo + rank[t]] = v[t];
-      stc[lo + rank[t]] = c[t];
-    }
   const int nb = (n + PB_BLK - 1) / PB_BLK;
   for (int j0 = 0; j0 < nb * PB_BLK; j0 += 64) {
     const int j = j0 + lane;
@@ -550,7 +576,9 @@ __global__ __launch_bounds__(PB_STAGE_THREADS) void pb_scatter_staged_kernel(
   int* lcur = pdst + S;                      // [S] staging cursor (local offset, advanced by the atomics)
   int* rp = lcur + S;                        // [H + 1] the bin's row offsets relative to its first entry
   int* rt = rp + H + 1;                      // [rt_len] row of every 64th entry (narrows the row search)
-  int* st = rt + rt_len;                     // [cap] staged entries: position relative to the first entry,
+  // enc8: [16 waves][PB_STAGE_SP] entries of the pass per (wave, slice) -> first staging position of that wave's part
+  int* wcnt = rt + rt_len;
+  int* st = wcnt + (ENC8 ? (PB_STAGE_THREADS / 64) * PB_STAGE_SP : 0);  // [cap] staged entries: position relative to the first entry,
   T* stv = reinterpret_cast<T*>(st + cap);   // [cap] value,
   uint16_t* stc = reinterpret_cast<uint16_t*>(stv + cap);  // [cap] column inside the slice
   __shared__ int pass_end, pass_direct;
@@ -607,6 +635,57 @@ __global__ __launch_bounds__(PB_STAGE_THREADS) void pb_scatter_staged_kernel(
     const int k = q >> 6;
     return row_between(q, rt[k], rt[k + 1] + 1);
   };
+  // slice of column c (exact: float reciprocal + one correction step; S <= 256 slices keep the quotient far inside the
+  // float's 24 bits), or -1 for an entry of a hub row that stays out of the tiles
+  const float inv_w = 1.0f / (float) W;
+  auto slice_of = [&](int q, int c) {
+    int sl = (int) ((float) c * inv_w);
+    if (sl * W > c)
+      --sl;
+    else if ((sl + 1) * W <= c)
+      ++sl;
+    if (hub_len > 0) {
+      const int r = row_of(q);
+      if (rp[r + 1] - rp[r] > hub_len)
+        return -1;
+    }
+    return sl;
+  };
+  if (ENC8) {
+    // entries per (wave, slice) of the whole bin, then -- per slice -- the exclusive scan over the waves
+    constexpr int NW = PB_STAGE_THREADS / 64;
+    const int L = (((ne + NW - 1) / NW) + 63) & ~63;
+    const int qlo = wave * L, qhi = (qlo + L) < ne ? (qlo + L) : ne;
+    for (int i = tid; i < NW * PB_STAGE_SP; i += PB_STAGE_THREADS)
+      wcnt[i] = 0;
+    __syncthreads();
+    constexpr int CU4 = 4;
+    for (int qb = qlo; qb < qhi; qb += 64 * CU4) {
+      int cbuf[CU4];
+#pragma unroll
+      for (int u = 0; u < CU4; ++u) {
+        const int q = qb + 64 * u + lane;
+        cbuf[u] = colind[p0 + (q < qhi ? q : qhi - 1)];
+      }
+#pragma unroll
+      for (int u = 0; u < CU4; ++u) {
+        const int q = qb + 64 * u + lane;
+        const int sl = q < qhi ? slice_of(q, cbuf[u]) : -1;
+        if (sl >= 0)
+          atomicAdd(&wcnt[wave * PB_STAGE_SP + sl], 1);
+      }
+    }
+    __syncthreads();
+    for (int sl = tid; sl < S; sl += PB_STAGE_THREADS) {
+      int run = 0;
+      for (int w = 0; w < NW; ++w) {
+        const int t = wcnt[w * PB_STAGE_SP + sl];
+        wcnt[w * PB_STAGE_SP + sl] = run;
+        run += t;
+      }
+    }
+    __syncthreads();
+  }
   int s0 = 0;
   while (s0 < S) {
     // wave 0: the longest slice range [s0, s1) whose entries fit the staging area, and their local offsets
@@ -645,6 +724,47 @@ __global__ __launch_bounds__(PB_STAGE_THREADS) void pb_scatter_staged_kernel(
     __syncthreads();
     const int s1 = pass_end;
     const bool direct = pass_direct != 0;
+    if (ENC8 && !direct) {
+      // Ordered staging (the one-byte row codes want every run sorted by row = by source position).  Wave w owns the
+      // contiguous positions [w L, (w + 1) L) of the bin (L a multiple of 64) and walks them in order, 64 at a time;
+      // the per-(wave, slice) counts of the whole bin were taken once, before the passes (wcnt: the offset of the wave's
+      // part inside every run), so a pass only places: position = run start + the wave's offset + a wave-private LDS
+      // cursor.  Entries of one wave and one slice are staged round by round in position order; only the lanes of ONE
+      // round that share a slice may come out permuted -- pb_sort_rounds puts those few back before the run is emitted.
+      // (Sorting whole runs by rank cost 2.1 ms of a 3.5 ms scatter at cfg2; a ballot match per round and pass with a
+      // second counting sweep per pass 1.6 ms and 6.0 instead of 3.3 GB of reads.)
+      constexpr int NW = PB_STAGE_THREADS / 64;
+      const int L = (((ne + NW - 1) / NW) + 63) & ~63;
+      const int qlo = wave * L, qhi = (qlo + L) < ne ? (qlo + L) : ne;
+      int* mycur = wcnt + wave * PB_STAGE_SP;
+      for (int i = tid; i < (s1 - s0) * NW; i += PB_STAGE_THREADS) {  // cursors of this pass: run start + wave offset
+        const int w = i / (s1 - s0), sl = s0 + i % (s1 - s0);
+        wcnt[w * PB_STAGE_SP + sl] += lcur[sl];
+      }
+      __syncthreads();
+      constexpr int CU4 = 4;  // rounds whose column loads are issued together
+      for (int qb = qlo; qb < qhi; qb += 64 * CU4) {
+        int cbuf[CU4];
+#pragma unroll
+        for (int u = 0; u < CU4; ++u) {
+          const int q = qb + 64 * u + lane;
+          cbuf[u] = colind[p0 + (q < qhi ? q : qhi - 1)];
+        }
+#pragma unroll
+        for (int u = 0; u < CU4; ++u) {
+          const int q = qb + 64 * u + lane;
+          const int c = cbuf[u];
+          const int sl = q < qhi ? slice_of(q, c) : -1;
+          if (sl >= s0 && sl < s1) {
+            const int pos = atomicAdd(&mycur[sl], 1);
+            st[pos] = q;
+            stv[pos] = values[p0 + q];
+            stc[pos] = (uint16_t) (c - sl * W);
+          }
+        }
+      }
+      __syncthreads();
+    } else {
     // eight column loads per thread are issued before the first is used: with one workgroup per CU the
     // loop is bound by load latency, not bandwidth
     constexpr int LU = 8;
@@ -687,6 +807,7 @@ __global__ __launch_bounds__(PB_STAGE_THREADS) void pb_scatter_staged_kernel(
       }
     }
     __syncthreads();
+    }
     if (ENC8 && direct && tid == 0)
       atomicExch(enc_fail, 1);
     if (!direct) {
@@ -695,23 +816,15 @@ __global__ __launch_bounds__(PB_STAGE_THREADS) void pb_scatter_staged_kernel(
       // L2 hits, run at ~10 cycles per request and CU)
       constexpr int NW = PB_STAGE_THREADS / 64;
       for (int sl = s0 + wave; sl < s1; sl += NW) {
-        const int n = lcnt[sl], lo = lcur[sl] - n, g = gdst[sl], gp = pdst[sl];
+        const int n = lcnt[sl], lo = ENC8 ? lcur[sl] : lcur[sl] - n, g = gdst[sl], gp = pdst[sl];
         if (ENC8) {
           unsigned* ei = exc_idx + (size_t) wb * exc_cap;
           uint16_t* er = exc_row + (size_t) wb * exc_cap;
-          if (n > PB_SORT_MAX) {
-            if (lane == 0)
-              atomicExch(enc_fail, 1);
-          } else if (n > 256) {
-            pb_emit_sorted_run<T, 8>(n, lo, g, gp, (int) p0, lane, st, stv, stc, row_of, s_val, s_col, perm, s_code, s_hdr,
-                                     &exc_n, exc_cap, ei, er);
-          } else if (n > 128) {
-            pb_emit_sorted_run<T, 4>(n, lo, g, gp, (int) p0, lane, st, stv, stc, row_of, s_val, s_col, perm, s_code, s_hdr,
-                                     &exc_n, exc_cap, ei, er);
-          } else if (n > 0) {
-            pb_emit_sorted_run<T, 2>(n, lo, g, gp, (int) p0, lane, st, stv, stc, row_of, s_val, s_col, perm, s_code, s_hdr,
-                                     &exc_n, exc_cap, ei, er);
-          }
+          if (n > 1)
+            pb_sort_rounds<T>(n, lo, lane, st, stv, stc);
+          if (n > 0)
+            pb_emit_sorted_run<T>(n, lo, g, gp, (int) p0, lane, st, stv, stc, row_of, s_val, s_col, perm, s_code, s_hdr,
+                                  &exc_n, exc_cap, ei, er);
           continue;
         }
         for (int j = lane; j < n; j += 64) {
@@ -1808,15 +1921,16 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
   if ((rc = dev_alloc((void**) &pl->s_blkdst, (size_t) (a_blocks + 8) * 4, s)))
     return rc;
   // Row stream of the reduce: one-byte codes when the tiles are dense enough for them (the average row advance inside
-  // a run is H * (non-empty tiles) / entries: beyond ~40 rows too many entries become exceptions), no run is too long
-  // to be sorted in registers and the staged scatter (which sorts) is in use; otherwise 16-bit rows.
+  // a run is H * (non-empty tiles) / entries: beyond ~40 rows too many entries become exceptions) and the staged scatter
+  // (whose ordered staging leaves every run sorted by row) is in use; otherwise 16-bit rows.
   typedef typename pb_hdr<T>::type hdr_t;
   const bool staged = S <= PB_STAGE_MAX_S && env_int("SPBLAS_GFX950_PB_STAGED_SCATTER", 1);
   int enc8 = env_int("SPBLAS_GFX950_PB_ENC8", 1);
   // ... and only when the wave-bins alone fill the chip: with fewer wavefronts in flight (row shards of a multi-GPU run,
   // K-split plans) the longer decode chain per group is no longer hidden -- cfg2 shards on one box, one-byte codes vs
   // 16-bit rows: 5 M rows (2 034 bins) 156.9 vs 162.8 us, 2.5 M (1 017 bins) 103.3 vs 93.1, 1.25 M 63.2 vs 58.3.
-  if (!staged || max_run > (unsigned long long) PB_SORT_MAX || placed_total == 0 ||
+  (void) max_run;
+  if (!staged || placed_total == 0 || S > PB_STAGE_SP ||
       (enc8 == 1 && ((double) H * (double) ne > 40.0 * (double) placed_total || NB < 1536)))
     enc8 = 0;
   pl->enc8 = enc8 ? 1 : 0;
@@ -1936,9 +2050,13 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
   tr.mark("work lists");
   // a quarter of the staging area at most goes to the row table (one entry per 64 matrix entries of a bin)
   const int rt_len = 2048;
-  const int cap = (int) (((size_t) PB_STAGE_LDS - (size_t) 16 * S - (size_t) 4 * (H + 1) - (size_t) 4 * rt_len - 128) /
-                         (6 + sizeof(T))) & ~7;
+  auto stage_cap = [&](bool e8) {
+    return (int) (((size_t) PB_STAGE_LDS - (size_t) 16 * S - (size_t) 4 * (H + 1) - (size_t) 4 * rt_len - 128 -
+                   (e8 ? (size_t) (PB_STAGE_THREADS / 64) * PB_STAGE_SP * 4 : 0)) /
+                  (6 + sizeof(T))) & ~7;
+  };
   auto launch_staged = [&](bool e8) {
+    const int cap = stage_cap(e8);
     const void* fn = e8 ? reinterpret_cast<const void*>(pb_scatter_staged_kernel<T, O, true>)
                         : reinterpret_cast<const void*>(pb_scatter_staged_kernel<T, O, false>);
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, PB_STAGE_LDS - 64);
