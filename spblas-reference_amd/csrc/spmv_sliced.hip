@@ -1984,7 +1984,8 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
       }
     } else if (total > 0 && (int64_t) max_slice * S > 3 * total) {
       const int cus = h->num_cus > 0 ? h->num_cus : 256;
-      const int64_t target = std::max<int64_t>(cdiv(a_blocks, 2 * cus), 4 * (int64_t) W / PB_BLK);
+      const int64_t target = std::max<int64_t>(cdiv(a_blocks, (int64_t) env_int("SPBLAS_GFX950_PB_XITEM_DIV", 2) * cus),
+                                               4 * (int64_t) W / PB_BLK);
       std::vector<int4> items;
       for (int i = 0; i < S; ++i) {
         const int64_t lo = h_sliceblk[(size_t) i], hi = h_sliceblk[(size_t) i + 1];
@@ -1999,6 +2000,10 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
         }
       }
       if (!items.empty()) {
+        // workgroups are dispatched in list order: with more items than CUs the heaviest go first (longest processing
+        // time first), so that no large item starts late and finishes alone (SPBLAS_GFX950_PB_LPT=0: list order = slice order)
+        if (env_int("SPBLAS_GFX950_PB_LPT", 1))
+          std::stable_sort(items.begin(), items.end(), [](const int4& a, const int4& b) { return a.z - a.y > b.z - b.y; });
         if ((rc = dev_alloc(&pl->s_xitems, items.size() * sizeof(int4), s)))
           return rc;
         if ((rc = upload_add(h, pl->s_xitems, items.data(), items.size() * sizeof(int4))) || (rc = readback_flush(h)))
@@ -2013,27 +2018,47 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
     // rows into a compact buffer and pb_combine_items_kernel adds them in part order (bit reproducible).
     const int64_t total = (int64_t) placed_total, max_tot = (int64_t) max_group;
     const int force_items = env_int("SPBLAS_GFX950_PB_RITEMS", 0);  // experiment: work list whatever the skew; value = parts per 1/768 of the entries
-    if (total > 0 && (max_tot * ngroups > 3 * total || force_items > 0) && ngroups > 1) {
+    // variable-height bins with more workgroups than the chip holds at once (cfg4: 1 425 groups of 4 bins, 512 slots, the
+    // heaviest group 0.87 of a slot's share): a work list ordered heaviest first, so that a heavy group never starts late
+    const int cus_r = h->num_cus > 0 ? h->num_cus : 256;
+    const bool lpt = env_int("SPBLAS_GFX950_PB_LPT", 1) && varbins && ngroups > 2 * (int64_t) cus_r && max_tot * ngroups > (3 * total) / 2;
+    if (total > 0 && (max_tot * ngroups > 3 * total || force_items > 0 || lpt) && ngroups > 1) {
       const int64_t target = std::max<int64_t>(total / (768 * (force_items > 0 ? force_items : 1)), 16384);
       const int64_t block = (int64_t) RW * H;  // values per partial block
       std::vector<int4> items, split;
+      std::vector<int64_t> weight;  // entries per item (for the heaviest-first order)
       int64_t poff = 0;
       for (int64_t g = 0; g < ngroups; ++g) {
         const int64_t tot_g = (int64_t) h_sum[(size_t) (2 * S + g)];
         int64_t Kg = (tot_g + target / 2) / target;
+        if (lpt && force_items <= 0 && max_tot * ngroups <= 3 * total)
+          Kg = 1;  // ordering only: no group is heavy enough to be cut
         // a part should still hold a few groups of every wave-bin's stream
         Kg = std::max<int64_t>(1, std::min<int64_t>(Kg, std::max<int64_t>(1, tot_g / ((int64_t) RW * 4 * PB_GRP))));
         Kg = std::min<int64_t>(Kg, 256);
         if (Kg == 1 || poff + Kg * block > (int64_t) INT32_MAX) {  // offsets are 32-bit: stop splitting
           items.push_back(make_int4((int) g, 0, 1, -1));
+          weight.push_back(tot_g);
           continue;
         }
-        for (int64_t k = 0; k < Kg; ++k)
+        for (int64_t k = 0; k < Kg; ++k) {
           items.push_back(make_int4((int) g, (int) k, (int) Kg, (int) (poff + k * block)));
+          weight.push_back(tot_g / Kg);
+        }
         split.push_back(make_int4((int) g, (int) Kg, (int) poff, 0));
         poff += Kg * block;
       }
-      if (!split.empty()) {
+      if (env_int("SPBLAS_GFX950_PB_LPT", 1) && (int64_t) items.size() > 2 * (int64_t) cus_r) {
+        std::vector<size_t> order(items.size());
+        for (size_t i = 0; i < order.size(); ++i)
+          order[i] = i;
+        std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return weight[a] > weight[b]; });
+        std::vector<int4> sorted(items.size());
+        for (size_t i = 0; i < order.size(); ++i)
+          sorted[i] = items[order[i]];
+        items.swap(sorted);
+      }
+      if (!split.empty() || lpt) {
         if ((rc = dev_alloc(&pl->s_ritems, items.size() * sizeof(int4), s)) ||
             (rc = dev_alloc(&pl->s_rsplit, split.size() * sizeof(int4), s)) ||
             (rc = dev_alloc(&pl->s_rpartial, (size_t) poff * sizeof(T), s)))
