@@ -50,6 +50,14 @@ def _hip_local_spmv(info, a_local, x, y_local):
     api.multiply(info, a_local, x, y_local)
 
 
+def _order_before_collective(group, tensor):
+    """RCCL collectives are ordered behind the kernels already queued on the current stream.  The gloo backend -- only
+    ever combined with device tensors by the one-GPU debug mode of bench.py and by tests -- reads device memory from the
+    host side: drain the device first, or it may ship a y the kernels have not finished writing."""
+    if tensor.is_cuda and dist.is_initialized() and dist.get_backend(group) == "gloo":
+        torch.cuda.synchronize()
+
+
 class ShardedSpMV:
     """y = A x with A row-sharded over the ranks of `group`.
 
@@ -106,6 +114,7 @@ class ShardedSpMV:
             if self.gather_mode == "padded":
                 self.y_full.copy_(self.y_local[:self.m])
             return self.y_full
+        _order_before_collective(self.group, self.y_full)
         if self.gather_mode == "inplace":
             dist.all_gather_into_tensor(self.y_full, self.y_local, group=self.group)
         elif self.gather_mode == "p2p":
@@ -211,6 +220,7 @@ class PipelinedShardedSpMV:
     def gather(self):
         """The all-gathers of every stripe alone (diagnostics)."""
         if self.world > 1:
+            _order_before_collective(self.group, self.y_full)
             for c in range(self.chunks):
                 dist.all_gather_into_tensor(self.y_stripe[c], self.y_local[c], group=self.group)
         return self.y_full
@@ -228,6 +238,7 @@ class PipelinedShardedSpMV:
             if events is not None:
                 events[c][1].record()
             if self.world > 1:
+                _order_before_collective(self.group, self.y_full)
                 works.append(dist.all_gather_into_tensor(self.y_stripe[c], self.y_local[c], group=self.group,
                                                          async_op=True))
         for w in works:

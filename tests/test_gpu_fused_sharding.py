@@ -105,3 +105,29 @@ def test_bench_single_gpu_line_is_self_checking(gpu):
     assert out["parity_check"] == "pass" and out["parity"]["rows"] == 1000000
     assert out["cpu_baseline"]["cores"] == 1 and out["cpu_baseline"]["cpu_model"]
     assert out["multi_gpu"] is None
+
+
+@pytest.mark.parametrize("world,workload,fused", [(2, "spmv", "auto"), (4, "spmv", "auto"), (2, "spmv", "off"), (2, "spmv_rmat", "auto"), (3, "spmv_rmat", "auto")])
+def test_bench_with_several_ranks_on_one_gpu(gpu, world, workload, fused):
+    """The whole N > 1 path of bench.py -- its own launcher, shard generation, row bounds (equal for cfg2, nnz-prefix
+    for the R-MAT graph), try_fused adoption over hipIpc between processes, timed loop, post-check, diagnostics and the
+    parity check of the gathered y on every rank -- with N real ranks that share cuda:0 (`--debug-one-gpu`: gloo as the
+    process-group backend, since RCCL refuses two ranks on one device).  The closest a one-GPU box gets to the driver's
+    SCALE run."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    rows = str(world * 600_000) if workload == "spmv" else str(1 << 18)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--debug-one-gpu", "--steps", "5", "--warmup",
+           "2", "--workload", workload, "--rows", rows, "--fused", fused]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1 and r.stdout.strip() == lines[0], (r.stdout[-2000:], r.stderr[-3000:])
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == world and out["parity_check"] == "pass", out["parity"]
+    mg = out["multi_gpu"]
+    assert len(mg["rows_per_rank"]) == world and sum(mg["rows_per_rank"]) == out["config"]["rows"]
+    if workload == "spmv":
+        assert mg["mode_timed"] == ("fused" if fused == "auto" else "plain")
+        assert mg["fused_post_check"] is (True if fused == "auto" else None)
+    else:
+        assert len(set(mg["rows_per_rank"])) > 1 and mg["gather"] == "p2p"   # nnz-prefix shards differ in rows
