@@ -40,9 +40,12 @@ struct spblas_gfx950_plan_s {
   void* s_sliceblk = nullptr;  // int32[S + 1]: first A'-order block of every slice
   void* s_binblk = nullptr;    // int32[NB + 1]: first P-order block of every wave-bin (multiples of 8)
   void* s_blkdst = nullptr;    // int32[a_blocks]: P-order block of every A'-order block
-  void* s_colind = nullptr;    // uint16[a_blocks*32] column inside the slice (A' order; pads 0)
-  void* s_values = nullptr;    // T[a_blocks*32] (A' order; pads 0)
-  void* s_perm = nullptr;      // int32[a_blocks*32] source position in the caller's CSR arrays (pads -1)
+  void* s_blksrc = nullptr;    // int32[a_blocks]: first entry of the block in the COMPACT A' arrays (round 3: runs occupy
+                               // their count rounded up to 4 entries there, not whole blocks)
+  int64_t a_entries = 0;       // entries the A' arrays hold (compact stream + one block of slack)
+  void* s_colind = nullptr;    // uint16[a_entries] column inside the slice (A' order, compact; pads 0)
+  void* s_values = nullptr;    // T[a_entries] (A' order, compact; pads 0)
+  void* s_perm = nullptr;      // int32[a_entries] source position in the caller's CSR arrays (pads -1)
   uint16_t* s_lrow = nullptr;  // uint16[p_blocks*32] row inside the bin | bit 15 = duplicate flag (P order; pads = H)
   // one-byte row codes instead of s_lrow (spmv_sliced.hip, "enc8"): runs sorted by row, the row advance per entry
   int enc8 = 0;

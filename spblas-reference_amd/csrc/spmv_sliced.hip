@@ -342,6 +342,15 @@ __global__ __launch_bounds__(256) void pb_nblk_kernel(int64_t nseg, const int32_
     aoff[i] = (cnt[i] + blk - 1) / blk;
 }
 
+// entries per run in the COMPACT A' stream (round 3): a run occupies its count rounded up to 4 entries -- the lanes of
+// the expand own 4 entries each, 16 / 32-byte aligned -- not whole blocks; scanned in place into eoff[]
+__global__ __launch_bounds__(256) void pb_ecnt_kernel(int64_t nseg, const int32_t* __restrict__ cnt,
+                                                      int32_t* __restrict__ eoff) {
+  const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
+  if (i < nseg)
+    eoff[i] = (cnt[i] + 3) & ~3;
+}
+
 // P order: one workgroup per wave-bin b scans the block counts of its S runs: prel[b*S + s] = blocks of the bin
 // before slice s; bintot[b] = the bin's blocks rounded up to whole groups (scanned afterwards into binblk[]).
 __global__ __launch_bounds__(256) void pb_bin_prefix_kernel(int S, int NB, const int32_t* __restrict__ cnt,
@@ -397,27 +406,29 @@ __global__ __launch_bounds__(256) void pb_scatter_kernel(int64_t m, const O* __r
                                                          const int32_t* __restrict__ binblk, T* __restrict__ s_val,
                                                          uint16_t* __restrict__ s_col, uint16_t* __restrict__ s_row,
                                                          int32_t* __restrict__ perm, int32_t* __restrict__ blkdst,
-                                                         int hub_len, const int32_t* __restrict__ binrow) {
+                                                         int hub_len, const int32_t* __restrict__ binrow,
+                                                         const int32_t* __restrict__ eoff, int32_t* __restrict__ blksrc) {
   constexpr int PB_BLK = pb_geom<T>::BLK;
   extern __shared__ int smem_i[];
-  int* cursor = smem_i;    // [S] next A' position of the run
+  int* cursor = smem_i;    // [S] next (compact) A' position of the run
   int* pdelta = smem_i + S;  // [S] P position minus A' position of the run's entries
   const int wb = blockIdx.x;
   const int pb0 = binblk[wb];
   for (int i = threadIdx.x; i < S; i += 256) {
     const int64_t key = (int64_t) i * NB + wb;
-    const int a0 = aoff[key], nb = aoff[key + 1] - a0, p0b = pb0 + prel[(int64_t) wb * S + i];
-    (void) nb;
-    cursor[i] = a0 * PB_BLK;
-    pdelta[i] = (p0b - a0) * PB_BLK;
+    const int p0b = pb0 + prel[(int64_t) wb * S + i];
+    cursor[i] = eoff[key];
+    pdelta[i] = p0b * PB_BLK - eoff[key];
   }
   __syncthreads();
   // the block map of the bin's runs: one wavefront per run, a lane per block
   for (int sl = threadIdx.x >> 6; sl < S; sl += 4) {
     const int64_t key = (int64_t) sl * NB + wb;
-    const int a0 = cursor[sl] / PB_BLK, nb = aoff[key + 1] - a0, p0b = a0 + pdelta[sl] / PB_BLK;
-    for (int k = threadIdx.x & 63; k < nb; k += 64)
+    const int a0 = aoff[key], nb = aoff[key + 1] - a0, e0 = eoff[key], p0b = (e0 + pdelta[sl]) / PB_BLK;
+    for (int k = threadIdx.x & 63; k < nb; k += 64) {
       blkdst[a0 + k] = p0b + k;
+      blksrc[a0 + k] = e0 + k * PB_BLK;
+    }
   }
   __syncthreads();
   int64_t r0, r1;
@@ -564,7 +575,8 @@ __global__ __launch_bounds__(PB_STAGE_THREADS) void pb_scatter_staged_kernel(
     uint16_t* __restrict__ s_col, uint16_t* __restrict__ s_row, int32_t* __restrict__ perm,
     int32_t* __restrict__ blkdst, int hub_len, int cap, int rt_len, const int32_t* __restrict__ binrow,
     unsigned char* __restrict__ s_code, typename pb_hdr<T>::type* __restrict__ s_hdr, unsigned* __restrict__ exc_idx,
-    uint16_t* __restrict__ exc_row, int32_t* __restrict__ exc_cnt, int exc_cap, int32_t* __restrict__ enc_fail) {
+    uint16_t* __restrict__ exc_row, int32_t* __restrict__ exc_cnt, int exc_cap, int32_t* __restrict__ enc_fail,
+    const int32_t* __restrict__ eoff, int32_t* __restrict__ blksrc) {
   constexpr int PB_BLK = pb_geom<T>::BLK;
   __shared__ int exc_n;
   if (ENC8 && threadIdx.x == 0)
@@ -595,9 +607,9 @@ __global__ __launch_bounds__(PB_STAGE_THREADS) void pb_scatter_staged_kernel(
   const int pb0 = binblk[wb];
   for (int i = tid; i < S; i += PB_STAGE_THREADS) {
     const int64_t key = (int64_t) i * NB + wb;
-    const int a0 = aoff[key], p0b = pb0 + prel[(int64_t) wb * S + i];
+    const int p0b = pb0 + prel[(int64_t) wb * S + i];
     lcnt[i] = cnt[key];
-    gdst[i] = a0 * PB_BLK;
+    gdst[i] = eoff[key];  // first entry of the run in the compact A' stream
     pdst[i] = p0b * PB_BLK;
   }
   for (int i = tid; i <= nr; i += PB_STAGE_THREADS)
@@ -605,9 +617,11 @@ __global__ __launch_bounds__(PB_STAGE_THREADS) void pb_scatter_staged_kernel(
   __syncthreads();
   // the block map of the bin's runs: one wavefront per run, a lane per block
   for (int sl = wave; sl < S; sl += PB_STAGE_THREADS / 64) {
-    const int nb = (lcnt[sl] + PB_BLK - 1) / PB_BLK, a0 = gdst[sl] / PB_BLK, p0b = pdst[sl] / PB_BLK;
-    for (int k = lane; k < nb; k += 64)
+    const int nb = (lcnt[sl] + PB_BLK - 1) / PB_BLK, a0 = aoff[(int64_t) sl * NB + wb], p0b = pdst[sl] / PB_BLK;
+    for (int k = lane; k < nb; k += 64) {
       blkdst[a0 + k] = p0b + k;
+      blksrc[a0 + k] = gdst[sl] + k * PB_BLK;
+    }
   }
   // row (inside the bin) of the entry at relative position q: last i in [lo, hi) with rp[i] <= q
   auto row_between = [&](int q, int lo, int hi) {
@@ -925,7 +939,11 @@ struct pack4<float> {
   static __device__ __forceinline__ void store(float* p, const float (&o)[4]) {
     f32x4 v;
     v.x = o[0]; v.y = o[1]; v.z = o[2]; v.w = o[3];
+#ifdef PB_EXP_NT_STORE  // A/B only (tools/build_variant.sh)
+    __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
+#else
     *reinterpret_cast<f32x4*>(p) = v;  // plain store: 12 % faster than nt here (measured)
+#endif
   }
 };
 template <>
@@ -958,7 +976,8 @@ __global__ __launch_bounds__(PB_THREADS) void pb_expand_kernel(int64_t n, int W,
                                                                const uint16_t* __restrict__ s_col,
                                                                const int32_t* __restrict__ blkdst,
                                                                const T* __restrict__ x, T* __restrict__ P,
-                                                               const int4* __restrict__ items, int S, int share) {
+                                                               const int4* __restrict__ items, int S, int share,
+                                                               const int32_t* __restrict__ blksrc) {
   constexpr int PB_BLK = pb_geom<T>::BLK, LPB = PB_BLK / 4;  // lanes per block: 8 (fp32) / 4 (fp64)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   T* xs = reinterpret_cast<T*>(smem);
@@ -975,8 +994,11 @@ __global__ __launch_bounds__(PB_THREADS) void pb_expand_kernel(int64_t n, int W,
   // blocks [b0, b1) of the slice whose x values are in LDS; two passes in flight
   auto process = [&](int b0, int b1) {
     int blk = b0 + bsel;
+    // A' is compact (round 3): the entries of block k start at blksrc[k], a multiple of 4; the lanes past the end of a
+    // run's last block read the entries that follow it -- their products land on pad positions of P, which the reduce
+    // leaves out (row = H / code 255)
     for (; blk + PASS < b1; blk += 2 * PASS) {
-      const int ea = blk * PB_BLK + sub, eb = ea + PASS * PB_BLK;
+      const int ea = stream_load(blksrc + blk) + sub, eb = stream_load(blksrc + blk + PASS) + sub;
       T va[4], vb[4], pa[4], pb[4];
       pack4<T>::load(s_val + ea, va);
       pack4<T>::load(s_val + eb, vb);
@@ -992,7 +1014,7 @@ __global__ __launch_bounds__(PB_THREADS) void pb_expand_kernel(int64_t n, int W,
       pack4<T>::store(P + (int64_t) db * PB_BLK + sub, pb);
     }
     for (; blk < b1; blk += PASS) {
-      const int ea = blk * PB_BLK + sub;
+      const int ea = stream_load(blksrc + blk) + sub;
       T va[4], pa[4];
       pack4<T>::load(s_val + ea, va);
       const u16x4 ca = stream_load(reinterpret_cast<const u16x4*>(s_col + ea));
@@ -1831,7 +1853,7 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
     return rc;
   struct temp_guard {  // inspect temporaries are released on every exit path
     hipStream_t s;
-    void* p[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    void* p[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     ~temp_guard() {
       for (void* q : p)
         dev_free(q, s);
@@ -1860,13 +1882,20 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
   int32_t* sliceblk = static_cast<int32_t*>(pl->s_sliceblk);
   hipLaunchKernelGGL(pb_nblk_kernel, dim3((unsigned) cdiv(nseg, 256)), dim3(256), 0, s, nseg, cnt, aoff, pb_geom<T>::BLK);
   (void) scan_counts_i32(s, nseg, aoff, partials);  // aoff[nseg] = blocks in A' order
+  int32_t* eoff = nullptr;  // first entry of every run in the compact A' stream (run lengths rounded up to 4)
+  if ((rc = dev_alloc((void**) &eoff, (size_t) (nseg + 1) * 4, s)))
+    return rc;
+  temps.p[4] = eoff;
+  hipLaunchKernelGGL(pb_ecnt_kernel, dim3((unsigned) cdiv(nseg, 256)), dim3(256), 0, s, nseg, cnt, eoff);
+  (void) scan_counts_i32(s, nseg, eoff, partials);  // eoff[nseg] = entries of the compact stream
   hipLaunchKernelGGL(pb_bin_prefix_kernel, dim3((unsigned) NB), dim3(256), 0, s, S, NB, cnt, prel, binblk, pb_geom<T>::BLK);
   (void) scan_counts_i32(s, NB, binblk, partials);  // binblk[NB] = blocks in P order (bins padded to groups)
   hipLaunchKernelGGL(pb_slice_blocks_kernel, dim3((unsigned) cdiv(S + 1, 256)), dim3(256), 0, s, S, NB, aoff, sliceblk);
   std::vector<int32_t> h_sliceblk((size_t) S + 1);
-  int32_t h_pblocks = 0;
+  int32_t h_pblocks = 0, h_epad = 0;
   if ((rc = readback_add(h, h_sliceblk.data(), sliceblk, (size_t) (S + 1) * 4)) ||
-      (rc = readback_add(h, &h_pblocks, binblk + NB, 4)) || (rc = readback_flush(h)))
+      (rc = readback_add(h, &h_pblocks, binblk + NB, 4)) || (rc = readback_add(h, &h_epad, eoff + nseg, 4)) ||
+      (rc = readback_flush(h)))
     return rc;
   unsigned long long placed_total = 0, max_slice = 0, max_group = 0, ne = 0, max_run = 0;
   for (int i = 0; i < S; ++i) {
@@ -1905,7 +1934,9 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
   pl->a_blocks = a_blocks;
   pl->p_blocks = p_blocks;
   constexpr int PB_BLK = pb_geom<T>::BLK, PB_GBLK = pb_geom<T>::GBLK;
-  const int64_t a_pad = a_blocks * PB_BLK, p_pad = p_blocks * PB_BLK;
+  // a_pad: entries of the compact A' stream + one block of slack (the lanes past the end of the last run's last block)
+  const int64_t a_pad = (int64_t) h_epad + PB_BLK, p_pad = p_blocks * PB_BLK;
+  pl->a_entries = a_pad;
   // 32-bit entry indices in the expand, 32-bit byte offsets into the product stream in the reduce; and the
   // padded copy must stay a small multiple of the matrix (runs of a few entries pad to a whole block: a matrix
   // that sparse per tile should not be tiled)
@@ -1918,7 +1949,8 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
     return rc;
   if ((rc = dev_alloc((void**) &pl->s_perm, (size_t) (a_pad + 8) * 4, s)))
     return rc;
-  if ((rc = dev_alloc((void**) &pl->s_blkdst, (size_t) (a_blocks + 8) * 4, s)))
+  if ((rc = dev_alloc((void**) &pl->s_blkdst, (size_t) (a_blocks + 8) * 4, s)) ||
+      (rc = dev_alloc((void**) &pl->s_blksrc, (size_t) (a_blocks + 8) * 4, s)))
     return rc;
   // Row stream of the reduce: one-byte codes when the tiles are dense enough for them (the average row advance inside
   // a run is H * (non-empty tiles) / entries: beyond ~40 rows too many entries become exceptions) and the staged scatter
@@ -1948,7 +1980,7 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
   }
   if ((rc = dev_alloc((void**) &pl->s_products, (size_t) (p_pad + PB_GRP) * sizeof(T), s)))
     return rc;
-  pl->device_bytes += (size_t) a_pad * (sizeof(T) + 6) + (size_t) a_blocks * 4 + (size_t) p_pad * sizeof(T) +
+  pl->device_bytes += (size_t) a_pad * (sizeof(T) + 6) + (size_t) a_blocks * 8 + (size_t) p_pad * sizeof(T) +
                       (enc8 ? (size_t) p_pad + hdr_bytes + (size_t) NB * PB_EXC_CAP * 6 : (size_t) p_pad * 2) +
                       (size_t) (NB + S + 2) * 4 + (size_t) nseg * 4;
   // pads: value 0, column 0, no source position, row = H (a dummy accumulator); products start finite
@@ -1956,6 +1988,7 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
   SPB_HIP(hipMemsetAsync(pl->s_colind, 0, (size_t) (a_pad + 8) * 2, s));
   SPB_HIP(hipMemsetAsync(pl->s_perm, 0xFF, (size_t) (a_pad + 8) * 4, s));
   SPB_HIP(hipMemsetAsync(pl->s_blkdst, 0, (size_t) (a_blocks + 8) * 4, s));
+  SPB_HIP(hipMemsetAsync(pl->s_blksrc, 0, (size_t) (a_blocks + 8) * 4, s));
   if (enc8) {  // pads: code 255 (left out of the main pass); headers and exception counts start at 0
     SPB_HIP(hipMemsetAsync(pl->s_code, 0xFF, (size_t) (p_pad + PB_GRP), s));
     SPB_HIP(hipMemsetAsync(pl->s_hdr, 0, hdr_bytes, s));
@@ -2100,9 +2133,10 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
     unsigned* ei = pl->s_exc_idx;
     uint16_t* er = pl->s_exc_row;
     int32_t *ec = pl->s_exc_cnt, *fail = pl->s_exc_cnt ? pl->s_exc_cnt + NB : nullptr;
-    const int32_t *cnt_ = cnt, *aoff_ = aoff, *prel_ = prel, *binblk_ = binblk;
+    const int32_t *cnt_ = cnt, *aoff_ = aoff, *prel_ = prel, *binblk_ = binblk, *eoff_ = eoff;
+    int32_t* bs = static_cast<int32_t*>(pl->s_blksrc);
     void* args[] = {&mm, &rowptr, &ci, &vp, &W_, &H_, &S_, &NB_, &cnt_, &aoff_, &prel_, &binblk_, &sv, &sc, &sr, &pm, &bd,
-                    &hub, &cap_, &rt_, &binrow, &code, &hdr, &ei, &er, &ec, &ecap, &fail};
+                    &hub, &cap_, &rt_, &binrow, &code, &hdr, &ei, &er, &ec, &ecap, &fail, &eoff_, &bs};
     return hipLaunchKernel(fn, dim3((unsigned) NB), dim3(PB_STAGE_THREADS), args, (size_t) PB_STAGE_LDS - 64, s);
   };
   if (staged) {
@@ -2113,7 +2147,8 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
     hipLaunchKernelGGL((pb_scatter_kernel<T, O>), dim3((unsigned) NB), dim3(256), (size_t) S * 8, s, m, rowptr,
                        pl->colind, static_cast<const T*>(values_p), W, H, S, NB, aoff, prel, binblk,
                        static_cast<T*>(pl->s_values), reinterpret_cast<uint16_t*>(pl->s_colind), pl->s_lrow,
-                       reinterpret_cast<int32_t*>(pl->s_perm), static_cast<int32_t*>(pl->s_blkdst), pl->hub_len, binrow);
+                       reinterpret_cast<int32_t*>(pl->s_perm), static_cast<int32_t*>(pl->s_blkdst), pl->hub_len, binrow,
+                       static_cast<const int32_t*>(eoff), static_cast<int32_t*>(pl->s_blksrc));
   }
   tr.mark("scatter");
   SPB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pb_flag_dups_kernel),
@@ -2182,7 +2217,7 @@ int spmv_sliced_build(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const 
 template <typename T>
 static int sliced_update_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const void* values) {
   pl->values_ptr = values;  // the hub rows read the caller's array directly
-  const int64_t a_pad = pl->a_blocks * pb_geom<T>::BLK;
+  const int64_t a_pad = pl->a_entries;
   if (pl->s_placed == 0 || a_pad == 0)
     return SPBLAS_GFX950_STATUS_SUCCESS;
   hipLaunchKernelGGL((pb_update_values_kernel<T>), dim3((unsigned) cdiv(a_pad, 256)), dim3(256), 0, h->stream, a_pad,
@@ -2242,7 +2277,8 @@ static int sliced_expand_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* p
   hipLaunchKernelGGL((pb_expand_kernel<T>), grid, dim3(PB_THREADS), xbytes, h->stream, pl->n, pl->slice_cols,
                      static_cast<const int32_t*>(pl->s_sliceblk), static_cast<const T*>(pl->s_values),
                      reinterpret_cast<const uint16_t*>(pl->s_colind), static_cast<const int32_t*>(pl->s_blkdst),
-                     static_cast<const T*>(x), static_cast<T*>(pl->s_products), items, (int) pl->n_slices, share);
+                     static_cast<const T*>(x), static_cast<T*>(pl->s_products), items, (int) pl->n_slices, share,
+                     static_cast<const int32_t*>(pl->s_blksrc));
   SPB_HIP(hipGetLastError());
   return SPBLAS_GFX950_STATUS_SUCCESS;
 }
@@ -2489,6 +2525,9 @@ void spmv_sliced_free(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl) {
   dev_free(pl->s_sliceblk, s);
   dev_free(pl->s_binblk, s);
   dev_free(pl->s_blkdst, s);
+  dev_free(pl->s_blksrc, s);
+  pl->s_blksrc = nullptr;
+  pl->a_entries = 0;
   dev_free(pl->s_colind, s);
   dev_free(pl->s_values, s);
   dev_free(pl->s_lrow, s);
