@@ -1221,7 +1221,11 @@ __global__ __launch_bounds__(RW * 64) void pb_reduce_kernel(int64_t m, int Hw, i
       pack4<T>::load(reinterpret_cast<const T*>(reinterpret_cast<const char*>(P) + offP), q.p[u]);
       if (ENC8) {
         q.cw[u] = stream_load(reinterpret_cast<const unsigned*>(reinterpret_cast<const char*>(s_row) + (offR >> 1)));
+#ifdef PB_EXP_NOHDR  // A/B only: what do the header loads cost? (results wrong)
+        q.hd[u] = (hdr_t) 0;
+#else
         q.hd[u] = stream_load(s_hdr + ((unsigned) gg * (unsigned) PB_GBLK + (unsigned) lane / LPB));
+#endif
         continue;
       }
 #ifdef PB_EXP_U8ROWS  // timing experiment (tools/build_variant.sh): one byte of row stream per entry; results are wrong
@@ -1308,18 +1312,35 @@ __global__ __launch_bounds__(RW * 64) void pb_reduce_kernel(int64_t m, int Hw, i
   if (partial) {
     // uniform split: slot k of the [K][m] array; work items: this wave's part of the item's own RW*Hw block
     T* dst = ritems ? partial : partial + (int64_t) blockIdx.y * pstride + r0;
-    for (int i = lane; i < rh; i += 64)
-      dst[i] = acc[i];
+    for (int i0 = lane; i0 < rh; i0 += 64 * 8) {  // (eight LDS reads in flight, as in the final loop below)
+      T v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        v[u] = acc[i0 + 64 * u < rh ? i0 + 64 * u : 0];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (i0 + 64 * u < rh)
+          dst[i0 + 64 * u] = v[u];
+    }
     return;
   }
   if (peers) {
     // fused all-gather (multi-GPU row shards): local row r is row peer_off + r of the full y, and is
     // stored straight into every rank's copy (peers[] holds the local buffer and the IPC-mapped
     // buffers of the other ranks; stores to those travel over xGMI).  beta = 0 by contract.
-    for (int p = 0; p < n_peers; ++p) {
-      T* dst = peers[p] + peer_off + r0;
-      for (int i = lane; i < rh; i += 64)
-        dst[i] = alpha * acc[i];
+    // the accumulators are read once, eight per lane at a time, and every value goes to all peers from registers
+    for (int i0 = lane; i0 < rh; i0 += 64 * 8) {
+      T v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        v[u] = alpha * acc[i0 + 64 * u < rh ? i0 + 64 * u : 0];
+      for (int p = 0; p < n_peers; ++p) {
+        T* dst = peers[p] + peer_off + r0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (i0 + 64 * u < rh)
+            dst[i0 + 64 * u] = v[u];
+      }
     }
     return;
   }
@@ -1334,9 +1355,21 @@ __global__ __launch_bounds__(RW * 64) void pb_reduce_kernel(int64_t m, int Hw, i
     }
     return;
   }
-  for (int i = lane; i < rh; i += 64) {
-    const T v = alpha * acc[i];
-    y[r0 + i] = beta == T(0) ? v : v + beta * y[r0 + i];
+  // eight accumulator reads in flight per lane before the first store: the epilogue runs while nothing else streams
+  // (every wavefront reaches it at the same time), one LDS round trip per row group was 4 % of the kernel
+  for (int i0 = lane; i0 < rh; i0 += 64 * 8) {
+    T v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + 64 * u;
+      v[u] = alpha * acc[i < rh ? i : 0];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + 64 * u;
+      if (i < rh)
+        y[r0 + i] = beta == T(0) ? v[u] : v[u] + beta * y[r0 + i];
+    }
   }
 }
 
