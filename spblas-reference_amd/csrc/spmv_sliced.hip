@@ -576,7 +576,7 @@ __global__ __launch_bounds__(PB_STAGE_THREADS) void pb_scatter_staged_kernel(
     int32_t* __restrict__ blkdst, int hub_len, int cap, int rt_len, const int32_t* __restrict__ binrow,
     unsigned char* __restrict__ s_code, typename pb_hdr<T>::type* __restrict__ s_hdr, unsigned* __restrict__ exc_idx,
     uint16_t* __restrict__ exc_row, int32_t* __restrict__ exc_cnt, int exc_cap, int32_t* __restrict__ enc_fail,
-    const int32_t* __restrict__ eoff, int32_t* __restrict__ blksrc) {
+    const int32_t* __restrict__ eoff, int32_t* __restrict__ blksrc, const int32_t* __restrict__ bin_order) {
   constexpr int PB_BLK = pb_geom<T>::BLK;
   __shared__ int exc_n;
   if (ENC8 && threadIdx.x == 0)
@@ -594,7 +594,9 @@ __global__ __launch_bounds__(PB_STAGE_THREADS) void pb_scatter_staged_kernel(
   T* stv = reinterpret_cast<T*>(st + cap);   // [cap] value,
   uint16_t* stc = reinterpret_cast<uint16_t*>(stv + cap);  // [cap] column inside the slice
   __shared__ int pass_end, pass_direct;
-  const int wb = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // bin_order (row-skewed matrices): the bins heaviest first -- a bin of 131 k entries makes 13 staging passes over all
+  // of them, a light one a single pass over 10 k, and a heavy bin that starts last finishes alone
+  const int wb = bin_order ? bin_order[blockIdx.x] : (int) blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int64_t r0, r1;
   pb_bin_rows(binrow, wb, H, m, &r0, &r1);
   if (r0 >= m)
@@ -2142,6 +2144,27 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
   tr.mark("work lists");
   // a quarter of the staging area at most goes to the row table (one entry per 64 matrix entries of a bin)
   const int rt_len = 2048;
+  // bins in the order the scatter should take them: groups of RW bins by weight, heaviest first (variable-height bins with
+  // more bins than CUs only; the weights are the group sums of the probe)
+  int32_t* bin_order_dev = nullptr;
+  if (varbins && NB > 2 * (h->num_cus > 0 ? h->num_cus : 256) && env_int("SPBLAS_GFX950_PB_LPT", 1)) {
+    std::vector<int64_t> gorder((size_t) ngroups);
+    for (int64_t g = 0; g < ngroups; ++g)
+      gorder[(size_t) g] = g;
+    std::stable_sort(gorder.begin(), gorder.end(), [&](int64_t a, int64_t b) {
+      return h_sum[(size_t) (2 * S + a)] > h_sum[(size_t) (2 * S + b)];
+    });
+    std::vector<int32_t> order;
+    order.reserve((size_t) NB);
+    for (int64_t g : gorder)
+      for (int64_t b = g * RW; b < std::min<int64_t>((g + 1) * RW, NB); ++b)
+        order.push_back((int32_t) b);
+    if ((rc = dev_alloc((void**) &bin_order_dev, (size_t) NB * 4, s)))
+      return rc;
+    temps.p[5] = bin_order_dev;
+    if ((rc = upload_add(h, bin_order_dev, order.data(), (size_t) NB * 4)) || (rc = readback_flush(h)))
+      return rc;
+  }
   auto stage_cap = [&](bool e8) {
     return (int) (((size_t) PB_STAGE_LDS - (size_t) 16 * S - (size_t) 4 * (H + 1) - (size_t) 4 * rt_len - 128 -
                    (e8 ? (size_t) (PB_STAGE_THREADS / 64) * PB_STAGE_SP * 4 : 0)) /
@@ -2168,8 +2191,9 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
     int32_t *ec = pl->s_exc_cnt, *fail = pl->s_exc_cnt ? pl->s_exc_cnt + NB : nullptr;
     const int32_t *cnt_ = cnt, *aoff_ = aoff, *prel_ = prel, *binblk_ = binblk, *eoff_ = eoff;
     int32_t* bs = static_cast<int32_t*>(pl->s_blksrc);
+    const int32_t* bo = bin_order_dev;
     void* args[] = {&mm, &rowptr, &ci, &vp, &W_, &H_, &S_, &NB_, &cnt_, &aoff_, &prel_, &binblk_, &sv, &sc, &sr, &pm, &bd,
-                    &hub, &cap_, &rt_, &binrow, &code, &hdr, &ei, &er, &ec, &ecap, &fail, &eoff_, &bs};
+                    &hub, &cap_, &rt_, &binrow, &code, &hdr, &ei, &er, &ec, &ecap, &fail, &eoff_, &bs, &bo};
     return hipLaunchKernel(fn, dim3((unsigned) NB), dim3(PB_STAGE_THREADS), args, (size_t) PB_STAGE_LDS - 64, s);
   };
   if (staged) {
