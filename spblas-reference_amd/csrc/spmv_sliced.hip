@@ -934,6 +934,10 @@ template <typename T>
 struct pack4;
 template <>
 struct pack4<float> {
+  static __device__ __forceinline__ void load_cached(const float* p, float (&o)[4]) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(p);
+    o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+  }
   static __device__ __forceinline__ void load(const float* p, float (&o)[4]) {
     const f32x4 v = stream_load(reinterpret_cast<const f32x4*>(p));
     o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
@@ -950,6 +954,11 @@ struct pack4<float> {
 };
 template <>
 struct pack4<double> {
+  static __device__ __forceinline__ void load_cached(const double* p, double (&o)[4]) {
+    const f64x2 a = reinterpret_cast<const f64x2*>(p)[0];
+    const f64x2 b = reinterpret_cast<const f64x2*>(p)[1];
+    o[0] = a.x; o[1] = a.y; o[2] = b.x; o[3] = b.y;
+  }
   static __device__ __forceinline__ void load(const double* p, double (&o)[4]) {
     const f64x2 a = stream_load(reinterpret_cast<const f64x2*>(p));
     const f64x2 b = stream_load(reinterpret_cast<const f64x2*>(p) + 1);
@@ -1002,10 +1011,17 @@ __global__ __launch_bounds__(PB_THREADS) void pb_expand_kernel(int64_t n, int W,
     for (; blk + PASS < b1; blk += 2 * PASS) {
       const int ea = stream_load(blksrc + blk) + sub, eb = stream_load(blksrc + blk + PASS) + sub;
       T va[4], vb[4], pa[4], pb[4];
+#ifdef PB_EXP_PLAIN_A  // A/B only: cached loads of the (now unaligned) A' blocks
+      pack4<T>::load_cached(s_val + ea, va);
+      pack4<T>::load_cached(s_val + eb, vb);
+      const u16x4 ca = *reinterpret_cast<const u16x4*>(s_col + ea);
+      const u16x4 cb = *reinterpret_cast<const u16x4*>(s_col + eb);
+#else
       pack4<T>::load(s_val + ea, va);
       pack4<T>::load(s_val + eb, vb);
       const u16x4 ca = stream_load(reinterpret_cast<const u16x4*>(s_col + ea));
       const u16x4 cb = stream_load(reinterpret_cast<const u16x4*>(s_col + eb));
+#endif
       const int da = stream_load(blkdst + blk), db = stream_load(blkdst + blk + PASS);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
