@@ -675,7 +675,7 @@ __global__ __launch_bounds__(PB_STAGE_THREADS) void pb_scatter_staged_kernel(
     for (int i = tid; i < NW * PB_STAGE_SP; i += PB_STAGE_THREADS)
       wcnt[i] = 0;
     __syncthreads();
-    constexpr int CU4 = 4;
+    constexpr int CU4 = 8;
     for (int qb = qlo; qb < qhi; qb += 64 * CU4) {
       int cbuf[CU4];
 #pragma unroll
@@ -758,7 +758,7 @@ __global__ __launch_bounds__(PB_STAGE_THREADS) void pb_scatter_staged_kernel(
         wcnt[w * PB_STAGE_SP + sl] += lcur[sl];
       }
       __syncthreads();
-      constexpr int CU4 = 4;  // rounds whose column loads are issued together
+      constexpr int CU4 = 8;  // rounds whose column loads are issued together
       for (int qb = qlo; qb < qhi; qb += 64 * CU4) {
         int cbuf[CU4];
 #pragma unroll
