@@ -836,8 +836,10 @@ __global__ __launch_bounds__(PB_STAGE_THREADS) void pb_scatter_staged_kernel(
         if (ENC8) {
           unsigned* ei = exc_idx + (size_t) wb * exc_cap;
           uint16_t* er = exc_row + (size_t) wb * exc_cap;
+#ifndef PB_EXP_NOSORT  // A/B only: what does the in-place sort of the rounds cost? (results wrong without it)
           if (n > 1)
             pb_sort_rounds<T>(n, lo, lane, st, stv, stc);
+#endif
           if (n > 0)
             pb_emit_sorted_run<T>(n, lo, g, gp, (int) p0, lane, st, stv, stc, row_of, s_val, s_col, perm, s_code, s_hdr,
                                   &exc_n, exc_cap, ei, er);
