@@ -382,7 +382,37 @@ def main():
         local_s, local_ev = measure(lambda: rccl_op.local(x), k, 2, multi, device)
         gather_s, _ = measure(lambda: rccl_op.gather(), k, 2, multi, device)
         rccl_s = (elapsed / args.steps * k) if mode != "fused" else measure(lambda: rccl_op.step(x), k, 2, multi, device)[0]
+        # Throughput form of the fused step (independent right-hand sides: the wait for step k-1 sits between the
+        # expand and the reduce of step k, so link time and expand overlap).  A diagnostic next to the timed, dependent
+        # form: never the metric value, and any failure here leaves the line as it is.
+        pipe_ms, pipe_ok = None, None
+        if mode == "fused":
+            try:
+                for _ in range(2):
+                    op.step_pipelined(x)
+                op.flush()
+                torch.cuda.synchronize()
+                dist.barrier()
+                t1 = time.perf_counter()
+                for _ in range(k):
+                    op.step_pipelined(x)
+                y_p = op.flush()
+                torch.cuda.synchronize()
+                dist.barrier()
+                el = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=device)
+                dist.all_reduce(el, op=dist.ReduceOp.MAX)
+                op.check_status()
+                y_p = y_p.clone()
+                y_d = op.step(x)
+                torch.cuda.synchronize()
+                okf = torch.tensor([int(torch.equal(y_p, y_d))], dtype=torch.int32, device=device)
+                dist.all_reduce(okf, op=dist.ReduceOp.MIN)
+                pipe_ms, pipe_ok = float(el.item()) / k * 1e3, bool(int(okf.item()))
+            except Exception as e:  # noqa: BLE001 - diagnostics only
+                if rank == 0:
+                    print(f"[bench] pipelined fused step not measured: {e}", file=sys.stderr)
         diag = {"mode_timed": mode, "local_spmv_ms": local_s / k * 1e3, "local_spmv_event_ms": local_ev,
+                "fused_pipelined_step_ms": pipe_ms, "fused_pipelined_check": pipe_ok,
                 "gather_ms": gather_s / k * 1e3, "rccl_step_ms": rccl_s / k * 1e3,
                 "fused_step_ms": elapsed / args.steps * 1e3 if mode == "fused" else None,
                 "fused_post_check": fused_post_check,

@@ -444,6 +444,7 @@ class FusedShardedSpMV:
         self._alpha = (ctypes.c_float if self.dtype == torch.float32 else ctypes.c_double)(1.0)
         self._plan = self.info.state_
         self._x, self._xp = None, None
+        self._pending = False  # a pipelined step whose wait has not been issued yet
 
     def _agree(self, err, what):
         """Collective: raise on every rank if any rank failed."""
@@ -457,6 +458,7 @@ class FusedShardedSpMV:
     def step(self, x, events=None):
         """One sharded SpMV; returns the full y (valid on this rank once the stream reaches this point)."""
         ct, lib = self._ct, api._capi.lib()
+        self.flush()  # (a pipelined step before this one: its wait comes first)
         if self._x is not x:
             self._x, self._xp = x, ct.c_void_p(x.data_ptr())
         self._step += 1
@@ -474,6 +476,42 @@ class FusedShardedSpMV:
         api.check(lib.spblas_gfx950_step_wait(h, ct.c_void_p(self.flags.data_ptr()), self.world, self._step,
                                               self._timeout, ct.c_void_p(self._status.data_ptr())), "step_wait")
         return self.y[b]
+
+    def step_pipelined(self, x):
+        """Throughput form of step() for INDEPENDENT right-hand sides (back-to-back SpMVs whose x does not depend on the
+        previous y): the device-side wait for step k-1 sits between this step's expand and its reduce, so the peers'
+        stores of step k-1 cross the links while this rank already expands step k -- link time and expand overlap
+        ("overlap collectives with compute").  Every step's y is still complete and bit-identical to step()'s; but the
+        buffer returned here may only be read after flush() (or after the next call has passed its internal wait and
+        before it signals).  A dependent iteration (x_k+1 = f(y_k)) needs step().  Buffer safety: a peer overwrites my
+        copy k & 1 in its step k + 2, which it starts after my signal of step k + 1, which I send after my wait of step k."""
+        ct, lib = self._ct, api._capi.lib()
+        if self._x is not x:
+            self._x, self._xp = x, ct.c_void_p(x.data_ptr())
+        self._step += 1
+        b = self._step & 1
+        h, plan = api._Handle.current(self.device).h, self._plan.plan
+        api.check(lib.spblas_gfx950_spmv_expand(h, plan, self._xp), "spmv_expand")
+        if self._pending:
+            api.check(lib.spblas_gfx950_step_wait(h, ct.c_void_p(self.flags.data_ptr()), self.world, self._step - 1,
+                                                  self._timeout, ct.c_void_p(self._status.data_ptr())), "step_wait")
+        api.check(lib.spblas_gfx950_spmv_reduce_rows_bcast(h, plan, ct.byref(self._alpha),
+                                                           ct.c_void_p(self._tabs[b].data_ptr()), self.world,
+                                                           self.bounds[self.rank], 0, self.L), "spmv_reduce_rows_bcast")
+        api.check(lib.spblas_gfx950_step_signal(h, ct.c_void_p(self._tabs[2].data_ptr()), self.world, self.rank,
+                                                self._step), "step_signal")
+        self._pending = True
+        return self.y[b]
+
+    def flush(self):
+        """Wait (on the device) for the last pipelined step: its y is complete on this rank once the stream gets here."""
+        if self._pending:
+            ct, lib = self._ct, api._capi.lib()
+            h = api._Handle.current(self.device).h
+            api.check(lib.spblas_gfx950_step_wait(h, ct.c_void_p(self.flags.data_ptr()), self.world, self._step,
+                                                  self._timeout, ct.c_void_p(self._status.data_ptr())), "step_wait")
+            self._pending = False
+        return self.y[self._step & 1]
 
     def check_status(self):
         """After a host synchronisation: raise if a step barrier timed out (a peer stopped responding)."""

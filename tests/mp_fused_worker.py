@@ -90,6 +90,18 @@ def main():
     chosen = sharded.try_fused(a_loc, bounds, x, reference_step_gathered, info=plans[rank][0], stripes=stripes)
     assert chosen is not None, "try_fused rejected the plan-sharing fused path"
     assert torch.equal(chosen.step(x), reference_step_gathered())
+    # throughput form (independent right-hand sides): the wait for step k-1 sits inside step k, results after flush()
+    # are the same bits; a different vector per step, mixed with dependent steps, so that a late or lost peer store shows
+    refs = {sc: reference_step_gathered(x * sc) for sc in (1.0, -2.0, 0.25, 4.0)}
+    for sc in (1.0, -2.0, 0.25):
+        chosen.step_pipelined(x * sc)
+    y_last = chosen.flush()
+    torch.cuda.synchronize()
+    chosen.check_status()
+    assert torch.equal(y_last, refs[0.25]), "pipelined steps: last y differs"
+    assert torch.equal(chosen.step(x * 4.0), refs[4.0]), "dependent step after pipelined ones differs"
+    chosen.step_pipelined(x * -2.0)
+    assert torch.equal(chosen.step(x), refs[1.0]), "step() must flush a pending pipelined step first"
     chosen.close()
     # a disagreement on ONE rank must make EVERY rank fall back
     assert sharded.try_fused(a_loc, bounds, x, lambda xk: reference_step(xk, True), alg=sp._capi.SPMV_SLICED) is None

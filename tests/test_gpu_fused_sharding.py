@@ -129,5 +129,7 @@ def test_bench_with_several_ranks_on_one_gpu(gpu, world, workload, fused):
     if workload == "spmv":
         assert mg["mode_timed"] == ("fused" if fused == "auto" else "plain")
         assert mg["fused_post_check"] is (True if fused == "auto" else None)
+        if fused == "auto":  # the throughput form is measured next to the timed one and reproduces its bits
+            assert mg["fused_pipelined_step_ms"] > 0 and mg["fused_pipelined_check"] is True
     else:
         assert len(set(mg["rows_per_rank"])) > 1 and mg["gather"] == "p2p"   # nnz-prefix shards differ in rows
