@@ -218,6 +218,12 @@ int spblas_gfx950_step_signal(spblas_gfx950_handle_t handle, void* const* flag_p
                               int64_t step);
 int spblas_gfx950_step_wait(spblas_gfx950_handle_t handle, const void* flags, int n_peers, int64_t step,
                             int64_t timeout_ms, int* status_dev);
+/* One-shot: the NEXT spmv_reduce_rows_bcast on this handle issues step_wait(flags, n_peers, step, ...) right before the
+ * kernel that stores into the peers' copies of y (the combine kernel when the reduce is K-split, else the reduce
+ * itself).  Throughput form of the fused step for independent right-hand sides: expand and reduce of step k overlap
+ * the peers' stores of step k-1. */
+int spblas_gfx950_bcast_wait_before(spblas_gfx950_handle_t handle, const void* flags, int n_peers, int64_t step,
+                                    int64_t timeout_ms, int* status_dev);
 
 /* ---- SpMM:  C = alpha * A * B + beta * C,  B (k x n), C (m x n) row-major --- */
 /* ldb/ldc are row strides in elements (mdspan layout_right, test/gtest/spmm_test.cpp).

@@ -20,6 +20,14 @@ struct spblas_gfx950_handle_s {
   int64_t max_ksplit = 0;     // SPBLAS_GFX950_OPT_MAX_KSPLIT (0 = no cap)
   int64_t value_snapshot = 0; // SPBLAS_GFX950_OPT_VALUE_SNAPSHOT: AUTO may pick a plan that copies A's values
   int64_t spgemm_keep_colind = 0;  // SPBLAS_GFX950_OPT_SPGEMM_KEEP_COLIND: same c_colind address = same contents
+  // one-shot: the next reduce_rows_bcast waits (on the device) for this step barrier right before the kernel that
+  // stores to the peers -- the combine kernel when the reduce is K-split, else the reduce itself (spblas_gfx950_bcast_wait_before)
+  struct bcast_wait_t {
+    const void* flags = nullptr;
+    int n_peers = 0;
+    int64_t step = 0, timeout_ms = 0;
+    int* status_dev = nullptr;
+  } bcast_wait;
   // second stream + fork/join events of the striped fused step (created on first use)
   hipStream_t aux_stream = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -202,6 +210,10 @@ struct readback_scope {
     }
   }
 };
+
+// launches the device-side step barrier of the fused multi-GPU step (multigpu.hip)
+int launch_step_wait(spblas_gfx950_handle_s* h, const void* flags, int n_peers, int64_t step, int64_t timeout_ms,
+                     int* status_dev);
 
 template <typename T>
 struct scalar_of;

@@ -38,6 +38,18 @@ __global__ void step_wait_kernel(const long long* __restrict__ flags, int n_peer
   }
 }
 
+int launch_step_wait(spblas_gfx950_handle_s* h, const void* flags, int n_peers, int64_t step, int64_t timeout_ms,
+                     int* status_dev) {
+  int rate_khz = 100000;  // wall_clock64 ticks at 100 MHz on gfx9
+  (void) hipDeviceGetAttribute(&rate_khz, hipDeviceAttributeWallClockRate, h->device);
+  if (rate_khz <= 0)
+    rate_khz = 100000;
+  hipLaunchKernelGGL(step_wait_kernel, dim3(1), dim3(64), 0, h->stream, static_cast<const long long*>(flags), n_peers,
+                     (long long) step, (long long) timeout_ms * rate_khz, status_dev);
+  SPB_HIP(hipGetLastError());
+  return SPBLAS_GFX950_STATUS_SUCCESS;
+}
+
 } // namespace spb
 
 using namespace spb;
@@ -119,13 +131,22 @@ int spblas_gfx950_step_wait(spblas_gfx950_handle_t handle, const void* flags, in
     return SPBLAS_GFX950_STATUS_INVALID_POINTER;
   if (n_peers < 1 || n_peers > 64)
     return SPBLAS_GFX950_STATUS_INVALID_SIZE;
-  int rate_khz = 100000;  // wall_clock64 ticks at 100 MHz on gfx9
-  (void) hipDeviceGetAttribute(&rate_khz, hipDeviceAttributeWallClockRate, handle->device);
-  if (rate_khz <= 0)
-    rate_khz = 100000;
-  hipLaunchKernelGGL(step_wait_kernel, dim3(1), dim3(64), 0, handle->stream, static_cast<const long long*>(flags),
-                     n_peers, (long long) step, (long long) timeout_ms * rate_khz, status_dev);
-  SPB_HIP(hipGetLastError());
+  return launch_step_wait(handle, flags, n_peers, step, timeout_ms, status_dev);
+}
+
+int spblas_gfx950_bcast_wait_before(spblas_gfx950_handle_t handle, const void* flags, int n_peers, int64_t step,
+                                    int64_t timeout_ms, int* status_dev) {
+  if (!handle)
+    return SPBLAS_GFX950_STATUS_INVALID_HANDLE;
+  if (!flags || !status_dev)
+    return SPBLAS_GFX950_STATUS_INVALID_POINTER;
+  if (n_peers < 1 || n_peers > 64)
+    return SPBLAS_GFX950_STATUS_INVALID_SIZE;
+  handle->bcast_wait.flags = flags;
+  handle->bcast_wait.n_peers = n_peers;
+  handle->bcast_wait.step = step;
+  handle->bcast_wait.timeout_ms = timeout_ms;
+  handle->bcast_wait.status_dev = status_dev;
   return SPBLAS_GFX950_STATUS_SUCCESS;
 }
 

@@ -2506,7 +2506,27 @@ static int sliced_reduce_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* p
                            static_cast<const T*>(pl->s_rpartial), static_cast<T*>(y), alpha, beta, pl->rows_per_blk,
                            binrow, pl->n_rblk, rowmap, piece_out);
     } else {
+      // fused multi-GPU step, throughput form: the wait for the PREVIOUS step's barrier goes right before the kernel that
+      // stores into the peers' copies of y -- everything before it overlaps the peers' stores still crossing the links
+      auto wait_hook = [&]() -> int {
+        auto& bw = h->bcast_wait;
+        if (!peers_p || !bw.flags)
+          return SPBLAS_GFX950_STATUS_SUCCESS;
+        const int rc_w = launch_step_wait(h, bw.flags, bw.n_peers, bw.step, bw.timeout_ms, bw.status_dev);
+        bw.flags = nullptr;
+        return rc_w;
+      };
+      if (!(K > 1 && r_hi > r_lo)) {
+        const int rc_w = wait_hook();
+        if (rc_w)
+          return rc_w;
+      }
       SPB_HIP(hipLaunchKernel(pb_reduce_fn<T>(RW, UB, e8), dim3((unsigned) groups, (unsigned) K), dim3(RW * 64), args, lds, s));
+      if (K > 1 && r_hi > r_lo) {
+        const int rc_w = wait_hook();
+        if (rc_w)
+          return rc_w;
+      }
       if (K > 1 && r_hi > r_lo)
         hipLaunchKernelGGL((pb_combine_kernel<T>), dim3((unsigned) cdiv(r_hi - r_lo, 256)), dim3(256), 0, s, r_lo, r_hi, K,
                            static_cast<const T*>(pl->s_partial), pl->s_m, static_cast<T*>(y), alpha, beta,

@@ -479,8 +479,9 @@ class FusedShardedSpMV:
 
     def step_pipelined(self, x):
         """Throughput form of step() for INDEPENDENT right-hand sides (back-to-back SpMVs whose x does not depend on the
-        previous y): the device-side wait for step k-1 sits between this step's expand and its reduce, so the peers'
-        stores of step k-1 cross the links while this rank already expands step k -- link time and expand overlap
+        previous y): the device-side wait for step k-1 sits right before the kernel of step k that stores to the peers (the
+        combine kernel of a K-split reduce, else the reduce), so the peers' stores of step k-1 cross the links while this
+        rank already expands and reduces step k -- link time and compute overlap
         ("overlap collectives with compute").  Every step's y is still complete and bit-identical to step()'s; but the
         buffer returned here may only be read after flush() (or after the next call has passed its internal wait and
         before it signals).  A dependent iteration (x_k+1 = f(y_k)) needs step().  Buffer safety: a peer overwrites my
@@ -492,9 +493,10 @@ class FusedShardedSpMV:
         b = self._step & 1
         h, plan = api._Handle.current(self.device).h, self._plan.plan
         api.check(lib.spblas_gfx950_spmv_expand(h, plan, self._xp), "spmv_expand")
-        if self._pending:
-            api.check(lib.spblas_gfx950_step_wait(h, ct.c_void_p(self.flags.data_ptr()), self.world, self._step - 1,
-                                                  self._timeout, ct.c_void_p(self._status.data_ptr())), "step_wait")
+        if self._pending:  # the wait goes right before the kernel that stores to the peers (combine, or the reduce itself)
+            api.check(lib.spblas_gfx950_bcast_wait_before(h, ct.c_void_p(self.flags.data_ptr()), self.world,
+                                                          self._step - 1, self._timeout,
+                                                          ct.c_void_p(self._status.data_ptr())), "bcast_wait_before")
         api.check(lib.spblas_gfx950_spmv_reduce_rows_bcast(h, plan, ct.byref(self._alpha),
                                                            ct.c_void_p(self._tabs[b].data_ptr()), self.world,
                                                            self.bounds[self.rank], 0, self.L), "spmv_reduce_rows_bcast")
