@@ -2018,7 +2018,7 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
       (rc = dev_alloc((void**) &pl->s_blksrc, (size_t) (a_blocks + 8) * 4, s)))
     return rc;
   // Row stream of the reduce: one-byte codes when the tiles are dense enough for them (the average row advance inside
-  // a run is H * (non-empty tiles) / entries: beyond ~40 rows too many entries become exceptions) and the staged scatter
+  // a run is H * (non-empty tiles) / entries: beyond ~32 rows a bin's exception list (128) gets tight: e^-8 of ~50 k entries) and the staged scatter
   // (whose ordered staging leaves every run sorted by row) is in use; otherwise 16-bit rows.
   typedef typename pb_hdr<T>::type hdr_t;
   const bool staged = S <= PB_STAGE_MAX_S && env_int("SPBLAS_GFX950_PB_STAGED_SCATTER", 1);
@@ -2028,7 +2028,7 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
   // 16-bit rows: 5 M rows (2 034 bins) 156.9 vs 162.8 us, 2.5 M (1 017 bins) 103.3 vs 93.1, 1.25 M 63.2 vs 58.3.
   (void) max_run;
   if (!staged || placed_total == 0 || S > PB_STAGE_SP ||
-      (enc8 == 1 && ((double) H * (double) ne > 40.0 * (double) placed_total || NB < 1536 ||
+      (enc8 == 1 && ((double) H * (double) ne > 32.0 * (double) placed_total || NB < 1536 ||
                      placed_total < (unsigned long long) 32 << 20)))  // below ~32 M entries the SpMV gains nothing (n = 1-3 M
     enc8 = 0;                                                        // at 10 per row: 55.6 / 78.9 / 102.0 vs 56.0 / 78.2 / 102.1 us) and inspect pays 25-50 % more
   pl->enc8 = enc8 ? 1 : 0;
