@@ -132,6 +132,35 @@ def build_dropin_run(libdir):
     return DROPIN_RUN
 
 
+DROPIN_RUN_CMAKE = os.path.join(OUT_DIR, "dropin_run_cmake")
+
+
+def build_dropin_run_with_cmake(libdir):
+    """The same program through CMake: cmake/SpblasGfx950.cmake (the `option(ENABLE_GFX950)` block INTEGRATION.md section 2
+    gives the reference's CMakeLists.txt, as an includable module) is configured with -DENABLE_GFX950=ON by
+    tests/compile_check/cmake_project/CMakeLists.txt and builds dropin_run.cpp against the patched header tree.  Returns
+    the binary's path, or None without the reference tree / cmake."""
+    cmake = shutil.which("cmake")
+    if not os.path.isdir(REF) or not cmake:
+        return None
+    os.makedirs(OUT_DIR, exist_ok=True)
+    with tempfile.TemporaryDirectory() as tmp:
+        scratch = patched_reference_headers(os.path.join(tmp, "patched"))
+        headers = ";".join([scratch, REF, os.path.join(HERE, "stubs")])
+        gen = ["-G", "Ninja"] if shutil.which("ninja") else []
+        cfg = [cmake, "-S", os.path.join(HERE, "cmake_project"), "-B", os.path.join(tmp, "build")] + gen + [
+            "-DENABLE_GFX950=ON", f"-DSPBLAS_HEADERS={headers}", f"-DSPBLAS_GFX950_LIBDIR={libdir}",
+            "-DCMAKE_BUILD_TYPE=Release", "-DCMAKE_CXX_COMPILER=" + shutil.which("g++")]
+        r = subprocess.run(cfg, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("cmake configure failed:\n" + r.stdout[-3000:] + r.stderr[-3000:])
+        r = subprocess.run([cmake, "--build", os.path.join(tmp, "build"), "-j", "4"], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("cmake build failed:\n" + r.stdout[-4000:] + r.stderr[-4000:])
+        shutil.copy2(os.path.join(tmp, "build", "dropin_run_cmake"), DROPIN_RUN_CMAKE)
+    return DROPIN_RUN_CMAKE
+
+
 def build_reference_device_tests(libdir, jobs=4):
     """The reference's device test files (test/gtest/device/*.cpp: thrust device vectors + GoogleTest macros)
     compiled as they are against the patched tree with -DSPBLAS_ENABLE_GFX950 -- i.e. with THIS backend behind

@@ -41,3 +41,19 @@ def test_dropin_headers_compile_inside_the_reference_tree(tmp_path):
     cmd = [gxx, "-fsyntax-only"] + compile_flags(scratch) + [os.path.join(CHECK, "dropin_check.cpp")]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, "drop-in headers do not compile inside the reference tree:\n" + r.stderr[-6000:]
+
+
+def test_cmake_module_configures_and_builds_the_backend():
+    """cmake/SpblasGfx950.cmake (INTEGRATION.md section 2's CMake lines as a module) with -DENABLE_GFX950=ON: configure +
+    build of tests/compile_check/cmake_project, which links dropin_run.cpp through the INTERFACE target `spblas` the way the
+    reference's CMakeLists.txt:80-88 links its rocSPARSE slot.  (The binary runs on the GPU in tests/test_gpu_dropin.py.)"""
+    import spblas_reference_amd as sp
+    from compile_check.build_dropin import build_dropin_run_with_cmake
+    if shutil.which("cmake") is None:
+        pytest.skip("cmake not installed")
+    if not os.path.exists(sp._build.LIBPATH):
+        sp._build.build()
+    binp = build_dropin_run_with_cmake(sp._build.LIBDIR)
+    assert binp and os.path.exists(binp)
+    needed = subprocess.run(["readelf", "-d", binp], capture_output=True, text=True).stdout
+    assert "libspblas_gfx950.so" in needed and "rocsparse" not in needed

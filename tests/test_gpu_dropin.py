@@ -29,6 +29,17 @@ def test_dropin_backend_runs_behind_the_reference_api(gpu):
     assert n >= 25, r.stdout
 
 
+def test_dropin_backend_built_through_cmake_runs(gpu):
+    """The same program, built by CMake: cmake/SpblasGfx950.cmake -- the `option(ENABLE_GFX950)` block of INTEGRATION.md
+    section 2 as an includable module -- configured with -DENABLE_GFX950=ON by tests/compile_check/cmake_project
+    (tests/compile_check/build_dropin.py:build_dropin_run_with_cmake, called from build())."""
+    binp = os.path.join(ROOT, "tests", "compile_check", "_build", "dropin_run_cmake")
+    if not os.path.exists(binp):
+        pytest.skip("dropin_run_cmake was not built (needs the reference tree and cmake: __graft_entry__.build())")
+    r = subprocess.run([binp], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "checks, 0 failed" in r.stdout, f"{r.stdout[-2000:]}\n{r.stderr[-3000:]}"
+
+
 REF_BIN = os.path.join(ROOT, "tests", "compile_check", "_build", "reference_device_tests")
 
 
