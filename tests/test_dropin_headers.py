@@ -43,6 +43,24 @@ def test_dropin_headers_compile_inside_the_reference_tree(tmp_path):
     assert r.returncode == 0, "drop-in headers do not compile inside the reference tree:\n" + r.stderr[-6000:]
 
 
+def test_dropin_headers_log_through_the_reference_macros(tmp_path):
+    """SURVEY.md section 5, metrics / logging: the reference's only instrumentation is the compile-time LOG_LEVEL printf
+    (`detail/log.hpp:32-90`, `log_trace("")` at each entry of `algorithms/multiply_impl.hpp:21,36,69` and of the oneMKL
+    backend).  Every public overload of this backend opens with the same `log_trace("")`; with -DLOG_LEVEL set the
+    macros expand to real calls and must still compile."""
+    gxx = shutil.which("g++")
+    scratch = patched_reference_headers(str(tmp_path / "patched"))
+    cmd = [gxx, "-fsyntax-only", "-DLOG_LEVEL=SPBLAS_INFO"] + compile_flags(scratch) + [os.path.join(CHECK, "dropin_check.cpp")]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-6000:]
+    n = 0
+    for name in os.listdir(os.path.join(ROOT, "include", "spblas", "vendor", "gfx950")):
+        if name.endswith(".hpp"):
+            with open(os.path.join(ROOT, "include", "spblas", "vendor", "gfx950", name)) as f:
+                n += f.read().count('log_trace("")')
+    assert n >= 30, n
+
+
 def test_cmake_module_configures_and_builds_the_backend():
     """cmake/SpblasGfx950.cmake (INTEGRATION.md section 2's CMake lines as a module) with -DENABLE_GFX950=ON: configure +
     build of tests/compile_check/cmake_project, which links dropin_run.cpp through the INTERFACE target `spblas` the way the
