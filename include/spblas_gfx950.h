@@ -98,7 +98,12 @@ const char* spblas_gfx950_status_string(int status);
 int spblas_gfx950_last_hip_error(void);
 
 /* stream: a hipStream_t (NULL = the null stream), cf. hip_allocator(hipStream_t),
- * vendor/rocsparse/hip_allocator.hpp:22. */
+ * vendor/rocsparse/hip_allocator.hpp:22.
+ * Graph capture: the execute calls that take a plan or a state whose structure is known (spblas_gfx950_spmv,
+ * spblas_gfx950_spmm, spblas_gfx950_sptrsv_solve, spblas_gfx950_spgemm_numeric after the first fill) only launch kernels
+ * and memsets on this stream and may be recorded with hipStreamBeginCapture and replayed.  Nothing is allocated on a
+ * capturing stream: a call that would have to (plan creation, inspect, symbolic passes, the first execute of a plan that
+ * sizes a workspace) returns SPBLAS_GFX950_STATUS_NOT_SUPPORTED there -- run it once outside the capture. */
 int spblas_gfx950_create(spblas_gfx950_handle_t* handle, void* stream);
 int spblas_gfx950_destroy(spblas_gfx950_handle_t handle);
 int spblas_gfx950_set_stream(spblas_gfx950_handle_t handle, void* stream);

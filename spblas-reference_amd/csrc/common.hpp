@@ -63,12 +63,26 @@ inline int hip_fail(hipError_t e) {
       return ::spb::hip_fail(spb_e_);                                                              \
   } while (0)
 
+// True while work submitted to `s` is being recorded into a graph (hipStreamBeginCapture, torch.cuda.graph).  Execute
+// paths with a plan are capturable -- launches and memsets only -- as long as they have nothing to allocate: a buffer
+// allocated or freed inside a capture would belong to the graph, not to the plan.
+inline bool stream_capturing(hipStream_t s) {
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &st) != hipSuccess) {
+    (void) hipGetLastError();
+    return false;
+  }
+  return st != hipStreamCaptureStatusNone;
+}
+
 // Stream-ordered device allocation, the same primitive the reference's
-// hip_allocator uses (vendor/rocsparse/hip_allocator.hpp:34-47).
+// hip_allocator uses (vendor/rocsparse/hip_allocator.hpp:34-47).  Refused on a stream that is being captured.
 inline int dev_alloc(void** p, size_t bytes, hipStream_t s) {
   *p = nullptr;
   if (bytes == 0)
     return SPBLAS_GFX950_STATUS_SUCCESS;
+  if (s && stream_capturing(s))
+    return SPBLAS_GFX950_STATUS_NOT_SUPPORTED;
   // On the legacy null stream plain hipMalloc/hipFree are used: pool memory released there by
   // stream order was seen to be recycled while still in use when the application mixes in ordinary
   // hipMalloc/hipFree traffic (tests/cpp/device_tests.cpp exposed it).  Allocation only happens at

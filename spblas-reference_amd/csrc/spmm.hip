@@ -536,6 +536,8 @@ static int spmm_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, int64_
     parts = parts < 1 ? 1 : (parts > 64 ? 64 : parts);
     const int64_t need = pl->n_long * parts * n;
     if (pl->mm_long_cap < need || pl->mm_long_parts != (int) parts) {
+      if (stream_capturing(s))  // the first call with this many columns has to run outside the capture
+        return SPBLAS_GFX950_STATUS_NOT_SUPPORTED;
       dev_free(pl->mm_long_part, s);
       pl->mm_long_part = nullptr;
       pl->mm_long_cap = 0;

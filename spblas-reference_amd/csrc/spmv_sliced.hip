@@ -976,9 +976,6 @@ struct pack4<double> {
 
 typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
 
-
-typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
-
 // expand: P[blkdst[blk]] = s_val[blk] * x[slice_base + s_col[blk]] over the slice's contiguous blocks of A'.
 // The x slice lives in LDS.  Eight consecutive lanes own one block of 32 entries (4 entries = 16 B of values,
 // 8 B of columns each): the wavefront reads 8 consecutive blocks -- 1 KiB of values -- and stores 8 whole
@@ -2462,6 +2459,8 @@ static int sliced_reduce_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* p
   T* piece_out = static_cast<T*>(pl->s_piece_out);
   const bool use_items = pl->s_ritems && !peers_p && wb_begin == 0 && wb_end == pl->n_rblk;
   if (!use_items && K > 1 && pl->s_partial_k < K) {  // grow the partial-sum workspace (stream ordered)
+    if (stream_capturing(s))
+      return SPBLAS_GFX950_STATUS_NOT_SUPPORTED;
     dev_free(pl->s_partial, s);
     pl->s_partial = nullptr;
     int rc = dev_alloc(&pl->s_partial, (size_t) K * pl->s_m * sizeof(T), s);
@@ -2577,6 +2576,8 @@ int spmv_sliced_reserve_partial(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* 
   if (K <= 1 || pl->s_partial_k >= K)
     return SPBLAS_GFX950_STATUS_SUCCESS;
   hipStream_t s = h->stream;
+  if (stream_capturing(s))
+    return SPBLAS_GFX950_STATUS_NOT_SUPPORTED;
   dev_free(pl->s_partial, s);
   pl->s_partial = nullptr;
   pl->s_partial_k = 0;

@@ -768,6 +768,13 @@ static int trsv_solve_typed(spblas_gfx950_handle_t h, spblas_gfx950_trsv_s* pl, 
   // ticket counters, [ng] unused, [ng + 1] = status word, then (32-int aligned) the grid barrier: one line for the
   // arrival counter and one release flag line per workgroup
   const size_t bar_off = (ng + 2 + 31) / 32 * 32, ctl_ints = bar_off + 32 * (size_t) (9 + 2 * cus);
+  // A solve recorded into a graph (hipStreamBeginCapture / torch.cuda.graph) is replayed with the arguments it was
+  // recorded with: no cooperative launch (the kernel node does not carry the co-residency guarantee of the launch: replays
+  // were seen to leave rows unsolved), no allocation (the first solve of a plan must run outside the capture), and the
+  // granule tags, which an ordinary solve tells apart by the solve number, are cleared by a recorded memset instead.
+  const bool capturing = stream_capturing(s);
+  if (capturing && (!pl->tickets || (any_selfsched && !pl->gran)))
+    return SPBLAS_GFX950_STATUS_NOT_SUPPORTED;
   if (!pl->tickets) {
     int rc = dev_alloc((void**) &pl->tickets, ctl_ints * 4, s);
     if (rc)
@@ -779,17 +786,27 @@ static int trsv_solve_typed(spblas_gfx950_handle_t h, spblas_gfx950_trsv_s* pl, 
       return rc;
     SPB_HIP(hipMemsetAsync(pl->gran, 0, (size_t) pl->m * 16, s));
   }
-  if (++pl->epoch == 0) {  // the solve number wrapped: start over with clean tags
+  unsigned epoch;
+  if (capturing) {
+    // tag 0xffffffff belongs to recorded solves: every replay clears the granules first, and an ordinary solve that
+    // follows never reaches that number (the wrap below restarts at 1)
+    epoch = 0xffffffffu;
     if (pl->gran)
       SPB_HIP(hipMemsetAsync(pl->gran, 0, (size_t) pl->m * 16, s));
-    pl->epoch = 1;
+  } else {
+    if (++pl->epoch == 0xffffffffu) {  // the solve number wrapped: start over with clean tags
+      if (pl->gran)
+        SPB_HIP(hipMemsetAsync(pl->gran, 0, (size_t) pl->m * 16, s));
+      pl->epoch = 1;
+    }
+    epoch = pl->epoch;
   }
   SPB_HIP(hipMemsetAsync(pl->tickets, 0, ctl_ints * 4, s));
   int* status = pl->tickets + ng + 1;
   const int spin_limit = env_int("SPBLAS_GFX950_TRSV_SPIN_LIMIT", 1 << 22);  // ~ seconds of polling
   // the whole solve as one cooperative launch (default when the device offers it and no narrow run is so long
   // that the waiting workgroups could exhaust their bounded spin: 4096 levels ~ 10 ms)
-  if (pl->coop_ok && !any_selfsched && ng > 1) {
+  if (pl->coop_ok && !any_selfsched && ng > 1 && !capturing) {
     int n_levels = (int) pl->h_level_ptr.size() - 1, narrow = pl->narrow;
     int wgs = env_int("SPBLAS_GFX950_TRSV_COOP_WGS", 1);
     int occ = 0;
@@ -826,16 +843,16 @@ static int trsv_solve_typed(spblas_gfx950_handle_t h, spblas_gfx950_trsv_s* pl, 
       const int grid = (int) std::min<int64_t>((int64_t) cus * 2, chunks);
       hipLaunchKernelGGL((trsv_selfsched_kernel<T, G>), dim3((unsigned) (grid > 0 ? grid : 1)), dim3(TRSV_SS_WAVES * 64), 0, s, g.l0,
                          g.l1 - g.l0, pl->chunk_ptr + pl->group_cp0[gi], pl->level_ptr, pl->order, rowptr, colind, values,
-                         alpha, b, x, upper, unit, m, pl->gran, pl->epoch, pl->tickets + gi, status, spin_limit);
+                         alpha, b, x, upper, unit, m, pl->gran, epoch, pl->tickets + gi, status, spin_limit);
       used_selfsched = true;
     } else if (g.wide) {
       const int f0 = pl->h_level_ptr[g.l0], f1 = pl->h_level_ptr[g.l0 + 1];
       hipLaunchKernelGGL((trsv_level_kernel<T, G>), dim3((unsigned) cdiv(f1 - f0, 256 / G)), dim3(256), 0, s, f0, f1,
-                         pl->order, rowptr, colind, values, alpha, b, x, upper, unit, m, pl->gran, pl->epoch);
+                         pl->order, rowptr, colind, values, alpha, b, x, upper, unit, m, pl->gran, epoch);
     } else {
       hipLaunchKernelGGL((trsv_chain_kernel<T, G>), dim3(1), dim3(TRSV_BLOCK_THREADS), 0, s, g.l0, g.l1,
                          pl->level_ptr, pl->order, rowptr, colind, values, alpha, b, x, upper, unit, m, pl->gran,
-                         pl->epoch);
+                         epoch);
     }
   }
   (void) used_selfsched;
