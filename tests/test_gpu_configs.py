@@ -269,3 +269,87 @@ def test_cfg5_spgemm_full_size(gpu):
         sp.multiply_fill(info, d_a, d_b, d_c)
         assert torch.equal(d_c.colind(), first_cols), attempt
         assert bool(((d_c.values() - 6.0 * first_vals).abs() <= 1e-5 * (6.0 * first_vals).abs() + 1e-30).all()), attempt
+
+
+def test_more_than_2_31_entries_need_64_bit_offsets(gpu):
+    """The maximum-size edge of the CSR boundary: nnz > 2^31 - 1, which only 64-bit row offsets can describe (the
+    reference's csr_view is templated on the offset type, /root/reference/include/spblas/views/csr_view.hpp; its vendor
+    back ends pass 64-bit offsets straight through, vendor/rocsparse/spmv_impl.hpp).  33.5 M rows of 65 entries =
+    2.18e9 entries (17.4 GB of values + columns -- nothing for a 288 GB device): SpMV plan-free and through every plan the
+    inspect accepts, SpMM with two columns, all against a float64 evaluation on the device in row chunks (too large
+    for the host oracle, which has pinned the same kernels on every smaller case).  The 32-bit position arrays of the
+    SLICED re-tiling cannot hold this matrix: a forced SLICED inspect must refuse or fall back, never wrap around."""
+    free, _ = torch.cuda.mem_get_info()
+    if free < 60 * 2 ** 30:
+        pytest.skip("needs 60 GB of device memory")
+    m, L, n = 1 << 25, 65, 1 << 20
+    nnz = m * L
+    assert nnz > 2 ** 31
+    g = torch.Generator(device="cuda").manual_seed(7)
+    colind = torch.empty(nnz, dtype=torch.int32, device="cuda")
+    values = torch.empty(nnz, dtype=torch.float32, device="cuda")
+    step = 1 << 28
+    for o in range(0, nnz, step):  # chunked: the generators index with 32 bits in places
+        e = min(nnz, o + step)
+        colind[o:e] = torch.randint(0, n, (e - o,), dtype=torch.int32, device="cuda", generator=g)
+        values[o:e] = torch.rand(e - o, device="cuda", generator=g) + 0.5
+    # distinct tails: the last rows are where a wrapped 32-bit offset would read the wrong entries
+    rowptr = torch.arange(m + 1, dtype=torch.int64, device="cuda") * L
+    x = torch.rand(n, device="cuda", generator=g) + 0.5
+    B = torch.rand((n, 2), device="cuda", generator=g) + 0.5
+
+    def reference(rhs):  # float64, row chunks of 2^20 rows, one right-hand side at a time (a (rows, L, k) sum over
+        # dim 1 came back with zeros from torch on this image; the (rows, L) form does not)
+        cols = [rhs.double()] if rhs.dim() == 1 else [rhs[:, c].double().contiguous() for c in range(rhs.shape[1])]
+        out = torch.empty((len(cols), m), dtype=torch.float64, device="cuda")
+        rows = 1 << 20
+        for r0 in range(0, m, rows):
+            sl = slice(r0 * L, (r0 + rows) * L)
+            idx, v = colind[sl].long(), values[sl].double()
+            for c, rd in enumerate(cols):
+                out[c, r0:r0 + rows] = (rd[idx] * v).view(rows, L).sum(1)
+        assert bool((out > 0).all())
+        return out[0] if rhs.dim() == 1 else out.t().contiguous()
+
+    a = sp.csr_view(values, rowptr, colind, (m, n), nnz)
+    y_ref = reference(x)  # all terms positive: the norm-wise bound is relative to the result
+    tol = max(1e-6, L * np.finfo(np.float32).eps)
+
+    def check_y(y, what):
+        err = ((y.double() - y_ref).abs() / y_ref).max().item()
+        assert err <= tol, f"{what}: max relative error {err}"
+        # the rows past entry 2^31: a wrapped offset would have read other entries
+        tail = slice((2 ** 31) // L + 1, m)
+        assert ((y.double()[tail] - y_ref[tail]).abs() / y_ref[tail]).max().item() <= tol
+
+    y = torch.full((m,), float("nan"), device="cuda")
+    sp.multiply(a, x, y)
+    check_y(y, "plan-free")
+    for name, alg in (("auto", _capi.SPMV_AUTO), ("vector", _capi.SPMV_VECTOR), ("rowblock", _capi.SPMV_ROWBLOCK)):
+        y.fill_(float("nan"))
+        info = sp.multiply_inspect(a, x, y, alg=alg)
+        assert info.state_.info()["alg"] != _capi.SPMV_SLICED
+        sp.multiply(info, a, x, y)
+        check_y(y, name)
+        del info
+    y.fill_(float("nan"))
+    try:
+        info = sp.multiply_inspect(a, x, y, alg=_capi.SPMV_SLICED)
+    except Exception:
+        info = None  # refused: fine
+    if info is not None:
+        assert info.state_.info()["alg"] != _capi.SPMV_SLICED, "32-bit positions cannot describe 2^31 entries"
+        sp.multiply(info, a, x, y)
+        check_y(y, "sliced -> fallback")
+        del info
+
+    C = torch.full((m, 2), float("nan"), device="cuda")
+    sp.multiply(a, B, C)
+    C_ref = reference(B)
+    errC = ((C.double() - C_ref).abs() / C_ref).max().item()
+    assert errC <= tol, f"SpMM: max relative error {errC}"
+    infoC = sp.multiply_inspect(a, B, C)
+    C.fill_(float("nan"))
+    sp.multiply(infoC, a, B, C)
+    errC = ((C.double() - C_ref).abs() / C_ref).max().item()
+    assert errC <= tol, f"SpMM with inspect: max relative error {errC}"
