@@ -24,6 +24,7 @@ as csr_view wraps caller-owned device pointers.  All compute goes through the C 
 (include/spblas_gfx950.h); nothing here computes on the CPU or through torch ops.
 """
 import ctypes
+import threading
 
 import torch
 
@@ -217,7 +218,12 @@ def _shape_of(t):
 
 # --------------------------------------------------------------------------- state
 class _Handle:
-    _by_device = {}
+    """One backend handle per (host thread, device).  A handle carries the stream the next call launches on and a
+    scratch buffer, so -- like the vendor handles it stands in for (vendor/rocsparse/detail/operation_state_t.hpp keeps
+    one per operation state) -- it must not be shared by threads that call concurrently: ctypes drops the GIL for the
+    duration of a call, and a second thread re-binding the stream between this thread's set_stream and its launch
+    would put the launch on the wrong stream."""
+    _tls = threading.local()
 
     def __init__(self, device):
         self.device = device
@@ -225,6 +231,14 @@ class _Handle:
         with torch.cuda.device(device):
             check(_capi.lib().spblas_gfx950_create(ctypes.byref(h), None), "spblas_gfx950_create")
         self.h = h
+
+    def __del__(self):  # a thread's handles go with the thread (plans and states keep theirs alive)
+        try:
+            if self.h:
+                _capi.lib().spblas_gfx950_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass  # interpreter shutdown
 
     def set_option(self, option, value):
         check(_capi.lib().spblas_gfx950_set_option(self.h, option, value), "spblas_gfx950_set_option")
@@ -234,9 +248,12 @@ class _Handle:
         if device.type != "cuda":
             raise RuntimeError("gfx950 backend: arrays must live in device (HIP) memory; there is no CPU fallback")
         key = device.index if device.index is not None else torch.cuda.current_device()
-        hd = cls._by_device.get(key)
+        by_device = getattr(cls._tls, "by_device", None)
+        if by_device is None:
+            by_device = cls._tls.by_device = {}
+        hd = by_device.get(key)
         if hd is None:
-            hd = cls._by_device[key] = cls(key)
+            hd = by_device[key] = cls(key)
         stream = torch.cuda.current_stream(key).cuda_stream
         check(_capi.lib().spblas_gfx950_set_stream(hd.h, ctypes.c_void_p(stream)), "spblas_gfx950_set_stream")
         return hd
