@@ -61,6 +61,10 @@ def launch_ranks(nproc):
     """One rank per GPU under torch.distributed.run on a free loopback port; stdout/stderr pass straight through."""
     import socket
     import subprocess
+    # (device_count() does not initialise the GPU: the parent stays a plain launcher)
+    if "--debug-one-gpu" not in sys.argv and torch.cuda.device_count() < nproc:
+        print(f"bench.py: --gpus {nproc} but {torch.cuda.device_count()} device(s) visible", file=sys.stderr)
+        return 2
     with socket.socket() as sock:
         sock.bind(("127.0.0.1", 0))
         port = sock.getsockname()[1]

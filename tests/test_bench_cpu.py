@@ -29,6 +29,7 @@ def test_plain_gpus_n_starts_a_child_torchrun_before_any_gpu_call(monkeypatch):
 
     import torch
     monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
     monkeypatch.setattr(torch.cuda, "set_device", lambda *_: (_ for _ in ()).throw(AssertionError("GPU touched in the parent")))
     monkeypatch.delenv("WORLD_SIZE", raising=False)
     monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
@@ -39,6 +40,18 @@ def test_plain_gpus_n_starts_a_child_torchrun_before_any_gpu_call(monkeypatch):
     assert 1024 < int(cmd[cmd.index("--master-port") + 1]) < 65536
     assert cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"] and cmd[-7].endswith("bench.py")
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_more_ranks_than_devices_is_refused_at_once(monkeypatch, capsys):
+    """--gpus 8 on a box with 2 devices: say so and exit 2 instead of starting ranks that cannot get a device."""
+    bench = _bench()
+    import torch
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 2)
+    monkeypatch.setattr(subprocess, "run", lambda *a, **k: (_ for _ in ()).throw(AssertionError("ranks were started")))
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8"])
+    assert bench.main() == 2
+    assert "2 device(s) visible" in capsys.readouterr().err
 
 
 def test_parity_report_bites():
