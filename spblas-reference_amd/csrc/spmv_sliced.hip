@@ -1747,7 +1747,7 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
     const int64_t nb_fill = env_int("SPBLAS_GFX950_PB_BINS", 2048);
     // (3 blocks per run: row shards of cfg2 2.5 M / 1.25 M rows 99.6 -> 93.2 / 61.3 -> 58.4 us against 4 blocks, 2 blocks
     // no better, square matrices of 1-6 M rows unchanged; tools/shard_run_sweep.sh, tools/run_min_mid.sh)
-    const int64_t nb_run = nnz / ((int64_t) S * env_int("SPBLAS_GFX950_PB_RUN_MIN", 96));
+    const int64_t nb_run = nnz / ((int64_t) S * std::max(1, env_int("SPBLAS_GFX950_PB_RUN_MIN", 96)));
     int64_t nb = std::max<int64_t>(nb_min, std::min<int64_t>(nb_fill, nb_run));
     if (nb < 1)
       nb = 1;
@@ -1791,7 +1791,7 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
     varbins = 1;  // the reduce maps compact rows through binrow[] + nzrow[]
   const int32_t* binrow = nullptr;
   if (varbins) {
-    int64_t E = nnz / env_int("SPBLAS_GFX950_PB_BINS", 2048);
+    int64_t E = nnz / std::max(1, env_int("SPBLAS_GFX950_PB_BINS", 2048));
     E = std::max<int64_t>(8192, std::min<int64_t>(E, 98304));
     int32_t* flag = nullptr;
     long long* fpart = nullptr;

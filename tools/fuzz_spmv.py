@@ -15,7 +15,9 @@ iters = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 HOOKS = ["SPBLAS_GFX950_SLICE_COLS", "SPBLAS_GFX950_SLICE_ROWS", "SPBLAS_GFX950_PB_KSPLIT", "SPBLAS_GFX950_PB_RWAVES",
          "SPBLAS_GFX950_PB_RBATCH", "SPBLAS_GFX950_PB_RLDS_KB", "SPBLAS_GFX950_PB_BINS", "SPBLAS_GFX950_PB_VARBINS",
-         "SPBLAS_GFX950_PB_HUB_LEN", "SPBLAS_GFX950_PB_COMPACT"]
+         "SPBLAS_GFX950_PB_HUB_LEN", "SPBLAS_GFX950_PB_COMPACT", "SPBLAS_GFX950_PB_ENC8", "SPBLAS_GFX950_PB_ENC8_FAIL",
+         "SPBLAS_GFX950_PB_LPT", "SPBLAS_GFX950_PB_XITEM_DIV", "SPBLAS_GFX950_PB_RITEMS", "SPBLAS_GFX950_PB_XLDS_KB",
+         "SPBLAS_GFX950_PB_STAGED_SCATTER", "SPBLAS_GFX950_PB_SPLIT_LEN", "SPBLAS_GFX950_PB_RUN_MIN"]
 dev = torch.device("cuda:0")
 bad = 0
 for it in range(iters):
@@ -66,6 +68,21 @@ for it in range(iters):
         hooks["SPBLAS_GFX950_PB_VARBINS"] = str(int(rng.choice([-1, 0, 1])))   # variable-height bins: auto / off / forced
         hooks["SPBLAS_GFX950_PB_HUB_LEN"] = str(int(rng.choice([1, 300, 16384])))
         hooks["SPBLAS_GFX950_PB_COMPACT"] = str(int(rng.choice([-1, 0, 1])))    # tiles over the non-empty rows only
+        # round 3: one-byte row codes (0 off / 1 rule / 2 forced; _FAIL = pretend the encoder overflowed -> 16-bit
+        # fall-back), heaviest-first work lists, finer expand items, K split of heavy reduce groups, x slice size,
+        # staged vs direct scatter, long rows in pieces, minimum run length
+        hooks["SPBLAS_GFX950_PB_ENC8"] = str(int(rng.choice([0, 1, 2, 2])))
+        if rng.random() < 0.1:
+            hooks["SPBLAS_GFX950_PB_ENC8_FAIL"] = "1"
+        hooks["SPBLAS_GFX950_PB_LPT"] = str(int(rng.choice([0, 1])))
+        hooks["SPBLAS_GFX950_PB_XITEM_DIV"] = str(int(rng.choice([1, 2, 8])))
+        hooks["SPBLAS_GFX950_PB_RITEMS"] = str(int(rng.choice([0, 1, 2, 4])))
+        hooks["SPBLAS_GFX950_PB_XLDS_KB"] = str(int(rng.choice([40, 80, 160])))
+        hooks["SPBLAS_GFX950_PB_STAGED_SCATTER"] = str(int(rng.choice([0, 1])))
+        if rng.random() < 0.5:
+            hooks["SPBLAS_GFX950_PB_SPLIT_LEN"] = str(int(rng.choice([64, 1000, 100000])))
+        if rng.random() < 0.3:
+            hooks["SPBLAS_GFX950_PB_RUN_MIN"] = str(int(rng.choice([1, 8, 64])))
     os.environ.update(hooks)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     rp_dev = t(rowptr.astype(np.int64 if off64 else np.int32))
