@@ -490,14 +490,15 @@ class _CscPlan:
         m, n = a_csc.shape()          # logical shape of the operand
         nnz = a_csc.size()
         dev, vals = a_csc.values().device, a_csc.values()
-        if a_csc.colptr().dtype != torch.int32:
-            raise TypeError("multiply_inspect on csc_view: int32 offsets only")
+        # the device transpose takes 32-bit offsets; 64-bit ones that fit are narrowed once into a plan-owned copy
+        # (multiply_inspect leaves operands with more than 2^31 - 1 entries to the plan-free kernels)
+        self.colptr32 = a_csc.colptr() if a_csc.colptr().dtype == torch.int32 else a_csc.colptr().to(torch.int32)
         self.rowptr = torch.empty(m + 1, dtype=torch.int32, device=dev)
         self.colind = torch.empty(max(nnz, 1), dtype=torch.int32, device=dev)
         self.values = torch.empty(max(nnz, 1), dtype=vals.dtype, device=dev)
         hd = _Handle.current(dev)
         # the stored arrays are the CSR of the (n x m) transpose
-        check(_capi.lib().spblas_gfx950_csr_transpose(hd.h, n, m, nnz, _ptr(a_csc.colptr()), _ptr(a_csc.rowind()),
+        check(_capi.lib().spblas_gfx950_csr_transpose(hd.h, n, m, nnz, _ptr(self.colptr32), _ptr(a_csc.rowind()),
                                                       _ptr(vals), _ptr(self.rowptr), _ptr(self.colind),
                                                       _ptr(self.values), _vtype(vals, "multiply_inspect")[0]),
               "multiply_inspect")
@@ -513,7 +514,7 @@ class _CscPlan:
         m, n = a_csc.shape()
         nnz = a_csc.size()
         hd = _Handle.current(a_csc.values().device)
-        check(_capi.lib().spblas_gfx950_csr_transpose(hd.h, n, m, nnz, _ptr(a_csc.colptr()), _ptr(a_csc.rowind()),
+        check(_capi.lib().spblas_gfx950_csr_transpose(hd.h, n, m, nnz, _ptr(self.colptr32), _ptr(a_csc.rowind()),
                                                       _ptr(a_csc.values()), _ptr(self.rowptr), _ptr(self.colind),
                                                       _ptr(self.values), _vtype(a_csc.values(), "multiply")[0]),
               "multiply")
@@ -549,13 +550,21 @@ def transpose(*args):
     if b.values() is None or b.colind() is None or b.values().numel() < nnz or b.colind().numel() < nnz:
         raise RuntimeError("transpose: Transpose ran out of memory.")  # transpose_impl.hpp:22-25
     _check_csr(a, "transpose")
-    if a.rowptr().dtype != torch.int32 or b.rowptr().dtype != torch.int32:
-        raise TypeError("transpose: int32 offsets only")
+    # the device kernel works on 32-bit offsets (its positions are 32-bit: nnz <= 2^31 - 1, checked there); 64-bit
+    # offset arrays -- csr_view is templated on the offset type, views/csr_view.hpp -- are narrowed on the way in and
+    # widened on the way out
+    if nnz >= 2 ** 31:
+        raise ValueError("transpose: more than 2^31 - 1 stored entries are not supported on the device")
+    a_rp = a.rowptr() if a.rowptr().dtype == torch.int32 else a.rowptr().to(torch.int32)
+    b_rp = b.rowptr() if b.rowptr().dtype == torch.int32 else torch.empty(b.shape()[0] + 1, dtype=torch.int32,
+                                                                          device=b.rowptr().device)
     hd = _Handle.current(a.rowptr().device)
-    check(_capi.lib().spblas_gfx950_csr_transpose(hd.h, a.shape()[0], a.shape()[1], nnz, _ptr(a.rowptr()),
-                                                  _ptr(a.colind()), _ptr(a.values()), _ptr(b.rowptr()),
+    check(_capi.lib().spblas_gfx950_csr_transpose(hd.h, a.shape()[0], a.shape()[1], nnz, _ptr(a_rp),
+                                                  _ptr(a.colind()), _ptr(a.values()), _ptr(b_rp),
                                                   _ptr(b.colind()), _ptr(b.values()),
                                                   _vtype(a.values(), "transpose")[0]), "transpose")
+    if b_rp is not b.rowptr():
+        b.rowptr()[:b.shape()[0] + 1].copy_(b_rp)
     _note_write(b.values(), b.colind())
     b.update(b.values(), b.rowptr(), b.colind(), b.shape(), nnz)  # transpose_impl.hpp:54
 
@@ -762,7 +771,7 @@ def multiply_inspect(*args, alg=_capi.SPMV_AUTO):
         info.state_ = plan
         if mo is not None:
             mo._plan = plan
-    elif isinstance(a_base, csc_view) and _is_tensor(get_ultimate_base(b)):
+    elif isinstance(a_base, csc_view) and _is_tensor(get_ultimate_base(b)) and a_base.size() < 2 ** 31:
         is_spmm = get_ultimate_base(b).dim() == 2
         info.state_ = _CscPlan(a_base, _capi.SPMV_ROWBLOCK if is_spmm else alg)
         if is_spmm:

@@ -190,3 +190,34 @@ def test_scale_in_place_matrix_and_vector(gpu, dtype):
     sp.multiply(d_a, x, y)
     ref = oracle.spmv((300, 200), a_h[1], a_h[2], a_h[0] * dtype(3.0), G.host(x))
     util.expect_eq_ref(ref, G.host(y))
+
+
+def test_64_bit_offsets_in_transpose_and_inspected_csc(gpu):
+    """csr_view / csc_view are templated on the offset type (views/csr_view.hpp): transpose() and multiply_inspect on a
+    csc_view take 64-bit offset arrays too (narrowed once on the way into the 32-bit device transpose, widened on the
+    way out) and give what the 32-bit call gives."""
+    values, rowptr, colind, shape, nnz = generate.generate_csr(700, 900, 15000, seed=13)
+    ref = oracle.transpose(shape, rowptr, colind, values)
+    a = G.csr_on_device(values, rowptr, colind, shape, nnz, offset64=True)
+    assert a.rowptr().dtype == torch.int64
+    b = sp.csr_view(torch.full((nnz,), float("nan"), device="cuda"),
+                    torch.full((shape[1] + 1,), -1, dtype=torch.int64, device="cuda"),
+                    torch.full((nnz,), -1, dtype=torch.int32, device="cuda"), (shape[1], shape[0]), nnz)
+    sp.transpose(a, b)
+    assert b.rowptr().dtype == torch.int64
+    for g, r in zip((G.host(b.rowptr()), G.host(b.colind()), G.host(b.values())), ref):
+        assert np.array_equal(g, r)
+    # the same arrays as a CSC operand with inspect: SpMV and SpMM
+    a_csc = sp.transposed(a)  # logical 900 x 700
+    x_h = np.random.default_rng(2).random(700).astype(np.float32)
+    y = torch.full((900,), float("nan"), device="cuda")
+    info = sp.multiply_inspect(a_csc, G.dev(x_h), y)
+    sp.multiply(info, a_csc, G.dev(x_h), y)
+    tr, tc, tv = ref
+    util.assert_parity(G.host(y), oracle.spmv((900, 700), tr, tc, tv, x_h), oracle.spmv_absrow(tr, tc, tv, x_h),
+                       np.float32, row_len=np.diff(tr), what="inspected csc spmv, 64-bit offsets")
+    B_h = generate.generate_dense(700, 8)
+    C = torch.full((900, 8), float("nan"), device="cuda")
+    infoC = sp.multiply_inspect(a_csc, G.dev(B_h), C)
+    sp.multiply(infoC, a_csc, G.dev(B_h), C)
+    np.testing.assert_allclose(G.host(C), oracle.spmm((900, 700), tr, tc, tv, B_h), rtol=2e-5, atol=1e-6)
