@@ -289,6 +289,63 @@ int main() {
     expect(close_vec(dc.host(), want, scale), "multiply(info, a, B, C) after multiply_inspect");
   }
 
+  // ---- 64-bit row offsets and fp64 values: csr_view<double, int32, int64> (views/csr_view.hpp is templated on all three;
+  //      the library-wide offset_t of this backend is 32-bit, a caller's view need not be) ----
+  {
+    using O64 = std::int64_t;
+    const I m = 9000, n = 11000, nc = 5;
+    const host_csr ha = random_csr(m, n, 7);
+    std::vector<O64> rp64(ha.rowptr.begin(), ha.rowptr.end());
+    std::vector<double> v64(ha.values.begin(), ha.values.end());
+    dev_array<double> dv(v64);
+    dev_array<O64> drp(rp64);
+    dev_array<I> dci(ha.colind);
+    csr_view<double, I, O64> a(dv.p, drp.p, dci.p, {m, n}, static_cast<O64>(ha.nnz()));
+    std::vector<T> hx32(n);
+    for (auto& v : hx32)
+      v = next_val();
+    std::vector<double> hx(hx32.begin(), hx32.end());
+    dev_array<double> dx(hx), dy(static_cast<std::size_t>(m));
+    std::vector<double> want, absrow;
+    host_spmv(ha, hx32, 1.0, want, absrow);
+    auto close64 = [&](const std::vector<double>& got, const std::vector<double>& w, const std::vector<double>& sc) {
+      bool ok = got.size() == w.size();
+      for (std::size_t i = 0; ok && i < got.size(); ++i)
+        ok = std::fabs(got[i] - w[i]) <= 1e-12 * sc[i] + 1e-300;
+      return ok;
+    };
+    multiply(a, dx.span(), dy.span());
+    expect(close64(dy.host(), want, absrow), "multiply(csr_view<double, int32, int64>, x, y)");
+    HIP_OK(hipMemset(dy.p, 0xFF, m * sizeof(double)));
+    operation_info_t info = multiply_inspect(a, dx.span(), dy.span());
+    multiply(info, a, dx.span(), dy.span());
+    expect(close64(dy.host(), want, absrow), "multiply(info, csr_view<double, int32, int64>, x, y)");
+    HIP_OK(hipMemset(dy.p, 0xFF, m * sizeof(double)));
+    matrix_opt a_opt(a);
+    multiply_inspect(a_opt, dx.span(), dy.span());
+    multiply(a_opt, dx.span(), dy.span());
+    expect(close64(dy.host(), want, absrow), "multiply(matrix_opt(csr_view<double, int32, int64>), x, y)");
+    std::vector<double> hb(static_cast<std::size_t>(n) * nc);
+    for (auto& v : hb)
+      v = next_val();
+    dev_array<double> db(hb), dc(static_cast<std::size_t>(m) * nc);
+    mdspan_row_major<double, I> B(db.p, n, nc), C(dc.p, m, nc);
+    std::vector<double> wantc(static_cast<std::size_t>(m) * nc, 0.0), scalec(static_cast<std::size_t>(m) * nc, 0.0);
+    for (I r = 0; r < m; ++r)
+      for (O p = ha.rowptr[r]; p < ha.rowptr[r + 1]; ++p)
+        for (I j = 0; j < nc; ++j) {
+          const double t = static_cast<double>(ha.values[p]) * hb[static_cast<std::size_t>(ha.colind[p]) * nc + j];
+          wantc[static_cast<std::size_t>(r) * nc + j] += t;
+          scalec[static_cast<std::size_t>(r) * nc + j] += std::fabs(t);
+        }
+    multiply(a, B, C);
+    expect(close64(dc.host(), wantc, scalec), "multiply(csr_view<double, int32, int64>, B, C)");
+    HIP_OK(hipMemset(dc.p, 0xFF, dc.n * sizeof(double)));
+    operation_info_t infoc = multiply_inspect(a, B, C);
+    multiply(infoc, a, B, C);
+    expect(close64(dc.host(), wantc, scalec), "multiply(info, csr_view<double, int32, int64>, B, C)");
+  }
+
   // ---- SpGEMM: multiply_compute / multiply_fill, then the symbolic / numeric split with reuse ----
   {
     const I m = 4000, k = 3000, n = 3500;
