@@ -329,6 +329,11 @@ def main():
             mode = "overlapped"
         except RuntimeError:
             op = None
+        if multi:  # all ranks or none: a rank on the striped path and a rank on the plain one would not meet in a collective
+            agree = torch.tensor([int(op is not None)], dtype=torch.int32, device=device)
+            dist.all_reduce(agree, op=dist.ReduceOp.MIN)
+            if not int(agree.item()):
+                op, mode, a_chunks = None, "plain", prob["a_chunks"]
     if op is None:
         if rmat:
             rccl_op = sharded.ShardedSpMV(a_chunks[0], bounds, inspect=args.alg != "noplan",
@@ -391,30 +396,53 @@ def main():
         # form: never the metric value, and any failure here leaves the line as it is.
         pipe_ms, pipe_ok = None, None
         if mode == "fused":
-            try:
+            # every collective below is executed by every rank whatever happened locally: a rank whose local part raised
+            # (say a barrier time-out reported by check_status) only lowers the flag that is reduced at the end
+            failed, y_p, same = None, None, 0
+
+            def local(fn):
+                nonlocal failed
+                if failed is None:
+                    try:
+                        return fn()
+                    except Exception as e:  # noqa: BLE001 - diagnostics only
+                        failed = e
+                return None
+
+            def warm():
                 for _ in range(2):
                     op.step_pipelined(x)
                 op.flush()
                 torch.cuda.synchronize()
-                dist.barrier()
-                t1 = time.perf_counter()
+
+            def timed():
                 for _ in range(k):
                     op.step_pipelined(x)
-                y_p = op.flush()
+                y = op.flush()
                 torch.cuda.synchronize()
-                dist.barrier()
-                el = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=device)
-                dist.all_reduce(el, op=dist.ReduceOp.MAX)
+                return y
+
+            def compare():
                 op.check_status()
-                y_p = y_p.clone()
+                y_keep = y_p.clone()
                 y_d = op.step(x)
                 torch.cuda.synchronize()
-                okf = torch.tensor([int(torch.equal(y_p, y_d))], dtype=torch.int32, device=device)
-                dist.all_reduce(okf, op=dist.ReduceOp.MIN)
-                pipe_ms, pipe_ok = float(el.item()) / k * 1e3, bool(int(okf.item()))
-            except Exception as e:  # noqa: BLE001 - diagnostics only
-                if rank == 0:
-                    print(f"[bench] pipelined fused step not measured: {e}", file=sys.stderr)
+                return int(torch.equal(y_keep, y_d))
+
+            local(warm)
+            dist.barrier()
+            t1 = time.perf_counter()
+            y_p = local(timed)
+            dist.barrier()
+            el = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=device)
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+            same = local(compare) or 0
+            okf = torch.tensor([0 if failed is not None else same], dtype=torch.int32, device=device)
+            dist.all_reduce(okf, op=dist.ReduceOp.MIN)
+            if failed is not None:
+                print(f"[bench] rank {rank}: pipelined fused step not measured: {failed}", file=sys.stderr)
+            pipe_ok = bool(int(okf.item()))
+            pipe_ms = float(el.item()) / k * 1e3 if pipe_ok else None
         diag = {"mode_timed": mode, "local_spmv_ms": local_s / k * 1e3, "local_spmv_event_ms": local_ev,
                 "fused_pipelined_step_ms": pipe_ms, "fused_pipelined_check": pipe_ok,
                 "gather_ms": gather_s / k * 1e3, "rccl_step_ms": rccl_s / k * 1e3,
