@@ -1105,6 +1105,8 @@ static int spgemm_symbolic_impl(spblas_gfx950_handle_t handle, spblas_gfx950_spg
                                 int32_t* c_rowptr, int64_t* c_nnz, bool identity_b) {
   if (!handle)
     return SPBLAS_GFX950_STATUS_INVALID_HANDLE;
+  if (stream_capturing(handle->stream))  // inspect-class call: sizes its output on the host, never part of a graph
+    return SPBLAS_GFX950_STATUS_NOT_SUPPORTED;
   if (!st || !c_nnz || !a_rowptr || (!identity_b && !b_rowptr) || !c_rowptr || (a_nnz > 0 && !a_colind) ||
       (b_nnz > 0 && !b_colind))
     return SPBLAS_GFX950_STATUS_INVALID_POINTER;

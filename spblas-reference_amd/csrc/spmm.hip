@@ -696,6 +696,8 @@ extern "C" int spblas_gfx950_spmm_inspect(spblas_gfx950_handle_t handle, spblas_
     return SPBLAS_GFX950_STATUS_INVALID_POINTER;
   if (plan->mm_ready)
     return SPBLAS_GFX950_STATUS_SUCCESS;
+  if (stream_capturing(handle->stream))  // inspect-class call: sizes its output on the host, never part of a graph
+    return SPBLAS_GFX950_STATUS_NOT_SUPPORTED;
   const int rc = plan->offset_type == SPBLAS_GFX950_I32 ? spmm_inspect_typed<int32_t>(handle, plan)
                                                          : spmm_inspect_typed<int64_t>(handle, plan);
   if (rc != SPBLAS_GFX950_STATUS_SUCCESS)

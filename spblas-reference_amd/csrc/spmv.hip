@@ -583,6 +583,8 @@ int spblas_gfx950_spmv_plan_create(spblas_gfx950_handle_t handle, spblas_gfx950_
                                    const void* values, int offset_type, int value_type, int alg) {
   if (!handle)
     return SPBLAS_GFX950_STATUS_INVALID_HANDLE;
+  if (stream_capturing(handle->stream))  // inspect-class call: sizes its output on the host, never part of a graph
+    return SPBLAS_GFX950_STATUS_NOT_SUPPORTED;
   if (!plan)
     return SPBLAS_GFX950_STATUS_INVALID_POINTER;
   *plan = nullptr;

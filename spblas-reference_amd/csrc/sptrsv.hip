@@ -881,6 +881,8 @@ int spblas_gfx950_sptrsv_create(spblas_gfx950_handle_t handle, spblas_gfx950_trs
                                 const int32_t* rowptr, const int32_t* colind, int uplo, int diag) {
   if (!handle)
     return SPBLAS_GFX950_STATUS_INVALID_HANDLE;
+  if (stream_capturing(handle->stream))  // inspect-class call: sizes its output on the host, never part of a graph
+    return SPBLAS_GFX950_STATUS_NOT_SUPPORTED;
   if (!plan_out || !rowptr || (nnz > 0 && !colind))
     return SPBLAS_GFX950_STATUS_INVALID_POINTER;
   if (m < 0 || nnz < 0 || m >= INT32_MAX || nnz > INT32_MAX)

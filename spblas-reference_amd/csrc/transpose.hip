@@ -432,6 +432,8 @@ extern "C" int spblas_gfx950_csr_transpose(spblas_gfx950_handle_t handle, int64_
                                            int32_t* t_rowptr, int32_t* t_colind, void* t_values, int value_type) {
   if (!handle)
     return SPBLAS_GFX950_STATUS_INVALID_HANDLE;
+  if (stream_capturing(handle->stream))  // the radix passes allocate their scratch per call
+    return SPBLAS_GFX950_STATUS_NOT_SUPPORTED;
   if (m < 0 || n < 0 || nnz < 0 || m > INT32_MAX || n >= INT32_MAX || nnz > INT32_MAX)
     return SPBLAS_GFX950_STATUS_INVALID_SIZE;
   if (value_type != SPBLAS_GFX950_F32 && value_type != SPBLAS_GFX950_F64)

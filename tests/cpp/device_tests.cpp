@@ -661,7 +661,82 @@ static void test_value_snapshot_contract() {
   }
 }
 
+// The execute call of a plan inside a HIP graph, straight through the C ABI (include/spblas_gfx950.h: "Graph capture"):
+// an iterative solver records multiply(info, A, x, y) once and replays it; inspect runs outside the capture.
+static void test_graph_capture() {
+#define HIP_REQUIRE(expr)                                                  \
+  do {                                                                     \
+    const hipError_t e_ = (expr);                                          \
+    if (e_ != hipSuccess) {                                                \
+      std::printf("FAIL %s:%d: %s -> %s\n", __FILE__, __LINE__, #expr, hipGetErrorString(e_)); \
+      ++g_fail;                                                            \
+      return;                                                              \
+    }                                                                      \
+  } while (0)
+  const int m = 30000, n = 50000;
+  auto h = generate_csr(m, n, 400000, 17);
+  device_csr a(h);
+  hipStream_t stream = nullptr;
+  HIP_REQUIRE(hipStreamCreate(&stream));
+  spblas_gfx950_handle_t handle = nullptr;
+  CHECK(spblas_gfx950_create(&handle, stream) == SPBLAS_GFX950_STATUS_SUCCESS);
+  for (int alg : {SPBLAS_GFX950_SPMV_SLICED, SPBLAS_GFX950_SPMV_ROWBLOCK}) {
+    spblas_gfx950_plan_t plan = nullptr;
+    CHECK(spblas_gfx950_spmv_plan_create(handle, &plan, m, n, h.nnz, a.rowptr.p, a.colind.p, a.values.p,
+                                         SPBLAS_GFX950_I32, SPBLAS_GFX950_F32, alg) == SPBLAS_GFX950_STATUS_SUCCESS);
+    dvec<value_t> d_x(std::vector<value_t>(n, 0)), d_y(std::vector<value_t>(m, -1));
+    const value_t alpha = 1, beta = 0;
+    auto call = [&]() {
+      return spblas_gfx950_spmv(handle, plan, SPBLAS_GFX950_OP_N, m, n, h.nnz, &alpha, a.rowptr.p, a.colind.p, a.values.p,
+                                d_x.p, &beta, d_y.p, SPBLAS_GFX950_I32, SPBLAS_GFX950_F32);
+    };
+    CHECK(call() == SPBLAS_GFX950_STATUS_SUCCESS);  // one ordinary call first
+    HIP_REQUIRE(hipStreamSynchronize(stream));
+    // creating a plan on a capturing stream is refused, not recorded
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    HIP_REQUIRE(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+    spblas_gfx950_plan_t refused = nullptr;
+    const int rc_plan = spblas_gfx950_spmv_plan_create(handle, &refused, m, n, h.nnz, a.rowptr.p, a.colind.p, a.values.p,
+                                                       SPBLAS_GFX950_I32, SPBLAS_GFX950_F32, alg);
+    const int rc_call = call();
+    HIP_REQUIRE(hipStreamEndCapture(stream, &graph));
+    CHECK(rc_plan != SPBLAS_GFX950_STATUS_SUCCESS);
+    CHECK(rc_call == SPBLAS_GFX950_STATUS_SUCCESS);
+    if (refused)
+      spblas_gfx950_plan_destroy(handle, refused);
+    HIP_REQUIRE(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    for (int rep = 0; rep < 3; ++rep) {
+      std::vector<value_t> x(n);
+      std::mt19937 g(100 + rep);
+      std::uniform_int_distribution<int> d(0, 7);
+      for (auto& v : x)
+        v = (value_t) d(g);  // small integers: sums are exact
+      HIP_REQUIRE(hipMemcpyAsync(d_x.p, x.data(), n * sizeof(value_t), hipMemcpyHostToDevice, stream));
+      HIP_REQUIRE(hipMemsetAsync(d_y.p, 0xFF, m * sizeof(value_t), stream));
+      HIP_REQUIRE(hipGraphLaunch(exec, stream));
+      HIP_REQUIRE(hipStreamSynchronize(stream));
+      auto y = d_y.download();
+      int bad = 0;
+      for (int i = 0; i < m; i++) {
+        value_t ref = 0;
+        for (auto p = h.rowptr[i]; p < h.rowptr[i + 1]; p++)
+          ref += h.values[p] * x[h.colind[p]];
+        bad += near_ref(ref, y[i]) ? 0 : 1;
+      }
+      CHECK(bad == 0);
+    }
+    HIP_REQUIRE(hipGraphExecDestroy(exec));
+    HIP_REQUIRE(hipGraphDestroy(graph));
+    CHECK(spblas_gfx950_plan_destroy(handle, plan) == SPBLAS_GFX950_STATUS_SUCCESS);
+  }
+  CHECK(spblas_gfx950_destroy(handle) == SPBLAS_GFX950_STATUS_SUCCESS);
+  HIP_REQUIRE(hipStreamDestroy(stream));
+#undef HIP_REQUIRE
+}
+
 int main() {
+  test_graph_capture();
   test_scale();
   test_value_snapshot_contract();
   test_spmv();

@@ -223,3 +223,43 @@ def test_spmm_with_long_rows_needs_one_call_outside_the_capture(gpu):
     g.replay()
     torch.cuda.synchronize()
     np.testing.assert_allclose(G.host(C), oracle.spmm(shape, rowptr, colind, values, B_h), rtol=5e-5)
+
+
+def test_inspect_class_calls_are_refused_inside_a_capture(gpu):
+    """multiply_inspect, multiply_compute, transpose and triangular_solve_inspect size their results on the host and
+    allocate: on a capturing stream they return NOT_SUPPORTED at once (nothing is recorded, the capture stays valid) and
+    work again right after it."""
+    values, rowptr, colind, shape, nnz = generate.generate_csr(4000, 5000, 60000, seed=71)
+    a = sp.csr_view(G.dev(values), G.dev(rowptr), G.dev(colind), shape, nnz)
+    x = torch.rand(5000, device="cuda")
+    y = torch.zeros(4000, device="cuda")
+    t = sp.csr_view(torch.zeros(nnz, device="cuda"), torch.zeros(5001, dtype=torch.int32, device="cuda"),
+                    torch.zeros(nnz, dtype=torch.int32, device="cuda"), (5000, 4000), nnz)
+    c_rp = torch.zeros(4001, dtype=torch.int32, device="cuda")
+    sp.multiply(a, x, y)  # the thread's handle exists before the capture
+    torch.cuda.synchronize()
+    refused = []
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for name, fn in (("multiply_inspect", lambda: sp.multiply_inspect(a, x, y, alg=_capi.SPMV_SLICED)),
+                         ("transpose", lambda: sp.transpose(a, t)),
+                         ("multiply_compute", lambda: sp.multiply_compute(a, sp.csr_view(t.values(), t.rowptr(), t.colind(),
+                                                                                         (5000, 4000), nnz),
+                                                                          sp.csr_view(None, c_rp, None, (4000, 4000), 0)))):
+            try:
+                fn()
+            except Exception as e:  # noqa: BLE001
+                refused.append((name, str(e)))
+        sp.multiply(a, x, y)  # the plan-free execute IS recordable
+    assert [n for n, _ in refused] == ["multiply_inspect", "transpose", "multiply_compute"], refused
+    assert all("not supported" in msg.lower() for _, msg in refused), refused
+    x.copy_(torch.rand(5000, device="cuda"))
+    g.replay()
+    torch.cuda.synchronize()
+    util.assert_parity(G.host(y), oracle.spmv(shape, rowptr, colind, values, G.host(x)),
+                       oracle.spmv_absrow(rowptr, colind, values, G.host(x)), np.float32, row_len=np.diff(rowptr),
+                       what="plan-free SpMV recorded next to refused inspect calls")
+    info = sp.multiply_inspect(a, x, y, alg=_capi.SPMV_SLICED)  # and outside the capture everything works as before
+    sp.multiply(info, a, x, y)
+    sp.transpose(a, t)
+    torch.cuda.synchronize()
