@@ -524,9 +524,12 @@ def main():
         local_bytes = spmv_bytes(rows_local, n, nnz_local, tsize)
         achieved = local_bytes / (kern_avg_ms * 1e-3) / 1e9
         alg_id = plan_info.get("alg")
-        traffic, traffic_src = read_pmc_traffic(prob["pmc_key"]) if (prob["pmc_key"] and alg_id == 3) else (None, None)
         u8 = plan_info.get("sliced", {}).get("row_code_u8")
-        kernels = {3: f"pb_expand_kernel<{'float' if tsize == 4 else 'double'}> + pb_reduce_kernel<{'float' if tsize == 4 else 'double'},4,{'2,true' if u8 else '4,false'}> "
+        nt = plan_info.get("sliced", {}).get("nt_product_stores")
+        # (the counters were taken for both flavours of the expand's product stores; the plan says which one this box picked)
+        pmc_key = prob["pmc_key"] + ("_nt" if (nt and prob["pmc_key"] == "spmv_cfg2") else "") if prob["pmc_key"] else None
+        traffic, traffic_src = read_pmc_traffic(pmc_key) if (pmc_key and alg_id == 3) else (None, None)
+        kernels = {3: f"pb_expand_kernel<{'float' if tsize == 4 else 'double'},{'true' if nt else 'false'}> + pb_reduce_kernel<{'float' if tsize == 4 else 'double'},4,{'2,true' if u8 else '4,false'}> "
                       "(one SpMV = this launch pair)",
                    2: f"spmv_rowblock_kernel<{'float,int,2048' if tsize == 4 else 'double,int,1024'}> (+ spmv_long_fixup_kernel)",
                    1: "spmv_vector_kernel<T,int,LPR>"}

@@ -166,8 +166,11 @@ int spblas_gfx950_plan_info(spblas_gfx950_plan_t plan, int64_t info[12]);
  * [3]=blocks in reduce order (bins padded to groups of 8 blocks), [4]=entries placed in tiles, [5]=#rows kept out of
  * the tiles (hub rows), [6]=hub threshold (row length), [7]=reduce K split, [8]=rows the tiles are built over (fewer
  * than m when the empty rows were taken out).  For ANY plan: [9] bit 0 = AUTO decided by a timed trial, bit 1 = the
- * reduce streams one-byte row codes (runs sorted by row) instead of 16-bit rows, [10]/[11]=time
- * of the row-block / the sliced plan in that trial, nanoseconds. */
+ * reduce streams one-byte row codes (runs sorted by row) instead of 16-bit rows, bit 2 = the expand stores its products
+ * with the non-temporal hint, bit 3 = this plan ran the store trial that decides bit 2 (plans with >= 32 M placed
+ * entries, once per process, device and value size; SPBLAS_GFX950_PB_NT=0/1 forces the flavour); [10]/[11]=time of the
+ * row-block / the sliced plan in AUTO's trial, nanoseconds -- or, when only the store trial ran, of one SpMV with plain /
+ * non-temporal product stores. */
 int spblas_gfx950_plan_info_sliced(spblas_gfx950_plan_t plan, int64_t info[12]);
 
 /* Two-stage execution of a SLICED plan (other plans: STATUS_NOT_SUPPORTED), used to overlap the

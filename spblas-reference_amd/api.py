@@ -312,8 +312,14 @@ class _Plan:
         names = ["n_bins", "variable_bins", "expand_blocks", "reduce_blocks", "placed_entries", "hub_rows", "hub_len",
                  "ksplit", "tiled_rows", "auto_trial", "trial_rowblock_ns", "trial_sliced_ns"]
         d = dict(zip(names, list(arr)))
-        d["row_code_u8"] = (d["auto_trial"] >> 1) & 1  # one-byte row codes in the reduce's stream (runs sorted by row)
-        d["auto_trial"] &= 1
+        bits = d["auto_trial"]
+        d["row_code_u8"] = (bits >> 1) & 1  # one-byte row codes in the reduce's stream (runs sorted by row)
+        d["nt_product_stores"] = (bits >> 2) & 1  # the expand stores its products with the non-temporal hint
+        d["store_trial"] = (bits >> 3) & 1  # THIS plan timed both store flavours (once per process, device and value size)
+        d["auto_trial"] = bits & 1
+        if d["store_trial"] and not d["auto_trial"]:  # (the two time slots carry AUTO's trial when both ran)
+            d["store_trial_ns"] = {"plain": d.pop("trial_rowblock_ns"), "non_temporal": d.pop("trial_sliced_ns")}
+            d["trial_rowblock_ns"] = d["trial_sliced_ns"] = 0
         return d
 
     # two-stage execution of a SLICED plan (include/spblas_gfx950.h: spmv_expand / spmv_reduce_rows)

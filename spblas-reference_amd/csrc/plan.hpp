@@ -104,6 +104,8 @@ struct spblas_gfx950_plan_s {
   // AUTO: the static rules could not tell which plan is faster (hot columns / heavy rows): plan_create times both
   int s_uncertain = 0;
   float trial_ms[2] = {0.f, 0.f};  // {row-block, sliced} when the trial ran
+  int nt_products = 0;             // SLICED: the expand stores its products with the non-temporal hint (spmv.hip: store_trial)
+  float store_trial_ms[2] = {0.f, 0.f};  // {plain, non-temporal} when THIS plan ran the per-device store trial
 
   // SpMM inspect (spblas_gfx950_spmm_inspect, spmm.hip): row blocks of 32 rows whose entries fall into at most 16
   // aligned tiles of 128 columns, densely enough, are multiplied from LDS-staged B tiles on the matrix cores

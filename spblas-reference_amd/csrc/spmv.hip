@@ -17,6 +17,7 @@
 #include "common.hpp"
 #include "plan.hpp"
 
+#include <atomic>
 #include <cstdlib>
 
 namespace spb {
@@ -572,6 +573,83 @@ static int auto_trial(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const 
   return SPBLAS_GFX950_STATUS_SUCCESS;
 }
 
+// Store trial (SLICED plans with >= 32 M placed entries: the product array is far larger than any cache): which flavour of
+// product store is faster is a property of the box, not of the matrix -- where the reduce pays for the expand's
+// write-backs the non-temporal hint wins 1-3 %, elsewhere it loses 3 % (tools/exp_r03o.sh, profiles/r03_store_trial.md).
+// Decided once per process, device and value size by timing the plan both ways (a warm-up and two timed runs each,
+// interleaved); later plans reuse the decision.  SPBLAS_GFX950_PB_NT = 0 / 1 forces it, unset or -1 = this trial.
+static std::atomic<int> g_nt_choice[32][2];  // [device][fp32 / fp64]: 0 = unknown, 1 = plain, 2 = non-temporal
+static void store_trial(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const void* values) {
+  const int forced = env_int_spmv("SPBLAS_GFX950_PB_NT", -1);
+  if (forced == 0 || forced == 1) {
+    pl->nt_products = forced;
+    return;
+  }
+  pl->nt_products = 0;
+  if (pl->s_placed < ((int64_t) 32 << 20))
+    return;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) {
+    (void) hipGetLastError();
+    return;
+  }
+  const size_t tsz = pl->value_type == SPBLAS_GFX950_F32 ? 4 : 8;
+  std::atomic<int>& slot = g_nt_choice[dev][tsz == 4 ? 0 : 1];
+  const int known = slot.load();
+  if (known != 0) {
+    pl->nt_products = known == 2;
+    return;
+  }
+  hipStream_t s = h->stream;
+  void *x = nullptr, *y = nullptr;
+  if (dev_alloc(&x, (size_t) pl->n * tsz, s) != SPBLAS_GFX950_STATUS_SUCCESS)
+    return;
+  if (dev_alloc(&y, (size_t) pl->m * tsz, s) != SPBLAS_GFX950_STATUS_SUCCESS) {
+    dev_free(x, s);
+    return;
+  }
+  hipEvent_t ev[2] = {nullptr, nullptr};
+  bool ok = hipMemsetAsync(x, 0, (size_t) pl->n * tsz, s) == hipSuccess;
+  for (int i = 0; i < 2 && ok; ++i)
+    ok = hipEventCreate(&ev[i]) == hipSuccess;
+  const double one = 1.0, zero = 0.0;
+  const float onef = 1.f, zerof = 0.f;
+  const void* alpha = tsz == 4 ? (const void*) &onef : (const void*) &one;
+  const void* beta = tsz == 4 ? (const void*) &zerof : (const void*) &zero;
+  const int saved_alg = pl->alg;
+  pl->alg = SPBLAS_GFX950_SPMV_SLICED;
+  auto run = [&](int nt) {
+    pl->nt_products = nt;
+    return spblas_gfx950_spmv(h, pl, SPBLAS_GFX950_OP_N, pl->m, pl->n, pl->nnz, alpha, pl->rowptr, pl->colind, values, x, beta, y,
+                              pl->offset_type, pl->value_type) == SPBLAS_GFX950_STATUS_SUCCESS;
+  };
+  float best[2] = {1e30f, 1e30f};
+  ok = ok && run(0) && run(1);  // warm-up of both kernels
+  for (int rep = 0; rep < 2 && ok; ++rep)
+    for (int nt = 0; nt < 2 && ok; ++nt) {
+      // two SpMVs per sample: the second one's expand runs behind a reduce, as in a solver loop
+      ok = hipEventRecord(ev[0], s) == hipSuccess && run(nt) && run(nt) && hipEventRecord(ev[1], s) == hipSuccess &&
+           hipEventSynchronize(ev[1]) == hipSuccess;
+      float ms = 0.f;
+      if (ok && hipEventElapsedTime(&ms, ev[0], ev[1]) == hipSuccess && ms < best[nt])
+        best[nt] = ms;
+    }
+  (void) hipStreamSynchronize(s);
+  for (int i = 0; i < 2; ++i)
+    if (ev[i])
+      (void) hipEventDestroy(ev[i]);
+  dev_free(x, s);
+  dev_free(y, s);
+  pl->alg = saved_alg;
+  pl->nt_products = 0;
+  if (ok) {
+    pl->store_trial_ms[0] = 0.5f * best[0];
+    pl->store_trial_ms[1] = 0.5f * best[1];
+    pl->nt_products = best[1] < 0.99f * best[0];  // the hint has to win by more than the noise of two samples
+    slot.store(pl->nt_products ? 2 : 1);
+  }
+}
+
 } // namespace spb
 
 using namespace spb;
@@ -615,6 +693,8 @@ int spblas_gfx950_spmv_plan_create(spblas_gfx950_handle_t handle, spblas_gfx950_
                                             : plan_build<int64_t>(handle, pl, alg);
   if (rc == SPBLAS_GFX950_STATUS_SUCCESS && pl->alg == SPBLAS_GFX950_SPMV_SLICED) {
     rc = spmv_sliced_build(handle, pl, values, false);
+    if (rc == SPBLAS_GFX950_STATUS_SUCCESS)
+      store_trial(handle, pl, values);
   } else if (rc == SPBLAS_GFX950_STATUS_SUCCESS && alg == SPBLAS_GFX950_SPMV_AUTO && values &&
              handle->value_snapshot != 0 && pl->alg == SPBLAS_GFX950_SPMV_ROWBLOCK && sliced_candidate(pl)) {
     // (only with SPBLAS_GFX950_OPT_VALUE_SNAPSHOT: the sliced plan keeps a copy of the values, and a caller
@@ -626,10 +706,12 @@ int spblas_gfx950_spmv_plan_create(spblas_gfx950_handle_t handle, spblas_gfx950_
       bool keep = true;
       if (pl->s_uncertain)
         (void) auto_trial(handle, pl, values, &keep);
-      if (keep)
+      if (keep) {
         pl->alg = SPBLAS_GFX950_SPMV_SLICED;
-      else
+        store_trial(handle, pl, values);
+      } else {
         spmv_sliced_free(handle, pl);
+      }
     } else {
       spmv_sliced_free(handle, pl);
       if (rc2 != SPBLAS_GFX950_STATUS_NOT_SUPPORTED)
@@ -815,9 +897,12 @@ int spblas_gfx950_plan_info_sliced(spblas_gfx950_plan_t plan, int64_t info[12]) 
   info[6] = sl ? plan->hub_len : 0;
   info[7] = sl ? plan->n_ksplit : 0;
   info[8] = sl ? plan->s_m : 0;
-  info[9] = (plan->trial_ms[0] > 0.f ? 1 : 0) | (sl && plan->enc8 ? 2 : 0);  // bit 0: AUTO ran its trial, bit 1: one-byte row codes
-  info[10] = (int64_t) (plan->trial_ms[0] * 1e6f);
-  info[11] = (int64_t) (plan->trial_ms[1] * 1e6f);
+  // bit 0: AUTO ran its trial, bit 1: one-byte row codes, bit 2: non-temporal product stores, bit 3: this plan ran the store trial
+  info[9] = (plan->trial_ms[0] > 0.f ? 1 : 0) | (sl && plan->enc8 ? 2 : 0) | (sl && plan->nt_products ? 4 : 0) |
+            (plan->store_trial_ms[0] > 0.f ? 8 : 0);
+  const float* tms = plan->trial_ms[0] > 0.f ? plan->trial_ms : plan->store_trial_ms;  // AUTO's times, else the store trial's
+  info[10] = (int64_t) (tms[0] * 1e6f);
+  info[11] = (int64_t) (tms[1] * 1e6f);
   return SPBLAS_GFX950_STATUS_SUCCESS;
 }
 

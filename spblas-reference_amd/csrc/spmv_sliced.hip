@@ -39,6 +39,7 @@
 // The order of additions into a row is fixed by the plan, so results are run-to-run
 // reproducible for a given plan (plans built twice may order entries differently).
 #include <algorithm>
+#include <type_traits>
 #include <vector>
 
 #include "common.hpp"
@@ -953,6 +954,11 @@ struct pack4<float> {
     *reinterpret_cast<f32x4*>(p) = v;  // plain store: 12 % faster than nt here (measured)
 #endif
   }
+  static __device__ __forceinline__ void store_nt(float* p, const float (&o)[4]) {
+    f32x4 v;
+    v.x = o[0]; v.y = o[1]; v.z = o[2]; v.w = o[3];
+    __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
+  }
 };
 template <>
 struct pack4<double> {
@@ -972,6 +978,12 @@ struct pack4<double> {
     reinterpret_cast<f64x2*>(p)[0] = a;
     reinterpret_cast<f64x2*>(p)[1] = b;
   }
+  static __device__ __forceinline__ void store_nt(double* p, const double (&o)[4]) {
+    f64x2 a, b;
+    a.x = o[0]; a.y = o[1]; b.x = o[2]; b.y = o[3];
+    __builtin_nontemporal_store(a, reinterpret_cast<f64x2*>(p));
+    __builtin_nontemporal_store(b, reinterpret_cast<f64x2*>(p) + 1);
+  }
 };
 
 typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
@@ -980,7 +992,11 @@ typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
 // The x slice lives in LDS.  Eight consecutive lanes own one block of 32 entries (4 entries = 16 B of values,
 // 8 B of columns each): the wavefront reads 8 consecutive blocks -- 1 KiB of values -- and stores 8 whole
 // 128-byte lines of products, each at the place the reduce kernel's stream wants it.
-template <typename T>
+// NT: the products are stored with the non-temporal hint.  Which flavour is faster depends on the BOX (round 3,
+// tools/exp_r03o.sh, same binaries): where the reduce pays for the expand's write-backs (reduce 118-122 us after plain
+// stores) the hint moves that cost into the expand and the pair gains 1-3 %; where it does not (reduce 105-107 us) the hint
+// costs 3 %.  spblas_gfx950_spmv_plan_create times both once per process and device for large plans (spmv.hip: store_trial).
+template <typename T, bool NT>
 __global__ __launch_bounds__(PB_THREADS) void pb_expand_kernel(int64_t n, int W, const int32_t* __restrict__ sliceblk,
                                                                const T* __restrict__ s_val,
                                                                const uint16_t* __restrict__ s_col,
@@ -1013,8 +1029,16 @@ __global__ __launch_bounds__(PB_THREADS) void pb_expand_kernel(int64_t n, int W,
     for (int i = tid; i < cw; i += PB_THREADS)
       xs[i] = x[c0 + i];
   };
-  // blocks [b0, b1) of the slice whose x values are in LDS; two passes in flight
-  auto process = [&](int b0, int b1) {
+  // blocks [b0, b1) of the slice whose x values are in LDS; two passes in flight.  nt_tag (A/B builds only): products stored
+  // non-temporally
+  auto process_impl = [&](auto nt_tag, int b0, int b1) {
+    constexpr bool nt_store = decltype(nt_tag)::value;
+    auto put = [&](T* ptr, const T (&val)[4]) {
+      if constexpr (nt_store)
+        pack4<T>::store_nt(ptr, val);
+      else
+        pack4<T>::store(ptr, val);
+    };
     int blk = b0 + bsel;
     // A' is compact (round 3): the entries of block k start at blksrc[k], a multiple of 4; the lanes past the end of a
     // run's last block read the entries that follow it -- their products land on pad positions of P, which the reduce
@@ -1039,8 +1063,8 @@ __global__ __launch_bounds__(PB_THREADS) void pb_expand_kernel(int64_t n, int W,
         pa[j] = va[j] * xs[ca[j]];
         pb[j] = vb[j] * xs[cb[j]];
       }
-      pack4<T>::store(P + (int64_t) da * PB_BLK + sub, pa);
-      pack4<T>::store(P + (int64_t) db * PB_BLK + sub, pb);
+      put(P + (int64_t) da * PB_BLK + sub, pa);
+      put(P + (int64_t) db * PB_BLK + sub, pb);
     }
     for (; blk < b1; blk += PASS) {
       const int ea = stream_load(blksrc + blk) + sub;
@@ -1051,8 +1075,18 @@ __global__ __launch_bounds__(PB_THREADS) void pb_expand_kernel(int64_t n, int W,
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         pa[j] = va[j] * xs[ca[j]];
-      pack4<T>::store(P + (int64_t) da * PB_BLK + sub, pa);
+      put(P + (int64_t) da * PB_BLK + sub, pa);
     }
+  };
+  auto process = [&](int b0, int b1) {
+#ifdef PB_EXP_NT_TAIL_PCT  // A/B only: the last N % of a workgroup's blocks are stored non-temporally (do the write-backs that
+    // the reduce runs into come from the END of the expand?  tools/exp_r03n.sh: no -- 10 / 25 / 50 % buy 2-3 us, all of them 5)
+    const int nt_from = b1 - (int) ((long long) (b1 - b0) * PB_EXP_NT_TAIL_PCT / 100);
+    process_impl(std::false_type{}, b0, nt_from);
+    process_impl(std::true_type{}, nt_from, b1);
+#else
+    process_impl(std::integral_constant<bool, NT>{}, b0, b1);
+#endif
   };
   if (items) {
     // items (column-skewed matrices): workgroup i takes the blocks [items[i].y, items[i].z) of slice items[i].x,
@@ -2281,7 +2315,9 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
     tr.mark("fallback to 16-bit rows");
   }
   tr.mark("flags");
-  SPB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pb_expand_kernel<T>),
+  SPB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pb_expand_kernel<T, false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, xlds > PB_LDS_BYTES ? xlds : PB_LDS_BYTES));
+  SPB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pb_expand_kernel<T, true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, xlds > PB_LDS_BYTES ? xlds : PB_LDS_BYTES));
   for (int ub : {1, 2, 4, 8})
     SPB_HIP(hipFuncSetAttribute(pb_reduce_fn<T>(pl->rwaves, ub, pl->enc8 != 0), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -2358,11 +2394,18 @@ static int sliced_expand_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* p
     return SPBLAS_GFX950_STATUS_SUCCESS;  // timing experiment: the reduce alone
   const int share = (int) cdiv(total, nwg);
   const dim3 grid = items ? dim3((unsigned) pl->n_xitems) : dim3((unsigned) cdiv(total, share));
-  hipLaunchKernelGGL((pb_expand_kernel<T>), grid, dim3(PB_THREADS), xbytes, h->stream, pl->n, pl->slice_cols,
-                     static_cast<const int32_t*>(pl->s_sliceblk), static_cast<const T*>(pl->s_values),
-                     reinterpret_cast<const uint16_t*>(pl->s_colind), static_cast<const int32_t*>(pl->s_blkdst),
-                     static_cast<const T*>(x), static_cast<T*>(pl->s_products), items, (int) pl->n_slices, share,
-                     static_cast<const int32_t*>(pl->s_blksrc));
+  if (pl->nt_products)
+    hipLaunchKernelGGL((pb_expand_kernel<T, true>), grid, dim3(PB_THREADS), xbytes, h->stream, pl->n, pl->slice_cols,
+                       static_cast<const int32_t*>(pl->s_sliceblk), static_cast<const T*>(pl->s_values),
+                       reinterpret_cast<const uint16_t*>(pl->s_colind), static_cast<const int32_t*>(pl->s_blkdst),
+                       static_cast<const T*>(x), static_cast<T*>(pl->s_products), items, (int) pl->n_slices, share,
+                       static_cast<const int32_t*>(pl->s_blksrc));
+  else
+    hipLaunchKernelGGL((pb_expand_kernel<T, false>), grid, dim3(PB_THREADS), xbytes, h->stream, pl->n, pl->slice_cols,
+                       static_cast<const int32_t*>(pl->s_sliceblk), static_cast<const T*>(pl->s_values),
+                       reinterpret_cast<const uint16_t*>(pl->s_colind), static_cast<const int32_t*>(pl->s_blkdst),
+                       static_cast<const T*>(x), static_cast<T*>(pl->s_products), items, (int) pl->n_slices, share,
+                       static_cast<const int32_t*>(pl->s_blksrc));
   SPB_HIP(hipGetLastError());
   return SPBLAS_GFX950_STATUS_SUCCESS;
 }

@@ -749,3 +749,83 @@ def test_spmv_auto_declines_sliced_for_skewed_matrices(gpu, monkeypatch, varbins
     info.state_.update_values(a.values())
     sp.multiply(info, a, xd, y)
     check(-val2, rowptr2, col2, (m, n), x, G.host(y), what="heavy row block (after update)", ref_cmp=False)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("nt", ["0", "1"])
+def test_spmv_sliced_product_store_flavours(gpu, monkeypatch, dtype, nt):
+    """The expand kernel exists with plain and with non-temporal product stores (which is faster depends on the box;
+    plans with >= 32 M entries time both once per process, csrc/spmv.hip: store_trial).  Forced either way here on a
+    matrix with ragged rows, a long row and duplicates: same answers, and the plan reports what it runs."""
+    monkeypatch.setenv("SPBLAS_GFX950_PB_NT", nt)
+    rng = np.random.default_rng(17)
+    m, n = 40000, 90000
+    lens = rng.integers(0, 25, m)
+    lens[123] = 20000
+    rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    nnz = int(rowptr[-1])
+    colind = rng.integers(0, n, nnz).astype(np.int32)
+    colind[:50] = 7  # duplicates inside the first rows
+    values = (rng.random(nnz) - 0.5).astype(dtype)
+    x = (rng.random(n) - 0.5).astype(dtype)
+    a = G.csr_on_device(values, rowptr, colind, (m, n), nnz)
+    xd = G.dev(x)
+    y = torch.full((m,), float("nan"), dtype=xd.dtype, device="cuda")
+    info = sp.multiply_inspect(a, xd, y, alg=_capi.SPMV_SLICED)
+    si = info.state_.sliced_info()
+    assert si["nt_product_stores"] == int(nt) and si["store_trial"] == 0
+    sp.multiply(info, a, xd, y)
+    check(values, rowptr, colind, (m, n), x, G.host(y), what=f"product stores nt={nt}", ref_cmp=False)
+
+
+def test_spmv_store_trial_runs_once_per_process_at_cfg2_size(gpu, monkeypatch):
+    """Plans with >= 32 M placed entries let the first of them time the SpMV with plain and with non-temporal product
+    stores (the faster flavour is a property of the box: tools/exp_r03o.sh) and keep the decision for the process.  Run in a
+    fresh interpreter: the first cfg2-sized plan reports the trial and its two times, the second one only the decision;
+    both forced flavours give the same y to rounding."""
+    import subprocess
+    import sys
+    code = r'''
+import json, os, sys, torch
+sys.path.insert(0, os.getcwd())
+import spblas_reference_amd as sp
+from spblas_reference_amd import generate, _capi
+n = 10_000_000
+v, rp, ci, shape, nnz = generate.uniform_csr_device(n, n, 10, seed=0)
+a = sp.csr_view(v, rp, ci, shape, nnz)
+x = torch.rand(n, device="cuda"); ys = []
+out = {}
+for tag, env in (("first", None), ("second", None), ("plain", "0"), ("nt", "1")):
+    if env is None:
+        os.environ.pop("SPBLAS_GFX950_PB_NT", None)
+    else:
+        os.environ["SPBLAS_GFX950_PB_NT"] = env
+    y = torch.full((n,), float("nan"), device="cuda")
+    info = sp.multiply_inspect(sp.matrix_opt(a), x, y)
+    assert info.state_.info()["alg"] == _capi.SPMV_SLICED
+    sp.multiply(info, a, x, y)
+    torch.cuda.synchronize()
+    out[tag] = info.state_.sliced_info()
+    ys.append(y)
+    del info
+absrow = torch.zeros(n, device="cuda")
+sp.multiply(sp.csr_view(v.abs(), rp, ci, shape, nnz), x, absrow)
+out["max_diff"] = max(float(((ys[i] - ys[2]).abs() / absrow).max()) for i in (0, 1, 3))
+print("RESULT " + json.dumps(out))
+'''
+    env = dict(os.environ)
+    env.pop("SPBLAS_GFX950_PB_NT", None)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    import json
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])
+    first, second = out["first"], out["second"]
+    assert first["store_trial"] == 1 and second["store_trial"] == 0
+    t = first["store_trial_ns"]
+    assert 150_000 < t["plain"] < 600_000 and 150_000 < t["non_temporal"] < 600_000, t
+    assert first["nt_product_stores"] == int(t["non_temporal"] < 0.99 * t["plain"])
+    assert second["nt_product_stores"] == first["nt_product_stores"]
+    assert out["plain"]["nt_product_stores"] == 0 and out["nt"]["nt_product_stores"] == 1
+    assert out["plain"]["store_trial"] == 0 and out["nt"]["store_trial"] == 0
+    assert out["max_diff"] <= 2e-6
