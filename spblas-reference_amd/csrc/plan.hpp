@@ -56,6 +56,7 @@ struct spblas_gfx950_plan_s {
   int32_t* s_exc_cnt = nullptr;     // [NB] exceptions per wave-bin; [NB] = "encoding failed" flag of the build
   int exc_cap = 0;
   void* s_products = nullptr;  // T[p_blocks*32] workspace: expanded products (P order)
+  size_t s_products_bytes = 0;
   int64_t a_blocks = 0, p_blocks = 0;
   int n_ksplit = 1;            // reduce workgroups per bin group (every wave-bin's stream cut into K parts)
   int rwaves = 4;              // reduce: wave-bins (= wavefronts) per workgroup

@@ -574,18 +574,19 @@ static int auto_trial(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const 
 }
 
 // Store trial (SLICED plans with >= 32 M placed entries: the product array is far larger than any cache): which flavour of
-// product store is faster is a property of the box, not of the matrix -- where the reduce pays for the expand's
-// write-backs the non-temporal hint wins 1-3 %, elsewhere it loses 3 % (tools/exp_r03o.sh, profiles/r03_store_trial.md).
-// Decided once per process, device and value size by timing the plan both ways (a warm-up and two timed runs each,
-// interleaved); later plans reuse the decision.  SPBLAS_GFX950_PB_NT = 0 / 1 forces it, unset or -1 = this trial.
+// product store is faster is a property of the box and the moment, not of the matrix -- where the reduce pays for the
+// expand's write-backs the non-temporal hint wins 1-4 %, elsewhere it loses 3 % (tools/exp_r03o.sh,
+// profiles/r03_store_trial.md).  Decided once per process, device and value size by timing the plan both ways (a warm-up
+// and two samples of two SpMVs each, interleaved, on a zero vector); later plans reuse the decision.
+// SPBLAS_GFX950_PB_NT = 0 / 1 forces it, unset or -1 = this trial.
+// (Also tried and NOT kept, same file: timing several placements of the product workspace.  The same plan runs 280-310 us
+// depending on which memory that one array got, but nothing the library can ask for -- another pool allocation, a fresh or
+// a contiguous one, an offset inside a larger one -- finds the fast kind reliably, and on four boxes in a row the search
+// ended 2 % slower than no search.)
 static std::atomic<int> g_nt_choice[32][2];  // [device][fp32 / fp64]: 0 = unknown, 1 = plain, 2 = non-temporal
 static void store_trial(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const void* values) {
   const int forced = env_int_spmv("SPBLAS_GFX950_PB_NT", -1);
-  if (forced == 0 || forced == 1) {
-    pl->nt_products = forced;
-    return;
-  }
-  pl->nt_products = 0;
+  pl->nt_products = forced == 1;
   if (pl->s_placed < ((int64_t) 32 << 20))
     return;
   int dev = 0;
@@ -595,7 +596,7 @@ static void store_trial(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, cons
   }
   const size_t tsz = pl->value_type == SPBLAS_GFX950_F32 ? 4 : 8;
   std::atomic<int>& slot = g_nt_choice[dev][tsz == 4 ? 0 : 1];
-  const int known = slot.load();
+  const int known = (forced == 0 || forced == 1) ? forced + 1 : slot.load();
   if (known != 0) {
     pl->nt_products = known == 2;
     return;
@@ -623,17 +624,32 @@ static void store_trial(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, cons
     return spblas_gfx950_spmv(h, pl, SPBLAS_GFX950_OP_N, pl->m, pl->n, pl->nnz, alpha, pl->rowptr, pl->colind, values, x, beta, y,
                               pl->offset_type, pl->value_type) == SPBLAS_GFX950_STATUS_SUCCESS;
   };
-  float best[2] = {1e30f, 1e30f};
-  ok = ok && run(0) && run(1);  // warm-up of both kernels
-  for (int rep = 0; rep < 2 && ok; ++rep)
-    for (int nt = 0; nt < 2 && ok; ++nt) {
-      // two SpMVs per sample: the second one's expand runs behind a reduce, as in a solver loop
-      ok = hipEventRecord(ev[0], s) == hipSuccess && run(nt) && run(nt) && hipEventRecord(ev[1], s) == hipSuccess &&
-           hipEventSynchronize(ev[1]) == hipSuccess;
-      float ms = 0.f;
-      if (ok && hipEventElapsedTime(&ms, ev[0], ev[1]) == hipSuccess && ms < best[nt])
-        best[nt] = ms;
+  // one sample = two SpMVs (the second one's expand runs behind a reduce, as in a solver loop), in ms per SpMV
+  auto sample = [&](int nt, float* out) {
+    float ms = 0.f;
+    const bool good = hipEventRecord(ev[0], s) == hipSuccess && run(nt) && run(nt) && hipEventRecord(ev[1], s) == hipSuccess &&
+                      hipEventSynchronize(ev[1]) == hipSuccess && hipEventElapsedTime(&ms, ev[0], ev[1]) == hipSuccess;
+    *out = 0.5f * ms;
+    return good;
+  };
+  if (ok) {
+    float best[2] = {1e30f, 1e30f};
+    ok = run(0) && run(1);  // warm-up of both kernels
+    for (int rep = 0; rep < 2 && ok; ++rep)
+      for (int nt = 0; nt < 2 && ok; ++nt) {
+        float ms = 0.f;
+        ok = sample(nt, &ms);
+        if (ok && ms < best[nt])
+          best[nt] = ms;
+      }
+    pl->nt_products = 0;
+    if (ok) {
+      pl->store_trial_ms[0] = best[0];
+      pl->store_trial_ms[1] = best[1];
+      pl->nt_products = best[1] < 0.99f * best[0];  // the hint has to win by more than the noise of two samples
+      slot.store(pl->nt_products ? 2 : 1);
     }
+  }
   (void) hipStreamSynchronize(s);
   for (int i = 0; i < 2; ++i)
     if (ev[i])
@@ -641,13 +657,6 @@ static void store_trial(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, cons
   dev_free(x, s);
   dev_free(y, s);
   pl->alg = saved_alg;
-  pl->nt_products = 0;
-  if (ok) {
-    pl->store_trial_ms[0] = 0.5f * best[0];
-    pl->store_trial_ms[1] = 0.5f * best[1];
-    pl->nt_products = best[1] < 0.99f * best[0];  // the hint has to win by more than the noise of two samples
-    slot.store(pl->nt_products ? 2 : 1);
-  }
 }
 
 } // namespace spb

@@ -2076,6 +2076,7 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
   }
   if ((rc = dev_alloc((void**) &pl->s_products, (size_t) (p_pad + PB_GRP) * sizeof(T), s)))
     return rc;
+  pl->s_products_bytes = (size_t) (p_pad + PB_GRP) * sizeof(T);
   pl->device_bytes += (size_t) a_pad * (sizeof(T) + 6) + (size_t) a_blocks * 8 + (size_t) p_pad * sizeof(T) +
                       (enc8 ? (size_t) p_pad + hdr_bytes + (size_t) NB * PB_EXC_CAP * 6 : (size_t) p_pad * 2) +
                       (size_t) (NB + S + 2) * 4 + (size_t) nseg * 4;
@@ -2315,6 +2316,10 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
     tr.mark("fallback to 16-bit rows");
   }
   tr.mark("flags");
+  if (tr.on)  // where the streams of the launch pair live (round 3: the same plan runs 292-315 us depending on where they land)
+    std::fprintf(stderr, "[inspect] arrays: s_val %p s_col %p blkdst %p blksrc %p P %p rows %p hdr %p  (a_pad %lld, p_pad %lld)\n",
+                 pl->s_values, pl->s_colind, pl->s_blkdst, pl->s_blksrc, pl->s_products,
+                 pl->enc8 ? (void*) pl->s_code : (void*) pl->s_lrow, pl->s_hdr, (long long) a_pad, (long long) p_pad);
   SPB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pb_expand_kernel<T, false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, xlds > PB_LDS_BYTES ? xlds : PB_LDS_BYTES));
   SPB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pb_expand_kernel<T, true>),
