@@ -1,7 +1,8 @@
 // Do equal-sized device allocations differ in speed?  (round 3: the cfg2 SpMV runs 292 or 313 us depending on which memory its
 // 433 MB product workspace got.)  N buffers of 433 MB, each: sequential 16-byte writes, sequential reads, and 128-byte
 // lines written in a scattered order by 8-lane groups -- the expand kernel's store pattern.  Best of 5, GB/s.
-//   hipcc --offload-arch=gfx950 -O3 -o region_speed region_speed.hip && ./region_speed [n_buffers] [pool=0|1]
+//   hipcc --offload-arch=gfx950 -O3 -o region_speed region_speed.hip && ./region_speed [n_buffers] [mode: 0 hipMalloc, 1 pool,
+//   2 hipDeviceMallocContiguous, 3 hipDeviceMallocUncached, 4 hipDeviceMallocFinegrained]
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -33,7 +34,8 @@ __global__ __launch_bounds__(1024) void scat_write(f4* p, size_t n_lines, size_t
 
 int main(int argc, char** argv) {
   const int nb = argc > 1 ? std::atoi(argv[1]) : 10;
-  const bool pool = argc > 2 && std::atoi(argv[2]) != 0;
+  const int mode = argc > 2 ? std::atoi(argv[2]) : 0;  // 0 hipMalloc, 1 stream-ordered pool, 2 contiguous, 3 uncached, 4 fine-grained
+  const bool pool = mode == 1;
   const size_t bytes = (size_t) 433 << 20, n16 = bytes / 16, n_lines = bytes / 128 - 1;  // (n_lines odd)
   hipStream_t s;
   CK(hipStreamCreate(&s));
@@ -44,6 +46,8 @@ int main(int argc, char** argv) {
     void* p = nullptr;
     if (pool)
       CK(hipMallocAsync(&p, bytes, s));
+    else if (mode >= 2)
+      CK(hipExtMallocWithFlags(&p, bytes, mode == 2 ? hipDeviceMallocContiguous : mode == 3 ? hipDeviceMallocUncached : hipDeviceMallocFinegrained));
     else
       CK(hipMalloc(&p, bytes));
     CK(hipMemsetAsync(p, 0, bytes, s));
