@@ -263,3 +263,14 @@ def test_inspect_class_calls_are_refused_inside_a_capture(gpu):
     sp.multiply(info, a, x, y)
     sp.transpose(a, t)
     torch.cuda.synchronize()
+
+
+def test_cg_example_with_the_iteration_in_a_graph(gpu):
+    # examples/cg_graph.py: SpMV + dot products + updates of one CG iteration recorded once, replayed 60 times
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "cg_graph.py")
+    spec = importlib.util.spec_from_file_location("cg_graph_example", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.main(100_000, 60) < 1e-8
