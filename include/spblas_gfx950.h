@@ -168,10 +168,8 @@ int spblas_gfx950_plan_info(spblas_gfx950_plan_t plan, int64_t info[12]);
  * than m when the empty rows were taken out).  For ANY plan: [9] bit 0 = AUTO decided by a timed trial, bit 1 = the
  * reduce streams one-byte row codes (runs sorted by row) instead of 16-bit rows, bit 2 = the expand stores its products
  * with the non-temporal hint, bit 3 = this plan ran the store trial that decides bit 2 (plans with >= 32 M placed
- * entries, once per process, device and value size; SPBLAS_GFX950_PB_NT=0/1 forces the flavour), bits 4-7 = allocations that were
- * write-tested for the product workspace at build (large plans; SPBLAS_GFX950_PB_PLACE, default 4: equal-sized
- * allocations differ by up to 20 % in how fast scattered lines can be stored into them, and the SpMV by 6 % with it);
- * [10]/[11]=time of the row-block / the sliced plan in AUTO's trial, nanoseconds -- or, when only the store trial ran, of one SpMV with plain /
+ * entries, once per process, device and value size; SPBLAS_GFX950_PB_NT=0/1 forces the flavour); [10]/[11]=time of the
+ * row-block / the sliced plan in AUTO's trial, nanoseconds -- or, when only the store trial ran, of one SpMV with plain /
  * non-temporal product stores. */
 int spblas_gfx950_plan_info_sliced(spblas_gfx950_plan_t plan, int64_t info[12]);
 

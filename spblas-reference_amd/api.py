@@ -316,7 +316,6 @@ class _Plan:
         d["row_code_u8"] = (bits >> 1) & 1  # one-byte row codes in the reduce's stream (runs sorted by row)
         d["nt_product_stores"] = (bits >> 2) & 1  # the expand stores its products with the non-temporal hint
         d["store_trial"] = (bits >> 3) & 1  # THIS plan timed both store flavours (once per process, device and value size)
-        d["workspace_candidates"] = (bits >> 4) & 15  # allocations write-tested for the product workspace at inspect
         d["auto_trial"] = bits & 1
         if d["store_trial"] and not d["auto_trial"]:  # (the two time slots carry AUTO's trial when both ran)
             d["store_trial_ns"] = {"plain": d.pop("trial_rowblock_ns"), "non_temporal": d.pop("trial_sliced_ns")}

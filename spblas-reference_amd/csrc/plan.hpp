@@ -57,7 +57,6 @@ struct spblas_gfx950_plan_s {
   int exc_cap = 0;
   void* s_products = nullptr;  // T[p_blocks*32] workspace: expanded products (P order)
   size_t s_products_bytes = 0;
-  int place_tried = 0;         // candidates for the product workspace that were write-tested at build (1 = no search)
   int64_t a_blocks = 0, p_blocks = 0;
   int n_ksplit = 1;            // reduce workgroups per bin group (every wave-bin's stream cut into K parts)
   int rwaves = 4;              // reduce: wave-bins (= wavefronts) per workgroup

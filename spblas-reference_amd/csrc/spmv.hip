@@ -579,8 +579,11 @@ static int auto_trial(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const 
 // profiles/r03_store_trial.md).  Decided once per process, device and value size by timing the plan both ways (a warm-up
 // and two samples of two SpMVs each, interleaved, on a zero vector); later plans reuse the decision.
 // SPBLAS_GFX950_PB_NT = 0 / 1 forces it, unset or -1 = this trial.
-// (Where the product workspace lives matters more than this flavour: spmv_sliced.hip: alloc_product_workspace picks it by a
-// write test at build time.  Timing whole SpMVs on three candidates here was tried first and did not find the fast kind.)
+// (Where the product workspace lives matters more than this flavour -- the same plan runs 290-318 us depending on which
+// memory that one array got -- but nothing tried so far picks the fast kind: timing whole SpMVs on three candidates, a
+// scattered-store test on four or eight (it chose worse than "take the first" on five boxes of six), memory mapped through
+// the virtual-memory API.  profiles/r03_store_trial.md has the measurements; the code is gone again.)
+// SPBLAS_GFX950_PB_TUNE_MIN: test hook, the number of placed entries from which a plan counts as large.
 static std::atomic<int> g_nt_choice[32][2];  // [device][fp32 / fp64]: 0 = unknown, 1 = plain, 2 = non-temporal
 static void store_trial(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const void* values) {
   const int forced = env_int_spmv("SPBLAS_GFX950_PB_NT", -1);
@@ -905,9 +908,8 @@ int spblas_gfx950_plan_info_sliced(spblas_gfx950_plan_t plan, int64_t info[12]) 
   info[7] = sl ? plan->n_ksplit : 0;
   info[8] = sl ? plan->s_m : 0;
   // bit 0: AUTO ran its trial, bit 1: one-byte row codes, bit 2: non-temporal product stores, bit 3: this plan ran the store trial
-  // bits 4-7: candidates for the product workspace that were write-tested at build (0 / 1 = no search)
   info[9] = (plan->trial_ms[0] > 0.f ? 1 : 0) | (sl && plan->enc8 ? 2 : 0) | (sl && plan->nt_products ? 4 : 0) |
-            (plan->store_trial_ms[0] > 0.f ? 8 : 0) | ((plan->place_tried & 15) << 4);
+            (plan->store_trial_ms[0] > 0.f ? 8 : 0);
   const float* tms = plan->trial_ms[0] > 0.f ? plan->trial_ms : plan->store_trial_ms;  // AUTO's times, else the store trial's
   info[10] = (int64_t) (tms[0] * 1e6f);
   info[11] = (int64_t) (tms[1] * 1e6f);

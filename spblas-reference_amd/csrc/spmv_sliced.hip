@@ -1605,77 +1605,6 @@ static void pick_tiling(int64_t extent, int max_elems, int round_to, int round_f
 }
 
 
-// Equal-sized device allocations are not equally fast to WRITE: tools/ubench/region_speed.hip measures 4.9-6.1 TB/s of
-// scattered 128-byte line stores into ten 433 MB buffers of one process (reads: 7.0-7.2 TB/s for all of them), stable per
-// buffer -- and the cfg2 SpMV runs 292 or 313 us depending on which memory its product workspace got, the one array the
-// expand writes that way (profiles/r03_store_trial.md).  pb_place_test_kernel is that store pattern: line l of the pass
-// goes to line (l * odd constant) mod n_lines, eight lanes per line.
-__global__ __launch_bounds__(1024) void pb_place_test_kernel(f32x4* __restrict__ p, size_t n_lines, size_t mul) {
-  const int sub = threadIdx.x & 7;
-  for (size_t l = ((size_t) blockIdx.x * 1024 + threadIdx.x) >> 3; l < n_lines; l += ((size_t) gridDim.x * 1024) >> 3) {
-    const size_t d = (l * mul) % n_lines;
-    f32x4 v;
-    v.x = v.y = v.z = v.w = 0.f;
-    p[d * 8 + sub] = v;
-  }
-}
-
-// The product workspace of a large plan (>= 32 M placed entries): SPBLAS_GFX950_PB_PLACE candidates (default 4; 1 = the
-// first one) are allocated together, each is written three times by the test kernel (the first pass touches it), the
-// fastest one is kept, the others go back to the pool.  ~0.5 ms per candidate at cfg2; candidates that cannot be allocated
-// end the search.  tools/exp_r03r.sh, three boxes, six interleaved runs each, SpMV time with 1 / 4 / 8 candidates:
-// 311.3 / 293.3 / 295.1 us on a box that is always slow without the search, 299.6 / 295.6 / 294.6 on a mixed one,
-// 294.2 / 296.9 / 297.6 on one that is always fast -- the slow mode (309-314 us) never survived the search.
-static int alloc_product_workspace(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, size_t bytes, bool large, bool trace) {
-  hipStream_t s = h->stream;
-  const int want = large ? std::max(1, env_int("SPBLAS_GFX950_PB_PLACE", 4)) : 1;
-  int rc = dev_alloc(&pl->s_products, bytes, s);
-  if (rc || want == 1 || bytes < 4096)
-    return rc;
-  std::vector<void*> cand{pl->s_products};
-  for (int i = 1; i < want; ++i) {
-    void* p = nullptr;
-    if (dev_alloc(&p, bytes, s) != SPBLAS_GFX950_STATUS_SUCCESS)
-      break;
-    cand.push_back(p);
-  }
-  hipEvent_t ev[2] = {nullptr, nullptr};
-  bool ok = hipEventCreate(&ev[0]) == hipSuccess && hipEventCreate(&ev[1]) == hipSuccess;
-  const size_t n_lines = (bytes / 128 - 1) | 1;  // odd: the multiplier below is coprime to it often enough for a test
-  size_t best_i = 0;
-  float best_ms = 1e30f;
-  for (size_t i = 0; i < cand.size() && ok; ++i) {
-    float mn = 1e30f;
-    for (int rep = 0; rep < 3 && ok; ++rep) {
-      ok = hipEventRecord(ev[0], s) == hipSuccess;
-      hipLaunchKernelGGL(pb_place_test_kernel, dim3(2048), dim3(1024), 0, s, static_cast<f32x4*>(cand[i]), n_lines,
-                         (size_t) 2654435761u);
-      float ms = 0.f;
-      ok = ok && hipEventRecord(ev[1], s) == hipSuccess && hipEventSynchronize(ev[1]) == hipSuccess &&
-           hipEventElapsedTime(&ms, ev[0], ev[1]) == hipSuccess;
-      if (ok && rep > 0 && ms < mn)
-        mn = ms;
-    }
-    if (trace)
-      std::fprintf(stderr, "[inspect] product workspace candidate %zu at %p: %.0f GB/s of scattered line stores\n", i, cand[i],
-                   (double) bytes / mn * 1e-6);
-    if (ok && mn < best_ms) {
-      best_ms = mn;
-      best_i = i;
-    }
-  }
-  for (int i = 0; i < 2; ++i)
-    if (ev[i])
-      (void) hipEventDestroy(ev[i]);
-  (void) hipGetLastError();
-  pl->s_products = cand[best_i];
-  for (size_t i = 0; i < cand.size(); ++i)
-    if (i != best_i)
-      dev_free(cand[i], s);
-  pl->place_tried = (int) cand.size();
-  return SPBLAS_GFX950_STATUS_SUCCESS;
-}
-
 // SPBLAS_GFX950_TRACE_INSPECT=1: host-side time stamps of the inspect phases on stderr (drains the stream)
 struct pb_tracer {
   bool on;
@@ -2145,11 +2074,9 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
   } else if ((rc = dev_alloc((void**) &pl->s_lrow, (size_t) (p_pad + PB_GRP) * 2, s))) {
     return rc;
   }
-  pl->s_products_bytes = (size_t) (p_pad + PB_GRP) * sizeof(T);
-  // (SPBLAS_GFX950_PB_TUNE_MIN: test hook, the threshold of "large" for this search and for the store trial of spmv.hip)
-  if ((rc = alloc_product_workspace(h, pl, pl->s_products_bytes,
-                                    placed_total >= (unsigned long long) env_int("SPBLAS_GFX950_PB_TUNE_MIN", 32 << 20), tr.on)))
+  if ((rc = dev_alloc((void**) &pl->s_products, (size_t) (p_pad + PB_GRP) * sizeof(T), s)))
     return rc;
+  pl->s_products_bytes = (size_t) (p_pad + PB_GRP) * sizeof(T);
   pl->device_bytes += (size_t) a_pad * (sizeof(T) + 6) + (size_t) a_blocks * 8 + (size_t) p_pad * sizeof(T) +
                       (enc8 ? (size_t) p_pad + hdr_bytes + (size_t) NB * PB_EXC_CAP * 6 : (size_t) p_pad * 2) +
                       (size_t) (NB + S + 2) * 4 + (size_t) nseg * 4;

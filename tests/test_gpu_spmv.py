@@ -773,7 +773,7 @@ def test_spmv_sliced_product_store_flavours(gpu, monkeypatch, dtype, nt):
     y = torch.full((m,), float("nan"), dtype=xd.dtype, device="cuda")
     info = sp.multiply_inspect(a, xd, y, alg=_capi.SPMV_SLICED)
     si = info.state_.sliced_info()
-    assert si["nt_product_stores"] == int(nt) and si["store_trial"] == 0 and si["workspace_candidates"] <= 1  # (small plan)
+    assert si["nt_product_stores"] == int(nt) and si["store_trial"] == 0
     sp.multiply(info, a, xd, y)
     check(values, rowptr, colind, (m, n), x, G.host(y), what=f"product stores nt={nt}", ref_cmp=False)
 
@@ -828,18 +828,14 @@ print("RESULT " + json.dumps(out))
     assert second["nt_product_stores"] == first["nt_product_stores"]
     assert out["plain"]["nt_product_stores"] == 0 and out["nt"]["nt_product_stores"] == 1
     assert out["plain"]["store_trial"] == 0 and out["nt"]["store_trial"] == 0
-    # ... and every plan of this size picked its product workspace among 4 write-tested allocations
-    assert all(out[k]["workspace_candidates"] == 4 for k in ("first", "second", "plain", "nt")), out
     assert out["max_diff"] <= 2e-6
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
-def test_spmv_large_plan_tuning_on_a_small_plan(gpu, monkeypatch, dtype):
-    """What large plans do at inspect -- pick the product workspace among several write-tested allocations, time the two
-    flavours of the product stores -- forced onto a small plan (SPBLAS_GFX950_PB_TUNE_MIN=0): the workspace that is kept
-    must be clean (the test kernel wrote into every candidate), the losers go back, the answers stay the same."""
+def test_spmv_store_trial_on_a_small_plan(gpu, monkeypatch, dtype):
+    """The store trial of large plans forced onto a small one (SPBLAS_GFX950_PB_TUNE_MIN=0): six SpMVs on a zero vector at
+    inspect, two temporary vectors that are given back, the same answers afterwards whichever flavour won."""
     monkeypatch.setenv("SPBLAS_GFX950_PB_TUNE_MIN", "0")
-    monkeypatch.setenv("SPBLAS_GFX950_PB_PLACE", "5")
     monkeypatch.delenv("SPBLAS_GFX950_PB_NT", raising=False)
     values, rowptr, colind, shape, nnz = generate.generate_csr(30000, 50000, 600000, dtype=dtype, seed=23)
     x = (np.random.default_rng(2).random(50000) - 0.5).astype(dtype)
@@ -849,10 +845,9 @@ def test_spmv_large_plan_tuning_on_a_small_plan(gpu, monkeypatch, dtype):
     for rep in range(3):
         y = torch.full((30000,), float("nan"), dtype=xd.dtype, device="cuda")
         info = sp.multiply_inspect(a, xd, y, alg=_capi.SPMV_SLICED)
-        si = info.state_.sliced_info()
-        assert si["workspace_candidates"] == 5
+        assert info.state_.sliced_info()["nt_product_stores"] in (0, 1)
         sp.multiply(info, a, xd, y)
-        check(values, rowptr, colind, shape, x, G.host(y), what=f"tuned small plan {rep}", ref_cmp=False)
+        check(values, rowptr, colind, shape, x, G.host(y), what=f"store trial on a small plan {rep}", ref_cmp=False)
         del info
     torch.cuda.synchronize()
-    assert free0 - torch.cuda.mem_get_info()[0] < 64 * 2 ** 20  # the rejected candidates were freed
+    assert free0 - torch.cuda.mem_get_info()[0] < 64 * 2 ** 20

@@ -17,8 +17,7 @@ HOOKS = ["SPBLAS_GFX950_SLICE_COLS", "SPBLAS_GFX950_SLICE_ROWS", "SPBLAS_GFX950_
          "SPBLAS_GFX950_PB_RBATCH", "SPBLAS_GFX950_PB_RLDS_KB", "SPBLAS_GFX950_PB_BINS", "SPBLAS_GFX950_PB_VARBINS",
          "SPBLAS_GFX950_PB_HUB_LEN", "SPBLAS_GFX950_PB_COMPACT", "SPBLAS_GFX950_PB_ENC8", "SPBLAS_GFX950_PB_ENC8_FAIL",
          "SPBLAS_GFX950_PB_LPT", "SPBLAS_GFX950_PB_XITEM_DIV", "SPBLAS_GFX950_PB_RITEMS", "SPBLAS_GFX950_PB_XLDS_KB",
-         "SPBLAS_GFX950_PB_STAGED_SCATTER", "SPBLAS_GFX950_PB_SPLIT_LEN", "SPBLAS_GFX950_PB_RUN_MIN", "SPBLAS_GFX950_PB_NT", "SPBLAS_GFX950_PB_TUNE_MIN",
-         "SPBLAS_GFX950_PB_PLACE"]
+         "SPBLAS_GFX950_PB_STAGED_SCATTER", "SPBLAS_GFX950_PB_SPLIT_LEN", "SPBLAS_GFX950_PB_RUN_MIN", "SPBLAS_GFX950_PB_NT", "SPBLAS_GFX950_PB_TUNE_MIN"]
 dev = torch.device("cuda:0")
 bad = 0
 for it in range(iters):
@@ -83,9 +82,8 @@ for it in range(iters):
         if rng.random() < 0.5:
             hooks["SPBLAS_GFX950_PB_SPLIT_LEN"] = str(int(rng.choice([64, 1000, 100000])))
         hooks["SPBLAS_GFX950_PB_NT"] = str(int(rng.choice([0, 1, -1])))  # product stores plain / non-temporal / by trial
-        if rng.random() < 0.3:  # the tuning of large plans (workspace search, store trial) on a small one
+        if rng.random() < 0.3:  # the store trial of large plans on a small one
             hooks["SPBLAS_GFX950_PB_TUNE_MIN"] = "0"
-            hooks["SPBLAS_GFX950_PB_PLACE"] = str(int(rng.choice([1, 2, 5])))
         if rng.random() < 0.3:
             hooks["SPBLAS_GFX950_PB_RUN_MIN"] = str(int(rng.choice([1, 8, 64])))
     os.environ.update(hooks)
