@@ -577,7 +577,7 @@ static int auto_trial(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const 
 // product store is faster is a property of the box and the moment, not of the matrix -- where the reduce pays for the
 // expand's write-backs the non-temporal hint wins 1-4 %, elsewhere it loses 3 % (tools/exp_r03o.sh,
 // profiles/r03_store_trial.md).  Decided once per process, device and value size by timing the plan both ways (a warm-up
-// and two samples of two SpMVs each, interleaved, on a zero vector); later plans reuse the decision.
+// and three samples of two SpMVs each, interleaved, on a zero vector); later plans reuse the decision.
 // SPBLAS_GFX950_PB_NT = 0 / 1 forces it, unset or -1 = this trial.
 // (Where the product workspace lives matters more than this flavour -- the same plan runs 290-318 us depending on which
 // memory that one array got -- but nothing tried so far picks the fast kind: timing whole SpMVs on three candidates, a
@@ -636,7 +636,7 @@ static void store_trial(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, cons
   if (ok) {
     float best[2] = {1e30f, 1e30f};
     ok = run(0) && run(1);  // warm-up of both kernels
-    for (int rep = 0; rep < 2 && ok; ++rep)
+    for (int rep = 0; rep < 3 && ok; ++rep)
       for (int nt = 0; nt < 2 && ok; ++nt) {
         float ms = 0.f;
         ok = sample(nt, &ms);
@@ -647,7 +647,9 @@ static void store_trial(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, cons
     if (ok) {
       pl->store_trial_ms[0] = best[0];
       pl->store_trial_ms[1] = best[1];
-      pl->nt_products = best[1] < 0.99f * best[0];  // the hint has to win by more than the noise of two samples
+      // the hint has to win by more than the noise of three samples (where it matters it wins by 2-4 %; where it does
+      // not, it loses by as much)
+      pl->nt_products = best[1] < 0.995f * best[0];
       slot.store(pl->nt_products ? 2 : 1);
     }
   }
