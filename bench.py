@@ -37,7 +37,7 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=50)
     p.add_argument("--warmup", type=int, default=5)
-    p.add_argument("--workload", default="spmv", choices=["spmv", "spmv_poisson", "spmv_rmat", "spmm", "spmm_banded", "spmm_rmat", "spgemm", "add", "transpose", "sptrsv"])
+    p.add_argument("--workload", default="spmv", choices=["spmv", "spmv_poisson", "spmv_rmat", "spmv_rmat1", "spmm", "spmm_banded", "spmm_rmat", "spgemm", "add", "transpose", "sptrsv"])
     p.add_argument("--rows", type=int, default=None, help="override the row count (debug only; reported)")
     p.add_argument("--cols", type=int, default=None, help="override the column count (debug: emulate one row shard)")
     p.add_argument("--alg", default="auto", choices=["auto", "vector", "rowblock", "sliced", "noplan"])
@@ -54,6 +54,8 @@ def parse():
                    help="debug/tests: all N ranks share cuda:0 with gloo as the process-group backend (RCCL refuses two "
                         "ranks on one device): exercises the N>1 code path end to end on a one-GPU box")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-secondary", action="store_true",
+                   help="default N=1 cfg2 run only: skip the cfg4 / cfg3 / cfg5 records of the `secondary` object")
     return p.parse_args()
 
 
@@ -61,7 +63,8 @@ def launch_ranks(nproc):
     """One rank per GPU under torch.distributed.run on a free loopback port; stdout/stderr pass straight through."""
     import socket
     import subprocess
-    # (device_count() does not initialise the GPU: the parent stays a plain launcher)
+    # (device_count() may call hipGetDeviceCount on ROCm builds without amdsmi; that is harmless here because this
+    # parent only ever STARTS a child process -- it never execs over itself and never launches GPU work)
     if "--debug-one-gpu" not in sys.argv and torch.cuda.device_count() < nproc:
         print(f"bench.py: --gpus {nproc} but {torch.cuda.device_count()} device(s) visible", file=sys.stderr)
         return 2
@@ -102,23 +105,7 @@ def spmv_bytes(m, n, nnz, tsize):
     return nnz * (tsize + 4) + (m + 1) * 4 + n * tsize + m * tsize
 
 
-def read_pmc_traffic(name):
-    """(HBM bytes per launch, provenance) from the committed PMC profile (profiles/pmc_traffic.json), or (None, None).
-    The provenance names the profile and the hash of csrc/spmv_sliced.hip it was measured on, and says whether the
-    kernels have changed since (a stale constant must be visible in the JSON line)."""
-    import hashlib
-    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    try:
-        with open(path) as f:
-            d = json.load(f)
-        stamp = dict((d.get("_stamp") or {}).get(name) or {})
-        with open(os.path.join(ROOT, "spblas-reference_amd", "csrc", "spmv_sliced.hip"), "rb") as f:
-            now = hashlib.sha256(f.read()).hexdigest()[:16]
-        stamp["spmv_sliced_hip_sha256_16_now"] = now
-        stamp["stale"] = stamp.get("spmv_sliced_hip_sha256_16") != now
-        return d.get(name), stamp
-    except Exception:
-        return None, None
+from bench_extra import read_pmc_traffic  # noqa: E402  (committed PMC constants + staleness stamp)
 
 
 def cpu_model():
@@ -289,7 +276,7 @@ def main():
     from spblas_reference_amd import _capi, sharded
     sp._capi.lib()  # fail loudly if the HIP library is missing
 
-    if args.workload in ("spmm", "spmm_banded", "spmm_rmat", "spgemm", "add", "transpose", "sptrsv"):
+    if args.workload in ("spmv_rmat1", "spmm", "spmm_banded", "spmm_rmat", "spgemm", "add", "transpose", "sptrsv"):
         from bench_extra import run_extra  # secondary configs (cfg3 / cfg5 / 8f rows), 1 GPU
         sys.stdout.flush()
         os.dup2(json_fd, 1)  # single-GPU secondary workloads print their own line
@@ -544,6 +531,10 @@ def main():
                                        "into hipIpc-mapped copies of y + device-side step barrier)" if mode == "fused" else
                                        f"row-sharded x{world} ({'nnz-prefix' if rmat else 'equal'} shards), {chunks} stripe(s) per step "
                                        f"({mode}), one RCCL all-gather(y) per stripe"),
+                       # what the headline is a number FOR: the sliced plan multiplies with a re-tiled snapshot of A, which
+                       # AUTO only builds for operands wrapped in matrix_opt; a plain inspected csr_view
+                       # gets the row-block plan on the caller's arrays: 1.71 ms at cfg2
+                       "operand": "matrix_opt(csr_view) + multiply_inspect" if args.alg != "noplan" else "csr_view, no inspect",
                        "alg": args.alg, "plan": plan_info, "inspect_ms_untimed": inspect_ms,
                        "inspect_warm_ms_untimed": inspect_warm_ms},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -569,6 +560,18 @@ def main():
             out["cpu_baseline"] = None
         out["parity_check"] = parity["status"] if parity else "not run (--no-cpu-baseline)"
         out["parity"] = parity
+        if world == 1 and not multi and args.workload == "spmv" and args.rows is None and args.cols is None \
+                and args.alg == "auto" and not args.no_secondary:
+            # The other single-GPU BASELINE configs, after the timed cfg2 loop and its check, in the same process: cfg4
+            # (1 GPU), cfg3, cfg5 -- each inspected, warmed up, timed between one event pair and checked against the
+            # oracle.  The headline fields above are untouched; a failing secondary check fails the run (exit code 3).
+            from bench_extra import secondary
+            del y_timed, values, rowptr, colind, op, rccl_op, a_chunks, prob, info0, x
+            torch.cuda.empty_cache()
+            out["secondary"] = secondary(args, device, log=lambda msg: print(f"[bench] {msg}", file=sys.stderr))
+            if any(v.get("parity_check") == "fail" for v in out["secondary"].values()):
+                sys.stderr.write("[bench] SECONDARY PARITY CHECK FAILED\n")
+                exit_code = 3
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
         if parity and parity["status"] == "fail":

@@ -12,6 +12,52 @@ import numpy as np
 import torch
 
 HBM_PEAK_GBS = 8000.0
+ROOT = os.path.dirname(os.path.abspath(__file__))
+
+
+def read_pmc_traffic(name):
+    """(HBM bytes per launch, provenance) from the committed PMC profile (profiles/pmc_traffic.json), or (None, None).
+    The provenance names the profile and the hash of the kernel source it was measured on (csrc/spmv_sliced.hip unless
+    the stamp names another `source_file`), and says whether that file has changed since: a stale constant must be
+    visible in the JSON line."""
+    import hashlib
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        stamp = dict((d.get("_stamp") or {}).get(name) or {})
+        src = stamp.get("source_file", "spmv_sliced.hip")
+        key = src.replace(".", "_") + "_sha256_16"
+        with open(os.path.join(ROOT, "spblas-reference_amd", "csrc", src), "rb") as f:
+            now = hashlib.sha256(f.read()).hexdigest()[:16]
+        stamp[key + "_now"] = now
+        stamp["stale"] = stamp.get(key) != now
+        return d.get(name), stamp
+    except Exception:
+        return None, None
+
+
+def rows_subproblem(rows, rowptr_d, colind_d, values_d):
+    """CSR of the selected rows as host arrays (gathered on the device): what the parity checks hand to the oracle."""
+    rows_d = torch.from_numpy(np.asarray(rows, dtype=np.int64)).to(rowptr_d.device)
+    rp = rowptr_d.long()
+    lo, ln = rp[rows_d], rp[rows_d + 1] - rp[rows_d]
+    sub_rp = torch.zeros(len(rows) + 1, dtype=torch.int64, device=rowptr_d.device)
+    torch.cumsum(ln, 0, out=sub_rp[1:])
+    total = int(sub_rp[-1])
+    owner = torch.repeat_interleave(torch.arange(len(rows), device=rowptr_d.device), ln)
+    idx = lo[owner] + (torch.arange(total, device=rowptr_d.device) - sub_rp[owner])
+    return sub_rp.cpu().numpy().astype(np.int32), colind_d[idx].cpu().numpy(), values_d[idx].cpu().numpy()
+
+
+def parity_rows(got, ref, absref, tol, eps, row_len):
+    """Norm-wise bound of SURVEY.md section 8c (tests/util.py:assert_parity): |got - ref| <= max(tol, k/2 * eps) * sum|a b| per row."""
+    err = np.abs(got.astype(np.float64) - ref.astype(np.float64))
+    tol_row = np.maximum(tol, 0.5 * np.asarray(row_len, dtype=np.float64) * eps)
+    if err.ndim == 2:
+        tol_row = tol_row[:, None]
+    bad = ~(err <= tol_row * absref + 1e-300)
+    return int(bad.sum()), float((err / np.maximum(absref, 1e-300)).max()) if err.size else 0.0
 
 
 def _time_steps(fn, warmup, steps):
@@ -39,23 +85,154 @@ def _time_steps(fn, warmup, steps):
     return elapsed, [avg, min(a.elapsed_time(b) for a, b in ev)]
 
 
-def _emit(args, metric, flops, alg_bytes, elapsed, ms, workload, extra, cpu):
+def _emit(args, metric, flops, alg_bytes, elapsed, ms, workload, extra, cpu, parity=None, pmc_key=None):
     avg = ms[0]
+    traffic, traffic_src = read_pmc_traffic(pmc_key) if pmc_key else (None, None)
+    kernel = extra.pop("kernel", None)
     out = {"metric": metric, "value": flops / (elapsed / args.steps) / 1e9, "unit": extra.pop("unit", "GFLOP/s"), "n_gpus": 1,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": extra.pop("dtype"),
            "data": "synthetic", "config": {"workload": workload, **extra},
            "roofline": {"bound": "hbm", "achieved": alg_bytes / (avg * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": alg_bytes / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                        "frac": alg_bytes / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
+                        "traffic_source": traffic_src, "kernel": kernel,
                         "algorithmic_bytes_per_launch": alg_bytes, "kernel_avg_ms": avg, "step_events_pass_min_ms": ms[1]},
            "cpu_baseline": cpu}
-    print(json.dumps(out))
+    if parity is not None:
+        out["parity_check"] = parity["status"]
+        out["parity"] = parity
+    return out
 
 
 def run_extra(args, device):
+    """One secondary workload as its own bench line (python bench.py --workload spmm|spgemm|...)."""
+    out = _run(args, device)
+    print(json.dumps(out))
+    return 3 if out.get("parity_check") == "fail" else 0
+
+
+def secondary(args, device, log=None):
+    """BASELINE cfg4 (single-GPU leg), cfg3 and cfg5 after the headline cfg2 loop, in the same process: each one
+    inspected, warmed up, timed between one pair of HIP events and checked against the oracle; compact records for the
+    `secondary` object of bench.py's JSON line."""
+    import copy
+    res = {}
+    for name, workload in (("cfg4", "spmv_rmat1"), ("cfg3", "spmm"), ("cfg5", "spgemm")):
+        a2 = copy.copy(args)
+        a2.workload, a2.rows, a2.cols = workload, None, None
+        a2.steps, a2.warmup = max(10, min(args.steps, 20)), 5
+        t0 = time.perf_counter()
+        try:
+            r = _run(a2, device)
+            cfg = r["config"]
+            res[name] = {"workload": cfg.pop("workload"), "metric": r["metric"], "value": r["value"], "unit": r["unit"],
+                         "dtype": r["dtype"], "steps": r["steps"], "warmup": r["warmup"], "ms_per_step": r["ms_per_step"],
+                         "roofline": r["roofline"], "parity_check": r.get("parity_check", "not run"),
+                         "parity": r.get("parity"), "cpu_baseline": r["cpu_baseline"], "detail": cfg}
+        except Exception as e:  # noqa: BLE001 - a broken secondary config must show in the line, not hide the headline
+            res[name] = {"workload": workload, "parity_check": "fail", "error": f"{type(e).__name__}: {e}"}
+        res[name]["wall_s"] = time.perf_counter() - t0
+        if log:
+            log(f"secondary {name}: {res[name].get('ms_per_step')} ms/step, parity {res[name]['parity_check']}, "
+                f"{res[name]['wall_s']:.1f} s")
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+    return res
+
+
+def _spgemm_parity(oracle, m, a_d, b_d, c_rp, c, cn, one_shot):
+    """cfg5: nnz(C) and EVERY row offset exact against a full symbolic run of the oracle on the host; the columns
+    (exact, ascending) and values (1e-6 norm-wise) of sampled rows of the timed one-shot fill against oracle_spgemm."""
+    (ar, ac, av), (br, bc, bv) = a_d, b_d
+    a_h, b_h = (ar.cpu().numpy(), ac.cpu().numpy()), (br.cpu().numpy(), bc.cpu().numpy())
+    n_ref, row_nnz = oracle.spgemm_symbolic((m, m), a_h[0], a_h[1], (m, m), b_h[0], b_h[1])
+    rowptr_ok = bool(cn == n_ref and np.array_equal(c_rp.cpu().numpy().astype(np.int64),
+                                                    np.concatenate([[0], np.cumsum(row_nnz)])))
+    rows = np.unique(np.concatenate([np.arange(0, m, 1009), [m - 1]]))
+    sub_rp, sub_c, sub_v = rows_subproblem(rows, ar, ac, av)
+    bv_h = bv.cpu().numpy()
+    n_sub, _ = oracle.spgemm_symbolic((len(rows), m), sub_rp, sub_c, (m, m), b_h[0], b_h[1])
+    cr, cc, cv = oracle.spgemm_numeric((len(rows), m), sub_rp, sub_c, sub_v, (m, m), b_h[0], b_h[1], bv_h, capacity=n_sub)
+    _, _, cabs = oracle.spgemm_numeric((len(rows), m), sub_rp, sub_c, np.abs(sub_v), (m, m), b_h[0], b_h[1], np.abs(bv_h),
+                                       capacity=n_sub)
+    got_rp, got_c, got_v = rows_subproblem(rows, c_rp, one_shot[0], one_shot[1])
+    cols_ok = bool(np.array_equal(got_rp, cr) and np.array_equal(got_c, cc))
+    nbad, worst = (1, float("inf"))
+    if cols_ok:
+        # a row of C sums <= 16 products per entry: the k/2*eps floor never applies
+        nbad, worst = parity_rows(got_v, cv, cabs.astype(np.float64), 1e-6, float(np.finfo(np.float32).eps), np.zeros(len(cv)))
+    finite = bool(torch.isfinite(one_shot[1]).all())
+    ok = rowptr_ok and cols_ok and nbad == 0 and finite
+    return {"status": "pass" if ok else "fail", "nnz_c": int(cn), "nnz_c_oracle": int(n_ref), "rowptr_exact_all_rows": rowptr_ok,
+            "sampled_rows": int(len(rows)), "sampled_entries": int(len(cv)), "sampled_colind_exact": cols_ok,
+            "values_out_of_bound": nbad, "tol": 1e-6, "worst_err_over_norm": worst,
+            "against": "oracle_spgemm_symbolic over all rows (spgemm_gustavsons.hpp:57-89); oracle_spgemm_numeric on every "
+                       "1 009th row (spgemm_gustavsons.hpp:17-52): sorted columns exact, values norm-wise"}
+
+
+def _run_spmv_rmat1(args, device, sp, oracle, generate):
+    """BASELINE cfg4, single-GPU leg: fp64 CSR SpMV on the R-MAT scale-24 graph (edge factor 16, duplicates kept), the
+    matrix_opt + multiply_inspect call shape; every row of the timed y against oracle_spmv on the host."""
+    scale = 24 if args.rows is None else int(np.log2(args.rows))
+    values, rowptr, colind, shape, nnz = generate.rmat_csr_device(scale, 16, dtype=torch.float64, seed=0, device=device)
+    m = n = shape[0]
+    a = sp.csr_view(values, rowptr, colind, shape, nnz)
+    g = torch.Generator(device=device).manual_seed(7)
+    x = torch.rand(n, dtype=torch.float64, device=device, generator=g)
+    y = torch.empty(m, dtype=torch.float64, device=device)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    info = sp.multiply_inspect(sp.matrix_opt(a), x, y)
+    torch.cuda.synchronize()
+    inspect_ms = (time.perf_counter() - t0) * 1e3
+    elapsed, ms = _time_steps(lambda: sp.multiply(info, a, x, y), args.warmup, args.steps)
+    plan = info.state_.info()
+    si = info.state_.sliced_info() if hasattr(info.state_, "sliced_info") else {}
+    if plan.get("alg") == 3:
+        plan["sliced"] = si
+    elif si.get("auto_trial"):
+        plan["auto_trial"] = {k: si[k] for k in ("trial_rowblock_ns", "trial_sliced_ns")}
+    y.fill_(float("nan"))
+    sp.multiply(info, a, x, y)
+    torch.cuda.synchronize()
+    alg_bytes = nnz * 12 + (m + 1) * 4 + (n + m) * 8
+    cpu, parity = None, None
+    if not args.no_cpu_baseline:
+        v, rp, ci, xh = values.cpu().numpy(), rowptr.cpu().numpy(), colind.cpu().numpy(), x.cpu().numpy()
+        try:
+            oracle.load(native=True)
+            native = True
+        except Exception:
+            native = False
+        t0 = time.perf_counter()
+        y_ref = oracle.spmv(shape, rp, ci, v, xh, native=native)
+        dt = time.perf_counter() - t0
+        absrow = oracle.spmv_absrow(rp, ci, v, xh)
+        cpu = {"value": 2.0 * nnz / dt / 1e9, "unit": "GFLOP/s", "cores": 1, "kind": "port", "seconds": dt,
+               "sample": f"full workload ({nnz} nnz), 1 run of oracle_spmv (-O3 -march={'native' if native else 'x86-64-v3'})"}
+        lens = np.diff(rp)
+        nbad, worst = parity_rows(y.cpu().numpy(), y_ref, absrow.astype(np.float64), 1e-12, float(np.finfo(np.float64).eps), lens)
+        parity = {"status": "pass" if nbad == 0 else "fail", "rows": int(m), "rows_out_of_bound": nbad, "tol": 1e-12,
+                  "worst_err_over_rownorm": worst,
+                  "against": "oracle_spmv (CPU restatement of multiply_impl.hpp:33-53), every row"}
+    dbl = "double"
+    kern = {3: f"pb_expand_kernel<{dbl},{'true' if si.get('nt_product_stores') else 'false'}> + pb_reduce_kernel<{dbl},...> "
+               "(+ pb_split_finish_kernel, pb_empty_rows_kernel; one SpMV = this launch group)",
+            2: "spmv_rowblock_kernel<double,int,1024> (+ spmv_long_fixup_kernel)"}.get(plan.get("alg"), "spmv_vector_kernel")
+    return _emit(args, "csr_spmv_gflops", 2.0 * nnz, alg_bytes, elapsed, ms,
+                 f"cfg4 (single-GPU leg): fp64 CSR SpMV, R-MAT scale {scale}, edge factor 16, duplicates kept, nnz={nnz}",
+                 {"dtype": "f64", "rows": m, "nnz": nnz, "operand": "matrix_opt(csr_view) + multiply_inspect", "plan": plan,
+                  "inspect_ms_untimed": inspect_ms, "kernel": kern}, cpu, parity=parity,
+                 pmc_key="spmv_rmat" if (args.rows is None and plan.get("alg") == 3) else None)
+
+
+def _run(args, device):
     import spblas_reference_amd as sp
     from oracle import oracle
     from spblas_reference_amd import generate
+
+    if args.workload == "spmv_rmat1":
+        return _run_spmv_rmat1(args, device, sp, oracle, generate)
 
     if args.workload in ("spmm", "spmm_banded", "spmm_rmat"):
         m = args.rows or 2_000_000
@@ -99,7 +276,28 @@ def run_extra(args, device):
             cpu = {"value": 2.0 * rp[-1] * ncols / dt / 1e9, "unit": "GFLOP/s", "cores": 1, "kind": "port",
                    "sample": f"first {rows} rows ({int(rp[-1])} nnz x {ncols} columns) of the same A and B, 1 run of oracle_spmm"}
         mi = info.state_.spmm_info()
-        _emit(args, "csr_spmm_gflops", 2.0 * nnz * ncols, alg_bytes, elapsed, ms,
+        # parity (outside the timed region): the first and last 1 500 rows and 1 500 sampled rows of the timed C against
+        # oracle_spmm on the compacted sub-problem (tests/test_gpu_configs.py does the same), plus the fp64 column checksum
+        rows = np.unique(np.concatenate([np.arange(1500), np.arange(m - 1500, m),
+                                         np.random.default_rng(0).integers(0, m, 1500)]))
+        sub_rp, sub_c, sub_v = rows_subproblem(rows, rowptr, colind, values)
+        uniq, inv = np.unique(sub_c, return_inverse=True)
+        inv = inv.astype(np.int32)
+        B_sub = B[torch.from_numpy(uniq.astype(np.int64)).to(device)].cpu().numpy()
+        C_ref = oracle.spmm((len(rows), len(uniq)), sub_rp, inv, sub_v, B_sub)
+        C_abs = oracle.spmm((len(rows), len(uniq)), sub_rp, inv, np.abs(sub_v), np.abs(B_sub)).astype(np.float64)
+        got = C[torch.from_numpy(rows.astype(np.int64)).to(device)].cpu().numpy()
+        nbad, worst = parity_rows(got, C_ref, C_abs, 1e-6, float(np.finfo(np.float32).eps), np.diff(sub_rp))
+        colsum = C.double().sum(0)
+        w = torch.zeros(shape[1], dtype=torch.float64, device=device).index_add_(0, colind.long(), values.double())
+        ref = (w[:, None] * B.double()).sum(0)
+        chk = bool(((colsum - ref).abs() <= 1e-6 * ref.abs()).all())
+        del w, ref, colsum
+        parity = {"status": "pass" if (nbad == 0 and chk) else "fail", "rows": int(len(rows)), "elements_out_of_bound": nbad,
+                  "tol": 1e-6, "worst_err_over_rownorm": worst, "column_checksum_fp64": "pass" if chk else "fail",
+                  "against": "oracle_spmm (CPU restatement of multiply_impl.hpp:66-92) on the first / last 1 500 and 1 500 "
+                             "sampled rows; every column's sum against an fp64 evaluation on the device"}
+        return _emit(args, "csr_spmm_gflops", 2.0 * nnz * ncols, alg_bytes, elapsed, ms,
               (f"R-MAT variant of cfg3: fp32 CSR x dense SpMM, A R-MAT scale 21 ({m}x{m}, {nnz} entries, duplicates kept), "
                f"B {m}x{ncols} row-major" if rmat else
                f"banded variant of cfg3: fp32 CSR x dense SpMM, A {m}x{m} 64 nnz/row within 48 columns of the diagonal, "
@@ -107,8 +305,8 @@ def run_extra(args, device):
                f"cfg3: fp32 CSR x dense SpMM, A {m}x{m} 32 nnz/row uniform random, B {m}x{ncols} row-major"),
               {"dtype": "f32", "rows": m, "nnz": nnz, "ncols": ncols, "spmm_inspect": mi,
                "kernel": "spmm_panel_kernel<int> (v_mfma_f32_32x32x2_f32)" if mi["panel_blocks"] > 0 else
-                         "spmm_rowgroup_kernel<float,int,4>"}, cpu)
-        return
+                         "spmm_rowgroup_kernel<float,int,4>"}, cpu, parity=parity,
+                     pmc_key=None if (banded or rmat or args.rows) else "spmm_cfg3")
 
     if args.workload == "spgemm":
         m = args.rows or 1_000_000
@@ -132,6 +330,8 @@ def run_extra(args, device):
         os.environ["SPBLAS_GFX950_SPGEMM_REUSE"] = "0"
         elapsed, ms = _time_steps(lambda: sp.multiply_fill(state, a, b, c), args.warmup, args.steps)
         del os.environ["SPBLAS_GFX950_SPGEMM_REUSE"]
+        torch.cuda.synchronize()
+        one_shot = (c.colind().clone(), c.values().clone())  # what the timed steps wrote: checked below
         alg_bytes = 2 * (annz * 8 + (m + 1) * 4) + cn * 8 + (m + 1) * 4
         # ... and, as a secondary figure, repeated fills of the same structure (multiply_numeric / symbolic-numeric reuse):
         # the second fill records the product ranks once, later ones accumulate by rank and leave the columns alone
@@ -169,7 +369,8 @@ def run_extra(args, device):
             cpu = {"value": 2.0 * (products * rows / m) / (t2 - t1) / 1e9, "unit": "GFLOP/s", "cores": 1, "kind": "port",
                    "sample": f"first {rows} rows of A x full B: symbolic {t1 - t0:.3f} s, numeric {t2 - t1:.3f} s (numeric timed)"}
         reuse_step = reuse_elapsed / args.steps
-        _emit(args, "csr_spgemm_fill_gflops", 2.0 * products, alg_bytes, elapsed, ms,
+        parity = _spgemm_parity(oracle, m, (ar, ac, av), (br, bc, bv), c_rp, c, cn, one_shot)
+        return _emit(args, "csr_spgemm_fill_gflops", 2.0 * products, alg_bytes, elapsed, ms,
               f"cfg5: fp32 CSR x CSR SpGEMM {m}x{m}, 16 nnz/row uniform random; timed step = one-shot multiply_fill "
               "(hash accumulators, sorted columns and values written), after multiply_compute",
               {"dtype": "f32", "rows": m, "products": products, "nnz_c": cn, "multiply_compute_ms_untimed": compute_warm_ms,
@@ -182,8 +383,8 @@ def run_extra(args, device):
                                   "algorithmic_bytes": reuse_bytes,
                                   "roofline_frac": reuse_bytes / (reuse_ms[0] * 1e-3) / 1e9 / 8000.0,
                                   "kernel": "spg_ranked_fill_kernel<float,16,256,4,false> (+ spg_rank_record_kernel<64,256> once)"},
-               "kernel": "spg_hash_kernel<float,9,64,true>"}, cpu)
-        return
+               "kernel": "spg_hash_kernel<float,9,64,true>"}, cpu, parity=parity,
+                     pmc_key=None if args.rows else "spgemm_cfg5")
 
     if args.workload == "add":  # C = A + B, timed step = add_compute (numeric)
         m = args.rows or 1_000_000
@@ -211,10 +412,9 @@ def run_extra(args, device):
             dt = time.perf_counter() - t0
             cpu = {"value": (ra[-1] + rb[-1]) / dt / 1e9, "unit": "Gentries/s", "cores": 1, "kind": "port",
                    "sample": f"first {rows} rows, oracle_add_f32 (SPA + sort per row)"}
-        _emit(args, "csr_add_gentries", float(annz + bnnz), alg_bytes, elapsed, ms,
+        return _emit(args, "csr_add_gentries", float(annz + bnnz), alg_bytes, elapsed, ms,
               f"8f: fp32 CSR + CSR add {m}x{m}, 16 nnz/row each, uniform random; timed step = add_compute; value = input entries/ns",
               {"dtype": "f32", "unit": "Gentries/s", "rows": m, "nnz_c": cn, "add_inspect_ms_untimed": inspect_ms}, cpu)
-        return
 
     if args.workload == "transpose":  # B = A^T (stable counting sort)
         m = args.rows or 10_000_000
@@ -235,10 +435,9 @@ def run_extra(args, device):
             dt = time.perf_counter() - t0
             cpu = {"value": rp[-1] / dt / 1e9, "unit": "Gentries/s", "cores": 1, "kind": "port",
                    "sample": f"first {rows} rows, oracle_transpose_f32"}
-        _emit(args, "csr_transpose_gentries", float(annz), alg_bytes, elapsed, ms,
+        return _emit(args, "csr_transpose_gentries", float(annz), alg_bytes, elapsed, ms,
               f"8f: fp32 CSR transpose {m}x{m}, 10 nnz/row uniform random; value = entries/ns",
               {"dtype": "f32", "unit": "Gentries/s", "rows": m, "nnz": annz}, cpu)
-        return
 
     if args.workload == "sptrsv":  # x = inv(L) b, L random lower triangular + diagonal
         m = args.rows or 4_000_000
@@ -281,11 +480,10 @@ def run_extra(args, device):
             dt = time.perf_counter() - t0
             cpu = {"value": 2.0 * nnz / dt / 1e9, "unit": "GFLOP/s", "cores": 1, "kind": "port",
                    "sample": f"full workload ({nnz} nnz), oracle_trsv_f32 (sequential reference loop)"}
-        _emit(args, "csr_sptrsv_gflops", 2.0 * nnz, alg_bytes, elapsed, ms,
+        return _emit(args, "csr_sptrsv_gflops", 2.0 * nnz, alg_bytes, elapsed, ms,
               f"8f: fp32 lower-triangular solve {m}x{m}, {k} random sub-diagonal entries per row + diagonal",
               {"dtype": "f32", "rows": m, "nnz": nnz, "plan": info.state_.info(),
                "triangular_solve_inspect_ms_untimed": inspect_ms,
                "triangular_solve_inspect_first_call_ms": inspect_first_ms}, cpu)
-        return
 
     raise SystemExit(f"unknown workload {args.workload}")

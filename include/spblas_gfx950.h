@@ -132,7 +132,15 @@ typedef enum spblas_gfx950_option {
    * fills of one result then leave the column indices alone (cfg5: 1.40 -> 0.94 ms per fill).  Default 0: every
    * numeric call writes c_colind -- an equal address proves nothing (allocators hand freed addresses out again:
    * the reference's SpGEMMReuseAndChangePointer test does exactly that, test/gtest/device/spgemm_reuse_test.cpp:325). */
-  SPBLAS_GFX950_OPT_SPGEMM_KEEP_COLIND = 4
+  SPBLAS_GFX950_OPT_SPGEMM_KEEP_COLIND = 4,
+  /* SLICED plans store their products with plain stores (value 0, the default) or with the non-temporal hint
+   * (value 1).  value 2 = decide by a timed trial: the first plan of this HANDLE with >= 32 M placed entries per
+   * value size runs eight SpMVs on a zero vector at inspect and the handle keeps the faster flavour for its later
+   * plans.  Which flavour wins is a property of the machine (-1...-4 % where the reduce pays for the expand's
+   * write-backs, +3 % where it does not); the trial roughly doubles the first inspect, so it is for callers who
+   * will run hundreds of multiplies.  Results are identical either way.  The environment variable
+   * SPBLAS_GFX950_PB_NT = 0 / 1 / -2 (trial) overrides the option for reproducible runs. */
+  SPBLAS_GFX950_OPT_STORE_TRIAL = 5
 } spblas_gfx950_option;
 int spblas_gfx950_set_option(spblas_gfx950_handle_t handle, int option, int64_t value);
 
@@ -248,6 +256,18 @@ int spblas_gfx950_spmm(spblas_gfx950_handle_t handle, spblas_gfx950_plan_t plan,
                        int64_t n, int64_t nnz, const void* alpha, const void* rowptr,
                        const int32_t* colind, const void* values, const void* B, int64_t ldb,
                        const void* beta, void* C, int64_t ldc, int offset_type, int value_type);
+/* The same product for dense operands of either mdspan layout: element (i, j) of B lives at B[i*b_row_stride +
+ * j*b_col_stride], likewise C.  The reference's CPU path takes any layout through mdspan's operator()
+ * (backend/view_customizations.hpp:230-240; mdspan_col_major is a public alias, detail/mdspan.hpp:31-36).  Both
+ * column strides 1 (layout_right): identical to spblas_gfx950_spmm with ldb / ldc = the row strides, plan included.
+ * Any other combination of layout_right / layout_left operands (row stride 1 and column stride >= rows, or column
+ * stride 1 and row stride >= n) runs a lane-group-per-row kernel whose gathers follow the strides; the plan is only
+ * checked.  Overlapping layouts return STATUS_INVALID_SIZE. */
+int spblas_gfx950_spmm_strided(spblas_gfx950_handle_t handle, spblas_gfx950_plan_t plan, int64_t m, int64_t k,
+                               int64_t n, int64_t nnz, const void* alpha, const void* rowptr,
+                               const int32_t* colind, const void* values, const void* B, int64_t b_row_stride,
+                               int64_t b_col_stride, const void* beta, void* C, int64_t c_row_stride,
+                               int64_t c_col_stride, int offset_type, int value_type);
 
 /* ---- SpGEMM:  C = alpha * A * B   (CSR x CSR -> CSR, int32 indices) -------- */
 /* State object = spgemm_state_t (vendor/rocsparse/multiply_spgemm.hpp:28-230). */

@@ -34,6 +34,7 @@ OPT_BIN_ROW_ALIGN = 1
 OPT_MAX_KSPLIT = 2
 OPT_VALUE_SNAPSHOT = 3
 OPT_SPGEMM_KEEP_COLIND = 4
+OPT_STORE_TRIAL = 5
 
 # every symbol include/spblas_gfx950.h declares: (name, restype, argtypes)
 PROTOTYPES = [
@@ -59,6 +60,9 @@ PROTOTYPES = [
     ("spblas_gfx950_spmm", c_int,
      [c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64,
       c_void_p, c_void_p, c_i64, c_int, c_int]),
+    ("spblas_gfx950_spmm_strided", c_int,
+     [c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_i64,
+      c_void_p, c_void_p, c_i64, c_i64, c_int, c_int]),
     ("spblas_gfx950_spmm_inspect", c_int, [c_void_p, c_void_p]),
     ("spblas_gfx950_spmm_plan_info", c_int, [c_void_p, ctypes.POINTER(c_i64)]),
     ("spblas_gfx950_csr_transpose", c_int,

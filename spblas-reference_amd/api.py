@@ -292,6 +292,13 @@ class _Plan:
         self.snapshot = self.info()["alg"] == _capi.SPMV_SLICED
         self.stamp = _values_stamp(tensors[2]) if tensors is not None and tensors[2] is not None else None
 
+    def _calling_handle(self, device=None):
+        """The CALLING thread's handle, bound to its current stream: a plan made in thread A and used in thread B (an
+        autograd backward thread, a worker pool) must launch its refresh / inspect work on B's stream, in order with B's
+        multiply -- not on whatever stream A's handle was last bound to.  The creator's handle (self.handle) is kept
+        alive for the plan's destruction only."""
+        return _Handle.current(device if device is not None else torch.device("cuda", self.handle.device))
+
     def refresh_if_stale(self, values):
         """SLICED plans only: re-copy the values when the caller's array was rebound or changed in place through
         torch or scale() since the copy was taken.  (Writes by foreign kernels are invisible here: call
@@ -315,7 +322,7 @@ class _Plan:
         bits = d["auto_trial"]
         d["row_code_u8"] = (bits >> 1) & 1  # one-byte row codes in the reduce's stream (runs sorted by row)
         d["nt_product_stores"] = (bits >> 2) & 1  # the expand stores its products with the non-temporal hint
-        d["store_trial"] = (bits >> 3) & 1  # THIS plan timed both store flavours (once per process, device and value size)
+        d["store_trial"] = (bits >> 3) & 1  # THIS plan timed both store flavours (opt-in: OPT_STORE_TRIAL = 2 on the handle or SPBLAS_GFX950_PB_NT=-2)
         d["auto_trial"] = bits & 1
         if d["store_trial"] and not d["auto_trial"]:  # (the two time slots carry AUTO's trial when both ran)
             d["store_trial_ns"] = {"plain": d.pop("trial_rowblock_ns"), "non_temporal": d.pop("trial_sliced_ns")}
@@ -329,8 +336,10 @@ class _Plan:
         lib = _capi.lib()
         ct = _VT[dtype][1]
         a, b = ct(alpha), ct(beta)
-        h, p, xp, yp = self.handle.h, self.plan, ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(y_base_ptr)
-        keep = (a, b, x)
+        # (the BINDING thread's handle: the callables belong to the thread that bound them)
+        hd = _Handle.current(x.device)
+        h, p, xp, yp = hd.h, self.plan, ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(y_base_ptr)
+        keep = (a, b, x, hd)
         # the stream that is current NOW: every other API call re-binds the handle to the then-current stream, so
         # the bound callables put the handle back on theirs before they launch
         stream = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
@@ -350,7 +359,7 @@ class _Plan:
     def spmm_inspect(self):
         """The SpMM part of multiply_inspect (spblas_gfx950_spmm_inspect): column-locality probe of every block of
         32 rows; qualifying blocks go to the LDS-staged matrix-core kernel, long rows are cut into parts."""
-        check(_capi.lib().spblas_gfx950_spmm_inspect(self.handle.h, self.plan), "multiply_inspect")
+        check(_capi.lib().spblas_gfx950_spmm_inspect(self._calling_handle().h, self.plan), "multiply_inspect")
         return self
 
     def spmm_info(self):
@@ -361,8 +370,8 @@ class _Plan:
     def update_values(self, values):
         """Refresh the plan after A's values changed in place (only the SLICED re-tiling keeps
         a copy of them; the other algorithms read the caller's array on every call)."""
-        check(_capi.lib().spblas_gfx950_spmv_plan_update_values(self.handle.h, self.plan, _ptr(values)),
-              "update_values")
+        check(_capi.lib().spblas_gfx950_spmv_plan_update_values(self._calling_handle(values.device).h, self.plan,
+                                                                _ptr(values)), "update_values")
         self.stamp = _values_stamp(values)
         if self.tensors is not None:
             self.tensors = (self.tensors[0], self.tensors[1], values)
@@ -409,15 +418,13 @@ class spgemm_state_t:
         return self._result_nnz
 
     def _ensure(self, device):
+        hd = _Handle.current(device)  # the CALLING thread's handle on its current stream (the state itself is handle-free)
         if self._state is None:
-            self._handle = _Handle.current(device)
+            self._handle = hd  # kept alive for the state's destruction
             st = ctypes.c_void_p()
-            check(_capi.lib().spblas_gfx950_spgemm_create(self._handle.h, ctypes.byref(st)),
-                  "spblas_gfx950_spgemm_create")
+            check(_capi.lib().spblas_gfx950_spgemm_create(hd.h, ctypes.byref(st)), "spblas_gfx950_spgemm_create")
             self._state = st
-        else:
-            _Handle.current(device)  # refresh the stream
-        return self._handle, self._state
+        return hd, self._state
 
     def __del__(self):
         try:
@@ -699,21 +706,31 @@ def _spmm(info, a, b, c):
     vt, ct = _vtype(a_base.values(), "multiply")
     if b_base.dtype != a_base.values().dtype or c.dtype != a_base.values().dtype:
         raise TypeError("multiply: A, B and C must share one value type")
-    for t in (b_base, c):  # layout_right only (vendor/onemkl_sycl/spmm_impl.hpp:133-138)
-        if t.numel() > 0 and t.stride(1) != 1:
-            raise ValueError("multiply: dense operands must be row-major (layout_right)")
+    # Dense operands: layout_right (row-major) or layout_left (column-major, mdspan_col_major of detail/mdspan.hpp:31-36) --
+    # the reference's CPU path takes any layout through mdspan's operator() (backend/view_customizations.hpp:230-240).
+    # Anything else (overlapping or doubly strided views) is refused like a non-mdspan argument would be.
+    m, k = a_base.shape()
+    n = c.shape[1]
+
+    def strides(t, rows):
+        if t.numel() == 0:
+            return max(n, 1), 1
+        rs, cs = t.stride(0), t.stride(1)
+        if (cs == 1 or n <= 1) and (rows <= 1 or rs >= n):      # layout_right, possibly a column window (rs > n)
+            return (rs if rows > 1 else max(n, 1)), 1
+        if (rs == 1 or rows <= 1) and (n <= 1 or cs >= rows):   # layout_left, possibly a row window (cs > rows)
+            return 1, (cs if n > 1 else max(rows, 1))
+        raise ValueError("multiply: dense operands must be row-major (layout_right) or column-major (layout_left)")
+
+    (brs, bcs), (crs, ccs) = strides(b_base, k), strides(c, m)
     alpha_opt = get_scaling_factor(a, b)
     alpha, beta = ct(1 if alpha_opt is None else alpha_opt), ct(0)
     hd = _Handle.current(c.device)
-    m, k = a_base.shape()
-    n = c.shape[1]
-    ldb = b_base.stride(0) if b_base.shape[0] > 1 else max(n, 1)
-    ldc = c.stride(0) if c.shape[0] > 1 else max(n, 1)
-    check(_capi.lib().spblas_gfx950_spmm(hd.h, plan.plan if plan is not None else None, m, k, n, a_base.size(),
-                                         ctypes.byref(alpha),
-                                         _ptr(a_base.rowptr()), _ptr(a_base.colind()), _ptr(a_base.values()),
-                                         _ptr(b_base), ldb, ctypes.byref(beta), _ptr(c), ldc,
-                                         _OT[a_base.rowptr().dtype], vt), "multiply")
+    check(_capi.lib().spblas_gfx950_spmm_strided(hd.h, plan.plan if plan is not None else None, m, k, n, a_base.size(),
+                                                 ctypes.byref(alpha),
+                                                 _ptr(a_base.rowptr()), _ptr(a_base.colind()), _ptr(a_base.values()),
+                                                 _ptr(b_base), brs, bcs, ctypes.byref(beta), _ptr(c), crs, ccs,
+                                                 _OT[a_base.rowptr().dtype], vt), "multiply")
 
 
 def _is_sparse(t):

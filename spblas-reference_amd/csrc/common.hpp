@@ -20,6 +20,8 @@ struct spblas_gfx950_handle_s {
   int64_t max_ksplit = 0;     // SPBLAS_GFX950_OPT_MAX_KSPLIT (0 = no cap)
   int64_t value_snapshot = 0; // SPBLAS_GFX950_OPT_VALUE_SNAPSHOT: AUTO may pick a plan that copies A's values
   int64_t spgemm_keep_colind = 0;  // SPBLAS_GFX950_OPT_SPGEMM_KEEP_COLIND: same c_colind address = same contents
+  int64_t store_flavour = 0;       // SPBLAS_GFX950_OPT_STORE_TRIAL: 0 plain product stores, 1 non-temporal, 2 timed trial
+  int nt_choice[2] = {0, 0};       // the trial's decision per value size (fp32 / fp64): 0 unknown, 1 plain, 2 non-temporal
   // one-shot: the next reduce_rows_bcast waits (on the device) for this step barrier right before the kernel that
   // stores to the peers -- the combine kernel when the reduce is K-split, else the reduce itself (spblas_gfx950_bcast_wait_before)
   struct bcast_wait_t {

@@ -109,6 +109,13 @@ int spblas_gfx950_set_option(spblas_gfx950_handle_t handle, int option, int64_t 
     handle->spgemm_keep_colind = value;
     return SPBLAS_GFX950_STATUS_SUCCESS;
   }
+  if (option == SPBLAS_GFX950_OPT_STORE_TRIAL) {
+    if (value < 0 || value > 2)
+      return SPBLAS_GFX950_STATUS_INVALID_VALUE;
+    handle->store_flavour = value;
+    handle->nt_choice[0] = handle->nt_choice[1] = 0;
+    return SPBLAS_GFX950_STATUS_SUCCESS;
+  }
   return SPBLAS_GFX950_STATUS_INVALID_VALUE;
 }
 

@@ -582,6 +582,75 @@ static int spmm_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, int64_
   return SPBLAS_GFX950_STATUS_SUCCESS;
 }
 
+
+// Dense operands of any mdspan layout (layout_left B and / or C): element (i, j) at i*rs + j*cs.  A group of G lanes owns
+// one row of A; the lanes walk the row's entries G at a time and keep JT output columns in registers, so every (column,
+// value) pair is loaded once per tile of JT columns and every gather is one element -- for a layout_left B the JT gathers
+// of an entry are JT different lines, which is what that layout costs.  Group reduction by shuffles, lane j of the group
+// writes column j of the tile.  The maths (per row, entries in storage order within a lane, lanes combined in a fixed
+// tree) is multiply_impl.hpp:66-92 up to the association of the row sum.
+template <typename T, typename O, int JT>
+__global__ __launch_bounds__(256) void spmm_strided_kernel(int64_t m, int64_t n, const O* __restrict__ rowptr,
+                                                           const int32_t* __restrict__ colind,
+                                                           const T* __restrict__ values, const T* __restrict__ B,
+                                                           int64_t brs, int64_t bcs, T* __restrict__ C, int64_t crs,
+                                                           int64_t ccs, T alpha, T beta, int G) {
+  const int64_t row = (int64_t) blockIdx.x * (256 / G) + threadIdx.x / G;
+  const int lig = threadIdx.x % G;
+  O p0 = 0, p1 = 0;
+  if (row < m) {
+    p0 = rowptr[row];
+    p1 = rowptr[row + 1];
+  }
+  for (int64_t j0 = (int64_t) blockIdx.y * JT; j0 < n; j0 += (int64_t) gridDim.y * JT) {
+    T acc[JT];
+#pragma unroll
+    for (int j = 0; j < JT; ++j)
+      acc[j] = T(0);
+    for (O p = p0 + lig; p < p1; p += G) {
+      const int64_t c = colind[p];
+      const T v = values[p];
+      const T* __restrict__ bp = B + c * brs + j0 * bcs;
+#pragma unroll
+      for (int j = 0; j < JT; ++j)
+        if (j0 + j < n)
+          acc[j] += v * bp[j * bcs];
+    }
+#pragma unroll
+    for (int j = 0; j < JT; ++j)
+      for (int o = G >> 1; o > 0; o >>= 1)
+        acc[j] += __shfl_xor(acc[j], o, G);
+    if (row < m) {
+#pragma unroll
+      for (int j = 0; j < JT; ++j)
+        if (lig == (j % G) && j0 + j < n) {
+          T* cp = C + row * crs + (j0 + j) * ccs;
+          *cp = beta == T(0) ? alpha * acc[j] : alpha * acc[j] + beta * *cp;
+        }
+    }
+  }
+}
+
+template <typename T, typename O>
+static int spmm_strided_typed(spblas_gfx950_handle_t h, int64_t m, int64_t n, int64_t nnz, const void* alpha_p,
+                              const void* rowptr_v, const int32_t* colind, const void* values_v, const void* B_v,
+                              int64_t brs, int64_t bcs, const void* beta_p, void* C_v, int64_t crs, int64_t ccs) {
+  if (m == 0 || n == 0)
+    return SPBLAS_GFX950_STATUS_SUCCESS;
+  const T alpha = *static_cast<const T*>(alpha_p), beta = *static_cast<const T*>(beta_p);
+  int G = 2;
+  const int64_t avg = m > 0 ? nnz / m : 0;
+  while (G < 64 && G < avg)
+    G <<= 1;
+  constexpr int JT = 8;
+  const int64_t tiles = cdiv(n, JT);
+  hipLaunchKernelGGL((spmm_strided_kernel<T, O, JT>), dim3((unsigned) cdiv(m, 256 / G), (unsigned) (tiles < 64 ? tiles : 64)),
+                     dim3(256), 0, h->stream, m, n, static_cast<const O*>(rowptr_v), colind, static_cast<const T*>(values_v),
+                     static_cast<const T*>(B_v), brs, bcs, static_cast<T*>(C_v), crs, ccs, alpha, beta, G);
+  SPB_HIP(hipGetLastError());
+  return SPBLAS_GFX950_STATUS_SUCCESS;
+}
+
 template <typename O>
 static int spmm_inspect_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl) {
   hipStream_t s = h->stream;
@@ -687,6 +756,43 @@ extern "C" int spblas_gfx950_spmm(spblas_gfx950_handle_t handle, spblas_gfx950_p
   return offset_type == SPBLAS_GFX950_I32
              ? spmm_typed<double, int32_t>(handle, plan, m, k, n, nnz, alpha, rowptr, colind, values, B, ldb, beta, C, ldc)
              : spmm_typed<double, int64_t>(handle, plan, m, k, n, nnz, alpha, rowptr, colind, values, B, ldb, beta, C, ldc);
+}
+
+extern "C" int spblas_gfx950_spmm_strided(spblas_gfx950_handle_t handle, spblas_gfx950_plan_t plan, int64_t m, int64_t k,
+                                          int64_t n, int64_t nnz, const void* alpha, const void* rowptr,
+                                          const int32_t* colind, const void* values, const void* B, int64_t brs, int64_t bcs,
+                                          const void* beta, void* C, int64_t crs, int64_t ccs, int offset_type,
+                                          int value_type) {
+  if (bcs == 1 && ccs == 1)  // both layout_right: the regular kernels, plan included
+    return spblas_gfx950_spmm(handle, plan, m, k, n, nnz, alpha, rowptr, colind, values, B, brs, beta, C, crs, offset_type,
+                              value_type);
+  if (!handle)
+    return SPBLAS_GFX950_STATUS_INVALID_HANDLE;
+  if (m < 0 || k < 0 || n < 0 || nnz < 0 || m > INT32_MAX || k > INT32_MAX)
+    return SPBLAS_GFX950_STATUS_INVALID_SIZE;
+  // each operand is layout_right (column stride 1, rows >= n apart) or layout_left (row stride 1, columns >= rows apart)
+  const auto layout_ok = [n](int64_t rows, int64_t rs, int64_t cs) {
+    return (cs == 1 && rs >= n) || (rs == 1 && cs >= rows) || rows <= 1 || n <= 1;
+  };
+  if (brs < 0 || bcs < 0 || crs < 0 || ccs < 0 || !layout_ok(k, brs, bcs) || !layout_ok(m, crs, ccs))
+    return SPBLAS_GFX950_STATUS_INVALID_SIZE;
+  if (offset_type == SPBLAS_GFX950_I32 && nnz > INT32_MAX)
+    return SPBLAS_GFX950_STATUS_INVALID_SIZE;
+  if ((offset_type != SPBLAS_GFX950_I32 && offset_type != SPBLAS_GFX950_I64) ||
+      (value_type != SPBLAS_GFX950_F32 && value_type != SPBLAS_GFX950_F64))
+    return SPBLAS_GFX950_STATUS_INVALID_VALUE;
+  if (!alpha || !beta || !rowptr || (nnz > 0 && (!colind || !values || !B)) || (m > 0 && n > 0 && !C))
+    return SPBLAS_GFX950_STATUS_INVALID_POINTER;
+  if (plan && (plan->m != m || plan->n != k || plan->nnz != nnz || plan->rowptr != rowptr ||
+               plan->colind != colind || plan->offset_type != offset_type || plan->value_type != value_type))
+    return SPBLAS_GFX950_STATUS_PLAN_MISMATCH;
+  if (value_type == SPBLAS_GFX950_F32)
+    return offset_type == SPBLAS_GFX950_I32
+               ? spmm_strided_typed<float, int32_t>(handle, m, n, nnz, alpha, rowptr, colind, values, B, brs, bcs, beta, C, crs, ccs)
+               : spmm_strided_typed<float, int64_t>(handle, m, n, nnz, alpha, rowptr, colind, values, B, brs, bcs, beta, C, crs, ccs);
+  return offset_type == SPBLAS_GFX950_I32
+             ? spmm_strided_typed<double, int32_t>(handle, m, n, nnz, alpha, rowptr, colind, values, B, brs, bcs, beta, C, crs, ccs)
+             : spmm_strided_typed<double, int64_t>(handle, m, n, nnz, alpha, rowptr, colind, values, B, brs, bcs, beta, C, crs, ccs);
 }
 
 extern "C" int spblas_gfx950_spmm_inspect(spblas_gfx950_handle_t handle, spblas_gfx950_plan_t plan) {

@@ -573,33 +573,24 @@ static int auto_trial(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const 
   return SPBLAS_GFX950_STATUS_SUCCESS;
 }
 
-// Store trial (SLICED plans with >= 32 M placed entries: the product array is far larger than any cache): which flavour of
-// product store is faster is a property of the box and the moment, not of the matrix -- where the reduce pays for the
-// expand's write-backs the non-temporal hint wins 1-4 %, elsewhere it loses 3 % (tools/exp_r03o.sh,
-// profiles/r03_store_trial.md).  Decided once per process, device and value size by timing the plan both ways (a warm-up
-// and three samples of two SpMVs each, interleaved, on a zero vector); later plans reuse the decision.
-// SPBLAS_GFX950_PB_NT = 0 / 1 forces it, unset or -1 = this trial.
-// (Where the product workspace lives matters more than this flavour -- the same plan runs 290-318 us depending on which
-// memory that one array got -- but nothing tried so far picks the fast kind: timing whole SpMVs on three candidates, a
-// scattered-store test on four or eight (it chose worse than "take the first" on five boxes of six), memory mapped through
-// the virtual-memory API.  profiles/r03_store_trial.md has the measurements; the code is gone again.)
+// Product-store flavour of a SLICED plan.  Which one is faster is a property of the box and the moment, not of the matrix:
+// where the reduce pays for the expand's write-backs the non-temporal hint wins 1-4 %, elsewhere it loses 3 %
+// (tools/exp_r03o.sh, profiles/r03_store_trial.md; on the round-3 driver box the two differed by 0.7 %).  Default: plain
+// stores, no trial.  Opt-in (SPBLAS_GFX950_OPT_STORE_TRIAL = 2 on the handle, or SPBLAS_GFX950_PB_NT=-2): the first plan of
+// the HANDLE with >= 32 M placed entries per value size times the plan both ways (a warm-up and three samples of two SpMVs
+// each, interleaved, on a zero vector) and the handle keeps the decision for its later plans -- no process-wide state.
+// SPBLAS_GFX950_PB_NT = 0 / 1 forces a flavour (reproducible runs, profiles); option value 0 / 1 does the same per handle.
 // SPBLAS_GFX950_PB_TUNE_MIN: test hook, the number of placed entries from which a plan counts as large.
-static std::atomic<int> g_nt_choice[32][2];  // [device][fp32 / fp64]: 0 = unknown, 1 = plain, 2 = non-temporal
 static void store_trial(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const void* values) {
-  const int forced = env_int_spmv("SPBLAS_GFX950_PB_NT", -1);
-  pl->nt_products = forced == 1;
-  if (pl->s_placed < (int64_t) env_int_spmv("SPBLAS_GFX950_PB_TUNE_MIN", 32 << 20))
+  const int env = env_int_spmv("SPBLAS_GFX950_PB_NT", -1);
+  const int mode = env == 0 || env == 1 ? env : env == -2 ? 2 : (int) h->store_flavour;
+  pl->nt_products = mode == 1;
+  if (mode != 2 || pl->s_placed < (int64_t) env_int_spmv("SPBLAS_GFX950_PB_TUNE_MIN", 32 << 20))
     return;
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) {
-    (void) hipGetLastError();
-    return;
-  }
   const size_t tsz = pl->value_type == SPBLAS_GFX950_F32 ? 4 : 8;
-  std::atomic<int>& slot = g_nt_choice[dev][tsz == 4 ? 0 : 1];
-  const int known = (forced == 0 || forced == 1) ? forced + 1 : slot.load();
-  if (known != 0) {
-    pl->nt_products = known == 2;
+  int& slot = h->nt_choice[tsz == 4 ? 0 : 1];
+  if (slot != 0) {
+    pl->nt_products = slot == 2;
     return;
   }
   hipStream_t s = h->stream;
@@ -650,7 +641,7 @@ static void store_trial(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, cons
       // the hint has to win by more than the noise of three samples (where it matters it wins by 2-4 %; where it does
       // not, it loses by as much)
       pl->nt_products = best[1] < 0.995f * best[0];
-      slot.store(pl->nt_products ? 2 : 1);
+      slot = pl->nt_products ? 2 : 1;
     }
   }
   (void) hipStreamSynchronize(s);
@@ -774,11 +765,22 @@ int spblas_gfx950_spmv_reduce_rows(spblas_gfx950_handle_t handle, spblas_gfx950_
   return spmv_sliced_reduce_rows(handle, plan, alpha, beta, y, row_begin, row_end, nullptr, 0, 0);
 }
 
+// The step wait armed by spblas_gfx950_bcast_wait_before belongs to exactly ONE bcast call: whatever path that call
+// leaves by (argument checks, NOT_SUPPORTED for hub rows, a refused workspace, an empty range, a failed launch), the wait
+// must not stay armed on the handle and fire inside a later, unrelated reduce with a stale step and status pointer.
+struct bcast_wait_disarm {
+  spblas_gfx950_handle_t h;
+  ~bcast_wait_disarm() {
+    h->bcast_wait.flags = nullptr;
+  }
+};
+
 int spblas_gfx950_spmv_reduce_rows_bcast(spblas_gfx950_handle_t handle, spblas_gfx950_plan_t plan, const void* alpha,
                                          void* const* y_peers, int n_peers, int64_t y_row_offset,
                                          int64_t row_begin, int64_t row_end) {
   if (!handle)
     return SPBLAS_GFX950_STATUS_INVALID_HANDLE;
+  bcast_wait_disarm disarm{handle};
   if (!plan || !alpha || !y_peers)
     return SPBLAS_GFX950_STATUS_INVALID_POINTER;
   if (plan->alg != SPBLAS_GFX950_SPMV_SLICED)
@@ -801,6 +803,7 @@ int spblas_gfx950_spmv_step_bcast(spblas_gfx950_handle_t handle, spblas_gfx950_p
                                   int stripes) {
   if (!handle)
     return SPBLAS_GFX950_STATUS_INVALID_HANDLE;
+  bcast_wait_disarm disarm{handle};
   if (!plan || !alpha || !x || !y_peers)
     return SPBLAS_GFX950_STATUS_INVALID_POINTER;
   if (plan->alg != SPBLAS_GFX950_SPMV_SLICED)

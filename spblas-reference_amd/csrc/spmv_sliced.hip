@@ -995,7 +995,7 @@ typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
 // NT: the products are stored with the non-temporal hint.  Which flavour is faster depends on the BOX (round 3,
 // tools/exp_r03o.sh, same binaries): where the reduce pays for the expand's write-backs (reduce 118-122 us after plain
 // stores) the hint moves that cost into the expand and the pair gains 1-3 %; where it does not (reduce 105-107 us) the hint
-// costs 3 %.  spblas_gfx950_spmv_plan_create times both once per process and device for large plans (spmv.hip: store_trial).
+// costs 3 %.  Default plain; a handle can ask for a timed trial at inspect (SPBLAS_GFX950_OPT_STORE_TRIAL, spmv.hip: store_trial).
 template <typename T, bool NT>
 __global__ __launch_bounds__(PB_THREADS) void pb_expand_kernel(int64_t n, int W, const int32_t* __restrict__ sliceblk,
                                                                const T* __restrict__ s_val,
@@ -2292,9 +2292,12 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
   } else {
     SPB_HIP(hipStreamSynchronize(s));
   }
-  if (enc_fail || env_int("SPBLAS_GFX950_PB_ENC8_FAIL", 0)) {
+  if (pl->enc8 && (enc_fail || env_int("SPBLAS_GFX950_PB_ENC8_FAIL", 0))) {
     // a wave-bin with more exceptions than its list holds, or a run that could not be sorted: the same plan with
-    // 16-bit rows (the tiles, offsets and work lists stay; the scatter and the duplicate flags run again)
+    // 16-bit rows (the tiles, offsets and work lists stay; the scatter and the duplicate flags run again).  Only a plan
+    // that WAS built with one-byte codes takes this branch (the test hook alone must not re-allocate live 16-bit rows).
+    pl->device_bytes -= (size_t) p_pad + hdr_bytes + (size_t) NB * PB_EXC_CAP * 6;
+    pl->device_bytes += (size_t) p_pad * 2;
     dev_free(pl->s_code, s);
     dev_free(pl->s_hdr, s);
     dev_free(pl->s_exc_idx, s);

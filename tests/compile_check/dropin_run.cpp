@@ -224,28 +224,57 @@ int main() {
     multiply(a_csc, x, y);
     expect(close_vec(dy.host(), want, absrow), "multiply(csc_view, x, y)");
     {
-      // inspected csc_view: the row-major form is materialised once (csc_spmv_state_t) and the regular kernels run;
-      // the result equals the atomics path above to rounding (vendor/rocsparse/detail/get_transpose.hpp:19-29 semantics)
+      // inspected PLAIN csc_view: structure only -- every multiply reads the caller's arrays (op = T), so values
+      // rewritten in place after the inspect are seen (algorithms/multiply_impl.hpp:48-52 reads A on every call)
       const std::vector<T> y_atomics = dy.host();
       HIP_OK(hipMemset(dy.p, 0xFF, m * sizeof(T)));
       operation_info_t info_csc = multiply_inspect(a_csc, x, y);
-      auto* st = info_csc.state_.get_state<__gfx950::csc_spmv_state_t<T>>();
-      expect(st != nullptr && st->inspections() == 1, "multiply_inspect(csc_view, ...) materialises the transpose once");
+      expect(info_csc.state_.get_state<__gfx950::csc_spmv_state_t<T>>() == nullptr,
+             "multiply_inspect(csc_view, ...) keeps no copy of the values");
       multiply(info_csc, a_csc, x, y);
-      multiply(info_csc, a_csc, x, y);
+      expect(close_vec(dy.host(), want, absrow), "multiply(info, csc_view, x, y) after multiply_inspect");
+      {
+        std::vector<T> doubled(ht.values);
+        for (auto& v : doubled)
+          v *= 2;
+        HIP_OK(hipMemcpy(dt.values.p, doubled.data(), doubled.size() * sizeof(T), hipMemcpyHostToDevice));
+        std::vector<double> want2, abs2;
+        host_spmv(ha, hx, 2.0, want2, abs2);
+        multiply(info_csc, a_csc, x, y);
+        expect(close_vec(dy.host(), want2, abs2), "inspected csc_view: values rewritten IN PLACE are seen by the next multiply");
+        HIP_OK(hipMemcpy(dt.values.p, ht.values.data(), ht.values.size() * sizeof(T), hipMemcpyHostToDevice));
+      }
+      // matrix_opt over the csc_view: the row-major form is materialised once (csc_spmv_state_t) and the regular kernels
+      // run; the result equals the atomics path above to rounding (vendor/rocsparse/detail/get_transpose.hpp:19-29)
+      matrix_opt c_opt(a_csc);
+      multiply_inspect(c_opt, x, y);
+      auto* st = c_opt.gfx950_state_->get<__gfx950::csc_spmv_state_t<T>>();
+      expect(st != nullptr && st->inspections() == 1, "multiply_inspect(matrix_opt(csc_view), ...) materialises the transpose once");
+      HIP_OK(hipMemset(dy.p, 0xFF, m * sizeof(T)));
+      multiply(c_opt, x, y);
+      multiply(c_opt, x, y);
       const std::vector<T> y_insp = dy.host();
-      expect(close_vec(y_insp, want, absrow) && st->inspections() == 1, "multiply(info, csc_view, x, y) after multiply_inspect");
+      expect(close_vec(y_insp, want, absrow) && st != nullptr && st->inspections() == 1,
+             "multiply(matrix_opt(csc_view), x, y) without info");
       bool same = true;
       for (std::size_t i = 0; i < y_insp.size(); ++i)
         same = same && std::fabs(static_cast<double>(y_insp[i]) - y_atomics[i]) <= 2e-6 * absrow[i] + 1e-30;
-      expect(same, "inspected csc_view result equals the atomics path to rounding");
-      // ... and through a matrix_opt over the csc_view, without info
-      matrix_opt c_opt(a_csc);
-      multiply_inspect(c_opt, x, y);
-      HIP_OK(hipMemset(dy.p, 0xFF, m * sizeof(T)));
-      multiply(c_opt, x, y);
-      expect(close_vec(dy.host(), want, absrow) && c_opt.gfx950_state_->get<__gfx950::csc_spmv_state_t<T>>() != nullptr,
-             "multiply(matrix_opt(csc_view), x, y) without info");
+      expect(same, "matrix_opt(csc_view) result equals the atomics path to rounding");
+      if (st) {
+        // the snapshot contract of matrix_opt: in-place changes reach the copy through update_values
+        std::vector<T> tripled(ht.values);
+        for (auto& v : tripled)
+          v *= 3;
+        HIP_OK(hipMemcpy(dt.values.p, tripled.data(), tripled.size() * sizeof(T), hipMemcpyHostToDevice));
+        st->update_values(dt.values.p);
+        std::vector<double> want3, abs3;
+        host_spmv(ha, hx, 3.0, want3, abs3);
+        multiply(c_opt, x, y);
+        expect(close_vec(dy.host(), want3, abs3) && st->inspections() == 1,
+               "matrix_opt(csc_view): update_values after an in-place change, no new inspect");
+        HIP_OK(hipMemcpy(dt.values.p, ht.values.data(), ht.values.size() * sizeof(T), hipMemcpyHostToDevice));
+        st->update_values(dt.values.p);
+      }
     }
     // y2 = A^T x2 through transposed(a)
     std::vector<T> hx2(m);
@@ -287,6 +316,27 @@ int main() {
     operation_info_t info = multiply_inspect(a, B, C);
     multiply(info, a, B, C);
     expect(close_vec(dc.host(), want, scale), "multiply(info, a, B, C) after multiply_inspect");
+    {
+      // column-major dense operands (mdspan_col_major, detail/mdspan.hpp:31-36; test/gtest/mdspan_overlays.cpp:38-45): B
+      // and C stored column by column, and the mixed pair B column-major / C row-major
+      std::vector<T> hb_cm(hb.size());
+      for (I r = 0; r < k; ++r)
+        for (I j = 0; j < n; ++j)
+          hb_cm[static_cast<std::size_t>(j) * k + r] = hb[static_cast<std::size_t>(r) * n + j];
+      dev_array<T> db_cm(hb_cm), dc_cm(static_cast<std::size_t>(m) * n);
+      mdspan_col_major<T, I> Bc(db_cm.p, k, n), Cc(dc_cm.p, m, n);
+      HIP_OK(hipMemset(dc_cm.p, 0xFF, dc_cm.n * sizeof(T)));
+      multiply(a, Bc, Cc);
+      const std::vector<T> got_cm = dc_cm.host();
+      std::vector<T> got_rm(got_cm.size());
+      for (I r = 0; r < m; ++r)
+        for (I j = 0; j < n; ++j)
+          got_rm[static_cast<std::size_t>(r) * n + j] = got_cm[static_cast<std::size_t>(j) * m + r];
+      expect(close_vec(got_rm, want, scale), "multiply(a, B, C) with mdspan_col_major B and C");
+      HIP_OK(hipMemset(dc.p, 0xFF, dc.n * sizeof(T)));
+      multiply(info, a, Bc, C);
+      expect(close_vec(dc.host(), want, scale), "multiply(info, a, B col-major, C row-major)");
+    }
   }
 
   // ---- 64-bit row offsets and fp64 values: csr_view<double, int32, int64> (views/csr_view.hpp is templated on all three;

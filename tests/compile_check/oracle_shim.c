@@ -185,6 +185,39 @@ int spblas_gfx950_spmm(spblas_gfx950_handle_t handle, spblas_gfx950_plan_t plan,
                                 (const double*) B, ldb, 0, 0.0, (double*) C, ldc, 1));
 }
 
+/* either mdspan layout for B and C (element (i, j) at i*rs + j*cs): both row-major or both column-major go straight to
+ * the oracle's two layouts; a mixed pair is staged through row-major temporaries */
+int spblas_gfx950_spmm_strided(spblas_gfx950_handle_t handle, spblas_gfx950_plan_t plan, int64_t m, int64_t k, int64_t n,
+                               int64_t nnz, const void* alpha, const void* rowptr, const int32_t* colind,
+                               const void* values, const void* B, int64_t brs, int64_t bcs, const void* beta, void* C,
+                               int64_t crs, int64_t ccs, int offset_type, int value_type) {
+  if (bcs == 1 && ccs == 1)
+    return spblas_gfx950_spmm(handle, plan, m, k, n, nnz, alpha, rowptr, colind, values, B, brs, beta, C, crs, offset_type,
+                              value_type);
+  if (offset_type != SPBLAS_GFX950_I32)
+    return SPBLAS_GFX950_STATUS_NOT_SUPPORTED;
+  const size_t tsz = value_type == SPBLAS_GFX950_F32 ? 4 : 8;
+  char* bt = (char*) malloc(tsz * (size_t) (k * n > 0 ? k * n : 1));
+  char* ct = (char*) malloc(tsz * (size_t) (m * n > 0 ? m * n : 1));
+  if (!bt || !ct) {
+    free(bt);
+    free(ct);
+    return SPBLAS_GFX950_STATUS_ALLOC_FAILED;
+  }
+  for (int64_t i = 0; i < k; ++i)
+    for (int64_t j = 0; j < n; ++j)
+      memcpy(bt + tsz * (size_t) (i * n + j), (const char*) B + tsz * (size_t) (i * brs + j * bcs), tsz);
+  const int rc = spblas_gfx950_spmm(handle, plan, m, k, n, nnz, alpha, rowptr, colind, values, bt, n > 0 ? n : 1, beta, ct,
+                                    n > 0 ? n : 1, offset_type, value_type);
+  if (rc == 0)
+    for (int64_t i = 0; i < m; ++i)
+      for (int64_t j = 0; j < n; ++j)
+        memcpy((char*) C + tsz * (size_t) (i * crs + j * ccs), ct + tsz * (size_t) (i * n + j), tsz);
+  free(bt);
+  free(ct);
+  return rc;
+}
+
 /* ---- SpGEMM and add ---- */
 int spblas_gfx950_spgemm_create(spblas_gfx950_handle_t handle, spblas_gfx950_spgemm_t* state) {
   (void) handle;

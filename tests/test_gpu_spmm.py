@@ -81,8 +81,53 @@ def test_spmm_strided_operands_and_errors(gpu):
     assert float(Cbig[:, :8].abs().sum()) == 0 and float(Cbig[:, 32:].abs().sum()) == 0
     with pytest.raises(ValueError):  # multiply_impl.hpp:70-76
         sp.multiply(a, torch.zeros((79, 8), device="cuda"), torch.zeros((64, 8), device="cuda"))
-    with pytest.raises(ValueError):
-        sp.multiply(a, torch.zeros((80, 8), device="cuda").t().contiguous().t(), torch.zeros((64, 8), device="cuda"))
+    with pytest.raises(ValueError):  # neither layout_right nor layout_left: strided in both directions
+        sp.multiply(a, torch.zeros((160, 16), device="cuda")[::2, ::2], torch.zeros((64, 8), device="cuda"))
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("n", [1, 8, 33, 130])
+@pytest.mark.parametrize("layouts", ["left_left", "left_right", "right_left"])
+def test_spmm_column_major_operands(gpu, layouts, n, dtype):
+    """mdspan_col_major dense operands (detail/mdspan.hpp:31-36; the CPU path takes any layout through mdspan's
+    operator(), backend/view_customizations.hpp:230-240; test/gtest/mdspan_overlays.cpp:38-45 builds such views): B and / or
+    C column-major, with and without padding between the columns, plan-free and after multiply_inspect, scaled -- against
+    the oracle on the same logical matrices."""
+    m, k, nnz = 300, 700, 9000
+    values, rowptr, colind, shape, _ = generate.generate_csr(m, k, nnz, dtype=dtype, seed=9)
+    a = G.csr_on_device(values, rowptr, colind, shape, nnz)
+    B = (generate.generate_dense(k, n, dtype=dtype) - 50).astype(dtype)
+    tdt = torch.float32 if dtype == np.float32 else torch.float64
+    lb, lc = layouts.split("_")
+
+    def dense(rows, cols, layout, pad, init=None):
+        if layout == "left":   # element (i, j) at i + j * (rows + pad)
+            store = torch.full((cols, rows + pad), float("nan"), dtype=tdt, device="cuda")
+            view = store[:, :rows].t()
+        else:
+            store = torch.full((rows, cols + pad), float("nan"), dtype=tdt, device="cuda")
+            view = store[:, :cols]
+        if init is not None:
+            view.copy_(torch.from_numpy(init).cuda())
+        return store, view
+
+    C_ref = oracle.spmm(shape, rowptr, colind, values, B, scale_a=-2.5)
+    ab = 2.5 * absprod(values, rowptr, colind, shape, B)
+    for pad in (0, 5):
+        _, Bv = dense(k, n, lb, pad, B)
+        c_store, Cv = dense(m, n, lc, pad)
+        assert (Bv.stride(1) == 1) == (lb == "right") or n == 1 or k == 1
+        for inspect in (False, True):
+            Cv.fill_(float("nan"))
+            if inspect:
+                info = sp.multiply_inspect(a, Bv, Cv)
+                sp.multiply(info, sp.scaled(-2.5, a), Bv, Cv)
+            else:
+                sp.multiply(sp.scaled(-2.5, a), Bv, Cv)
+            util.assert_parity(G.host(Cv.contiguous()), C_ref, ab, dtype, row_len=np.diff(rowptr),
+                               what=f"spmm {layouts} n={n} pad={pad} inspect={inspect}")
+            if pad:  # the padding between rows / columns of C is never written
+                assert bool(torch.isnan(c_store[:, -pad:]).all())
 
 
 def test_spmm_cfg3_shape_properties(gpu):

@@ -755,7 +755,7 @@ def test_spmv_auto_declines_sliced_for_skewed_matrices(gpu, monkeypatch, varbins
 @pytest.mark.parametrize("nt", ["0", "1"])
 def test_spmv_sliced_product_store_flavours(gpu, monkeypatch, dtype, nt):
     """The expand kernel exists with plain and with non-temporal product stores (which is faster depends on the box;
-    plans with >= 32 M entries time both once per process, csrc/spmv.hip: store_trial).  Forced either way here on a
+    a handle can ask for a timed trial, csrc/spmv.hip: store_trial).  Forced either way here on a
     matrix with ragged rows, a long row and duplicates: same answers, and the plan reports what it runs."""
     monkeypatch.setenv("SPBLAS_GFX950_PB_NT", nt)
     rng = np.random.default_rng(17)
@@ -779,10 +779,11 @@ def test_spmv_sliced_product_store_flavours(gpu, monkeypatch, dtype, nt):
 
 
 def test_spmv_store_trial_runs_once_per_process_at_cfg2_size(gpu, monkeypatch):
-    """Plans with >= 32 M placed entries let the first of them time the SpMV with plain and with non-temporal product
-    stores (the faster flavour is a property of the box: tools/exp_r03o.sh) and keep the decision for the process.  Run in a
-    fresh interpreter: the first cfg2-sized plan reports the trial and its two times, the second one only the decision;
-    both forced flavours give the same y to rounding."""
+    """Opt-in (SPBLAS_GFX950_PB_NT=-2, or SPBLAS_GFX950_OPT_STORE_TRIAL = 2 on the handle): the first plan of a handle with
+    >= 32 M placed entries times the SpMV with plain and with non-temporal product stores (the faster flavour is a property
+    of the box: tools/exp_r03o.sh) and the handle keeps the decision.  Run in a fresh interpreter: without the opt-in no
+    trial runs and the stores are plain; with it the first cfg2-sized plan reports the trial and its two times, the second
+    one only the decision; both forced flavours give the same y to rounding."""
     import subprocess
     import sys
     code = r'''
@@ -795,7 +796,7 @@ v, rp, ci, shape, nnz = generate.uniform_csr_device(n, n, 10, seed=0)
 a = sp.csr_view(v, rp, ci, shape, nnz)
 x = torch.rand(n, device="cuda"); ys = []
 out = {}
-for tag, env in (("first", None), ("second", None), ("plain", "0"), ("nt", "1")):
+for tag, env in (("default", None), ("first", "-2"), ("second", "-2"), ("plain", "0"), ("nt", "1")):
     if env is None:
         os.environ.pop("SPBLAS_GFX950_PB_NT", None)
     else:
@@ -810,7 +811,7 @@ for tag, env in (("first", None), ("second", None), ("plain", "0"), ("nt", "1"))
     del info
 absrow = torch.zeros(n, device="cuda")
 sp.multiply(sp.csr_view(v.abs(), rp, ci, shape, nnz), x, absrow)
-out["max_diff"] = max(float(((ys[i] - ys[2]).abs() / absrow).max()) for i in (0, 1, 3))
+out["max_diff"] = max(float(((ys[i] - ys[3]).abs() / absrow).max()) for i in (0, 1, 2, 4))
 print("RESULT " + json.dumps(out))
 '''
     env = dict(os.environ)
@@ -821,6 +822,7 @@ print("RESULT " + json.dumps(out))
     import json
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])
     first, second = out["first"], out["second"]
+    assert out["default"]["store_trial"] == 0 and out["default"]["nt_product_stores"] == 0
     assert first["store_trial"] == 1 and second["store_trial"] == 0
     t = first["store_trial_ns"]
     assert 150_000 < t["plain"] < 600_000 and 150_000 < t["non_temporal"] < 600_000, t
@@ -836,7 +838,7 @@ def test_spmv_store_trial_on_a_small_plan(gpu, monkeypatch, dtype):
     """The store trial of large plans forced onto a small one (SPBLAS_GFX950_PB_TUNE_MIN=0): six SpMVs on a zero vector at
     inspect, two temporary vectors that are given back, the same answers afterwards whichever flavour won."""
     monkeypatch.setenv("SPBLAS_GFX950_PB_TUNE_MIN", "0")
-    monkeypatch.delenv("SPBLAS_GFX950_PB_NT", raising=False)
+    monkeypatch.setenv("SPBLAS_GFX950_PB_NT", "-2")
     values, rowptr, colind, shape, nnz = generate.generate_csr(30000, 50000, 600000, dtype=dtype, seed=23)
     x = (np.random.default_rng(2).random(50000) - 0.5).astype(dtype)
     a = G.csr_on_device(values, rowptr, colind, shape, nnz)

@@ -77,3 +77,57 @@ def test_threads_on_their_own_streams_do_not_share_a_handle(gpu):
         th.join(timeout=300)
     assert not errors, errors
     assert len(set(handles.values())) == n_threads, f"threads shared a handle: {handles}"
+
+
+def test_plan_made_in_one_thread_refreshes_on_the_calling_threads_stream(gpu):
+    """A SLICED plan (matrix_opt: it multiplies with a snapshot of the values) created in thread A and used in thread B on
+    B's own stream after the values changed in place: the refresh of the snapshot and the SpGEMM fill of a state created
+    in A must be issued through B's handle -- B's stream, in order with B's multiply (round-3 advice: they used the
+    creator's handle, i.e. whatever stream A last bound)."""
+    m, n, nnz = 30000, 40000, 500000
+    values, rowptr, colind, shape, _ = generate.generate_csr(m, n, nnz, seed=77)
+    x_h = np.random.default_rng(5).standard_normal(n).astype(np.float32)
+    made, errors, used = {}, [], {}
+
+    def maker():
+        try:
+            with torch.cuda.stream(torch.cuda.Stream()):
+                a = sp.csr_view(G.dev(values), G.dev(rowptr), G.dev(colind), shape, nnz)
+                x = G.dev(x_h)
+                y = torch.empty(m, device="cuda")
+                info = sp.multiply_inspect(sp.matrix_opt(a), x, y, alg=_capi.SPMV_SLICED)
+                sp.multiply(info, a, x, y)
+                torch.cuda.current_stream().synchronize()
+                made.update(a=a, x=x, info=info, handle=sp.api._Handle.current(x.device).h.value)
+        except BaseException as e:  # noqa: BLE001
+            errors.append(("maker", repr(e)))
+
+    def user():
+        try:
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                a, x, info = made["a"], made["x"], made["info"]
+                used["handle"] = sp.api._Handle.current(x.device).h.value
+                y = torch.full((m,), float("nan"), device="cuda")
+                for k in (2.0, -0.5):
+                    a.values().mul_(k)  # in place, on THIS thread's stream, right before the multiply
+                    sp.multiply(info, a, x, y)
+                    used[k] = y.clone()
+                stream.synchronize()
+        except BaseException as e:  # noqa: BLE001
+            errors.append(("user", repr(e)))
+
+    for fn in (maker, user):
+        th = threading.Thread(target=fn)
+        th.start()
+        th.join(timeout=300)
+    assert not errors, errors
+    assert used["handle"] != made["handle"]
+    lens = np.diff(rowptr)
+    scale = 1.0
+    for k in (2.0, -0.5):
+        scale *= k
+        v = (values * np.float32(scale)).astype(np.float32)
+        util.assert_parity(G.host(used[k]), oracle.spmv(shape, rowptr, colind, v, x_h),
+                           oracle.spmv_absrow(rowptr, colind, v, x_h), np.float32, row_len=lens,
+                           what=f"cross-thread plan after in-place scaling by {k}")
