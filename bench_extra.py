@@ -25,6 +25,8 @@ def read_pmc_traffic(name):
     try:
         with open(path) as f:
             d = json.load(f)
+        if name not in d:
+            return None, None
         stamp = dict((d.get("_stamp") or {}).get(name) or {})
         src = stamp.get("source_file", "spmv_sliced.hip")
         key = src.replace(".", "_") + "_sha256_16"

@@ -12,7 +12,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline $*"
+BENCH="python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary $*"
 CALIB="python3 $ROOT/tools/calib_copy.py"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- $BENCH > $OUT/stats.log 2>&1
 i=0
