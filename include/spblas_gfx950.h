@@ -180,6 +180,10 @@ int spblas_gfx950_plan_info(spblas_gfx950_plan_t plan, int64_t info[12]);
  * row-block / the sliced plan in AUTO's trial, nanoseconds -- or, when only the store trial ran, of one SpMV with plain /
  * non-temporal product stores. */
 int spblas_gfx950_plan_info_sliced(spblas_gfx950_plan_t plan, int64_t info[12]);
+/* Hot-column split of a SLICED plan (column-skewed matrices, csrc/spmv_hot.hip): [0] hot columns, [1] entries multiplied
+ * in row order with those x values in LDS, [2] rows that have such entries, [3] of them longer than a window, [4] entries
+ * left to the tiles, [5] device bytes of the tiled part.  All 0 for a plan without the split. */
+int spblas_gfx950_plan_info_hot(spblas_gfx950_plan_t plan, int64_t info[6]);
 
 /* Two-stage execution of a SLICED plan (other plans: STATUS_NOT_SUPPORTED), used to overlap the
  * multi-GPU all-gather of finished y rows with the rest of the SpMV:

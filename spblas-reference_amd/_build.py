@@ -11,7 +11,7 @@ _ROOT = os.path.dirname(_PKG)
 CSRC = os.path.join(_PKG, "csrc")
 LIBDIR = os.path.join(_PKG, "lib")
 LIBPATH = os.path.join(LIBDIR, "libspblas_gfx950.so")
-SOURCES = ["handle.hip", "spmv.hip", "spmv_sliced.hip", "spmm.hip", "spgemm.hip", "transpose.hip", "sptrsv.hip", "multigpu.hip"]
+SOURCES = ["handle.hip", "spmv.hip", "spmv_sliced.hip", "spmv_hot.hip", "spmm.hip", "spgemm.hip", "transpose.hip", "sptrsv.hip", "multigpu.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
          "-Wall", "-Wno-unused-function", "-I", os.path.join(_ROOT, "include"), "-I", CSRC]
 
@@ -50,7 +50,7 @@ def build(force=False, verbose=False):
             print(r.stderr)
         return obj
 
-    with ThreadPoolExecutor(max_workers=6) as ex:
+    with ThreadPoolExecutor(max_workers=8) as ex:
         objs = list(ex.map(compile_one, SOURCES))
     r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIBPATH] + objs,
                        capture_output=True, text=True)

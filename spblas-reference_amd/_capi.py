@@ -54,6 +54,7 @@ PROTOTYPES = [
     ("spblas_gfx950_plan_destroy", c_int, [c_void_p, c_void_p]),
     ("spblas_gfx950_plan_info", c_int, [c_void_p, ctypes.POINTER(c_i64)]),
     ("spblas_gfx950_plan_info_sliced", c_int, [c_void_p, ctypes.POINTER(c_i64)]),
+    ("spblas_gfx950_plan_info_hot", c_int, [c_void_p, ctypes.POINTER(c_i64)]),
     ("spblas_gfx950_spmv", c_int,
      [c_void_p, c_void_p, c_int, c_i64, c_i64, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
       c_void_p, c_int, c_int]),

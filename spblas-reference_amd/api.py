@@ -324,6 +324,11 @@ class _Plan:
         d["nt_product_stores"] = (bits >> 2) & 1  # the expand stores its products with the non-temporal hint
         d["store_trial"] = (bits >> 3) & 1  # THIS plan timed both store flavours (opt-in: OPT_STORE_TRIAL = 2 on the handle or SPBLAS_GFX950_PB_NT=-2)
         d["auto_trial"] = bits & 1
+        if (bits >> 4) & 1:  # hot-column split (csrc/spmv_hot.hip): the tile numbers above are those of A_rest
+            hot = (ctypes.c_int64 * 6)()
+            check(_capi.lib().spblas_gfx950_plan_info_hot(self.plan, hot), "spblas_gfx950_plan_info_hot")
+            d["hot_split"] = dict(zip(("hot_columns", "hot_entries", "hot_rows", "hot_long_rows", "tiled_entries",
+                                       "tiled_device_bytes"), list(hot)))
         if d["store_trial"] and not d["auto_trial"]:  # (the two time slots carry AUTO's trial when both ran)
             d["store_trial_ns"] = {"plain": d.pop("trial_rowblock_ns"), "non_temporal": d.pop("trial_sliced_ns")}
             d["trial_rowblock_ns"] = d["trial_sliced_ns"] = 0

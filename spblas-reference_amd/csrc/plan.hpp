@@ -16,6 +16,7 @@ struct spblas_gfx950_plan_s {
   // ROWBLOCK: nnz windows of `win` entries; win_row[w] = first row whose start
   // offset is >= w*win (w = 0..nwin), win_row[nwin] = m.
   int win = 0;
+  int win_req = 0;  // > 0: window length asked for by the builder (the hot-column part of a split plan: 256)
   int64_t nwin = 0;
   int32_t* win_row = nullptr;
   // rows longer than `win` are split across the windows they cover
@@ -120,6 +121,25 @@ struct spblas_gfx950_plan_s {
   void* mm_long_part = nullptr;          // T[n_long * mm_long_parts * n] partial rows of the long rows (grown on demand)
   int64_t mm_long_cap = 0;               // elements held by mm_long_part
   int mm_long_parts = 1;
+
+  // Hot-column split (spmv_hot.hip): the entries in the K most referenced columns live in A_hot (row order, 16-bit index
+  // into hot_cols[], over the rows that have such entries) and are multiplied straight out of LDS; the others form the CSR
+  // matrix A_rest, which carries the tiled plan.  Both are plans of their own (is_child: never split again, never handed out).
+  spblas_gfx950_plan_s* hot_plan = nullptr;   // window partition / long rows / partials of A_hot (ROWBLOCK structures)
+  spblas_gfx950_plan_s* rest_plan = nullptr;  // SLICED plan of A_rest
+  int is_child = 0;
+  int hot_k = 0;                 // hot columns
+  int64_t hot_nnz = 0, hot_m = 0;  // entries / rows of A_hot
+  int32_t* hot_cols = nullptr;   // [hot_k] their numbers, ascending
+  uint16_t* hot_col = nullptr;   // [hot_nnz] index into hot_cols
+  void* hot_val = nullptr;       // T[hot_nnz]
+  int32_t* hot_src = nullptr;    // [hot_nnz] position in the caller's arrays
+  void* hot_rowptr = nullptr;    // O[hot_m + 1]
+  int32_t* hot_rows = nullptr;   // [hot_m] row of y
+  void* rest_rowptr = nullptr;   // O[m + 1]
+  int32_t* rest_col = nullptr;   // [nnz - hot_nnz]
+  void* rest_val = nullptr;      // T[nnz - hot_nnz]
+  int32_t* rest_src = nullptr;   // [nnz - hot_nnz] position in the caller's arrays
 
   size_t device_bytes = 0;
 };

@@ -384,6 +384,7 @@ int spmv_sliced_build(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const 
 int spmv_sliced_update(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const void* values);
 void spmv_sliced_free(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl);
 void spmm_plan_free(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl);
+int spmv_hot_rows(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const void* alpha, const void* x, void* y);
 
 template <typename T, typename O>
 static int spmv_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, int op, int64_t m, int64_t n,
@@ -444,7 +445,8 @@ static int plan_build(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, int al
   hipStream_t s = h->stream;
   const O* rowptr = static_cast<const O*>(pl->rowptr);
   const int64_t m = pl->m, nnz = pl->nnz;
-  pl->win = pl->value_type == SPBLAS_GFX950_F32 ? window_of<float>::value : window_of<double>::value;
+  pl->win = pl->win_req > 0 ? pl->win_req
+                            : pl->value_type == SPBLAS_GFX950_F32 ? window_of<float>::value : window_of<double>::value;
   pl->nwin = nnz / pl->win + 1;
   pl->vector_lpr = pick_lpr(m, nnz);
   const size_t tsz = pl->value_type == SPBLAS_GFX950_F32 ? 4 : 8;
@@ -495,6 +497,24 @@ static int plan_build(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, int al
   }
   pl->alg = alg;
   return SPBLAS_GFX950_STATUS_SUCCESS;
+}
+
+// for the builders of composite plans (spmv_hot.hip): the row statistics / window partition of one CSR matrix ...
+int spmv_plan_structures(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, int alg_req) {
+  return pl->offset_type == SPBLAS_GFX950_I32 ? plan_build<int32_t>(h, pl, alg_req) : plan_build<int64_t>(h, pl, alg_req);
+}
+// ... and the end of a plan they own: everything it holds, then the object
+void spmv_plan_release(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl) {
+  if (!pl)
+    return;
+  hipStream_t s = h->stream;
+  dev_free(pl->win_row, s);
+  dev_free(pl->long_rows, s);
+  dev_free(pl->part_head, s);
+  dev_free(pl->part_tail, s);
+  spmv_sliced_free(h, pl);
+  spmm_plan_free(h, pl);
+  delete pl;
 }
 
 // AUTO considers the sliced re-tiling only when x approaches an XCD's 4 MiB L2 (measured
@@ -871,13 +891,7 @@ int spblas_gfx950_plan_destroy(spblas_gfx950_handle_t handle, spblas_gfx950_plan
     }
     (void) hipGetLastError();
   }
-  dev_free(plan->win_row, s);
-  dev_free(plan->long_rows, s);
-  dev_free(plan->part_head, s);
-  dev_free(plan->part_tail, s);
-  spmv_sliced_free(handle, plan);
-  spmm_plan_free(handle, plan);
-  delete plan;
+  spmv_plan_release(handle, plan);
   return SPBLAS_GFX950_STATUS_SUCCESS;
 }
 
@@ -890,12 +904,13 @@ int spblas_gfx950_plan_info(spblas_gfx950_plan_t plan, int64_t info[12]) {
   info[3] = plan->n_long;
   info[4] = plan->max_row_len;
   info[5] = (int64_t) plan->device_bytes;
-  info[6] = plan->n_slices;
+  const spblas_gfx950_plan_s* tp = plan->rest_plan ? plan->rest_plan : plan;  // the tiles of a split plan are A_rest's
+  info[6] = tp->n_slices;
   info[7] = plan->empty_rows;
-  info[8] = plan->rows_per_blk;
-  info[9] = plan->bin_aligned;
-  info[10] = plan->n_xitems;
-  info[11] = plan->n_ritems;
+  info[8] = tp->rows_per_blk;
+  info[9] = tp->bin_aligned;
+  info[10] = tp->n_xitems;
+  info[11] = tp->n_ritems;
   return SPBLAS_GFX950_STATUS_SUCCESS;
 }
 
@@ -903,21 +918,36 @@ int spblas_gfx950_plan_info_sliced(spblas_gfx950_plan_t plan, int64_t info[12]) 
   if (!plan || !info)
     return SPBLAS_GFX950_STATUS_INVALID_POINTER;
   const bool sl = plan->alg == SPBLAS_GFX950_SPMV_SLICED;
-  info[0] = sl ? plan->n_rblk : 0;
-  info[1] = sl && plan->s_binrow ? 1 : 0;
-  info[2] = sl ? plan->a_blocks : 0;
-  info[3] = sl ? plan->p_blocks : 0;
-  info[4] = sl ? plan->s_placed : 0;
-  info[5] = sl && plan->hub_len > 0 ? plan->n_hub : 0;
-  info[6] = sl ? plan->hub_len : 0;
-  info[7] = sl ? plan->n_ksplit : 0;
-  info[8] = sl ? plan->s_m : 0;
-  // bit 0: AUTO ran its trial, bit 1: one-byte row codes, bit 2: non-temporal product stores, bit 3: this plan ran the store trial
-  info[9] = (plan->trial_ms[0] > 0.f ? 1 : 0) | (sl && plan->enc8 ? 2 : 0) | (sl && plan->nt_products ? 4 : 0) |
-            (plan->store_trial_ms[0] > 0.f ? 8 : 0);
+  const spblas_gfx950_plan_s* tp = plan->rest_plan ? plan->rest_plan : plan;  // the tiles of a split plan are A_rest's
+  info[0] = sl ? tp->n_rblk : 0;
+  info[1] = sl && tp->s_binrow ? 1 : 0;
+  info[2] = sl ? tp->a_blocks : 0;
+  info[3] = sl ? tp->p_blocks : 0;
+  info[4] = sl ? tp->s_placed : 0;
+  info[5] = sl && tp->hub_len > 0 ? tp->n_hub : 0;
+  info[6] = sl ? tp->hub_len : 0;
+  info[7] = sl ? tp->n_ksplit : 0;
+  info[8] = sl ? tp->s_m : 0;
+  // bit 0: AUTO ran its trial, bit 1: one-byte row codes, bit 2: non-temporal product stores, bit 3: this plan ran the store
+  // trial, bit 4: hot-column split (spblas_gfx950_plan_info_hot has its numbers)
+  info[9] = (plan->trial_ms[0] > 0.f ? 1 : 0) | (sl && tp->enc8 ? 2 : 0) | (sl && plan->nt_products ? 4 : 0) |
+            (plan->store_trial_ms[0] > 0.f ? 8 : 0) | (sl && plan->rest_plan ? 16 : 0);
   const float* tms = plan->trial_ms[0] > 0.f ? plan->trial_ms : plan->store_trial_ms;  // AUTO's times, else the store trial's
   info[10] = (int64_t) (tms[0] * 1e6f);
   info[11] = (int64_t) (tms[1] * 1e6f);
+  return SPBLAS_GFX950_STATUS_SUCCESS;
+}
+
+int spblas_gfx950_plan_info_hot(spblas_gfx950_plan_t plan, int64_t info[6]) {
+  if (!plan || !info)
+    return SPBLAS_GFX950_STATUS_INVALID_POINTER;
+  const bool on = plan->alg == SPBLAS_GFX950_SPMV_SLICED && plan->hot_plan && plan->rest_plan;
+  info[0] = on ? plan->hot_k : 0;                  // hot columns (their x values live in LDS)
+  info[1] = on ? plan->hot_nnz : 0;                // entries multiplied in row order out of LDS
+  info[2] = on ? plan->hot_m : 0;                  // rows that have such entries
+  info[3] = on ? plan->hot_plan->n_long : 0;       // ... longer than a window of 256 entries
+  info[4] = on ? plan->rest_plan->nnz : 0;         // entries left to the tiled plan
+  info[5] = on ? (int64_t) plan->rest_plan->device_bytes : 0;
   return SPBLAS_GFX950_STATUS_SUCCESS;
 }
 

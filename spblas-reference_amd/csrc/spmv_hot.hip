@@ -1,0 +1,661 @@
+// Hot-column split of the SLICED SpMV plan (round 4) -- the same maths as spmv_sliced.hip,
+//   y <- alpha * A x + beta * y     (/root/reference/include/spblas/algorithms/multiply_impl.hpp:33-53),
+// for matrices whose entries concentrate in few COLUMNS (power-law graphs: on the R-MAT scale-24 matrix of BASELINE cfg4
+// the 12 288 most referenced of 16.8 M columns hold 27 % of the entries, tools/rmat_stats.py).
+//
+// The tiled plan moves 28 B per stored fp64 entry by design (value + 16-bit column in, product out; product + row word
+// in): a gather from x is only cheap out of LDS and an entry cannot be ordered by column slice and by row at once.  For
+// the hot columns it can: their x values -- ONE slice, whatever their numbers are -- fit the LDS of every CU at the same
+// time, so the entries that reference them are multiplied in ROW order, straight into y, at 10 B per entry:
+//
+//   inspect   sample the column indices (1 in 16) into a histogram, take the K most referenced columns (K = what LDS
+//             holds next to the product staging: 12 288 fp64 / 32 768 fp32) if they cover >= 15 % of the sample, and
+//             split A once, stably, into A_hot (values, 16-bit index into the hot list, row offsets) and A_rest (an
+//             ordinary CSR matrix with the remaining entries), each with the source position of every entry (for
+//             update_values).  A_rest gets the regular tiled plan; A_hot the nnz-window row partition of the row-block
+//             plan (spmv.hip: plan_build) with windows of 256 entries.
+//   multiply  the tiled plan of A_rest with the caller's alpha and beta (it writes every row of y), then
+//             pb_hot_rows_kernel: y += alpha * A_hot x over the rows that HAVE hot entries (A_hot is kept over those rows
+//             only, hot_rows[] names them: a window never owns more rows than it has entries, however many rows of the
+//             matrix are empty).  One workgroup of 16 wavefronts per CU, the hot x values gathered into LDS once; every
+//             wavefront walks its own windows: products staged in a wave-private LDS strip, a lane group per row sums
+//             them -- the row-block kernel's scheme at wavefront scope, no workgroup barrier after the fill; rows longer
+//             than a window go through per-window partials and pb_hot_fixup_kernel.
+//
+// Results: a row's sum is associated differently (tiled part, then the hot part added to it) -- inside the parity bound
+// like every other plan; bit-reproducible from run to run (no atomics on this path).
+// Chosen by spmv_sliced_build for row-skewed matrices (the ones that get variable-height bins) unless the handle asks for
+// row-range reduces (SPBLAS_GFX950_OPT_BIN_ROW_ALIGN); SPBLAS_GFX950_PB_HOT = 0 / 1 switches it off / forces the attempt,
+// SPBLAS_GFX950_PB_HOT_MIN_PCT the coverage from which the split is taken (default 15).
+#include "common.hpp"
+#include "plan.hpp"
+#include "scan.hpp"
+
+#include <cstdlib>
+#include <new>
+#include <vector>
+
+namespace spb {
+
+int spmv_plan_structures(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, int alg_req);  // spmv.hip
+int spmv_sliced_build(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const void* values, bool auto_mode);
+int spmv_sliced_update(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const void* values);
+int spmv_sliced_exec(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const void* alpha, const void* x,
+                     const void* beta, void* y);
+int spmv_sliced_expand(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const void* x);
+void spmv_sliced_free(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl);
+void spmv_plan_release(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl);  // spmv.hip: everything a plan owns, and the plan
+
+static int hot_env(const char* name, int dflt) {
+  const char* v = std::getenv(name);
+  return v && *v ? std::atoi(v) : dflt;
+}
+
+static constexpr int HOT_WIN = 256;       // entries per window: 64 lanes x 4
+static constexpr int HOT_CAP = 2 * HOT_WIN;
+static constexpr int HOT_THREADS = 1024;  // 16 wavefronts share the hot x values
+static constexpr int HOT_WAVES = HOT_THREADS / 64;
+static constexpr int HOT_LDS = 160 * 1024;
+static constexpr int HOT_HIST = 1024;     // sampled reference counts 0 .. 1022, last bucket = more
+
+template <typename T>
+static constexpr int hot_max_cols() {
+  return (HOT_LDS - HOT_WAVES * HOT_CAP * (int) sizeof(T)) / (int) sizeof(T);  // 12 288 fp64, 32 768 fp32
+}
+
+// ---------------------------------------------------------------------------------------------------------- inspect
+// one entry in 16, at a position inside its group of 16 that changes from group to group (matrices with rows of 16
+// sorted columns would otherwise show the sampler one column range only)
+__global__ __launch_bounds__(256) void hot_sample_kernel(int64_t nnz, const int32_t* __restrict__ colind,
+                                                         int32_t* __restrict__ cnt) {
+  const int64_t g = (int64_t) blockIdx.x * 256 + threadIdx.x;
+  const uint32_t hsh = (uint32_t) g * 2654435761u;
+  const int64_t p = g * 16 + (hsh >> 28);
+  if (p < nnz)
+    atomicAdd(cnt + colind[p], 1);
+}
+
+// hist[c] = columns referenced c times by the sample (c clipped to HOT_HIST - 1), mass[c] = sum of their counts
+__global__ __launch_bounds__(256) void hot_hist_kernel(int64_t n, const int32_t* __restrict__ cnt,
+                                                       unsigned long long* __restrict__ hist,
+                                                       unsigned long long* __restrict__ mass) {
+  __shared__ unsigned int sh[HOT_HIST];
+  __shared__ unsigned long long sm[HOT_HIST];
+  for (int i = threadIdx.x; i < HOT_HIST; i += 256) {
+    sh[i] = 0;
+    sm[i] = 0;
+  }
+  __syncthreads();
+  for (int64_t c = (int64_t) blockIdx.x * 256 + threadIdx.x; c < n; c += (int64_t) gridDim.x * 256) {
+    const int v = cnt[c];
+    if (v > 0) {
+      const int b = v < HOT_HIST - 1 ? v : HOT_HIST - 1;
+      atomicAdd(&sh[b], 1u);
+      atomicAdd(&sm[b], (unsigned long long) v);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < HOT_HIST; i += 256)
+    if (sh[i]) {
+      atomicAdd(&hist[i], (unsigned long long) sh[i]);
+      atomicAdd(&mass[i], sm[i]);
+    }
+}
+
+__global__ __launch_bounds__(256) void hot_flag_cols_kernel(int64_t n, const int32_t* __restrict__ cnt, int thr,
+                                                            int32_t* __restrict__ flag) {
+  const int64_t c = (int64_t) blockIdx.x * 256 + threadIdx.x;
+  if (c < n)
+    flag[c] = cnt[c] >= thr;
+}
+
+// pos = exclusive scan of the column flags: colmap[c] = index in the hot list or -1, hot_cols[index] = c (ascending)
+__global__ __launch_bounds__(256) void hot_colmap_kernel(int64_t n, const int32_t* __restrict__ pos,
+                                                         int32_t* __restrict__ colmap, int32_t* __restrict__ hot_cols) {
+  const int64_t c = (int64_t) blockIdx.x * 256 + threadIdx.x;
+  if (c >= n)
+    return;
+  const int32_t i = pos[c];
+  const bool hot = pos[c + 1] != i;
+  colmap[c] = hot ? i : -1;
+  if (hot)
+    hot_cols[i] = (int32_t) c;
+}
+
+__global__ __launch_bounds__(256) void hot_flag_entries_kernel(int64_t nnz, const int32_t* __restrict__ colind,
+                                                               const int32_t* __restrict__ colmap,
+                                                               int32_t* __restrict__ flag) {
+  const int64_t p = (int64_t) blockIdx.x * 256 + threadIdx.x;
+  if (p < nnz)
+    flag[p] = colmap[stream_load(colind + p)] >= 0;
+}
+
+// hotpos = exclusive scan of the entry flags (hotpos[nnz] = hot entries): a stable two-way split in one pass
+template <typename T>
+__global__ __launch_bounds__(256) void hot_split_kernel(int64_t nnz, const int32_t* __restrict__ colind,
+                                                        const T* __restrict__ values, const int32_t* __restrict__ colmap,
+                                                        const int32_t* __restrict__ hotpos, T* __restrict__ hot_val,
+                                                        uint16_t* __restrict__ hot_col, int32_t* __restrict__ hot_src,
+                                                        T* __restrict__ rest_val, int32_t* __restrict__ rest_col,
+                                                        int32_t* __restrict__ rest_src) {
+  const int64_t p = (int64_t) blockIdx.x * 256 + threadIdx.x;
+  if (p >= nnz)
+    return;
+  const int32_t c = stream_load(colind + p);
+  const T v = stream_load(values + p);
+  const int32_t hp = hotpos[p];
+  const int32_t k = colmap[c];
+  if (k >= 0) {
+    hot_val[hp] = v;
+    hot_col[hp] = (uint16_t) k;
+    hot_src[hp] = (int32_t) p;
+  } else {
+    const int64_t rp = p - hp;
+    rest_val[rp] = v;
+    rest_col[rp] = c;
+    rest_src[rp] = (int32_t) p;
+  }
+}
+
+// rest_rowptr[r] = entries of A_rest before row r; rowflag[r] = row r has hot entries
+template <typename O>
+__global__ __launch_bounds__(256) void hot_rowptr_kernel(int64_t m, const O* __restrict__ rowptr,
+                                                         const int32_t* __restrict__ hotpos, O* __restrict__ rest_rowptr,
+                                                         int32_t* __restrict__ rowflag) {
+  const int64_t r = (int64_t) blockIdx.x * 256 + threadIdx.x;
+  if (r > m)
+    return;
+  const O p = rowptr[r];
+  const O hp = (O) hotpos[p];
+  rest_rowptr[r] = p - hp;
+  if (r < m)
+    rowflag[r] = hotpos[rowptr[r + 1]] != (int32_t) hp;
+}
+
+// rowpos = exclusive scan of rowflag: A_hot over the rows that have hot entries only
+template <typename O>
+__global__ __launch_bounds__(256) void hot_compact_rows_kernel(int64_t m, const O* __restrict__ rowptr,
+                                                               const int32_t* __restrict__ hotpos,
+                                                               const int32_t* __restrict__ rowpos, int64_t n_hot,
+                                                               O* __restrict__ hot_rowptr, int32_t* __restrict__ hot_rows) {
+  const int64_t r = (int64_t) blockIdx.x * 256 + threadIdx.x;
+  if (r > m)
+    return;
+  const int32_t i = rowpos[r];
+  if (r == m) {
+    hot_rowptr[i] = (O) n_hot;
+    return;
+  }
+  if (rowpos[r + 1] != i) {
+    hot_rowptr[i] = (O) hotpos[rowptr[r]];
+    hot_rows[i] = (int32_t) r;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void hot_gather_values_kernel(int64_t cnt, const int32_t* __restrict__ src,
+                                                                const T* __restrict__ values, T* __restrict__ out) {
+  const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
+  if (i < cnt)
+    out[i] = values[src[i]];
+}
+
+// ---------------------------------------------------------------------------------------------------------- multiply
+template <typename T>
+__device__ __forceinline__ void hot_load4(const T* p, T (&out)[4]);
+template <>
+__device__ __forceinline__ void hot_load4<float>(const float* p, float (&out)[4]) {
+  const f32x4 v = stream_load(reinterpret_cast<const f32x4*>(p));
+  out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
+}
+template <>
+__device__ __forceinline__ void hot_load4<double>(const double* p, double (&out)[4]) {
+  const f64x2 a = stream_load(reinterpret_cast<const f64x2*>(p));
+  const f64x2 b = stream_load(reinterpret_cast<const f64x2*>(p) + 1);
+  out[0] = a.x; out[1] = a.y; out[2] = b.x; out[3] = b.y;
+}
+typedef unsigned short hot_u16x4 __attribute__((ext_vector_type(4)));
+
+// sum of val[p] * xs[col[p]] over [lo, hi) by one wavefront; valid in every lane
+template <typename T, typename O>
+__device__ __forceinline__ T hot_wave_dot(O lo, O hi, const uint16_t* __restrict__ col, const T* __restrict__ val,
+                                          const T* xs, int lane) {
+  T s = 0;
+  for (O p = lo + (O) lane; p < hi; p += 64)
+    s += stream_load(val + p) * xs[stream_load(col + p)];
+  return group_sum_c<64>(s);
+}
+
+// Window w (HOT_WIN entries of A_hot) owns the rows of A_hot whose first entry lies in it (every row of A_hot has entries,
+// so at most HOT_WIN of them); y[hot_rows[r]] += alpha * sum.  A row no longer than a window is summed entirely by its owner (it ends before
+// the end of the next window, hence 2 * HOT_WIN staging slots); a longer one leaves a partial per window it covers
+// (part_tail where it starts, part_head in the later ones) for pb_hot_fixup_kernel.  spmv.hip: spmv_rowblock_kernel is the
+// same scheme at workgroup scope with x in global memory.
+template <typename T, typename O, bool HAS_LONG>
+__global__ __launch_bounds__(HOT_THREADS) void pb_hot_rows_kernel(int64_t nnz, int64_t nwin, const O* __restrict__ rowptr,
+                                                                  const uint16_t* __restrict__ col,
+                                                                  const T* __restrict__ val,
+                                                                  const int32_t* __restrict__ hot_cols, int K,
+                                                                  const T* __restrict__ x, T* __restrict__ y, T alpha,
+                                                                  const int32_t* __restrict__ hot_rows,
+                                                                  const int32_t* __restrict__ win_row,
+                                                                  T* __restrict__ part_head, T* __restrict__ part_tail) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  T* xs = reinterpret_cast<T*>(smem);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  T* prod = xs + hot_max_cols<T>() + wave * HOT_CAP;
+  for (int i = tid; i < K; i += HOT_THREADS)
+    xs[i] = x[hot_cols[i]];
+  __syncthreads();
+
+  const int64_t stride = (int64_t) gridDim.x * HOT_WAVES;
+  int64_t w = (int64_t) blockIdx.x * HOT_WAVES + wave;
+  // (window bounds one iteration ahead: the chain win_row -> rowptr -> entries would otherwise be paid per window)
+  int nb = 0, ne = 0;
+  O na = 0, nend = 0;
+  if (w < nwin) {
+    nb = win_row[w];
+    ne = win_row[w + 1];
+    na = rowptr[nb];
+    nend = rowptr[ne];
+  }
+  for (; w < nwin; w += stride) {
+    const int r_begin = nb;
+    int r_end = ne;
+    const O a = na;
+    O e = nend;
+    if (w + stride < nwin) {
+      nb = win_row[w + stride];
+      ne = win_row[w + stride + 1];
+      na = rowptr[nb];
+      nend = rowptr[ne];
+    }
+    const O wlo = (O) (w * HOT_WIN);
+    const O whi = (O) ((w + 1) * HOT_WIN < nnz ? (w + 1) * HOT_WIN : nnz);
+    if (HAS_LONG) {
+      if (r_begin > 0 && a > wlo) {  // a long row entering this window from an earlier one
+        const O hs = rowptr[r_begin - 1];
+        if (a - hs > (O) HOT_WIN) {
+          const T s = hot_wave_dot<T, O>(wlo, a < whi ? a : whi, col, val, xs, lane);
+          if (lane == 0)
+            part_head[w] = s;
+        }
+      }
+      if (r_end > r_begin) {  // a long row starting in this window (necessarily the last owned row)
+        const O ls = rowptr[r_end - 1];
+        if (e - ls > (O) HOT_WIN) {
+          const T s = hot_wave_dot<T, O>(ls, whi, col, val, xs, lane);
+          if (lane == 0)
+            part_tail[w] = s;
+          r_end -= 1;
+          e = ls;
+        }
+      }
+    }
+    const O a_al = a & ~(O) 3;  // >= wlo: HOT_WIN is a multiple of 4
+    const int total = (int) (e - a_al);
+    const int nrows = r_end - r_begin;
+    int lpr = 1;
+    while (lpr < 64 && nrows * lpr * 2 <= 64)
+      lpr <<= 1;
+    const int grp = lane / lpr, lig = lane % lpr, ngrp = 64 / lpr;
+    // the first round's row bounds travel with the entry loads
+    const int r0 = r_begin + grp;
+    O s0 = 0, s1 = 0;
+    int yr = 0;
+    if (r0 < r_end) {
+      s0 = rowptr[r0];
+      s1 = rowptr[r0 + 1];
+      yr = hot_rows[r0];
+    }
+    T v[2][4];
+    hot_u16x4 c[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int q = (it * 64 + lane) * 4;
+      const O p = a_al + (O) q;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        v[it][j] = T(0);
+        c[it][j] = 0;
+      }
+      if (q < total) {
+        if ((int64_t) p + 4 <= nnz) {
+          hot_load4<T>(val + p, v[it]);
+          c[it] = stream_load(reinterpret_cast<const hot_u16x4*>(col + p));
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if ((int64_t) p + j < nnz) {
+              v[it][j] = stream_load(val + p + j);
+              c[it][j] = stream_load(col + p + j);
+            }
+        }
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int q = (it * 64 + lane) * 4;
+      if (q < total) {
+        const O p = a_al + (O) q;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const bool in = (p + j >= a) && (p + j < e);
+          prod[q + j] = in ? v[it][j] * xs[c[it][j]] : T(0);
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wavefront's products have landed in its strip
+    for (int r = r0; r < r_end; r += ngrp) {
+      if (r != r0) {
+        s0 = rowptr[r];
+        s1 = rowptr[r + 1];
+        yr = hot_rows[r];
+      }
+      T s = 0;
+      for (int q = (int) (s0 - a_al) + lig; q < (int) (s1 - a_al); q += lpr)
+        s += prod[q];
+      s = group_sum(s, lpr);
+      if (lig == 0)
+        y[yr] += alpha * s;
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // the strip is read out before the next window overwrites it
+  }
+}
+
+// one wavefront per long row: y[hot_rows[r]] += alpha * (tail + heads)
+template <typename T, typename O>
+__global__ __launch_bounds__(64) void pb_hot_fixup_kernel(int64_t n_long, const int32_t* __restrict__ long_rows,
+                                                          const O* __restrict__ rowptr, const T* __restrict__ part_head,
+                                                          const T* __restrict__ part_tail, T* __restrict__ y, T alpha,
+                                                          const int32_t* __restrict__ hot_rows) {
+  const int64_t i = blockIdx.x;
+  if (i >= n_long)
+    return;
+  const int r = long_rows[i];
+  const int64_t p0 = (int64_t) rowptr[r], p1 = (int64_t) rowptr[r + 1];
+  const int64_t w0 = p0 / HOT_WIN, w1 = (p1 - 1) / HOT_WIN;
+  T s = 0;
+  for (int64_t w = w0 + 1 + threadIdx.x; w <= w1; w += 64)
+    s += part_head[w];
+  s = group_sum_c<64>(s);
+  if (threadIdx.x == 0) {
+    s += part_tail[w0];
+    y[hot_rows[r]] += alpha * s;
+  }
+}
+
+template <typename T, typename O>
+static int hot_launch(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const void* alpha_p, const void* x, void* y) {
+  spblas_gfx950_plan_s* hp = pl->hot_plan;
+  hipStream_t s = h->stream;
+  const T alpha = *static_cast<const T*>(alpha_p);
+  const int cus = h->num_cus > 0 ? h->num_cus : 256;
+  const int64_t grid = cdiv(hp->nwin, HOT_WAVES) < cus ? cdiv(hp->nwin, HOT_WAVES) : cus;
+  const O* rowptr = static_cast<const O*>(hp->rowptr);
+  hp->last_stream = s;
+  hp->used = true;
+  if (hp->n_long > 0) {
+    hipLaunchKernelGGL((pb_hot_rows_kernel<T, O, true>), dim3((unsigned) grid), dim3(HOT_THREADS), HOT_LDS, s, hp->nnz, hp->nwin,
+                       rowptr, pl->hot_col, static_cast<const T*>(pl->hot_val), pl->hot_cols, pl->hot_k,
+                       static_cast<const T*>(x), static_cast<T*>(y), alpha, pl->hot_rows, hp->win_row,
+                       static_cast<T*>(hp->part_head), static_cast<T*>(hp->part_tail));
+    hipLaunchKernelGGL((pb_hot_fixup_kernel<T, O>), dim3((unsigned) hp->n_long), dim3(64), 0, s, hp->n_long, hp->long_rows,
+                       rowptr, static_cast<const T*>(hp->part_head), static_cast<const T*>(hp->part_tail), static_cast<T*>(y),
+                       alpha, pl->hot_rows);
+  } else {
+    hipLaunchKernelGGL((pb_hot_rows_kernel<T, O, false>), dim3((unsigned) grid), dim3(HOT_THREADS), HOT_LDS, s, hp->nnz, hp->nwin,
+                       rowptr, pl->hot_col, static_cast<const T*>(pl->hot_val), pl->hot_cols, pl->hot_k,
+                       static_cast<const T*>(x), static_cast<T*>(y), alpha, pl->hot_rows, hp->win_row, static_cast<T*>(nullptr),
+                       static_cast<T*>(nullptr));
+  }
+  SPB_HIP(hipGetLastError());
+  return SPBLAS_GFX950_STATUS_SUCCESS;
+}
+
+// y += alpha * A_hot x (the second half of a multiply with a split plan: the tiled plan of A_rest has written every row)
+int spmv_hot_rows(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const void* alpha, const void* x, void* y) {
+  const bool o32 = pl->offset_type == SPBLAS_GFX950_I32;
+  if (pl->value_type == SPBLAS_GFX950_F32)
+    return o32 ? hot_launch<float, int32_t>(h, pl, alpha, x, y) : hot_launch<float, int64_t>(h, pl, alpha, x, y);
+  return o32 ? hot_launch<double, int32_t>(h, pl, alpha, x, y) : hot_launch<double, int64_t>(h, pl, alpha, x, y);
+}
+
+int spmv_hot_exec(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const void* alpha, const void* x, const void* beta,
+                  void* y) {
+  pl->last_stream = h->stream;
+  pl->used = true;
+  pl->rest_plan->nt_products = pl->nt_products;
+  const int rc = spmv_sliced_exec(h, pl->rest_plan, alpha, x, beta, y);
+  if (rc)
+    return rc;
+  return spmv_hot_rows(h, pl, alpha, x, y);
+}
+
+// ---------------------------------------------------------------------------------------------------------- build
+void spmv_hot_free(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl) {
+  hipStream_t s = h->stream;
+  if (pl->hot_plan) {
+    spmv_plan_release(h, pl->hot_plan);
+    pl->hot_plan = nullptr;
+  }
+  if (pl->rest_plan) {
+    spmv_plan_release(h, pl->rest_plan);
+    pl->rest_plan = nullptr;
+  }
+  dev_free(pl->hot_cols, s);
+  dev_free(pl->hot_col, s);
+  dev_free(pl->hot_val, s);
+  dev_free(pl->hot_src, s);
+  dev_free(pl->hot_rowptr, s);
+  dev_free(pl->hot_rows, s);
+  dev_free(pl->rest_rowptr, s);
+  dev_free(pl->rest_col, s);
+  dev_free(pl->rest_val, s);
+  dev_free(pl->rest_src, s);
+  pl->hot_cols = nullptr;
+  pl->hot_col = nullptr;
+  pl->hot_val = pl->rest_val = nullptr;
+  pl->hot_src = pl->rest_src = pl->rest_col = pl->hot_rows = nullptr;
+  pl->hot_rowptr = pl->rest_rowptr = nullptr;
+  pl->hot_k = 0;
+  pl->hot_nnz = 0;
+}
+
+template <typename T, typename O>
+static int hot_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const void* values_p, bool auto_mode) {
+  hipStream_t s = h->stream;
+  const int64_t m = pl->m, n = pl->n, nnz = pl->nnz;
+  const int32_t* colind = pl->colind;
+  const T* values = static_cast<const T*>(values_p);
+  const O* rowptr = static_cast<const O*>(pl->rowptr);
+  int rc;
+  readback_scope rb_scope(h);
+  // temporaries of the inspect, released on every exit path
+  struct guard_t {
+    hipStream_t s;
+    std::vector<void*> p;
+    ~guard_t() {
+      for (void* q : p)
+        dev_free(q, s);
+    }
+    int alloc(void** out, size_t bytes) {
+      const int rc_a = dev_alloc(out, bytes, s);
+      if (rc_a == SPBLAS_GFX950_STATUS_SUCCESS && *out)
+        p.push_back(*out);
+      return rc_a;
+    }
+  } g{s, {}};
+  int32_t *cnt = nullptr, *pos = nullptr;
+  unsigned long long* hist = nullptr;
+  long long* partials = nullptr;
+  const int64_t scan_len = nnz > n ? nnz : n;
+  if ((rc = g.alloc((void**) &cnt, (size_t) n * 4)) || (rc = g.alloc((void**) &pos, (size_t) (scan_len + 1) * 4)) ||
+      (rc = g.alloc((void**) &hist, (size_t) 2 * HOT_HIST * sizeof(unsigned long long))) ||
+      (rc = g.alloc((void**) &partials, (size_t) (cdiv(scan_len, 2048) + 2) * sizeof(long long))))
+    return rc;
+  SPB_HIP(hipMemsetAsync(cnt, 0, (size_t) n * 4, s));
+  SPB_HIP(hipMemsetAsync(hist, 0, (size_t) 2 * HOT_HIST * sizeof(unsigned long long), s));
+  const int64_t nsamp = cdiv(nnz, 16);
+  hipLaunchKernelGGL(hot_sample_kernel, dim3((unsigned) cdiv(nsamp, 256)), dim3(256), 0, s, nnz, colind, cnt);
+  hipLaunchKernelGGL(hot_hist_kernel, dim3((unsigned) (cdiv(n, 256) < 2048 ? cdiv(n, 256) : 2048)), dim3(256), 0, s, n, cnt, hist,
+                     hist + HOT_HIST);
+  std::vector<unsigned long long> h_hist((size_t) 2 * HOT_HIST);
+  if ((rc = readback_add(h, h_hist.data(), hist, h_hist.size() * sizeof(unsigned long long))) || (rc = readback_flush(h)))
+    return rc;
+  SPB_HIP(hipGetLastError());
+  // the smallest count threshold (>= 2 sampled references) whose columns still fit the LDS
+  const int kmax = hot_max_cols<T>();
+  unsigned long long cols = 0, mass = 0, sampled = 0;
+  for (int c = 1; c < HOT_HIST; ++c)
+    sampled += h_hist[(size_t) HOT_HIST + c];
+  int thr = HOT_HIST;  // nothing
+  for (int c = HOT_HIST - 1; c >= 2; --c) {
+    if (cols + h_hist[(size_t) c] > (unsigned long long) kmax)
+      break;
+    cols += h_hist[(size_t) c];
+    mass += h_hist[(size_t) HOT_HIST + c];
+    thr = c;
+  }
+  const int min_pct = hot_env("SPBLAS_GFX950_PB_HOT_MIN_PCT", 15);
+  if (cols == 0 || sampled == 0 || mass * 100 < sampled * (unsigned long long) min_pct)
+    return SPBLAS_GFX950_STATUS_NOT_SUPPORTED;  // no set of columns that small carries enough of the matrix
+  // hot list (ascending columns) and the column -> hot index map
+  int32_t* colmap = nullptr;
+  if ((rc = g.alloc((void**) &colmap, (size_t) n * 4)) || (rc = dev_alloc((void**) &pl->hot_cols, (size_t) cols * 4, s)))
+    return rc;
+  hipLaunchKernelGGL(hot_flag_cols_kernel, dim3((unsigned) cdiv(n, 256)), dim3(256), 0, s, n, cnt, thr, pos);
+  (void) scan_counts_i32(s, n, pos, partials);
+  hipLaunchKernelGGL(hot_colmap_kernel, dim3((unsigned) cdiv(n, 256)), dim3(256), 0, s, n, pos, colmap, pl->hot_cols);
+  pl->hot_k = (int) cols;
+  // stable split of the entries
+  hipLaunchKernelGGL(hot_flag_entries_kernel, dim3((unsigned) cdiv(nnz, 256)), dim3(256), 0, s, nnz, colind, colmap, pos);
+  long long* total_dev = scan_counts_i32(s, nnz, pos, partials);
+  long long n_hot = 0;
+  if ((rc = readback_add(h, &n_hot, total_dev, sizeof(n_hot))) || (rc = readback_flush(h)))
+    return rc;
+  SPB_HIP(hipGetLastError());
+  const int64_t n_rest = nnz - (int64_t) n_hot;
+  if (n_hot * 100 < nnz * (long long) min_pct || n_rest < 1)
+    return SPBLAS_GFX950_STATUS_NOT_SUPPORTED;  // (the sample promised more than the matrix holds)
+  pl->hot_nnz = (int64_t) n_hot;
+  if ((rc = dev_alloc(&pl->hot_val, (size_t) (n_hot + 8) * sizeof(T), s)) ||
+      (rc = dev_alloc((void**) &pl->hot_col, (size_t) (n_hot + 8) * 2, s)) ||
+      (rc = dev_alloc((void**) &pl->hot_src, (size_t) n_hot * 4, s)) ||
+      (rc = dev_alloc(&pl->rest_rowptr, (size_t) (m + 1) * sizeof(O), s)) ||
+      (rc = dev_alloc(&pl->rest_val, (size_t) n_rest * sizeof(T), s)) ||
+      (rc = dev_alloc((void**) &pl->rest_col, (size_t) n_rest * 4, s)) ||
+      (rc = dev_alloc((void**) &pl->rest_src, (size_t) n_rest * 4, s)))
+    return rc;
+  hipLaunchKernelGGL((hot_split_kernel<T>), dim3((unsigned) cdiv(nnz, 256)), dim3(256), 0, s, nnz, colind, values, colmap, pos,
+                     static_cast<T*>(pl->hot_val), pl->hot_col, pl->hot_src, static_cast<T*>(pl->rest_val), pl->rest_col,
+                     pl->rest_src);
+  int32_t *rowflag = nullptr;
+  long long* rpartials = nullptr;
+  if ((rc = g.alloc((void**) &rowflag, (size_t) (m + 1) * 4)) ||
+      (rc = g.alloc((void**) &rpartials, (size_t) (cdiv(m, 2048) + 2) * sizeof(long long))))
+    return rc;
+  hipLaunchKernelGGL((hot_rowptr_kernel<O>), dim3((unsigned) cdiv(m + 1, 256)), dim3(256), 0, s, m, rowptr, pos,
+                     static_cast<O*>(pl->rest_rowptr), rowflag);
+  long long* mc_dev = scan_counts_i32(s, m, rowflag, rpartials);
+  long long m_hot = 0;
+  if ((rc = readback_add(h, &m_hot, mc_dev, sizeof(m_hot))) || (rc = readback_flush(h)))
+    return rc;
+  SPB_HIP(hipGetLastError());
+  if (m_hot < 1)
+    return SPBLAS_GFX950_STATUS_NOT_SUPPORTED;
+  if ((rc = dev_alloc(&pl->hot_rowptr, (size_t) (m_hot + 1) * sizeof(O), s)) ||
+      (rc = dev_alloc((void**) &pl->hot_rows, (size_t) m_hot * 4, s)))
+    return rc;
+  hipLaunchKernelGGL((hot_compact_rows_kernel<O>), dim3((unsigned) cdiv(m + 1, 256)), dim3(256), 0, s, m, rowptr, pos, rowflag,
+                     (int64_t) n_hot, static_cast<O*>(pl->hot_rowptr), pl->hot_rows);
+  SPB_HIP(hipGetLastError());
+  // A_hot: the nnz-window row partition (windows of HOT_WIN entries), long-row list and partials of the row-block plan
+  auto* hp = new (std::nothrow) spblas_gfx950_plan_s();
+  if (!hp)
+    return SPBLAS_GFX950_STATUS_ALLOC_FAILED;
+  pl->hot_plan = hp;
+  hp->m = (int64_t) m_hot;
+  hp->n = pl->hot_k;
+  hp->nnz = (int64_t) n_hot;
+  hp->rowptr = pl->hot_rowptr;
+  hp->colind = nullptr;
+  hp->offset_type = pl->offset_type;
+  hp->value_type = pl->value_type;
+  hp->win_req = HOT_WIN;
+  hp->is_child = 1;
+  if ((rc = spmv_plan_structures(h, hp, SPBLAS_GFX950_SPMV_ROWBLOCK)))
+    return rc;
+  // A_rest: an ordinary CSR matrix for the tiled plan
+  auto* rp = new (std::nothrow) spblas_gfx950_plan_s();
+  if (!rp)
+    return SPBLAS_GFX950_STATUS_ALLOC_FAILED;
+  pl->rest_plan = rp;
+  rp->m = m;
+  rp->n = n;
+  rp->nnz = n_rest;
+  rp->rowptr = pl->rest_rowptr;
+  rp->colind = pl->rest_col;
+  rp->offset_type = pl->offset_type;
+  rp->value_type = pl->value_type;
+  rp->is_child = 1;
+  if ((rc = spmv_plan_structures(h, rp, SPBLAS_GFX950_SPMV_ROWBLOCK)))
+    return rc;
+  if ((rc = spmv_sliced_build(h, rp, pl->rest_val, auto_mode)))
+    return rc;
+  rp->alg = SPBLAS_GFX950_SPMV_SLICED;
+  rp->nt_products = pl->nt_products;
+  pl->s_uncertain = rp->s_uncertain;
+  pl->s_placed = rp->s_placed;
+  pl->values_ptr = values_p;
+  pl->device_bytes += hp->device_bytes + rp->device_bytes + (size_t) cols * 4 + (size_t) n_hot * (sizeof(T) + 6) +
+                      (size_t) n_rest * (sizeof(T) + 8) + (size_t) (m + 1) * sizeof(O) + (size_t) (m_hot + 1) * (sizeof(O) + 4);
+  pl->hot_m = (int64_t) m_hot;
+  SPB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pb_hot_rows_kernel<T, O, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, HOT_LDS));
+  SPB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pb_hot_rows_kernel<T, O, false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, HOT_LDS));
+  return SPBLAS_GFX950_STATUS_SUCCESS;
+}
+
+// Tries the split.  SUCCESS: pl->hot_plan / pl->rest_plan are set and the plan multiplies through spmv_hot_exec.
+// NOT_SUPPORTED: no small set of columns carries enough of the matrix (or the tiled plan declined A_rest): nothing is left
+// behind and the caller builds the ordinary tiled plan.
+int spmv_hot_build(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const void* values, bool auto_mode) {
+  const bool o32 = pl->offset_type == SPBLAS_GFX950_I32;
+  int rc;
+  if (pl->value_type == SPBLAS_GFX950_F32)
+    rc = o32 ? hot_build_typed<float, int32_t>(h, pl, values, auto_mode) : hot_build_typed<float, int64_t>(h, pl, values, auto_mode);
+  else
+    rc = o32 ? hot_build_typed<double, int32_t>(h, pl, values, auto_mode) : hot_build_typed<double, int64_t>(h, pl, values, auto_mode);
+  if (rc != SPBLAS_GFX950_STATUS_SUCCESS)
+    spmv_hot_free(h, pl);
+  return rc;
+}
+
+// the caller's value array changed: both halves take their values again through the source positions of the split
+int spmv_hot_update(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const void* values) {
+  hipStream_t s = h->stream;
+  spblas_gfx950_plan_s* rp = pl->rest_plan;
+  if (pl->value_type == SPBLAS_GFX950_F32) {
+    hipLaunchKernelGGL((hot_gather_values_kernel<float>), dim3((unsigned) cdiv(pl->hot_nnz, 256)), dim3(256), 0, s, pl->hot_nnz,
+                       pl->hot_src, static_cast<const float*>(values), static_cast<float*>(pl->hot_val));
+    hipLaunchKernelGGL((hot_gather_values_kernel<float>), dim3((unsigned) cdiv(rp->nnz, 256)), dim3(256), 0, s, rp->nnz,
+                       pl->rest_src, static_cast<const float*>(values), static_cast<float*>(pl->rest_val));
+  } else {
+    hipLaunchKernelGGL((hot_gather_values_kernel<double>), dim3((unsigned) cdiv(pl->hot_nnz, 256)), dim3(256), 0, s, pl->hot_nnz,
+                       pl->hot_src, static_cast<const double*>(values), static_cast<double*>(pl->hot_val));
+    hipLaunchKernelGGL((hot_gather_values_kernel<double>), dim3((unsigned) cdiv(rp->nnz, 256)), dim3(256), 0, s, rp->nnz,
+                       pl->rest_src, static_cast<const double*>(values), static_cast<double*>(pl->rest_val));
+  }
+  SPB_HIP(hipGetLastError());
+  const int rc = spmv_sliced_update(h, rp, pl->rest_val);
+  if (rc)
+    return rc;
+  pl->values_ptr = values;
+  return SPBLAS_GFX950_STATUS_SUCCESS;
+}
+
+} // namespace spb

@@ -51,6 +51,14 @@
 
 namespace spb {
 
+// hot-column split of a column-skewed matrix (spmv_hot.hip)
+int spmv_hot_build(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const void* values, bool auto_mode);
+int spmv_hot_exec(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const void* alpha, const void* x, const void* beta,
+                  void* y);
+int spmv_hot_rows(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const void* alpha, const void* x, void* y);
+int spmv_hot_update(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const void* values);
+void spmv_hot_free(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl);
+
 static int env_int(const char* name, int dflt) {
   const char* v = std::getenv(name);
   return v && *v ? std::atoi(v) : dflt;
@@ -2334,6 +2342,20 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
 }
 
 int spmv_sliced_build(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const void* values, bool auto_mode) {
+  // Row-skewed matrices (the ones that get variable-height bins below) are usually column-skewed too (graphs): try to take
+  // the entries of the most referenced columns out of the tiles first (spmv_hot.hip).  Not for the halves of a split plan
+  // themselves, not when the caller wants row-range reduces (the split plan multiplies all rows in one call).
+  {
+    const int hot = env_int("SPBLAS_GFX950_PB_HOT", -1);
+    const double avg = pl->m > 0 ? (double) pl->nnz / (double) pl->m : 0.0;
+    const bool skewed = (double) pl->max_row_len > 16.0 * avg + 64.0 || pl->empty_rows * 4 > pl->m;
+    if (!pl->is_child && hot != 0 && h->bin_row_align <= 1 && pl->nnz > 0 && pl->nnz <= INT32_MAX - 8 && pl->m >= 2 &&
+        (hot == 1 || (skewed && pl->nnz >= (4 << 20) && env_int("SPBLAS_GFX950_PB_VARBINS", -1) != 0))) {
+      const int rc_h = spmv_hot_build(h, pl, values, auto_mode);
+      if (rc_h != SPBLAS_GFX950_STATUS_NOT_SUPPORTED)
+        return rc_h;
+    }
+  }
   const bool f32 = pl->value_type == SPBLAS_GFX950_F32, o32 = pl->offset_type == SPBLAS_GFX950_I32;
   if (f32)
     return o32 ? sliced_build_typed<float, int32_t>(h, pl, values, auto_mode)
@@ -2356,6 +2378,8 @@ static int sliced_update_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* p
 }
 
 int spmv_sliced_update(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const void* values) {
+  if (pl->rest_plan)
+    return spmv_hot_update(h, pl, values);
   return pl->value_type == SPBLAS_GFX950_F32 ? sliced_update_typed<float>(h, pl, values)
                                              : sliced_update_typed<double>(h, pl, values);
 }
@@ -2641,6 +2665,11 @@ int spmv_sliced_reserve_partial(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* 
 }
 
 int spmv_sliced_expand(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const void* x) {
+  if (pl->rest_plan) {  // split plan: the tiles are A_rest's; the hot part needs x again at reduce time
+    pl->last_x = x;
+    pl->rest_plan->nt_products = pl->nt_products;
+    return spmv_sliced_expand(h, pl->rest_plan, x);
+  }
   return pl->value_type == SPBLAS_GFX950_F32 ? sliced_expand_typed<float>(h, pl, x)
                                              : sliced_expand_typed<double>(h, pl, x);
 }
@@ -2649,6 +2678,13 @@ int spmv_sliced_expand(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const
 int spmv_sliced_reduce_rows(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const void* alpha, const void* beta,
                             void* y, int64_t row_begin, int64_t row_end, void* const* peers, int n_peers,
                             int64_t peer_off) {
+  if (pl->rest_plan) {
+    // split plan: all rows in one call, no peer stores (the hot part adds into y after the tiles have written it)
+    if (peers || row_begin > 0 || row_end < pl->m || !pl->last_x)
+      return SPBLAS_GFX950_STATUS_NOT_SUPPORTED;
+    const int rc_r = spmv_sliced_reduce_rows(h, pl->rest_plan, alpha, beta, y, 0, pl->m, nullptr, 0, 0);
+    return rc_r ? rc_r : spmv_hot_rows(h, pl, alpha, pl->last_x, y);
+  }
   const int64_t H = pl->rows_per_blk;
   int64_t wb0 = cdiv(row_begin, H);
   int64_t wb1 = cdiv(row_end, H);
@@ -2672,6 +2708,8 @@ int spmv_sliced_reduce_rows(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, 
 
 int spmv_sliced_exec(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const void* alpha, const void* x,
                      const void* beta, void* y) {
+  if (pl->rest_plan)
+    return spmv_hot_exec(h, pl, alpha, x, beta, y);
   int rc = spmv_sliced_expand(h, pl, x);
   if (rc)
     return rc;
@@ -2680,6 +2718,7 @@ int spmv_sliced_exec(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const v
 
 void spmv_sliced_free(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl) {
   hipStream_t s = h->stream;
+  spmv_hot_free(h, pl);
   dev_free(pl->seg_ptr, s);
   dev_free(pl->s_sliceblk, s);
   dev_free(pl->s_binblk, s);

@@ -853,3 +853,72 @@ def test_spmv_store_trial_on_a_small_plan(gpu, monkeypatch, dtype):
         del info
     torch.cuda.synchronize()
     assert free0 - torch.cuda.mem_get_info()[0] < 64 * 2 ** 20
+
+
+@pytest.mark.parametrize("offsets", [np.int32, np.int64])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_spmv_hot_column_split(gpu, monkeypatch, dtype, offsets):
+    """Column-skewed matrix (csrc/spmv_hot.hip): the entries in the most referenced columns are taken out of the tiles and
+    multiplied in row order with their x values in LDS, the rest keeps the tiled plan.  Forced here on a small matrix with
+    everything the split has to get right: empty rows, rows with hot entries only / without any, rows with more hot
+    entries than a window of 256 (per-window partials + fix-up), duplicates, alpha and beta, a rebound value array
+    (both halves take their values again through the recorded source positions), in-place update, two-stage calls."""
+    monkeypatch.setenv("SPBLAS_GFX950_PB_HOT", "1")
+    rng = np.random.default_rng(91)
+    m, n = 60000, 300000
+    lens = rng.integers(0, 14, m)
+    lens[rng.random(m) < 0.3] = 0
+    lens[[5, 777, 31000, m - 1]] = [9000, 2500, 700, 40000]
+    rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(offsets)
+    nnz = int(rowptr[-1])
+    hot_cols = rng.choice(n, 3000, replace=False)
+    hot = rng.random(nnz) < 0.45
+    colind = np.where(hot, hot_cols[rng.integers(0, 3000, nnz)], rng.integers(0, n, nnz)).astype(np.int32)
+    # one row with hot entries only, one without any
+    colind[rowptr[777]:rowptr[778]] = hot_cols[rng.integers(0, 3000, 2500)]
+    cold = np.setdiff1d(np.arange(n), hot_cols)
+    colind[rowptr[31000]:rowptr[31001]] = cold[rng.integers(0, len(cold), 700)]
+    colind[rowptr[5]:rowptr[5] + 40] = hot_cols[7]  # duplicates
+    values = (rng.random(nnz) - 0.5).astype(dtype)
+    x = (rng.random(n) - 0.5).astype(dtype)
+    a = G.csr_on_device(values, rowptr, colind, (m, n), nnz)
+    xd = G.dev(x)
+    y = torch.full((m,), float("nan"), dtype=xd.dtype, device="cuda")
+    info = sp.multiply_inspect(a, xd, y, alg=_capi.SPMV_SLICED)
+    si = info.state_.sliced_info()
+    hs = si["hot_split"]
+    assert 2000 <= hs["hot_columns"] <= 32768 and hs["hot_entries"] + hs["tiled_entries"] == nnz
+    assert hs["hot_entries"] >= 0.4 * nnz and hs["hot_long_rows"] >= 3
+    sp.multiply(info, a, xd, y)
+    check(values, rowptr, colind, (m, n), x, G.host(y), what="hot split", ref_cmp=False)
+    # alpha and beta through the C ABI
+    y0 = (rng.random(m) - 0.5).astype(dtype)
+    y.copy_(G.dev(y0))
+    G.spmv_abi(info, a, xd, y, alpha=-1.5, beta=0.25)
+    _, absrow = util.spmv_exact(rowptr, colind, values, x)
+    y_ref = -1.5 * oracle.spmv((m, n), rowptr, colind, values, x).astype(np.float64) + 0.25 * y0
+    util.assert_parity(G.host(y), y_ref, 1.5 * absrow + 0.25 * np.abs(y0), dtype, row_len=np.diff(rowptr) + 1,
+                       what="hot split alpha / beta")
+    # rebound value array: the next multiply refreshes both halves
+    v2 = (rng.random(nnz) - 0.5).astype(dtype)
+    a.update(G.dev(v2), a.rowptr(), a.colind())
+    y.fill_(float("nan"))
+    sp.multiply(info, a, xd, y)
+    check(v2, rowptr, colind, (m, n), x, G.host(y), what="hot split, rebound values", ref_cmp=False)
+    # in place
+    a.values().mul_(2.0)
+    sp.multiply(info, a, xd, y)
+    check((v2 * dtype(2)).astype(dtype), rowptr, colind, (m, n), x, G.host(y), what="hot split, values scaled in place",
+          ref_cmp=False)
+    # two-stage form: all rows in one reduce; a proper row range is refused (the hot part adds into y afterwards)
+    expand, reduce_rows = info.state_.bind_stages(xd, y.data_ptr(), xd.dtype)
+    y.fill_(float("nan"))
+    expand()
+    reduce_rows(0, m)
+    check((v2 * dtype(2)).astype(dtype), rowptr, colind, (m, n), x, G.host(y), what="hot split, two-stage", ref_cmp=False)
+    with pytest.raises(Exception):
+        reduce_rows(0, m // 2)
+    # the same matrix without the split gives the same answer to rounding
+    monkeypatch.setenv("SPBLAS_GFX950_PB_HOT", "0")
+    info2 = sp.multiply_inspect(a, xd, y, alg=_capi.SPMV_SLICED)
+    assert "hot_split" not in info2.state_.sliced_info()
