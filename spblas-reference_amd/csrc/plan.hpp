@@ -136,6 +136,9 @@ struct spblas_gfx950_plan_s {
   int32_t* hot_src = nullptr;    // [hot_nnz] position in the caller's arrays
   void* hot_rowptr = nullptr;    // O[hot_m + 1]
   int32_t* hot_rows = nullptr;   // [hot_m] row of y
+  void* hot_part = nullptr;      // T[2 * nwin]: per window of A_hot the piece of the row that runs in / the row that runs on
+  int32_t* hot_cross = nullptr;  // [hot_ncross] rows of A_hot that lie in more than one window
+  int64_t hot_ncross = 0;
   void* rest_rowptr = nullptr;   // O[m + 1]
   int32_t* rest_col = nullptr;   // [nnz - hot_nnz]
   void* rest_val = nullptr;      // T[nnz - hot_nnz]

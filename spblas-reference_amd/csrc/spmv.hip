@@ -945,7 +945,7 @@ int spblas_gfx950_plan_info_hot(spblas_gfx950_plan_t plan, int64_t info[6]) {
   info[0] = on ? plan->hot_k : 0;                  // hot columns (their x values live in LDS)
   info[1] = on ? plan->hot_nnz : 0;                // entries multiplied in row order out of LDS
   info[2] = on ? plan->hot_m : 0;                  // rows that have such entries
-  info[3] = on ? plan->hot_plan->n_long : 0;       // ... longer than a window of 256 entries
+  info[3] = on ? plan->hot_ncross : 0;             // ... whose entries lie in more than one window of 256
   info[4] = on ? plan->rest_plan->nnz : 0;         // entries left to the tiled plan
   info[5] = on ? (int64_t) plan->rest_plan->device_bytes : 0;
   return SPBLAS_GFX950_STATUS_SUCCESS;

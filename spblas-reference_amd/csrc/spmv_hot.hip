@@ -9,7 +9,7 @@
 // time, so the entries that reference them are multiplied in ROW order, straight into y, at 10 B per entry:
 //
 //   inspect   sample the column indices (1 in 16) into a histogram, take the K most referenced columns (K = what LDS
-//             holds next to the product staging: 12 288 fp64 / 32 768 fp32) if they cover >= 15 % of the sample, and
+//             holds next to the scan strips: 16 320 fp64 / 36 800 fp32) if they cover >= 15 % of the sample, and
 //             split A once, stably, into A_hot (values, 16-bit index into the hot list, row offsets) and A_rest (an
 //             ordinary CSR matrix with the remaining entries), each with the source position of every entry (for
 //             update_values).  A_rest gets the regular tiled plan; A_hot the nnz-window row partition of the row-block
@@ -51,16 +51,18 @@ static int hot_env(const char* name, int dflt) {
   return v && *v ? std::atoi(v) : dflt;
 }
 
-static constexpr int HOT_WIN = 256;       // entries per window: 64 lanes x 4
-static constexpr int HOT_CAP = 2 * HOT_WIN;
+#ifndef HOT_EPL
+#define HOT_EPL 4                         // consecutive entries per lane: 4 or 8
+#endif
+static constexpr int HOT_WIN = 64 * HOT_EPL;  // entries per window (one wavefront)
 static constexpr int HOT_THREADS = 1024;  // 16 wavefronts share the hot x values
 static constexpr int HOT_WAVES = HOT_THREADS / 64;
 static constexpr int HOT_LDS = 160 * 1024;
 static constexpr int HOT_HIST = 1024;     // sampled reference counts 0 .. 1022, last bucket = more
 
 template <typename T>
-static constexpr int hot_max_cols() {
-  return (HOT_LDS - HOT_WAVES * HOT_CAP * (int) sizeof(T)) / (int) sizeof(T);  // 12 288 fp64, 32 768 fp32
+static constexpr int hot_max_cols() {  // 16 320 fp64, 36 800 fp32 (a multiple of 64 entries; 512 B of row-start bitmaps)
+  return (HOT_LDS - HOT_WAVES * HOT_WIN * (int) sizeof(T) - HOT_WAVES * HOT_WIN / 8) / (int) sizeof(T) / 64 * 64;
 }
 
 // ---------------------------------------------------------------------------------------------------------- inspect
@@ -216,175 +218,278 @@ __device__ __forceinline__ void hot_load4<double>(const double* p, double (&out)
 }
 typedef unsigned short hot_u16x4 __attribute__((ext_vector_type(4)));
 
-// sum of val[p] * xs[col[p]] over [lo, hi) by one wavefront; valid in every lane
-template <typename T, typename O>
-__device__ __forceinline__ T hot_wave_dot(O lo, O hi, const uint16_t* __restrict__ col, const T* __restrict__ val,
-                                          const T* xs, int lane) {
-  T s = 0;
-  for (O p = lo + (O) lane; p < hi; p += 64)
-    s += stream_load(val + p) * xs[stream_load(col + p)];
-  return group_sum_c<64>(s);
+// Window w (HOT_WIN entries of A_hot) owns the rows of A_hot whose first entry lies in it (every row of A_hot has entries,
+// so at most HOT_WIN of them); y[hot_rows[r]] += alpha * sum.  A row no longer than a window is summed entirely by its
+// owner: it ends before the end of the NEXT window, so a wavefront stages the products of entries [w, w + 2) * HOT_WIN in
+// its LDS strip (the second half is read again by the neighbouring wavefront, out of L2).  A longer row leaves a partial
+// per window it covers (part_tail where it starts, part_head in the later ones), summed out of the same strip, for
+// pb_hot_fixup_kernel.  spmv.hip: spmv_rowblock_kernel is this scheme at workgroup scope with x in global memory.
+//
+// A wavefront's windows are latency chains (window -> rows -> rows of y -> y), and a CU holds only the 16 wavefronts its
+// LDS-resident x slice allows, so the chain is software-pipelined over four windows: the row numbers of window w + 3
+// strides, the row offsets / row bounds / entries of window w + 2, the y values of window w + 1 and the arithmetic of window
+// w (its entries arrive with its y values) are in flight together -- nothing an iteration loads is used before the next one; every load is unconditional (clamped
+// indices, padded arrays) so that the waits count loads, not branches.
+// DPP moves for the wave-wide segmented scan (no LDS round trips): CTRL 0x110 + n = row_shr:n inside the 16-lane rows,
+// 0x142 / 0x143 = row_bcast:15 / row_bcast:31 (lane 15 of a row to the next row / lane 31 to the upper half; gfx9 family),
+// 0x138 = wave_shr:1.  Lanes without a source (and rows outside ROWS) read 0.
+template <int CTRL, int ROWS>
+__device__ __forceinline__ unsigned hot_dpp(unsigned v) {
+  return (unsigned) __builtin_amdgcn_update_dpp(0, (int) v, CTRL, ROWS, 0xf, true);
+}
+template <int CTRL, int ROWS>
+__device__ __forceinline__ float hot_dpp(float v) {
+  return __uint_as_float(hot_dpp<CTRL, ROWS>(__float_as_uint(v)));
+}
+template <int CTRL, int ROWS>
+__device__ __forceinline__ double hot_dpp(double v) {
+  const unsigned long long b = (unsigned long long) __double_as_longlong(v);
+  const unsigned lo = hot_dpp<CTRL, ROWS>((unsigned) b), hi = hot_dpp<CTRL, ROWS>((unsigned) (b >> 32));
+  return __longlong_as_double((long long) (((unsigned long long) hi << 32) | lo));
+}
+// one step of the inclusive segmented scan over lanes: (v, f) of this lane absorbs (vp, fp) of the lanes before it
+template <int CTRL, int ROWS, typename T>
+__device__ __forceinline__ void hot_seg_step(T& v, unsigned& f, bool take) {
+  const T vp = hot_dpp<CTRL, ROWS>(v);
+  const unsigned fp = hot_dpp<CTRL, ROWS>(f);
+  if (take) {
+    if (!f)
+      v += vp;
+    f |= fp;
+  }
 }
 
-// Window w (HOT_WIN entries of A_hot) owns the rows of A_hot whose first entry lies in it (every row of A_hot has entries,
-// so at most HOT_WIN of them); y[hot_rows[r]] += alpha * sum.  A row no longer than a window is summed entirely by its owner (it ends before
-// the end of the next window, hence 2 * HOT_WIN staging slots); a longer one leaves a partial per window it covers
-// (part_tail where it starts, part_head in the later ones) for pb_hot_fixup_kernel.  spmv.hip: spmv_rowblock_kernel is the
-// same scheme at workgroup scope with x in global memory.
-template <typename T, typename O, bool HAS_LONG>
+// Window w = entries [w, w + 1) * HOT_WIN of A_hot, one wavefront, four consecutive entries per lane.  Every row of A_hot
+// has entries, so a window sees at most HOT_WIN row starts.  The products stay in registers; the row starts of the window
+// go into a bitmap (LDS, 256 bits); an exact segmented inclusive scan -- sums restart at every row start: no differences
+// of prefix sums, a row's rounding depends on its own terms only -- runs over lanes with DPP moves; the scan values go to
+// the wavefront's LDS strip, where the sum of a row is the value at its last entry:
+//   rows that start and end inside the window      y[hot_rows[r]] += alpha * sum         (the lane that loaded the row's bounds)
+//   the piece of a row that began in an earlier window   head[w] = value before the window's first row start
+//   the piece of the last row if it runs on               tail[w] = value at the window's last entry
+// and pb_hot_fixup_kernel adds tail + heads for the rows that cross a window boundary (listed at inspect).  A window
+// without any row start (inside a long row: about half of the windows of a power-law graph) is a plain wave reduction.
+//
+// A wavefront's windows are latency chains (window -> rows -> rows of y -> y) and a CU holds only the 16 wavefronts its
+// LDS-resident x slice allows, so the chain is software-pipelined over four windows: the row numbers of window w + 3
+// strides, the row bounds of window w + 2, the y values and entries of window w + 1 and the arithmetic of window w are in
+// flight together -- nothing a step loads is used before the next one; every load is unconditional (clamped indices,
+// padded arrays) so that the waits count loads, not branches; the four stages rotate through four register sets by
+// unrolling (copying a stage that was loaded in the same step would wait for it).
+template <typename T, typename O>
+struct hot_stage {
+  int rb, re;      // rows of A_hot that start in the window: [rb, re)
+  O a, e;          // first entry of row rb, one past the last entry of row re - 1
+  O s0[2], s1[2];  // bounds of the rows rb + lane (+ 64)
+  int hr[2];       // their rows of y
+  T yv[2];         // ... and what y holds there (loaded one window ahead: nobody else writes these rows in this launch)
+  T v[HOT_EPL];    // entries w * HOT_WIN + HOT_EPL * lane ...
+  hot_u16x4 c[HOT_EPL / 4];
+};
+
+template <typename T, typename O>
 __global__ __launch_bounds__(HOT_THREADS) void pb_hot_rows_kernel(int64_t nnz, int64_t nwin, const O* __restrict__ rowptr,
                                                                   const uint16_t* __restrict__ col,
                                                                   const T* __restrict__ val,
                                                                   const int32_t* __restrict__ hot_cols, int K,
                                                                   const T* __restrict__ x, T* __restrict__ y, T alpha,
-                                                                  const int32_t* __restrict__ hot_rows,
+                                                                  const int32_t* __restrict__ hot_rows, int m_hot,
                                                                   const int32_t* __restrict__ win_row,
                                                                   T* __restrict__ part_head, T* __restrict__ part_tail) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   T* xs = reinterpret_cast<T*>(smem);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  T* prod = xs + hot_max_cols<T>() + wave * HOT_CAP;
-  for (int i = tid; i < K; i += HOT_THREADS)
-    xs[i] = x[hot_cols[i]];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  T* strip = xs + hot_max_cols<T>() + wave * HOT_WIN;
+  // row starts of the current window: one bit per entry (HOT_WIN / 32 words per wavefront, behind the strips)
+  constexpr int BW = HOT_WIN / 32;
+  unsigned* bits = reinterpret_cast<unsigned*>(xs + hot_max_cols<T>() + HOT_WAVES * HOT_WIN) + wave * BW;
+  for (int i0 = 0; i0 < K; i0 += 4 * HOT_THREADS) {  // (four gathers in flight per thread)
+    int idx[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      idx[u] = i0 + u * HOT_THREADS + tid < K ? hot_cols[i0 + u * HOT_THREADS + tid] : 0;
+    T xv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      xv[u] = x[idx[u]];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (i0 + u * HOT_THREADS + tid < K)
+        xs[i0 + u * HOT_THREADS + tid] = xv[u];
+  }
+  if (lane < BW)
+    bits[lane] = 0;
   __syncthreads();
 
   const int64_t stride = (int64_t) gridDim.x * HOT_WAVES;
   int64_t w = (int64_t) blockIdx.x * HOT_WAVES + wave;
-  // (window bounds one iteration ahead: the chain win_row -> rowptr -> entries would otherwise be paid per window)
-  int nb = 0, ne = 0;
-  O na = 0, nend = 0;
-  if (w < nwin) {
-    nb = win_row[w];
-    ne = win_row[w + 1];
-    na = rowptr[nb];
-    nend = rowptr[ne];
-  }
-  for (; w < nwin; w += stride) {
-    const int r_begin = nb;
-    int r_end = ne;
-    const O a = na;
-    O e = nend;
-    if (w + stride < nwin) {
-      nb = win_row[w + stride];
-      ne = win_row[w + stride + 1];
-      na = rowptr[nb];
-      nend = rowptr[ne];
+  if (w >= nwin)
+    return;
+  const int64_t last = nwin - 1;
+  auto clampw = [&](int64_t ww) { return ww < last ? ww : last; };
+  auto load_rows = [&](int64_t ww, hot_stage<T, O>& st) {
+    st.rb = win_row[ww];
+    st.re = win_row[ww + 1];
+  };
+  auto load_bounds = [&](hot_stage<T, O>& st) {
+    const int rb = st.rb, re = st.re;
+    st.a = rowptr[rb];
+    st.e = rowptr[re];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int r = rb + lane + 64 * k < re ? rb + lane + 64 * k : re;
+      st.s0[k] = rowptr[r];
+      st.s1[k] = rowptr[r < re ? r + 1 : re];
+      st.hr[k] = hot_rows[r < m_hot ? r : m_hot - 1];
     }
+  };
+  auto load_entries = [&](int64_t ww, hot_stage<T, O>& st) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+      st.yv[k] = y[st.hr[k]];
+    const int64_t base = ww * HOT_WIN + HOT_EPL * lane;  // (the arrays end in HOT_WIN zero entries)
+#pragma unroll
+    for (int q = 0; q < HOT_EPL / 4; ++q) {
+      hot_load4<T>(val + base + 4 * q, reinterpret_cast<T (&)[4]>(st.v[4 * q]));
+      st.c[q] = stream_load(reinterpret_cast<const hot_u16x4*>(col + base + 4 * q));
+    }
+  };
+  const int lir = lane & 15;  // lane in its DPP row
+  auto step = [&](hot_stage<T, O>& cur, hot_stage<T, O>& mid, hot_stage<T, O>& far, hot_stage<T, O>& next) {
+    load_rows(clampw(w + 3 * stride), next);
+    load_bounds(far);
+    load_entries(clampw(w + stride), mid);
+    const int rb = cur.rb, re = cur.re;
     const O wlo = (O) (w * HOT_WIN);
     const O whi = (O) ((w + 1) * HOT_WIN < nnz ? (w + 1) * HOT_WIN : nnz);
-    if (HAS_LONG) {
-      if (r_begin > 0 && a > wlo) {  // a long row entering this window from an earlier one
-        const O hs = rowptr[r_begin - 1];
-        if (a - hs > (O) HOT_WIN) {
-          const T s = hot_wave_dot<T, O>(wlo, a < whi ? a : whi, col, val, xs, lane);
-          if (lane == 0)
-            part_head[w] = s;
-        }
-      }
-      if (r_end > r_begin) {  // a long row starting in this window (necessarily the last owned row)
-        const O ls = rowptr[r_end - 1];
-        if (e - ls > (O) HOT_WIN) {
-          const T s = hot_wave_dot<T, O>(ls, whi, col, val, xs, lane);
-          if (lane == 0)
-            part_tail[w] = s;
-          r_end -= 1;
-          e = ls;
-        }
-      }
-    }
-    const O a_al = a & ~(O) 3;  // >= wlo: HOT_WIN is a multiple of 4
-    const int total = (int) (e - a_al);
-    const int nrows = r_end - r_begin;
-    int lpr = 1;
-    while (lpr < 64 && nrows * lpr * 2 <= 64)
-      lpr <<= 1;
-    const int grp = lane / lpr, lig = lane % lpr, ngrp = 64 / lpr;
-    // the first round's row bounds travel with the entry loads
-    const int r0 = r_begin + grp;
-    O s0 = 0, s1 = 0;
-    int yr = 0;
-    if (r0 < r_end) {
-      s0 = rowptr[r0];
-      s1 = rowptr[r0 + 1];
-      yr = hot_rows[r0];
-    }
-    T v[2][4];
-    hot_u16x4 c[2];
+    T t[HOT_EPL];
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      const int q = (it * 64 + lane) * 4;
-      const O p = a_al + (O) q;
+    for (int j = 0; j < HOT_EPL; ++j)
+      t[j] = cur.v[j] * xs[cur.c[j / 4][j % 4]];  // (pads: 0 * xs[0])
+    if (rb == re) {  // no row starts here: one wave reduction, the piece of the row that covers the window
+      T v = t[0];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        v[it][j] = T(0);
-        c[it][j] = 0;
-      }
-      if (q < total) {
-        if ((int64_t) p + 4 <= nnz) {
-          hot_load4<T>(val + p, v[it]);
-          c[it] = stream_load(reinterpret_cast<const hot_u16x4*>(col + p));
-        } else {
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            if ((int64_t) p + j < nnz) {
-              v[it][j] = stream_load(val + p + j);
-              c[it][j] = stream_load(col + p + j);
-            }
-        }
-      }
+      for (int j = 1; j < HOT_EPL; ++j)
+        v += t[j];
+      v += hot_dpp<0x111, 0xf>(v);
+      v += hot_dpp<0x112, 0xf>(v);
+      v += hot_dpp<0x114, 0xf>(v);
+      v += hot_dpp<0x118, 0xf>(v);
+      v += hot_dpp<0x142, 0xa>(v);
+      v += hot_dpp<0x143, 0xc>(v);
+      if (lane == 63)
+        part_head[w] = v;
+      return;
     }
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      const int q = (it * 64 + lane) * 4;
-      if (q < total) {
-        const O p = a_al + (O) q;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const bool in = (p + j >= a) && (p + j < e);
-          prod[q + j] = in ? v[it][j] * xs[c[it][j]] : T(0);
-        }
-      }
+    for (int k = 0; k < 2; ++k)
+      if (rb + lane + 64 * k < re)
+        atomicOr(&bits[(int) (cur.s0[k] - wlo) >> 5], 1u << ((int) (cur.s0[k] - wlo) & 31));
+    for (int r = rb + 128 + lane; r < re; r += 64) {  // (more than 128 rows in one window: rare)
+      const int q = (int) (rowptr[r] - wlo);
+      atomicOr(&bits[q >> 5], 1u << (q & 31));
     }
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wavefront's products have landed in its strip
-    for (int r = r0; r < r_end; r += ngrp) {
-      if (r != r0) {
-        s0 = rowptr[r];
-        s1 = rowptr[r + 1];
-        yr = hot_rows[r];
-      }
-      T s = 0;
-      for (int q = (int) (s0 - a_al) + lig; q < (int) (s1 - a_al); q += lpr)
-        s += prod[q];
-      s = group_sum(s, lpr);
-      if (lig == 0)
-        y[yr] += alpha * s;
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the row starts are in the bitmap
+    constexpr unsigned EMASK = (1u << HOT_EPL) - 1u;
+    const unsigned nib = (bits[(lane * HOT_EPL) >> 5] >> ((lane * HOT_EPL) & 31)) & EMASK;
+#pragma unroll
+    for (int j = 1; j < HOT_EPL; ++j)
+      t[j] = (nib & (1u << j)) ? t[j] : t[j - 1] + t[j];
+    T v = t[HOT_EPL - 1];
+    unsigned f = nib != 0u;
+    hot_seg_step<0x111, 0xf>(v, f, lir >= 1);
+    hot_seg_step<0x112, 0xf>(v, f, lir >= 2);
+    hot_seg_step<0x114, 0xf>(v, f, lir >= 4);
+    hot_seg_step<0x118, 0xf>(v, f, lir >= 8);
+    hot_seg_step<0x142, 0xa>(v, f, (lane & 16) != 0);
+    hot_seg_step<0x143, 0xc>(v, f, lane >= 32);
+    const T c = hot_dpp<0x138, 0xf>(v);  // what the lanes before me carry into my first segment (lane 0: nothing)
+    T* dst = strip + HOT_EPL * lane;
+#pragma unroll
+    for (int j = 0; j < HOT_EPL; ++j)
+      dst[j] = (nib & ((2u << j) - 1u)) ? t[j] : t[j] + c;
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // the scan values have landed in the strip
+    if (lane < BW)
+      bits[lane] = 0;  // (read by nobody before the next window's barrier)
+    const bool runs_on = cur.e > whi;  // the last row that starts here ends in a later window
+    if (lane == 0) {
+      if (cur.a > wlo)
+        part_head[w] = strip[(int) (cur.a - wlo) - 1];
+      if (runs_on)
+        part_tail[w] = strip[(int) (whi - wlo) - 1];
     }
+    const int r_end = re - (runs_on ? 1 : 0);
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+      if (rb + lane + 64 * k < r_end)
+        y[cur.hr[k]] = cur.yv[k] + alpha * strip[(int) (cur.s1[k] - wlo) - 1];
+    for (int r = rb + 128 + lane; r < r_end; r += 64)
+      y[hot_rows[r]] += alpha * strip[(int) (rowptr[r + 1] - wlo) - 1];
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0xc07f);  // the strip is read out before the next window overwrites it
+  };
+  hot_stage<T, O> sa, sb, sc, sd;
+  load_rows(w, sa);
+  load_rows(clampw(w + stride), sb);
+  load_rows(clampw(w + 2 * stride), sc);
+  load_bounds(sa);
+  load_bounds(sb);
+  load_entries(w, sa);
+  for (;;) {
+    step(sa, sb, sc, sd);
+    if ((w += stride) > last)
+      break;
+    step(sb, sc, sd, sa);
+    if ((w += stride) > last)
+      break;
+    step(sc, sd, sa, sb);
+    if ((w += stride) > last)
+      break;
+    step(sd, sa, sb, sc);
+    if ((w += stride) > last)
+      break;
   }
 }
 
-// one wavefront per long row: y[hot_rows[r]] += alpha * (tail + heads)
+// the rows of A_hot that cross a window boundary: y[hot_rows[r]] += alpha * (tail of the window the row starts in + heads of
+// the windows it runs through), 16 lanes per row
 template <typename T, typename O>
-__global__ __launch_bounds__(64) void pb_hot_fixup_kernel(int64_t n_long, const int32_t* __restrict__ long_rows,
-                                                          const O* __restrict__ rowptr, const T* __restrict__ part_head,
-                                                          const T* __restrict__ part_tail, T* __restrict__ y, T alpha,
-                                                          const int32_t* __restrict__ hot_rows) {
-  const int64_t i = blockIdx.x;
-  if (i >= n_long)
-    return;
-  const int r = long_rows[i];
-  const int64_t p0 = (int64_t) rowptr[r], p1 = (int64_t) rowptr[r + 1];
-  const int64_t w0 = p0 / HOT_WIN, w1 = (p1 - 1) / HOT_WIN;
+__global__ __launch_bounds__(256) void pb_hot_fixup_kernel(int64_t n_cross, const int32_t* __restrict__ cross_rows,
+                                                           const O* __restrict__ rowptr, const T* __restrict__ part_head,
+                                                           const T* __restrict__ part_tail, T* __restrict__ y, T alpha,
+                                                           const int32_t* __restrict__ hot_rows) {
+  const int64_t i = ((int64_t) blockIdx.x * 256 + threadIdx.x) >> 4;
+  const int lig = threadIdx.x & 15;
   T s = 0;
-  for (int64_t w = w0 + 1 + threadIdx.x; w <= w1; w += 64)
-    s += part_head[w];
-  s = group_sum_c<64>(s);
-  if (threadIdx.x == 0) {
-    s += part_tail[w0];
-    y[hot_rows[r]] += alpha * s;
+  int r = 0;
+  int64_t w0 = 0;
+  if (i < n_cross) {
+    r = cross_rows[i];
+    const int64_t p0 = (int64_t) rowptr[r], p1 = (int64_t) rowptr[r + 1];
+    w0 = p0 / HOT_WIN;
+    const int64_t w1 = (p1 - 1) / HOT_WIN;
+    for (int64_t w = w0 + 1 + lig; w <= w1; w += 16)
+      s += part_head[w];
   }
+  s = group_sum_c<16>(s);
+  if (i < n_cross && lig == 0)
+    y[hot_rows[r]] += alpha * (s + part_tail[w0]);
+}
+
+// inspect: the rows of A_hot whose entries lie in more than one window
+template <typename O>
+__global__ __launch_bounds__(256) void hot_cross_rows_kernel(int64_t m_hot, const O* __restrict__ rowptr,
+                                                             int32_t* __restrict__ cross_rows,
+                                                             unsigned long long* __restrict__ n_cross) {
+  const int64_t r = (int64_t) blockIdx.x * 256 + threadIdx.x;
+  if (r >= m_hot)
+    return;
+  const int64_t p0 = (int64_t) rowptr[r], p1 = (int64_t) rowptr[r + 1];
+  if (p0 / HOT_WIN != (p1 - 1) / HOT_WIN)
+    cross_rows[atomicAdd(n_cross, 1ull)] = (int32_t) r;
 }
 
 template <typename T, typename O>
@@ -395,22 +500,16 @@ static int hot_launch(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const 
   const int cus = h->num_cus > 0 ? h->num_cus : 256;
   const int64_t grid = cdiv(hp->nwin, HOT_WAVES) < cus ? cdiv(hp->nwin, HOT_WAVES) : cus;
   const O* rowptr = static_cast<const O*>(hp->rowptr);
+  T* head = static_cast<T*>(pl->hot_part);
+  T* tail = head + hp->nwin;
   hp->last_stream = s;
   hp->used = true;
-  if (hp->n_long > 0) {
-    hipLaunchKernelGGL((pb_hot_rows_kernel<T, O, true>), dim3((unsigned) grid), dim3(HOT_THREADS), HOT_LDS, s, hp->nnz, hp->nwin,
-                       rowptr, pl->hot_col, static_cast<const T*>(pl->hot_val), pl->hot_cols, pl->hot_k,
-                       static_cast<const T*>(x), static_cast<T*>(y), alpha, pl->hot_rows, hp->win_row,
-                       static_cast<T*>(hp->part_head), static_cast<T*>(hp->part_tail));
-    hipLaunchKernelGGL((pb_hot_fixup_kernel<T, O>), dim3((unsigned) hp->n_long), dim3(64), 0, s, hp->n_long, hp->long_rows,
-                       rowptr, static_cast<const T*>(hp->part_head), static_cast<const T*>(hp->part_tail), static_cast<T*>(y),
-                       alpha, pl->hot_rows);
-  } else {
-    hipLaunchKernelGGL((pb_hot_rows_kernel<T, O, false>), dim3((unsigned) grid), dim3(HOT_THREADS), HOT_LDS, s, hp->nnz, hp->nwin,
-                       rowptr, pl->hot_col, static_cast<const T*>(pl->hot_val), pl->hot_cols, pl->hot_k,
-                       static_cast<const T*>(x), static_cast<T*>(y), alpha, pl->hot_rows, hp->win_row, static_cast<T*>(nullptr),
-                       static_cast<T*>(nullptr));
-  }
+  hipLaunchKernelGGL((pb_hot_rows_kernel<T, O>), dim3((unsigned) grid), dim3(HOT_THREADS), HOT_LDS, s, hp->nnz, hp->nwin, rowptr,
+                     pl->hot_col, static_cast<const T*>(pl->hot_val), pl->hot_cols, pl->hot_k, static_cast<const T*>(x),
+                     static_cast<T*>(y), alpha, pl->hot_rows, (int) pl->hot_m, hp->win_row, head, tail);
+  if (pl->hot_ncross > 0)
+    hipLaunchKernelGGL((pb_hot_fixup_kernel<T, O>), dim3((unsigned) cdiv(pl->hot_ncross * 16, 256)), dim3(256), 0, s,
+                       pl->hot_ncross, pl->hot_cross, rowptr, head, tail, static_cast<T*>(y), alpha, pl->hot_rows);
   SPB_HIP(hipGetLastError());
   return SPBLAS_GFX950_STATUS_SUCCESS;
 }
@@ -451,6 +550,11 @@ void spmv_hot_free(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl) {
   dev_free(pl->hot_src, s);
   dev_free(pl->hot_rowptr, s);
   dev_free(pl->hot_rows, s);
+  dev_free(pl->hot_part, s);
+  dev_free(pl->hot_cross, s);
+  pl->hot_part = nullptr;
+  pl->hot_cross = nullptr;
+  pl->hot_ncross = 0;
   dev_free(pl->rest_rowptr, s);
   dev_free(pl->rest_col, s);
   dev_free(pl->rest_val, s);
@@ -541,14 +645,18 @@ static int hot_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, c
   if (n_hot * 100 < nnz * (long long) min_pct || n_rest < 1)
     return SPBLAS_GFX950_STATUS_NOT_SUPPORTED;  // (the sample promised more than the matrix holds)
   pl->hot_nnz = (int64_t) n_hot;
-  if ((rc = dev_alloc(&pl->hot_val, (size_t) (n_hot + 8) * sizeof(T), s)) ||
-      (rc = dev_alloc((void**) &pl->hot_col, (size_t) (n_hot + 8) * 2, s)) ||
+  // (the multiply loads whole windows: the arrays end in zero entries up to the end of the last window)
+  const size_t hot_pad = (size_t) (n_hot / HOT_WIN + 1) * HOT_WIN + HOT_WIN;
+  if ((rc = dev_alloc(&pl->hot_val, hot_pad * sizeof(T), s)) ||
+      (rc = dev_alloc((void**) &pl->hot_col, hot_pad * 2, s)) ||
       (rc = dev_alloc((void**) &pl->hot_src, (size_t) n_hot * 4, s)) ||
       (rc = dev_alloc(&pl->rest_rowptr, (size_t) (m + 1) * sizeof(O), s)) ||
       (rc = dev_alloc(&pl->rest_val, (size_t) n_rest * sizeof(T), s)) ||
       (rc = dev_alloc((void**) &pl->rest_col, (size_t) n_rest * 4, s)) ||
       (rc = dev_alloc((void**) &pl->rest_src, (size_t) n_rest * 4, s)))
     return rc;
+  SPB_HIP(hipMemsetAsync(static_cast<T*>(pl->hot_val) + n_hot, 0, (hot_pad - (size_t) n_hot) * sizeof(T), s));
+  SPB_HIP(hipMemsetAsync(pl->hot_col + n_hot, 0, (hot_pad - (size_t) n_hot) * 2, s));
   hipLaunchKernelGGL((hot_split_kernel<T>), dim3((unsigned) cdiv(nnz, 256)), dim3(256), 0, s, nnz, colind, values, colmap, pos,
                      static_cast<T*>(pl->hot_val), pl->hot_col, pl->hot_src, static_cast<T*>(pl->rest_val), pl->rest_col,
                      pl->rest_src);
@@ -588,6 +696,24 @@ static int hot_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, c
   hp->is_child = 1;
   if ((rc = spmv_plan_structures(h, hp, SPBLAS_GFX950_SPMV_ROWBLOCK)))
     return rc;
+  {
+    // the rows that cross a window boundary (a row of n entries crosses with probability ~ n / HOT_WIN) and the two
+    // partial sums per window they are put together from
+    unsigned long long* n_cross_dev = nullptr;
+    if ((rc = g.alloc((void**) &n_cross_dev, sizeof(unsigned long long))) ||
+        (rc = dev_alloc((void**) &pl->hot_cross, (size_t) (hp->nwin + 1) * 4, s)) ||
+        (rc = dev_alloc(&pl->hot_part, (size_t) 2 * hp->nwin * sizeof(T), s)))
+      return rc;
+    SPB_HIP(hipMemsetAsync(n_cross_dev, 0, sizeof(unsigned long long), s));
+    SPB_HIP(hipMemsetAsync(pl->hot_part, 0, (size_t) 2 * hp->nwin * sizeof(T), s));
+    hipLaunchKernelGGL((hot_cross_rows_kernel<O>), dim3((unsigned) cdiv(m_hot, 256)), dim3(256), 0, s, (int64_t) m_hot,
+                       static_cast<const O*>(pl->hot_rowptr), pl->hot_cross, n_cross_dev);
+    unsigned long long n_cross = 0;
+    if ((rc = readback_add(h, &n_cross, n_cross_dev, sizeof(n_cross))) || (rc = readback_flush(h)))
+      return rc;
+    SPB_HIP(hipGetLastError());
+    pl->hot_ncross = (int64_t) n_cross;  // (at most one row crosses each boundary: <= nwin - 1)
+  }
   // A_rest: an ordinary CSR matrix for the tiled plan
   auto* rp = new (std::nothrow) spblas_gfx950_plan_s();
   if (!rp)
@@ -613,9 +739,8 @@ static int hot_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, c
   pl->device_bytes += hp->device_bytes + rp->device_bytes + (size_t) cols * 4 + (size_t) n_hot * (sizeof(T) + 6) +
                       (size_t) n_rest * (sizeof(T) + 8) + (size_t) (m + 1) * sizeof(O) + (size_t) (m_hot + 1) * (sizeof(O) + 4);
   pl->hot_m = (int64_t) m_hot;
-  SPB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pb_hot_rows_kernel<T, O, true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, HOT_LDS));
-  SPB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pb_hot_rows_kernel<T, O, false>),
+  pl->device_bytes += (size_t) (hp->nwin + 1) * 4 + (size_t) 2 * hp->nwin * sizeof(T);
+  SPB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pb_hot_rows_kernel<T, O>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, HOT_LDS));
   return SPBLAS_GFX950_STATUS_SUCCESS;
 }

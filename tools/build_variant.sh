@@ -5,7 +5,7 @@ set -e
 cd "$(dirname "$0")/.."
 name=$1; shift
 out=tools/ab/obj_$name; mkdir -p $out
-for f in handle spmv spmv_sliced spmm spgemm transpose sptrsv multigpu; do
+for f in handle spmv spmv_sliced spmv_hot spmm spgemm transpose sptrsv multigpu; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wno-unused-function \
     -I include -I spblas-reference_amd/csrc "$@" -c spblas-reference_amd/csrc/$f.hip -o $out/$f.o &
 done
