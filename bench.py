@@ -43,6 +43,9 @@ def parse():
     p.add_argument("--alg", default="auto", choices=["auto", "vector", "rowblock", "sliced", "noplan"])
     p.add_argument("--chunks", type=int, default=0,
                    help="N>1: stripes per step whose all-gathers overlap the next stripe's compute (0 = auto)")
+    p.add_argument("--flag-chunks", type=int, default=4,
+                   help="N>1, fused path on a square matrix: chunks of the dependent chain without a step barrier (diagnostic "
+                        "`fused_chunked_step_ms`; 0 = off)")
     p.add_argument("--fused", default="auto", choices=["auto", "off"],
                    help="N>1: auto = peer stores of y from the reduce kernels (hipIpc) when every rank can, "
                         "validated against the RCCL all-gather path; off = RCCL all-gather only")
@@ -333,7 +336,8 @@ def main():
     if multi and mode == "plain" and args.fused == "auto" and args.alg in ("auto", "sliced") and \
             len({bounds[r + 1] - bounds[r] for r in range(world)}) == 1:
         fused_op = sharded.try_fused(a_chunks[0], bounds, x, lambda xk: rccl_op.step(xk), alg=algs[args.alg],
-                                     info=rccl_op.infos[0],
+                                     info=rccl_op.infos[0], chunks=args.flag_chunks if m == n else 0,
+                                     shared_device=args.debug_one_gpu,
                                      log=(lambda msg: print(f"[bench] {msg}; using RCCL all-gather", file=sys.stderr))
                                      if rank == 0 else None)
         if fused_op is not None:
@@ -430,7 +434,62 @@ def main():
                 print(f"[bench] rank {rank}: pipelined fused step not measured: {failed}", file=sys.stderr)
             pipe_ok = bool(int(okf.item()))
             pipe_ms = float(el.item()) / k * 1e3 if pipe_ok else None
+        # Dependent chain WITHOUT a step barrier (round 4): y_{j+1} = A y_j, the peers' rows of step j arriving chunk by
+        # chunk behind the expand of step j + 1.  A diagnostic like the pipelined form (the timed step multiplies a fixed
+        # x and ends in the barrier), checked against the barrier chain's bits; any failure leaves the line as it is.
+        chunk_ms, chunk_ok, chunk_wait_us = None, None, None
+        if mode == "fused" and getattr(op, "chunks", 0):
+            failed, same = None, 0
+
+            def local2(fn):
+                nonlocal failed
+                if failed is None:
+                    try:
+                        return fn()
+                    except Exception as e:  # noqa: BLE001 - diagnostics only
+                        failed = e
+                return None
+
+            def chain(n_steps, barrier):
+                # (x in [0, 1): |y| grows ~2.5x per step -- alpha keeps a long chain in range)
+                if barrier:
+                    y = op.step(x)
+                    for _ in range(n_steps - 1):
+                        y = op.step(y.clone())
+                    return y.clone()
+                y = op.step_dependent(x, alpha=1.0 if n_steps <= 8 else 0.4)
+                for _ in range(n_steps - 1):
+                    y = op.step_dependent(alpha=1.0 if n_steps <= 8 else 0.4)
+                y = op.flush_chain()
+                torch.cuda.synchronize()
+                return y
+
+            def check():
+                a, b = chain(4, True), chain(4, False).clone()
+                op.check_status()
+                return int(torch.equal(a, b))
+
+            same = local2(check) or 0
+            local2(lambda: chain(4, False))  # warm-up
+            dist.barrier()
+            t1 = time.perf_counter()
+            local2(lambda: chain(k, False))
+            dist.barrier()
+            el = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=device)
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+            wait_t = torch.tensor([local2(lambda: op.chunk_wait_us()) or 0.0], dtype=torch.float64, device=device)
+            dist.all_reduce(wait_t, op=dist.ReduceOp.MAX)
+            okc = torch.tensor([0 if failed is not None else same], dtype=torch.int32, device=device)
+            dist.all_reduce(okc, op=dist.ReduceOp.MIN)
+            if failed is not None:
+                print(f"[bench] rank {rank}: chunked dependent chain not measured: {failed}", file=sys.stderr)
+            chunk_ok = bool(int(okc.item()))
+            chunk_ms = float(el.item()) / k * 1e3 if chunk_ok else None
+            chunk_wait_us = float(wait_t.item())
         diag = {"mode_timed": mode, "local_spmv_ms": local_s / k * 1e3, "local_spmv_event_ms": local_ev,
+                "rccl_nranks": dist.get_world_size(), "backend": dist.get_backend(),
+                "chunks": getattr(op, "chunks", 0) if mode == "fused" else 0,
+                "fused_chunked_step_ms": chunk_ms, "fused_chunked_check": chunk_ok, "expand_wait_us": chunk_wait_us,
                 "fused_pipelined_step_ms": pipe_ms, "fused_pipelined_check": pipe_ok,
                 "gather_ms": gather_s / k * 1e3, "rccl_step_ms": rccl_s / k * 1e3,
                 "fused_step_ms": elapsed / args.steps * 1e3 if mode == "fused" else None,

@@ -234,6 +234,34 @@ int spblas_gfx950_spmv_reduce_rows_bcast(spblas_gfx950_handle_t handle, spblas_g
 int spblas_gfx950_spmv_step_bcast(spblas_gfx950_handle_t handle, spblas_gfx950_plan_t plan, const void* alpha,
                                   const void* x, void* const* y_peers, int n_peers, int64_t y_row_offset,
                                   int stripes);
+/* Dependent iteration (x of step k + 1 is y of step k) with the peers' rows arriving BEHIND the next expand instead of in
+ * front of it (round 4).  The reduce runs in `chunks` stripes as in spmv_step_bcast; after each stripe's peer stores a
+ * small kernel on the same stream publishes slot rank * chunks + c = step in every rank's flag array (flag_peers: device
+ * array of the n_peers flag arrays, int64[n_peers * chunks] each, uncached memory).  With `wait` the expand of THIS step --
+ * whose x must be this rank's copy of the previous step's y -- waits, x slice by x slice, for the chunks that slice is made
+ * of (own rows: stream order; bounded spin with s_sleep; a time-out sets status_dev[0] and lets the kernel finish) and reads
+ * the slice with system-scope loads; status_dev[1] receives the longest wait of a workgroup in wall-clock ticks.  There is
+ * no step barrier: a rank's step k + 2 overwrites copy k & 1 only after its expand has seen every rank's chunks of step
+ * k + 1, which they publish after their expand of step k + 1 has read that copy.  spmv_chunk_rows: the local row
+ * boundaries (chunks + 1, host) of the stripes -- every rank needs every rank's (chunk_rows of the wait descriptor: global
+ * rows, device, int64[n_ranks * (chunks + 1)]).  Plans cut on the arithmetic bin grid only (row shards of a matrix with
+ * uniform rows); STATUS_NOT_SUPPORTED otherwise.  Nothing here has been run across
+ * devices yet: n ranks sharing one device exercise the code path (tests/mp_fused_worker.py), max_expand_workgroups
+ * keeps their waiting expands from filling that one device. */
+typedef struct spblas_gfx950_chunk_wait {
+  const void* flags;          /* this rank's flag array */
+  const int64_t* chunk_rows;  /* device */
+  int n_ranks, chunks;
+  int64_t step;               /* wait until the slots have reached this step */
+  int64_t timeout_ms;
+  int* status_dev;            /* device int[2] */
+  int max_expand_workgroups;  /* 0 = one workgroup per x slice */
+} spblas_gfx950_chunk_wait;
+int spblas_gfx950_spmv_chunk_rows(spblas_gfx950_plan_t plan, int chunks, int64_t* rows);
+int spblas_gfx950_spmv_step_bcast_chunked(spblas_gfx950_handle_t handle, spblas_gfx950_plan_t plan, const void* alpha,
+                                          const void* x, void* const* y_peers, int n_peers, int64_t y_row_offset,
+                                          int chunks, void* const* flag_peers, int rank, int64_t step,
+                                          const spblas_gfx950_chunk_wait* wait);
 int spblas_gfx950_step_signal(spblas_gfx950_handle_t handle, void* const* flag_peers, int n_peers, int rank,
                               int64_t step);
 int spblas_gfx950_step_wait(spblas_gfx950_handle_t handle, const void* flags, int n_peers, int64_t step,

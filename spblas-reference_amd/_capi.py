@@ -92,6 +92,9 @@ PROTOTYPES = [
      [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_i64, c_i64, c_i64]),
     ("spblas_gfx950_spmv_step_bcast", c_int,
      [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_i64, c_int]),
+    ("spblas_gfx950_spmv_chunk_rows", c_int, [c_void_p, c_int, ctypes.POINTER(c_i64)]),
+    ("spblas_gfx950_spmv_step_bcast_chunked", c_int,
+     [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_i64, c_int, c_void_p, c_int, c_i64, c_void_p]),
     ("spblas_gfx950_step_signal", c_int, [c_void_p, c_void_p, c_int, c_int, c_i64]),
     ("spblas_gfx950_step_wait", c_int, [c_void_p, c_void_p, c_int, c_i64, c_i64, c_void_p]),
     ("spblas_gfx950_bcast_wait_before", c_int, [c_void_p, c_void_p, c_int, c_i64, c_i64, c_void_p]),
@@ -124,6 +127,12 @@ class BackendError(RuntimeError):
 def library_path():
     # SPBLAS_GFX950_LIB: another build of the same library (tools/build_variant.sh: same-box A/B measurements only)
     return os.environ.get("SPBLAS_GFX950_LIB") or _build.LIBPATH
+
+
+class chunk_wait(ctypes.Structure):
+    """spblas_gfx950_chunk_wait (include/spblas_gfx950.h)."""
+    _fields_ = [("flags", c_void_p), ("chunk_rows", c_void_p), ("n_ranks", c_int), ("chunks", c_int), ("step", c_i64),
+                ("timeout_ms", c_i64), ("status_dev", c_void_p), ("max_expand_workgroups", c_int)]
 
 
 def lib():

@@ -30,6 +30,24 @@ struct spblas_gfx950_handle_s {
     int64_t step = 0, timeout_ms = 0;
     int* status_dev = nullptr;
   } bcast_wait;
+  // one-shot: the next expand waits, slice by slice, for the chunks of the peers' previous-step y its x slice is made of
+  // (spblas_gfx950_spmv_step_bcast_chunked; csrc/spmv_sliced.hip: pb_expand_kernel)
+  struct chunk_wait_t {
+    const long long* flags = nullptr;       // this rank's flag array [n_ranks * chunks]
+    const long long* chunk_rows = nullptr;  // device [n_ranks * (chunks + 1)]: global first row of every chunk
+    int n_ranks = 0, chunks = 0, rank = 0;
+    long long step = 0, timeout_ticks = 0;
+    int* status_dev = nullptr;              // [0] timed out, [1] longest wait of a workgroup in wall-clock ticks
+    int max_wgs = 0;                        // > 0: at most this many expand workgroups (several ranks sharing one device)
+  } chunk_wait;
+  // one-shot: the next K-split combine of a reduce_rows_bcast publishes a flag per chunk of rows itself -- the last
+  // workgroup of a chunk, after a system-scope fence -- instead of ending at a kernel boundary (pb_combine_publish_kernel)
+  struct chunk_pub_t {
+    void* const* flag_peers = nullptr;
+    int n_peers = 0, slot0 = 0, chunks = 0;
+    long long step = 0, rows_per_chunk = 0, delay_ticks = 0;
+  } chunk_pub;
+  int* chunk_done = nullptr;  // [64] arrival counters of the publishing combine (zero between launches)
   // second stream + fork/join events of the striped fused step (created on first use)
   hipStream_t aux_stream = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -230,6 +248,9 @@ struct readback_scope {
 // launches the device-side step barrier of the fused multi-GPU step (multigpu.hip)
 int launch_step_wait(spblas_gfx950_handle_s* h, const void* flags, int n_peers, int64_t step, int64_t timeout_ms,
                      int* status_dev);
+int launch_chunk_signal(spblas_gfx950_handle_s* h, hipStream_t s, void* const* flag_peers, int n_peers, int slot, int n_slots,
+                        int64_t step, int64_t delay_us);
+int wall_clock_khz(spblas_gfx950_handle_s* h);
 
 template <typename T>
 struct scalar_of;

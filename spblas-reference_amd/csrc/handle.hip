@@ -71,6 +71,10 @@ int spblas_gfx950_destroy(spblas_gfx950_handle_t handle) {
   }
   if (handle->pinned)
     (void) hipHostFree(handle->pinned);
+  if (handle->chunk_done) {
+    (void) hipDeviceSynchronize();
+    (void) hipFree(handle->chunk_done);
+  }
   delete handle;
   return SPBLAS_GFX950_STATUS_SUCCESS;
 }

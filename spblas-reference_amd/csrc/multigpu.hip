@@ -22,6 +22,21 @@ __global__ void step_signal_kernel(long long* const* __restrict__ flag_peers, in
     __hip_atomic_store(flag_peers[p] + rank, step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// chunked step: slot (rank * chunks + c) of every rank's flag array <- step, after the peer stores of chunk c (same stream)
+__global__ void chunk_signal_kernel(long long* const* __restrict__ flag_peers, int n_peers, int slot, int n_slots, long long step,
+                                    long long delay_ticks) {
+  if (delay_ticks > 0 && threadIdx.x == 0) {  // test hook: a deliberately late chunk
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < delay_ticks)
+      __builtin_amdgcn_s_sleep(32);
+  }
+  __syncthreads();
+  const int p = threadIdx.x;
+  if (p < n_peers)
+    for (int k = 0; k < n_slots; ++k)
+      __hip_atomic_store(flag_peers[p] + slot + k, step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // status[0] = 1 when the wait timed out (a peer died): the host checks it after synchronising.
 __global__ void step_wait_kernel(const long long* __restrict__ flags, int n_peers, long long step,
                                  long long timeout_ticks, int* __restrict__ status) {
@@ -36,6 +51,20 @@ __global__ void step_wait_kernel(const long long* __restrict__ flags, int n_peer
       return;
     }
   }
+}
+
+int wall_clock_khz(spblas_gfx950_handle_s* h) {
+  int rate_khz = 100000;  // wall_clock64 ticks at 100 MHz on gfx9
+  (void) hipDeviceGetAttribute(&rate_khz, hipDeviceAttributeWallClockRate, h->device);
+  return rate_khz > 0 ? rate_khz : 100000;
+}
+
+int launch_chunk_signal(spblas_gfx950_handle_s* h, hipStream_t s, void* const* flag_peers, int n_peers, int slot, int n_slots,
+                        int64_t step, int64_t delay_us) {
+  hipLaunchKernelGGL(chunk_signal_kernel, dim3(1), dim3(64), 0, s, reinterpret_cast<long long* const*>(flag_peers), n_peers, slot,
+                     n_slots, (long long) step, (long long) (delay_us * wall_clock_khz(h) / 1000));
+  SPB_HIP(hipGetLastError());
+  return SPBLAS_GFX950_STATUS_SUCCESS;
 }
 
 int launch_step_wait(spblas_gfx950_handle_s* h, const void* flags, int n_peers, int64_t step, int64_t timeout_ms,

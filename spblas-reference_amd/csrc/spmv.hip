@@ -873,6 +873,167 @@ int spblas_gfx950_spmv_step_bcast(spblas_gfx950_handle_t handle, spblas_gfx950_p
   return rc;
 }
 
+// Row boundaries of the chunks a chunked step cuts this plan's rows into (local rows, chunks + 1 entries, host array):
+// the stripes of spmv_step_bcast -- contiguous groups of whole reduce workgroups on the arithmetic bin grid.  A plan with
+// fewer stripes than asked for leaves the last chunks empty.
+static int chunk_layout(const spblas_gfx950_plan_s* plan, int chunks, int64_t* per_bins, int* n_str) {
+  const int64_t NB = plan->n_rblk, RW = plan->rwaves;
+  int64_t per = cdiv(cdiv(NB, RW), chunks) * RW;
+  if (per < RW)
+    per = RW;
+  *per_bins = per;
+  *n_str = plan->s_binrow ? 1 : (int) cdiv(NB, per);
+  return SPBLAS_GFX950_STATUS_SUCCESS;
+}
+
+// K-split plans (the shards of N >= 8 ranks): the combine kernel publishes the chunks itself, the reduce stays ONE launch
+static bool chunk_in_combine(spblas_gfx950_plan_s* plan) {
+  return !plan->s_nzrow && plan->n_split == 0 && spmv_sliced_full_ksplit(plan) > 1 &&
+         env_int_spmv("SPBLAS_GFX950_CHUNK_STRIPES", 0) == 0;
+}
+
+int spblas_gfx950_spmv_chunk_rows(spblas_gfx950_plan_t plan, int chunks, int64_t* rows) {
+  if (!plan || !rows)
+    return SPBLAS_GFX950_STATUS_INVALID_POINTER;
+  if (chunks < 1 || chunks > 64)
+    return SPBLAS_GFX950_STATUS_INVALID_SIZE;
+  if (plan->alg != SPBLAS_GFX950_SPMV_SLICED || plan->rest_plan || plan->m == 0 || plan->nnz == 0)
+    return SPBLAS_GFX950_STATUS_NOT_SUPPORTED;
+  if (chunk_in_combine(plan)) {  // chunks of whole combine workgroups (2 048 rows: spmv_sliced.hip PB_PUB_ROWS)
+    const int64_t rpc = cdiv(cdiv(plan->m, chunks), 2048) * 2048;
+    for (int c = 0; c <= chunks; ++c)
+      rows[c] = c * rpc < plan->m ? c * rpc : plan->m;
+    rows[chunks] = plan->m;
+    return SPBLAS_GFX950_STATUS_SUCCESS;
+  }
+  int64_t per = 0;
+  int n_str = 0;
+  chunk_layout(plan, chunks, &per, &n_str);
+  const int64_t H = plan->rows_per_blk;
+  for (int c = 0; c <= chunks; ++c) {
+    const int64_t b = c < n_str ? (int64_t) c * per : plan->n_rblk;
+    const int64_t r = n_str <= 1 ? (c == 0 ? 0 : plan->m) : b * H;
+    rows[c] = r < plan->m ? r : plan->m;
+  }
+  rows[chunks] = plan->m;
+  return SPBLAS_GFX950_STATUS_SUCCESS;
+}
+
+// Dependent iteration over row shards with the all-gather fused in AND overlapped with the next expand (round 4).  x must
+// be this rank's copy of the previous step's y (all ranks' rows, the buffer the peers stored into).  The expand waits per x
+// slice for the chunks of the peers' rows that slice is made of (wait->flags: this rank's flag array, slot q * chunks + c);
+// the reduce runs in `chunks` stripes as in spmv_step_bcast, each stripe's peer stores followed -- on the stripe's stream --
+// by a kernel that publishes slot rank * chunks + c = step in every rank's flag array.  wait == NULL: the first step (x is
+// complete everywhere: a plain expand).  No step barrier: buffer safety comes from the data dependence itself (a rank
+// overwrites copy k & 1 in step k + 2, whose expand has waited for every rank's chunks of step k + 1, which they publish
+// after their expand of step k + 1 has read copy k & 1).
+int spblas_gfx950_spmv_step_bcast_chunked(spblas_gfx950_handle_t handle, spblas_gfx950_plan_t plan, const void* alpha,
+                                          const void* x, void* const* y_peers, int n_peers, int64_t y_row_offset,
+                                          int chunks, void* const* flag_peers, int rank, int64_t step,
+                                          const spblas_gfx950_chunk_wait* wait) {
+  if (!handle)
+    return SPBLAS_GFX950_STATUS_INVALID_HANDLE;
+  struct disarm_t {
+    spblas_gfx950_handle_t h;
+    ~disarm_t() {
+      h->chunk_wait.flags = nullptr;
+    }
+  } disarm{handle};
+  if (!plan || !alpha || !x || !y_peers || !flag_peers)
+    return SPBLAS_GFX950_STATUS_INVALID_POINTER;
+  if (plan->alg != SPBLAS_GFX950_SPMV_SLICED || plan->rest_plan)
+    return SPBLAS_GFX950_STATUS_NOT_SUPPORTED;
+  if (n_peers < 1 || n_peers > 64 || rank < 0 || rank >= n_peers || y_row_offset < 0 || chunks < 1 || chunks > 64)
+    return SPBLAS_GFX950_STATUS_INVALID_SIZE;
+  if (plan->nnz == 0 || plan->m == 0 || plan->n_split > 0 || plan->s_binrow)
+    return SPBLAS_GFX950_STATUS_NOT_SUPPORTED;
+  if (wait) {
+    if (!wait->flags || !wait->chunk_rows || !wait->status_dev || wait->n_ranks != n_peers || wait->chunks != chunks)
+      return SPBLAS_GFX950_STATUS_INVALID_VALUE;
+    auto& cw = handle->chunk_wait;
+    cw.flags = static_cast<const long long*>(wait->flags);
+    cw.chunk_rows = reinterpret_cast<const long long*>(wait->chunk_rows);
+    cw.n_ranks = wait->n_ranks;
+    cw.chunks = wait->chunks;
+    cw.rank = rank;
+    cw.step = (long long) wait->step;
+    cw.timeout_ticks = (long long) wait->timeout_ms * wall_clock_khz(handle);
+    cw.status_dev = wait->status_dev;
+    cw.max_wgs = wait->max_expand_workgroups;
+  }
+  const double zero = 0.0;
+  const int64_t delay_us = env_int_spmv("SPBLAS_GFX950_CHUNK_DELAY_US", 0);  // test hook: chunk 1 of every step is late
+  hipStream_t main_s = handle->stream;
+  int rc;
+  if (chunk_in_combine(plan)) {
+    // one expand, one reduce, one combine that publishes its chunks as their last workgroup finishes
+    if (!handle->chunk_done) {
+      if (stream_capturing(main_s))
+        return SPBLAS_GFX950_STATUS_NOT_SUPPORTED;
+      SPB_HIP(hipMalloc((void**) &handle->chunk_done, 64 * sizeof(int)));
+      SPB_HIP(hipMemset(handle->chunk_done, 0, 64 * sizeof(int)));
+    }
+    if ((rc = spmv_sliced_expand(handle, plan, x)))
+      return rc;
+    auto& cp = handle->chunk_pub;
+    cp.flag_peers = flag_peers;
+    cp.n_peers = n_peers;
+    cp.slot0 = rank * chunks;
+    cp.chunks = chunks;
+    cp.step = (long long) step;
+    cp.rows_per_chunk = cdiv(cdiv(plan->m, chunks), 2048) * 2048;
+    cp.delay_ticks = (long long) (delay_us * wall_clock_khz(handle) / 1000);
+    rc = spmv_sliced_reduce_rows(handle, plan, alpha, &zero, nullptr, 0, plan->m, y_peers, n_peers, y_row_offset);
+    const bool consumed = cp.flag_peers == nullptr;
+    cp.flag_peers = nullptr;
+    if (rc)
+      return rc;
+    // (a reduce that did not end in the K-split combine after all: publish at the kernel boundary)
+    return consumed ? SPBLAS_GFX950_STATUS_SUCCESS
+                    : launch_chunk_signal(handle, main_s, flag_peers, n_peers, rank * chunks, chunks, step, 0);
+  }
+  int64_t per = 0;
+  int n_str = 0;
+  chunk_layout(plan, chunks, &per, &n_str);
+  const int64_t NB = plan->n_rblk, H = plan->rows_per_blk;
+  if (n_str <= 1) {
+    if ((rc = spmv_sliced_expand(handle, plan, x)))
+      return rc;
+    if ((rc = spmv_sliced_reduce_rows(handle, plan, alpha, &zero, nullptr, 0, plan->m, y_peers, n_peers, y_row_offset)))
+      return rc;
+    return launch_chunk_signal(handle, main_s, flag_peers, n_peers, rank * chunks, chunks, step, delay_us);
+  }
+  if (!handle->aux_stream) {
+    SPB_HIP(hipStreamCreateWithFlags(&handle->aux_stream, hipStreamNonBlocking));
+    SPB_HIP(hipEventCreateWithFlags(&handle->ev_fork, hipEventDisableTiming));
+    SPB_HIP(hipEventCreateWithFlags(&handle->ev_join, hipEventDisableTiming));
+  }
+  const int K = spmv_sliced_full_ksplit(plan);
+  if ((rc = spmv_sliced_reserve_partial(handle, plan, K)))
+    return rc;
+  if ((rc = spmv_sliced_expand(handle, plan, x)))
+    return rc;
+  SPB_HIP(hipEventRecord(handle->ev_fork, main_s));
+  SPB_HIP(hipStreamWaitEvent(handle->aux_stream, handle->ev_fork, 0));
+  const int64_t saved_cap = handle->max_ksplit;
+  handle->max_ksplit = K;
+  rc = SPBLAS_GFX950_STATUS_SUCCESS;
+  for (int c = 0; c < n_str && rc == SPBLAS_GFX950_STATUS_SUCCESS; ++c) {
+    const int64_t b0 = c * per, b1 = (c + 1) * per < NB ? (c + 1) * per : NB;
+    const int64_t r_lo = b0 * H, r_hi = b1 * H < plan->m ? b1 * H : plan->m;
+    handle->stream = (c & 1) ? handle->aux_stream : main_s;
+    rc = spmv_sliced_reduce_rows(handle, plan, alpha, &zero, nullptr, r_lo, r_hi, y_peers, n_peers, y_row_offset);
+    if (rc == SPBLAS_GFX950_STATUS_SUCCESS)  // (the chunks past the last stripe are empty: published with it)
+      rc = launch_chunk_signal(handle, handle->stream, flag_peers, n_peers, rank * chunks + c, c == n_str - 1 ? chunks - c : 1, step,
+                               c == 1 ? delay_us : 0);
+  }
+  handle->stream = main_s;
+  handle->max_ksplit = saved_cap;
+  SPB_HIP(hipEventRecord(handle->ev_join, handle->aux_stream));
+  SPB_HIP(hipStreamWaitEvent(main_s, handle->ev_join, 0));
+  return rc;
+}
+
 int spblas_gfx950_plan_destroy(spblas_gfx950_handle_t handle, spblas_gfx950_plan_t plan) {
   if (!handle)
     return SPBLAS_GFX950_STATUS_INVALID_HANDLE;

@@ -1004,6 +1004,15 @@ typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
 // tools/exp_r03o.sh, same binaries): where the reduce pays for the expand's write-backs (reduce 118-122 us after plain
 // stores) the hint moves that cost into the expand and the pair gains 1-3 %; where it does not (reduce 105-107 us) the hint
 // costs 3 %.  Default plain; a handle can ask for a timed trial at inspect (SPBLAS_GFX950_OPT_STORE_TRIAL, spmv.hip: store_trial).
+// what the expand of a chunked multi-GPU step waits for (flags == nullptr: an ordinary expand)
+struct pb_chunk_wait {
+  const long long* flags;
+  const long long* chunk_rows;
+  int n_ranks, chunks, rank;
+  long long step, timeout_ticks;
+  int* status_dev;
+};
+
 template <typename T, bool NT>
 __global__ __launch_bounds__(PB_THREADS) void pb_expand_kernel(int64_t n, int W, const int32_t* __restrict__ sliceblk,
                                                                const T* __restrict__ s_val,
@@ -1011,7 +1020,8 @@ __global__ __launch_bounds__(PB_THREADS) void pb_expand_kernel(int64_t n, int W,
                                                                const int32_t* __restrict__ blkdst,
                                                                const T* __restrict__ x, T* __restrict__ P,
                                                                const int4* __restrict__ items, int S, int share,
-                                                               const int32_t* __restrict__ blksrc) {
+                                                               const int32_t* __restrict__ blksrc, int n_items, int rot,
+                                                               pb_chunk_wait cw) {
   constexpr int PB_BLK = pb_geom<T>::BLK, LPB = PB_BLK / 4;  // lanes per block: 8 (fp32) / 4 (fp64)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   T* xs = reinterpret_cast<T*>(smem);
@@ -1019,22 +1029,71 @@ __global__ __launch_bounds__(PB_THREADS) void pb_expand_kernel(int64_t n, int W,
   const int sub = (tid & (LPB - 1)) * 4;  // first of this lane's 4 entries inside its block
   const int bsel = tid / LPB;             // block inside the workgroup's pass of PB_THREADS / LPB blocks
   constexpr int PASS = PB_THREADS / LPB;
+  // Chunked multi-GPU step (cw.flags != nullptr): x IS the previous step's y, row-sharded over cw.n_ranks ranks, and the
+  // peers deliver their rows chunk by chunk (peer stores + one flag per (rank, chunk) after the chunk's stores).  Before a
+  // workgroup loads an x slice it waits for exactly the chunks that slice is made of -- bounded, with s_sleep -- so the
+  // links drain behind this kernel instead of in front of it; an acquire fence then drops stale copies of the slice's lines.
+  auto wait_slice = [&](int s) {
+    if (!cw.flags)
+      return;
+    if (tid == 0) {
+      const long long c0 = (long long) s * W, c1 = (c0 + W) < (long long) n ? (c0 + W) : (long long) n;
+      const long long t0 = wall_clock64();
+      bool late = false;
+      for (int q = 0; q < cw.n_ranks && !late; ++q) {
+        if (q == cw.rank)
+          continue;  // my own rows: stream order
+        const long long* cr = cw.chunk_rows + (long long) q * (cw.chunks + 1);
+        if (cr[cw.chunks] <= c0 || cr[0] >= c1)
+          continue;
+        for (int c = 0; c < cw.chunks && !late; ++c) {
+          if (cr[c + 1] <= c0 || cr[c] >= c1 || cr[c + 1] <= cr[c])
+            continue;
+          const long long* f = cw.flags + (long long) q * cw.chunks + c;
+          while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < cw.step) {
+            __builtin_amdgcn_s_sleep(8);
+            if (wall_clock64() - t0 > cw.timeout_ticks) {
+              cw.status_dev[0] = 1;
+              late = true;
+              break;
+            }
+          }
+        }
+      }
+      const long long waited = wall_clock64() - t0;
+      if (waited > 200)  // (2 us at 100 MHz: not every workgroup needs to touch the counter)
+        atomicMax(cw.status_dev + 1, (int) (waited < 0x7fffffffLL ? waited : 0x7fffffffLL));
+    }
+    __syncthreads();
+#ifdef PB_CHUNK_ACQ_FENCE
+    // the slice's lines were written by other devices after this kernel started: drop what this XCD's caches hold of
+    // them (an invalidate, not a write-back), then load the slice with the ordinary 16-byte loads
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+#endif
+  };
   auto load_x = [&](int s) {
     const int64_t c0 = (int64_t) s * W;
-    const int cw = (int) ((n - c0) < W ? (n - c0) : W);
+    const int cw_ = (int) ((n - c0) < W ? (n - c0) : W);
+#ifndef PB_CHUNK_ACQ_FENCE  // (A/B: an acquire fence + ordinary loads instead: 141 against 117 us for the shard step)
+    if (cw.flags) {
+      for (int i = tid; i < cw_; i += PB_THREADS)
+        xs[i] = __hip_atomic_load(x + c0 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      return;
+    }
+#endif
     // 16-byte lane loads when the slice starts on a 16-byte boundary (W is a multiple of 4; x itself usually is aligned):
     // a quarter of the load and LDS-store instructions of the 160 KiB fill
     constexpr int VE = 16 / (int) sizeof(T);
     if ((reinterpret_cast<uintptr_t>(x + c0) & 15) == 0) {
       typedef T vec_t __attribute__((ext_vector_type(VE)));
-      const int nv = cw / VE;
+      const int nv = cw_ / VE;
       for (int i = tid; i < nv; i += PB_THREADS)
         reinterpret_cast<vec_t*>(xs)[i] = reinterpret_cast<const vec_t*>(x + c0)[i];
-      for (int i = nv * VE + tid; i < cw; i += PB_THREADS)
+      for (int i = nv * VE + tid; i < cw_; i += PB_THREADS)
         xs[i] = x[c0 + i];
       return;
     }
-    for (int i = tid; i < cw; i += PB_THREADS)
+    for (int i = tid; i < cw_; i += PB_THREADS)
       xs[i] = x[c0 + i];
   };
   // blocks [b0, b1) of the slice whose x values are in LDS; two passes in flight.  nt_tag (A/B builds only): products stored
@@ -1099,10 +1158,19 @@ __global__ __launch_bounds__(PB_THREADS) void pb_expand_kernel(int64_t n, int W,
   if (items) {
     // items (column-skewed matrices): workgroup i takes the blocks [items[i].y, items[i].z) of slice items[i].x,
     // so that a slice holding a large share of the matrix is spread over proportionally many workgroups
-    const int4 item = items[blockIdx.x];
-    load_x(item.x);
-    __syncthreads();
-    process(item.y, item.z);
+    // (rot: the chunked multi-GPU step starts every rank on its OWN slices -- nothing to wait for -- and goes round the
+    // ranks from there; a grid smaller than the list walks it in strides)
+    for (int it = blockIdx.x; it < n_items; it += gridDim.x) {
+      int idx = it + rot;
+      idx = idx >= n_items ? idx - n_items : idx;
+      const int4 item = items[idx];
+      if (it != (int) blockIdx.x)
+        __syncthreads();  // everyone is done with the previous x slice
+      wait_slice(item.x);
+      load_x(item.x);
+      __syncthreads();
+      process(item.y, item.z);
+    }
     return;
   }
   // Equal shares: workgroup b takes the blocks [b*share, (b+1)*share) of A' and loads the x slice of every
@@ -1110,7 +1178,9 @@ __global__ __launch_bounds__(PB_THREADS) void pb_expand_kernel(int64_t n, int W,
   // exactly one wave of workgroups whatever the slice count is (slices cut for LDS capacity rarely come in
   // multiples of 512; a second, nearly empty round of whole-slice workgroups cost up to 2x).
   const int total = sliceblk[S];
-  const long long g0l = (long long) blockIdx.x * share;
+  int bid = (int) blockIdx.x + rot;
+  bid = bid >= (int) gridDim.x ? bid - (int) gridDim.x : bid;
+  const long long g0l = (long long) bid * share;
   int g0 = g0l < total ? (int) g0l : total;
   const int g1 = (total - g0) < share ? total : g0 + share;
   if (g0 >= g1)
@@ -1129,6 +1199,7 @@ __global__ __launch_bounds__(PB_THREADS) void pb_expand_kernel(int64_t n, int W,
       continue;  // empty slice
     const int a1 = g1 < slice_end ? g1 : slice_end;
     __syncthreads();  // everyone is done with the previous x slice
+    wait_slice(s);
     load_x(s);
     __syncthreads();
     process(g0, a1);
@@ -1472,6 +1543,61 @@ __global__ __launch_bounds__(256) void pb_combine_kernel(int64_t r_lo, int64_t r
     return;
   }
   y[i] = beta == T(0) ? alpha * s : alpha * s + beta * y[i];
+}
+
+// The same for the chunked multi-GPU step (peer stores only, no row map): the rows are published to the peers chunk by
+// chunk WITHOUT a kernel boundary per chunk -- splitting the reduce into stripes costs 28 / 55 us for 2 / 4 stripes on a
+// 1.25 M-row shard (profiles/r03_shards_and_fused_floor.md), extra launches cost as much.  Workgroups are dispatched in row
+// order; every workgroup ends with a system-scope release fence and counts itself into its chunk's arrival counter, and the
+// workgroup that completes a chunk stores `step` into slot slot0 + chunk of every rank's flag array.  (Ordering by hand:
+// rows and flags are both system-scope write-through stores; a workgroup counts itself in only after its stores were
+// acknowledged; the agent-scope counter is an atomic in memory, not in an L2.  Exercised with ranks that share ONE device --
+// across devices nothing of this has run yet.)
+static constexpr int PB_PUB_ROWS = 2048;  // rows per workgroup of the publishing combine (chunks are multiples of it)
+template <typename T>
+__global__ __launch_bounds__(256) void pb_combine_publish_kernel(int64_t r_lo, int64_t r_hi, int K,
+                                                                 const T* __restrict__ partial, int64_t pstride, T alpha,
+                                                                 T* const* __restrict__ peers, int n_peers, int64_t peer_off,
+                                                                 long long* const* __restrict__ flag_peers, int slot0,
+                                                                 int chunks, long long rows_per_chunk, long long step,
+                                                                 int* __restrict__ done, long long delay_ticks) {
+  // (2 048 rows per workgroup, not 256: the arrival counters are same-address atomics, ~11 ns each one after the other --
+  // 4 883 of them made the combine of a 1.25 M-row shard 55 us instead of 5)
+#pragma unroll
+  for (int u = 0; u < PB_PUB_ROWS / 256; ++u) {
+    const int64_t i = r_lo + (int64_t) blockIdx.x * PB_PUB_ROWS + u * 256 + threadIdx.x;
+    if (i < r_hi) {
+      T s = partial[i];
+      for (int k = 1; k < K; ++k)
+        s += partial[(int64_t) k * pstride + i];
+      // write-through, system-scope stores: nothing of y stays dirty in this XCD's L2, so "visible everywhere" is "all my
+      // stores have been acknowledged" -- a system-scope release FENCE instead writes the whole L2 back, per workgroup:
+      // 241 instead of 62 us for the step of a 1.25 M-row shard (tools/chunk_overhead.py)
+      for (int p = 0; p < n_peers; ++p)
+        __hip_atomic_store(peers[p] + peer_off + i, alpha * s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): this wavefront's stores have been acknowledged
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const long long first = (long long) blockIdx.x * PB_PUB_ROWS;
+    long long c = first / rows_per_chunk;
+    c = c < chunks ? c : chunks - 1;
+    const long long c_lo = c * rows_per_chunk;
+    const long long c_hi = (c == chunks - 1 || (c + 1) * rows_per_chunk > (long long) (r_hi - r_lo)) ? (long long) (r_hi - r_lo)
+                                                                                                    : (c + 1) * rows_per_chunk;
+    const int wgs = (int) ((c_hi - c_lo + PB_PUB_ROWS - 1) / PB_PUB_ROWS);
+    if (__hip_atomic_fetch_add(done + c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == wgs - 1) {
+      __hip_atomic_store(done + c, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (the next step counts from zero)
+      if (delay_ticks > 0 && c == 1) {  // test hook: a deliberately late chunk
+        const long long t0 = wall_clock64();
+        while (wall_clock64() - t0 < delay_ticks)
+          __builtin_amdgcn_s_sleep(32);
+      }
+      for (int p = 0; p < n_peers; ++p)
+        __hip_atomic_store(flag_peers[p] + slot0 + c, step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
 }
 
 // Rows that were kept out of the tiles (longer than plan->hub_len).  gridDim.y workgroups share a row
@@ -2424,20 +2550,40 @@ static int sliced_expand_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* p
     nwg = 1;
   if (env_int("SPBLAS_GFX950_PB_DBG", 0) & 4)
     return SPBLAS_GFX950_STATUS_SUCCESS;  // timing experiment: the reduce alone
+  // one-shot from spblas_gfx950_spmv_step_bcast_chunked: this expand waits, slice by slice, for the peers' chunks of x
+  pb_chunk_wait cw = {nullptr, nullptr, 0, 0, 0, 0, 0, nullptr};
+  int rot_ranks = 0, rot_of = 1, cap = 0;
+  {
+    auto& hw = h->chunk_wait;
+    if (hw.flags) {
+      cw = {hw.flags, hw.chunk_rows, hw.n_ranks, hw.chunks, hw.rank, hw.step, hw.timeout_ticks, hw.status_dev};
+      rot_ranks = hw.rank;
+      rot_of = hw.n_ranks > 0 ? hw.n_ranks : 1;
+      cap = hw.max_wgs;
+      hw.flags = nullptr;
+    }
+  }
+  if (cap > 0 && nwg > cap)
+    nwg = cap;
   const int share = (int) cdiv(total, nwg);
-  const dim3 grid = items ? dim3((unsigned) pl->n_xitems) : dim3((unsigned) cdiv(total, share));
+  dim3 grid = items ? dim3((unsigned) pl->n_xitems) : dim3((unsigned) cdiv(total, share));
+  if (items && cap > 0 && (int64_t) cap < pl->n_xitems)
+    grid = dim3((unsigned) cap);
+  // (a waiting expand starts every rank on the work that reads its OWN rows of x -- nothing to wait for -- and goes round
+  // the ranks from there: the slices follow the rows of x, and so do the items and the shares of A')
+  const int rot = (int) ((int64_t) rot_ranks * (items ? pl->n_xitems : (int64_t) grid.x) / rot_of);
   if (pl->nt_products)
     hipLaunchKernelGGL((pb_expand_kernel<T, true>), grid, dim3(PB_THREADS), xbytes, h->stream, pl->n, pl->slice_cols,
                        static_cast<const int32_t*>(pl->s_sliceblk), static_cast<const T*>(pl->s_values),
                        reinterpret_cast<const uint16_t*>(pl->s_colind), static_cast<const int32_t*>(pl->s_blkdst),
                        static_cast<const T*>(x), static_cast<T*>(pl->s_products), items, (int) pl->n_slices, share,
-                       static_cast<const int32_t*>(pl->s_blksrc));
+                       static_cast<const int32_t*>(pl->s_blksrc), (int) pl->n_xitems, rot, cw);
   else
     hipLaunchKernelGGL((pb_expand_kernel<T, false>), grid, dim3(PB_THREADS), xbytes, h->stream, pl->n, pl->slice_cols,
                        static_cast<const int32_t*>(pl->s_sliceblk), static_cast<const T*>(pl->s_values),
                        reinterpret_cast<const uint16_t*>(pl->s_colind), static_cast<const int32_t*>(pl->s_blkdst),
                        static_cast<const T*>(x), static_cast<T*>(pl->s_products), items, (int) pl->n_slices, share,
-                       static_cast<const int32_t*>(pl->s_blksrc));
+                       static_cast<const int32_t*>(pl->s_blksrc), (int) pl->n_xitems, rot, cw);
   SPB_HIP(hipGetLastError());
   return SPBLAS_GFX950_STATUS_SUCCESS;
 }
@@ -2601,7 +2747,15 @@ static int sliced_reduce_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* p
         if (rc_w)
           return rc_w;
       }
-      if (K > 1 && r_hi > r_lo)
+      if (K > 1 && r_hi > r_lo && h->chunk_pub.flag_peers && peers_p && !rowmap) {
+        // chunked multi-GPU step: the combine publishes its rows chunk by chunk itself (one-shot)
+        const auto cp = h->chunk_pub;
+        h->chunk_pub.flag_peers = nullptr;
+        hipLaunchKernelGGL((pb_combine_publish_kernel<T>), dim3((unsigned) cdiv(r_hi - r_lo, PB_PUB_ROWS)), dim3(256), 0, s, r_lo, r_hi,
+                           K, static_cast<const T*>(pl->s_partial), pl->s_m, alpha, reinterpret_cast<T* const*>(peers_p),
+                           n_peers, peer_off, reinterpret_cast<long long* const*>(cp.flag_peers), cp.slot0, cp.chunks,
+                           cp.rows_per_chunk, cp.step, h->chunk_done, cp.delay_ticks);
+      } else if (K > 1 && r_hi > r_lo)
         hipLaunchKernelGGL((pb_combine_kernel<T>), dim3((unsigned) cdiv(r_hi - r_lo, 256)), dim3(256), 0, s, r_lo, r_hi, K,
                            static_cast<const T*>(pl->s_partial), pl->s_m, static_cast<T*>(y), alpha, beta,
                            reinterpret_cast<T* const*>(peers_p), n_peers, peer_off, rowmap, piece_out);

@@ -383,9 +383,13 @@ class FusedShardedSpMV:
     finished consuming step k.  Requires equal row shards and a SLICED local plan; raises otherwise so
     that callers fall back to ShardedSpMV (RCCL all-gather)."""
 
-    def __init__(self, a_local, bounds, group=None, alg=None, timeout_ms=20000, info=None, stripes=1):
+    def __init__(self, a_local, bounds, group=None, alg=None, timeout_ms=20000, info=None, stripes=1, chunks=0,
+                 shared_device=False):
         """info: an operation_info_t from multiply_inspect on the SAME a_local may be passed to reuse its plan
-        (no second inspect; results bit-identical to the path that plan also serves)."""
+        (no second inspect; results bit-identical to the path that plan also serves).
+        chunks > 0 prepares step_dependent(): the dependent iteration whose peer rows arrive chunk by chunk behind the next
+        expand (spblas_gfx950_spmv_step_bcast_chunked); shared_device: several ranks run on ONE device (tests, bench.py
+        --debug-one-gpu) -- their waiting expands are kept to a fraction of the device so that they cannot starve each other."""
         import ctypes
         if not (dist.is_available() and dist.is_initialized()):
             raise RuntimeError("FusedShardedSpMV needs an initialised process group")
@@ -416,26 +420,44 @@ class FusedShardedSpMV:
             if not isinstance(self.info.state_, api._Plan) or self.info.state_.info()["alg"] != api._capi.SPMV_SLICED:
                 raise RuntimeError("FusedShardedSpMV needs a SLICED local plan")
             # buffers: two copies of y, one flag array (slot q = last step signalled by rank q)
-            self._bufs = [_IpcBuffer(self.m * item), _IpcBuffer(self.m * item), _IpcBuffer(self.world * 8, uncached=True)]
+            self.chunks = max(0, int(chunks))
+            if self.world * max(self.chunks, 1) > 64:
+                raise RuntimeError("FusedShardedSpMV: ranks x chunks must not exceed 64")
+            self._bufs = [_IpcBuffer(self.m * item), _IpcBuffer(self.m * item), _IpcBuffer(self.world * 8, uncached=True),
+                          _IpcBuffer(self.world * max(self.chunks, 1) * 8, uncached=True)]
             self.y = [self._bufs[0].tensor(self.dtype, self.m), self._bufs[1].tensor(self.dtype, self.m)]
             self.flags = self._bufs[2].tensor(torch.int64, self.world)
-            mine = [b.handle() for b in self._bufs]
+            self.chunk_flags = self._bufs[3].tensor(torch.int64, self.world * max(self.chunks, 1))
+            my_rows = None
+            if self.chunks:
+                rows = (ctypes.c_int64 * (self.chunks + 1))()
+                api.check(api._capi.lib().spblas_gfx950_spmv_chunk_rows(self.info.state_.plan, self.chunks, rows),
+                          "spmv_chunk_rows")
+                my_rows = [self.bounds[self.rank] + int(r) for r in rows]
+            mine = [b.handle() for b in self._bufs] + [my_rows]
         except Exception as e:  # noqa: BLE001 - reported after the agreement
             err, mine = e, None
         self._agree(err, "preparing the local plan and buffers")
         everyone = [None] * self.world
         dist.all_gather_object(everyone, mine, group=group)
-        ptrs = [[0] * self.world for _ in range(3)]
+        ptrs = [[0] * self.world for _ in range(4)]
         try:
             for q in range(self.world):
-                for j in range(3):
+                for j in range(4):
                     if q == self.rank:
                         ptrs[j][q] = self._bufs[j].ptr
                     else:
                         ptrs[j][q] = _ipc_open(everyone[q][j])
                         self._opened.append(ptrs[j][q])
-            self._tabs = [torch.tensor(ptrs[j], dtype=torch.int64, device=self.device) for j in range(3)]
+            self._tabs = [torch.tensor(ptrs[j], dtype=torch.int64, device=self.device) for j in range(4)]
             self._status = torch.zeros(1, dtype=torch.int32, device=self.device)
+            self._chunk_status = torch.zeros(2, dtype=torch.int32, device=self.device)  # [timed out, longest wait in ticks]
+            self._chunk_rows = None
+            if self.chunks:
+                self._chunk_rows = torch.tensor([r for q in range(self.world) for r in everyone[q][4]], dtype=torch.int64,
+                                                device=self.device)
+            cus = torch.cuda.get_device_properties(self.device).multi_processor_count
+            self._max_wgs = max(1, cus // (2 * self.world)) if shared_device else 0
             torch.cuda.synchronize()
         except Exception as e:  # noqa: BLE001
             err = e
@@ -445,6 +467,7 @@ class FusedShardedSpMV:
         self._plan = self.info.state_
         self._x, self._xp = None, None
         self._pending = False  # a pipelined step whose wait has not been issued yet
+        self._chained = False  # the last step was a step_dependent(): its rows arrive behind chunk flags, not a barrier
 
     def _agree(self, err, what):
         """Collective: raise on every rank if any rank failed."""
@@ -455,10 +478,65 @@ class FusedShardedSpMV:
             self._release()
             raise RuntimeError(f"FusedShardedSpMV: a rank failed while {what}" + (f": {err}" if err is not None else ""))
 
+    def step_dependent(self, x=None, alpha=None):
+        """One step of the dependent iteration y_{k+1} = alpha * A y_k WITHOUT a step barrier (constructor: chunks > 0).
+        x given: the chain starts here (x is complete on every rank: a plain expand).  x None: multiply the y this operator
+        produced last -- the expand waits, x slice by x slice, for the chunks of the peers' rows that slice is made of, so
+        the link time of step k hides behind the expand of step k + 1; flush_chain() before reading y on the host or
+        handing it to anything but the next step_dependent().  Bit-identical to step() on the same vectors."""
+        ct, lib = self._ct, api._capi.lib()
+        if not self.chunks:
+            raise RuntimeError("FusedShardedSpMV: created without chunks")
+        if x is not None:
+            self.flush()
+            self.flush_chain()
+        elif not self._step:
+            raise RuntimeError("step_dependent(): nothing to continue from")
+        elif not self._chained:
+            self.flush()  # the last step ended with the barrier: its y is complete here, nothing to wait for
+        wait = None
+        if x is None:
+            x = self.y[self._step & 1]
+            if self._chained:
+                wait = api._capi.chunk_wait(self.chunk_flags.data_ptr(), self._chunk_rows.data_ptr(), self.world, self.chunks,
+                                            self._step, self._timeout, self._chunk_status.data_ptr(), self._max_wgs)
+        self._step += 1
+        b = self._step & 1
+        a = self._alpha if alpha is None else type(self._alpha)(alpha)
+        h, plan = api._Handle.current(self.device).h, self._plan.plan
+        api.check(lib.spblas_gfx950_spmv_step_bcast_chunked(h, plan, ct.byref(a), ct.c_void_p(x.data_ptr()),
+                                                            ct.c_void_p(self._tabs[b].data_ptr()), self.world,
+                                                            self.bounds[self.rank], self.chunks,
+                                                            ct.c_void_p(self._tabs[3].data_ptr()), self.rank, self._step,
+                                                            ct.byref(wait) if wait is not None else None),
+                  "spmv_step_bcast_chunked")
+        self._chained = True
+        self._keep_x = x
+        return self.y[b]
+
+    def flush_chain(self):
+        """Wait (on the device) until every rank's chunks of the last step_dependent() have arrived in this rank's copy."""
+        if self._chained:
+            ct, lib = self._ct, api._capi.lib()
+            h = api._Handle.current(self.device).h
+            api.check(lib.spblas_gfx950_step_wait(h, ct.c_void_p(self.chunk_flags.data_ptr()), self.world * self.chunks,
+                                                  self._step, self._timeout, ct.c_void_p(self._chunk_status.data_ptr())),
+                      "step_wait")
+            self._chained = False
+        return self.y[self._step & 1]
+
+    def chunk_wait_us(self, reset=True):
+        """Longest time a workgroup of a waiting expand has spent on its chunk flags since the last reset (host sync)."""
+        ticks = int(self._chunk_status[1].item())
+        if reset:
+            self._chunk_status[1] = 0
+        return ticks / 100.0  # wall_clock64: 100 MHz on gfx9
+
     def step(self, x, events=None):
         """One sharded SpMV; returns the full y (valid on this rank once the stream reaches this point)."""
         ct, lib = self._ct, api._capi.lib()
         self.flush()  # (a pipelined step before this one: its wait comes first)
+        self.flush_chain()
         if self._x is not x:
             self._x, self._xp = x, ct.c_void_p(x.data_ptr())
         self._step += 1
@@ -487,6 +565,7 @@ class FusedShardedSpMV:
         before it signals).  A dependent iteration (x_k+1 = f(y_k)) needs step().  Buffer safety: a peer overwrites my
         copy k & 1 in its step k + 2, which it starts after my signal of step k + 1, which I send after my wait of step k."""
         ct, lib = self._ct, api._capi.lib()
+        self.flush_chain()
         if self._x is not x:
             self._x, self._xp = x, ct.c_void_p(x.data_ptr())
         self._step += 1
@@ -519,6 +598,8 @@ class FusedShardedSpMV:
         """After a host synchronisation: raise if a step barrier timed out (a peer stopped responding)."""
         if int(self._status.item()) != 0:
             raise RuntimeError("FusedShardedSpMV: step barrier timed out")
+        if int(self._chunk_status[0].item()) != 0:
+            raise RuntimeError("FusedShardedSpMV: a chunk of a peer's rows did not arrive in time")
 
     def close(self):
         torch.cuda.synchronize()
@@ -534,13 +615,14 @@ class FusedShardedSpMV:
         for p in self._opened:
             lib.spblas_gfx950_ipc_close(self._ct.c_void_p(p))
         self._opened = []
-        self.y, self.flags = [], None
+        self.y, self.flags, self.chunk_flags = [], None, None
         for b in self._bufs:
             b.free()
         self._bufs = []
 
 
-def try_fused(a_local, bounds, x, reference_step, alg=None, group=None, log=None, info=None, stripes=1):
+def try_fused(a_local, bounds, x, reference_step, alg=None, group=None, log=None, info=None, stripes=1, chunks=0,
+              shared_device=False):
     """Collective.  Returns a FusedShardedSpMV if EVERY rank could set it up and its full y agrees with
     `reference_step(x_k)` (the RCCL all-gather path) on every rank for FOUR different vectors x_k; otherwise
     None, with everything the attempt allocated released again.  Never raises: any failure means "keep the
@@ -562,7 +644,8 @@ def try_fused(a_local, bounds, x, reference_step, alg=None, group=None, log=None
     import inspect as _inspect
     fused, same = None, 0
     try:
-        fused = FusedShardedSpMV(a_local, bounds, group=group, alg=alg, info=info, timeout_ms=3000, stripes=stripes)
+        fused = FusedShardedSpMV(a_local, bounds, group=group, alg=alg, info=info, timeout_ms=3000, stripes=stripes,
+                                 chunks=chunks, shared_device=shared_device)
         takes_x = len(_inspect.signature(reference_step).parameters) >= 1
         xs = [x, 2.0 * x, x + 1.0, 0.5 * x - 1.0] if takes_x else [x, x, x]
         # Every rank issues the SAME collective sequence whatever happens locally: all reference steps (RCCL

@@ -108,9 +108,52 @@ def main():
     # a rank that cannot build a SLICED plan (forced row-block here) makes every rank fall back, no hang
     bad_alg = sp._capi.SPMV_ROWBLOCK if rank == 0 else sp._capi.SPMV_SLICED
     assert sharded.try_fused(a_loc, bounds, x, reference_step, alg=bad_alg) is None
+    # The dependent iteration without a step barrier (round 4): y_{k+1} = alpha * A y_k, the peers' rows of step k
+    # arriving chunk by chunk behind the expand of step k + 1 (spblas_gfx950_spmv_step_bcast_chunked).  Needs a square
+    # matrix; compared bit for bit with the same chain through step() (full barrier after every step) on the same plan;
+    # then once more with chunk 1 of every step deliberately late on ONE rank: the other ranks' expands have to wait
+    # for it (and report that they did), the bits stay the same.
+    chunks = int(os.environ.get("FUSED_CHUNKS", "0"))
+    if chunks:
+        msq = 64000 * world
+        v2, rp2, ci2, shape2, _ = generate.uniform_csr_device(msq, msq, per_row, dtype=dtype, seed=3, device=dev)
+        b2 = sharded.partition_rows_even(msq, world)
+        a2 = sharded.shard_csr(v2, rp2, ci2, shape2, b2[rank], b2[rank + 1])
+        op2 = sharded.FusedShardedSpMV(a2, b2, alg=sp._capi.SPMV_SLICED, timeout_ms=8000, chunks=chunks, shared_device=True)
+        x0 = torch.rand(msq, dtype=dtype, device=dev, generator=g)
+        nsteps = 7  # (entries in [0, 1): y grows by ~2.2x per step, far from overflow)
+        y = op2.step(x0).clone()
+        ref_chain = [y.clone()]
+        for _ in range(nsteps - 1):
+            y = op2.step(y.clone()).clone()
+            ref_chain.append(y.clone())
+        torch.cuda.synchronize()
+        op2.check_status()
+        for delay in ("0", "4000"):
+            if rank == world - 1:
+                os.environ["SPBLAS_GFX950_CHUNK_DELAY_US"] = delay
+            dist.barrier()
+            y = op2.step_dependent(x0, alpha=1.0)
+            for _ in range(nsteps - 1):
+                y = op2.step_dependent(alpha=1.0)
+            y = op2.flush_chain()
+            torch.cuda.synchronize()
+            op2.check_status()
+            assert torch.equal(y, ref_chain[-1]), f"rank {rank}: chunked chain differs from the barrier chain (delay {delay})"
+            waited = op2.chunk_wait_us()
+            if delay != "0" and world > 1 and chunks > 1 and rank != world - 1:
+                assert waited >= 2000.0, f"rank {rank}: no expand waited for the late chunk ({waited} us)"
+            # a step() after the chain flushes it; both copies of y are in use again afterwards
+            assert torch.equal(op2.step(x0), ref_chain[0])
+        os.environ.pop("SPBLAS_GFX950_CHUNK_DELAY_US", None)
+        # every rank holds the same bits
+        parts = [None] * world
+        dist.all_gather_object(parts, ref_chain[-1].cpu().numpy().tobytes())
+        assert all(pb == parts[0] for pb in parts)
+        op2.close()
     dist.barrier()
     if rank == 0:
-        print("FUSED_OK", world, str(dtype), "stripes", stripes)
+        print("FUSED_OK", world, str(dtype), "stripes", stripes, "chunks", chunks)
     dist.destroy_process_group()
 
 
