@@ -17,7 +17,8 @@ HOOKS = ["SPBLAS_GFX950_SLICE_COLS", "SPBLAS_GFX950_SLICE_ROWS", "SPBLAS_GFX950_
          "SPBLAS_GFX950_PB_RBATCH", "SPBLAS_GFX950_PB_RLDS_KB", "SPBLAS_GFX950_PB_BINS", "SPBLAS_GFX950_PB_VARBINS",
          "SPBLAS_GFX950_PB_HUB_LEN", "SPBLAS_GFX950_PB_COMPACT", "SPBLAS_GFX950_PB_ENC8", "SPBLAS_GFX950_PB_ENC8_FAIL",
          "SPBLAS_GFX950_PB_LPT", "SPBLAS_GFX950_PB_XITEM_DIV", "SPBLAS_GFX950_PB_RITEMS", "SPBLAS_GFX950_PB_XLDS_KB",
-         "SPBLAS_GFX950_PB_STAGED_SCATTER", "SPBLAS_GFX950_PB_SPLIT_LEN", "SPBLAS_GFX950_PB_RUN_MIN", "SPBLAS_GFX950_PB_NT", "SPBLAS_GFX950_PB_TUNE_MIN"]
+         "SPBLAS_GFX950_PB_STAGED_SCATTER", "SPBLAS_GFX950_PB_SPLIT_LEN", "SPBLAS_GFX950_PB_RUN_MIN", "SPBLAS_GFX950_PB_NT", "SPBLAS_GFX950_PB_TUNE_MIN",
+         "SPBLAS_GFX950_PB_HOT", "SPBLAS_GFX950_PB_HOT_MIN_PCT"]
 dev = torch.device("cuda:0")
 bad = 0
 for it in range(iters):
@@ -26,11 +27,13 @@ for it in range(iters):
         os.environ.pop(h, None)
     m = int(rng.choice([1, 7, 300, 5000, 40000, 150000]))
     n = int(rng.choice([1, 13, 999, 20000, 70000, 300000]))
-    kind = rng.choice(["uniform", "powerlaw", "banded", "sparse_rows", "dups"])
+    kind = rng.choice(["uniform", "powerlaw", "banded", "sparse_rows", "dups", "hotcols", "hotcols"])
     if kind == "uniform":
         lens = rng.integers(0, 24, m)
-    elif kind == "powerlaw":
+    elif kind == "powerlaw" or (kind == "hotcols" and rng.random() < 0.5):
         lens = np.minimum(rng.zipf(1.5, m), 30000)
+    elif kind == "hotcols":
+        lens = rng.integers(0, 40, m)
     elif kind == "banded":
         lens = np.full(m, min(n, 9))
     elif kind == "sparse_rows":
@@ -47,12 +50,19 @@ for it in range(iters):
         colind = ((rows * max(n // max(m, 1), 1) + rng.integers(0, min(n, 50), nnz)) % n).astype(np.int32)
     elif kind == "dups":
         colind = rng.integers(0, max(1, min(n, 40)), nnz).astype(np.int32)   # few distinct columns: many duplicates
+    elif kind == "hotcols":  # round 4: a few columns carry most of the entries (the hot-column split of the SLICED plan)
+        nh = int(rng.choice([1, 5, 200, 5000]))
+        hot_set = rng.integers(0, n, nh)
+        is_hot = rng.random(nnz) < rng.choice([0.2, 0.6, 0.95])
+        colind = np.where(is_hot, hot_set[rng.integers(0, nh, nnz)], rng.integers(0, n, nnz)).astype(np.int32)
     else:
         colind = rng.integers(0, n, nnz).astype(np.int32)
     dtype = rng.choice([np.float32, np.float64])
     values = (rng.random(nnz) - (0.5 if rng.random() < 0.5 else 0.0)).astype(dtype)
     x = (rng.random(n) - 0.5).astype(dtype)
     alg = rng.choice(["auto", "vector", "rowblock", "sliced", "none"])
+    if os.environ.get("FUZZ_FORCE_HOT"):  # round 4: every case through the SLICED plan with the hot-column split forced
+        alg = "sliced"
     off64 = bool(rng.random() < 0.3)
     hooks = {}
     if alg == "sliced":
@@ -86,6 +96,11 @@ for it in range(iters):
             hooks["SPBLAS_GFX950_PB_TUNE_MIN"] = "0"
         if rng.random() < 0.3:
             hooks["SPBLAS_GFX950_PB_RUN_MIN"] = str(int(rng.choice([1, 8, 64])))
+        # round 4: hot-column split off / by rule / forced, with the coverage threshold down to "whatever the sample shows"
+        hooks["SPBLAS_GFX950_PB_HOT"] = str(int(rng.choice([-1, 0, 1, 1, 1])))
+        hooks["SPBLAS_GFX950_PB_HOT_MIN_PCT"] = str(int(rng.choice([0, 1, 15])))
+        if os.environ.get("FUZZ_FORCE_HOT"):
+            hooks["SPBLAS_GFX950_PB_HOT"], hooks["SPBLAS_GFX950_PB_HOT_MIN_PCT"] = "1", "0"
     os.environ.update(hooks)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     rp_dev = t(rowptr.astype(np.int64 if off64 else np.int32))
@@ -107,6 +122,14 @@ for it in range(iters):
                 continue
             sp.multiply(info, A, xd, y)
             sp.multiply(info, A, xd, y)
+            if alg == "sliced" and "hot_split" in info.state_.sliced_info():
+                desc += " [hot split]"
+            if rng.random() < 0.3:  # a rebound value array: snapshot plans (tiles, hot split) take their values again
+                values = (values * dtype(-0.5) + dtype(0.25)).astype(dtype)
+                a.update(t(values), a.rowptr(), a.colind())
+                A = sp.scaled(alpha, a) if alpha != 1.0 else a
+                sp.multiply(info, A, xd, y)
+                desc += " +rebound"
         torch.cuda.synchronize()
         yh = y.cpu().numpy()
         rp32 = rowptr.astype(np.int32)
