@@ -469,21 +469,40 @@ def main():
                 op.check_status()
                 return int(torch.equal(a, b))
 
+            # (short time-outs while the form is being checked: across devices none of this has run before, and a flag that
+            # never shows up must cost seconds, not the run; every rank goes through the same collectives whatever happened)
+            saved_timeout, op._timeout = op._timeout, 1500
             same = local2(check) or 0
-            local2(lambda: chain(4, False))  # warm-up
+            okc = torch.tensor([0 if failed is not None else same], dtype=torch.int32, device=device)
+            dist.all_reduce(okc, op=dist.ReduceOp.MIN)
+            go = bool(int(okc.item()))
+            if go:
+                local2(lambda: chain(4, False))  # warm-up
             dist.barrier()
             t1 = time.perf_counter()
-            local2(lambda: chain(k, False))
+            if go:
+                local2(lambda: chain(k, False))
             dist.barrier()
             el = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=device)
             dist.all_reduce(el, op=dist.ReduceOp.MAX)
             wait_t = torch.tensor([local2(lambda: op.chunk_wait_us()) or 0.0], dtype=torch.float64, device=device)
             dist.all_reduce(wait_t, op=dist.ReduceOp.MAX)
-            okc = torch.tensor([0 if failed is not None else same], dtype=torch.int32, device=device)
+            okc = torch.tensor([0 if (failed is not None or not go) else 1], dtype=torch.int32, device=device)
             dist.all_reduce(okc, op=dist.ReduceOp.MIN)
+            op._timeout = saved_timeout
             if failed is not None:
                 print(f"[bench] rank {rank}: chunked dependent chain not measured: {failed}", file=sys.stderr)
             chunk_ok = bool(int(okc.item()))
+            # whatever happened, every kernel of the attempt has finished on every rank before anything else uses the
+            # operator; a failed attempt leaves no armed wait and no time-out mark behind (the timed value, its post-check
+            # and the parity check below are about the barrier step)
+            torch.cuda.synchronize()
+            dist.barrier()
+            if not chunk_ok:
+                op._chunk_status.zero_()
+                op._chained = False
+                torch.cuda.synchronize()
+                dist.barrier()
             chunk_ms = float(el.item()) / k * 1e3 if chunk_ok else None
             chunk_wait_us = float(wait_t.item())
         diag = {"mode_timed": mode, "local_spmv_ms": local_s / k * 1e3, "local_spmv_event_ms": local_ev,
