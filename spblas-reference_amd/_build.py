@@ -81,6 +81,28 @@ def build_cpp_tests(force=False):
     return CPP_TEST_BIN
 
 
+RCCL_TEST_SRC = os.path.join(_ROOT, "tests", "cpp", "sharded_rccl_test.cpp")
+RCCL_TEST_BIN = os.path.join(_ROOT, "tests", "cpp", "sharded_rccl_test")
+
+
+def build_rccl_test(force=False):
+    """The C++ row-sharded SpMV over RCCL (include/spblas/vendor/gfx950/sharded_spmv.hpp): a caller-side program that links
+    librccl itself (the backend library does not)."""
+    deps = [RCCL_TEST_SRC, os.path.join(_ROOT, "include", "spblas", "vendor", "gfx950", "sharded_spmv.hpp"),
+            os.path.join(_ROOT, "include", "spblas", "vendor", "gfx950", "detail", "backend_calls.hpp"), LIBPATH]
+    if not force and os.path.exists(RCCL_TEST_BIN) and os.path.getmtime(RCCL_TEST_BIN) >= max(map(os.path.getmtime, deps)):
+        return RCCL_TEST_BIN
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    cmd = ["g++", "-std=c++20", "-O1", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(_ROOT, "include"),
+           "-I", os.path.join(rocm, "include"), RCCL_TEST_SRC, "-L", LIBDIR, "-lspblas_gfx950",
+           "-L", os.path.join(rocm, "lib"), "-lamdhip64", "-lrccl", "-lpthread",
+           "-Wl,-rpath,$ORIGIN/../../spblas-reference_amd/lib", "-Wl,-rpath," + os.path.join(rocm, "lib"), "-o", RCCL_TEST_BIN]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"g++ failed on sharded_rccl_test.cpp:\n{r.stderr}")
+    return RCCL_TEST_BIN
+
+
 EXAMPLES = ["device_spmv", "device_spgemm", "device_sptrsv"]
 
 
@@ -109,4 +131,5 @@ def build_examples(force=False):
 if __name__ == "__main__":
     print(build(force=True, verbose=True))
     print(build_cpp_tests(force=True))
+    print(build_rccl_test(force=True))
     print(build_examples(force=True))

@@ -31,3 +31,16 @@ def test_cpp_examples(gpu, name):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert name in r.stdout
+
+
+def test_cpp_sharded_spmv_over_rccl_one_rank(gpu):
+    """include/spblas/vendor/gfx950/sharded_spmv.hpp: the row-sharded SpMV a C++ caller can use -- local SpMV into its slot of
+    the full y + ONE ncclAllGather (equal shards) / grouped ncclBroadcast (nnz-balanced shards) on the same stream -- with
+    the communicator of one rank this box allows (tests/cpp/sharded_rccl_test.cpp; librccl is linked by the PROGRAM, the
+    backend library stays free of it)."""
+    exe = _build.RCCL_TEST_BIN
+    if not os.path.exists(exe):
+        exe = _build.build_rccl_test()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "SHARDED_RCCL_OK ranks=1" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
