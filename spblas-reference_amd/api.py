@@ -325,10 +325,14 @@ class _Plan:
         d["store_trial"] = (bits >> 3) & 1  # THIS plan timed both store flavours (opt-in: OPT_STORE_TRIAL = 2 on the handle or SPBLAS_GFX950_PB_NT=-2)
         d["auto_trial"] = bits & 1
         if (bits >> 4) & 1:  # hot-column split (csrc/spmv_hot.hip): the tile numbers above are those of A_rest
-            hot = (ctypes.c_int64 * 6)()
+            hot = (ctypes.c_int64 * 8)()
             check(_capi.lib().spblas_gfx950_plan_info_hot(self.plan, hot), "spblas_gfx950_plan_info_hot")
             d["hot_split"] = dict(zip(("hot_columns", "hot_entries", "hot_rows", "hot_long_rows", "tiled_entries",
                                        "tiled_device_bytes"), list(hot)))
+            # pre-summing plan: ALL entries go through the row-ordered kernel (hot_columns = slice width, hot_rows = the
+            # (row, slice) pairs), tiled_entries = the pairs whose sums make the round trip through the product stream
+            d["hot_split"]["presummed"] = (bits >> 5) & 1
+            d["hot_split"]["windows"], d["hot_split"]["windows_with_slot_table"] = int(hot[6]), int(hot[7])
         if d["store_trial"] and not d["auto_trial"]:  # (the two time slots carry AUTO's trial when both ran)
             d["store_trial_ns"] = {"plain": d.pop("trial_rowblock_ns"), "non_temporal": d.pop("trial_sliced_ns")}
             d["trial_rowblock_ns"] = d["trial_sliced_ns"] = 0

@@ -19,7 +19,7 @@ if not f: print(sys.argv[1], "no stats"); sys.exit()
 t={}
 for r in csv.DictReader(open(f[0])):
     n=r['Name']
-    for k in ("pb_expand","pb_reduce","pb_combine","pb_hot_rows","pb_hot_fixup","pb_split","pb_empty","spmv_rowblock","spmm_","spg_"):
+    for k in ("pb_expand","pb_reduce","pb_combine","pb_hot_rows","pb_hot_fixup","pb_presum","pb_split","pb_empty","spmv_rowblock","spmm_","spg_"):
         if k in n: t[k]=t.get(k,0)+float(r['AverageNs'])/1e3
 print(f"{sys.argv[1]:28s} " + "  ".join(f"{k}={v:7.1f}us" for k,v in t.items()) + f"   [{sys.argv[2]}]")
 PY
