@@ -333,6 +333,11 @@ int spblas_gfx950_spgemm_numeric(spblas_gfx950_handle_t handle, spblas_gfx950_sp
                                  const int32_t* b_rowptr, const int32_t* b_colind, const void* b_values,
                                  int32_t* c_rowptr, int32_t* c_colind, void* c_values, int64_t c_capacity,
                                  int value_type);
+/* Introspection of a state after spgemm_symbolic (no reference counterpart; the tests and bench.py use it):
+ * info[0] = nnz(C), info[1] = rows with 65..256 products (the wave-per-row bin), info[2] = those of them that are
+ * "direct" -- product count == structural length and an A row of one round of loads: sorted in registers by the
+ * persistent kernel, no hash --, info[3] = 1 when later fills accumulate by recorded rank, info[4..7] = 0. */
+int spblas_gfx950_spgemm_info(spblas_gfx950_spgemm_t state, int64_t info[8]);
 
 /* Four-argument SpGEMM  C = alpha*A*B + beta*D  (the reference
  * surface is multiply_compute, multiply_fill, multiply_symbolic_compute, multiply_symbolic_fill and

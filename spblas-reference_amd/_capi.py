@@ -71,6 +71,7 @@ PROTOTYPES = [
     ("spblas_gfx950_scale", c_int, [c_void_p, c_i64, c_void_p, c_void_p, c_int]),
     ("spblas_gfx950_spgemm_create", c_int, [c_void_p, ctypes.POINTER(c_void_p)]),
     ("spblas_gfx950_spgemm_destroy", c_int, [c_void_p, c_void_p]),
+    ("spblas_gfx950_spgemm_info", c_int, [c_void_p, ctypes.POINTER(ctypes.c_int64)]),
     ("spblas_gfx950_spgemm_symbolic", c_int,
      [c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_void_p,
       ctypes.POINTER(c_i64)]),

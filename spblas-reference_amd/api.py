@@ -435,6 +435,14 @@ class spgemm_state_t:
             self._state = st
         return hd, self._state
 
+    def info(self):
+        """Introspection (spblas_gfx950_spgemm_info): which kernels the numeric passes of this state take."""
+        if self._state is None:
+            return {}
+        raw = (ctypes.c_int64 * 8)()
+        check(_capi.lib().spblas_gfx950_spgemm_info(self._state, raw), "spblas_gfx950_spgemm_info")
+        return {"nnz_c": raw[0], "wave_per_row_rows": raw[1], "direct_rows": raw[2], "fills_by_rank": bool(raw[3])}
+
     def __del__(self):
         try:
             if self._state:

@@ -38,6 +38,12 @@
 #define SPG_NBK64 64   // buckets of the rank sort in the numeric wave-per-row kernel (round 4, same box, cfg5 one-shot fill:
                        // 32 -> 1.62 ms, 64 -> 1.51, 128 -> 1.65, 256 -> 1.90: the bucket scan costs more than the rank loop saves)
 #endif
+#ifndef SPG_DIR_NBK
+#define SPG_DIR_NBK 128  // buckets of the rank sort in spg_direct_kernel (64 / 128 / 256)
+#endif
+#ifndef SPG_DIR_READ2
+#define SPG_DIR_READ2 1  // its rank loop compares two keys per iteration
+#endif
 #ifndef SPG_INREG
 #define SPG_INREG 1    // A/B: 0 = direct rows always go through the product list
 #endif
@@ -73,6 +79,12 @@ struct spblas_gfx950_spgemm_s {
   // rank read (profiles/r02e_spgemm_pmc.md).  nullptr (no B, out of memory, SPBLAS_GFX950_SPG_ADESC=0): the kernels
   // look the rows up themselves.
   int2* r_adesc = nullptr;      // [a_nnz]
+  // Direct rows of bin 2 (spg_direct_kernel): rows whose product count equals their structural length (nothing to
+  // accumulate) and whose A row is one round of loads, listed by the symbolic pass as (first A entry, A entries, first
+  // output position, row); the other rows of the bin keep the hash kernel (dir_rest).  nullptr: everything hashes.
+  int4* dir_desc = nullptr;     // [n_dir]
+  int32_t* dir_rest = nullptr;  // [n_rest] rows of bin 2 that are not direct
+  int64_t n_dir = 0, n_rest = 0;
   bool r_ready = false;
   int numeric_calls = 0;        // numeric passes since the symbolic one (the SECOND records: a one-shot fill pays nothing)
 };
@@ -221,7 +233,7 @@ __global__ __launch_bounds__(256) void spg_hash_kernel(
     int64_t count, const int32_t* __restrict__ perm, const int32_t* __restrict__ a_rowptr,
     const int32_t* __restrict__ a_colind, const T* __restrict__ a_values, const int32_t* __restrict__ b_rowptr,
     const int32_t* __restrict__ b_colind, const T* __restrict__ b_values, int32_t* __restrict__ c_rowptr,
-    int32_t* __restrict__ c_colind, T* __restrict__ c_values, T alpha, int sub, long long ncols,
+    int32_t* __restrict__ c_colind, T* __restrict__ c_values, T alpha, int sub, unsigned bucket_mul,
     const int32_t* __restrict__ d_rowptr, const int32_t* __restrict__ d_colind, const T* __restrict__ d_values,
     T beta, int b_has_entries, const int2* __restrict__ adesc) {
   // adesc != nullptr: (start, length) of the B row of every A entry (then a_colind / b_rowptr are not read)
@@ -251,10 +263,10 @@ __global__ __launch_bounds__(256) void spg_hash_kernel(
   constexpr int NBK = (NUMERIC && TPR == 64) ? SPG_NBK64 : (TPR < 64 ? TPR : 64);
   int* bcnt = NUMERIC ? sortws + team * (2 * NBK + 2) : nullptr;  // [NBK+1] counts -> offsets
   int* bfill = NUMERIC ? bcnt + NBK + 1 : nullptr;                // [NBK] cursors
-  // bucket of a key = floor(key * NBK / ncols), as a 32x32 -> high-32 multiply (a 64-bit division per
-  // key and pass costs more than the rest of the sort): monotone in the key, < NBK for key < ncols
-  const unsigned long long bm = ((unsigned long long) NBK << 32) / (unsigned long long) (ncols > 0 ? ncols : 1);
-  const unsigned bucket_mul = bm > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned) bm;
+  // bucket of a key = floor(key * NBK / ncols), as a 32x32 -> high-32 multiply by bucket_mul = floor(NBK * 2^32 / ncols),
+  // which the host computes (spg_bucket_mul: a 64-bit division per wavefront was 120 scalar instructions of a
+  // 900-instruction row): monotone in the key, < NBK for key < ncols.  `sub` is a power of two: shifts, not divisions.
+  const int lsub = __builtin_ctz((unsigned) sub);
   // exclusive scan of the bucket counts in place (bcnt[NBK] = total): one bucket per lane, or NBK / TPR per lane
   auto scan_buckets = [&]() {
     if constexpr (NBK > TPR) {
@@ -337,8 +349,8 @@ __global__ __launch_bounds__(256) void spg_hash_kernel(
       // ... and when the whole row is one round of loads (<= 4 * 64 / sub entries in the A row, no B row longer than `sub`:
       // BASELINE cfg5 again) the products never leave the registers: count the buckets (the atomic returns the arrival
       // number inside the bucket), scan, place the KEYS in bucket order, rank each product's key inside its bucket, write.
-      if (SPG_INREG && direct && na <= 4 * (TPR / sub) && __ballot(len > sub) == 0ull) {
-        const int sg = lt / sub, sl = lt % sub, nsg = TPR / sub;
+      if (SPG_INREG && direct && na <= 4 * (TPR >> lsub) && __ballot(len > sub) == 0ull) {
+        const int sg = lt >> lsub, sl = lt & (sub - 1), nsg = TPR >> lsub;
         constexpr int U = 4;
         int col[U], bk[U], ai[U];
         T pv[U];
@@ -387,7 +399,7 @@ __global__ __launch_bounds__(256) void spg_hash_kernel(
         int* ckeys = list + team * (HS / 2);
         T* cvals = reinterpret_cast<T*>(list + RPB * (HS / 2)) + team * (HS / 2);
         spg_team_sync<TPR>();  // the bucket counters are zero
-        const int sg = lt / sub, sl = lt % sub, nsg = TPR / sub;
+        const int sg = lt >> lsub, sl = lt & (sub - 1), nsg = TPR >> lsub;
         constexpr int U = 4;
         for (int j0 = 0; j0 < na; j0 += U * nsg) {
           int q0[U], q1[U], col[U], pos[U];
@@ -435,7 +447,7 @@ __global__ __launch_bounds__(256) void spg_hash_kernel(
 
   if (live && !direct) {
     const int p0 = a_rowptr[row], p1 = a_rowptr[row + 1];
-    const int sg = lt / sub, sl = lt % sub, nsg = TPR / sub;
+    const int sg = lt >> lsub, sl = lt & (sub - 1), nsg = TPR >> lsub;
     auto insert = [&](int col, T prod) {
       unsigned slot = spg_hash(col, LOG2HS);
       while (true) {
@@ -583,8 +595,10 @@ __global__ __launch_bounds__(256) void spg_hash_kernel(
         svals[pos] = cvals[e];
       }
     spg_team_sync<TPR>();
-    if (live) {
-      const int out0 = c_rowptr[row];
+    // the sorted row is put together in the (dead) compacted list and leaves in consecutive elements: lanes storing
+    // 4 bytes each at their keys' ranks are one access per lane in the vector-memory address unit, which is what bounded
+    // the numeric pass (TA_BUSY 80 - 93 %, profiles/r04_spgemm_direct.md)
+    if (live)
       for (int e = lt; e < d; e += TPR) {
         const int key = skeys[e];
         const int bk = (int) __umulhi((unsigned) key, bucket_mul);
@@ -592,8 +606,15 @@ __global__ __launch_bounds__(256) void spg_hash_kernel(
         int rank = b0;
         for (int j = b0; j < b1; ++j)
           rank += skeys[j] < key;
-        c_colind[out0 + rank] = key;
-        c_values[out0 + rank] = svals[e];
+        ckeys[rank] = key;
+        cvals[rank] = svals[e];
+      }
+    spg_team_sync<TPR>();
+    if (live) {
+      const int out0 = c_rowptr[row];
+      for (int e = lt; e < d; e += TPR) {
+        c_colind[out0 + e] = ckeys[e];
+        c_values[out0 + e] = cvals[e];
       }
     }
   }
@@ -751,7 +772,8 @@ __global__ __launch_bounds__(256) void spg_rank_record_kernel(
   if (!live)
     return;
   const int p0 = a_rowptr[row], p1 = a_rowptr[row + 1];
-  const int sg = lt / sub, sl = lt % sub, nsg = TPR / sub;
+  const int lsub = __builtin_ctz((unsigned) sub);  // power of two
+  const int sg = lt >> lsub, sl = lt & (sub - 1), nsg = TPR >> lsub;
   const int tbase = (threadIdx.x & 63) - lt;  // first lane of the team in its wave
   auto rank_of = [&](int col) {
     int lo = 0, hi = d;  // last position with tkeys[pos] <= col (the column is present by construction)
@@ -855,7 +877,8 @@ __global__ __launch_bounds__(256) void spg_ranked_fill_kernel(
   spg_team_sync<TPR>();
   if (live) {
     const int p0 = a_rowptr[row], p1 = a_rowptr[row + 1];
-    const int sg = lt / sub, sl = lt % sub, nsg = TPR / sub;
+    const int lsub = __builtin_ctz((unsigned) sub);  // power of two
+    const int sg = lt >> lsub, sl = lt & (sub - 1), nsg = TPR >> lsub;
     const int tbase = (threadIdx.x & 63) - lt;  // first lane of the team in its wave
     for (int pc = p0; pc < p1; pc += TPR) {
       int qb = 0, len = 0;
@@ -965,11 +988,259 @@ static size_t hash_smem_bytes() {
   return b;
 }
 
+// ---- direct rows (round 4) ------------------------------------------------------------------------------------------
+// A row of C whose product count equals its structural length has no two products in the same column: there is nothing
+// to accumulate, only to sort.  When, in addition, the A row is one round of loads (<= 4 * 64 / sub entries, no B row
+// longer than `sub`: BASELINE cfg5), a wavefront holds the row's <= 256 products in registers.  The symbolic pass lists
+// such rows (spg_direct_classify_kernel); spg_direct_kernel is a PERSISTENT kernel over that list: the hash kernel above
+// was bound by its chain of dependent loads -- perm -> row offsets -> A entries -> B entries, one row per wavefront,
+// 67 % of the wave cycles waiting (SQ counters, profiles/r04_spgemm_direct.md) -- so every wavefront here keeps three rows
+// in flight: while row i is sorted it has already issued the B loads of row i + 1, the A loads of row i + 2 and the
+// descriptor load of row i + 3.
+// flag[idx] = 1 when row perm[idx] is direct.  16 lanes per row: one (start, length) pair of the A row's B rows each.
+__global__ __launch_bounds__(256) void spg_direct_flag_kernel(int64_t count, const int32_t* __restrict__ perm,
+                                                              const int32_t* __restrict__ a_rowptr,
+                                                              const int2* __restrict__ adesc,
+                                                              const int32_t* __restrict__ c_rowptr, int sub,
+                                                              int64_t b_nnz, int32_t* __restrict__ flag) {
+  const int64_t idx = ((int64_t) blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+  const int l16 = threadIdx.x & 15;
+  const bool live = idx < count;
+  int p0 = 0, na = 0, dlen = -1;
+  if (live) {
+    const int row = perm[idx];
+    p0 = a_rowptr[row];
+    na = a_rowptr[row + 1] - p0;
+    dlen = c_rowptr[row + 1] - c_rowptr[row];
+  }
+  const bool fits = live && na <= 4 * (64 / sub) && na <= 64;
+  int sum = 0, bad = 0;
+  if (fits)
+    for (int p = l16; p < na; p += 16) {
+      const int2 dd = adesc[p0 + p];
+      const int len = dd.y;
+      // (the direct kernel reads a B row in vectors of four entries: the padded range has to stay inside the arrays)
+      bad |= (int) (len > sub) | (int) ((int64_t) dd.x + ((len + 3) & ~3) > b_nnz);
+      sum += len;
+    }
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) {
+    sum += __shfl_xor(sum, o, 16);
+    bad |= __shfl_xor(bad, o, 16);
+  }
+  if (live && l16 == 0)
+    flag[idx] = (int32_t) (fits && !bad && sum == dlen && sum > 0 && sum <= 256);
+}
+
+// flag[] scanned: the direct rows' descriptors in list order, the other rows of the bin behind each other in `rest`
+__global__ __launch_bounds__(256) void spg_direct_lists_kernel(int64_t count, const int32_t* __restrict__ perm,
+                                                               const int32_t* __restrict__ a_rowptr,
+                                                               const int32_t* __restrict__ c_rowptr,
+                                                               const int32_t* __restrict__ flag_excl,
+                                                               int4* __restrict__ desc, int32_t* __restrict__ rest) {
+  const int64_t idx = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= count)
+    return;
+  const int pos = flag_excl[idx];
+  const int row = perm[idx];
+  if (flag_excl[idx + 1] != pos) {
+    const int p0 = a_rowptr[row], out0 = c_rowptr[row];
+    desc[pos] = make_int4(p0, a_rowptr[row + 1] - p0, out0, c_rowptr[row + 1] - out0);
+  } else {
+    rest[idx - pos] = row;
+  }
+}
+
+// four consecutive elements as one 16-byte (fp64 values: 32-byte) access at 4-byte (8-byte) alignment: global memory takes
+// unaligned vector accesses, and the vector-memory address unit spends its 16 cycles per INSTRUCTION, however wide
+typedef int spg_i4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef float spg_f4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef double spg_d4u __attribute__((ext_vector_type(4), aligned(8)));
+template <typename T> struct spg_vec4;
+template <> struct spg_vec4<float> { typedef spg_f4u type; };
+template <> struct spg_vec4<double> { typedef spg_d4u type; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void spg_direct_kernel(
+    int n_dir, const int4* __restrict__ desc, const int2* __restrict__ adesc, const T* __restrict__ a_values,
+    const int32_t* __restrict__ b_colind, const T* __restrict__ b_values, int32_t* __restrict__ c_colind,
+    T* __restrict__ c_values, T alpha, int sub, unsigned bucket_mul) {
+  constexpr int NBK = SPG_DIR_NBK, BPL = NBK / 64;
+  typedef typename spg_vec4<T>::type v4u;
+  __shared__ __attribute__((aligned(16))) int s_keys[4][256 + 4];
+  __shared__ __attribute__((aligned(16))) T s_vals[4][256];
+  __shared__ __attribute__((aligned(16))) int s_bcnt[4][NBK + 4];
+  const int wave = threadIdx.x >> 6, lt = threadIdx.x & 63;
+  int* tkeys = s_keys[wave];
+  T* tvals = s_vals[wave];
+  int* bcnt = s_bcnt[wave];
+  // sub / 4 lanes per B row, four consecutive entries each: lane lt works on entries c4 .. c4 + 3 of the B row of A entry jr
+  const int lshift = __builtin_ctz((unsigned) sub) - 2;  // sub is 4, 8 or 16
+  const int jr = lt >> lshift, c4 = (lt & ((1 << lshift) - 1)) * 4;
+  const int stride = (int) gridDim.x * 4;
+  int i = __builtin_amdgcn_readfirstlane((int) blockIdx.x * 4 + wave);
+  constexpr int U = 4;
+  struct arow {
+    int qb, len;
+    T a;
+  };
+  struct brow {  // four consecutive entries of a B row, loaded as vectors whether or not the row has that many left:
+    spg_i4u cc;  // the classification admits a row only if reading up to the next multiple of four entries of each of its
+    v4u vv;      // B rows stays inside B's arrays (spg_direct_flag_kernel); what lies beyond the row is masked out by n
+    int n;       // entries of the lane: 0 .. 4
+  };
+  auto load_desc = [&](int r) { return r < n_dir ? desc[r] : make_int4(0, 0, 0, 0); };
+  auto load_a = [&](const int4& d) {
+    arow a{0, 0, T(0)};
+    if (lt < d.y) {
+      const int2 dd = adesc[d.x + lt];
+      a.qb = dd.x;
+      a.len = dd.y;
+      a.a = a_values[d.x + lt];
+    }
+    return a;
+  };
+  auto load_b = [&](const arow& a, int na) {
+    brow b;
+    const int q0 = __shfl(a.qb, jr, 64) + c4, ln = __shfl(a.len, jr, 64) - c4;  // (lanes >= na hold length 0)
+    b.n = jr < na ? (ln < 0 ? 0 : ln > 4 ? 4 : ln) : 0;
+    const int q = b.n > 0 ? q0 : 0;  // (entries 0 .. 3 exist: some admitted row has a B row whose padded range is inside)
+    b.cc = *reinterpret_cast<const spg_i4u*>(b_colind + q);  // (non-temporal gathers were measured: 1.55 against 1.11 ms)
+    b.vv = *reinterpret_cast<const v4u*>(b_values + q);
+    return b;
+  };
+  int4 d0 = load_desc(i), d1 = load_desc(i + stride), d2 = load_desc(i + 2 * stride);
+  arow a0 = load_a(d0), a1 = load_a(d1);
+  brow b0 = load_b(a0, d0.y);
+  auto zero_buckets = [&]() {
+#pragma unroll
+    for (int j = 0; j < BPL; ++j)
+      bcnt[lt * BPL + j] = 0;
+    if (lt == 0)
+      bcnt[NBK] = 0;
+  };
+  zero_buckets();
+  spg_team_sync<64>();
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the loop is entered with every load complete, like its back edge
+  while (i < n_dir) {
+    // the next rows' loads first: B entries of row i + 1, A entries of row i + 2, descriptor of row i + 3
+    const brow b1 = load_b(a1, d1.y);
+    const arow a2 = load_a(d2);
+    const int4 d3 = load_desc(i + 3 * stride);
+    // row i: products, bucket counts (the atomic returns the arrival number inside the bucket), scan, keys in bucket
+    // order, rank of every product's key inside its bucket, sorted row in LDS, write
+    const int out0 = d0.z, dlen = d0.w;
+    const T av = __shfl(alpha * a0.a, jr, 64);
+    int col[U], bk[U], ai[U];
+    T pv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      col[u] = u < b0.n ? b0.cc[u] : -1;
+      pv[u] = av * b0.vv[u];
+      bk[u] = col[u] >= 0 ? (int) __umulhi((unsigned) col[u], bucket_mul) : 0;
+      ai[u] = col[u] >= 0 ? atomicAdd(&bcnt[bk[u]], 1) : 0;
+    }
+    spg_team_sync<64>();
+    {
+      int c[BPL], tot = 0;
+#pragma unroll
+      for (int j = 0; j < BPL; ++j) {
+        c[j] = bcnt[lt * BPL + j];
+        tot += c[j];
+      }
+      int incl = tot;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o, 64);
+        if (lt >= o)
+          incl += t;
+      }
+      int run = incl - tot;
+#pragma unroll
+      for (int j = 0; j < BPL; ++j) {
+        bcnt[lt * BPL + j] = run;
+        run += c[j];
+      }
+      if (lt == 63)
+        bcnt[NBK] = incl;
+    }
+    spg_team_sync<64>();
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (col[u] >= 0)
+        tkeys[bcnt[bk[u]] + ai[u]] = col[u];
+    spg_team_sync<64>();
+    int rank[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      rank[u] = 0;
+      if (col[u] >= 0) {
+        const int e0 = bcnt[bk[u]], e1 = bcnt[bk[u] + 1];
+        rank[u] = e0;
+#if SPG_DIR_READ2
+        for (int j = e0; j < e1; j += 2) {  // (a key past the bucket's end is read -- the array has the slack -- and not counted)
+          const int k0 = tkeys[j], k1 = tkeys[j + 1];
+          rank[u] += (int) (k0 < col[u]) + (int) ((j + 1 < e1) & (k1 < col[u]));
+        }
+#else
+        for (int j = e0; j < e1; ++j)
+          rank[u] += tkeys[j] < col[u];
+#endif
+      }
+    }
+    spg_team_sync<64>();
+    zero_buckets();
+    // The sorted row is put together in LDS and leaves as whole lines.  Lanes storing 4 bytes each at their products'
+    // ranks were 495 separate accesses per row in the vector-memory address unit (TCP_TOTAL_WRITE; TA_BUSY 80 - 93 %:
+    // what bounded the kernel); four consecutive elements per lane are two store instructions per row.
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (col[u] >= 0) {
+        tkeys[rank[u]] = col[u];
+        tvals[rank[u]] = pv[u];
+      }
+    spg_team_sync<64>();
+    // the loads issued at the top have had the whole sort to arrive: wait for them HERE, before this row's stores are
+    // issued (vmcnt counts in order: a wait placed after the stores -- where the register rotation below would put it --
+    // would wait for the stores as well)
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt and lgkmcnt untouched
+    {
+      const int e = 4 * lt, n_out = dlen - e;
+      if (n_out >= 4) {
+        *reinterpret_cast<spg_i4u*>(c_colind + out0 + e) = *reinterpret_cast<const spg_i4u*>(tkeys + e);
+        *reinterpret_cast<v4u*>(c_values + out0 + e) = *reinterpret_cast<const v4u*>(tvals + e);
+      } else {
+#pragma unroll
+        for (int u = 0; u < U - 1; ++u)
+          if (u < n_out) {
+            c_colind[out0 + e + u] = tkeys[e + u];
+            c_values[out0 + e + u] = tvals[e + u];
+          }
+      }
+    }
+    spg_team_sync<64>();  // (the next row's keys go into the same array)
+    b0 = b1;
+    a0 = a1;
+    a1 = a2;
+    d0 = d1;
+    d1 = d2;
+    d2 = d3;
+    i += stride;
+  }
+}
+
+// floor(NBK * 2^32 / ncols), clamped: the multiplier of the rank sort's bucket function (see spg_hash_kernel)
+static unsigned spg_bucket_mul(int nbk, int64_t ncols) {
+  const unsigned long long bm = ((unsigned long long) nbk << 32) / (unsigned long long) (ncols > 0 ? ncols : 1);
+  return bm > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned) bm;
+}
+
 template <typename T, int LOG2HS, int TPR, bool NUMERIC>
 static int launch_hash(hipStream_t s, const spblas_gfx950_spgemm_s* st, int bin, const T* a_values,
                        const T* b_values, int32_t* c_rowptr, int32_t* c_colind, T* c_values, T alpha,
-                       const T* d_values, T beta) {
-  const int64_t count = st->bin_off[bin + 1] - st->bin_off[bin];
+                       const T* d_values, T beta, const int32_t* rows = nullptr, int64_t n_rows = 0) {
+  // rows != nullptr: that list instead of the whole bin (the rows of bin 2 the direct kernel does not take)
+  const int64_t count = rows ? n_rows : st->bin_off[bin + 1] - st->bin_off[bin];
   if (count == 0)
     return SPBLAS_GFX950_STATUS_SUCCESS;
   constexpr int RPB = 256 / TPR;
@@ -980,9 +1251,10 @@ static int launch_hash(hipStream_t s, const spblas_gfx950_spgemm_s* st, int bin,
                                 (int) smem));
   int sub = st->sub < TPR ? st->sub : TPR;
   hipLaunchKernelGGL(kern, dim3((unsigned) cdiv(count, RPB)), dim3(256), smem, s, count,
-                     st->perm + st->bin_off[bin], st->a_rowptr, st->a_colind, a_values, st->b_rowptr,
-                     st->b_colind, b_values, c_rowptr, c_colind, c_values, alpha, sub, (long long) (st->n > 0 ? st->n : 1),
-                     st->d_rowptr, st->d_colind, d_values, beta, (int) (st->b_nnz > 0), st->r_adesc);
+                     rows ? rows : st->perm + st->bin_off[bin], st->a_rowptr, st->a_colind, a_values, st->b_rowptr,
+                     st->b_colind, b_values, c_rowptr, c_colind, c_values, alpha, sub,
+                     spg_bucket_mul((NUMERIC && TPR == 64) ? SPG_NBK64 : (TPR < 64 ? TPR : 64), st->n), st->d_rowptr,
+                     st->d_colind, d_values, beta, (int) (st->b_nnz > 0), st->r_adesc);
   SPB_HIP(hipGetLastError());
   return SPBLAS_GFX950_STATUS_SUCCESS;
 }
@@ -1000,9 +1272,23 @@ static int run_bins(spblas_gfx950_handle_t h, spblas_gfx950_spgemm_s* st, const 
     return rc;
   // bin 2: a wave per row for the numeric pass (its rank sort works on TPR buckets: 32-lane teams take 3.2 instead of
   // 2.1 ms at cfg5), two rows per wave for the symbolic one (0.61 -> 0.56 ms: more rows' loads in flight)
-  if (skip_upto < 2 &&
-      (rc = launch_hash<T, 9, NUMERIC ? 64 : 32, NUMERIC>(s, st, 2, a_values, b_values, c_rowptr, c_colind, c_values,
-                                                          alpha, d_values, beta)))
+  if (NUMERIC && skip_upto < 2 && st->dir_desc && !st->d_rowptr && st->b_rowptr && st->r_adesc) {
+    if constexpr (NUMERIC) {
+      if (st->n_dir > 0) {
+        const int64_t wgs = std::min<int64_t>(cdiv(st->n_dir, 4), (int64_t) h->num_cus * 8);
+        hipLaunchKernelGGL((spg_direct_kernel<T>), dim3((unsigned) wgs), dim3(256), 0, s, (int) st->n_dir, st->dir_desc,
+                           st->r_adesc, a_values, st->b_colind, b_values, c_colind, c_values, alpha,
+                           st->sub < 64 ? st->sub : 64, spg_bucket_mul(SPG_DIR_NBK, st->n));
+        SPB_HIP(hipGetLastError());
+      }
+      // (the hash kernel on a second stream next to the direct kernel was measured: 1.257 against 1.225 ms)
+      if ((rc = launch_hash<T, 9, 64, true>(s, st, 2, a_values, b_values, c_rowptr, c_colind, c_values, alpha, d_values,
+                                            beta, st->dir_rest, st->n_rest)))
+        return rc;
+    }
+  } else if (skip_upto < 2 &&
+             (rc = launch_hash<T, 9, NUMERIC ? 64 : 32, NUMERIC>(s, st, 2, a_values, b_values, c_rowptr, c_colind,
+                                                                 c_values, alpha, d_values, beta)))
     return rc;
   if (skip_upto < 3 &&
       (rc = launch_hash<T, 11, 128, NUMERIC>(s, st, 3, a_values, b_values, c_rowptr, c_colind, c_values, alpha,
@@ -1208,6 +1494,11 @@ static void spgemm_release(spblas_gfx950_spgemm_s* st, hipStream_t s) {
   dev_free(st->r_cols, s);
   dev_free(st->r_adesc, s);
   st->r_adesc = nullptr;
+  dev_free(st->dir_desc, s);
+  dev_free(st->dir_rest, s);
+  st->dir_desc = nullptr;
+  st->dir_rest = nullptr;
+  st->n_dir = st->n_rest = 0;
   st->r_pbase = nullptr;
   st->r_rank = nullptr;
   st->r_cols = nullptr;
@@ -1244,6 +1535,18 @@ int spblas_gfx950_spgemm_destroy(spblas_gfx950_handle_t handle, spblas_gfx950_sp
     return SPBLAS_GFX950_STATUS_SUCCESS;
   spgemm_release(state, handle->stream);
   delete state;
+  return SPBLAS_GFX950_STATUS_SUCCESS;
+}
+
+int spblas_gfx950_spgemm_info(spblas_gfx950_spgemm_t st, int64_t info[8]) {
+  if (!st || !info)
+    return SPBLAS_GFX950_STATUS_INVALID_POINTER;
+  for (int i = 0; i < 8; ++i)
+    info[i] = 0;
+  info[0] = st->c_nnz;
+  info[1] = st->bin_off[3] - st->bin_off[2];
+  info[2] = st->dir_desc ? st->n_dir : 0;
+  info[3] = st->r_ready ? 1 : 0;
   return SPBLAS_GFX950_STATUS_SUCCESS;
 }
 
@@ -1354,8 +1657,39 @@ static int spgemm_symbolic_impl(spblas_gfx950_handle_t handle, spblas_gfx950_spg
     hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned) nb), dim3(256), 0, s, m, st->rowptr, partials, c_rowptr);
     long long total = 0;
     hipError_t e = hipMemcpyAsync(&total, partials + nb, sizeof(total), hipMemcpyDeviceToHost, s);
+    // direct rows of bin 2 (see spg_direct_kernel): flag, scan, two lists; the list length comes back with the total.
+    // (The flags and the scan's partial sums reuse the scratch of the binning: both are dead, and the copy of the total
+    // above is ordered before the kernels that overwrite `partials`.)
+    const int64_t c2 = st->bin_off[3] - st->bin_off[2];
+    static const int dir_env = [] {
+      const char* ev = std::getenv("SPBLAS_GFX950_SPG_DIRECT");
+      return ev ? std::atoi(ev) : 1;
+    }();
+    bool classify = e == hipSuccess && dir_env != 0 && c2 > 0 && c2 <= INT32_MAX - 16 && !identity_b && b_rowptr &&
+                    st->r_adesc && !st->d_rowptr && b_nnz > 0;
+    if (classify && (dev_alloc((void**) &st->dir_desc, (size_t) c2 * sizeof(int4), s) != SPBLAS_GFX950_STATUS_SUCCESS ||
+                     dev_alloc((void**) &st->dir_rest, (size_t) c2 * 4, s) != SPBLAS_GFX950_STATUS_SUCCESS)) {
+      dev_free(st->dir_desc, s);
+      dev_free(st->dir_rest, s);
+      st->dir_desc = nullptr;
+      st->dir_rest = nullptr;
+      classify = false;  // out of memory for the optional lists: every row hashes
+    }
+    long long n_dir = 0;
+    if (classify) {
+      int32_t* flag = bin_of_row;  // [c2 + 1] <= [m + 1] ints: the bin numbers and, behind them, the bin counters
+      hipLaunchKernelGGL(spg_direct_flag_kernel, dim3((unsigned) cdiv(c2 * 16, 256)), dim3(256), 0, s, c2,
+                         st->perm + st->bin_off[2], a_rowptr, st->r_adesc, st->rowptr, st->sub < 64 ? st->sub : 64, b_nnz,
+                         flag);
+      long long* n_dir_dev = scan_counts_i32(s, c2, flag, partials);
+      hipLaunchKernelGGL(spg_direct_lists_kernel, dim3((unsigned) cdiv(c2, 256)), dim3(256), 0, s, c2,
+                         st->perm + st->bin_off[2], a_rowptr, st->rowptr, flag, st->dir_desc, st->dir_rest);
+      e = hipMemcpyAsync(&n_dir, n_dir_dev, sizeof(n_dir), hipMemcpyDeviceToHost, s);
+    }
     if (e == hipSuccess)
       e = hipStreamSynchronize(s);
+    st->n_dir = classify ? n_dir : 0;
+    st->n_rest = classify ? c2 - n_dir : 0;
     if (e != hipSuccess)
       rc = hip_fail(e);
     else if (total > INT32_MAX)

@@ -364,3 +364,60 @@ def test_spgemm_mixed_csr_csc_operands(gpu, a_fmt, b_fmt, c_fmt):
             ab = abt
         assert np.array_equal(got_p, cr) and np.array_equal(got_i, cc)
         util.assert_parity(got_v, cv, ab, dtype, row_len=np.full(len(cv), 64), what=f"spgemm {a_fmt}*{b_fmt}->{c_fmt}")
+
+
+def _random_csr(rng, rows, cols, len_lo, len_hi, dtype, sorted_rows=True):
+    lens = rng.integers(len_lo, len_hi + 1, rows)
+    rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    colind = np.empty(int(rowptr[-1]), np.int32)
+    for r in range(rows):
+        c = rng.choice(cols, int(lens[r]), replace=False)
+        colind[rowptr[r]:rowptr[r + 1]] = np.sort(c) if sorted_rows else c
+    values = (rng.random(len(colind)) - 0.5).astype(dtype)
+    return values, rowptr, colind, (rows, cols)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("b_len", [(12, 16), (5, 8), (1, 4), (0, 16)])
+def test_spgemm_direct_rows(gpu, dtype, b_len):
+    """Rows whose product count equals their structural length (csrc/spgemm.hip: spg_direct_kernel, a persistent kernel that
+    sorts the products in registers and LDS -- no hash): very sparse operands with a wide column range, B rows of every
+    admitted length class (16 / 8 / 4 lanes' worth, empty rows, unsorted rows), A rows of 0 .. the round's limit, a last
+    B row that ends at the end of the arrays (its vector reads may not run over: those rows must take the hash kernel),
+    alpha, and a second fill with new values (the one-shot path again: recording off).  Exact structure, values in bound."""
+    rng = np.random.default_rng(97 + b_len[0])
+    m, k, n = 6000, 9000, 3_000_000
+    sub = 16 if b_len[1] > 8 else 8 if b_len[1] > 4 else 4
+    a_h = _random_csr(rng, m, k, 0, 256 // sub, dtype)
+    b_h = _random_csr(rng, k, n, b_len[0], b_len[1], dtype, sorted_rows=False)
+    # make sure the last B row is used by many A rows
+    av, ar, ac, ash = a_h
+    first = ar[:-1][np.diff(ar) > 0]
+    ac[first[::7]] = k - 1
+    got = device_spgemm((av, ar, ac, ash), b_h, True, scale_a=-2.5)
+    check_against_oracle((av, ar, ac, ash), b_h, got, dtype, scale=-2.5)
+    # the kernel choice, and a second fill with other values through the same state
+    d_a = G.csr_on_device(av, ar, ac, ash, len(av))
+    d_b = G.csr_on_device(*b_h, len(b_h[0]))
+    d_rp = torch.zeros(m + 1, dtype=torch.int32, device="cuda")
+    d_c = sp.csr_view(None, d_rp, None, (m, n), 0)
+    state = sp.spgemm_state_t()
+    sp.multiply_compute(state, d_a, d_b, d_c)
+    info = state.info()
+    products = np.add.reduceat(np.diff(b_h[1])[ac], ar[:-1])[np.diff(ar) > 0] if len(ac) else np.zeros(0)
+    wave_rows = int(((products > 64) & (products <= 256)).sum())
+    assert info["nnz_c"] == got[0] and info["wave_per_row_rows"] == wave_rows
+    assert 0.5 * wave_rows <= info["direct_rows"] <= wave_rows and wave_rows > 100
+    nnz = state.result_nnz()
+    vals = torch.full((nnz,), float("nan"), dtype=G.dev(av).dtype, device="cuda")
+    cols = torch.full((nnz,), -1, dtype=torch.int32, device="cuda")
+    d_c.update(vals, d_rp, cols, (m, n), nnz)
+    for rep in range(2):
+        d_a.values().mul_(1.5)
+        d_b.values().add_(0.25)
+        sp.multiply_fill(state, d_a, d_b, d_c)
+        a2 = (G.host(d_a.values()), ar, ac, ash)
+        b2 = (G.host(d_b.values()), b_h[1], b_h[2], b_h[3])
+        check_against_oracle(a2, b2, (nnz, G.host(d_rp), G.host(cols), G.host(vals)), dtype)
+        vals.fill_(float("nan"))
+        cols.fill_(-1)
