@@ -58,7 +58,9 @@ def parse():
                         "ranks on one device): exercises the N>1 code path end to end on a one-GPU box")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-secondary", action="store_true",
-                   help="default N=1 cfg2 run only: skip the cfg4 / cfg3 / cfg5 records of the `secondary` object")
+                   help="default N=1 cfg2 run only: skip the cfg4 / cfg3 / cfg5 / 8(f) records of the `secondary` object")
+    p.add_argument("--no-8f", dest="no_8f", action="store_true",
+                   help="`secondary` without the SURVEY 8(f) records (add, transpose, triangular solve)")
     return p.parse_args()
 
 
@@ -641,8 +643,8 @@ def main():
         if world == 1 and not multi and args.workload == "spmv" and args.rows is None and args.cols is None \
                 and args.alg == "auto" and not args.no_secondary:
             # The other single-GPU BASELINE configs, after the timed cfg2 loop and its check, in the same process: cfg4
-            # (1 GPU), cfg3, cfg5 -- each inspected, warmed up, timed between one event pair and checked against the
-            # oracle.  The headline fields above are untouched; a failing secondary check fails the run (exit code 3).
+            # (1 GPU), cfg3, cfg5, then the SURVEY 8(f) operations add / transpose / triangular solve -- each inspected,
+            # warmed up, timed between one event pair and checked against the oracle.  The headline fields above are untouched; a failing secondary check fails the run (exit code 3).
             from bench_extra import secondary
             del y_timed, values, rowptr, colind, op, rccl_op, a_chunks, prob, info0, x
             torch.cuda.empty_cache()

@@ -114,12 +114,15 @@ def run_extra(args, device):
 
 
 def secondary(args, device, log=None):
-    """BASELINE cfg4 (single-GPU leg), cfg3 and cfg5 after the headline cfg2 loop, in the same process: each one
-    inspected, warmed up, timed between one pair of HIP events and checked against the oracle; compact records for the
-    `secondary` object of bench.py's JSON line."""
+    """BASELINE cfg4 (single-GPU leg), cfg3 and cfg5 after the headline cfg2 loop, in the same process, then the three
+    SURVEY 8(f) operations (add, transpose, triangular solve): each one inspected, warmed up, timed between one pair of
+    HIP events and checked against the oracle; compact records for the `secondary` object of bench.py's JSON line."""
     import copy
     res = {}
-    for name, workload in (("cfg4", "spmv_rmat1"), ("cfg3", "spmm"), ("cfg5", "spgemm")):
+    todo = [("cfg4", "spmv_rmat1"), ("cfg3", "spmm"), ("cfg5", "spgemm")]
+    if not getattr(args, "no_8f", False):  # SURVEY 8(f): add, transpose, triangular solve at their bench sizes
+        todo += [("f_add", "add"), ("f_transpose", "transpose"), ("f_sptrsv", "sptrsv")]
+    for name, workload in todo:
         a2 = copy.copy(args)
         a2.workload, a2.rows, a2.cols = workload, None, None
         a2.steps, a2.warmup = max(10, min(args.steps, 20)), 5
@@ -359,7 +362,7 @@ def _run(args, device):
         del state2
         cpu = None
         if not args.no_cpu_baseline:
-            rows = 20_000
+            rows = min(20_000, m)
             rp = ar[:rows + 1].cpu().numpy()
             sub = ((rows, m), rp, ac[:rp[-1]].cpu().numpy(), av[:rp[-1]].cpu().numpy())
             bh = ((m, m), br.cpu().numpy(), bc.cpu().numpy(), bv.cpu().numpy())
@@ -409,7 +412,7 @@ def _run(args, device):
         alg_bytes = (annz + bnnz + cn) * 8 + 3 * (m + 1) * 4
         cpu = None
         if not args.no_cpu_baseline:
-            rows = 200_000
+            rows = min(200_000, m)
             ra, rb = ar[:rows + 1].cpu().numpy(), br[:rows + 1].cpu().numpy()
             t0 = time.perf_counter()
             oracle.add((rows, m), ra, ac[:ra[-1]].cpu().numpy(), av[:ra[-1]].cpu().numpy(), (rows, m), rb,
@@ -417,9 +420,23 @@ def _run(args, device):
             dt = time.perf_counter() - t0
             cpu = {"value": (ra[-1] + rb[-1]) / dt / 1e9, "unit": "Gentries/s", "cores": 1, "kind": "port",
                    "sample": f"first {rows} rows, oracle_add_f32 (SPA + sort per row)"}
+        # parity: every row against the oracle (structure exact, values norm-wise)
+        torch.cuda.synchronize()
+        r_rp, r_ci, r_v = oracle.add((m, m), ar.cpu().numpy(), ac.cpu().numpy(), av.cpu().numpy(), (m, m), br.cpu().numpy(),
+                                     bc.cpu().numpy(), bv.cpu().numpy())
+        _, _, r_abs = oracle.add((m, m), ar.cpu().numpy(), ac.cpu().numpy(), np.abs(av.cpu().numpy()), (m, m),
+                                 br.cpu().numpy(), bc.cpu().numpy(), np.abs(bv.cpu().numpy()))
+        g_rp, g_ci, g_v = c_rp.cpu().numpy(), c.colind().cpu().numpy(), c.values().cpu().numpy()
+        struct_ok = bool(cn == int(r_rp[-1]) and np.array_equal(g_rp, r_rp) and np.array_equal(g_ci, r_ci[:cn]))
+        n_bad, worst = (parity_rows(g_v, r_v[:cn], r_abs[:cn].astype(np.float64), 1e-6, float(np.finfo(np.float32).eps),
+                                    np.full(cn, 2)) if struct_ok else (cn, float("inf")))
+        parity = {"status": "pass" if struct_ok and n_bad == 0 else "fail", "rows": m, "rowptr_colind_exact": struct_ok,
+                  "values_out_of_bound": int(n_bad), "tol": 1e-6, "worst_err_over_norm": float(worst),
+                  "against": "oracle_add (CPU restatement of add_impl.hpp:40-77), every row"}
         return _emit(args, "csr_add_gentries", float(annz + bnnz), alg_bytes, elapsed, ms,
               f"8f: fp32 CSR + CSR add {m}x{m}, 16 nnz/row each, uniform random; timed step = add_compute; value = input entries/ns",
-              {"dtype": "f32", "unit": "Gentries/s", "rows": m, "nnz_c": cn, "add_inspect_ms_untimed": inspect_ms}, cpu)
+              {"dtype": "f32", "unit": "Gentries/s", "rows": m, "nnz_c": cn, "add_inspect_ms_untimed": inspect_ms,
+               "kernel": "spg_ranked_fill_kernel / spg_hash_kernel (identity B + addend)"}, cpu, parity=parity)
 
     if args.workload == "transpose":  # B = A^T (stable counting sort)
         m = args.rows or 10_000_000
@@ -433,16 +450,24 @@ def _run(args, device):
         alg_bytes = 2 * (annz * 8 + (m + 1) * 4)
         cpu = None
         if not args.no_cpu_baseline:
-            rows = 1_000_000
+            rows = min(1_000_000, m)
             rp = ar[:rows + 1].cpu().numpy()
             t0 = time.perf_counter()
             oracle.transpose((rows, m), rp, ac[:rp[-1]].cpu().numpy(), av[:rp[-1]].cpu().numpy())
             dt = time.perf_counter() - t0
             cpu = {"value": rp[-1] / dt / 1e9, "unit": "Gentries/s", "cores": 1, "kind": "port",
                    "sample": f"first {rows} rows, oracle_transpose_f32"}
+        # parity: bit-exact against the oracle's stable counting sort, every entry
+        torch.cuda.synchronize()
+        r_rp, r_ci, r_v = oracle.transpose((m, m), ar.cpu().numpy(), ac.cpu().numpy(), av.cpu().numpy())
+        ok = bool(np.array_equal(t_rp.cpu().numpy(), r_rp) and np.array_equal(t_ci.cpu().numpy(), r_ci) and
+                  np.array_equal(t_v.cpu().numpy().view(np.uint32), r_v.view(np.uint32)))
+        parity = {"status": "pass" if ok else "fail", "entries": annz, "bit_exact": ok,
+                  "against": "oracle_transpose (CPU restatement of transpose_impl.hpp:14-53), every row offset, column and value bit"}
         return _emit(args, "csr_transpose_gentries", float(annz), alg_bytes, elapsed, ms,
               f"8f: fp32 CSR transpose {m}x{m}, 10 nnz/row uniform random; value = entries/ns",
-              {"dtype": "f32", "unit": "Gentries/s", "rows": m, "nnz": annz}, cpu)
+              {"dtype": "f32", "unit": "Gentries/s", "rows": m, "nnz": annz,
+               "kernel": "spt_count_kernel + spt_scatter_kernel, three 8-bit passes"}, cpu, parity=parity)
 
     if args.workload == "sptrsv":  # x = inv(L) b, L random lower triangular + diagonal
         m = args.rows or 4_000_000
@@ -485,10 +510,31 @@ def _run(args, device):
             dt = time.perf_counter() - t0
             cpu = {"value": 2.0 * nnz / dt / 1e9, "unit": "GFLOP/s", "cores": 1, "kind": "port",
                    "sample": f"full workload ({nnz} nnz), oracle_trsv_f32 (sequential reference loop)"}
+        # parity: row-wise backward error in fp64 on the device (every row) and forward error against the oracle's solve
+        torch.cuda.synchronize()
+        xd, vd, bd = x.double(), values.double(), b.double()
+        rows_e = torch.arange(m, device=device).repeat_interleave(k + 1)
+        tx = torch.zeros(m, dtype=torch.float64, device=device).index_add_(0, rows_e, vd * xd[colind.long()])
+        ab = torch.zeros(m, dtype=torch.float64, device=device).index_add_(0, rows_e, vd.abs() * xd[colind.long()].abs())
+        tol_r = max(1e-6, 0.5 * (k + 3) * float(np.finfo(np.float32).eps))
+        ok_r = (tx - bd).abs() <= tol_r * (bd.abs() + ab)
+        ok_r[0] = True  # row 0: its eight sub-diagonal draws land ON the diagonal (col <= row), which L x above adds up while
+        bad_r = int((~ok_r).sum().item())  # the solve takes one diagonal entry; the oracle comparison below covers the row
+        x_ref = oracle.triangular_solve((m, m), rp.int().cpu().numpy(), colind.cpu().numpy(), values.cpu().numpy(),
+                                        b.cpu().numpy()).astype(np.float64)
+        scale = np.maximum(np.abs(x_ref), np.abs(x_ref).max() * 1e-3 + 1e-30)
+        ferr = float((np.abs(x.cpu().numpy().astype(np.float64) - x_ref) / scale).max())
+        parity = {"status": "pass" if bad_r == 0 and ferr <= 1e-4 else "fail", "rows": m, "rows_out_of_residual_bound": bad_r,
+                  "residual_tol": tol_r, "max_forward_error_vs_oracle": ferr, "forward_tol": 1e-4,
+                  "against": "row-wise |b - Lx| <= tol (|b| + |L||x|) in fp64 on the device, rows 1..m-1; x (every row) against oracle_trsv "
+                             "(CPU restatement of triangular_solve_impl.hpp:41-94) at 100x the tolerance (conditioning), "
+                             "as tests/test_gpu_sptrsv.py"}
+        del xd, vd, bd, rows_e, tx, ab
         return _emit(args, "csr_sptrsv_gflops", 2.0 * nnz, alg_bytes, elapsed, ms,
               f"8f: fp32 lower-triangular solve {m}x{m}, {k} random sub-diagonal entries per row + diagonal",
               {"dtype": "f32", "rows": m, "nnz": nnz, "plan": info.state_.info(),
                "triangular_solve_inspect_ms_untimed": inspect_ms,
-               "triangular_solve_inspect_first_call_ms": inspect_first_ms}, cpu)
+               "triangular_solve_inspect_first_call_ms": inspect_first_ms,
+               "kernel": "sptrsv cooperative level kernel"}, cpu, parity=parity)
 
     raise SystemExit(f"unknown workload {args.workload}")

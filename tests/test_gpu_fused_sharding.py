@@ -147,3 +147,18 @@ def test_bench_with_several_ranks_on_one_gpu(gpu, world, workload, fused):
             assert mg["fused_pipelined_step_ms"] > 0 and mg["fused_pipelined_check"] is True
     else:
         assert len(set(mg["rows_per_rank"])) > 1 and mg["gather"] == "p2p"   # nnz-prefix shards differ in rows
+
+
+@pytest.mark.parametrize("workload,rows", [("add", 60000), ("transpose", 300000), ("sptrsv", 200000), ("spgemm", 50000)])
+def test_bench_secondary_workloads_check_themselves(gpu, workload, rows):
+    """The SURVEY 8(f) operations (and cfg5) as bench workloads at a reduced size: every line carries a parity object from
+    the oracle -- structure exact for add / transpose / SpGEMM, residual + oracle comparison for the triangular solve --
+    the same records the default `python bench.py` run puts into `secondary` at full size."""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", workload, "--rows", str(rows),
+                        "--steps", "3", "--warmup", "1"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.stdout[-2000:], r.stderr[-2000:])
+    out = json.loads(lines[0])
+    assert out["parity_check"] == "pass", out["parity"]
+    assert out["roofline"]["kernel"] and out["value"] > 0
