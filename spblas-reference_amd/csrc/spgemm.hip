@@ -34,6 +34,10 @@
 #include <new>
 
 #define SPG_NBINS 6
+// counters of the binning pass: the accumulator bins plus one for the rows of bin 2 that a wavefront can take in ONE round
+// of vector loads (placed at the end of bin 2's range of perm[]: spg_sort_symbolic_kernel / spg_direct_kernel)
+#define SPG_NCNT 7
+#define SPG_SORTABLE 6
 #ifndef SPG_NBK64
 #define SPG_NBK64 64   // buckets of the rank sort in the numeric wave-per-row kernel (round 4, same box, cfg5 one-shot fill:
                        // 32 -> 1.62 ms, 64 -> 1.51, 128 -> 1.65, 256 -> 1.90: the bucket scan costs more than the rank loop saves)
@@ -83,8 +87,12 @@ struct spblas_gfx950_spgemm_s {
   // accumulate) and whose A row is one round of loads, listed by the symbolic pass as (first A entry, A entries, first
   // output position, row); the other rows of the bin keep the hash kernel (dir_rest).  nullptr: everything hashes.
   int4* dir_desc = nullptr;     // [n_dir]
-  int32_t* dir_rest = nullptr;  // [n_rest] rows of bin 2 that are not direct
+  int32_t* dir_rest = nullptr;  // [n_rest] rows of bin 2 that are not sortable
   int64_t n_dir = 0, n_rest = 0;
+  int64_t n_nodup = 0;          // the first n_nodup descriptors: no two products share a column
+  int64_t n_sortable = 0;       // rows at the end of bin 2's range that are one round of vector loads
+  int2* b_pack = nullptr;       // fp32 fills with many direct rows: (column, value bits) of B interleaved, REWRITTEN BY EVERY FILL
+  int32_t* sym_flag = nullptr;  // symbolic pass only: [n_sortable] 1 = no two products of the row share a column
   bool r_ready = false;
   int numeric_calls = 0;        // numeric passes since the symbolic one (the SECOND records: a one-shot fill pays nothing)
 };
@@ -112,36 +120,44 @@ __global__ __launch_bounds__(256) void spg_bound_kernel(int64_t m, const int32_t
                                                         const int32_t* __restrict__ d_rowptr,
                                                         const int2* __restrict__ adesc,
                                                         int32_t* __restrict__ bin_of_row,
-                                                        unsigned long long* __restrict__ bin_count) {
+                                                        unsigned long long* __restrict__ bin_count, int sub, int64_t b_nnz,
+                                                        int sortable_ok) {
   // grid-stride over groups of 32 rows: the bin histogram stays in LDS for the whole workgroup and reaches the
   // global counters once per workgroup -- with one workgroup per 32 rows the 31 k same-address atomics of a
   // 1 M-row matrix (~11 ns each, serialised) were the whole 0.38 ms of this kernel
-  __shared__ unsigned int hist[SPG_NBINS];
-  if (threadIdx.x < SPG_NBINS)
+  __shared__ unsigned int hist[SPG_NCNT];
+  if (threadIdx.x < SPG_NCNT)
     hist[threadIdx.x] = 0;
   __syncthreads();
   const int lane = threadIdx.x % 8;
   for (int64_t row = (int64_t) blockIdx.x * 32 + threadIdx.x / 8; row < m; row += (int64_t) gridDim.x * 32) {
     int64_t ub = 0;
-    for (int p = a_rowptr[row] + lane; p < a_rowptr[row + 1]; p += 8) {
+    int bad = 0;  // a B row longer than `sub`, or one whose range padded to whole vectors of four leaves B's arrays
+    const int p0 = a_rowptr[row], p1 = a_rowptr[row + 1];
+    for (int p = p0 + lane; p < p1; p += 8) {
       if (adesc) {
-        ub += adesc[p].y;
+        const int2 dd = adesc[p];
+        ub += dd.y;
+        bad |= (int) (dd.y > sub) | (int) ((int64_t) dd.x + ((dd.y + 3) & ~3) > b_nnz);
         continue;
       }
       const int kk = a_colind[p];
       ub += b_rowptr ? b_rowptr[kk + 1] - b_rowptr[kk] : 1;  // no B: identity (add(), see below)
     }
     ub = group_sum_c<8>(ub);
+    bad = group_sum_c<8>(bad);
     if (d_rowptr)
       ub += d_rowptr[row + 1] - d_rowptr[row];
     if (lane == 0) {
-      const int b = spg_bin_of(ub);
+      int b = spg_bin_of(ub);
+      if (b == 2 && sortable_ok && !bad && p1 - p0 <= 4 * (64 / sub) && p1 - p0 <= 64)
+        b = SPG_SORTABLE;
       bin_of_row[row] = b;
       atomicAdd(&hist[b], 1u);
     }
   }
   __syncthreads();
-  if (threadIdx.x < SPG_NBINS && hist[threadIdx.x])
+  if (threadIdx.x < SPG_NCNT && hist[threadIdx.x])
     atomicAdd(&bin_count[threadIdx.x], (unsigned long long) hist[threadIdx.x]);
 }
 
@@ -151,16 +167,16 @@ __global__ __launch_bounds__(1024) void spg_fill_perm_kernel(int64_t m, const in
   // workgroup-aggregated append: one global atomic per (workgroup of 1024 rows, bin).  With uniform inputs every
   // row lands in the same bin: per-row atomics on that one cursor serialise (12 ms at 1 M rows), per-wavefront
   // atomics still cost 0.19 ms (15.6 k of them at ~11 ns), per-workgroup ones 1 k.
-  __shared__ unsigned s_cnt[SPG_NBINS];
-  __shared__ unsigned long long s_base[SPG_NBINS];
-  if (threadIdx.x < SPG_NBINS)
+  __shared__ unsigned s_cnt[SPG_NCNT];
+  __shared__ unsigned long long s_base[SPG_NCNT];
+  if (threadIdx.x < SPG_NCNT)
     s_cnt[threadIdx.x] = 0;
   __syncthreads();
   const int64_t row = (int64_t) blockIdx.x * 1024 + threadIdx.x;
   const int lane = threadIdx.x & 63;
   const int bin = row < m ? bin_of_row[row] : -1;
   unsigned my_off = 0;  // position of this row among the workgroup's rows of its bin
-  for (int b = 0; b < SPG_NBINS; ++b) {
+  for (int b = 0; b < SPG_NCNT; ++b) {
     const unsigned long long mask = __ballot(bin == b);
     if (mask == 0)
       continue;
@@ -173,7 +189,7 @@ __global__ __launch_bounds__(1024) void spg_fill_perm_kernel(int64_t m, const in
       my_off = base + (unsigned) __popcll(mask & ((1ull << lane) - 1ull));
   }
   __syncthreads();
-  if (threadIdx.x < SPG_NBINS && s_cnt[threadIdx.x])
+  if (threadIdx.x < SPG_NCNT && s_cnt[threadIdx.x])
     s_base[threadIdx.x] = atomicAdd(&cursor[threadIdx.x], (unsigned long long) s_cnt[threadIdx.x]);
   __syncthreads();
   if (bin >= 0)
@@ -997,58 +1013,41 @@ static size_t hash_smem_bytes() {
 // 67 % of the wave cycles waiting (SQ counters, profiles/r04_spgemm_direct.md) -- so every wavefront here keeps three rows
 // in flight: while row i is sorted it has already issued the B loads of row i + 1, the A loads of row i + 2 and the
 // descriptor load of row i + 3.
-// flag[idx] = 1 when row perm[idx] is direct.  16 lanes per row: one (start, length) pair of the A row's B rows each.
-__global__ __launch_bounds__(256) void spg_direct_flag_kernel(int64_t count, const int32_t* __restrict__ perm,
-                                                              const int32_t* __restrict__ a_rowptr,
-                                                              const int2* __restrict__ adesc,
-                                                              const int32_t* __restrict__ c_rowptr, int sub,
-                                                              int64_t b_nnz, int32_t* __restrict__ flag) {
-  const int64_t idx = ((int64_t) blockIdx.x * blockDim.x + threadIdx.x) >> 4;
-  const int l16 = threadIdx.x & 15;
-  const bool live = idx < count;
-  int p0 = 0, na = 0, dlen = -1;
-  if (live) {
-    const int row = perm[idx];
-    p0 = a_rowptr[row];
-    na = a_rowptr[row + 1] - p0;
-    dlen = c_rowptr[row + 1] - c_rowptr[row];
-  }
-  const bool fits = live && na <= 4 * (64 / sub) && na <= 64;
-  int sum = 0, bad = 0;
-  if (fits)
-    for (int p = l16; p < na; p += 16) {
-      const int2 dd = adesc[p0 + p];
-      const int len = dd.y;
-      // (the direct kernel reads a B row in vectors of four entries: the padded range has to stay inside the arrays)
-      bad |= (int) (len > sub) | (int) ((int64_t) dd.x + ((len + 3) & ~3) > b_nnz);
-      sum += len;
-    }
-#pragma unroll
-  for (int o = 8; o > 0; o >>= 1) {
-    sum += __shfl_xor(sum, o, 16);
-    bad |= __shfl_xor(bad, o, 16);
-  }
-  if (live && l16 == 0)
-    flag[idx] = (int32_t) (fits && !bad && sum == dlen && sum > 0 && sum <= 256);
-}
-
-// flag[] scanned: the direct rows' descriptors in list order, the other rows of the bin behind each other in `rest`
-__global__ __launch_bounds__(256) void spg_direct_lists_kernel(int64_t count, const int32_t* __restrict__ perm,
+// descriptors of the sortable rows for spg_direct_kernel, (first A entry, A entries, first output position, output
+// length): flag[] of spg_sort_symbolic_kernel scanned -- the rows whose products all have a column of their own from the
+// front of desc[] in list order, the rows with shared columns from its end
+__global__ __launch_bounds__(256) void spg_direct_lists_kernel(int64_t count, const int32_t* __restrict__ rows,
                                                                const int32_t* __restrict__ a_rowptr,
                                                                const int32_t* __restrict__ c_rowptr,
                                                                const int32_t* __restrict__ flag_excl,
-                                                               int4* __restrict__ desc, int32_t* __restrict__ rest) {
+                                                               int4* __restrict__ desc) {
   const int64_t idx = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= count)
     return;
-  const int pos = flag_excl[idx];
-  const int row = perm[idx];
-  if (flag_excl[idx + 1] != pos) {
-    const int p0 = a_rowptr[row], out0 = c_rowptr[row];
-    desc[pos] = make_int4(p0, a_rowptr[row + 1] - p0, out0, c_rowptr[row + 1] - out0);
-  } else {
-    rest[idx - pos] = row;
-  }
+  const int row = rows[idx];
+  const int p0 = a_rowptr[row], out0 = c_rowptr[row], pos = flag_excl[idx];
+  const int4 d = make_int4(p0, a_rowptr[row + 1] - p0, out0, c_rowptr[row + 1] - out0);
+  if (flag_excl[idx + 1] != pos)
+    desc[pos] = d;
+  else
+    desc[count - 1 - (idx - pos)] = d;
+}
+
+// Inclusive scan of one int per lane over the wavefront with DPP moves (row_shr 1 / 2 / 4 / 8 inside the rows of 16 lanes,
+// row_bcast:15 / :31 across them; lanes without a source read 0): six vector instructions with no LDS round trip -- the
+// shuffle form is six DEPENDENT ds_bpermute, a third of the LDS latency chain of a row in the kernels below.
+template <int CTRL, int ROWS>
+__device__ __forceinline__ int spg_dpp(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, ROWS, 0xf, true);
+}
+__device__ __forceinline__ int spg_wave_incl_scan(int v) {
+  v += spg_dpp<0x111, 0xf>(v);
+  v += spg_dpp<0x112, 0xf>(v);
+  v += spg_dpp<0x114, 0xf>(v);
+  v += spg_dpp<0x118, 0xf>(v);
+  v += spg_dpp<0x142, 0xa>(v);
+  v += spg_dpp<0x143, 0xc>(v);
+  return v;
 }
 
 // four consecutive elements as one 16-byte (fp64 values: 32-byte) access at 4-byte (8-byte) alignment: global memory takes
@@ -1060,11 +1059,21 @@ template <typename T> struct spg_vec4;
 template <> struct spg_vec4<float> { typedef spg_f4u type; };
 template <> struct spg_vec4<double> { typedef spg_d4u type; };
 
-template <typename T>
+// (column, value) pairs of B in one array: what limits spg_direct_kernel is the number of distinct 128-byte lines the
+// memory system can fetch at random (~32 G/s measured, whether the 16 M gathers of cfg5 ask for one line each -- the symbolic
+// pass, 0.56 ms -- or two -- columns and values of the numeric pass, 1.0 ms); a B row of 16 entries is ONE line here.
+__global__ __launch_bounds__(256) void spg_pack_b_kernel(int64_t nnz, const int32_t* __restrict__ col,
+                                                         const float* __restrict__ val, int2* __restrict__ out) {
+  const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nnz)
+    out[i] = make_int2(col[i], __float_as_int(val[i]));
+}
+
+template <typename T, bool PACKED, bool DUP>
 __global__ __launch_bounds__(256) void spg_direct_kernel(
     int n_dir, const int4* __restrict__ desc, const int2* __restrict__ adesc, const T* __restrict__ a_values,
     const int32_t* __restrict__ b_colind, const T* __restrict__ b_values, int32_t* __restrict__ c_colind,
-    T* __restrict__ c_values, T alpha, int sub, unsigned bucket_mul) {
+    T* __restrict__ c_values, T alpha, int sub, unsigned bucket_mul, const int2* __restrict__ b_pack) {
   constexpr int NBK = SPG_DIR_NBK, BPL = NBK / 64;
   typedef typename spg_vec4<T>::type v4u;
   __shared__ __attribute__((aligned(16))) int s_keys[4][256 + 4];
@@ -1092,7 +1101,7 @@ __global__ __launch_bounds__(256) void spg_direct_kernel(
   auto load_desc = [&](int r) { return r < n_dir ? desc[r] : make_int4(0, 0, 0, 0); };
   auto load_a = [&](const int4& d) {
     arow a{0, 0, T(0)};
-    if (lt < d.y) {
+    if (lt < (d.y & 0xFFFF)) {
       const int2 dd = adesc[d.x + lt];
       a.qb = dd.x;
       a.len = dd.y;
@@ -1100,13 +1109,20 @@ __global__ __launch_bounds__(256) void spg_direct_kernel(
     }
     return a;
   };
-  auto load_b = [&](const arow& a, int na) {
+  auto load_b = [&](const arow& a, int na_f) {
+    const int na = na_f & 0xFFFF;
     brow b;
     const int q0 = __shfl(a.qb, jr, 64) + c4, ln = __shfl(a.len, jr, 64) - c4;  // (lanes >= na hold length 0)
     b.n = jr < na ? (ln < 0 ? 0 : ln > 4 ? 4 : ln) : 0;
     const int q = b.n > 0 ? q0 : 0;  // (entries 0 .. 3 exist: some admitted row has a B row whose padded range is inside)
-    b.cc = *reinterpret_cast<const spg_i4u*>(b_colind + q);  // (non-temporal gathers were measured: 1.55 against 1.11 ms)
-    b.vv = *reinterpret_cast<const v4u*>(b_values + q);
+    if constexpr (PACKED && sizeof(T) == 4) {
+      const spg_i4u lo = *reinterpret_cast<const spg_i4u*>(b_pack + q), hi = *reinterpret_cast<const spg_i4u*>(b_pack + q + 2);
+      b.cc = spg_i4u{lo[0], lo[2], hi[0], hi[2]};
+      b.vv = v4u{__int_as_float(lo[1]), __int_as_float(lo[3]), __int_as_float(hi[1]), __int_as_float(hi[3])};
+    } else {
+      b.cc = *reinterpret_cast<const spg_i4u*>(b_colind + q);  // (non-temporal gathers were measured: 1.55 against 1.11 ms)
+      b.vv = *reinterpret_cast<const v4u*>(b_values + q);
+    }
     return b;
   };
   int4 d0 = load_desc(i), d1 = load_desc(i + stride), d2 = load_desc(i + 2 * stride);
@@ -1130,6 +1146,8 @@ __global__ __launch_bounds__(256) void spg_direct_kernel(
     // row i: products, bucket counts (the atomic returns the arrival number inside the bucket), scan, keys in bucket
     // order, rank of every product's key inside its bucket, sorted row in LDS, write
     const int out0 = d0.z, dlen = d0.w;
+    constexpr bool dup = DUP;  // some products of the row share a column: ties in the sort, sums in the output (the rows
+                               // of that kind have a launch of their own: the extra registers cost the others a wavefront per SIMD)
     const T av = __shfl(alpha * a0.a, jr, 64);
     int col[U], bk[U], ai[U];
     T pv[U];
@@ -1148,13 +1166,7 @@ __global__ __launch_bounds__(256) void spg_direct_kernel(
         c[j] = bcnt[lt * BPL + j];
         tot += c[j];
       }
-      int incl = tot;
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const int t = __shfl_up(incl, o, 64);
-        if (lt >= o)
-          incl += t;
-      }
+      const int incl = spg_wave_incl_scan(tot);
       int run = incl - tot;
 #pragma unroll
       for (int j = 0; j < BPL; ++j) {
@@ -1178,6 +1190,13 @@ __global__ __launch_bounds__(256) void spg_direct_kernel(
         const int e0 = bcnt[bk[u]], e1 = bcnt[bk[u] + 1];
         rank[u] = e0;
 #if SPG_DIR_READ2
+        if (dup) {  // equal keys: the earlier arrival first
+          const int mypos = e0 + ai[u];
+          for (int j = e0; j < e1; ++j) {
+            const int k0 = tkeys[j];
+            rank[u] += (int) (k0 < col[u]) + (int) ((k0 == col[u]) & (j < mypos));
+          }
+        } else
         for (int j = e0; j < e1; j += 2) {  // (a key past the bucket's end is read -- the array has the slack -- and not counted)
           const int k0 = tkeys[j], k1 = tkeys[j + 1];
           rank[u] += (int) (k0 < col[u]) + (int) ((j + 1 < e1) & (k1 < col[u]));
@@ -1189,6 +1208,11 @@ __global__ __launch_bounds__(256) void spg_direct_kernel(
       }
     }
     spg_team_sync<64>();
+    int n_prod = dlen;  // products of the row (the scan's total)
+    if constexpr (dup) {
+      n_prod = bcnt[NBK];
+      spg_team_sync<64>();
+    }
     zero_buckets();
     // The sorted row is put together in LDS and leaves as whole lines.  Lanes storing 4 bytes each at their products'
     // ranks were 495 separate accesses per row in the vector-memory address unit (TCP_TOTAL_WRITE; TA_BUSY 80 - 93 %:
@@ -1200,6 +1224,43 @@ __global__ __launch_bounds__(256) void spg_direct_kernel(
         tvals[rank[u]] = pv[u];
       }
     spg_team_sync<64>();
+    if constexpr (dup) {
+      // equal columns are neighbours now: the first of a run takes the run's sum (later arrivals added in order) and moves
+      // to position (number of runs before it); every lane works its four elements out in registers before anything is
+      // written back
+      const int n = n_prod, e = 4 * lt;
+      int k[U], o[U];
+      T sv[U];
+      bool head[U];
+      const int prev = e > 0 && e <= n ? tkeys[e - 1] : -1;
+      int heads = 0;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        k[u] = e + u < n ? tkeys[e + u] : -1;
+        head[u] = e + u < n && k[u] != (u == 0 ? prev : k[u - 1]);
+        heads += (int) head[u];
+      }
+      int before = spg_wave_incl_scan(heads) - heads;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        o[u] = before;
+        sv[u] = T(0);
+        if (head[u]) {
+          sv[u] = tvals[e + u];
+          for (int j = e + u + 1; j < n && tkeys[j] == k[u]; ++j)
+            sv[u] += tvals[j];
+          ++before;
+        }
+      }
+      spg_team_sync<64>();
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (head[u]) {
+          tkeys[o[u]] = k[u];
+          tvals[o[u]] = sv[u];
+        }
+      spg_team_sync<64>();
+    }
     // the loads issued at the top have had the whole sort to arrive: wait for them HERE, before this row's stores are
     // issued (vmcnt counts in order: a wait placed after the stores -- where the register rotation below would put it --
     // would wait for the stores as well)
@@ -1225,6 +1286,158 @@ __global__ __launch_bounds__(256) void spg_direct_kernel(
     d0 = d1;
     d1 = d2;
     d2 = d3;
+    i += stride;
+  }
+}
+
+// Symbolic pass over the sortable rows (the same mapping and pipeline as spg_direct_kernel, keys only): the distinct
+// columns of a row are its products minus the keys that have an equal key at a lower position of their bucket.
+// row_nnz[row] = distinct columns; flag[i] = 1 when every product has a column of its own (the row is direct).  The LDS
+// hash of spg_hash_kernel<.., false> was VALU-bound on these rows (308 vector instructions per row, 90 % busy).
+__global__ __launch_bounds__(256) void spg_sort_symbolic_kernel(int n_rows, const int32_t* __restrict__ rows,
+                                                                const int32_t* __restrict__ a_rowptr,
+                                                                const int2* __restrict__ adesc,
+                                                                const int32_t* __restrict__ b_colind,
+                                                                int32_t* __restrict__ row_nnz, int32_t* __restrict__ flag,
+                                                                int sub, unsigned bucket_mul) {
+  constexpr int NBK = SPG_DIR_NBK, BPL = NBK / 64;
+  __shared__ __attribute__((aligned(16))) int s_keys[4][256 + 4];
+  __shared__ __attribute__((aligned(16))) int s_bcnt[4][NBK + 4];
+  const int wave = threadIdx.x >> 6, lt = threadIdx.x & 63;
+  int* tkeys = s_keys[wave];
+  int* bcnt = s_bcnt[wave];
+  const int lshift = __builtin_ctz((unsigned) sub) - 2;
+  const int jr = lt >> lshift, c4 = (lt & ((1 << lshift) - 1)) * 4;
+  const int stride = (int) gridDim.x * 4;
+  int i = __builtin_amdgcn_readfirstlane((int) blockIdx.x * 4 + wave);
+  constexpr int U = 4;
+  struct rdesc {
+    int row, p0, na;
+  };
+  struct arow {
+    int qb, len;
+  };
+  struct brow {
+    spg_i4u cc;
+    int n;
+  };
+  auto load_row = [&](int r) { return r < n_rows ? rows[r] : -1; };
+  auto load_rp = [&](int row) {
+    rdesc d{row, 0, 0};
+    if (row >= 0) {
+      d.p0 = a_rowptr[row];
+      d.na = a_rowptr[row + 1] - d.p0;
+    }
+    return d;
+  };
+  auto load_a = [&](const rdesc& d) {
+    arow a{0, 0};
+    if (lt < d.na) {
+      const int2 dd = adesc[d.p0 + lt];
+      a.qb = dd.x;
+      a.len = dd.y;
+    }
+    return a;
+  };
+  auto load_b = [&](const arow& a, int na) {
+    brow b;
+    const int q0 = __shfl(a.qb, jr, 64) + c4, ln = __shfl(a.len, jr, 64) - c4;
+    b.n = jr < na ? (ln < 0 ? 0 : ln > 4 ? 4 : ln) : 0;
+    b.cc = *reinterpret_cast<const spg_i4u*>(b_colind + (b.n > 0 ? q0 : 0));
+    return b;
+  };
+  int r3 = load_row(i + 3 * stride);
+  rdesc d0 = load_rp(load_row(i)), d1 = load_rp(load_row(i + stride)), d2 = load_rp(load_row(i + 2 * stride));
+  arow a0 = load_a(d0), a1 = load_a(d1);
+  brow b0 = load_b(a0, d0.na);
+  auto zero_buckets = [&]() {
+#pragma unroll
+    for (int j = 0; j < BPL; ++j)
+      bcnt[lt * BPL + j] = 0;
+    if (lt == 0)
+      bcnt[NBK] = 0;
+  };
+  zero_buckets();
+  spg_team_sync<64>();
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): as in spg_direct_kernel
+  while (i < n_rows) {
+    const brow b1 = load_b(a1, d1.na);
+    const arow a2 = load_a(d2);
+    const rdesc d3 = load_rp(r3);
+    const int r4 = load_row(i + 4 * stride);
+    int col[U], bk[U], ai[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      col[u] = u < b0.n ? b0.cc[u] : -1;
+      bk[u] = col[u] >= 0 ? (int) __umulhi((unsigned) col[u], bucket_mul) : 0;
+      ai[u] = col[u] >= 0 ? atomicAdd(&bcnt[bk[u]], 1) : 0;
+    }
+    spg_team_sync<64>();
+    {
+      int c[BPL], tot = 0;
+#pragma unroll
+      for (int j = 0; j < BPL; ++j) {
+        c[j] = bcnt[lt * BPL + j];
+        tot += c[j];
+      }
+      const int incl = spg_wave_incl_scan(tot);
+      int run = incl - tot;
+#pragma unroll
+      for (int j = 0; j < BPL; ++j) {
+        bcnt[lt * BPL + j] = run;
+        run += c[j];
+      }
+      if (lt == 63)
+        bcnt[NBK] = incl;
+    }
+    spg_team_sync<64>();
+    // positions, keys in bucket order, and for every key whether an EQUAL key arrived in its bucket before it -- the
+    // arrival number ai is the count of such predecessors, which sit at e0 .. e0 + ai - 1.  All reads of a step are issued
+    // before the first is used (unconditional: invalid lanes read bucket 0; the key array has four words of slack): the
+    // row is a chain of LDS round trips, and a wavefront has nothing else to do while one is in flight.
+    int e0[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      e0[u] = bcnt[bk[u]];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (col[u] >= 0)
+        tkeys[e0[u] + ai[u]] = col[u];
+    spg_team_sync<64>();
+    int pk[U][4];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        pk[u][k] = tkeys[e0[u] + k];
+    int products = 0, distinct = 0;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      bool first = col[u] >= 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        first = first && !(k < ai[u] && pk[u][k] == col[u]);
+      if (__ballot(col[u] >= 0 && ai[u] > 4) != 0ull)  // (a bucket of more than five keys: rare with 128 buckets)
+        for (int j = 4; j < ai[u]; ++j)
+          first = first && tkeys[e0[u] + j] != col[u];
+      products += (int) __popcll(__ballot(col[u] >= 0));
+      distinct += (int) __popcll(__ballot(first));
+    }
+    spg_team_sync<64>();
+    zero_buckets();
+    spg_team_sync<64>();
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // the prefetched loads, before this row's stores (see spg_direct_kernel)
+    if (lt == 0) {
+      row_nnz[d0.row] = distinct;
+      flag[i] = (int32_t) (distinct == products && products > 0);
+    }
+    b0 = b1;
+    a0 = a1;
+    a1 = a2;
+    d0 = d1;
+    d1 = d2;
+    d2 = d3;
+    r3 = r4;
     i += stride;
   }
 }
@@ -1275,17 +1488,60 @@ static int run_bins(spblas_gfx950_handle_t h, spblas_gfx950_spgemm_s* st, const 
   if (NUMERIC && skip_upto < 2 && st->dir_desc && !st->d_rowptr && st->b_rowptr && st->r_adesc) {
     if constexpr (NUMERIC) {
       if (st->n_dir > 0) {
-        const int64_t wgs = std::min<int64_t>(cdiv(st->n_dir, 4), (int64_t) h->num_cus * 8);
-        hipLaunchKernelGGL((spg_direct_kernel<T>), dim3((unsigned) wgs), dim3(256), 0, s, (int) st->n_dir, st->dir_desc,
-                           st->r_adesc, a_values, st->b_colind, b_values, c_colind, c_values, alpha,
-                           st->sub < 64 ? st->sub : 64, spg_bucket_mul(SPG_DIR_NBK, st->n));
+        // fp32 with enough direct rows: one pass interleaves B's columns and values (3 ps per entry of B against ~30 ps
+        // per line a gather no longer fetches).  SPBLAS_GFX950_SPG_PACK=0 / 1: never / whenever there is a direct row
+        static const int pack_env = [] {
+          const char* ev = std::getenv("SPBLAS_GFX950_SPG_PACK");
+          return ev ? std::atoi(ev) : -1;
+        }();
+        bool packed = false;
+        if constexpr (sizeof(T) == 4) {
+          const double dir_entries = (double) st->n_dir * (st->m > 0 ? (double) st->a_nnz / (double) st->m : 0.0);
+          if (pack_env != 0 && (pack_env == 1 || dir_entries * 8.0 >= (double) st->b_nnz) &&
+              (st->b_pack || dev_alloc((void**) &st->b_pack, (size_t) (st->b_nnz + 4) * 8, s) == SPBLAS_GFX950_STATUS_SUCCESS)) {
+            hipLaunchKernelGGL(spg_pack_b_kernel, dim3((unsigned) cdiv(st->b_nnz, 256)), dim3(256), 0, s, st->b_nnz,
+                               st->b_colind, b_values, st->b_pack);
+            packed = true;
+          }
+        }
+        const int sub_k = st->sub < 64 ? st->sub : 64;
+        const unsigned bmul = spg_bucket_mul(SPG_DIR_NBK, st->n);
+        const int64_t n_dup = st->n_dir - st->n_nodup;
+        const int64_t wgs1 = std::min<int64_t>(cdiv(st->n_nodup, 4), (int64_t) h->num_cus * 8);
+        const int64_t wgs2 = std::min<int64_t>(cdiv(n_dup, 4), (int64_t) h->num_cus * 8);
+        auto launch = [&](auto kern, int64_t g, int64_t first, int64_t cnt) {
+          if (cnt > 0)
+            hipLaunchKernelGGL(kern, dim3((unsigned) g), dim3(256), 0, s, (int) cnt, st->dir_desc + first, st->r_adesc, a_values,
+                               st->b_colind, b_values, c_colind, c_values, alpha, sub_k, bmul, st->b_pack);
+        };
+        if (packed) {
+          launch(spg_direct_kernel<T, true, false>, wgs1, 0, st->n_nodup);
+          launch(spg_direct_kernel<T, true, true>, wgs2, st->n_nodup, n_dup);
+        } else {
+          launch(spg_direct_kernel<T, false, false>, wgs1, 0, st->n_nodup);
+          launch(spg_direct_kernel<T, false, true>, wgs2, st->n_nodup, n_dup);
+        }
         SPB_HIP(hipGetLastError());
       }
       // (the hash kernel on a second stream next to the direct kernel was measured: 1.257 against 1.225 ms)
-      if ((rc = launch_hash<T, 9, 64, true>(s, st, 2, a_values, b_values, c_rowptr, c_colind, c_values, alpha, d_values,
+      if (st->n_rest > 0 &&
+          (rc = launch_hash<T, 9, 64, true>(s, st, 2, a_values, b_values, c_rowptr, c_colind, c_values, alpha, d_values,
                                             beta, st->dir_rest, st->n_rest)))
         return rc;
     }
+  } else if (!NUMERIC && st->sym_flag && st->n_sortable > 0) {
+    // symbolic pass: the sortable rows (the end of the bin's range) are sorted, the others hashed
+    const int64_t c2 = st->bin_off[3] - st->bin_off[2], n_other = c2 - st->n_sortable;
+    if constexpr (!NUMERIC) {
+      if (n_other > 0 && (rc = launch_hash<T, 9, 32, false>(s, st, 2, a_values, b_values, c_rowptr, c_colind, c_values, alpha,
+                                                            d_values, beta, st->perm + st->bin_off[2], n_other)))
+        return rc;
+    }
+    const int64_t wgs = std::min<int64_t>(cdiv(st->n_sortable, 4), (int64_t) h->num_cus * 8);
+    hipLaunchKernelGGL(spg_sort_symbolic_kernel, dim3((unsigned) wgs), dim3(256), 0, s, (int) st->n_sortable,
+                       st->perm + st->bin_off[3] - st->n_sortable, st->a_rowptr, st->r_adesc, st->b_colind, c_rowptr,
+                       st->sym_flag, st->sub < 64 ? st->sub : 64, spg_bucket_mul(SPG_DIR_NBK, st->n));
+    SPB_HIP(hipGetLastError());
   } else if (skip_upto < 2 &&
              (rc = launch_hash<T, 9, NUMERIC ? 64 : 32, NUMERIC>(s, st, 2, a_values, b_values, c_rowptr, c_colind,
                                                                  c_values, alpha, d_values, beta)))
@@ -1496,9 +1752,11 @@ static void spgemm_release(spblas_gfx950_spgemm_s* st, hipStream_t s) {
   st->r_adesc = nullptr;
   dev_free(st->dir_desc, s);
   dev_free(st->dir_rest, s);
+  dev_free(st->b_pack, s);
   st->dir_desc = nullptr;
   st->dir_rest = nullptr;
-  st->n_dir = st->n_rest = 0;
+  st->b_pack = nullptr;
+  st->n_dir = st->n_rest = st->n_nodup = 0;
   st->r_pbase = nullptr;
   st->r_rank = nullptr;
   st->r_cols = nullptr;
@@ -1610,14 +1868,14 @@ static int spgemm_symbolic_impl(spblas_gfx950_handle_t handle, spblas_gfx950_spg
   // (on the null stream every dev_alloc / dev_free is a synchronous hipMalloc / hipFree)
   const int64_t nb = cdiv(m, 2048);
   const size_t bin_bytes = (((size_t) m * 4) + 255) & ~(size_t) 255;
-  const size_t cnt_bytes = 256;  // 2 * SPG_NBINS counters
+  const size_t cnt_bytes = 256;  // 2 * SPG_NCNT counters
   void* scratch = nullptr;
   if ((rc = handle_scratch(handle, bin_bytes + cnt_bytes + (size_t) (nb + 1) * sizeof(long long) + 256, &scratch)))
     return rc;
   int32_t* bin_of_row = static_cast<int32_t*>(scratch);
   unsigned long long* d_cnt = reinterpret_cast<unsigned long long*>(static_cast<char*>(scratch) + bin_bytes);
   long long* partials = reinterpret_cast<long long*>(static_cast<char*>(scratch) + bin_bytes + cnt_bytes);
-  SPB_HIP(hipMemsetAsync(d_cnt, 0, 2 * SPG_NBINS * sizeof(unsigned long long), s));
+  SPB_HIP(hipMemsetAsync(d_cnt, 0, 2 * SPG_NCNT * sizeof(unsigned long long), s));
   // (start, length) of the B row of every A entry, one coalesced pass while b_rowptr still has the L2s to itself
   {
     const char* env = std::getenv("SPBLAS_GFX950_SPG_ADESC");
@@ -1627,23 +1885,35 @@ static int spgemm_symbolic_impl(spblas_gfx950_handle_t handle, spblas_gfx950_spg
                          st->r_adesc);
   }
   const int64_t bound_wgs = cdiv(m, 32) < 8 * (int64_t) handle->num_cus ? cdiv(m, 32) : 8 * (int64_t) handle->num_cus;
+  // rows of bin 2 that a wavefront can take in one round of vector loads get a counter of their own and the END of bin 2's
+  // range in perm[] (SPBLAS_GFX950_SPG_DIRECT=0: none): sorted, not hashed, by both passes
+  static const int dir_env = [] {
+    const char* ev = std::getenv("SPBLAS_GFX950_SPG_DIRECT");
+    return ev ? std::atoi(ev) : 1;
+  }();
+  const int sortable_ok = dir_env != 0 && !identity_b && b_rowptr && st->r_adesc && !st->d_rowptr && b_nnz >= 4;
   hipLaunchKernelGGL(spg_bound_kernel, dim3((unsigned) bound_wgs), dim3(256), 0, s, m, a_rowptr, a_colind,
-                     b_rowptr, st->d_rowptr, st->r_adesc, bin_of_row, d_cnt);
+                     b_rowptr, st->d_rowptr, st->r_adesc, bin_of_row, d_cnt, st->sub < 64 ? st->sub : 64, b_nnz, sortable_ok);
   SPB_HIP(hipGetLastError());
-  unsigned long long counts[SPG_NBINS];
+  unsigned long long counts[SPG_NCNT];
   SPB_HIP(hipMemcpyAsync(counts, d_cnt, sizeof(counts), hipMemcpyDeviceToHost, s));
   SPB_HIP(hipStreamSynchronize(s));
-  unsigned long long cursors[SPG_NBINS];
+  unsigned long long cursors[SPG_NCNT];
   st->bin_off[0] = 0;
   for (int b = 0; b < SPG_NBINS; ++b) {
     cursors[b] = (unsigned long long) st->bin_off[b];
-    st->bin_off[b + 1] = st->bin_off[b] + (int64_t) counts[b];
+    st->bin_off[b + 1] = st->bin_off[b] + (int64_t) counts[b] + (b == 2 ? (int64_t) counts[SPG_SORTABLE] : 0);
   }
-  SPB_HIP(hipMemcpyAsync(d_cnt + SPG_NBINS, cursors, sizeof(cursors), hipMemcpyHostToDevice, s));
+  cursors[SPG_SORTABLE] = (unsigned long long) st->bin_off[2] + counts[2];
+  st->n_sortable = (int64_t) counts[SPG_SORTABLE];
+  SPB_HIP(hipMemcpyAsync(d_cnt + SPG_NCNT, cursors, sizeof(cursors), hipMemcpyHostToDevice, s));
   hipLaunchKernelGGL(spg_fill_perm_kernel, dim3((unsigned) cdiv(m, 1024)), dim3(1024), 0, s, m, bin_of_row,
-                     d_cnt + SPG_NBINS, st->perm);
+                     d_cnt + SPG_NCNT, st->perm);
   SPB_HIP(hipGetLastError());
 
+  // (the flags of the sortable rows go where the bin numbers were: dead once perm[] is filled, and [m + 1] ints with the
+  // counter block behind them)
+  st->sym_flag = st->n_sortable > 0 ? bin_of_row : nullptr;
   // distinct-column counts per row -> st->rowptr (as counts)
   if (st->bin_off[1] > 0)
     hipLaunchKernelGGL(spg_zero_rows_kernel, dim3((unsigned) cdiv(st->bin_off[1], 256)), dim3(256), 0, s,
@@ -1657,39 +1927,35 @@ static int spgemm_symbolic_impl(spblas_gfx950_handle_t handle, spblas_gfx950_spg
     hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned) nb), dim3(256), 0, s, m, st->rowptr, partials, c_rowptr);
     long long total = 0;
     hipError_t e = hipMemcpyAsync(&total, partials + nb, sizeof(total), hipMemcpyDeviceToHost, s);
-    // direct rows of bin 2 (see spg_direct_kernel): flag, scan, two lists; the list length comes back with the total.
-    // (The flags and the scan's partial sums reuse the scratch of the binning: both are dead, and the copy of the total
-    // above is ordered before the kernels that overwrite `partials`.)
-    const int64_t c2 = st->bin_off[3] - st->bin_off[2];
-    static const int dir_env = [] {
-      const char* ev = std::getenv("SPBLAS_GFX950_SPG_DIRECT");
-      return ev ? std::atoi(ev) : 1;
-    }();
-    bool classify = e == hipSuccess && dir_env != 0 && c2 > 0 && c2 <= INT32_MAX - 16 && !identity_b && b_rowptr &&
-                    st->r_adesc && !st->d_rowptr && b_nnz > 0;
-    if (classify && (dev_alloc((void**) &st->dir_desc, (size_t) c2 * sizeof(int4), s) != SPBLAS_GFX950_STATUS_SUCCESS ||
-                     dev_alloc((void**) &st->dir_rest, (size_t) c2 * 4, s) != SPBLAS_GFX950_STATUS_SUCCESS)) {
+    // sortable rows (see spg_direct_kernel): one descriptor each, with the symbolic sort's "no shared column" flag; the
+    // rows of the bin that are not sortable keep the hash kernel (dir_rest)
+    const int64_t c2 = st->bin_off[3] - st->bin_off[2], ns = st->n_sortable, n_other = c2 - ns;
+    bool classify = e == hipSuccess && ns > 0 && st->sym_flag && ns <= INT32_MAX - 16;
+    if (classify && (dev_alloc((void**) &st->dir_desc, (size_t) ns * sizeof(int4), s) != SPBLAS_GFX950_STATUS_SUCCESS ||
+                     (n_other > 0 && dev_alloc((void**) &st->dir_rest, (size_t) n_other * 4, s) != SPBLAS_GFX950_STATUS_SUCCESS))) {
       dev_free(st->dir_desc, s);
       dev_free(st->dir_rest, s);
       st->dir_desc = nullptr;
       st->dir_rest = nullptr;
       classify = false;  // out of memory for the optional lists: every row hashes
     }
-    long long n_dir = 0;
+    long long n_nodup = 0;
     if (classify) {
-      int32_t* flag = bin_of_row;  // [c2 + 1] <= [m + 1] ints: the bin numbers and, behind them, the bin counters
-      hipLaunchKernelGGL(spg_direct_flag_kernel, dim3((unsigned) cdiv(c2 * 16, 256)), dim3(256), 0, s, c2,
-                         st->perm + st->bin_off[2], a_rowptr, st->r_adesc, st->rowptr, st->sub < 64 ? st->sub : 64, b_nnz,
-                         flag);
-      long long* n_dir_dev = scan_counts_i32(s, c2, flag, partials);
-      hipLaunchKernelGGL(spg_direct_lists_kernel, dim3((unsigned) cdiv(c2, 256)), dim3(256), 0, s, c2,
-                         st->perm + st->bin_off[2], a_rowptr, st->rowptr, flag, st->dir_desc, st->dir_rest);
-      e = hipMemcpyAsync(&n_dir, n_dir_dev, sizeof(n_dir), hipMemcpyDeviceToHost, s);
+      if (n_other > 0)
+        e = hipMemcpyAsync(st->dir_rest, st->perm + st->bin_off[2], (size_t) n_other * 4, hipMemcpyDeviceToDevice, s);
+      // (the scan's partial sums reuse `partials`: the copy of the total above is ordered before these kernels)
+      long long* n_nodup_dev = scan_counts_i32(s, ns, st->sym_flag, partials);
+      hipLaunchKernelGGL(spg_direct_lists_kernel, dim3((unsigned) cdiv(ns, 256)), dim3(256), 0, s, ns,
+                         st->perm + st->bin_off[3] - ns, a_rowptr, st->rowptr, st->sym_flag, st->dir_desc);
+      if (e == hipSuccess)
+        e = hipMemcpyAsync(&n_nodup, n_nodup_dev, sizeof(n_nodup), hipMemcpyDeviceToHost, s);
     }
+    st->sym_flag = nullptr;
     if (e == hipSuccess)
       e = hipStreamSynchronize(s);
-    st->n_dir = classify ? n_dir : 0;
-    st->n_rest = classify ? c2 - n_dir : 0;
+    st->n_dir = classify ? ns : 0;
+    st->n_nodup = classify ? n_nodup : 0;
+    st->n_rest = classify ? n_other : 0;
     if (e != hipSuccess)
       rc = hip_fail(e);
     else if (total > INT32_MAX)
