@@ -377,8 +377,8 @@ def _run(args, device):
         parity = _spgemm_parity(oracle, m, (ar, ac, av), (br, bc, bv), c_rp, c, cn, one_shot)
         return _emit(args, "csr_spgemm_fill_gflops", 2.0 * products, alg_bytes, elapsed, ms,
               f"cfg5: fp32 CSR x CSR SpGEMM {m}x{m}, 16 nnz/row uniform random; timed step = one-shot multiply_fill "
-              "(sorted columns and values written: rows without duplicate columns sorted by the direct kernel, the others "
-              "through the hash accumulators), after multiply_compute",
+              "(sorted columns and values written; at this size every row is sorted by the direct kernel, none hashed), "
+              "after multiply_compute",
               {"dtype": "f32", "rows": m, "products": products, "nnz_c": cn, "state": state.info(),
                "multiply_compute_ms_untimed": compute_warm_ms,
                "multiply_compute_first_call_ms": compute_ms,
@@ -390,8 +390,8 @@ def _run(args, device):
                                   "algorithmic_bytes": reuse_bytes,
                                   "roofline_frac": reuse_bytes / (reuse_ms[0] * 1e-3) / 1e9 / 8000.0,
                                   "kernel": "spg_ranked_fill_kernel<float,16,256,4,false> (+ spg_rank_record_kernel<64,256> once)"},
-               "kernel": "spg_direct_kernel<float> (+ spg_hash_kernel<float,9,64,true> for the rows with duplicate columns; "
-                         "one fill = this launch pair)"}, cpu, parity=parity,
+               "kernel": "spg_pack_b_kernel + spg_direct_kernel<float,true,false> + <float,true,true> (rows with shared columns); "
+                         "one fill = this launch group"}, cpu, parity=parity,
                      pmc_key=None if args.rows else "spgemm_cfg5")
 
     if args.workload == "add":  # C = A + B, timed step = add_compute (numeric)
