@@ -323,7 +323,9 @@ int spblas_gfx950_spgemm_symbolic(spblas_gfx950_handle_t handle, spblas_gfx950_s
  * (test/gtest/device/spgemm_reuse_test.cpp).  a_values/b_values may change between
  * calls; the pattern may not.
  * Memory held by the state: 8 bytes per entry of A from the symbolic pass on (the bounds of the B row
- * every A entry selects); from the SECOND numeric pass on -- a one-shot fill pays nothing -- also one
+ * every A entry selects) and 16 bytes per row of 65..256 products that a wavefront can sort in one round
+ * (spblas_gfx950_spgemm_info: "direct" rows); fp32 fills with many such rows keep an interleaved
+ * (column, value) copy of B, 8 bytes per entry, rewritten by every fill; from the SECOND numeric pass on -- a one-shot fill pays nothing -- also one
  * byte per product of the rows with at most 256 products, two per product of the rows with 257..1024,
  * and 4 bytes per entry of C: later passes accumulate by recorded rank (SPBLAS_GFX950_SPGEMM_REUSE=0
  * in the environment keeps every pass on the hash kernels).  All of it is optional: an allocation
