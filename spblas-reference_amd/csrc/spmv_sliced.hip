@@ -2251,7 +2251,7 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
       }
     } else if (total > 0 && (int64_t) max_slice * S > 3 * total) {
       const int cus = h->num_cus > 0 ? h->num_cus : 256;
-      const int64_t target = std::max<int64_t>(cdiv(a_blocks, (int64_t) env_int("SPBLAS_GFX950_PB_XITEM_DIV", 3) * cus),
+      const int64_t target = std::max<int64_t>(cdiv(a_blocks, (int64_t) env_int("SPBLAS_GFX950_PB_XITEM_DIV", 2) * cus),
                                                4 * (int64_t) W / PB_BLK);
       std::vector<int4> items;
       for (int i = 0; i < S; ++i) {
