@@ -1079,8 +1079,10 @@ __global__ __launch_bounds__(256) void spg_direct_kernel(
   __shared__ __attribute__((aligned(16))) int s_keys[4][256 + 4];
   __shared__ __attribute__((aligned(16))) T s_vals[4][256];
   __shared__ __attribute__((aligned(16))) int s_bcnt[4][NBK + 4];
+  __shared__ unsigned char s_enum[4][DUP ? 256 + 4 : 4];  // DUP: the enumeration number of the product behind every key
   const int wave = threadIdx.x >> 6, lt = threadIdx.x & 63;
   int* tkeys = s_keys[wave];
+  unsigned char* tenum = s_enum[wave];
   T* tvals = s_vals[wave];
   int* bcnt = s_bcnt[wave];
   // sub / 4 lanes per B row, four consecutive entries each: lane lt works on entries c4 .. c4 + 3 of the B row of A entry jr
@@ -1179,8 +1181,11 @@ __global__ __launch_bounds__(256) void spg_direct_kernel(
     spg_team_sync<64>();
 #pragma unroll
     for (int u = 0; u < U; ++u)
-      if (col[u] >= 0)
+      if (col[u] >= 0) {
         tkeys[bcnt[bk[u]] + ai[u]] = col[u];
+        if constexpr (dup)  // lane lt, entry u = product number 4 lt + u of the reference's enumeration (A entry, then B entry)
+          tenum[bcnt[bk[u]] + ai[u]] = (unsigned char) (4 * lt + u);
+      }
     spg_team_sync<64>();
     int rank[U];
 #pragma unroll
@@ -1190,11 +1195,11 @@ __global__ __launch_bounds__(256) void spg_direct_kernel(
         const int e0 = bcnt[bk[u]], e1 = bcnt[bk[u] + 1];
         rank[u] = e0;
 #if SPG_DIR_READ2
-        if (dup) {  // equal keys: the earlier arrival first
-          const int mypos = e0 + ai[u];
+        if (dup) {  // equal keys in the order the reference enumerates the products: the run sums below then add in its order
+          const int me = 4 * lt + u;
           for (int j = e0; j < e1; ++j) {
             const int k0 = tkeys[j];
-            rank[u] += (int) (k0 < col[u]) + (int) ((k0 == col[u]) & (j < mypos));
+            rank[u] += (int) (k0 < col[u]) + (int) ((k0 == col[u]) & ((int) tenum[j] < me));
           }
         } else
         for (int j = e0; j < e1; j += 2) {  // (a key past the bucket's end is read -- the array has the slack -- and not counted)
@@ -1225,7 +1230,8 @@ __global__ __launch_bounds__(256) void spg_direct_kernel(
       }
     spg_team_sync<64>();
     if constexpr (dup) {
-      // equal columns are neighbours now: the first of a run takes the run's sum (later arrivals added in order) and moves
+      // equal columns are neighbours now, in enumeration order: the first of a run takes the run's sum (added in that order:
+      // the reference's sequence of += on one accumulator, multiply_impl / spgemm_gustavsons.hpp:30-41) and moves
       // to position (number of runs before it); every lane works its four elements out in registers before anything is
       // written back
       const int n = n_prod, e = 4 * lt;

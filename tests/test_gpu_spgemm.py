@@ -378,18 +378,24 @@ def _random_csr(rng, rows, cols, len_lo, len_hi, dtype, sorted_rows=True):
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("n", [3_000_000, 300])
 @pytest.mark.parametrize("b_len", [(12, 16), (5, 8), (1, 4), (0, 16)])
-def test_spgemm_direct_rows(gpu, dtype, b_len):
+def test_spgemm_direct_rows(gpu, dtype, b_len, n):
     """Rows whose product count equals their structural length (csrc/spgemm.hip: spg_direct_kernel, a persistent kernel that
     sorts the products in registers and LDS -- no hash): very sparse operands with a wide column range, B rows of every
     admitted length class (16 / 8 / 4 lanes' worth, empty rows, unsorted rows), A rows of 0 .. the round's limit, a last
     B row that ends at the end of the arrays (its vector reads may not run over: those rows must take the hash kernel),
-    alpha, and a second fill with new values (the one-shot path again: recording off).  Exact structure, values in bound."""
-    rng = np.random.default_rng(97 + b_len[0])
-    m, k, n = 6000, 9000, 3_000_000
+    alpha, and further fills with new values (by hash + recording, then by rank).  n = 300 columns: every row has products
+    that share a column, many of them several times (the DUP instance of the kernel: ties in the sort, run sums, compaction).
+    Exact structure, values in bound."""
+    rng = np.random.default_rng(97 + b_len[0] + (n & 7))
+    m, k = 6000, 9000
     sub = 16 if b_len[1] > 8 else 8 if b_len[1] > 4 else 4
     a_h = _random_csr(rng, m, k, 0, 256 // sub, dtype)
     b_h = _random_csr(rng, k, n, b_len[0], b_len[1], dtype, sorted_rows=False)
+    if n < 10000:  # sums of many products per entry: positive values, as the reference's generators produce -- its comparator
+        a_h = (np.abs(a_h[0]) + dtype(0.01),) + a_h[1:]  # (EXPECT_EQ_, relative to the RESULT) is not meant for cancellation
+        b_h = (np.abs(b_h[0]) + dtype(0.01),) + b_h[1:]
     # make sure the last B row is used by many A rows
     av, ar, ac, ash = a_h
     first = ar[:-1][np.diff(ar) > 0]
@@ -408,13 +414,15 @@ def test_spgemm_direct_rows(gpu, dtype, b_len):
     wave_rows = int(((products > 64) & (products <= 256)).sum())
     assert info["nnz_c"] == got[0] and info["wave_per_row_rows"] == wave_rows
     assert 0.5 * wave_rows <= info["direct_rows"] <= wave_rows and wave_rows > 100
+    if n < 10000:
+        assert got[0] < 0.9 * products[products > 0].sum()  # (shared columns everywhere: C is much smaller than the product list)
     nnz = state.result_nnz()
     vals = torch.full((nnz,), float("nan"), dtype=G.dev(av).dtype, device="cuda")
     cols = torch.full((nnz,), -1, dtype=torch.int32, device="cuda")
     d_c.update(vals, d_rp, cols, (m, n), nnz)
     for rep in range(2):
         d_a.values().mul_(1.5)
-        d_b.values().add_(0.25)
+        d_b.values().add_(0.25 if n < 10000 else -0.25)
         sp.multiply_fill(state, d_a, d_b, d_c)
         a2 = (G.host(d_a.values()), ar, ac, ash)
         b2 = (G.host(d_b.values()), b_h[1], b_h[2], b_h[3])
