@@ -567,6 +567,10 @@ __device__ __forceinline__ void pb_emit_sorted_run(int n, int lo, int g, int gp,
       s_code[gp + j] = (unsigned char) (bi == 0 ? 0 : (exc ? 255 : r - Dp));
       if (bi == 0)
         s_hdr[(gp + j) / PB_BLK] = pb_hdr<T>::make((unsigned) r, 0u);
+    } else if (j < ((n + 3) & ~3)) {  // the run's share of A' ends on a multiple of 4: value 0, column 0, no source position
+      s_val[g + j] = T(0);            // (written here, so that the plan arrays need no clearing pass: pb_clear_tail)
+      s_col[g + j] = 0;
+      perm[g + j] = -1;
     }
     if (exc) {
       const int k = atomicAdd(exc_n, 1);
@@ -837,6 +841,14 @@ __global__ __launch_bounds__(PB_STAGE_THREADS) void pb_scatter_staged_kernel(
     }
     if (ENC8 && direct && tid == 0)
       atomicExch(enc_fail, 1);
+    if (!ENC8 && direct && tid < 3) {  // the run that went straight to memory: pads of its last quad
+      const int n = lcnt[s0];
+      if (tid < ((n + 3) & ~3) - n) {
+        s_val[gdst[s0] + n + tid] = T(0);
+        s_col[gdst[s0] + n + tid] = 0;
+        perm[gdst[s0] + n + tid] = -1;
+      }
+    }
     if (!direct) {
       // every wave writes whole runs from the staging area (contiguous stores, no global gathers: fetching
       // value and column again by position cost 2.4 of the kernel's 2.75 ms -- random 4-byte reads, even
@@ -862,6 +874,11 @@ __global__ __launch_bounds__(PB_STAGE_THREADS) void pb_scatter_staged_kernel(
           s_col[g + j] = stc[lo + j];
           perm[g + j] = (int32_t) (p0 + q);
           s_row[gp + j] = (uint16_t) row_of(q);
+        }
+        if (lane < ((n + 3) & ~3) - n) {  // pads of the run's last quad (see pb_emit_sorted_run)
+          s_val[g + n + lane] = T(0);
+          s_col[g + n + lane] = 0;
+          perm[g + n + lane] = -1;
         }
       }
     }
@@ -2217,9 +2234,13 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
                       (enc8 ? (size_t) p_pad + hdr_bytes + (size_t) NB * PB_EXC_CAP * 6 : (size_t) p_pad * 2) +
                       (size_t) (NB + S + 2) * 4 + (size_t) nseg * 4;
   // pads: value 0, column 0, no source position, row = H (a dummy accumulator); products start finite
-  SPB_HIP(hipMemsetAsync(pl->s_values, 0, (size_t) (a_pad + 8) * sizeof(T), s));
-  SPB_HIP(hipMemsetAsync(pl->s_colind, 0, (size_t) (a_pad + 8) * 2, s));
-  SPB_HIP(hipMemsetAsync(pl->s_perm, 0xFF, (size_t) (a_pad + 8) * 4, s));
+  // The staged scatter writes every entry of the compact stream, the pads of the runs' last quads included: only the slack
+  // behind the stream is cleared (1 GB of memsets at cfg2: 0.15 of the 3.3 ms of a warm inspect).  The direct scatter
+  // (more slices than the staged one takes) and SPBLAS_GFX950_PB_CLEAR=1 clear everything.
+  const int64_t a_keep = (staged && !env_int("SPBLAS_GFX950_PB_CLEAR", 0)) ? (int64_t) h_epad & ~(int64_t) 63 : 0;
+  SPB_HIP(hipMemsetAsync(static_cast<T*>(pl->s_values) + a_keep, 0, (size_t) (a_pad + 8 - a_keep) * sizeof(T), s));
+  SPB_HIP(hipMemsetAsync(static_cast<uint16_t*>(pl->s_colind) + a_keep, 0, (size_t) (a_pad + 8 - a_keep) * 2, s));
+  SPB_HIP(hipMemsetAsync(static_cast<int32_t*>(pl->s_perm) + a_keep, 0xFF, (size_t) (a_pad + 8 - a_keep) * 4, s));
   SPB_HIP(hipMemsetAsync(pl->s_blkdst, 0, (size_t) (a_blocks + 8) * 4, s));
   SPB_HIP(hipMemsetAsync(pl->s_blksrc, 0, (size_t) (a_blocks + 8) * 4, s));
   if (enc8) {  // pads: code 255 (left out of the main pass); headers and exception counts start at 0
