@@ -182,9 +182,8 @@ int spblas_gfx950_plan_info(spblas_gfx950_plan_t plan, int64_t info[12]);
 int spblas_gfx950_plan_info_sliced(spblas_gfx950_plan_t plan, int64_t info[12]);
 /* Hot-column split of a SLICED plan (column-skewed matrices, csrc/spmv_hot.hip): [0] hot columns, [1] entries multiplied
  * in row order with those x values in LDS, [2] rows that have such entries, [3] of them longer than a window, [4] entries
- * left to the tiles, [5] device bytes of the tiled part; pre-summing plan (every (row, x slice) pair makes one round trip
- * through the product stream): [0] slice width, [1] all entries, [2] pairs, [3] pairs that cross a window, [4] pairs,
- * [6] windows, [7] windows that read their slots from the per-pair table.  All 0 for a plan without either. */
+ * left to the tiles, [5] device bytes of the tiled part, [6] windows of 256 entries the hot part is cut into, [7] = 0.
+ * All 0 for a plan without the split. */
 int spblas_gfx950_plan_info_hot(spblas_gfx950_plan_t plan, int64_t info[8]);
 
 /* Two-stage execution of a SLICED plan (other plans: STATUS_NOT_SUPPORTED), used to overlap the

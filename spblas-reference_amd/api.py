@@ -328,11 +328,7 @@ class _Plan:
             hot = (ctypes.c_int64 * 8)()
             check(_capi.lib().spblas_gfx950_plan_info_hot(self.plan, hot), "spblas_gfx950_plan_info_hot")
             d["hot_split"] = dict(zip(("hot_columns", "hot_entries", "hot_rows", "hot_long_rows", "tiled_entries",
-                                       "tiled_device_bytes"), list(hot)))
-            # pre-summing plan: ALL entries go through the row-ordered kernel (hot_columns = slice width, hot_rows = the
-            # (row, slice) pairs), tiled_entries = the pairs whose sums make the round trip through the product stream
-            d["hot_split"]["presummed"] = (bits >> 5) & 1
-            d["hot_split"]["windows"], d["hot_split"]["windows_with_slot_table"] = int(hot[6]), int(hot[7])
+                                       "tiled_device_bytes", "windows"), list(hot)))
         if d["store_trial"] and not d["auto_trial"]:  # (the two time slots carry AUTO's trial when both ran)
             d["store_trial_ns"] = {"plain": d.pop("trial_rowblock_ns"), "non_temporal": d.pop("trial_sliced_ns")}
             d["trial_rowblock_ns"] = d["trial_sliced_ns"] = 0

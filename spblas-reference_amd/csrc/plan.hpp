@@ -136,16 +136,6 @@ struct spblas_gfx950_plan_s {
   int32_t* hot_src = nullptr;    // [hot_nnz] position in the caller's arrays
   void* hot_rowptr = nullptr;    // O[hot_m + 1]
   int32_t* hot_rows = nullptr;   // [hot_m] row of y
-  // Pre-summing expand (ps_mode = 1): the same arrays hold A re-ordered by x slice (hot_val / hot_col / hot_src: padded to
-  // whole windows per slice; hot_rowptr: int32 first entry of every (row, slice) pair; hot_rows: the pair's slot in the
-  // product stream of rest_plan, a tiled plan over the PAIRS); ps_slice_win[s] = first window of slice s
-  int ps_mode = 0, ps_W = 0, ps_S = 0;
-  int64_t ps_over = 0;               // windows whose pairs' slots jump more than three times (slots from the per-pair table)
-  int32_t* ps_slice_win = nullptr;   // device [ps_S + 1]
-  void* ps_desc = nullptr;           // ps_windesc[nwin]: slots of the pairs that start in every window (spmv_hot.hip)
-  int32_t* ps_win_pair0 = nullptr;   // [nwin] first pair that starts in the window
-  int32_t* ps_ap_rowptr = nullptr;   // the pair matrix rest_plan was built over (CSR by row: kept alive with the plan)
-  int32_t* ps_ap_col = nullptr;
   void* hot_part = nullptr;      // T[2 * nwin]: per window of A_hot the piece of the row that runs in / the row that runs on
   int32_t* hot_cross = nullptr;  // [hot_ncross] rows of A_hot that lie in more than one window
   int64_t hot_ncross = 0;

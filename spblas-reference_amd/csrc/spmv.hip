@@ -1090,9 +1090,9 @@ int spblas_gfx950_plan_info_sliced(spblas_gfx950_plan_t plan, int64_t info[12]) 
   info[7] = sl ? tp->n_ksplit : 0;
   info[8] = sl ? tp->s_m : 0;
   // bit 0: AUTO ran its trial, bit 1: one-byte row codes, bit 2: non-temporal product stores, bit 3: this plan ran the store
-  // trial, bit 4: hot-column split or (bit 5 as well) pre-summing plan (spblas_gfx950_plan_info_hot has the numbers)
+  // trial, bit 4: hot-column split (spblas_gfx950_plan_info_hot has the numbers)
   info[9] = (plan->trial_ms[0] > 0.f ? 1 : 0) | (sl && tp->enc8 ? 2 : 0) | (sl && plan->nt_products ? 4 : 0) |
-            (plan->store_trial_ms[0] > 0.f ? 8 : 0) | (sl && plan->rest_plan ? 16 : 0) | (sl && plan->ps_mode ? 32 : 0);
+            (plan->store_trial_ms[0] > 0.f ? 8 : 0) | (sl && plan->rest_plan ? 16 : 0);
   const float* tms = plan->trial_ms[0] > 0.f ? plan->trial_ms : plan->store_trial_ms;  // AUTO's times, else the store trial's
   info[10] = (int64_t) (tms[0] * 1e6f);
   info[11] = (int64_t) (tms[1] * 1e6f);
@@ -1109,8 +1109,8 @@ int spblas_gfx950_plan_info_hot(spblas_gfx950_plan_t plan, int64_t info[8]) {
   info[3] = on ? plan->hot_ncross : 0;             // ... whose entries lie in more than one window of 256
   info[4] = on ? plan->rest_plan->nnz : 0;         // entries left to the tiled plan
   info[5] = on ? (int64_t) plan->rest_plan->device_bytes : 0;
-  info[6] = on && plan->ps_mode ? plan->hot_plan->nwin : 0;  // pre-summing plan: windows of the slice-ordered stream ...
-  info[7] = on && plan->ps_mode ? plan->ps_over : 0;         // ... of which need the per-pair slot table
+  info[6] = on ? plan->hot_plan->nwin : 0;         // windows of 256 entries of A_hot
+  info[7] = 0;
   return SPBLAS_GFX950_STATUS_SUCCESS;
 }
 

@@ -57,8 +57,6 @@ int spmv_hot_exec(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const void
                   void* y);
 int spmv_hot_rows(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const void* alpha, const void* x, void* y);
 int spmv_hot_update(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const void* values);
-int spmv_presum_build(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const void* values);
-int spmv_presum_expand(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const void* x);
 void spmv_hot_free(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl);
 
 static int env_int(const char* name, int dflt) {
@@ -2211,7 +2209,7 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
   // K-split plans) the longer decode chain per group is no longer hidden -- cfg2 shards on one box, one-byte codes vs
   // 16-bit rows: 5 M rows (2 034 bins) 156.9 vs 162.8 us, 2.5 M (1 017 bins) 103.3 vs 93.1, 1.25 M 63.2 vs 58.3.
   (void) max_run;
-  if (!staged || placed_total == 0 || S > PB_STAGE_SP || pl->is_child < 0 ||  // (a pair plan's slots are addressed through s_lrow)
+  if (!staged || placed_total == 0 || S > PB_STAGE_SP ||
       (enc8 == 1 && ((double) H * (double) ne > 32.0 * (double) placed_total || NB < 1536 ||
                      placed_total < (unsigned long long) 32 << 20)))  // below ~32 M entries the SpMV gains nothing (n = 1-3 M
     enc8 = 0;                                                        // at 10 per row: 55.6 / 78.9 / 102.0 vs 56.0 / 78.2 / 102.1 us) and inspect pays 25-50 % more
@@ -2490,22 +2488,6 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
   return SPBLAS_GFX950_STATUS_SUCCESS;
 }
 
-// the duplicate flags of the 16-bit row words again (a builder of a composite plan re-ordered the entries inside the bins)
-int spmv_sliced_reflag_dups(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl) {
-  if (pl->enc8 || !pl->s_lrow || !pl->s_binblk)
-    return SPBLAS_GFX950_STATUS_NOT_SUPPORTED;
-  const int H = pl->rows_per_blk;
-  const int64_t NB = pl->n_rblk;
-  const int gblk = PB_GRP / pb_blk_of(pl->value_type);
-  SPB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pb_flag_dups_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              PB_LDS_BYTES + 16 * 1024));
-  hipLaunchKernelGGL(pb_flag_dups_kernel, dim3((unsigned) cdiv(NB, PB_FWAVES)), dim3(PB_FTHREADS),
-                     (size_t) PB_FWAVES * (size_t) ((H + 63) & ~63), h->stream, H, NB, static_cast<const int32_t*>(pl->s_binblk),
-                     pl->s_lrow, gblk);
-  SPB_HIP(hipGetLastError());
-  return SPBLAS_GFX950_STATUS_SUCCESS;
-}
-
 int spmv_sliced_build(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const void* values, bool auto_mode) {
   // Row-skewed matrices (the ones that get variable-height bins below) are usually column-skewed too (graphs): try to take
   // the entries of the most referenced columns out of the tiles first (spmv_hot.hip).  Not for the halves of a split plan
@@ -2520,14 +2502,9 @@ int spmv_sliced_build(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const 
     if (pl->is_child >= 0 && pl->is_child < depth && hot != 0 && h->bin_row_align <= 1 && pl->nnz > 0 &&
         pl->nnz <= INT32_MAX - 8 && pl->m >= 2 &&
         (hot == 1 || (skewed && pl->nnz >= (4 << 20) && env_int("SPBLAS_GFX950_PB_VARBINS", -1) != 0))) {
-      // SPBLAS_GFX950_PB_PS=1 (experiment, off by default): the pre-summing plan -- every (row, slice) pair makes ONE round
-      // trip through the product stream instead of every entry.  Correct, but measured slower than the hot-column split on
-      // cfg4 (2.39 ms against 1.57-1.75 ms, profiles/r04_presum.md): its expand alone takes as long as the whole split SpMV.
-      if (pl->is_child == 0 && env_int("SPBLAS_GFX950_PB_PS", 0) == 1) {
-        const int rc_p = spmv_presum_build(h, pl, values);
-        if (rc_p != SPBLAS_GFX950_STATUS_NOT_SUPPORTED)
-          return rc_p;
-      }
+      // (a pre-summing plan -- one product per (row, x slice) pair through the product stream -- was built and measured in
+      // round 4: correct, 2.39 ms against 1.57 - 1.75 ms at cfg4; removed again, profiles/r04_presum.md has the numbers
+      // and the commit that holds the code)
       const int rc_h = spmv_hot_build(h, pl, values, auto_mode);
       if (rc_h != SPBLAS_GFX950_STATUS_NOT_SUPPORTED)
         return rc_h;
@@ -2870,8 +2847,6 @@ int spmv_sliced_reserve_partial(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* 
 }
 
 int spmv_sliced_expand(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const void* x) {
-  if (pl->ps_mode)
-    return spmv_presum_expand(h, pl, x);
   if (pl->rest_plan) {  // split plan: the tiles are A_rest's; the hot part needs x again at reduce time
     pl->last_x = x;
     pl->rest_plan->nt_products = pl->nt_products;
@@ -2887,8 +2862,6 @@ int spmv_sliced_reduce_rows(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, 
                             int64_t peer_off) {
   if (pl->rest_plan) {
     // split plan: all rows in one call, no peer stores (the hot part adds into y after the tiles have written it)
-    if (pl->ps_mode)  // the product stream is that of the pair plan: its reduce, any row range it supports
-      return spmv_sliced_reduce_rows(h, pl->rest_plan, alpha, beta, y, row_begin, row_end, peers, n_peers, peer_off);
     if (peers || row_begin > 0 || row_end < pl->m || !pl->last_x)
       return SPBLAS_GFX950_STATUS_NOT_SUPPORTED;
     const int rc_r = spmv_sliced_reduce_rows(h, pl->rest_plan, alpha, beta, y, 0, pl->m, nullptr, 0, 0);

@@ -451,15 +451,6 @@ extern "C" int spblas_gfx950_csr_transpose(spblas_gfx950_handle_t handle, int64_
                                  t_colind, static_cast<double*>(t_values));
 }
 
-namespace spb {
-// (for the builders of composite SpMV plans, spmv_hot.hip: the stable counting sort by column with a 32-bit payload)
-int spblas_gfx950_csr_transpose_internal(spblas_gfx950_handle_t handle, int64_t m, int64_t n, int64_t nnz, const int32_t* rowptr,
-                                         const int32_t* colind, const void* values, int32_t* t_rowptr, int32_t* t_colind,
-                                         void* t_values, int value_type) {
-  return spblas_gfx950_csr_transpose(handle, m, n, nnz, rowptr, colind, values, t_rowptr, t_colind, t_values, value_type);
-}
-} // namespace spb
-
 extern "C" int spblas_gfx950_scale(spblas_gfx950_handle_t handle, int64_t n, const void* alpha, void* values,
                                    int value_type) {
   if (!handle)

@@ -930,36 +930,3 @@ def test_spmv_hot_column_split(gpu, monkeypatch, dtype, offsets):
     monkeypatch.setenv("SPBLAS_GFX950_PB_HOT", "0")
     info2 = sp.multiply_inspect(a, xd, y, alg=_capi.SPMV_SLICED)
     assert "hot_split" not in info2.state_.sliced_info()
-
-
-@pytest.mark.parametrize("dtype", [np.float32, np.float64])
-def test_spmv_presum_plan_opt_in(gpu, monkeypatch, dtype):
-    """SPBLAS_GFX950_PB_PS=1 (csrc/spmv_hot.hip, second half; an experiment kept behind the knob because it measured slower
-    than the hot-column split, profiles/r04_presum.md): entries re-ordered by x slice, one product per (row, slice) pair.
-    Same answer as the oracle, also after a value update; off by default (no `presummed` plan without the knob)."""
-    rng = np.random.default_rng(92)
-    m, n = 50000, 120000
-    lens = rng.integers(0, 20, m)
-    lens[rng.random(m) < 0.25] = 0
-    lens[[3, 4000, m - 1]] = [30000, 900, 5000]
-    rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
-    nnz = int(rowptr[-1])
-    colind = np.minimum((rng.pareto(0.9, nnz) * 40).astype(np.int64), n - 1).astype(np.int32)  # skewed, with duplicates
-    values = (rng.random(nnz) - 0.5).astype(dtype)
-    x = (rng.random(n) - 0.5).astype(dtype)
-    a = G.csr_on_device(values, rowptr, colind, (m, n), nnz)
-    xd = G.dev(x)
-    y = torch.full((m,), float("nan"), dtype=xd.dtype, device="cuda")
-    info0 = sp.multiply_inspect(a, xd, y, alg=_capi.SPMV_SLICED)
-    assert not info0.state_.sliced_info().get("hot_split", {}).get("presummed", False)
-    monkeypatch.setenv("SPBLAS_GFX950_PB_HOT", "1")
-    monkeypatch.setenv("SPBLAS_GFX950_PB_PS", "1")
-    info = sp.multiply_inspect(a, xd, y, alg=_capi.SPMV_SLICED)
-    assert info.state_.sliced_info()["hot_split"]["presummed"]
-    sp.multiply(info, a, xd, y)
-    check(values, rowptr, colind, (m, n), x, G.host(y), what="pre-summing plan", ref_cmp=False)
-    a.values().mul_(-3.0)
-    y.fill_(float("nan"))
-    sp.multiply(info, a, xd, y)
-    check((values * dtype(-3)).astype(dtype), rowptr, colind, (m, n), x, G.host(y), what="pre-summing plan, new values",
-          ref_cmp=False)
