@@ -67,13 +67,15 @@ static constexpr int hot_max_cols() {  // 16 320 fp64, 36 800 fp32 (a multiple o
 }
 
 // ---------------------------------------------------------------------------------------------------------- inspect
-// one entry in 16, at a position inside its group of 16 that changes from group to group (matrices with rows of 16
-// sorted columns would otherwise show the sampler one column range only)
+// one entry in 16: WHOLE 128-byte lines of the column indices (32 consecutive entries -- two or three rows of a graph), one
+// line out of every 16, its place inside the group of 16 changing from group to group.  (Round 4, end: one entry out of
+// every 16 consecutive ones touched every line of the array -- 1.07 GB for a 67 MB sample.)
 __global__ __launch_bounds__(256) void hot_sample_kernel(int64_t nnz, const int32_t* __restrict__ colind,
                                                          int32_t* __restrict__ cnt) {
-  const int64_t g = (int64_t) blockIdx.x * 256 + threadIdx.x;
+  const int64_t t = (int64_t) blockIdx.x * 256 + threadIdx.x;
+  const int64_t g = t >> 5;  // group of 16 lines
   const uint32_t hsh = (uint32_t) g * 2654435761u;
-  const int64_t p = g * 16 + (hsh >> 28);
+  const int64_t p = (g * 16 + (hsh >> 28)) * 32 + (t & 31);
   if (p < nnz)
     atomicAdd(cnt + colind[p], 1);
 }
@@ -112,25 +114,34 @@ __global__ __launch_bounds__(256) void hot_flag_cols_kernel(int64_t n, const int
     flag[c] = cnt[c] >= thr;
 }
 
-// pos = exclusive scan of the column flags: colmap[c] = index in the hot list or -1, hot_cols[index] = c (ascending)
+// pos = exclusive scan of the column flags: colmap[c] = index in the hot list or -1, hot_cols[index] = c (ascending),
+// bitmap = one bit per column (2 MB for 16.8 M columns: what the per-entry test below reads -- it stays in the L2s, where
+// the 64 MB column map made every entry's lookup a line from memory: 12.5 GB for 268 M entries)
 __global__ __launch_bounds__(256) void hot_colmap_kernel(int64_t n, const int32_t* __restrict__ pos,
-                                                         int32_t* __restrict__ colmap, int32_t* __restrict__ hot_cols) {
+                                                         int32_t* __restrict__ colmap, int32_t* __restrict__ hot_cols,
+                                                         unsigned long long* __restrict__ bitmap) {
   const int64_t c = (int64_t) blockIdx.x * 256 + threadIdx.x;
-  if (c >= n)
-    return;
-  const int32_t i = pos[c];
-  const bool hot = pos[c + 1] != i;
-  colmap[c] = hot ? i : -1;
-  if (hot)
-    hot_cols[i] = (int32_t) c;
+  bool hot = false;
+  if (c < n) {
+    const int32_t i = pos[c];
+    hot = pos[c + 1] != i;
+    colmap[c] = hot ? i : -1;
+    if (hot)
+      hot_cols[i] = (int32_t) c;
+  }
+  const unsigned long long word = __ballot(hot);  // columns 64 w .. 64 w + 63 (a workgroup starts on a multiple of 256)
+  if ((threadIdx.x & 63) == 0 && (c & ~(int64_t) 63) < n)
+    bitmap[c >> 6] = word;
 }
 
 __global__ __launch_bounds__(256) void hot_flag_entries_kernel(int64_t nnz, const int32_t* __restrict__ colind,
-                                                               const int32_t* __restrict__ colmap,
+                                                               const unsigned long long* __restrict__ bitmap,
                                                                int32_t* __restrict__ flag) {
   const int64_t p = (int64_t) blockIdx.x * 256 + threadIdx.x;
-  if (p < nnz)
-    flag[p] = colmap[stream_load(colind + p)] >= 0;
+  if (p < nnz) {
+    const int32_t c = stream_load(colind + p);
+    flag[p] = (int32_t) ((bitmap[c >> 6] >> (c & 63)) & 1ull);
+  }
 }
 
 // hotpos = exclusive scan of the entry flags (hotpos[nnz] = hot entries): a stable two-way split in one pass
@@ -147,10 +158,9 @@ __global__ __launch_bounds__(256) void hot_split_kernel(int64_t nnz, const int32
   const int32_t c = stream_load(colind + p);
   const T v = stream_load(values + p);
   const int32_t hp = hotpos[p];
-  const int32_t k = colmap[c];
-  if (k >= 0) {
+  if (hotpos[p + 1] != hp) {  // a hot entry: only those look their column up (the few thousand map lines of the hot columns)
     hot_val[hp] = v;
-    hot_col[hp] = (uint16_t) k;
+    hot_col[hp] = (uint16_t) colmap[c];
     hot_src[hp] = (int32_t) p;
   } else {
     const int64_t rp = p - hp;
@@ -647,14 +657,16 @@ static int hot_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, c
     return SPBLAS_GFX950_STATUS_NOT_SUPPORTED;  // no set of columns that small carries enough of the matrix
   // hot list (ascending columns) and the column -> hot index map
   int32_t* colmap = nullptr;
-  if ((rc = g.alloc((void**) &colmap, (size_t) n * 4)) || (rc = dev_alloc((void**) &pl->hot_cols, (size_t) cols * 4, s)))
+  unsigned long long* colbits = nullptr;
+  if ((rc = g.alloc((void**) &colmap, (size_t) n * 4)) || (rc = g.alloc((void**) &colbits, (size_t) (n / 64 + 1) * 8)) ||
+      (rc = dev_alloc((void**) &pl->hot_cols, (size_t) cols * 4, s)))
     return rc;
   hipLaunchKernelGGL(hot_flag_cols_kernel, dim3((unsigned) cdiv(n, 256)), dim3(256), 0, s, n, cnt, thr, pos);
   (void) scan_counts_i32(s, n, pos, partials);
-  hipLaunchKernelGGL(hot_colmap_kernel, dim3((unsigned) cdiv(n, 256)), dim3(256), 0, s, n, pos, colmap, pl->hot_cols);
+  hipLaunchKernelGGL(hot_colmap_kernel, dim3((unsigned) cdiv(n, 256)), dim3(256), 0, s, n, pos, colmap, pl->hot_cols, colbits);
   pl->hot_k = (int) cols;
   // stable split of the entries
-  hipLaunchKernelGGL(hot_flag_entries_kernel, dim3((unsigned) cdiv(nnz, 256)), dim3(256), 0, s, nnz, colind, colmap, pos);
+  hipLaunchKernelGGL(hot_flag_entries_kernel, dim3((unsigned) cdiv(nnz, 256)), dim3(256), 0, s, nnz, colind, colbits, pos);
   long long* total_dev = scan_counts_i32(s, nnz, pos, partials);
   long long n_hot = 0;
   if ((rc = readback_add(h, &n_hot, total_dev, sizeof(n_hot))) || (rc = readback_flush(h)))
