@@ -509,11 +509,21 @@ __global__ __launch_bounds__(256) void hot_cross_rows_kernel(int64_t m_hot, cons
                                                              int32_t* __restrict__ cross_rows,
                                                              unsigned long long* __restrict__ n_cross) {
   const int64_t r = (int64_t) blockIdx.x * 256 + threadIdx.x;
-  if (r >= m_hot)
-    return;
-  const int64_t p0 = (int64_t) rowptr[r], p1 = (int64_t) rowptr[r + 1];
-  if (p0 / HOT_WIN != (p1 - 1) / HOT_WIN)
-    cross_rows[atomicAdd(n_cross, 1ull)] = (int32_t) r;
+  bool cross = false;
+  if (r < m_hot) {
+    const int64_t p0 = (int64_t) rowptr[r], p1 = (int64_t) rowptr[r + 1];
+    cross = p0 / HOT_WIN != (p1 - 1) / HOT_WIN;
+  }
+  const unsigned long long mask = __ballot(cross);  // one atomic per wavefront on the single counter
+  if (mask) {
+    const int lane = threadIdx.x & 63, leader = __builtin_ctzll(mask);
+    unsigned long long base = 0;
+    if (lane == leader)
+      base = atomicAdd(n_cross, (unsigned long long) __popcll(mask));
+    base = __shfl(base, leader);
+    if (cross)
+      cross_rows[base + __popcll(mask & ((1ull << lane) - 1ull))] = (int32_t) r;
+  }
 }
 
 template <typename T, typename O>

@@ -204,26 +204,35 @@ __global__ __launch_bounds__(256) void pb_row_pieces_kernel(int64_t m, const O* 
 // rowptr_c / nzrow of the compact rows (nzrow = row of y, PB_PIECE_BIT set on the pieces of a split row), the list of
 // empty rows that were taken out and the list of split rows (both appended in arbitrary order)
 template <typename O>
-__global__ __launch_bounds__(256) void pb_row_map_kernel(int64_t m, const O* __restrict__ rowptr,
+__global__ __launch_bounds__(1024) void pb_row_map_kernel(int64_t m, const O* __restrict__ rowptr,
                                                          const int32_t* __restrict__ pos, int L, O* __restrict__ rowptr_c,
                                                          int32_t* __restrict__ nzrow, int32_t* __restrict__ zrow,
                                                          int4* __restrict__ split_rows,
                                                          unsigned long long* __restrict__ counters) {
-  const int64_t r = (int64_t) blockIdx.x * 256 + threadIdx.x;
+  const int64_t r = (int64_t) blockIdx.x * 1024 + threadIdx.x;
   const int32_t i = r < m ? pos[r] : 0, k = r < m ? pos[r + 1] - i : -1;
   {
-    // wave-aggregated append of the empty rows (one atomic per wavefront: R-MAT scale 24 has 9.4 M of them, one atomic
-    // each on a single counter took 3 ms)
+    // workgroup-aggregated append of the empty rows: ONE atomic per 1 024 rows on the single counter (R-MAT scale 24 has
+    // 9.4 M empty rows: an atomic each took 3 ms, one per wavefront -- 262 k same-address atomics at ~11 ns -- still 2.9 ms)
+    __shared__ unsigned s_cnt[16];
+    __shared__ unsigned long long s_base;
     const unsigned long long mask = __ballot(k == 0);
-    if (mask) {
-      const int lane = threadIdx.x & 63, leader = __builtin_ctzll(mask);
-      unsigned long long base = 0;
-      if (lane == leader)
-        base = atomicAdd(&counters[0], (unsigned long long) __popcll(mask));
-      base = __shfl(base, leader);
-      if (k == 0)
-        zrow[base + __popcll(mask & ((1ull << lane) - 1ull))] = (int32_t) r;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0)
+      s_cnt[wave] = (unsigned) __popcll(mask);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned tot = 0;
+      for (int w = 0; w < 16; ++w) {
+        const unsigned c = s_cnt[w];
+        s_cnt[w] = tot;
+        tot += c;
+      }
+      s_base = tot ? atomicAdd(&counters[0], (unsigned long long) tot) : 0ull;
     }
+    __syncthreads();
+    if (k == 0)
+      zrow[s_base + s_cnt[wave] + __popcll(mask & ((1ull << lane) - 1ull))] = (int32_t) r;
   }
   if (r > m)
     return;
@@ -1850,7 +1859,7 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
         (rc = dev_alloc(&pl->s_zrow, (size_t) (compact ? pl->empty_rows : 1) * 4, s)) ||
         (rc = dev_alloc(&pl->s_split_rows, (size_t) split_cap * sizeof(int4), s)))
       return rc;
-    hipLaunchKernelGGL((pb_row_map_kernel<O>), dim3((unsigned) cdiv(m + 1, 256)), dim3(256), 0, s, m, rowptr, pieces, split_len,
+    hipLaunchKernelGGL((pb_row_map_kernel<O>), dim3((unsigned) cdiv(m + 1, 1024)), dim3(1024), 0, s, m, rowptr, pieces, split_len,
                        static_cast<O*>(pl->s_rowptr_c), static_cast<int32_t*>(pl->s_nzrow),
                        static_cast<int32_t*>(pl->s_zrow), static_cast<int4*>(pl->s_split_rows), counters);
     unsigned long long h_cnt[2] = {0, 0};
