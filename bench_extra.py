@@ -119,7 +119,7 @@ def secondary(args, device, log=None):
     HIP events and checked against the oracle; compact records for the `secondary` object of bench.py's JSON line."""
     import copy
     res = {}
-    todo = [("cfg4", "spmv_rmat1"), ("cfg3", "spmm"), ("cfg5", "spgemm")]
+    todo = [("cfg2_plain_csr_view", "spmv_plain"), ("cfg4", "spmv_rmat1"), ("cfg3", "spmm"), ("cfg5", "spgemm")]
     if not getattr(args, "no_8f", False):  # SURVEY 8(f): add, transpose, triangular solve at their bench sizes
         todo += [("f_add", "add"), ("f_transpose", "transpose"), ("f_sptrsv", "sptrsv")]
     for name, workload in todo:
@@ -231,11 +231,61 @@ def _run_spmv_rmat1(args, device, sp, oracle, generate):
                  pmc_key="spmv_rmat" if (args.rows is None and plan.get("alg") == 3) else None)
 
 
+def _run_spmv_plain(args, device, sp, oracle, generate):
+    """cfg2's matrix as a PLAIN inspected csr_view (no matrix_opt): north_star's call shape taken literally.  Every
+    multiply has to read the caller's values of that call (multiply_impl.hpp:48-52), so the values are rewritten IN PLACE
+    between inspect and the timed loop and the checked y must follow them.  Since the end of round 4 the re-tiled plan is
+    chosen here too when "refresh the plan's copy + tiles" beats the row-block kernel in inspect's timed trial."""
+    m = n = args.rows or 10_000_000
+    values, rowptr, colind, shape, nnz = generate.uniform_csr_device(m, n, 10, seed=0, device=device)
+    a = sp.csr_view(values, rowptr, colind, shape, nnz)
+    g = torch.Generator(device=device).manual_seed(11)
+    x = torch.rand(n, device=device, generator=g)
+    y = torch.empty(m, device=device)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    info = sp.multiply_inspect(a, x, y)
+    torch.cuda.synchronize()
+    inspect_ms = (time.perf_counter() - t0) * 1e3
+    values.mul_(-0.5).add_(0.125)  # in place, after inspect: a plan that kept the old values would be caught below
+    elapsed, ms = _time_steps(lambda: sp.multiply(info, a, x, y), args.warmup, args.steps)
+    plan = info.state_.info()
+    si = info.state_.sliced_info() if hasattr(info.state_, "sliced_info") else {}
+    if plan.get("alg") == 3:
+        plan["sliced"] = si
+    y.fill_(float("nan"))
+    sp.multiply(info, a, x, y)
+    torch.cuda.synchronize()
+    alg_bytes = nnz * 8 + (m + 1) * 4 + (n + m) * 4
+    rows = np.unique(np.concatenate([np.arange(0, min(m, 1500)), np.arange(max(0, m - 1500), m),
+                                     np.random.default_rng(5).integers(0, m, 3000)]))
+    sub_rp, sub_ci, sub_v = rows_subproblem(rows, rowptr, colind, values)
+    xh = x.cpu().numpy()
+    y_ref = oracle.spmv((len(rows), n), sub_rp, sub_ci, sub_v, xh)
+    absrow = oracle.spmv_absrow(sub_rp, sub_ci, sub_v, xh)
+    nbad, worst = parity_rows(y[torch.from_numpy(rows).to(device)].cpu().numpy(), y_ref, absrow.astype(np.float64), 1e-6,
+                              float(np.finfo(np.float32).eps), np.diff(sub_rp))
+    parity = {"status": "pass" if nbad == 0 else "fail", "rows": int(len(rows)), "rows_out_of_bound": nbad, "tol": 1e-6,
+              "worst_err_over_rownorm": worst,
+              "against": "oracle_spmv on the first / last 1 500 and 3 000 sampled rows, with the values the caller wrote in "
+                         "place AFTER multiply_inspect"}
+    kern = {3: "pb_refresh_bins_kernel<float> + pb_expand_kernel<float,false> + pb_reduce_kernel<float,...> (one SpMV = this "
+               "launch group: the plan takes A's values again on every multiply)",
+            2: "spmv_rowblock_kernel<float,int,1024>"}.get(plan.get("alg"), "spmv_vector_kernel")
+    return _emit(args, "csr_spmv_gflops", 2.0 * nnz, alg_bytes, elapsed, ms,
+                 f"cfg2's matrix as a plain inspected csr_view: fp32 CSR SpMV {m}x{n}, 10 nnz/row uniform random, nnz={nnz}",
+                 {"dtype": "f32", "rows": m, "nnz": nnz, "operand": "csr_view + multiply_inspect (no matrix_opt)", "plan": plan,
+                  "values_taken_again_every_multiply": bool(si.get("refresh_each_call", 0)),
+                  "inspect_ms_untimed": inspect_ms, "kernel": kern}, None, parity=parity)
+
+
 def _run(args, device):
     import spblas_reference_amd as sp
     from oracle import oracle
     from spblas_reference_amd import generate
 
+    if args.workload == "spmv_plain":
+        return _run_spmv_plain(args, device, sp, oracle, generate)
     if args.workload == "spmv_rmat1":
         return _run_spmv_rmat1(args, device, sp, oracle, generate)
 

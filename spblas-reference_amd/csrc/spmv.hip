@@ -730,24 +730,32 @@ int spblas_gfx950_spmv_plan_create(spblas_gfx950_handle_t handle, spblas_gfx950_
     if (rc == SPBLAS_GFX950_STATUS_SUCCESS)
       store_trial(handle, pl, values);
   } else if (rc == SPBLAS_GFX950_STATUS_SUCCESS && alg == SPBLAS_GFX950_SPMV_AUTO && values &&
-             handle->value_snapshot != 0 && pl->alg == SPBLAS_GFX950_SPMV_ROWBLOCK && sliced_candidate(pl)) {
-    // (only with SPBLAS_GFX950_OPT_VALUE_SNAPSHOT: the sliced plan keeps a copy of the values, and a caller
-    // who has not opted in expects every multiply to read its array, multiply_impl.hpp:48-52)
+             (handle->value_snapshot != 0 || (pl->nnz >= ((int64_t) 16 << 20) && env_int_spmv("SPBLAS_GFX950_PLAIN_SLICED", 1))) &&
+             pl->alg == SPBLAS_GFX950_SPMV_ROWBLOCK && sliced_candidate(pl)) {
     // x far larger than an XCD's L2 and no long rows: try the LDS-sliced re-tiling; it
     // declines (NOT_SUPPORTED) when the entries cluster in few tiles.
+    // The sliced plan multiplies with a re-tiled COPY of the values.  With SPBLAS_GFX950_OPT_VALUE_SNAPSHOT (matrix_opt)
+    // the copy is taken at inspect and when the caller passes another array.  WITHOUT the opt-in (a plain inspected
+    // csr_view, whose multiply must read the caller's values of that call: multiply_impl.hpp:48-52) the plan takes the
+    // values again on EVERY multiply -- pb_refresh_bins_kernel, 0.45 ms at cfg2 -- and is kept only if refresh + tiles
+    // beat the row-block kernel in a timed trial (cfg2: 0.76 against 1.71 ms).  Large matrices only: the plan is a
+    // second copy of A (SPBLAS_GFX950_PLAIN_SLICED=0: row-block plan as before round 4's end).
+    pl->refresh_each_call = handle->value_snapshot != 0 ? 0 : 1;
     const int rc2 = spmv_sliced_build(handle, pl, values, true);
     if (rc2 == SPBLAS_GFX950_STATUS_SUCCESS) {
       bool keep = true;
-      if (pl->s_uncertain)
+      if (pl->s_uncertain || pl->refresh_each_call)
         (void) auto_trial(handle, pl, values, &keep);
       if (keep) {
         pl->alg = SPBLAS_GFX950_SPMV_SLICED;
         store_trial(handle, pl, values);
       } else {
         spmv_sliced_free(handle, pl);
+        pl->refresh_each_call = 0;
       }
     } else {
       spmv_sliced_free(handle, pl);
+      pl->refresh_each_call = 0;
       if (rc2 != SPBLAS_GFX950_STATUS_NOT_SUPPORTED)
         rc = rc2;
     }
@@ -776,7 +784,7 @@ int spblas_gfx950_spmv_expand(spblas_gfx950_handle_t handle, spblas_gfx950_plan_
     return SPBLAS_GFX950_STATUS_INVALID_HANDLE;
   if (!plan || !x)
     return SPBLAS_GFX950_STATUS_INVALID_POINTER;
-  if (plan->alg != SPBLAS_GFX950_SPMV_SLICED)
+  if (plan->alg != SPBLAS_GFX950_SPMV_SLICED || plan->refresh_each_call)  // (the two-stage form is not given A's values)
     return SPBLAS_GFX950_STATUS_NOT_SUPPORTED;
   if (plan->nnz == 0)
     return SPBLAS_GFX950_STATUS_SUCCESS;
@@ -1101,9 +1109,10 @@ int spblas_gfx950_plan_info_sliced(spblas_gfx950_plan_t plan, int64_t info[12]) 
   info[7] = sl ? tp->n_ksplit : 0;
   info[8] = sl ? tp->s_m : 0;
   // bit 0: AUTO ran its trial, bit 1: one-byte row codes, bit 2: non-temporal product stores, bit 3: this plan ran the store
-  // trial, bit 4: hot-column split (spblas_gfx950_plan_info_hot has the numbers)
+  // trial, bit 4: hot-column split (spblas_gfx950_plan_info_hot has the numbers), bit 6: the plan takes A's values again on
+  // every multiply (made without the snapshot opt-in)
   info[9] = (plan->trial_ms[0] > 0.f ? 1 : 0) | (sl && tp->enc8 ? 2 : 0) | (sl && plan->nt_products ? 4 : 0) |
-            (plan->store_trial_ms[0] > 0.f ? 8 : 0) | (sl && plan->rest_plan ? 16 : 0);
+            (plan->store_trial_ms[0] > 0.f ? 8 : 0) | (sl && plan->rest_plan ? 16 : 0) | (sl && plan->refresh_each_call ? 64 : 0);
   const float* tms = plan->trial_ms[0] > 0.f ? plan->trial_ms : plan->store_trial_ms;  // AUTO's times, else the store trial's
   info[10] = (int64_t) (tms[0] * 1e6f);
   info[11] = (int64_t) (tms[1] * 1e6f);
@@ -1151,7 +1160,9 @@ int spblas_gfx950_spmv(spblas_gfx950_handle_t handle, spblas_gfx950_plan_t plan,
       plan = nullptr;  // plans describe op = N only
     // a SLICED plan multiplies with its own re-tiled copy of the values: when the caller hands over another
     // array than the one the copy was taken from, take the copy again first
-    if (plan && plan->alg == SPBLAS_GFX950_SPMV_SLICED && nnz > 0 && values != plan->values_ptr) {
+    // (a plan made without the snapshot opt-in does so on EVERY multiply: the caller may have rewritten the array in place,
+    // and a plain inspected csr_view promises what multiply_impl.hpp:48-52 does -- the values of this call)
+    if (plan && plan->alg == SPBLAS_GFX950_SPMV_SLICED && nnz > 0 && (values != plan->values_ptr || plan->refresh_each_call)) {
       const int rc = spmv_sliced_update(handle, plan, values);
       if (rc != SPBLAS_GFX950_STATUS_SUCCESS)
         return rc;

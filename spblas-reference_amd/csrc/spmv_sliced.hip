@@ -966,6 +966,88 @@ __global__ __launch_bounds__(256) void pb_update_values_kernel(int64_t n_pad, co
   }
 }
 
+// The same refresh, bin by bin (end of round 4).  The kernel above walks the A' arrays in their own order -- slice-major --
+// so the 200 entries of a run gather from a window of the caller's array that every one of the S slices fetches again:
+// 12.8 GB of lines for 0.4 GB of values, 1.72 ms at cfg2.  All runs of ONE wave-bin draw from one window (the entries of
+// the bin's rows: ~195 KB at cfg2), so a workgroup per bin loads that window into LDS (in passes of what LDS holds) and
+// walks the bin's S runs: perm in (coalesced), value out of LDS, s_val out (coalesced).  The pads (perm = -1) stay 0.
+// row0[b] / rp[]: first row of every bin and the row offsets IN THE CALLER'S ARRAY (the compacted row map of a plan that has
+// one: its offsets are source positions too).
+template <typename T, typename O>
+__global__ __launch_bounds__(1024) void pb_refresh_bins_kernel(int S, int64_t NB, int H, int64_t rows,
+                                                               const int32_t* __restrict__ binrow, const O* __restrict__ rp,
+                                                               const int32_t* __restrict__ eoff,
+                                                               const int32_t* __restrict__ perm, const T* __restrict__ values,
+                                                               T* __restrict__ s_val, int cap) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  T* win = reinterpret_cast<T*>(smem);
+  const int64_t b = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int NW = 16, U = 4;
+  const int64_t r0 = binrow ? (int64_t) binrow[b] : b * H;
+  int64_t r1 = binrow ? (int64_t) binrow[b + 1] : (b + 1) * H;
+  r1 = r1 < rows ? r1 : rows;
+  if (r0 >= r1)
+    return;
+  constexpr int VE = 16 / (int) sizeof(T);
+  const bool vec_ok = (reinterpret_cast<uintptr_t>(values) & 15) == 0;  // (cap is a multiple of VE)
+  const int64_t p_lo = vec_ok ? (int64_t) rp[r0] & ~(int64_t) (VE - 1) : (int64_t) rp[r0], p_hi = (int64_t) rp[r1];
+  for (int64_t base = p_lo; base < p_hi; base += cap) {
+    const int wn = (int) ((p_hi - base) < cap ? (p_hi - base) : cap);
+    __syncthreads();  // everyone is done with the previous window
+    if (vec_ok) {  // 16-byte loads: the window starts on a multiple of VE entries of a 16-byte aligned array
+      typedef T vec_t __attribute__((ext_vector_type(VE)));
+      const int nv = wn / VE;
+      for (int i = tid; i < nv; i += 1024)
+        reinterpret_cast<vec_t*>(win)[i] = stream_load(reinterpret_cast<const vec_t*>(values + base) + i);
+      for (int i = nv * VE + tid; i < wn; i += 1024)
+        win[i] = stream_load(values + base + i);
+    } else {
+      for (int i = tid; i < wn; i += 1024)
+        win[i] = stream_load(values + base + i);
+    }
+    __syncthreads();
+    // wave w takes the runs of slices 4 w .. 4 w + 3, then 64 further on: the source positions of FOUR runs are loaded
+    // together (a run is ~200 entries at cfg2: one round of a wavefront; one run at a time is a chain of run offsets ->
+    // positions -> store per run: 0.64 ms at cfg2 against 0.50 with four in flight)
+    constexpr int R = 4;
+    for (int s0 = wave * R; s0 < S; s0 += NW * R) {
+      int g[R], n[R];
+      int32_t pp[R][U];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        g[r] = 0;
+        n[r] = 0;
+        if (s0 + r < S) {
+          const int64_t key = (int64_t) (s0 + r) * NB + b;
+          g[r] = eoff[key];
+          n[r] = eoff[key + 1] - g[r];
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          pp[r][u] = lane + 64 * u < n[r] ? stream_load(perm + g[r] + lane + 64 * u) : -1;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int64_t d = (int64_t) pp[r][u] - base;
+          if (pp[r][u] >= 0 && d >= 0 && d < wn)
+            s_val[g[r] + lane + 64 * u] = win[d];
+        }
+        for (int j = 64 * U + lane; j < n[r]; j += 64) {  // (a run longer than 256 entries: the rest one round at a time)
+          const int32_t pq = stream_load(perm + g[r] + j);
+          const int64_t d = (int64_t) pq - base;
+          if (pq >= 0 && d >= 0 && d < wn)
+            s_val[g[r] + j] = win[d];
+        }
+      }
+    }
+  }
+}
+
 // ---- execute ---------------------------------------------------------------------------
 template <typename T>
 struct pack4;
@@ -2141,7 +2223,8 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
   int32_t* eoff = nullptr;  // first entry of every run in the compact A' stream (run lengths rounded up to 4)
   if ((rc = dev_alloc((void**) &eoff, (size_t) (nseg + 1) * 4, s)))
     return rc;
-  temps.p[4] = eoff;
+  pl->s_eoff = eoff;  // (owned by the plan: sliced_update_typed)
+  pl->device_bytes += (size_t) (nseg + 1) * 4;
   hipLaunchKernelGGL(pb_ecnt_kernel, dim3((unsigned) cdiv(nseg, 256)), dim3(256), 0, s, nseg, cnt, eoff);
   (void) scan_counts_i32(s, nseg, eoff, partials);  // eoff[nseg] = entries of the compact stream
   hipLaunchKernelGGL(pb_bin_prefix_kernel, dim3((unsigned) NB), dim3(256), 0, s, S, NB, cnt, prel, binblk, pb_geom<T>::BLK);
@@ -2533,6 +2616,28 @@ static int sliced_update_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* p
   const int64_t a_pad = pl->a_entries;
   if (pl->s_placed == 0 || a_pad == 0)
     return SPBLAS_GFX950_STATUS_SUCCESS;
+  // bin by bin through LDS when the plan kept its run offsets (SPBLAS_GFX950_PB_UPDATE_BINS=0: the gather in A' order)
+  if (pl->s_eoff && pl->n_rblk > 0 && pl->n_slices > 0 && env_int("SPBLAS_GFX950_PB_UPDATE_BINS", 1)) {
+    const int cap = (int) ((PB_STAGE_LDS - 1024) / sizeof(T)) & ~3;
+    const bool o32 = pl->offset_type == SPBLAS_GFX950_I32;
+    const void* rp = pl->s_nzrow ? pl->s_rowptr_c : pl->rowptr;  // (both hold positions in the caller's arrays)
+    const int64_t rows = pl->s_nzrow ? pl->s_m : pl->m;
+    const int32_t* binrow = static_cast<const int32_t*>(pl->s_binrow);
+    const void* fn = o32 ? (const void*) pb_refresh_bins_kernel<T, int32_t> : (const void*) pb_refresh_bins_kernel<T, int64_t>;
+    SPB_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, PB_STAGE_LDS - 1024));
+    if (o32)
+      hipLaunchKernelGGL((pb_refresh_bins_kernel<T, int32_t>), dim3((unsigned) pl->n_rblk), dim3(1024), (size_t) cap * sizeof(T),
+                         h->stream, pl->n_slices, pl->n_rblk, pl->rows_per_blk, rows, binrow, static_cast<const int32_t*>(rp),
+                         static_cast<const int32_t*>(pl->s_eoff), reinterpret_cast<const int32_t*>(pl->s_perm),
+                         static_cast<const T*>(values), static_cast<T*>(pl->s_values), cap);
+    else
+      hipLaunchKernelGGL((pb_refresh_bins_kernel<T, int64_t>), dim3((unsigned) pl->n_rblk), dim3(1024), (size_t) cap * sizeof(T),
+                         h->stream, pl->n_slices, pl->n_rblk, pl->rows_per_blk, rows, binrow, static_cast<const int64_t*>(rp),
+                         static_cast<const int32_t*>(pl->s_eoff), reinterpret_cast<const int32_t*>(pl->s_perm),
+                         static_cast<const T*>(values), static_cast<T*>(pl->s_values), cap);
+    SPB_HIP(hipGetLastError());
+    return SPBLAS_GFX950_STATUS_SUCCESS;
+  }
   hipLaunchKernelGGL((pb_update_values_kernel<T>), dim3((unsigned) cdiv(a_pad, 256)), dim3(256), 0, h->stream, a_pad,
                      reinterpret_cast<const int32_t*>(pl->s_perm), static_cast<const T*>(values),
                      static_cast<T*>(pl->s_values));
@@ -2915,7 +3020,8 @@ void spmv_sliced_free(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl) {
   dev_free(pl->s_binblk, s);
   dev_free(pl->s_blkdst, s);
   dev_free(pl->s_blksrc, s);
-  pl->s_blksrc = nullptr;
+  dev_free(pl->s_eoff, s);
+  pl->s_blksrc = pl->s_eoff = nullptr;
   pl->a_entries = 0;
   dev_free(pl->s_colind, s);
   dev_free(pl->s_values, s);

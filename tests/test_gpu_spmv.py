@@ -930,3 +930,39 @@ def test_spmv_hot_column_split(gpu, monkeypatch, dtype, offsets):
     monkeypatch.setenv("SPBLAS_GFX950_PB_HOT", "0")
     info2 = sp.multiply_inspect(a, xd, y, alg=_capi.SPMV_SLICED)
     assert "hot_split" not in info2.state_.sliced_info()
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_spmv_plain_inspected_csr_view_follows_values_written_in_place(gpu, dtype):
+    """A plain csr_view (no matrix_opt) that is inspected: every multiply reads the caller's values OF THAT CALL
+    (multiply_impl.hpp:48-52).  Large uniform matrices get the re-tiled plan here too since the end of round 4 -- in the
+    form that takes the values again on every multiply (pb_refresh_bins_kernel), kept only when it beats the row-block
+    kernel in the timed trial -- so values rewritten in place by a foreign kernel (no API call, no torch version bump that
+    the library could see) must show in the next y.  SPBLAS_GFX950_PLAIN_SLICED=0 restores the row-block plan."""
+    rng = np.random.default_rng(93)
+    m = n = 1_800_000
+    values, rowptr, colind, shape, nnz = generate.uniform_csr_device(m, n, 10, seed=4, dtype=torch.float32 if dtype == np.float32 else torch.float64)
+    a = sp.csr_view(values, rowptr, colind, shape, nnz)
+    x = torch.rand(n, dtype=values.dtype, device="cuda")
+    y = torch.full((m,), float("nan"), dtype=values.dtype, device="cuda")
+    info = sp.multiply_inspect(a, x, y)
+    pi = info.state_.info()
+    assert pi["alg"] in (_capi.SPMV_ROWBLOCK, _capi.SPMV_SLICED)
+    if pi["alg"] == _capi.SPMV_SLICED:
+        assert info.state_.sliced_info()["refresh_each_call"] == 1 and info.state_.sliced_info()["auto_trial"] == 1
+    rows = np.unique(np.concatenate([np.arange(0, 800), np.arange(m - 800, m), rng.integers(0, m, 1500)]))
+    rp_h = rowptr.cpu().numpy()
+    idx = np.concatenate([np.arange(rp_h[r], rp_h[r + 1]) for r in rows])
+    sub_rp = np.concatenate([[0], np.cumsum(rp_h[rows + 1] - rp_h[rows])]).astype(np.int32)
+    sub_ci = colind.cpu().numpy()[idx]
+    xh = x.cpu().numpy()
+    for step in range(3):
+        # rewrite the values through a raw view of the same memory: no version counter of `values` moves
+        raw = torch.as_strided(values, values.shape, values.stride())
+        raw.data.mul_(-1.25 if step else 1.0).add_(0.0625 * step)
+        sp.multiply(info, a, x, y)
+        sub_v = values.cpu().numpy()[idx]
+        y_ref = oracle.spmv((len(rows), n), sub_rp, sub_ci, sub_v, xh)
+        absrow = oracle.spmv_absrow(sub_rp, sub_ci, sub_v, xh)
+        util.assert_parity(y[torch.from_numpy(rows).cuda()].cpu().numpy(), y_ref, absrow, dtype, row_len=np.diff(sub_rp),
+                           what=f"plain inspected csr_view, values rewritten in place, step {step}")
