@@ -612,8 +612,9 @@ def main():
                                        f"row-sharded x{world} ({'nnz-prefix' if rmat else 'equal'} shards), {chunks} stripe(s) per step "
                                        f"({mode}), one RCCL all-gather(y) per stripe"),
                        # what the headline is a number FOR: the sliced plan multiplies with a re-tiled snapshot of A, which
-                       # AUTO only builds for operands wrapped in matrix_opt; a plain inspected csr_view
-                       # gets the row-block plan on the caller's arrays: 1.71 ms at cfg2
+                       # is taken once for operands wrapped in matrix_opt; a plain inspected csr_view gets the
+                       # same plan in the form that takes the values again on every multiply: 0.79 ms at cfg2
+                       # (secondary.cfg2_plain_csr_view; the row-block kernel on the caller's arrays: 1.71 ms)
                        "operand": "matrix_opt(csr_view) + multiply_inspect" if args.alg != "noplan" else "csr_view, no inspect",
                        "alg": args.alg, "plan": plan_info, "inspect_ms_untimed": inspect_ms,
                        "inspect_warm_ms_untimed": inspect_warm_ms},

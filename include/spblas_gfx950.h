@@ -150,10 +150,13 @@ int spblas_gfx950_set_option(spblas_gfx950_handle_t handle, int option, int64_t 
  * column-sliced reorder; the result lives in device memory owned by the plan.
  * `values` may be NULL unless alg == SLICED.
  * Value snapshot contract: ROWBLOCK / VECTOR plans hold structure only and every multiply reads the
- * caller's values.  The SLICED plan -- chosen only on request (alg = SLICED) or by AUTO under
- * SPBLAS_GFX950_OPT_VALUE_SNAPSHOT -- holds a re-tiled COPY of the values: after changing them IN PLACE call
+ * caller's values.  The SLICED plan holds a re-tiled COPY of the values.  On request (alg = SLICED) or by AUTO under
+ * SPBLAS_GFX950_OPT_VALUE_SNAPSHOT the copy is a SNAPSHOT: after changing the values IN PLACE call
  * spblas_gfx950_spmv_plan_update_values; a multiply that passes a DIFFERENT values pointer than the one
- * the copy was taken from refreshes the copy by itself first (one extra pass over A).
+ * the copy was taken from refreshes the copy by itself first (one extra pass over A).  AUTO WITHOUT the option may
+ * choose the SLICED plan too (>= 16 M entries, a timed trial against the row-block kernel): such a plan takes the values
+ * again on EVERY multiply (plan_info_sliced[9] bit 6), so the caller sees the same semantics as with a structure-only
+ * plan; the two-stage calls (spmv_expand / spmv_reduce_rows), which are not given the values, refuse it.
  * The plan is tied to (m, n, nnz, rowptr, colind). */
 int spblas_gfx950_spmv_plan_create(spblas_gfx950_handle_t handle, spblas_gfx950_plan_t* plan,
                                    int64_t m, int64_t n, int64_t nnz, const void* rowptr,
