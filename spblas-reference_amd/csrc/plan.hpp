@@ -41,8 +41,8 @@ struct spblas_gfx950_plan_s {
   void* s_sliceblk = nullptr;  // int32[S + 1]: first A'-order block of every slice
   void* s_binblk = nullptr;    // int32[NB + 1]: first P-order block of every wave-bin (multiples of 8)
   void* s_blkdst = nullptr;    // int32[a_blocks]: P-order block of every A'-order block
-  void* s_eoff = nullptr;      // int32[S*NB + 1]: first entry of every (slice, bin) run in the compact A' arrays, key = s*NB + b
-                               // (kept since the end of round 4: the value refresh walks the runs bin by bin)
+  void* s_eoff = nullptr;      // int2[NB*S]: (first entry, padded length) of every (slice, bin) run in the compact A' arrays,
+                               // BIN-major: key = b*S + s (end of round 4: the value refresh walks the runs bin by bin)
   void* s_blksrc = nullptr;    // int32[a_blocks]: first entry of the block in the COMPACT A' arrays (round 3: runs occupy
                                // their count rounded up to 4 entries there, not whole blocks)
   int64_t a_entries = 0;       // entries the A' arrays hold (compact stream + one block of slack)

@@ -737,7 +737,7 @@ int spblas_gfx950_spmv_plan_create(spblas_gfx950_handle_t handle, spblas_gfx950_
     // The sliced plan multiplies with a re-tiled COPY of the values.  With SPBLAS_GFX950_OPT_VALUE_SNAPSHOT (matrix_opt)
     // the copy is taken at inspect and when the caller passes another array.  WITHOUT the opt-in (a plain inspected
     // csr_view, whose multiply must read the caller's values of that call: multiply_impl.hpp:48-52) the plan takes the
-    // values again on EVERY multiply -- pb_refresh_bins_kernel, 0.45 ms at cfg2 -- and is kept only if refresh + tiles
+    // values again on EVERY multiply -- pb_refresh_bins_kernel, 0.38 ms at cfg2 -- and is kept only if refresh + tiles
     // beat the row-block kernel in a timed trial (cfg2: 0.76 against 1.71 ms).  Large matrices only: the plan is a
     // second copy of A (SPBLAS_GFX950_PLAIN_SLICED=0: row-block plan as before round 4's end).
     pl->refresh_each_call = handle->value_snapshot != 0 ? 0 : 1;

@@ -966,6 +966,17 @@ __global__ __launch_bounds__(256) void pb_update_values_kernel(int64_t n_pad, co
   }
 }
 
+// runs[b * S + s] = (first entry, padded length) of run (slice s, bin b): the slice-major offsets turned bin-major
+__global__ __launch_bounds__(256) void pb_run_table_kernel(int S, int64_t NB, const int32_t* __restrict__ eoff,
+                                                           int2* __restrict__ runs) {
+  const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;  // = b * S + s
+  if (i >= (int64_t) S * NB)
+    return;
+  const int64_t b = i / S, sl = i % S, key = sl * NB + b;
+  const int g = eoff[key];
+  runs[i] = make_int2(g, eoff[key + 1] - g);
+}
+
 // The same refresh, bin by bin (end of round 4).  The kernel above walks the A' arrays in their own order -- slice-major --
 // so the 200 entries of a run gather from a window of the caller's array that every one of the S slices fetches again:
 // 12.8 GB of lines for 0.4 GB of values, 1.72 ms at cfg2.  All runs of ONE wave-bin draw from one window (the entries of
@@ -976,11 +987,12 @@ __global__ __launch_bounds__(256) void pb_update_values_kernel(int64_t n_pad, co
 template <typename T, typename O>
 __global__ __launch_bounds__(1024) void pb_refresh_bins_kernel(int S, int64_t NB, int H, int64_t rows,
                                                                const int32_t* __restrict__ binrow, const O* __restrict__ rp,
-                                                               const int32_t* __restrict__ eoff,
+                                                               const int2* __restrict__ runs,
                                                                const int32_t* __restrict__ perm, const T* __restrict__ values,
                                                                T* __restrict__ s_val, int cap) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  T* win = reinterpret_cast<T*>(smem);
+  int2* lrun = reinterpret_cast<int2*>(smem);                    // [S] the bin's runs (one coalesced read)
+  T* win = reinterpret_cast<T*>(smem + (((size_t) S * 8 + 15) & ~(size_t) 15));
   const int64_t b = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   constexpr int NW = 16, U = 4;
@@ -992,6 +1004,8 @@ __global__ __launch_bounds__(1024) void pb_refresh_bins_kernel(int S, int64_t NB
   constexpr int VE = 16 / (int) sizeof(T);
   const bool vec_ok = (reinterpret_cast<uintptr_t>(values) & 15) == 0;  // (cap is a multiple of VE)
   const int64_t p_lo = vec_ok ? (int64_t) rp[r0] & ~(int64_t) (VE - 1) : (int64_t) rp[r0], p_hi = (int64_t) rp[r1];
+  for (int i = tid; i < S; i += 1024)
+    lrun[i] = runs[b * S + i];
   for (int64_t base = p_lo; base < p_hi; base += cap) {
     const int wn = (int) ((p_hi - base) < cap ? (p_hi - base) : cap);
     __syncthreads();  // everyone is done with the previous window
@@ -1009,7 +1023,8 @@ __global__ __launch_bounds__(1024) void pb_refresh_bins_kernel(int S, int64_t NB
     __syncthreads();
     // wave w takes the runs of slices 4 w .. 4 w + 3, then 64 further on: the source positions of FOUR runs are loaded
     // together (a run is ~200 entries at cfg2: one round of a wavefront; one run at a time is a chain of run offsets ->
-    // positions -> store per run: 0.64 ms at cfg2 against 0.50 with four in flight)
+    // positions -> store per run: 0.64 ms at cfg2 against 0.50 with four in flight, 0.45 with 16-byte window loads, 0.38
+    // with the bin's run table read once into LDS instead of two strided 4-byte loads per run)
     constexpr int R = 4;
     for (int s0 = wave * R; s0 < S; s0 += NW * R) {
       int g[R], n[R];
@@ -1019,9 +1034,9 @@ __global__ __launch_bounds__(1024) void pb_refresh_bins_kernel(int S, int64_t NB
         g[r] = 0;
         n[r] = 0;
         if (s0 + r < S) {
-          const int64_t key = (int64_t) (s0 + r) * NB + b;
-          g[r] = eoff[key];
-          n[r] = eoff[key + 1] - g[r];
+          const int2 rr = lrun[s0 + r];
+          g[r] = rr.x;
+          n[r] = rr.y;
         }
       }
 #pragma unroll
@@ -2223,10 +2238,15 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
   int32_t* eoff = nullptr;  // first entry of every run in the compact A' stream (run lengths rounded up to 4)
   if ((rc = dev_alloc((void**) &eoff, (size_t) (nseg + 1) * 4, s)))
     return rc;
-  pl->s_eoff = eoff;  // (owned by the plan: sliced_update_typed)
-  pl->device_bytes += (size_t) (nseg + 1) * 4;
+  temps.p[4] = eoff;
   hipLaunchKernelGGL(pb_ecnt_kernel, dim3((unsigned) cdiv(nseg, 256)), dim3(256), 0, s, nseg, cnt, eoff);
   (void) scan_counts_i32(s, nseg, eoff, partials);  // eoff[nseg] = entries of the compact stream
+  // the same offsets bin-major, with the padded run lengths: what the value refresh reads (sliced_update_typed)
+  if ((rc = dev_alloc(&pl->s_eoff, (size_t) nseg * sizeof(int2), s)))
+    return rc;
+  pl->device_bytes += (size_t) nseg * sizeof(int2);
+  hipLaunchKernelGGL(pb_run_table_kernel, dim3((unsigned) cdiv(nseg, 256)), dim3(256), 0, s, S, (int64_t) NB, eoff,
+                     static_cast<int2*>(pl->s_eoff));
   hipLaunchKernelGGL(pb_bin_prefix_kernel, dim3((unsigned) NB), dim3(256), 0, s, S, NB, cnt, prel, binblk, pb_geom<T>::BLK);
   (void) scan_counts_i32(s, NB, binblk, partials);  // binblk[NB] = blocks in P order (bins padded to groups)
   hipLaunchKernelGGL(pb_slice_blocks_kernel, dim3((unsigned) cdiv(S + 1, 256)), dim3(256), 0, s, S, NB, aoff, sliceblk);
@@ -2618,7 +2638,7 @@ static int sliced_update_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* p
     return SPBLAS_GFX950_STATUS_SUCCESS;
   // bin by bin through LDS when the plan kept its run offsets (SPBLAS_GFX950_PB_UPDATE_BINS=0: the gather in A' order)
   if (pl->s_eoff && pl->n_rblk > 0 && pl->n_slices > 0 && env_int("SPBLAS_GFX950_PB_UPDATE_BINS", 1)) {
-    const int cap = (int) ((PB_STAGE_LDS - 1024) / sizeof(T)) & ~3;
+    const int cap = (int) ((PB_STAGE_LDS - 1024 - (((size_t) pl->n_slices * 8 + 15) & ~(size_t) 15)) / sizeof(T)) & ~3;
     const bool o32 = pl->offset_type == SPBLAS_GFX950_I32;
     const void* rp = pl->s_nzrow ? pl->s_rowptr_c : pl->rowptr;  // (both hold positions in the caller's arrays)
     const int64_t rows = pl->s_nzrow ? pl->s_m : pl->m;
@@ -2626,14 +2646,14 @@ static int sliced_update_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* p
     const void* fn = o32 ? (const void*) pb_refresh_bins_kernel<T, int32_t> : (const void*) pb_refresh_bins_kernel<T, int64_t>;
     SPB_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, PB_STAGE_LDS - 1024));
     if (o32)
-      hipLaunchKernelGGL((pb_refresh_bins_kernel<T, int32_t>), dim3((unsigned) pl->n_rblk), dim3(1024), (size_t) cap * sizeof(T),
+      hipLaunchKernelGGL((pb_refresh_bins_kernel<T, int32_t>), dim3((unsigned) pl->n_rblk), dim3(1024), (size_t) PB_STAGE_LDS - 1024,
                          h->stream, pl->n_slices, pl->n_rblk, pl->rows_per_blk, rows, binrow, static_cast<const int32_t*>(rp),
-                         static_cast<const int32_t*>(pl->s_eoff), reinterpret_cast<const int32_t*>(pl->s_perm),
+                         static_cast<const int2*>(pl->s_eoff), reinterpret_cast<const int32_t*>(pl->s_perm),
                          static_cast<const T*>(values), static_cast<T*>(pl->s_values), cap);
     else
-      hipLaunchKernelGGL((pb_refresh_bins_kernel<T, int64_t>), dim3((unsigned) pl->n_rblk), dim3(1024), (size_t) cap * sizeof(T),
+      hipLaunchKernelGGL((pb_refresh_bins_kernel<T, int64_t>), dim3((unsigned) pl->n_rblk), dim3(1024), (size_t) PB_STAGE_LDS - 1024,
                          h->stream, pl->n_slices, pl->n_rblk, pl->rows_per_blk, rows, binrow, static_cast<const int64_t*>(rp),
-                         static_cast<const int32_t*>(pl->s_eoff), reinterpret_cast<const int32_t*>(pl->s_perm),
+                         static_cast<const int2*>(pl->s_eoff), reinterpret_cast<const int32_t*>(pl->s_perm),
                          static_cast<const T*>(values), static_cast<T*>(pl->s_values), cap);
     SPB_HIP(hipGetLastError());
     return SPBLAS_GFX950_STATUS_SUCCESS;
