@@ -730,7 +730,12 @@ int spblas_gfx950_spmv_plan_create(spblas_gfx950_handle_t handle, spblas_gfx950_
     if (rc == SPBLAS_GFX950_STATUS_SUCCESS)
       store_trial(handle, pl, values);
   } else if (rc == SPBLAS_GFX950_STATUS_SUCCESS && alg == SPBLAS_GFX950_SPMV_AUTO && values &&
-             (handle->value_snapshot != 0 || (pl->nnz >= ((int64_t) 16 << 20) && env_int_spmv("SPBLAS_GFX950_PLAIN_SLICED", 1))) &&
+             (handle->value_snapshot != 0 ||
+              // (plain operands: large and NOT skewed -- a power-law matrix would get the hot-column split, whose refresh
+              // gathers through two source maps: 6.9 against 3.4 ms for the row-block kernel at cfg4, after 50 ms of inspect)
+              (pl->nnz >= ((int64_t) 16 << 20) && env_int_spmv("SPBLAS_GFX950_PLAIN_SLICED", 1) &&
+               (double) pl->max_row_len <= 16.0 * ((double) pl->nnz / (double) (pl->m > 0 ? pl->m : 1)) + 64.0 &&
+               pl->empty_rows * 4 <= pl->m)) &&
              pl->alg == SPBLAS_GFX950_SPMV_ROWBLOCK && sliced_candidate(pl)) {
     // x far larger than an XCD's L2 and no long rows: try the LDS-sliced re-tiling; it
     // declines (NOT_SUPPORTED) when the entries cluster in few tiles.
