@@ -7,11 +7,15 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import spblas_reference_amd as sp
 from spblas_reference_amd import _capi, generate
 
-m = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
-values, rowptr, colind, shape, nnz = generate.uniform_csr_device(m, m, 10, seed=0)
+if len(sys.argv) > 1 and sys.argv[1] == "rmat":  # cfg4: fp64 R-MAT scale 24 (hot-column split + tiles over a row map)
+    values, rowptr, colind, shape, nnz = generate.rmat_csr_device(24, 16, dtype=torch.float64, seed=0)
+    m = shape[0]
+else:
+    m = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
+    values, rowptr, colind, shape, nnz = generate.uniform_csr_device(m, m, 10, seed=0)
 a = sp.csr_view(values, rowptr, colind, shape, nnz)
-x = torch.rand(m, device="cuda")
-y = torch.empty(m, device="cuda")
+x = torch.rand(m, dtype=values.dtype, device="cuda")
+y = torch.empty(m, dtype=values.dtype, device="cuda")
 info = sp.multiply_inspect(sp.matrix_opt(a), x, y)
 print("plan", info.state_.info()["alg"], info.state_.sliced_info().get("row_code_u8"))
 hd = sp.api._Handle.current(x.device)
