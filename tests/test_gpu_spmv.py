@@ -966,3 +966,22 @@ def test_spmv_plain_inspected_csr_view_follows_values_written_in_place(gpu, dtyp
         absrow = oracle.spmv_absrow(sub_rp, sub_ci, sub_v, xh)
         util.assert_parity(y[torch.from_numpy(rows).cuda()].cpu().numpy(), y_ref, absrow, dtype, row_len=np.diff(sub_rp),
                            what=f"plain inspected csr_view, values rewritten in place, step {step}")
+    # ... also when the multiply is a recorded HIP graph: the replay reads the array as it is THEN
+    s_ = torch.cuda.Stream()
+    s_.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s_):
+        sp.multiply(info, a, x, y)
+    torch.cuda.current_stream().wait_stream(s_)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        sp.multiply(info, a, x, y)
+    values.mul_(0.5).sub_(0.03125)
+    y.fill_(float("nan"))
+    g.replay()
+    torch.cuda.synchronize()
+    sub_v = values.cpu().numpy()[idx]
+    y_ref = oracle.spmv((len(rows), n), sub_rp, sub_ci, sub_v, xh)
+    absrow = oracle.spmv_absrow(sub_rp, sub_ci, sub_v, xh)
+    util.assert_parity(y[torch.from_numpy(rows).cuda()].cpu().numpy(), y_ref, absrow, dtype, row_len=np.diff(sub_rp),
+                       what="plain inspected csr_view, graph replay after an in-place change")
