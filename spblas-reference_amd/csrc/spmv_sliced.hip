@@ -2644,7 +2644,14 @@ static int sliced_update_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* p
     const int64_t rows = pl->s_nzrow ? pl->s_m : pl->m;
     const int32_t* binrow = static_cast<const int32_t*>(pl->s_binrow);
     const void* fn = o32 ? (const void*) pb_refresh_bins_kernel<T, int32_t> : (const void*) pb_refresh_bins_kernel<T, int64_t>;
-    SPB_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, PB_STAGE_LDS - 1024));
+    // (once per device, offset type and value type -- this function is a template --: a plan without the snapshot opt-in
+    // comes here on every multiply)
+    static bool attr_set[64][2] = {};
+    const int dev = h->device >= 0 && h->device < 64 ? h->device : 0;
+    if (!attr_set[dev][o32 ? 0 : 1] || h->device >= 64) {
+      SPB_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, PB_STAGE_LDS - 1024));
+      attr_set[dev][o32 ? 0 : 1] = true;
+    }
     if (o32)
       hipLaunchKernelGGL((pb_refresh_bins_kernel<T, int32_t>), dim3((unsigned) pl->n_rblk), dim3(1024), (size_t) PB_STAGE_LDS - 1024,
                          h->stream, pl->n_slices, pl->n_rblk, pl->rows_per_blk, rows, binrow, static_cast<const int32_t*>(rp),
