@@ -322,6 +322,7 @@ class _Plan:
         bits = d["auto_trial"]
         d["row_code_u8"] = (bits >> 1) & 1  # one-byte row codes in the reduce's stream (runs sorted by row)
         d["refresh_each_call"] = (bits >> 6) & 1  # made without the snapshot opt-in: every multiply takes A's values again
+        d["value_free"] = (bits >> 7) & 1  # ... and holds no copy of them: the reduce reads the caller's array through LDS (round 5)
         d["nt_product_stores"] = (bits >> 2) & 1  # the expand stores its products with the non-temporal hint
         d["store_trial"] = (bits >> 3) & 1  # THIS plan timed both store flavours (opt-in: OPT_STORE_TRIAL = 2 on the handle or SPBLAS_GFX950_PB_NT=-2)
         d["auto_trial"] = bits & 1

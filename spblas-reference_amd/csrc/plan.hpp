@@ -67,6 +67,13 @@ struct spblas_gfx950_plan_s {
   int64_t s_placed = 0;        // entries in the tiles (nnz minus the hub rows' entries)
   const void* values_ptr = nullptr;  // caller's values array the copy was taken from (inspect / last update)
   int refresh_each_call = 0;         // 1: the plan was made WITHOUT the snapshot opt-in: every multiply takes the values again
+  // Value-free tiles (round 5, spmv_sliced.hip "vfree"): the plan holds NO copy of A's values.  The expand writes the gathered
+  // x[col] to the product stream; the reduce of a bin stages the bin's window of the CALLER's values (contiguous:
+  // rowptr[r0] .. rowptr[r1]) in LDS and forms values[src] * xg with a 16-bit in-window source offset per entry.
+  int vfree = 0;
+  int vf_win_cap = 0;                // entries the LDS window area of the reduce holds
+  int vf_waves = 0;                  // wavefronts of a reduce workgroup (one bin per WORKGROUP; private accumulators per wave)
+  uint16_t* s_src = nullptr;         // uint16[p_blocks*BLK] source position inside the bin's window (P order; pads 0)
   const void* last_x = nullptr;      // x of the last expand
   void* s_hub_part = nullptr;        // T[n_long * hub_parts] partial sums of the hub rows
   int hub_parts = 1;                 // workgroups per hub row

@@ -726,7 +726,15 @@ int spblas_gfx950_spmv_plan_create(spblas_gfx950_handle_t handle, spblas_gfx950_
   int rc = offset_type == SPBLAS_GFX950_I32 ? plan_build<int32_t>(handle, pl, alg)
                                             : plan_build<int64_t>(handle, pl, alg);
   if (rc == SPBLAS_GFX950_STATUS_SUCCESS && pl->alg == SPBLAS_GFX950_SPMV_SLICED) {
+    // (an explicitly requested SLICED plan keeps its copy of the values -- the documented snapshot -- unless the test hook
+    // SPBLAS_GFX950_PB_VFREE=2 asks for the value-free form, which then reads the caller's array on every multiply)
+    if (env_int_spmv("SPBLAS_GFX950_PB_VFREE", 1) == 2) {
+      pl->vfree = 1;
+      pl->refresh_each_call = 1;
+    }
     rc = spmv_sliced_build(handle, pl, values, false);
+    if (rc == SPBLAS_GFX950_STATUS_SUCCESS && !pl->vfree && env_int_spmv("SPBLAS_GFX950_PB_VFREE", 1) == 2)
+      pl->refresh_each_call = 0;
     if (rc == SPBLAS_GFX950_STATUS_SUCCESS)
       store_trial(handle, pl, values);
   } else if (rc == SPBLAS_GFX950_STATUS_SUCCESS && alg == SPBLAS_GFX950_SPMV_AUTO && values &&
@@ -745,7 +753,11 @@ int spblas_gfx950_spmv_plan_create(spblas_gfx950_handle_t handle, spblas_gfx950_
     // values again on EVERY multiply -- pb_refresh_bins_kernel, 0.38 ms at cfg2 -- and is kept only if refresh + tiles
     // beat the row-block kernel in a timed trial (cfg2: 0.76 against 1.71 ms).  Large matrices only: the plan is a
     // second copy of A (SPBLAS_GFX950_PLAIN_SLICED=0: row-block plan as before round 4's end).
+    // Round 5: such a plan is built VALUE-FREE when the matrix allows it (spmv_sliced.hip, pb_reduce_vf_kernel): no copy
+    // of the values at all -- the expand moves x[col], the reduce multiplies by the caller's array through an LDS window
+    // per bin -- and falls back to the copying form otherwise.
     pl->refresh_each_call = handle->value_snapshot != 0 ? 0 : 1;
+    pl->vfree = pl->refresh_each_call;
     const int rc2 = spmv_sliced_build(handle, pl, values, true);
     if (rc2 == SPBLAS_GFX950_STATUS_SUCCESS) {
       bool keep = true;
@@ -761,6 +773,7 @@ int spblas_gfx950_spmv_plan_create(spblas_gfx950_handle_t handle, spblas_gfx950_
     } else {
       spmv_sliced_free(handle, pl);
       pl->refresh_each_call = 0;
+      pl->vfree = 0;
       if (rc2 != SPBLAS_GFX950_STATUS_NOT_SUPPORTED)
         rc = rc2;
     }
@@ -827,7 +840,8 @@ int spblas_gfx950_spmv_reduce_rows_bcast(spblas_gfx950_handle_t handle, spblas_g
   bcast_wait_disarm disarm{handle};
   if (!plan || !alpha || !y_peers)
     return SPBLAS_GFX950_STATUS_INVALID_POINTER;
-  if (plan->alg != SPBLAS_GFX950_SPMV_SLICED)
+  // (a plan made without the snapshot opt-in must take A's values of THIS call: these entry points are not given them)
+  if (plan->alg != SPBLAS_GFX950_SPMV_SLICED || plan->refresh_each_call)
     return SPBLAS_GFX950_STATUS_NOT_SUPPORTED;
   if (n_peers < 1 || y_row_offset < 0 || row_begin < 0 || row_end > plan->m || row_begin > row_end)
     return SPBLAS_GFX950_STATUS_INVALID_SIZE;
@@ -850,7 +864,7 @@ int spblas_gfx950_spmv_step_bcast(spblas_gfx950_handle_t handle, spblas_gfx950_p
   bcast_wait_disarm disarm{handle};
   if (!plan || !alpha || !x || !y_peers)
     return SPBLAS_GFX950_STATUS_INVALID_POINTER;
-  if (plan->alg != SPBLAS_GFX950_SPMV_SLICED)
+  if (plan->alg != SPBLAS_GFX950_SPMV_SLICED || plan->refresh_each_call)  // (as above: no values of this call here)
     return SPBLAS_GFX950_STATUS_NOT_SUPPORTED;
   if (n_peers < 1 || y_row_offset < 0 || stripes < 1)
     return SPBLAS_GFX950_STATUS_INVALID_SIZE;
@@ -965,7 +979,7 @@ int spblas_gfx950_spmv_step_bcast_chunked(spblas_gfx950_handle_t handle, spblas_
   } disarm{handle};
   if (!plan || !alpha || !x || !y_peers || !flag_peers)
     return SPBLAS_GFX950_STATUS_INVALID_POINTER;
-  if (plan->alg != SPBLAS_GFX950_SPMV_SLICED || plan->rest_plan)
+  if (plan->alg != SPBLAS_GFX950_SPMV_SLICED || plan->rest_plan || plan->refresh_each_call)
     return SPBLAS_GFX950_STATUS_NOT_SUPPORTED;
   if (n_peers < 1 || n_peers > 64 || rank < 0 || rank >= n_peers || y_row_offset < 0 || chunks < 1 || chunks > 64)
     return SPBLAS_GFX950_STATUS_INVALID_SIZE;
@@ -1117,7 +1131,8 @@ int spblas_gfx950_plan_info_sliced(spblas_gfx950_plan_t plan, int64_t info[12]) 
   // trial, bit 4: hot-column split (spblas_gfx950_plan_info_hot has the numbers), bit 6: the plan takes A's values again on
   // every multiply (made without the snapshot opt-in)
   info[9] = (plan->trial_ms[0] > 0.f ? 1 : 0) | (sl && tp->enc8 ? 2 : 0) | (sl && plan->nt_products ? 4 : 0) |
-            (plan->store_trial_ms[0] > 0.f ? 8 : 0) | (sl && plan->rest_plan ? 16 : 0) | (sl && plan->refresh_each_call ? 64 : 0);
+            (plan->store_trial_ms[0] > 0.f ? 8 : 0) | (sl && plan->rest_plan ? 16 : 0) | (sl && plan->refresh_each_call ? 64 : 0) |
+            (sl && tp->vfree ? 128 : 0);  // bit 7: value-free tiles (no copy of A's values in the plan)
   const float* tms = plan->trial_ms[0] > 0.f ? plan->trial_ms : plan->store_trial_ms;  // AUTO's times, else the store trial's
   info[10] = (int64_t) (tms[0] * 1e6f);
   info[11] = (int64_t) (tms[1] * 1e6f);

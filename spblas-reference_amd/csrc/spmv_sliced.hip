@@ -547,7 +547,8 @@ __device__ __forceinline__ void pb_emit_sorted_run(int n, int lo, int g, int gp,
                                                    T* __restrict__ s_val, uint16_t* __restrict__ s_col,
                                                    int32_t* __restrict__ perm, unsigned char* __restrict__ s_code,
                                                    typename pb_hdr<T>::type* __restrict__ s_hdr, int* exc_n, int exc_cap,
-                                                   unsigned* __restrict__ exc_idx, uint16_t* __restrict__ exc_row) {
+                                                   unsigned* __restrict__ exc_idx, uint16_t* __restrict__ exc_row,
+                                                   uint16_t* __restrict__ s_src) {
   constexpr int PB_BLK = pb_geom<T>::BLK;
   const int nb = (n + PB_BLK - 1) / PB_BLK;
   for (int j0 = 0; j0 < nb * PB_BLK; j0 += 64) {
@@ -568,16 +569,22 @@ __device__ __forceinline__ void pb_emit_sorted_run(int n, int lo, int g, int gp,
     const int Dp = __shfl_up(D, 1, 64);
     const bool exc = valid && bi > 0 && r - Dp >= 255;
     if (valid) {
-      s_val[g + j] = stv[lo + j];
       s_col[g + j] = stc[lo + j];
-      perm[g + j] = (int32_t) (p0 + qq);
+      if (s_src) {  // value-free tiles: no copy of the value, the source position goes to the REDUCE's stream (16 bits: the
+        s_src[gp + j] = (uint16_t) qq;  // bin's window of the caller's array holds < 65 536 entries)
+      } else {
+        s_val[g + j] = stv[lo + j];
+        perm[g + j] = (int32_t) (p0 + qq);
+      }
       s_code[gp + j] = (unsigned char) (bi == 0 ? 0 : (exc ? 255 : r - Dp));
       if (bi == 0)
         s_hdr[(gp + j) / PB_BLK] = pb_hdr<T>::make((unsigned) r, 0u);
     } else if (j < ((n + 3) & ~3)) {  // the run's share of A' ends on a multiple of 4: value 0, column 0, no source position
-      s_val[g + j] = T(0);            // (written here, so that the plan arrays need no clearing pass: pb_clear_tail)
-      s_col[g + j] = 0;
-      perm[g + j] = -1;
+      s_col[g + j] = 0;               // (written here, so that the plan arrays need no clearing pass: pb_clear_tail)
+      if (!s_src) {
+        s_val[g + j] = T(0);
+        perm[g + j] = -1;
+      }
     }
     if (exc) {
       const int k = atomicAdd(exc_n, 1);
@@ -598,7 +605,8 @@ __global__ __launch_bounds__(PB_STAGE_THREADS) void pb_scatter_staged_kernel(
     int32_t* __restrict__ blkdst, int hub_len, int cap, int rt_len, const int32_t* __restrict__ binrow,
     unsigned char* __restrict__ s_code, typename pb_hdr<T>::type* __restrict__ s_hdr, unsigned* __restrict__ exc_idx,
     uint16_t* __restrict__ exc_row, int32_t* __restrict__ exc_cnt, int exc_cap, int32_t* __restrict__ enc_fail,
-    const int32_t* __restrict__ eoff, int32_t* __restrict__ blksrc, const int32_t* __restrict__ bin_order) {
+    const int32_t* __restrict__ eoff, int32_t* __restrict__ blksrc, const int32_t* __restrict__ bin_order,
+    uint16_t* __restrict__ s_src) {
   constexpr int PB_BLK = pb_geom<T>::BLK;
   __shared__ int exc_n;
   if (ENC8 && threadIdx.x == 0)
@@ -796,7 +804,8 @@ __global__ __launch_bounds__(PB_STAGE_THREADS) void pb_scatter_staged_kernel(
           if (sl >= s0 && sl < s1) {
             const int pos = atomicAdd(&mycur[sl], 1);
             st[pos] = q;
-            stv[pos] = values[p0 + q];
+            if (!s_src)
+              stv[pos] = values[p0 + q];
             stc[pos] = (uint16_t) (c - sl * W);
           }
         }
@@ -833,13 +842,18 @@ __global__ __launch_bounds__(PB_STAGE_THREADS) void pb_scatter_staged_kernel(
         if (ENC8)
           continue;  // a run larger than the staging area cannot be sorted here: the plan falls back (flag below)
         const int i = gdst[sl] + pos;
-        s_val[i] = values[p0 + q];
         s_col[i] = (uint16_t) (c - sl * W);
-        perm[i] = (int32_t) (p0 + q);
+        if (s_src) {
+          s_src[pdst[sl] + pos] = (uint16_t) q;
+        } else {
+          s_val[i] = values[p0 + q];
+          perm[i] = (int32_t) (p0 + q);
+        }
         s_row[pdst[sl] + pos] = (uint16_t) r;
       } else {
         st[pos] = q;
-        stv[pos] = values[p0 + q];  // neighbouring threads: neighbouring addresses
+        if (!s_src)
+          stv[pos] = values[p0 + q];  // neighbouring threads: neighbouring addresses
         stc[pos] = (uint16_t) (c - sl * W);
       }
       }
@@ -851,9 +865,11 @@ __global__ __launch_bounds__(PB_STAGE_THREADS) void pb_scatter_staged_kernel(
     if (!ENC8 && direct && tid < 3) {  // the run that went straight to memory: pads of its last quad
       const int n = lcnt[s0];
       if (tid < ((n + 3) & ~3) - n) {
-        s_val[gdst[s0] + n + tid] = T(0);
         s_col[gdst[s0] + n + tid] = 0;
-        perm[gdst[s0] + n + tid] = -1;
+        if (!s_src) {
+          s_val[gdst[s0] + n + tid] = T(0);
+          perm[gdst[s0] + n + tid] = -1;
+        }
       }
     }
     if (!direct) {
@@ -872,20 +888,26 @@ __global__ __launch_bounds__(PB_STAGE_THREADS) void pb_scatter_staged_kernel(
 #endif
           if (n > 0)
             pb_emit_sorted_run<T>(n, lo, g, gp, (int) p0, lane, st, stv, stc, row_of, s_val, s_col, perm, s_code, s_hdr,
-                                  &exc_n, exc_cap, ei, er);
+                                  &exc_n, exc_cap, ei, er, s_src);
           continue;
         }
         for (int j = lane; j < n; j += 64) {
           const int q = st[lo + j];
-          s_val[g + j] = stv[lo + j];
           s_col[g + j] = stc[lo + j];
-          perm[g + j] = (int32_t) (p0 + q);
+          if (s_src) {
+            s_src[gp + j] = (uint16_t) q;
+          } else {
+            s_val[g + j] = stv[lo + j];
+            perm[g + j] = (int32_t) (p0 + q);
+          }
           s_row[gp + j] = (uint16_t) row_of(q);
         }
         if (lane < ((n + 3) & ~3) - n) {  // pads of the run's last quad (see pb_emit_sorted_run)
-          s_val[g + n + lane] = T(0);
           s_col[g + n + lane] = 0;
-          perm[g + n + lane] = -1;
+          if (!s_src) {
+            s_val[g + n + lane] = T(0);
+            perm[g + n + lane] = -1;
+          }
         }
       }
     }
@@ -1136,7 +1158,9 @@ struct pb_chunk_wait {
   int* status_dev;
 };
 
-template <typename T, bool NT>
+// VF (value-free tiles, round 5): the plan holds no values -- the "product" is the gathered x[col] alone (2 B read, 4 B
+// written per entry); the reduce multiplies by the caller's values (pb_reduce_vf_kernel)
+template <typename T, bool NT, bool VF = false>
 __global__ __launch_bounds__(PB_THREADS) void pb_expand_kernel(int64_t n, int W, const int32_t* __restrict__ sliceblk,
                                                                const T* __restrict__ s_val,
                                                                const uint16_t* __restrict__ s_col,
@@ -1242,16 +1266,23 @@ __global__ __launch_bounds__(PB_THREADS) void pb_expand_kernel(int64_t n, int W,
       const u16x4 ca = *reinterpret_cast<const u16x4*>(s_col + ea);
       const u16x4 cb = *reinterpret_cast<const u16x4*>(s_col + eb);
 #else
-      pack4<T>::load(s_val + ea, va);
-      pack4<T>::load(s_val + eb, vb);
+      if constexpr (!VF) {
+        pack4<T>::load(s_val + ea, va);
+        pack4<T>::load(s_val + eb, vb);
+      }
       const u16x4 ca = stream_load(reinterpret_cast<const u16x4*>(s_col + ea));
       const u16x4 cb = stream_load(reinterpret_cast<const u16x4*>(s_col + eb));
 #endif
       const int da = stream_load(blkdst + blk), db = stream_load(blkdst + blk + PASS);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        pa[j] = va[j] * xs[ca[j]];
-        pb[j] = vb[j] * xs[cb[j]];
+        if constexpr (VF) {
+          pa[j] = xs[ca[j]];
+          pb[j] = xs[cb[j]];
+        } else {
+          pa[j] = va[j] * xs[ca[j]];
+          pb[j] = vb[j] * xs[cb[j]];
+        }
       }
       put(P + (int64_t) da * PB_BLK + sub, pa);
       put(P + (int64_t) db * PB_BLK + sub, pb);
@@ -1259,12 +1290,17 @@ __global__ __launch_bounds__(PB_THREADS) void pb_expand_kernel(int64_t n, int W,
     for (; blk < b1; blk += PASS) {
       const int ea = stream_load(blksrc + blk) + sub;
       T va[4], pa[4];
-      pack4<T>::load(s_val + ea, va);
+      if constexpr (!VF)
+        pack4<T>::load(s_val + ea, va);
       const u16x4 ca = stream_load(reinterpret_cast<const u16x4*>(s_col + ea));
       const int da = stream_load(blkdst + blk);
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        pa[j] = va[j] * xs[ca[j]];
+      for (int j = 0; j < 4; ++j) {
+        if constexpr (VF)
+          pa[j] = xs[ca[j]];
+        else
+          pa[j] = va[j] * xs[ca[j]];
+      }
       put(P + (int64_t) da * PB_BLK + sub, pa);
     }
   };
@@ -1638,6 +1674,229 @@ __global__ __launch_bounds__(RW * 64) void pb_reduce_kernel(int64_t m, int Hw, i
   }
 }
 
+
+// ---- value-free reduce (round 5) ---------------------------------------------------------------------------------------
+// A plain inspected csr_view must multiply with the caller's values OF THAT CALL (multiply_impl.hpp:48-52), and until round
+// 5 the tiled plan did so by copying them into its A' stream before every multiply (pb_refresh_bins_kernel: 12.3 B per
+// entry on top of the pair's 16).  Here the values never pass through the expand: the product stream carries the gathered
+// x[col] (pb_expand_kernel<.., VF>), and the reduce of a bin multiplies by the caller's values itself.  All entries of a
+// bin's rows lie in ONE window of the caller's array (rowptr[r0] .. rowptr[r1]), which the workgroup stages in LDS once;
+// every entry of the bin's stream carries its 16-bit position inside that window next to its row code.  Bytes per padded
+// entry: expand 2 + 4, reduce 4 + 2 + 1.25, plus 4 per entry for the window: ~17-19 B against 28.
+// The window is what sizes the bin (fp32: H rows * (avg entries per row + NW) * 4 B <= 160 KiB), so a bin belongs to a
+// WORKGROUP, not to a wavefront: wave w of NW reduces the w-th part of the bin's stream into accumulators of its own (plain
+// LDS read-add-write stays race free: nobody else touches them; duplicates inside a group are flagged as before), and the
+// NW partial rows are added in wave order at the end -- the order of additions is fixed by the plan.
+//   rowptr: the caller's row offsets (o64: 64-bit); values: the caller's array of THIS call; win_cap: entries the window area
+//   holds (the build checked every bin's span + the alignment shift against it)
+template <typename T, int NW, int UB, bool ENC8>
+__global__ __launch_bounds__(NW * 64) void pb_reduce_vf_kernel(int64_t m, int Hw, int64_t wb_begin, int64_t wb_end,
+                                                               const int32_t* __restrict__ binblk, const T* __restrict__ P,
+                                                               const uint16_t* __restrict__ s_row,
+                                                               const uint16_t* __restrict__ s_src,
+                                                               const T* __restrict__ values, const void* __restrict__ rowptr,
+                                                               int o64, T* __restrict__ y, T alpha, T beta, int win_cap,
+                                                               const typename pb_hdr<T>::type* __restrict__ s_hdr,
+                                                               const unsigned* __restrict__ exc_idx,
+                                                               const uint16_t* __restrict__ exc_row,
+                                                               const int32_t* __restrict__ exc_cnt, int exc_cap) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  T* win = reinterpret_cast<T*>(smem);                      // [win_cap] the bin's window of the caller's values
+  T* acc = win + win_cap + (size_t) wave * (Hw + 64);       // this wave's Hw accumulators + 64 dummy slots
+  const int64_t wb = wb_begin + blockIdx.x;
+  if (wb >= wb_end)
+    return;
+  const int64_t r0 = wb * Hw, r1 = (r0 + Hw) < m ? (r0 + Hw) : m;
+  const int rh = (int) (r1 - r0);
+  const int64_t p0 = o64 ? (int64_t) static_cast<const int64_t*>(rowptr)[r0] : (int64_t) static_cast<const int32_t*>(rowptr)[r0];
+  const int64_t p1 = o64 ? (int64_t) static_cast<const int64_t*>(rowptr)[r1] : (int64_t) static_cast<const int32_t*>(rowptr)[r1];
+  constexpr int PB_GBLK = pb_geom<T>::GBLK;
+  constexpr int LPB = pb_geom<T>::BLK / 4;  // lanes per block
+  const int gb0 = binblk[wb] / PB_GBLK, ng = binblk[wb + 1] / PB_GBLK - gb0;
+  const int g_lo = gb0 + (int) ((int64_t) ng * wave / NW);
+  const int g_hi = gb0 + (int) ((int64_t) ng * (wave + 1) / NW);
+  typedef typename pb_hdr<T>::type hdr_t;
+  struct batch_t {
+    T p[UB][4];       // gathered x values
+    u16x4 s[UB];      // positions inside the window
+    u16x4 r[UB];      // 16-bit rows
+    unsigned cw[UB];  // enc8: four row codes
+    hdr_t hd[UB];     // enc8: the header of the lane's block
+  };
+  T* const dummy = acc + Hw + lane;
+  auto issue = [&](int g, batch_t& q) {
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int gg = (g + u) < g_hi ? (g + u) : (g_hi - 1);
+      const unsigned offR = ((unsigned) gg * PB_GRP + 4u * (unsigned) lane) * 2u;
+      const unsigned offP = offR * (unsigned) (sizeof(T) / 2);
+      pack4<T>::load(reinterpret_cast<const T*>(reinterpret_cast<const char*>(P) + offP), q.p[u]);
+      q.s[u] = stream_load(reinterpret_cast<const u16x4*>(reinterpret_cast<const char*>(s_src) + offR));
+      if (ENC8) {
+        q.cw[u] = stream_load(reinterpret_cast<const unsigned*>(reinterpret_cast<const char*>(s_row) + (offR >> 1)));
+        q.hd[u] = stream_load(s_hdr + ((unsigned) gg * (unsigned) PB_GBLK + (unsigned) lane / LPB));
+      } else {
+        q.r[u] = stream_load(reinterpret_cast<const u16x4*>(reinterpret_cast<const char*>(s_row) + offR));
+      }
+    }
+  };
+  // the first batch of the stream is on its way while the window is staged
+  batch_t qa, qb;
+  if (g_hi > g_lo)
+    issue(g_lo, qa);
+  for (int i = lane; i < rh; i += 64)
+    acc[i] = T(0);
+  // the window: 16-byte loads from the aligned position at or before p0 (the array itself must be 16-byte aligned for that)
+  constexpr int VE = 16 / (int) sizeof(T);
+  const bool vec_ok = (reinterpret_cast<uintptr_t>(values) & 15) == 0;
+  const int64_t p_lo = vec_ok ? (p0 & ~(int64_t) (VE - 1)) : p0;
+  const int shift = (int) (p0 - p_lo), wn = (int) (p1 - p_lo);
+  if (vec_ok) {
+    typedef T vec_t __attribute__((ext_vector_type(VE)));
+    const int nv = wn / VE;
+    const vec_t* src = reinterpret_cast<const vec_t*>(values + p_lo);
+    constexpr int SU = 4;  // loads in flight per lane
+    for (int i0 = tid; i0 < nv; i0 += SU * NW * 64) {
+      vec_t t[SU];
+#pragma unroll
+      for (int u = 0; u < SU; ++u) {
+        const int i = i0 + u * NW * 64;
+        t[u] = stream_load(src + (i < nv ? i : nv - 1));
+      }
+#pragma unroll
+      for (int u = 0; u < SU; ++u) {
+        const int i = i0 + u * NW * 64;
+        if (i < nv)
+          reinterpret_cast<vec_t*>(win)[i] = t[u];
+      }
+    }
+    for (int i = nv * VE + tid; i < wn; i += NW * 64)
+      win[i] = stream_load(values + p_lo + i);
+  } else {
+    for (int i = tid; i < wn; i += NW * 64)
+      win[i] = stream_load(values + p_lo + i);
+  }
+  // LDS traffic complete in every wave, then the barrier (not __syncthreads(): no reason to drain the stream loads)
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  const T* wv = win + shift;
+  auto consume = [&](int g, const batch_t& q) {
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      if (g + u >= g_hi)
+        break;
+      T v[4], pr[4];
+      T* slot[4];
+      bool flagged[4], atomic[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        pr[j] = wv[q.s[u][j]];
+      if (ENC8) {
+        unsigned row[4];
+        bool skip[4];
+        pb_decode_rows<LPB>(q.cw[u], pb_hdr<T>::base(q.hd[u]), lane, (unsigned) Hw, row, skip);
+        const unsigned fl = pb_hdr<T>::flags(q.hd[u]) >> (4 * (lane & (LPB - 1)));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          atomic[j] = ((fl >> j) & 1u) != 0 && !skip[j];
+          flagged[j] = atomic[j] || skip[j];
+          slot[j] = acc + row[j];
+          v[j] = *slot[j];
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          unsigned r = q.r[u][j];
+          asm("" : "+v"(r));
+          flagged[j] = atomic[j] = r > 0x7FFFu;
+          slot[j] = acc + (r & 0x7FFFu);
+          v[j] = *slot[j];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        pr[j] *= q.p[u][j];
+        T* w = flagged[j] ? dummy : slot[j];
+        *w = v[j] + pr[j];
+      }
+      if (__builtin_amdgcn_ballot_w64(atomic[0] | atomic[1] | atomic[2] | atomic[3]) != 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (atomic[j])
+            unsafeAtomicAdd(slot[j], pr[j]);
+      }
+    }
+  };
+  if (g_hi > g_lo) {
+    for (int g = g_lo; g < g_hi; g += 2 * UB) {
+      issue(g + UB, qb);
+      consume(g, qa);
+      issue(g + 2 * UB, qa);
+      consume(g + UB, qb);
+    }
+  }
+  if (ENC8 && wave == 0) {
+    // exceptions of this bin (entries the one-byte codes could not reach): added once, by the first wave
+    const int ne = exc_cnt[wb];
+    for (int i = lane; i < ne; i += 64) {
+      const unsigned e = exc_idx[(size_t) wb * exc_cap + i];
+      unsafeAtomicAdd(acc + exc_row[(size_t) wb * exc_cap + i], P[e] * wv[s_src[e]]);
+    }
+  }
+  __syncthreads();
+  // y = alpha * (the waves' partial rows, in wave order) + beta * y
+  const T* a0 = win + win_cap;
+  for (int i0 = tid; i0 < rh; i0 += NW * 64 * 4) {
+    T sum[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = (i0 + u * NW * 64) < rh ? (i0 + u * NW * 64) : 0;
+      T t = a0[i];
+#pragma unroll
+      for (int w = 1; w < NW; ++w)
+        t += a0[(size_t) w * (Hw + 64) + i];
+      sum[u] = alpha * t;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * NW * 64;
+      if (i < rh)
+        y[r0 + i] = beta == T(0) ? sum[u] : sum[u] + beta * y[r0 + i];
+    }
+  }
+}
+
+template <typename T>
+static const void* pb_reduce_vf_fn(int nw, int ub, bool enc8) {
+#define SPB_VF(NW_, UB_, E_) reinterpret_cast<const void*>(pb_reduce_vf_kernel<T, NW_, UB_, E_>)
+  if (enc8) {
+    if (nw == 8)
+      return ub == 4 ? SPB_VF(8, 4, true) : SPB_VF(8, 2, true);
+    return ub == 4 ? SPB_VF(4, 4, true) : SPB_VF(4, 2, true);
+  }
+  if (nw == 8)
+    return ub == 2 ? SPB_VF(8, 2, false) : SPB_VF(8, 4, false);
+  return ub == 2 ? SPB_VF(4, 2, false) : SPB_VF(4, 4, false);
+#undef SPB_VF
+}
+// widest bin window of the arithmetic bin grid: max over b of rowptr[min((b + 1) H, m)] - rowptr[b H]
+template <typename O>
+__global__ __launch_bounds__(256) void pb_bin_span_kernel(int64_t m, int H, int64_t NB, const O* __restrict__ rowptr,
+                                                          unsigned long long* __restrict__ out) {
+  const int64_t b = (int64_t) blockIdx.x * 256 + threadIdx.x;
+  unsigned long long span = 0;
+  if (b < NB) {
+    const int64_t r0 = b * H, r1 = (r0 + H) < m ? (r0 + H) : m;
+    span = (unsigned long long) (rowptr[r1] - rowptr[r0]);
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned long long u = __shfl_xor(span, o, 64);
+    span = u > span ? u : span;
+  }
+  if ((threadIdx.x & 63) == 0 && span > 0)
+    atomicMax(out, span);
+}
+
 // y = alpha * (partial[0] + partial[1] + ... in this fixed order) + beta * y
 template <typename T>
 __global__ __launch_bounds__(256) void pb_combine_kernel(int64_t r_lo, int64_t r_hi, int K,
@@ -1998,7 +2257,6 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
   int RW = env_int("SPBLAS_GFX950_PB_RWAVES", PB_RWAVES_DEFAULT);
   if (RW != 4 && RW != 8)
     RW = PB_RWAVES_DEFAULT;
-  pl->rwaves = RW;
   int rlds = env_int("SPBLAS_GFX950_PB_RLDS_KB", PB_LDS_BYTES / 1024) * 1024;
   if (rlds < 16 * 1024 || rlds > 160 * 1024)
     rlds = PB_LDS_BYTES;
@@ -2006,6 +2264,73 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
   int max_rows = rlds / RW / (int) sizeof(T) - 64;
   if (max_rows > 32000)
     max_rows = 32000;
+  // Value-free tiles (pb_reduce_vf_kernel): asked for by plan_create for a plan that has to read the caller's values on
+  // every multiply.  A bin is then a WORKGROUP's (NWv wavefronts with accumulators of their own) and its height follows
+  // from the window of the caller's values that has to fit LDS beside them: H * (entries per row + NWv) elements.  Arithmetic
+  // bins over the rows of y only (no row map, no variable heights), the widest window checked on the device; anything else
+  // falls back to the copying plan (vfree = 0) before a byte is allocated.
+  const bool vf_forced = env_int("SPBLAS_GFX950_PB_VFREE", 1) == 2;  // test hook: also for small / skewed matrices
+  int vfree = pl->vfree && env_int("SPBLAS_GFX950_PB_VFREE", 1) && !compact && split_len == 0 && h->bin_row_align <= 1 &&
+              env_int("SPBLAS_GFX950_SLICE_ROWS", 0) <= 0;
+  int NWv = env_int("SPBLAS_GFX950_PB_VF_WAVES", 4);
+  if (NWv != 4 && NWv != 8)
+    NWv = 4;
+  constexpr int VF_LDS = 160 * 1024 - 64;
+  const int vf_elems = VF_LDS / (int) sizeof(T);
+  int vf_rows = 0, vf_cap = 0;
+  if (vfree) {
+    const double avg = m > 0 ? (double) nnz / (double) m : 0.0;
+    const double skew = (double) pl->max_row_len > 16.0 * avg + 64.0 || pl->empty_rows * 4 > pl->m;
+    int64_t hh = (int64_t) ((double) (vf_elems - NWv * 64 - 16) / (avg * 1.02 + (double) NWv));
+    hh = std::min<int64_t>(hh, vf_elems / (2 * NWv) - 64);  // never more than half of LDS in accumulators
+    hh = std::min<int64_t>(hh, 32000);
+    const int vf_rows_env = env_int("SPBLAS_GFX950_PB_VF_ROWS", 0);  // test hook: small bins
+    if (vf_rows_env > 0)
+      hh = std::min<int64_t>(hh, vf_rows_env);
+    if ((skew && !vf_forced) || hh < (vf_forced ? 1 : 64) || m < 2)
+      vfree = 0;
+    for (int attempt = 0; vfree && attempt < 4; ++attempt) {
+      const int64_t nb = cdiv(m, hh);
+      const int64_t cap = (int64_t) vf_elems - (int64_t) NWv * (hh + 64) - 16;  // 16: the alignment shift of the window
+      unsigned long long* d_span = nullptr;
+      unsigned long long h_span = 0;
+      if ((rc = dev_alloc((void**) &d_span, sizeof(unsigned long long), s)))
+        return rc;
+      hipError_t e = hipMemsetAsync(d_span, 0, sizeof(unsigned long long), s);
+      if (e == hipSuccess) {
+        hipLaunchKernelGGL((pb_bin_span_kernel<O>), dim3((unsigned) cdiv(nb, 256)), dim3(256), 0, s, m, (int) hh, nb, rowptr, d_span);
+        e = hipMemcpyAsync(&h_span, d_span, sizeof(h_span), hipMemcpyDeviceToHost, s);
+      }
+      if (e == hipSuccess)
+        e = hipStreamSynchronize(s);
+      dev_free(d_span, s);
+      if (e != hipSuccess)
+        return hip_fail(e);
+      if ((int64_t) h_span <= cap && h_span < 65536ull) {
+        vf_rows = (int) hh;
+        vf_cap = (int) cap;
+        break;
+      }
+      // a denser stretch of rows than the average: shrink the bins in proportion (with a margin) and look again
+      hh = (int64_t) ((double) hh * (double) std::min<int64_t>(cap, 65535) / (double) h_span * 0.97);
+      if (hh < (vf_forced ? 1 : 64) || attempt == 3)
+        vfree = 0;
+    }
+    if (vf_rows == 0)
+      vfree = 0;
+    // one workgroup per bin and CU: enough bins for a few rounds over the chip
+    if (vfree && !vf_forced && cdiv(m, vf_rows) < 2 * (int64_t) (h->num_cus > 0 ? h->num_cus : 256))
+      vfree = 0;
+    tr.mark("value-free tiles: bin height from the widest window");
+  }
+  pl->vfree = vfree;
+  if (vfree) {
+    RW = 1;  // inspect-side bookkeeping is per bin
+    max_rows = vf_rows;
+    pl->vf_waves = NWv;
+    pl->vf_win_cap = vf_cap;
+  }
+  pl->rwaves = RW;
   int S, W, NB, H;
   const int w_env = env_int("SPBLAS_GFX950_SLICE_COLS", 0);  // test hooks: force small tiles
   const int h_env = env_int("SPBLAS_GFX950_SLICE_ROWS", 0);
@@ -2052,6 +2377,10 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
     H = (int) hh;
     NB = (int) cdiv(m > 0 ? m : 1, H);
   }
+  if (vfree) {  // exactly the grid whose windows were measured
+    H = vf_rows;
+    NB = (int) cdiv(m, H);
+  }
   if (h->bin_row_align > 1) {
     // caller wants bin boundaries on multiples of bin_row_align (stripe boundaries of the overlapped
     // multi-GPU step): use the largest divisor of it that fits the LDS budget, if a decent one exists
@@ -2080,6 +2409,8 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
     varbins = 0;
   if (compact)
     varbins = 1;  // the reduce maps compact rows through binrow[] + nzrow[]
+  if (vfree)
+    varbins = 0;
   const int32_t* binrow = nullptr;
   if (varbins) {
     int64_t E = nnz / std::max(1, env_int("SPBLAS_GFX950_PB_BINS", 2048));
@@ -2242,11 +2573,13 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
   hipLaunchKernelGGL(pb_ecnt_kernel, dim3((unsigned) cdiv(nseg, 256)), dim3(256), 0, s, nseg, cnt, eoff);
   (void) scan_counts_i32(s, nseg, eoff, partials);  // eoff[nseg] = entries of the compact stream
   // the same offsets bin-major, with the padded run lengths: what the value refresh reads (sliced_update_typed)
-  if ((rc = dev_alloc(&pl->s_eoff, (size_t) nseg * sizeof(int2), s)))
-    return rc;
-  pl->device_bytes += (size_t) nseg * sizeof(int2);
-  hipLaunchKernelGGL(pb_run_table_kernel, dim3((unsigned) cdiv(nseg, 256)), dim3(256), 0, s, S, (int64_t) NB, eoff,
-                     static_cast<int2*>(pl->s_eoff));
+  if (!vfree) {
+    if ((rc = dev_alloc(&pl->s_eoff, (size_t) nseg * sizeof(int2), s)))
+      return rc;
+    pl->device_bytes += (size_t) nseg * sizeof(int2);
+    hipLaunchKernelGGL(pb_run_table_kernel, dim3((unsigned) cdiv(nseg, 256)), dim3(256), 0, s, S, (int64_t) NB, eoff,
+                       static_cast<int2*>(pl->s_eoff));
+  }
   hipLaunchKernelGGL(pb_bin_prefix_kernel, dim3((unsigned) NB), dim3(256), 0, s, S, NB, cnt, prel, binblk, pb_geom<T>::BLK);
   (void) scan_counts_i32(s, NB, binblk, partials);  // binblk[NB] = blocks in P order (bins padded to groups)
   hipLaunchKernelGGL(pb_slice_blocks_kernel, dim3((unsigned) cdiv(S + 1, 256)), dim3(256), 0, s, S, NB, aoff, sliceblk);
@@ -2302,11 +2635,13 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
   if (p_pad > INT32_MAX - 1024 || (uint64_t) (p_pad + 1024) * sizeof(T) >= ((uint64_t) 1 << 32) ||
       (auto_mode && p_pad > 2 * nnz + 65536))
     return SPBLAS_GFX950_STATUS_NOT_SUPPORTED;
-  if ((rc = dev_alloc((void**) &pl->s_values, (size_t) (a_pad + 8) * sizeof(T), s)))
+  if (!vfree && (rc = dev_alloc((void**) &pl->s_values, (size_t) (a_pad + 8) * sizeof(T), s)))
     return rc;
   if ((rc = dev_alloc((void**) &pl->s_colind, (size_t) (a_pad + 8) * 2, s)))
     return rc;
-  if ((rc = dev_alloc((void**) &pl->s_perm, (size_t) (a_pad + 8) * 4, s)))
+  if (!vfree && (rc = dev_alloc((void**) &pl->s_perm, (size_t) (a_pad + 8) * 4, s)))
+    return rc;
+  if (vfree && (rc = dev_alloc((void**) &pl->s_src, (size_t) (p_pad + PB_GRP) * 2, s)))
     return rc;
   if ((rc = dev_alloc((void**) &pl->s_blkdst, (size_t) (a_blocks + 8) * 4, s)) ||
       (rc = dev_alloc((void**) &pl->s_blksrc, (size_t) (a_blocks + 8) * 4, s)))
@@ -2321,6 +2656,8 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
   // K-split plans) the longer decode chain per group is no longer hidden -- cfg2 shards on one box, one-byte codes vs
   // 16-bit rows: 5 M rows (2 034 bins) 156.9 vs 162.8 us, 2.5 M (1 017 bins) 103.3 vs 93.1, 1.25 M 63.2 vs 58.3.
   (void) max_run;
+  if (vfree && !staged)
+    return SPBLAS_GFX950_STATUS_NOT_SUPPORTED;  // (more than 2 048 slices: n > 80 M columns)
   if (!staged || placed_total == 0 || S > PB_STAGE_SP ||
       (enc8 == 1 && ((double) H * (double) ne > 32.0 * (double) placed_total || NB < 1536 ||
                      placed_total < (unsigned long long) 32 << 20)))  // below ~32 M entries the SpMV gains nothing (n = 1-3 M
@@ -2340,7 +2677,8 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
   if ((rc = dev_alloc((void**) &pl->s_products, (size_t) (p_pad + PB_GRP) * sizeof(T), s)))
     return rc;
   pl->s_products_bytes = (size_t) (p_pad + PB_GRP) * sizeof(T);
-  pl->device_bytes += (size_t) a_pad * (sizeof(T) + 6) + (size_t) a_blocks * 8 + (size_t) p_pad * sizeof(T) +
+  pl->device_bytes += (size_t) a_pad * (vfree ? 2 : sizeof(T) + 6) + (vfree ? (size_t) p_pad * 2 : 0) + (size_t) a_blocks * 8 +
+                      (size_t) p_pad * sizeof(T) +
                       (enc8 ? (size_t) p_pad + hdr_bytes + (size_t) NB * PB_EXC_CAP * 6 : (size_t) p_pad * 2) +
                       (size_t) (NB + S + 2) * 4 + (size_t) nseg * 4;
   // pads: value 0, column 0, no source position, row = H (a dummy accumulator); products start finite
@@ -2348,9 +2686,13 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
   // behind the stream is cleared (1 GB of memsets at cfg2: 0.15 of the 3.3 ms of a warm inspect).  The direct scatter
   // (more slices than the staged one takes) and SPBLAS_GFX950_PB_CLEAR=1 clear everything.
   const int64_t a_keep = (staged && !env_int("SPBLAS_GFX950_PB_CLEAR", 0)) ? (int64_t) h_epad & ~(int64_t) 63 : 0;
-  SPB_HIP(hipMemsetAsync(static_cast<T*>(pl->s_values) + a_keep, 0, (size_t) (a_pad + 8 - a_keep) * sizeof(T), s));
+  if (!vfree)
+    SPB_HIP(hipMemsetAsync(static_cast<T*>(pl->s_values) + a_keep, 0, (size_t) (a_pad + 8 - a_keep) * sizeof(T), s));
   SPB_HIP(hipMemsetAsync(static_cast<uint16_t*>(pl->s_colind) + a_keep, 0, (size_t) (a_pad + 8 - a_keep) * 2, s));
-  SPB_HIP(hipMemsetAsync(static_cast<int32_t*>(pl->s_perm) + a_keep, 0xFF, (size_t) (a_pad + 8 - a_keep) * 4, s));
+  if (!vfree)
+    SPB_HIP(hipMemsetAsync(static_cast<int32_t*>(pl->s_perm) + a_keep, 0xFF, (size_t) (a_pad + 8 - a_keep) * 4, s));
+  if (vfree)  // pads point at the first entry of the window (their row code keeps them out of the sums)
+    SPB_HIP(hipMemsetAsync(pl->s_src, 0, (size_t) (p_pad + PB_GRP) * 2, s));
   SPB_HIP(hipMemsetAsync(pl->s_blkdst, 0, (size_t) (a_blocks + 8) * 4, s));
   SPB_HIP(hipMemsetAsync(pl->s_blksrc, 0, (size_t) (a_blocks + 8) * 4, s));
   if (enc8) {  // pads: code 255 (left out of the main pass); headers and exception counts start at 0
@@ -2420,7 +2762,7 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
     // heaviest group 0.87 of a slot's share): a work list ordered heaviest first, so that a heavy group never starts late
     const int cus_r = h->num_cus > 0 ? h->num_cus : 256;
     const bool lpt = env_int("SPBLAS_GFX950_PB_LPT", 1) && varbins && ngroups > 2 * (int64_t) cus_r && max_tot * ngroups > (3 * total) / 2;
-    if (total > 0 && (max_tot * ngroups > 3 * total || force_items > 0 || lpt) && ngroups > 1) {
+    if (!vfree && total > 0 && (max_tot * ngroups > 3 * total || force_items > 0 || lpt) && ngroups > 1) {
       const int64_t target = std::max<int64_t>(total / (768 * (force_items > 0 ? force_items : 1)), 16384);
       const int64_t block = (int64_t) RW * H;  // values per partial block
       std::vector<int4> items, split;
@@ -2521,8 +2863,9 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
     const int32_t *cnt_ = cnt, *aoff_ = aoff, *prel_ = prel, *binblk_ = binblk, *eoff_ = eoff;
     int32_t* bs = static_cast<int32_t*>(pl->s_blksrc);
     const int32_t* bo = bin_order_dev;
+    uint16_t* ssrc = pl->s_src;
     void* args[] = {&mm, &rowptr, &ci, &vp, &W_, &H_, &S_, &NB_, &cnt_, &aoff_, &prel_, &binblk_, &sv, &sc, &sr, &pm, &bd,
-                    &hub, &cap_, &rt_, &binrow, &code, &hdr, &ei, &er, &ec, &ecap, &fail, &eoff_, &bs, &bo};
+                    &hub, &cap_, &rt_, &binrow, &code, &hdr, &ei, &er, &ec, &ecap, &fail, &eoff_, &bs, &bo, &ssrc};
     return hipLaunchKernel(fn, dim3((unsigned) NB), dim3(PB_STAGE_THREADS), args, (size_t) PB_STAGE_LDS - 64, s);
   };
   if (staged) {
@@ -2594,6 +2937,16 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
                               hipFuncAttributeMaxDynamicSharedMemorySize, xlds > PB_LDS_BYTES ? xlds : PB_LDS_BYTES));
   SPB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pb_expand_kernel<T, true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, xlds > PB_LDS_BYTES ? xlds : PB_LDS_BYTES));
+  if (vfree) {
+    SPB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pb_expand_kernel<T, false, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, xlds > PB_LDS_BYTES ? xlds : PB_LDS_BYTES));
+    SPB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pb_expand_kernel<T, true, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, xlds > PB_LDS_BYTES ? xlds : PB_LDS_BYTES));
+    for (int ub : {2, 4})
+      SPB_HIP(hipFuncSetAttribute(pb_reduce_vf_fn<T>(pl->vf_waves, ub, pl->enc8 != 0), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  VF_LDS));
+    return SPBLAS_GFX950_STATUS_SUCCESS;
+  }
   for (int ub : {1, 2, 4, 8})
     SPB_HIP(hipFuncSetAttribute(pb_reduce_fn<T>(pl->rwaves, ub, pl->enc8 != 0), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024));
@@ -2634,7 +2987,7 @@ template <typename T>
 static int sliced_update_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const void* values) {
   pl->values_ptr = values;  // the hub rows read the caller's array directly
   const int64_t a_pad = pl->a_entries;
-  if (pl->s_placed == 0 || a_pad == 0)
+  if (pl->s_placed == 0 || a_pad == 0 || pl->vfree)  // (value-free tiles: the reduce reads the caller's array itself)
     return SPBLAS_GFX950_STATUS_SUCCESS;
   // bin by bin through LDS when the plan kept its run offsets (SPBLAS_GFX950_PB_UPDATE_BINS=0: the gather in A' order)
   if (pl->s_eoff && pl->n_rblk > 0 && pl->n_slices > 0 && env_int("SPBLAS_GFX950_PB_UPDATE_BINS", 1)) {
@@ -2741,7 +3094,20 @@ static int sliced_expand_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* p
   // (a waiting expand starts every rank on the work that reads its OWN rows of x -- nothing to wait for -- and goes round
   // the ranks from there: the slices follow the rows of x, and so do the items and the shares of A')
   const int rot = (int) ((int64_t) rot_ranks * (items ? pl->n_xitems : (int64_t) grid.x) / rot_of);
-  if (pl->nt_products)
+  if (pl->vfree) {
+    if (pl->nt_products)
+      hipLaunchKernelGGL((pb_expand_kernel<T, true, true>), grid, dim3(PB_THREADS), xbytes, h->stream, pl->n, pl->slice_cols,
+                         static_cast<const int32_t*>(pl->s_sliceblk), static_cast<const T*>(nullptr),
+                         reinterpret_cast<const uint16_t*>(pl->s_colind), static_cast<const int32_t*>(pl->s_blkdst),
+                         static_cast<const T*>(x), static_cast<T*>(pl->s_products), items, (int) pl->n_slices, share,
+                         static_cast<const int32_t*>(pl->s_blksrc), (int) pl->n_xitems, rot, cw);
+    else
+      hipLaunchKernelGGL((pb_expand_kernel<T, false, true>), grid, dim3(PB_THREADS), xbytes, h->stream, pl->n, pl->slice_cols,
+                         static_cast<const int32_t*>(pl->s_sliceblk), static_cast<const T*>(nullptr),
+                         reinterpret_cast<const uint16_t*>(pl->s_colind), static_cast<const int32_t*>(pl->s_blkdst),
+                         static_cast<const T*>(x), static_cast<T*>(pl->s_products), items, (int) pl->n_slices, share,
+                         static_cast<const int32_t*>(pl->s_blksrc), (int) pl->n_xitems, rot, cw);
+  } else if (pl->nt_products)
     hipLaunchKernelGGL((pb_expand_kernel<T, true>), grid, dim3(PB_THREADS), xbytes, h->stream, pl->n, pl->slice_cols,
                        static_cast<const int32_t*>(pl->s_sliceblk), static_cast<const T*>(pl->s_values),
                        reinterpret_cast<const uint16_t*>(pl->s_colind), static_cast<const int32_t*>(pl->s_blkdst),
@@ -2818,6 +3184,13 @@ static int sliced_reduce_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* p
   int K = pick_ksplit(wb_end - wb_begin, pl->n_rblk > 0 ? pl->p_blocks / pb_geom<T>::GBLK / pl->n_rblk : 0);
   if (h->max_ksplit > 0 && K > h->max_ksplit)
     K = (int) h->max_ksplit;  // striped callers run several reduces side by side
+  if (pl->vfree) {
+    if (peers_p)
+      return SPBLAS_GFX950_STATUS_NOT_SUPPORTED;  // value-free tiles: single-device multiplies only
+    if (!pl->values_ptr)
+      return SPBLAS_GFX950_STATUS_INVALID_VALUE;
+    K = 1;
+  }
   // [r_lo, r_hi): the rows of these bins in the index space the tiles were built over (compact rows when the empty
   // rows were taken out); [o_lo, o_hi): the same range in rows of y (hub rows and empty rows are listed by those)
   int64_t r_lo = wb_begin * pl->rows_per_blk;
@@ -2858,7 +3231,33 @@ static int sliced_reduce_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* p
       return rc;
     pl->s_partial_k = K;
   }
-  {
+  if (pl->vfree) {
+    // one workgroup per bin: the bin's window of the caller's values in LDS, vf_waves wavefronts on the bin's stream
+    const int32_t* binblk = static_cast<const int32_t*>(pl->s_binblk);
+    const T* Pp = static_cast<const T*>(pl->s_products);
+    const uint16_t* rowp = pl->enc8 ? reinterpret_cast<const uint16_t*>(pl->s_code) : pl->s_lrow;
+    const uint16_t* srcp = pl->s_src;
+    const T* vals = static_cast<const T*>(pl->values_ptr);
+    const void* rp = pl->rowptr;
+    int o64 = pl->offset_type == SPBLAS_GFX950_I32 ? 0 : 1;
+    typedef typename pb_hdr<T>::type hdr_t;
+    const hdr_t* hdr = static_cast<const hdr_t*>(pl->s_hdr);
+    const unsigned* exc_idx = pl->s_exc_idx;
+    const uint16_t* exc_row = pl->s_exc_row;
+    const int32_t* exc_cnt = pl->s_exc_cnt;
+    int exc_cap = pl->exc_cap, Hw = pl->rows_per_blk, cap = pl->vf_win_cap;
+    int64_t mm = pl->m;
+    T* yp = static_cast<T*>(y);
+    T a = alpha, b = beta;
+    int UBv = env_int("SPBLAS_GFX950_PB_RBATCH", pl->enc8 ? 2 : 4);
+    if (UBv != 2)
+      UBv = 4;
+    void* args[] = {&mm, &Hw, &wb_begin, &wb_end, &binblk, &Pp, &rowp, &srcp, &vals, &rp, &o64, &yp, &a, &b, &cap, &hdr,
+                    &exc_idx, &exc_row, &exc_cnt, &exc_cap};
+    const size_t lds = ((size_t) cap + (size_t) pl->vf_waves * (Hw + 64)) * sizeof(T);
+    SPB_HIP(hipLaunchKernel(pb_reduce_vf_fn<T>(pl->vf_waves, UBv, pl->enc8 != 0), dim3((unsigned) (wb_end - wb_begin)),
+                            dim3(pl->vf_waves * 64), args, lds, s));
+  } else {
     const int32_t* binblk = static_cast<const int32_t*>(pl->s_binblk);
     const T* Pp = static_cast<const T*>(pl->s_products);
     const uint16_t* rowp = pl->enc8 ? reinterpret_cast<const uint16_t*>(pl->s_code) : pl->s_lrow;
@@ -3065,6 +3464,9 @@ void spmv_sliced_free(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl) {
   pl->s_exc_cnt = nullptr;
   pl->enc8 = 0;
   dev_free(pl->s_perm, s);
+  dev_free(pl->s_src, s);
+  pl->s_src = nullptr;
+  pl->vfree = 0;
   dev_free(pl->s_products, s);
   dev_free(pl->s_partial, s);
   dev_free(pl->s_hub_part, s);

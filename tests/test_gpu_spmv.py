@@ -950,6 +950,7 @@ def test_spmv_plain_inspected_csr_view_follows_values_written_in_place(gpu, dtyp
     assert pi["alg"] in (_capi.SPMV_ROWBLOCK, _capi.SPMV_SLICED)
     if pi["alg"] == _capi.SPMV_SLICED:
         assert info.state_.sliced_info()["refresh_each_call"] == 1 and info.state_.sliced_info()["auto_trial"] == 1
+        assert info.state_.sliced_info()["value_free"] == 1  # round 5: no copy of the values in the plan
     rows = np.unique(np.concatenate([np.arange(0, 800), np.arange(m - 800, m), rng.integers(0, m, 1500)]))
     rp_h = rowptr.cpu().numpy()
     idx = np.concatenate([np.arange(rp_h[r], rp_h[r + 1]) for r in rows])
@@ -985,3 +986,97 @@ def test_spmv_plain_inspected_csr_view_follows_values_written_in_place(gpu, dtyp
     absrow = oracle.spmv_absrow(sub_rp, sub_ci, sub_v, xh)
     util.assert_parity(y[torch.from_numpy(rows).cuda()].cpu().numpy(), y_ref, absrow, dtype, row_len=np.diff(sub_rp),
                        what="plain inspected csr_view, graph replay after an in-place change")
+
+
+@pytest.mark.parametrize("offsets", [np.int32, np.int64])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("waves,enc", [("4", "0"), ("4", "2"), ("8", "2"), ("8", "0")])
+def test_spmv_value_free_tiles(gpu, monkeypatch, dtype, offsets, waves, enc):
+    """Round 5: the tiled plan of a plain inspected csr_view holds NO copy of A's values.  The expand writes the gathered
+    x[col]; the reduce of a bin stages the bin's window of the caller's values (rowptr[r0] .. rowptr[r1]) in LDS and
+    multiplies through a 16-bit in-window position per entry (pb_reduce_vf_kernel: one bin per workgroup, accumulators per
+    wavefront, partial rows added in wave order).  Small tiles through the test hooks (SPBLAS_GFX950_PB_VFREE=2 builds the
+    value-free form on explicit request, PB_VF_ROWS caps the bin height), ragged rows so that windows start at every
+    alignment, a value array that is itself only 4-byte aligned, both row encodings, values rewritten in place between
+    multiplies (multiply_impl.hpp:48-52: the values of THAT call), alpha / beta."""
+    monkeypatch.setenv("SPBLAS_GFX950_PB_VFREE", "2")
+    monkeypatch.setenv("SPBLAS_GFX950_SLICE_COLS", "128")
+    monkeypatch.setenv("SPBLAS_GFX950_PB_VF_ROWS", "300")
+    monkeypatch.setenv("SPBLAS_GFX950_PB_VF_WAVES", waves)
+    monkeypatch.setenv("SPBLAS_GFX950_PB_ENC8", enc)
+    rng = np.random.default_rng(41)
+    m, n = 7001, 2500
+    lens = rng.integers(0, 30, m)
+    lens[rng.random(m) < 0.1] = 0
+    lens[1234] = 240                                   # a row that repeats inside runs (duplicate flags)
+    rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(offsets)
+    nnz = int(rowptr[-1])
+    colind = rng.integers(0, n, nnz).astype(np.int32)
+    values = (rng.random(nnz) - 0.5).astype(dtype)
+    x = (rng.random(n) - 0.5).astype(dtype)
+    tdt = torch.float32 if dtype == np.float32 else torch.float64
+    for misaligned in (False, True):
+        backing = torch.zeros(nnz + 4, dtype=tdt, device="cuda")
+        vt = backing[1:nnz + 1] if misaligned else backing[:nnz]
+        vt.copy_(torch.from_numpy(values))
+        assert (vt.data_ptr() % 16 != 0) == misaligned
+        a = sp.csr_view(vt, G.dev(rowptr), G.dev(colind), (m, n), nnz)
+        xd = G.dev(x)
+        y = torch.full((m,), float("nan"), dtype=tdt, device="cuda")
+        info = sp.multiply_inspect(a, xd, y, alg=_capi.SPMV_SLICED)
+        si = info.state_.sliced_info()
+        assert info.state_.info()["alg"] == _capi.SPMV_SLICED and si["value_free"] == 1 and si["refresh_each_call"] == 1, si
+        assert si["row_code_u8"] == (1 if enc == "2" else 0)
+        rp32 = rowptr.astype(np.int32)
+        sp.multiply(info, a, xd, y)
+        check(values, rp32, colind, (m, n), x, G.host(y), what=f"value-free tiles misaligned={misaligned}", ref_cmp=False)
+        # values rewritten in place through a raw view: the next multiply reads them
+        raw = torch.as_strided(vt, vt.shape, vt.stride())
+        raw.data.mul_(-1.25).add_(0.0625)
+        v2 = (values * dtype(-1.25) + dtype(0.0625)).astype(dtype)
+        y.fill_(float("nan"))
+        sp.multiply(info, sp.scaled(2.0, a), xd, y)
+        check(v2, rp32, colind, (m, n), x, G.host(y), scale=2.0, what="value-free tiles, values rewritten in place", ref_cmp=False)
+        # alpha / beta through the C ABI
+        y0 = (rng.random(m) - 0.5).astype(dtype)
+        y.copy_(torch.from_numpy(y0))
+        ct = ctypes.c_float if dtype == np.float32 else ctypes.c_double
+        al, be = ct(-1.5), ct(0.25)
+        hd = sp.api._Handle.current(xd.device)
+        sp.api.check(_capi.lib().spblas_gfx950_spmv(hd.h, info.state_.plan, _capi.OP_N, m, n, nnz, ctypes.byref(al),
+                                                    sp.api._ptr(a.rowptr()), sp.api._ptr(a.colind()), sp.api._ptr(a.values()),
+                                                    sp.api._ptr(xd), ctypes.byref(be), sp.api._ptr(y),
+                                                    _capi.I32 if offsets == np.int32 else _capi.I64,
+                                                    _capi.F32 if dtype == np.float32 else _capi.F64), "spmv")
+        _, absrow = util.spmv_exact(rp32, colind, v2, x)
+        y_ref = -1.5 * oracle.spmv((m, n), rp32, colind, v2, x).astype(np.float64) + 0.25 * y0
+        util.assert_parity(G.host(y), y_ref, 1.5 * absrow + 0.25 * np.abs(y0), dtype, row_len=np.diff(rp32) + 1,
+                           what="value-free tiles alpha / beta")
+        # the multi-GPU entry points are not given A's values: a plan that must read them on every call refuses
+        peers = (ctypes.c_void_p * 1)(y.data_ptr())
+        rc = _capi.lib().spblas_gfx950_spmv_step_bcast(hd.h, info.state_.plan, ctypes.byref(al), sp.api._ptr(xd), peers, 1, 0, 1)
+        assert rc == _capi.NOT_SUPPORTED
+
+
+def test_spmv_value_free_tiles_fall_back_when_the_matrix_does_not_fit(gpu, monkeypatch):
+    """A matrix the value-free form does not take (a row far longer than the rest is cut into pieces: a row map) still
+    gets the copying plan on explicit request, and the answer."""
+    monkeypatch.setenv("SPBLAS_GFX950_PB_VFREE", "2")
+    monkeypatch.setenv("SPBLAS_GFX950_SLICE_COLS", "128")
+    rng = np.random.default_rng(43)
+    m, n = 3000, 2500
+    lens = rng.integers(1, 12, m)
+    lens[77] = 6000
+    rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    nnz = int(rowptr[-1])
+    colind = rng.integers(0, n, nnz).astype(np.int32)
+    values = (rng.random(nnz) - 0.5).astype(np.float32)
+    x = (rng.random(n) - 0.5).astype(np.float32)
+    a = G.csr_on_device(values, rowptr, colind, (m, n), nnz)
+    xd = G.dev(x)
+    y = torch.full((m,), float("nan"), device="cuda")
+    info = sp.multiply_inspect(a, xd, y, alg=_capi.SPMV_SLICED)
+    si = info.state_.sliced_info()
+    assert si["value_free"] == 0 and si["refresh_each_call"] == 0, si
+    sp.multiply(info, a, xd, y)
+    check(values, rowptr, colind, (m, n), x, G.host(y), what="fallback from value-free tiles", ref_cmp=False)
