@@ -1689,6 +1689,17 @@ __global__ __launch_bounds__(RW * 64) void pb_reduce_kernel(int64_t m, int Hw, i
 // NW partial rows are added in wave order at the end -- the order of additions is fixed by the plan.
 //   rowptr: the caller's row offsets (o64: 64-bit); values: the caller's array of THIS call; win_cap: entries the window area
 //   holds (the build checked every bin's span + the alignment shift against it)
+#ifndef PB_VF_GLDS_AUX
+#define PB_VF_GLDS_AUX 2  // non-temporal: every window is read by one CU, once per multiply
+#endif
+// PERSISTENT: the workgroup walks the bins wb_begin + blockIdx.x, + gridDim.x, ... (one workgroup per CU: a bin's window +
+// accumulators fill LDS).  A wavefront's part of one bin's stream is short (~13 groups of 256 entries at cfg2), so the loads
+// run across the bin boundary: the wave's stream is a flat sequence of BATCHES (UB groups, never straddling a bin), two in
+// flight in two register sets, and the batch issued while the last one of bin b is applied already belongs to bin b + 1.
+// Between two bins:  barrier A (every wave is done with bin b: window free, accumulators complete) -> y of bin b out of the
+// accumulators, which are zeroed by the threads that read them -> window of bin b + 1 by LDS-DMA -> barrier B.  A
+// non-persistent form (one bin per workgroup, loads starting behind the staging) took 259 us at cfg2, this one ... see
+// DESIGN I.3.
 template <typename T, int NW, int UB, bool ENC8>
 __global__ __launch_bounds__(NW * 64) void pb_reduce_vf_kernel(int64_t m, int Hw, int64_t wb_begin, int64_t wb_end,
                                                                const int32_t* __restrict__ binblk, const T* __restrict__ P,
@@ -1703,19 +1714,15 @@ __global__ __launch_bounds__(NW * 64) void pb_reduce_vf_kernel(int64_t m, int Hw
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   T* win = reinterpret_cast<T*>(smem);                      // [win_cap] the bin's window of the caller's values
-  T* acc = win + win_cap + (size_t) wave * (Hw + 64);       // this wave's Hw accumulators + 64 dummy slots
-  const int64_t wb = wb_begin + blockIdx.x;
+  T* const acc0 = win + win_cap;                            // NW x (Hw accumulators + 64 dummy slots)
+  T* const acc = acc0 + (size_t) wave * (Hw + 64);          // this wave's
+  const int64_t stride = gridDim.x;
+  int64_t wb = wb_begin + blockIdx.x;                       // the bin being reduced
   if (wb >= wb_end)
     return;
-  const int64_t r0 = wb * Hw, r1 = (r0 + Hw) < m ? (r0 + Hw) : m;
-  const int rh = (int) (r1 - r0);
-  const int64_t p0 = o64 ? (int64_t) static_cast<const int64_t*>(rowptr)[r0] : (int64_t) static_cast<const int32_t*>(rowptr)[r0];
-  const int64_t p1 = o64 ? (int64_t) static_cast<const int64_t*>(rowptr)[r1] : (int64_t) static_cast<const int32_t*>(rowptr)[r1];
   constexpr int PB_GBLK = pb_geom<T>::GBLK;
   constexpr int LPB = pb_geom<T>::BLK / 4;  // lanes per block
-  const int gb0 = binblk[wb] / PB_GBLK, ng = binblk[wb + 1] / PB_GBLK - gb0;
-  const int g_lo = gb0 + (int) ((int64_t) ng * wave / NW);
-  const int g_hi = gb0 + (int) ((int64_t) ng * (wave + 1) / NW);
+  constexpr int VE = 16 / (int) sizeof(T);
   typedef typename pb_hdr<T>::type hdr_t;
   struct batch_t {
     T p[UB][4];       // gathered x values
@@ -1725,10 +1732,22 @@ __global__ __launch_bounds__(NW * 64) void pb_reduce_vf_kernel(int64_t m, int Hw
     hdr_t hd[UB];     // enc8: the header of the lane's block
   };
   T* const dummy = acc + Hw + lane;
-  auto issue = [&](int g, batch_t& q) {
+  auto row_off = [&](int64_t r) -> int64_t {
+    return o64 ? (int64_t) static_cast<const int64_t*>(rowptr)[r] : (int64_t) static_cast<const int32_t*>(rowptr)[r];
+  };
+  // this wave's part [lo, hi) of bin b's groups
+  auto wave_range = [&](int64_t b, int& lo, int& hi) {
+    const int gb0 = binblk[b] / PB_GBLK, ng = binblk[b + 1] / PB_GBLK - gb0;
+    lo = gb0 + (int) ((int64_t) ng * wave / NW);
+    hi = gb0 + (int) ((int64_t) ng * (wave + 1) / NW);
+  };
+  // loads of the groups g .. g + UB - 1, clamped to `last` (loads past the end of a part re-read its last group -- same lines,
+  // no extra traffic -- because a load inside a branch makes the compiler's wait counts pessimistic; a part without groups
+  // reads the group at its start: inside the arrays, which carry one group of slack -- and is never applied)
+  auto issue = [&](int g, int last, batch_t& q) {
 #pragma unroll
     for (int u = 0; u < UB; ++u) {
-      const int gg = (g + u) < g_hi ? (g + u) : (g_hi - 1);
+      const int gg = (g + u) < last ? (g + u) : last;
       const unsigned offR = ((unsigned) gg * PB_GRP + 4u * (unsigned) lane) * 2u;
       const unsigned offP = offR * (unsigned) (sizeof(T) / 2);
       pack4<T>::load(reinterpret_cast<const T*>(reinterpret_cast<const char*>(P) + offP), q.p[u]);
@@ -1741,46 +1760,38 @@ __global__ __launch_bounds__(NW * 64) void pb_reduce_vf_kernel(int64_t m, int Hw
       }
     }
   };
-  // the first batch of the stream is on its way while the window is staged
-  batch_t qa, qb;
-  if (g_hi > g_lo)
-    issue(g_lo, qa);
-  for (int i = lane; i < rh; i += 64)
-    acc[i] = T(0);
-  // the window: 16-byte loads from the aligned position at or before p0 (the array itself must be 16-byte aligned for that)
-  constexpr int VE = 16 / (int) sizeof(T);
-  const bool vec_ok = (reinterpret_cast<uintptr_t>(values) & 15) == 0;
-  const int64_t p_lo = vec_ok ? (p0 & ~(int64_t) (VE - 1)) : p0;
-  const int shift = (int) (p0 - p_lo), wn = (int) (p1 - p_lo);
-  if (vec_ok) {
-    typedef T vec_t __attribute__((ext_vector_type(VE)));
-    const int nv = wn / VE;
-    const vec_t* src = reinterpret_cast<const vec_t*>(values + p_lo);
-    constexpr int SU = 4;  // loads in flight per lane
-    for (int i0 = tid; i0 < nv; i0 += SU * NW * 64) {
-      vec_t t[SU];
-#pragma unroll
-      for (int u = 0; u < SU; ++u) {
-        const int i = i0 + u * NW * 64;
-        t[u] = stream_load(src + (i < nv ? i : nv - 1));
-      }
-#pragma unroll
-      for (int u = 0; u < SU; ++u) {
-        const int i = i0 + u * NW * 64;
+  // ---- the window of bin b: 16-byte pieces straight into LDS (global_load_lds_dwordx4: one wave-instruction moves 1 KiB to a
+  // wave-uniform LDS base + 16 B per lane, no registers, no ds_write pass), the whole window in flight at once
+  int shift = 0;  // position of the bin's first entry inside the staged window
+  auto stage_window = [&](int64_t b) {
+    const int64_t r0 = b * Hw, r1 = (r0 + Hw) < m ? (r0 + Hw) : m;
+    const int64_t p0 = row_off(r0), p1 = row_off(r1);
+    const bool vec_ok = (reinterpret_cast<uintptr_t>(values) & 15) == 0;
+    const int64_t p_lo = vec_ok ? (p0 & ~(int64_t) (VE - 1)) : p0;
+    shift = (int) (p0 - p_lo);
+    const int wn = (int) (p1 - p_lo);
+    if (vec_ok) {
+      typedef T vec_t __attribute__((ext_vector_type(VE)));
+      const int nv = wn / VE;
+      const vec_t* src = reinterpret_cast<const vec_t*>(values + p_lo);
+      const int nchunk = (nv + 63) >> 6;
+      for (int c = wave; c < nchunk; c += NW) {
+        const int i = c * 64 + lane;
         if (i < nv)
-          reinterpret_cast<vec_t*>(win)[i] = t[u];
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*) (src + i),
+                                           (__attribute__((address_space(3))) void*) (reinterpret_cast<vec_t*>(win) + c * 64),
+                                           16, 0, PB_VF_GLDS_AUX);
       }
+      for (int i = nv * VE + tid; i < wn; i += NW * 64)
+        win[i] = stream_load(values + p_lo + i);
+    } else {
+      for (int i = tid; i < wn; i += NW * 64)
+        win[i] = stream_load(values + p_lo + i);
     }
-    for (int i = nv * VE + tid; i < wn; i += NW * 64)
-      win[i] = stream_load(values + p_lo + i);
-  } else {
-    for (int i = tid; i < wn; i += NW * 64)
-      win[i] = stream_load(values + p_lo + i);
-  }
-  // LDS traffic complete in every wave, then the barrier (not __syncthreads(): no reason to drain the stream loads)
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-  const T* wv = win + shift;
-  auto consume = [&](int g, const batch_t& q) {
+  };
+  // ---- one batch into the wave's accumulators
+  auto consume = [&](int g, int g_hi, const batch_t& q) {
+    const T* wv = win + shift;
 #pragma unroll
     for (int u = 0; u < UB; ++u) {
       if (g + u >= g_hi)
@@ -1827,42 +1838,85 @@ __global__ __launch_bounds__(NW * 64) void pb_reduce_vf_kernel(int64_t m, int Hw
       }
     }
   };
-  if (g_hi > g_lo) {
-    for (int g = g_lo; g < g_hi; g += 2 * UB) {
-      issue(g + UB, qb);
-      consume(g, qa);
-      issue(g + 2 * UB, qa);
-      consume(g + UB, qb);
+  // ---- between two bins
+  auto end_of_bin = [&]() {
+    if (ENC8 && wave == 0) {
+      // exceptions of this bin (entries the one-byte codes could not reach): added once, by the first wave
+      const T* wv = win + shift;
+      const int ne = exc_cnt[wb];
+      for (int i = lane; i < ne; i += 64) {
+        const unsigned e = exc_idx[(size_t) wb * exc_cap + i];
+        unsafeAtomicAdd(acc + exc_row[(size_t) wb * exc_cap + i], P[e] * wv[s_src[e]]);
+      }
     }
-  }
-  if (ENC8 && wave == 0) {
-    // exceptions of this bin (entries the one-byte codes could not reach): added once, by the first wave
-    const int ne = exc_cnt[wb];
-    for (int i = lane; i < ne; i += 64) {
-      const unsigned e = exc_idx[(size_t) wb * exc_cap + i];
-      unsafeAtomicAdd(acc + exc_row[(size_t) wb * exc_cap + i], P[e] * wv[s_src[e]]);
-    }
-  }
-  __syncthreads();
-  // y = alpha * (the waves' partial rows, in wave order) + beta * y
-  const T* a0 = win + win_cap;
-  for (int i0 = tid; i0 < rh; i0 += NW * 64 * 4) {
-    T sum[4];
+    // A: every wave is done with the bin (its LDS traffic complete; the loads already issued for the next bin stay in flight)
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_s_barrier();
+    // y = alpha * (the waves' partial rows, in wave order) + beta * y; the accumulators are left zeroed
+    const int64_t r0 = wb * Hw;
+    const int rh = (int) (((r0 + Hw) < m ? (r0 + Hw) : m) - r0);
+    for (int i0 = tid; i0 < rh; i0 += NW * 64 * 4) {
+      T sum[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int i = (i0 + u * NW * 64) < rh ? (i0 + u * NW * 64) : 0;
-      T t = a0[i];
+      for (int u = 0; u < 4; ++u) {
+        const int i = (i0 + u * NW * 64) < rh ? (i0 + u * NW * 64) : 0;
+        T t = acc0[i];
 #pragma unroll
-      for (int w = 1; w < NW; ++w)
-        t += a0[(size_t) w * (Hw + 64) + i];
-      sum[u] = alpha * t;
-    }
+        for (int w = 1; w < NW; ++w)
+          t += acc0[(size_t) w * (Hw + 64) + i];
+        sum[u] = alpha * t;
+      }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int i = i0 + u * NW * 64;
-      if (i < rh)
-        y[r0 + i] = beta == T(0) ? sum[u] : sum[u] + beta * y[r0 + i];
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * NW * 64;
+        if (i < rh) {
+          y[r0 + i] = beta == T(0) ? sum[u] : sum[u] + beta * y[r0 + i];
+#pragma unroll
+          for (int w = 0; w < NW; ++w)
+            acc0[(size_t) w * (Hw + 64) + i] = T(0);
+        }
+      }
     }
+    wb += stride;
+    if (wb < wb_end) {
+      stage_window(wb);
+      // B: the window has landed, the accumulators are zeroed.  (The builtin, not inline asm: the compiler's wait-count pass
+      // has to SEE that the LDS-DMA loads are done -- otherwise it drains vmcnt(0) before every LDS read of the main loop,
+      // i.e. right after the next batch's loads were issued.)
+      __builtin_amdgcn_s_waitcnt(0);
+      __builtin_amdgcn_s_barrier();
+    }
+  };
+  batch_t qa, qb;
+  int g_lo, g_hi;
+  wave_range(wb, g_lo, g_hi);
+  issue(g_lo, g_hi > g_lo ? g_hi - 1 : g_lo, qa);
+  for (int i = tid; i < NW * (Hw + 64); i += NW * 64)
+    acc0[i] = T(0);
+  stage_window(wb);
+  __builtin_amdgcn_s_waitcnt(0);
+  __builtin_amdgcn_s_barrier();
+  for (;;) {
+    // the wave's part of the NEXT bin: its first batch is loaded while the last batches of this bin are applied
+    const int64_t nb = wb + stride;
+    int n_lo = g_hi > g_lo ? g_hi - 1 : g_lo, n_hi = n_lo;  // (no next bin: a part without groups on the last group read)
+    if (nb < wb_end)
+      wave_range(nb, n_lo, n_hi);
+    const int last = g_hi > g_lo ? g_hi - 1 : g_lo, n_last = n_hi > n_lo ? n_hi - 1 : n_lo;
+    int g = g_lo;
+    do {  // (at least once: a wave without groups in this bin still has the next bin's first batch to load)
+      issue(g + UB, last, qb);
+      consume(g, g_hi, qa);
+      const bool more = g + 2 * UB < g_hi;
+      issue(more ? g + 2 * UB : n_lo, more ? last : n_last, qa);
+      consume(g + UB, g_hi, qb);
+      g += 2 * UB;
+    } while (g < g_hi);
+    end_of_bin();
+    if (wb >= wb_end)
+      break;
+    g_lo = n_lo;
+    g_hi = n_hi;
   }
 }
 
@@ -3255,7 +3309,11 @@ static int sliced_reduce_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* p
     void* args[] = {&mm, &Hw, &wb_begin, &wb_end, &binblk, &Pp, &rowp, &srcp, &vals, &rp, &o64, &yp, &a, &b, &cap, &hdr,
                     &exc_idx, &exc_row, &exc_cnt, &exc_cap};
     const size_t lds = ((size_t) cap + (size_t) pl->vf_waves * (Hw + 64)) * sizeof(T);
-    SPB_HIP(hipLaunchKernel(pb_reduce_vf_fn<T>(pl->vf_waves, UBv, pl->enc8 != 0), dim3((unsigned) (wb_end - wb_begin)),
+    // persistent: one workgroup per CU walks the bins (SPBLAS_GFX950_PB_VF_GRID: test / experiment hook)
+    int64_t grid = env_int("SPBLAS_GFX950_PB_VF_GRID", h->num_cus > 0 ? h->num_cus : 256);
+    if (grid < 1 || grid > wb_end - wb_begin)
+      grid = wb_end - wb_begin;
+    SPB_HIP(hipLaunchKernel(pb_reduce_vf_fn<T>(pl->vf_waves, UBv, pl->enc8 != 0), dim3((unsigned) grid),
                             dim3(pl->vf_waves * 64), args, lds, s));
   } else {
     const int32_t* binblk = static_cast<const int32_t*>(pl->s_binblk);
