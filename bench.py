@@ -149,8 +149,9 @@ def cpu_baseline_spmv(values, rowptr, colind, shape, x, nnz):
     return y_ref, absrow, {"value": 2.0 * nnz / best / 1e9, "unit": "GFLOP/s", "cores": 1, "kind": "port", "cpu_model": cpu_model(),
             "sample": f"full workload ({nnz} nnz), best of 3 runs of oracle_spmv (-O3 -march={'native' if native else 'x86-64-v3'})",
             "seconds": best,
-            "all_cores": {"value": 2.0 * nnz / best_omp / 1e9, "cores": ncpu, "seconds": best_omp,
-                          "note": "OpenMP static row-parallel variant of the same loop"}}
+            # (scalar fields: a parser that keeps only the flat keys of cpu_baseline keeps the all-core figure too)
+            "all_cores_value": 2.0 * nnz / best_omp / 1e9, "all_cores": ncpu, "all_cores_seconds": best_omp,
+            "all_cores_note": "OpenMP static row-parallel variant of the same loop, every host core"}
 
 
 def parity_spmv(y, y_ref, absrow, tol, row_len=None):
@@ -613,11 +614,14 @@ def main():
                                        f"({mode}), one RCCL all-gather(y) per stripe"),
                        # what the headline is a number FOR: the sliced plan multiplies with a re-tiled snapshot of A, which
                        # is taken once for operands wrapped in matrix_opt; a plain inspected csr_view gets the
-                       # same plan in the form that takes the values again on every multiply: 0.79 ms at cfg2
-                       # (secondary.cfg2_plain_csr_view; the row-block kernel on the caller's arrays: 1.71 ms)
+                       # tiles WITHOUT a copy of the values (round 5: the reduce reads the caller's array through LDS): 0.37 ms
+                       # at cfg2 (secondary.cfg2_plain_csr_view; the row-block kernel on the caller's arrays: 1.71 ms)
                        "operand": "matrix_opt(csr_view) + multiply_inspect" if args.alg != "noplan" else "csr_view, no inspect",
-                       "alg": args.alg, "plan": plan_info, "inspect_ms_untimed": inspect_ms,
-                       "inspect_warm_ms_untimed": inspect_warm_ms},
+                       "alg": args.alg, "plan": plan_info,
+                       # what the plan holds on the device next to the caller's CSR arrays (which it does not copy or free)
+                       "plan_bytes": plan_info.get("device_bytes"),
+                       "plan_bytes_over_matrix": (plan_info.get("device_bytes") or 0) / float(nnz_local * (tsize + 4) + (rows_local + 1) * 4),
+                       "inspect_ms_untimed": inspect_ms, "inspect_warm_ms_untimed": inspect_warm_ms},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          # fraction of the rate a streaming copy reaches on this part (6.29 TB/s, MI355X_MICROARCH.md)

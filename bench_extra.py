@@ -87,9 +87,12 @@ def _time_steps(fn, warmup, steps):
     return elapsed, [avg, min(a.elapsed_time(b) for a, b in ev)]
 
 
-def _emit(args, metric, flops, alg_bytes, elapsed, ms, workload, extra, cpu, parity=None, pmc_key=None):
+def _emit(args, metric, flops, alg_bytes, elapsed, ms, workload, extra, cpu, parity=None, pmc_key=None, mfma_key=None):
     avg = ms[0]
     traffic, traffic_src = read_pmc_traffic(pmc_key) if pmc_key else (None, None)
+    # matrix-core utilisation of the SpMM panel kernel (north_star: "MFMA utilisation for SpMM"): committed PMC figures
+    # (SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES and friends, tools/prof_mfma.sh), stamped like the traffic
+    mfma, mfma_src = read_pmc_traffic(mfma_key) if mfma_key else (None, None)
     kernel = extra.pop("kernel", None)
     out = {"metric": metric, "value": flops / (elapsed / args.steps) / 1e9, "unit": extra.pop("unit", "GFLOP/s"), "n_gpus": 1,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -100,6 +103,10 @@ def _emit(args, metric, flops, alg_bytes, elapsed, ms, workload, extra, cpu, par
                         "traffic_source": traffic_src, "kernel": kernel,
                         "algorithmic_bytes_per_launch": alg_bytes, "kernel_avg_ms": avg, "step_events_pass_min_ms": ms[1]},
            "cpu_baseline": cpu}
+    if mfma_key:
+        out["roofline"]["mfma_util"] = (mfma or {}).get("mfma_util") if isinstance(mfma, dict) else mfma
+        out["roofline"]["mfma_detail"] = mfma if isinstance(mfma, dict) else None
+        out["roofline"]["mfma_source"] = mfma_src
     if parity is not None:
         out["parity_check"] = parity["status"]
         out["parity"] = parity
@@ -119,7 +126,8 @@ def secondary(args, device, log=None):
     HIP events and checked against the oracle; compact records for the `secondary` object of bench.py's JSON line."""
     import copy
     res = {}
-    todo = [("cfg2_plain_csr_view", "spmv_plain"), ("cfg4", "spmv_rmat1"), ("cfg3", "spmm"), ("cfg5", "spgemm")]
+    todo = [("cfg2_plain_csr_view", "spmv_plain"), ("cfg4", "spmv_rmat1"), ("cfg3", "spmm"), ("spmm_banded", "spmm_banded"),
+            ("cfg5", "spgemm")]
     if not getattr(args, "no_8f", False):  # SURVEY 8(f): add, transpose, triangular solve at their bench sizes
         todo += [("f_add", "add"), ("f_transpose", "transpose"), ("f_sptrsv", "sptrsv")]
     for name, workload in todo:
@@ -227,6 +235,8 @@ def _run_spmv_rmat1(args, device, sp, oracle, generate):
     return _emit(args, "csr_spmv_gflops", 2.0 * nnz, alg_bytes, elapsed, ms,
                  f"cfg4 (single-GPU leg): fp64 CSR SpMV, R-MAT scale {scale}, edge factor 16, duplicates kept, nnz={nnz}",
                  {"dtype": "f64", "rows": m, "nnz": nnz, "operand": "matrix_opt(csr_view) + multiply_inspect", "plan": plan,
+                  "plan_bytes": plan.get("device_bytes"),
+                  "plan_bytes_over_matrix": (plan.get("device_bytes") or 0) / float(nnz * 12 + (m + 1) * 4),
                   "inspect_ms_untimed": inspect_ms, "kernel": kern}, cpu, parity=parity,
                  pmc_key="spmv_rmat" if (args.rows is None and plan.get("alg") == 3) else None)
 
@@ -269,14 +279,21 @@ def _run_spmv_plain(args, device, sp, oracle, generate):
               "worst_err_over_rownorm": worst,
               "against": "oracle_spmv on the first / last 1 500 and 3 000 sampled rows, with the values the caller wrote in "
                          "place AFTER multiply_inspect"}
-    kern = {3: "pb_refresh_bins_kernel<float> + pb_expand_kernel<float,false> + pb_reduce_kernel<float,...> (one SpMV = this "
-               "launch group: the plan takes A's values again on every multiply)",
+    vf = bool(si.get("value_free", 0))
+    kern = {3: ("pb_expand_kernel<float,false,true> + pb_reduce_vf_kernel<float,8,2,true> (one SpMV = this launch pair: the "
+                "plan holds no values -- the expand moves x[col], the reduce multiplies by the caller's array through an LDS "
+                "window per bin)") if vf else
+               ("pb_refresh_bins_kernel<float> + pb_expand_kernel<float,false> + pb_reduce_kernel<float,...> (one SpMV = this "
+                "launch group: the plan takes A's values again on every multiply)"),
             2: "spmv_rowblock_kernel<float,int,1024>"}.get(plan.get("alg"), "spmv_vector_kernel")
     return _emit(args, "csr_spmv_gflops", 2.0 * nnz, alg_bytes, elapsed, ms,
                  f"cfg2's matrix as a plain inspected csr_view: fp32 CSR SpMV {m}x{n}, 10 nnz/row uniform random, nnz={nnz}",
                  {"dtype": "f32", "rows": m, "nnz": nnz, "operand": "csr_view + multiply_inspect (no matrix_opt)", "plan": plan,
                   "values_taken_again_every_multiply": bool(si.get("refresh_each_call", 0)),
-                  "inspect_ms_untimed": inspect_ms, "kernel": kern}, None, parity=parity)
+                  "plan_holds_no_values": vf, "plan_bytes": plan.get("device_bytes"),
+                  "plan_bytes_over_matrix": (plan.get("device_bytes") or 0) / float(nnz * 8 + (m + 1) * 4),
+                  "inspect_ms_untimed": inspect_ms, "kernel": kern}, None, parity=parity,
+                 pmc_key="spmv_plain_cfg2" if (args.rows is None and vf) else None)
 
 
 def _run(args, device):
@@ -361,7 +378,8 @@ def _run(args, device):
               {"dtype": "f32", "rows": m, "nnz": nnz, "ncols": ncols, "spmm_inspect": mi,
                "kernel": "spmm_panel_kernel<int> (v_mfma_f32_32x32x2_f32)" if mi["panel_blocks"] > 0 else
                          "spmm_rowgroup_kernel<float,int,4>"}, cpu, parity=parity,
-                     pmc_key=None if (banded or rmat or args.rows) else "spmm_cfg3")
+                     pmc_key=None if (rmat or args.rows) else ("spmm_banded" if banded else "spmm_cfg3"),
+                     mfma_key="spmm_banded_mfma" if (banded and not args.rows and mi["panel_blocks"] > 0) else None)
 
     if args.workload == "spgemm":
         m = args.rows or 1_000_000
@@ -486,7 +504,8 @@ def _run(args, device):
         return _emit(args, "csr_add_gentries", float(annz + bnnz), alg_bytes, elapsed, ms,
               f"8f: fp32 CSR + CSR add {m}x{m}, 16 nnz/row each, uniform random; timed step = add_compute; value = input entries/ns",
               {"dtype": "f32", "unit": "Gentries/s", "rows": m, "nnz_c": cn, "add_inspect_ms_untimed": inspect_ms,
-               "kernel": "spg_ranked_fill_kernel / spg_hash_kernel (identity B + addend)"}, cpu, parity=parity)
+               "kernel": "spg_ranked_fill_kernel / spg_hash_kernel (identity B + addend)"}, cpu, parity=parity,
+                     pmc_key=None if args.rows else "add_8f")
 
     if args.workload == "transpose":  # B = A^T (stable counting sort)
         m = args.rows or 10_000_000
@@ -517,7 +536,8 @@ def _run(args, device):
         return _emit(args, "csr_transpose_gentries", float(annz), alg_bytes, elapsed, ms,
               f"8f: fp32 CSR transpose {m}x{m}, 10 nnz/row uniform random; value = entries/ns",
               {"dtype": "f32", "unit": "Gentries/s", "rows": m, "nnz": annz,
-               "kernel": "spt_count_kernel + spt_scatter_kernel, three 8-bit passes"}, cpu, parity=parity)
+               "kernel": "spt_count_kernel + spt_scatter_kernel, three 8-bit passes"}, cpu, parity=parity,
+                     pmc_key=None if args.rows else "transpose_8f")
 
     if args.workload == "sptrsv":  # x = inv(L) b, L random lower triangular + diagonal
         m = args.rows or 4_000_000
@@ -585,6 +605,7 @@ def _run(args, device):
               {"dtype": "f32", "rows": m, "nnz": nnz, "plan": info.state_.info(),
                "triangular_solve_inspect_ms_untimed": inspect_ms,
                "triangular_solve_inspect_first_call_ms": inspect_first_ms,
-               "kernel": "sptrsv cooperative level kernel"}, cpu, parity=parity)
+               "kernel": "sptrsv cooperative level kernel"}, cpu, parity=parity,
+                     pmc_key=None if args.rows else "sptrsv_8f")
 
     raise SystemExit(f"unknown workload {args.workload}")

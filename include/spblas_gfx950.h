@@ -270,6 +270,10 @@ int spblas_gfx950_step_signal(spblas_gfx950_handle_t handle, void* const* flag_p
                               int64_t step);
 int spblas_gfx950_step_wait(spblas_gfx950_handle_t handle, const void* flags, int n_peers, int64_t step,
                             int64_t timeout_ms, int* status_dev);
+/* Tick rate (kHz) of the device clock the waits above are bounded by and the wait statistics (status_dev[1] of a
+ * chunk wait) are counted in: hipDeviceAttributeWallClockRate of the handle's device (100 MHz on gfx9).  No vendor call
+ * replaced: rocSPARSE has no device-side waits. */
+int spblas_gfx950_wall_clock_khz(spblas_gfx950_handle_t handle, int* khz);
 /* One-shot: the NEXT spmv_reduce_rows_bcast on this handle issues step_wait(flags, n_peers, step, ...) right before the
  * kernel that stores into the peers' copies of y (the combine kernel when the reduce is K-split, else the reduce
  * itself).  Throughput form of the fused step for independent right-hand sides: expand and reduce of step k overlap

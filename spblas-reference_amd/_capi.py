@@ -98,6 +98,7 @@ PROTOTYPES = [
      [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_i64, c_int, c_void_p, c_int, c_i64, c_void_p]),
     ("spblas_gfx950_step_signal", c_int, [c_void_p, c_void_p, c_int, c_int, c_i64]),
     ("spblas_gfx950_step_wait", c_int, [c_void_p, c_void_p, c_int, c_i64, c_i64, c_void_p]),
+    ("spblas_gfx950_wall_clock_khz", c_int, [c_void_p, ctypes.POINTER(c_int)]),
     ("spblas_gfx950_bcast_wait_before", c_int, [c_void_p, c_void_p, c_int, c_i64, c_i64, c_void_p]),
     ("spblas_gfx950_sptrsv_create", c_int,
      [c_void_p, ctypes.POINTER(c_void_p), c_i64, c_i64, c_void_p, c_void_p, c_int, c_int]),

@@ -163,6 +163,15 @@ int spblas_gfx950_step_wait(spblas_gfx950_handle_t handle, const void* flags, in
   return launch_step_wait(handle, flags, n_peers, step, timeout_ms, status_dev);
 }
 
+int spblas_gfx950_wall_clock_khz(spblas_gfx950_handle_t handle, int* khz) {
+  if (!handle)
+    return SPBLAS_GFX950_STATUS_INVALID_HANDLE;
+  if (!khz)
+    return SPBLAS_GFX950_STATUS_INVALID_POINTER;
+  *khz = wall_clock_khz(handle);
+  return SPBLAS_GFX950_STATUS_SUCCESS;
+}
+
 int spblas_gfx950_bcast_wait_before(spblas_gfx950_handle_t handle, const void* flags, int n_peers, int64_t step,
                                     int64_t timeout_ms, int* status_dev) {
   if (!handle)

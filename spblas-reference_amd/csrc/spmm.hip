@@ -763,9 +763,13 @@ extern "C" int spblas_gfx950_spmm_strided(spblas_gfx950_handle_t handle, spblas_
                                           const int32_t* colind, const void* values, const void* B, int64_t brs, int64_t bcs,
                                           const void* beta, void* C, int64_t crs, int64_t ccs, int offset_type,
                                           int value_type) {
-  if (bcs == 1 && ccs == 1)  // both layout_right: the regular kernels, plan included
-    return spblas_gfx950_spmm(handle, plan, m, k, n, nnz, alpha, rowptr, colind, values, B, brs, beta, C, crs, offset_type,
+  if (bcs == 1 && ccs == 1) {  // both layout_right: the regular kernels, plan included
+    // (a layout_left mdspan with ONE row also has strides (1, 1): its row stride says nothing -- an operand of at most one
+    // row gets the leading dimension the regular entry point asks for; round-4 advisor finding)
+    const int64_t ldb = k <= 1 ? (n > 1 ? n : 1) : brs, ldc = m <= 1 ? (n > 1 ? n : 1) : crs;
+    return spblas_gfx950_spmm(handle, plan, m, k, n, nnz, alpha, rowptr, colind, values, B, ldb, beta, C, ldc, offset_type,
                               value_type);
+  }
   if (!handle)
     return SPBLAS_GFX950_STATUS_INVALID_HANDLE;
   if (m < 0 || k < 0 || n < 0 || nnz < 0 || m > INT32_MAX || k > INT32_MAX)

@@ -39,6 +39,7 @@
 // The order of additions into a row is fixed by the plan, so results are run-to-run
 // reproducible for a given plan (plans built twice may order entries differently).
 #include <algorithm>
+#include <atomic>
 #include <type_traits>
 #include <vector>
 
@@ -1218,6 +1219,37 @@ __global__ __launch_bounds__(PB_THREADS) void pb_expand_kernel(int64_t n, int W,
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
 #endif
   };
+  // ... and ONE workgroup, at its end, waits for EVERY chunk of every peer, whatever the sparsity pattern.  The reduce /
+  // combine that follows this kernel on the stream peer-stores the rows of step k + 1 into the buffer the peers' expand of
+  // step k is reading; that is only safe once every peer has published step k (its publish follows its expand on its
+  // stream).  The per-slice waits above cover exactly the peers in whose column ranges this shard has entries -- a block
+  // triangular matrix, an upwind stencil or a directed graph leaves peers out, and a rank that never waits for a peer can
+  // run steps ahead of it (round-4 advisor finding).  Whole-step order per peer, bounded like the slice waits.
+  auto wait_all_peers = [&]() {
+    if (!cw.flags || blockIdx.x != 0 || tid != 0)
+      return;
+    const long long t0 = wall_clock64();
+    for (int q = 0; q < cw.n_ranks; ++q) {
+      if (q == cw.rank)
+        continue;
+      const long long* cr = cw.chunk_rows + (long long) q * (cw.chunks + 1);
+      for (int c = 0; c < cw.chunks; ++c) {
+        if (cr[c + 1] <= cr[c])
+          continue;  // an empty chunk is never published on its own
+        const long long* f = cw.flags + (long long) q * cw.chunks + c;
+        while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < cw.step) {
+          __builtin_amdgcn_s_sleep(8);
+          if (wall_clock64() - t0 > cw.timeout_ticks) {
+            cw.status_dev[0] = 1;
+            return;
+          }
+        }
+      }
+    }
+    const long long waited = wall_clock64() - t0;
+    if (waited > 200)
+      atomicMax(cw.status_dev + 1, (int) (waited < 0x7fffffffLL ? waited : 0x7fffffffLL));
+  };
   auto load_x = [&](int s) {
     const int64_t c0 = (int64_t) s * W;
     const int cw_ = (int) ((n - c0) < W ? (n - c0) : W);
@@ -1330,6 +1362,7 @@ __global__ __launch_bounds__(PB_THREADS) void pb_expand_kernel(int64_t n, int W,
       __syncthreads();
       process(item.y, item.z);
     }
+    wait_all_peers();
     return;
   }
   // Equal shares: workgroup b takes the blocks [b*share, (b+1)*share) of A' and loads the x slice of every
@@ -1342,8 +1375,10 @@ __global__ __launch_bounds__(PB_THREADS) void pb_expand_kernel(int64_t n, int W,
   const long long g0l = (long long) bid * share;
   int g0 = g0l < total ? (int) g0l : total;
   const int g1 = (total - g0) < share ? total : g0 + share;
-  if (g0 >= g1)
+  if (g0 >= g1) {
+    wait_all_peers();
     return;
+  }
   int lo = 0, hi = S;  // last slice starting at or before g0
   while (hi - lo > 1) {
     const int mid = (lo + hi) >> 1;
@@ -1364,6 +1399,7 @@ __global__ __launch_bounds__(PB_THREADS) void pb_expand_kernel(int64_t n, int W,
     process(g0, a1);
     g0 = a1;
   }
+  wait_all_peers();
 }
 
 // inspect: mark duplicates.  Same walk as the reduce kernel: wave-bin -> groups of 256 entries; lane l holds the
@@ -2023,7 +2059,10 @@ __global__ __launch_bounds__(256) void pb_combine_publish_kernel(int64_t r_lo, i
     const long long c_hi = (c == chunks - 1 || (c + 1) * rows_per_chunk > (long long) (r_hi - r_lo)) ? (long long) (r_hi - r_lo)
                                                                                                     : (c + 1) * rows_per_chunk;
     const int wgs = (int) ((c_hi - c_lo + PB_PUB_ROWS - 1) / PB_PUB_ROWS);
-    if (__hip_atomic_fetch_add(done + c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == wgs - 1) {
+    // (acquire-release on the arrival counter, release on the flags: only the thread that completes a chunk pays for the
+    // fences, and nothing in the memory model lets a flag overtake the rows it stands for -- the hand-made order above
+    // [write-through stores, vmcnt(0), barrier] was exercised with ranks sharing ONE device only; round-4 advisor finding)
+    if (__hip_atomic_fetch_add(done + c, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == wgs - 1) {
       __hip_atomic_store(done + c, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (the next step counts from zero)
       if (delay_ticks > 0 && c == 1) {  // test hook: a deliberately late chunk
         const long long t0 = wall_clock64();
@@ -2031,7 +2070,7 @@ __global__ __launch_bounds__(256) void pb_combine_publish_kernel(int64_t r_lo, i
           __builtin_amdgcn_s_sleep(32);
       }
       for (int p = 0; p < n_peers; ++p)
-        __hip_atomic_store(flag_peers[p] + slot0 + c, step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(flag_peers[p] + slot0 + c, step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
 }
@@ -3025,8 +3064,14 @@ int spmv_sliced_build(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const 
       // round 4: correct, 2.39 ms against 1.57 - 1.75 ms at cfg4; removed again, profiles/r04_presum.md has the numbers
       // and the commit that holds the code)
       const int rc_h = spmv_hot_build(h, pl, values, auto_mode);
-      if (rc_h != SPBLAS_GFX950_STATUS_NOT_SUPPORTED)
+      // (the split needs roughly two more copies of A: when THAT does not fit, the ordinary tiled plan -- or, under AUTO, the
+      // row-block plan -- still may; round-4 advisor finding)
+      if (rc_h == SPBLAS_GFX950_STATUS_ALLOC_FAILED) {
+        spmv_hot_free(h, pl);
+        (void) hipGetLastError();
+      } else if (rc_h != SPBLAS_GFX950_STATUS_NOT_SUPPORTED) {
         return rc_h;
+      }
     }
   }
   const bool f32 = pl->value_type == SPBLAS_GFX950_F32, o32 = pl->offset_type == SPBLAS_GFX950_I32;
@@ -3053,11 +3098,11 @@ static int sliced_update_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* p
     const void* fn = o32 ? (const void*) pb_refresh_bins_kernel<T, int32_t> : (const void*) pb_refresh_bins_kernel<T, int64_t>;
     // (once per device, offset type and value type -- this function is a template --: a plan without the snapshot opt-in
     // comes here on every multiply)
-    static bool attr_set[64][2] = {};
+    static std::atomic<bool> attr_set[64][2] = {};  // (written on every multiply of a refreshing plan, from any thread)
     const int dev = h->device >= 0 && h->device < 64 ? h->device : 0;
-    if (!attr_set[dev][o32 ? 0 : 1] || h->device >= 64) {
+    if (!attr_set[dev][o32 ? 0 : 1].load(std::memory_order_acquire) || h->device >= 64) {
       SPB_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, PB_STAGE_LDS - 1024));
-      attr_set[dev][o32 ? 0 : 1] = true;
+      attr_set[dev][o32 ? 0 : 1].store(true, std::memory_order_release);
     }
     if (o32)
       hipLaunchKernelGGL((pb_refresh_bins_kernel<T, int32_t>), dim3((unsigned) pl->n_rblk), dim3(1024), (size_t) PB_STAGE_LDS - 1024,

@@ -419,6 +419,10 @@ class FusedShardedSpMV:
                                                                            y_probe, **kw)
             if not isinstance(self.info.state_, api._Plan) or self.info.state_.info()["alg"] != api._capi.SPMV_SLICED:
                 raise RuntimeError("FusedShardedSpMV needs a SLICED local plan")
+            if self.info.state_.sliced_info().get("refresh_each_call"):
+                # (a plan made from a plain inspected csr_view must read A's values of every call; the fused entry
+                # points are not given them -- they would multiply with the inspect-time copy, or have none at all)
+                raise RuntimeError("FusedShardedSpMV needs a plan that owns its values: inspect matrix_opt(a_local)")
             # buffers: two copies of y, one flag array (slot q = last step signalled by rank q)
             self.chunks = max(0, int(chunks))
             if self.world * max(self.chunks, 1) > 64:
@@ -530,7 +534,10 @@ class FusedShardedSpMV:
         ticks = int(self._chunk_status[1].item())
         if reset:
             self._chunk_status[1] = 0
-        return ticks / 100.0  # wall_clock64: 100 MHz on gfx9
+        khz = self._ct.c_int(0)  # (the device's own rate, as the timeouts use: wall_clock64 ticks at 100 MHz on gfx9)
+        api.check(api._capi.lib().spblas_gfx950_wall_clock_khz(api._Handle.current(self.device).h, self._ct.byref(khz)),
+                  "wall_clock_khz")
+        return ticks * 1e3 / max(1, khz.value)
 
     def step(self, x, events=None):
         """One sharded SpMV; returns the full y (valid on this rank once the stream reaches this point)."""

@@ -118,6 +118,14 @@ def main():
         msq = 64000 * world
         v2, rp2, ci2, shape2, _ = generate.uniform_csr_device(msq, msq, per_row, dtype=dtype, seed=3, device=dev)
         b2 = sharded.partition_rows_even(msq, world)
+        if os.environ.get("FUSED_TRIANGULAR", "0") == "1":
+            # lower BLOCK triangular: the rows of rank q only have columns below the end of q's own block, so rank 0 reads
+            # no peer's rows at all and rank q never reads those of the ranks above it -- no x slice of its expand waits for
+            # them.  With the last rank's chunk made late below, the lower ranks run ahead unless the step itself orders
+            # them behind EVERY peer (round-4 advisor finding: a write-after-read race on the peers' copies of y).
+            row_of = torch.repeat_interleave(torch.arange(msq, device=dev), (rp2[1:] - rp2[:-1]).long())
+            limit = (torch.div(row_of, msq // world, rounding_mode="floor") + 1) * (msq // world)
+            ci2 = (ci2.long() % limit).to(torch.int32)
         a2 = sharded.shard_csr(v2, rp2, ci2, shape2, b2[rank], b2[rank + 1])
         op2 = sharded.FusedShardedSpMV(a2, b2, alg=sp._capi.SPMV_SLICED, timeout_ms=8000, chunks=chunks, shared_device=True)
         x0 = torch.rand(msq, dtype=dtype, device=dev, generator=g)

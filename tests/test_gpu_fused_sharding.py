@@ -23,15 +23,18 @@ def test_fused_sharded_spmv_multiprocess(gpu, world, dt, stripes):
     assert r.returncode == 0 and "FUSED_OK" in r.stdout, (r.stdout[-3000:], r.stderr[-3000:])
 
 
-@pytest.mark.parametrize("world,dt,chunks", [(2, "f32", 4), (4, "f32", 3), (3, "f64", 2), (8, "f32", 4)])
-def test_fused_dependent_chain_with_chunk_flags(gpu, world, dt, chunks):
+@pytest.mark.parametrize("world,dt,chunks,tri", [(2, "f32", 4, 0), (4, "f32", 3, 0), (3, "f64", 2, 0), (8, "f32", 4, 0),
+                                                 (4, "f32", 3, 1), (3, "f64", 2, 1)])
+def test_fused_dependent_chain_with_chunk_flags(gpu, world, dt, chunks, tri):
     """The dependent iteration y_{k+1} = A y_k without a step barrier: the reduce publishes a flag per (rank, chunk) after
     the chunk's peer stores, the next expand waits per x slice for exactly the chunks it needs.  Bit-compared with the
-    barrier chain on every rank, also with one rank's chunk 1 made 4 ms late in every step (tests/mp_fused_worker.py)."""
+    barrier chain on every rank, also with one rank's chunk 1 made 4 ms late in every step (tests/mp_fused_worker.py).
+    tri = 1: a lower block-triangular matrix -- ranks that read none of a late peer's rows must still not run ahead of
+    it (one expand workgroup waits for every peer's chunks, whatever the sparsity pattern)."""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", FUSED_STRIPES="1",
-               FUSED_CHUNKS=str(chunks))
+               FUSED_CHUNKS=str(chunks), FUSED_TRIANGULAR=str(tri))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
-           "--master-addr", "127.0.0.1", "--master-port", str(29690 + world + (7 if dt == "f64" else 0)),
+           "--master-addr", "127.0.0.1", "--master-port", str(29690 + world + (7 if dt == "f64" else 0) + 20 * tri),
            os.path.join(ROOT, "tests", "mp_fused_worker.py"), dt]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0 and "FUSED_OK" in r.stdout and f"chunks {chunks}" in r.stdout, (r.stdout[-3000:], r.stderr[-3000:])
