@@ -66,6 +66,8 @@ struct spblas_gfx950_plan_s {
   int hub_len = 0;             // > 0: rows longer than this are NOT in the tiles (pb_hub_rows_kernel does them)
   int64_t s_placed = 0;        // entries in the tiles (nnz minus the hub rows' entries)
   const void* values_ptr = nullptr;  // caller's values array the copy was taken from (inspect / last update)
+  int keep_src = 0;                  // 1: keep the source position of every entry (s_perm / hot_src / rest_src): value refreshes
+  size_t base_device_bytes = 0;      // device_bytes of the structures plan_build made (before any SLICED arrays)
   int refresh_each_call = 0;         // 1: the plan was made WITHOUT the snapshot opt-in: every multiply takes the values again
   // Value-free tiles (round 5, spmv_sliced.hip "vfree"): the plan holds NO copy of A's values.  The expand writes the gathered
   // x[col] to the product stream; the reduce of a bin stages the bin's window of the CALLER's values (contiguous:

@@ -725,6 +725,7 @@ int spblas_gfx950_spmv_plan_create(spblas_gfx950_handle_t handle, spblas_gfx950_
   pl->value_type = value_type;
   int rc = offset_type == SPBLAS_GFX950_I32 ? plan_build<int32_t>(handle, pl, alg)
                                             : plan_build<int64_t>(handle, pl, alg);
+  pl->base_device_bytes = pl->device_bytes;
   if (rc == SPBLAS_GFX950_STATUS_SUCCESS && pl->alg == SPBLAS_GFX950_SPMV_SLICED) {
     // (an explicitly requested SLICED plan keeps its copy of the values -- the documented snapshot -- unless the test hook
     // SPBLAS_GFX950_PB_VFREE=2 asks for the value-free form, which then reads the caller's array on every multiply)

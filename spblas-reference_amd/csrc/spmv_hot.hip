@@ -161,12 +161,14 @@ __global__ __launch_bounds__(256) void hot_split_kernel(int64_t nnz, const int32
   if (hotpos[p + 1] != hp) {  // a hot entry: only those look their column up (the few thousand map lines of the hot columns)
     hot_val[hp] = v;
     hot_col[hp] = (uint16_t) colmap[c];
-    hot_src[hp] = (int32_t) p;
+    if (hot_src)  // (source positions only for plans that refresh their values: plan.hpp keep_src)
+      hot_src[hp] = (int32_t) p;
   } else {
     const int64_t rp = p - hp;
     rest_val[rp] = v;
     rest_col[rp] = c;
-    rest_src[rp] = (int32_t) p;
+    if (rest_src)
+      rest_src[rp] = (int32_t) p;
   }
 }
 
@@ -688,13 +690,16 @@ static int hot_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, c
   pl->hot_nnz = (int64_t) n_hot;
   // (the multiply loads whole windows: the arrays end in zero entries up to the end of the last window)
   const size_t hot_pad = (size_t) (n_hot / HOT_WIN + 1) * HOT_WIN + HOT_WIN;
+  // the source position of every entry (what a value refresh gathers through) only when the plan is known to refresh:
+  // spmv_sliced.hip, keep_src (the first change of values builds a plan without them again, with them)
+  const bool keep_src = pl->keep_src || pl->refresh_each_call || hot_env("SPBLAS_GFX950_PB_KEEP_SRC", 0);
   if ((rc = dev_alloc(&pl->hot_val, hot_pad * sizeof(T), s)) ||
       (rc = dev_alloc((void**) &pl->hot_col, hot_pad * 2, s)) ||
-      (rc = dev_alloc((void**) &pl->hot_src, (size_t) n_hot * 4, s)) ||
+      (keep_src && (rc = dev_alloc((void**) &pl->hot_src, (size_t) n_hot * 4, s))) ||
       (rc = dev_alloc(&pl->rest_rowptr, (size_t) (m + 1) * sizeof(O), s)) ||
       (rc = dev_alloc(&pl->rest_val, (size_t) n_rest * sizeof(T), s)) ||
       (rc = dev_alloc((void**) &pl->rest_col, (size_t) n_rest * 4, s)) ||
-      (rc = dev_alloc((void**) &pl->rest_src, (size_t) n_rest * 4, s)))
+      (keep_src && (rc = dev_alloc((void**) &pl->rest_src, (size_t) n_rest * 4, s))))
     return rc;
   SPB_HIP(hipMemsetAsync(static_cast<T*>(pl->hot_val) + n_hot, 0, (hot_pad - (size_t) n_hot) * sizeof(T), s));
   SPB_HIP(hipMemsetAsync(pl->hot_col + n_hot, 0, (hot_pad - (size_t) n_hot) * 2, s));
@@ -768,6 +773,7 @@ static int hot_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, c
   rp->offset_type = pl->offset_type;
   rp->value_type = pl->value_type;
   rp->is_child = pl->is_child + 1;
+  rp->keep_src = keep_src ? 1 : 0;
   if ((rc = spmv_plan_structures(h, rp, SPBLAS_GFX950_SPMV_ROWBLOCK)))
     return rc;
   if ((rc = spmv_sliced_build(h, rp, pl->rest_val, auto_mode)))
@@ -777,8 +783,25 @@ static int hot_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, c
   pl->s_uncertain = rp->s_uncertain;
   pl->s_placed = rp->s_placed;
   pl->values_ptr = values_p;
-  pl->device_bytes += hp->device_bytes + rp->device_bytes + (size_t) cols * 4 + (size_t) n_hot * (sizeof(T) + 6) +
-                      (size_t) n_rest * (sizeof(T) + 8) + (size_t) (m + 1) * sizeof(O) + (size_t) (m_hot + 1) * (sizeof(O) + 4);
+  // A_rest as a CSR matrix was the INPUT of its tiles; only a plan that refreshes values (the gather goes caller -> rest_val
+  // -> tiles) or whose tiles left rows out (hub rows are multiplied from the CSR arrays) needs it afterwards: 12 B per
+  // entry of A_rest otherwise given back (cfg4: 2.27 of 9.5 GB)
+  size_t rest_csr_bytes = (size_t) n_rest * (sizeof(T) + 4);
+  {
+    spblas_gfx950_plan_s* tp = rp->rest_plan ? nullptr : rp;  // (a remainder that was split again keeps its input)
+    if (!keep_src && tp && !(tp->hub_len > 0 && tp->n_hub > 0) && !hot_env("SPBLAS_GFX950_PB_KEEP_REST", 0)) {
+      dev_free(pl->rest_val, s);
+      dev_free(pl->rest_col, s);
+      pl->rest_val = nullptr;
+      pl->rest_col = nullptr;
+      rp->colind = nullptr;
+      rp->values_ptr = nullptr;
+      rest_csr_bytes = 0;
+    }
+  }
+  pl->device_bytes += hp->device_bytes + rp->device_bytes + (size_t) cols * 4 + (size_t) n_hot * (sizeof(T) + 2 + (keep_src ? 4 : 0)) +
+                      rest_csr_bytes + (keep_src ? (size_t) n_rest * 4 : 0) + (size_t) (m + 1) * sizeof(O) +
+                      (size_t) (m_hot + 1) * (sizeof(O) + 4);
   pl->hot_m = (int64_t) m_hot;
   pl->device_bytes += (size_t) (hp->nwin + 1) * 4 + (size_t) 2 * hp->nwin * sizeof(T);
   SPB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pb_hot_rows_kernel<T, O>),

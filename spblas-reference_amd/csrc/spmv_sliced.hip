@@ -59,6 +59,7 @@ int spmv_hot_exec(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const void
 int spmv_hot_rows(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const void* alpha, const void* x, void* y);
 int spmv_hot_update(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const void* values);
 void spmv_hot_free(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl);
+void spmv_sliced_free(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl);
 
 static int env_int(const char* name, int dflt) {
   const char* v = std::getenv(name);
@@ -464,7 +465,8 @@ __global__ __launch_bounds__(256) void pb_scatter_kernel(int64_t m, const O* __r
     const int i = atomicAdd(&cursor[sl], 1);
     s_val[i] = values[p];
     s_col[i] = (uint16_t) (c - sl * W);
-    perm[i] = (int32_t) p;
+    if (perm)
+      perm[i] = (int32_t) p;
     s_row[i + pdelta[sl]] = (uint16_t) (lo - r0);
   }
 }
@@ -575,7 +577,8 @@ __device__ __forceinline__ void pb_emit_sorted_run(int n, int lo, int g, int gp,
         s_src[gp + j] = (uint16_t) qq;  // bin's window of the caller's array holds < 65 536 entries)
       } else {
         s_val[g + j] = stv[lo + j];
-        perm[g + j] = (int32_t) (p0 + qq);
+        if (perm)
+          perm[g + j] = (int32_t) (p0 + qq);
       }
       s_code[gp + j] = (unsigned char) (bi == 0 ? 0 : (exc ? 255 : r - Dp));
       if (bi == 0)
@@ -584,7 +587,8 @@ __device__ __forceinline__ void pb_emit_sorted_run(int n, int lo, int g, int gp,
       s_col[g + j] = 0;               // (written here, so that the plan arrays need no clearing pass: pb_clear_tail)
       if (!s_src) {
         s_val[g + j] = T(0);
-        perm[g + j] = -1;
+        if (perm)
+          perm[g + j] = -1;
       }
     }
     if (exc) {
@@ -848,7 +852,8 @@ __global__ __launch_bounds__(PB_STAGE_THREADS) void pb_scatter_staged_kernel(
           s_src[pdst[sl] + pos] = (uint16_t) q;
         } else {
           s_val[i] = values[p0 + q];
-          perm[i] = (int32_t) (p0 + q);
+          if (perm)
+            perm[i] = (int32_t) (p0 + q);
         }
         s_row[pdst[sl] + pos] = (uint16_t) r;
       } else {
@@ -869,7 +874,8 @@ __global__ __launch_bounds__(PB_STAGE_THREADS) void pb_scatter_staged_kernel(
         s_col[gdst[s0] + n + tid] = 0;
         if (!s_src) {
           s_val[gdst[s0] + n + tid] = T(0);
-          perm[gdst[s0] + n + tid] = -1;
+          if (perm)
+            perm[gdst[s0] + n + tid] = -1;
         }
       }
     }
@@ -899,7 +905,8 @@ __global__ __launch_bounds__(PB_STAGE_THREADS) void pb_scatter_staged_kernel(
             s_src[gp + j] = (uint16_t) q;
           } else {
             s_val[g + j] = stv[lo + j];
-            perm[g + j] = (int32_t) (p0 + q);
+            if (perm)
+              perm[g + j] = (int32_t) (p0 + q);
           }
           s_row[gp + j] = (uint16_t) row_of(q);
         }
@@ -907,7 +914,8 @@ __global__ __launch_bounds__(PB_STAGE_THREADS) void pb_scatter_staged_kernel(
           s_col[g + n + lane] = 0;
           if (!s_src) {
             s_val[g + n + lane] = T(0);
-            perm[g + n + lane] = -1;
+            if (perm)
+              perm[g + n + lane] = -1;
           }
         }
       }
@@ -2666,7 +2674,7 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
   hipLaunchKernelGGL(pb_ecnt_kernel, dim3((unsigned) cdiv(nseg, 256)), dim3(256), 0, s, nseg, cnt, eoff);
   (void) scan_counts_i32(s, nseg, eoff, partials);  // eoff[nseg] = entries of the compact stream
   // the same offsets bin-major, with the padded run lengths: what the value refresh reads (sliced_update_typed)
-  if (!vfree) {
+  if (!vfree && (pl->keep_src || pl->refresh_each_call || env_int("SPBLAS_GFX950_PB_KEEP_SRC", 0))) {
     if ((rc = dev_alloc(&pl->s_eoff, (size_t) nseg * sizeof(int2), s)))
       return rc;
     pl->device_bytes += (size_t) nseg * sizeof(int2);
@@ -2732,7 +2740,12 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
     return rc;
   if ((rc = dev_alloc((void**) &pl->s_colind, (size_t) (a_pad + 8) * 2, s)))
     return rc;
-  if (!vfree && (rc = dev_alloc((void**) &pl->s_perm, (size_t) (a_pad + 8) * 4, s)))
+  // Source positions (4 B per entry: what a value refresh gathers through) only for plans that are known to need them: a plan
+  // that takes the values again on every multiply, or one whose caller HAS changed the values once (keep_src: the first
+  // update of a plan built without them builds it again, spmv_sliced_update).  A plan that is inspected once and multiplied
+  // many times -- the common case -- is a quarter smaller without them (cfg2: 1.61 -> 1.18 GB).
+  const bool keep_src = !vfree && (pl->keep_src || pl->refresh_each_call || env_int("SPBLAS_GFX950_PB_KEEP_SRC", 0));
+  if (keep_src && (rc = dev_alloc((void**) &pl->s_perm, (size_t) (a_pad + 8) * 4, s)))
     return rc;
   if (vfree && (rc = dev_alloc((void**) &pl->s_src, (size_t) (p_pad + PB_GRP) * 2, s)))
     return rc;
@@ -2770,7 +2783,8 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
   if ((rc = dev_alloc((void**) &pl->s_products, (size_t) (p_pad + PB_GRP) * sizeof(T), s)))
     return rc;
   pl->s_products_bytes = (size_t) (p_pad + PB_GRP) * sizeof(T);
-  pl->device_bytes += (size_t) a_pad * (vfree ? 2 : sizeof(T) + 6) + (vfree ? (size_t) p_pad * 2 : 0) + (size_t) a_blocks * 8 +
+  pl->device_bytes += (size_t) a_pad * (vfree ? 2 : sizeof(T) + 2 + (keep_src ? 4 : 0)) + (vfree ? (size_t) p_pad * 2 : 0) +
+                      (size_t) a_blocks * 8 +
                       (size_t) p_pad * sizeof(T) +
                       (enc8 ? (size_t) p_pad + hdr_bytes + (size_t) NB * PB_EXC_CAP * 6 : (size_t) p_pad * 2) +
                       (size_t) (NB + S + 2) * 4 + (size_t) nseg * 4;
@@ -2782,7 +2796,7 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
   if (!vfree)
     SPB_HIP(hipMemsetAsync(static_cast<T*>(pl->s_values) + a_keep, 0, (size_t) (a_pad + 8 - a_keep) * sizeof(T), s));
   SPB_HIP(hipMemsetAsync(static_cast<uint16_t*>(pl->s_colind) + a_keep, 0, (size_t) (a_pad + 8 - a_keep) * 2, s));
-  if (!vfree)
+  if (keep_src)
     SPB_HIP(hipMemsetAsync(static_cast<int32_t*>(pl->s_perm) + a_keep, 0xFF, (size_t) (a_pad + 8 - a_keep) * 4, s));
   if (vfree)  // pads point at the first entry of the window (their row code keeps them out of the sums)
     SPB_HIP(hipMemsetAsync(pl->s_src, 0, (size_t) (p_pad + PB_GRP) * 2, s));
@@ -2842,6 +2856,18 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
         if ((rc = upload_add(h, pl->s_xitems, items.data(), items.size() * sizeof(int4))) || (rc = readback_flush(h)))
           return rc;
         pl->n_xitems = (int64_t) items.size();
+        if (tr.on) {  // list-scheduling makespan of the work list on `cus` workgroup slots, in blocks (+ one x slice per item)
+          std::vector<int64_t> slot((size_t) cus, 0);
+          const int64_t xcost = (int64_t) W / PB_BLK * (int64_t) sizeof(T) / (int64_t) (2 * sizeof(T) + 2);
+          for (const int4& it : items) {
+            auto mn = std::min_element(slot.begin(), slot.end());
+            *mn += (it.z - it.y) + xcost;
+          }
+          const int64_t mk = *std::max_element(slot.begin(), slot.end());
+          std::fprintf(stderr, "[inspect] expand work list: %zu items, %lld blocks, largest %d, makespan %lld = %.2f x the even share "
+                       "(x slice ~ %lld blocks)\n", items.size(), (long long) a_blocks, items.empty() ? 0 : items[0].z - items[0].y,
+                       (long long) mk, (double) mk * cus / (double) std::max<int64_t>(1, a_blocks), (long long) xcost);
+        }
       }
     }
   }
@@ -3125,6 +3151,24 @@ static int sliced_update_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* p
 }
 
 int spmv_sliced_update(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const void* values) {
+  // A plan built without source positions (the default: see keep_src in sliced_build_typed) meets its first change of
+  // values: it is built again from the caller's arrays, this time WITH them, so that every later change is the cheap
+  // gather.  Inspect-class work: not inside a stream capture.
+  const bool have_src = pl->rest_plan ? pl->hot_src != nullptr : (pl->vfree || pl->s_perm != nullptr || pl->s_placed == 0);
+  if (!have_src && !pl->is_child) {
+    if (stream_capturing(h->stream))
+      return SPBLAS_GFX950_STATUS_NOT_SUPPORTED;
+    if (pl->used && pl->last_stream != h->stream)
+      SPB_HIP(hipStreamSynchronize(pl->last_stream));
+    const int nt = pl->nt_products, refresh = pl->refresh_each_call;
+    spmv_sliced_free(h, pl);
+    pl->device_bytes = pl->base_device_bytes;
+    pl->keep_src = 1;
+    pl->refresh_each_call = refresh;
+    const int rc = spmv_sliced_build(h, pl, values, false);
+    pl->nt_products = nt;
+    return rc;
+  }
   if (pl->rest_plan)
     return spmv_hot_update(h, pl, values);
   return pl->value_type == SPBLAS_GFX950_F32 ? sliced_update_typed<float>(h, pl, values)

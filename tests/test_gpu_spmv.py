@@ -1080,3 +1080,46 @@ def test_spmv_value_free_tiles_fall_back_when_the_matrix_does_not_fit(gpu, monke
     assert si["value_free"] == 0 and si["refresh_each_call"] == 0, si
     sp.multiply(info, a, xd, y)
     check(values, rowptr, colind, (m, n), x, G.host(y), what="fallback from value-free tiles", ref_cmp=False)
+
+
+@pytest.mark.parametrize("shape", ["uniform", "hot_split"])
+def test_spmv_snapshot_plan_keeps_no_source_positions_until_the_values_change(gpu, monkeypatch, shape):
+    """Round 5: a snapshot plan (matrix_opt / explicit SLICED) is built WITHOUT the 4 B per entry of source positions a value
+    refresh gathers through -- and, for a hot-column split, without the CSR copy of A_rest its tiles were made from.  The
+    first change of values builds the plan again from the caller's arrays, this time with them (device_bytes grows); later
+    changes are the cheap gather.  Results follow the values at every step."""
+    monkeypatch.setenv("SPBLAS_GFX950_SLICE_COLS", "128")
+    rng = np.random.default_rng(47)
+    m, n = 6000, 4000
+    if shape == "hot_split":
+        monkeypatch.setenv("SPBLAS_GFX950_PB_HOT", "1")
+        lens = rng.integers(1, 40, m)
+        nnz = int(lens.sum())
+        colind = np.where(rng.random(nnz) < 0.4, rng.integers(0, 64, nnz), rng.integers(0, n, nnz)).astype(np.int32)
+    else:
+        lens = rng.integers(0, 24, m)
+        nnz = int(lens.sum())
+        colind = rng.integers(0, n, nnz).astype(np.int32)
+    rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    values = (rng.random(nnz) - 0.5).astype(np.float64)
+    x = (rng.random(n) - 0.5).astype(np.float64)
+    a = G.csr_on_device(values, rowptr, colind, (m, n), nnz)
+    xd = G.dev(x)
+    y = torch.full((m,), float("nan"), dtype=torch.float64, device="cuda")
+    info = sp.multiply_inspect(a, xd, y, alg=_capi.SPMV_SLICED)
+    if shape == "hot_split":
+        assert "hot_split" in info.state_.sliced_info()
+    bytes0 = info.state_.info()["device_bytes"]
+    sp.multiply(info, a, xd, y)
+    check(values, rowptr, colind, (m, n), x, G.host(y), what=f"{shape}: as inspected", ref_cmp=False)
+    a.values().mul_(-2.0)                                  # first change: the plan is built again, with source positions
+    info.state_.update_values(a.values())
+    bytes1 = info.state_.info()["device_bytes"]
+    assert bytes1 >= bytes0 + 4 * nnz, (bytes0, bytes1, nnz)
+    sp.multiply(info, a, xd, y)
+    check(values * -2.0, rowptr, colind, (m, n), x, G.host(y), what=f"{shape}: first change", ref_cmp=False)
+    a.values().add_(0.125)                                 # second change: the gather through the source positions
+    info.state_.update_values(a.values())
+    assert info.state_.info()["device_bytes"] == bytes1
+    sp.multiply(info, a, xd, y)
+    check(values * -2.0 + 0.125, rowptr, colind, (m, n), x, G.host(y), what=f"{shape}: second change", ref_cmp=False)
