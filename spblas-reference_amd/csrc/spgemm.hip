@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void spg_bound_kernel(int64_t m, const int32_t
                                                         const int2* __restrict__ adesc,
                                                         int32_t* __restrict__ bin_of_row,
                                                         unsigned long long* __restrict__ bin_count, int sub, int64_t b_nnz,
-                                                        int sortable_ok) {
+                                                        int sortable_ok, int2* __restrict__ adesc_out) {
   // grid-stride over groups of 32 rows: the bin histogram stays in LDS for the whole workgroup and reaches the
   // global counters once per workgroup -- with one workgroup per 32 rows the 31 k same-address atomics of a
   // 1 M-row matrix (~11 ns each, serialised) were the whole 0.38 ms of this kernel
@@ -135,6 +135,19 @@ __global__ __launch_bounds__(256) void spg_bound_kernel(int64_t m, const int32_t
     int bad = 0;  // a B row longer than `sub`, or one whose range padded to whole vectors of four leaves B's arrays
     const int p0 = a_rowptr[row], p1 = a_rowptr[row + 1];
     for (int p = p0 + lane; p < p1; p += 8) {
+      if (adesc_out) {
+        // (start, length) of the B row of every A entry, written here (round 5: a pass of its own over a_colind wrote them
+        // before this kernel read them back: 128 + 54 us at cfg5 for what one pass does)
+        struct __attribute__((packed, aligned(4))) pair_t {
+          int lo, hi;
+        };
+        const pair_t r = *reinterpret_cast<const pair_t*>(b_rowptr + a_colind[p]);  // one 8-byte load, 4-byte aligned
+        const int2 dd = make_int2(r.lo, r.hi - r.lo);
+        adesc_out[p] = dd;
+        ub += dd.y;
+        bad |= (int) (dd.y > sub) | (int) ((int64_t) dd.x + ((dd.y + 3) & ~3) > b_nnz);
+        continue;
+      }
       if (adesc) {
         const int2 dd = adesc[p];
         ub += dd.y;
@@ -1885,11 +1898,10 @@ static int spgemm_symbolic_impl(spblas_gfx950_handle_t handle, spblas_gfx950_spg
   // (start, length) of the B row of every A entry, one coalesced pass while b_rowptr still has the L2s to itself
   {
     const char* env = std::getenv("SPBLAS_GFX950_SPG_ADESC");
-    if (b_rowptr && a_nnz > 0 && !(env && env[0] == '0') &&
-        dev_alloc((void**) &st->r_adesc, (size_t) a_nnz * sizeof(int2), s) == SPBLAS_GFX950_STATUS_SUCCESS)
-      hipLaunchKernelGGL(spg_adesc_kernel, dim3((unsigned) cdiv(a_nnz, 256)), dim3(256), 0, s, a_nnz, a_colind, b_rowptr,
-                         st->r_adesc);
+    if (b_rowptr && a_nnz > 0 && !(env && env[0] == '0'))
+      (void) dev_alloc((void**) &st->r_adesc, (size_t) a_nnz * sizeof(int2), s);  // (filled by spg_bound_kernel below)
   }
+  readback_scope rb_scope(handle);
   const int64_t bound_wgs = cdiv(m, 32) < 8 * (int64_t) handle->num_cus ? cdiv(m, 32) : 8 * (int64_t) handle->num_cus;
   // rows of bin 2 that a wavefront can take in one round of vector loads get a counter of their own and the END of bin 2's
   // range in perm[] (SPBLAS_GFX950_SPG_DIRECT=0: none): sorted, not hashed, by both passes
@@ -1899,11 +1911,14 @@ static int spgemm_symbolic_impl(spblas_gfx950_handle_t handle, spblas_gfx950_spg
   }();
   const int sortable_ok = dir_env != 0 && !identity_b && b_rowptr && st->r_adesc && !st->d_rowptr && b_nnz >= 4;
   hipLaunchKernelGGL(spg_bound_kernel, dim3((unsigned) bound_wgs), dim3(256), 0, s, m, a_rowptr, a_colind,
-                     b_rowptr, st->d_rowptr, st->r_adesc, bin_of_row, d_cnt, st->sub < 64 ? st->sub : 64, b_nnz, sortable_ok);
+                     b_rowptr, st->d_rowptr, st->r_adesc, bin_of_row, d_cnt, st->sub < 64 ? st->sub : 64, b_nnz, sortable_ok,
+                     st->r_adesc);
   SPB_HIP(hipGetLastError());
+  // (the bin counts come back through the handle's pinned buffer -- a copy kernel, no SDMA transfer: hipMemcpyAsync to
+  // pageable memory left the queue idle for 35 us on either side of it, round-5 timeline)
   unsigned long long counts[SPG_NCNT];
-  SPB_HIP(hipMemcpyAsync(counts, d_cnt, sizeof(counts), hipMemcpyDeviceToHost, s));
-  SPB_HIP(hipStreamSynchronize(s));
+  if ((rc = readback_add(handle, counts, d_cnt, sizeof(counts))) || (rc = readback_flush(handle)))
+    return rc;
   unsigned long long cursors[SPG_NCNT];
   st->bin_off[0] = 0;
   for (int b = 0; b < SPG_NBINS; ++b) {
@@ -1912,7 +1927,8 @@ static int spgemm_symbolic_impl(spblas_gfx950_handle_t handle, spblas_gfx950_spg
   }
   cursors[SPG_SORTABLE] = (unsigned long long) st->bin_off[2] + counts[2];
   st->n_sortable = (int64_t) counts[SPG_SORTABLE];
-  SPB_HIP(hipMemcpyAsync(d_cnt + SPG_NCNT, cursors, sizeof(cursors), hipMemcpyHostToDevice, s));
+  if ((rc = upload_add(handle, d_cnt + SPG_NCNT, cursors, sizeof(cursors))))
+    return rc;
   hipLaunchKernelGGL(spg_fill_perm_kernel, dim3((unsigned) cdiv(m, 1024)), dim3(1024), 0, s, m, bin_of_row,
                      d_cnt + SPG_NCNT, st->perm);
   SPB_HIP(hipGetLastError());
@@ -1932,7 +1948,9 @@ static int spgemm_symbolic_impl(spblas_gfx950_handle_t handle, spblas_gfx950_spg
     hipLaunchKernelGGL(scan_partials_kernel, dim3(1), dim3(256), 0, s, nb, partials);
     hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned) nb), dim3(256), 0, s, m, st->rowptr, partials, c_rowptr);
     long long total = 0;
-    hipError_t e = hipMemcpyAsync(&total, partials + nb, sizeof(total), hipMemcpyDeviceToHost, s);
+    hipError_t e = hipSuccess;
+    if ((rc = readback_add(handle, &total, partials + nb, sizeof(total))))
+      return rc;
     // sortable rows (see spg_direct_kernel): one descriptor each, with the symbolic sort's "no shared column" flag; the
     // rows of the bin that are not sortable keep the hash kernel (dir_rest)
     const int64_t c2 = st->bin_off[3] - st->bin_off[2], ns = st->n_sortable, n_other = c2 - ns;
@@ -1953,12 +1971,15 @@ static int spgemm_symbolic_impl(spblas_gfx950_handle_t handle, spblas_gfx950_spg
       long long* n_nodup_dev = scan_counts_i32(s, ns, st->sym_flag, partials);
       hipLaunchKernelGGL(spg_direct_lists_kernel, dim3((unsigned) cdiv(ns, 256)), dim3(256), 0, s, ns,
                          st->perm + st->bin_off[3] - ns, a_rowptr, st->rowptr, st->sym_flag, st->dir_desc);
-      if (e == hipSuccess)
-        e = hipMemcpyAsync(&n_nodup, n_nodup_dev, sizeof(n_nodup), hipMemcpyDeviceToHost, s);
+      if (e == hipSuccess && (rc = readback_add(handle, &n_nodup, n_nodup_dev, sizeof(n_nodup))))
+        return rc;
     }
     st->sym_flag = nullptr;
-    if (e == hipSuccess)
-      e = hipStreamSynchronize(s);
+    {
+      const int rc_f = readback_flush(handle);  // the ONE wait the API asks for: nnz(C) sizes the caller's arrays
+      if (rc_f)
+        return rc_f;
+    }
     st->n_dir = classify ? ns : 0;
     st->n_nodup = classify ? n_nodup : 0;
     st->n_rest = classify ? n_other : 0;
