@@ -196,6 +196,54 @@ def measure(step, steps, warmup, multi, device):
     return float(el.item()), region[0].elapsed_time(region[1]) / steps
 
 
+def measure_guarded(op, step, steps, warmup, device):
+    """measure() for a path that may fail on SOME ranks (the fused exchange on its first contact with N devices): every
+    rank issues the same collectives whatever happens locally -- a short probe with a short time-out and an agreement, then
+    the timed loop and a second agreement.  Returns (valid on every rank, wall seconds: max over ranks, ms per step between
+    the events, the local exception or None).  Device-side waits are bounded (op._timeout), so a rank whose peers never
+    publish comes back with a time-out status instead of hanging."""
+    failed = None
+
+    def run(n):
+        nonlocal failed
+        if failed is None:
+            try:
+                for _ in range(n):
+                    step()
+                torch.cuda.synchronize()
+                op.check_status()
+            except Exception as e:  # noqa: BLE001 - reported, the RCCL number stands
+                failed = e
+
+    def agree():
+        flag = torch.tensor([0 if failed is not None else 1], dtype=torch.int32, device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return bool(int(flag.item()))
+
+    saved, op._timeout = op._timeout, 2000
+    run(2)
+    if not agree():
+        op._timeout = saved
+        return False, None, None, failed
+    op._timeout = min(saved, 5000)  # (no step takes seconds: a flag that stops arriving must not cost the run)
+    run(warmup)
+    dist.barrier()
+    torch.cuda.synchronize()
+    region = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+    t0 = time.perf_counter()
+    region[0].record()
+    run(steps)
+    region[1].record()
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+    dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    ok = agree()
+    op._timeout = saved
+    return ok, float(el.item()), region[0].elapsed_time(region[1]) / steps, failed
+
+
 def build_cfg2(args, world, rank, device, sharded, sp):
     """cfg2: the SAME global 10M x 10M matrix for every N (generated per fixed row chunk), equal row shards."""
     poisson = args.workload == "spmv_poisson"
@@ -356,26 +404,49 @@ def main():
         elif si.get("auto_trial"):
             plan_info["auto_trial"] = {k: si[k] for k in ("trial_rowblock_ns", "trial_sliced_ns")}
 
-    elapsed, kern_avg_ms = measure(lambda: op.step(x), args.steps, args.warmup, multi, device)
-    fused_post_check = None
+    # First contact with N devices (nothing of the fused exchange has run across devices before a SCALE run): the RCCL
+    # path is ALWAYS timed first and is the number that stands unless the fused path -- validated before (try_fused), timed
+    # behind a collective-safe guard, checked again after its timed loop -- is valid AND faster.  A fused failure of any
+    # kind (time-out, exception, mismatch) on any rank leaves the RCCL number as ms_per_step and exit code 0.
+    fused_post_check, fused_elapsed, fused_kern_ms, fused_fail = None, None, None, None
     if multi and mode == "fused" and rccl_op is not None:
-        # The fused exchange was validated against the RCCL path before the timed loop (sharded.try_fused); check it once
-        # more AFTER hundreds of steps, with vectors it has not seen, so that a peer store that only goes stale under
-        # load cannot publish a number: any mismatch on any rank and the RCCL path is timed instead.
-        ok = 1
-        for x_k in (1.25 * x + 0.5, 0.75 * x - 0.25):
-            y_f = op.step(x_k).clone()
-            y_r = rccl_op.step(x_k)
-            torch.cuda.synchronize()
-            ok &= int(torch.equal(y_f, y_r))
-        flag = torch.tensor([ok], dtype=torch.int32, device=device)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        fused_post_check = bool(int(flag.item()))
-        if not fused_post_check:
+        rccl_elapsed, rccl_kern_ms = measure(lambda: rccl_op.step(x), args.steps, args.warmup, multi, device)
+        ok_f, fused_elapsed, fused_kern_ms, fused_fail = measure_guarded(op, lambda: op.step(x), args.steps, args.warmup, device)
+        if ok_f:
+            # ... and once more AFTER hundreds of steps, with vectors it has not seen, so that a peer store that only goes
+            # stale under load cannot publish a number (every rank runs the same collectives whatever happens locally)
+            ok, y_rs = 1, [rccl_op.step(x_k).clone() for x_k in (1.25 * x + 0.5, 0.75 * x - 0.25)]
+            try:
+                for x_k, y_r in zip((1.25 * x + 0.5, 0.75 * x - 0.25), y_rs):
+                    y_f = op.step(x_k)
+                    torch.cuda.synchronize()
+                    op.check_status()
+                    ok &= int(torch.equal(y_f, y_r))
+            except Exception as e:  # noqa: BLE001
+                ok, fused_fail = 0, e
+            flag = torch.tensor([ok], dtype=torch.int32, device=device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            fused_post_check = bool(int(flag.item()))
+        fused_valid = bool(ok_f and fused_post_check)
+        if not fused_valid:
             if rank == 0:
-                print("[bench] fused all-gather failed its post-check; timing the RCCL all-gather path instead", file=sys.stderr)
+                print(f"[bench] fused all-gather not used ({fused_fail or 'failed its check on some rank'}); the RCCL "
+                      "all-gather path is the timed one", file=sys.stderr)
+            try:
+                fused_op.close()
+            except Exception:  # noqa: BLE001
+                pass
+            fused_op, fused_elapsed, fused_kern_ms = None, None, None
             op, mode = rccl_op, "plain"
-            elapsed, kern_avg_ms = measure(lambda: op.step(x), args.steps, args.warmup, multi, device)
+            elapsed, kern_avg_ms = rccl_elapsed, rccl_kern_ms
+        elif fused_elapsed <= rccl_elapsed:
+            elapsed, kern_avg_ms = fused_elapsed, fused_kern_ms
+        else:  # valid but slower than the library collective on this machine: the faster valid path is the timed one
+            op, mode = rccl_op, "plain"
+            elapsed, kern_avg_ms = rccl_elapsed, rccl_kern_ms
+    else:
+        elapsed, kern_avg_ms = measure(lambda: op.step(x), args.steps, args.warmup, multi, device)
+        rccl_elapsed = elapsed if (multi and rccl_op is not None and op is rccl_op) else None
 
     # Where the time of a multi-GPU step goes (outside the timed region, same K): the local kernels alone, the
     # all-gather alone, the RCCL step and -- when it could be set up -- the fused step.
@@ -384,12 +455,13 @@ def main():
         k = max(5, min(args.steps, 50))
         local_s, local_ev = measure(lambda: rccl_op.local(x), k, 2, multi, device)
         gather_s, _ = measure(lambda: rccl_op.gather(), k, 2, multi, device)
-        rccl_s = (elapsed / args.steps * k) if mode != "fused" else measure(lambda: rccl_op.step(x), k, 2, multi, device)[0]
+        rccl_s = (rccl_elapsed / args.steps * k) if rccl_elapsed is not None else measure(lambda: rccl_op.step(x), k, 2, multi, device)[0]
         # Throughput form of the fused step (independent right-hand sides: the wait for step k-1 sits between the
         # expand and the reduce of step k, so link time and expand overlap).  A diagnostic next to the timed, dependent
         # form: never the metric value, and any failure here leaves the line as it is.
         pipe_ms, pipe_ok = None, None
-        if mode == "fused":
+        fop = fused_op  # (valid, whether or not it is the timed path)
+        if fop is not None:
             # every collective below is executed by every rank whatever happened locally: a rank whose local part raised
             # (say a barrier time-out reported by check_status) only lowers the flag that is reduced at the end
             failed, y_p, same = None, None, 0
@@ -405,21 +477,21 @@ def main():
 
             def warm():
                 for _ in range(2):
-                    op.step_pipelined(x)
-                op.flush()
+                    fop.step_pipelined(x)
+                fop.flush()
                 torch.cuda.synchronize()
 
             def timed():
                 for _ in range(k):
-                    op.step_pipelined(x)
-                y = op.flush()
+                    fop.step_pipelined(x)
+                y = fop.flush()
                 torch.cuda.synchronize()
                 return y
 
             def compare():
-                op.check_status()
+                fop.check_status()
                 y_keep = y_p.clone()
-                y_d = op.step(x)
+                y_d = fop.step(x)
                 torch.cuda.synchronize()
                 return int(torch.equal(y_keep, y_d))
 
@@ -441,7 +513,7 @@ def main():
         # chunk behind the expand of step j + 1.  A diagnostic like the pipelined form (the timed step multiplies a fixed
         # x and ends in the barrier), checked against the barrier chain's bits; any failure leaves the line as it is.
         chunk_ms, chunk_ok, chunk_wait_us = None, None, None
-        if mode == "fused" and getattr(op, "chunks", 0):
+        if fop is not None and getattr(fop, "chunks", 0):
             failed, same = None, 0
 
             def local2(fn):
@@ -456,25 +528,25 @@ def main():
             def chain(n_steps, barrier):
                 # (x in [0, 1): |y| grows ~2.5x per step -- alpha keeps a long chain in range)
                 if barrier:
-                    y = op.step(x)
+                    y = fop.step(x)
                     for _ in range(n_steps - 1):
-                        y = op.step(y.clone())
+                        y = fop.step(y.clone())
                     return y.clone()
-                y = op.step_dependent(x, alpha=1.0 if n_steps <= 8 else 0.4)
+                y = fop.step_dependent(x, alpha=1.0 if n_steps <= 8 else 0.4)
                 for _ in range(n_steps - 1):
-                    y = op.step_dependent(alpha=1.0 if n_steps <= 8 else 0.4)
-                y = op.flush_chain()
+                    y = fop.step_dependent(alpha=1.0 if n_steps <= 8 else 0.4)
+                y = fop.flush_chain()
                 torch.cuda.synchronize()
                 return y
 
             def check():
                 a, b = chain(4, True), chain(4, False).clone()
-                op.check_status()
+                fop.check_status()
                 return int(torch.equal(a, b))
 
             # (short time-outs while the form is being checked: across devices none of this has run before, and a flag that
             # never shows up must cost seconds, not the run; every rank goes through the same collectives whatever happened)
-            saved_timeout, op._timeout = op._timeout, 1500
+            saved_timeout, fop._timeout = fop._timeout, 1500
             same = local2(check) or 0
             okc = torch.tensor([0 if failed is not None else same], dtype=torch.int32, device=device)
             dist.all_reduce(okc, op=dist.ReduceOp.MIN)
@@ -488,11 +560,11 @@ def main():
             dist.barrier()
             el = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=device)
             dist.all_reduce(el, op=dist.ReduceOp.MAX)
-            wait_t = torch.tensor([local2(lambda: op.chunk_wait_us()) or 0.0], dtype=torch.float64, device=device)
+            wait_t = torch.tensor([local2(lambda: fop.chunk_wait_us()) or 0.0], dtype=torch.float64, device=device)
             dist.all_reduce(wait_t, op=dist.ReduceOp.MAX)
             okc = torch.tensor([0 if (failed is not None or not go) else 1], dtype=torch.int32, device=device)
             dist.all_reduce(okc, op=dist.ReduceOp.MIN)
-            op._timeout = saved_timeout
+            fop._timeout = saved_timeout
             if failed is not None:
                 print(f"[bench] rank {rank}: chunked dependent chain not measured: {failed}", file=sys.stderr)
             chunk_ok = bool(int(okc.item()))
@@ -502,19 +574,32 @@ def main():
             torch.cuda.synchronize()
             dist.barrier()
             if not chunk_ok:
-                op._chunk_status.zero_()
-                op._chained = False
+                fop._chunk_status.zero_()
+                fop._chained = False
                 torch.cuda.synchronize()
                 dist.barrier()
             chunk_ms = float(el.item()) / k * 1e3 if chunk_ok else None
             chunk_wait_us = float(wait_t.item())
-        diag = {"mode_timed": mode, "local_spmv_ms": local_s / k * 1e3, "local_spmv_event_ms": local_ev,
+        fused_ms = fused_elapsed / args.steps * 1e3 if fused_elapsed is not None else None
+        local_ms = local_s / k * 1e3
+        shard_bytes = float(max(bounds[r + 1] - bounds[r] for r in range(world)) * tsize)
+        # what one link and direction carried per second if the step time beyond the local kernels was all link time (every
+        # rank stores its shard to each of the N - 1 peers over that peer's own link): a floor for the link rate, null when
+        # the exchange hid behind the kernels or nothing crossed a link
+        link_gbs = (shard_bytes / ((fused_ms - local_ms) * 1e-3) / 1e9
+                    if (fused_ms is not None and world > 1 and not args.debug_one_gpu and fused_ms > local_ms) else None)
+        diag = {"mode_timed": mode, "path_used": "fused" if mode == "fused" else "rccl",
+                "local_spmv_ms": local_ms, "local_spmv_event_ms": local_ev,
                 "rccl_nranks": dist.get_world_size(), "backend": dist.get_backend(),
-                "chunks": getattr(op, "chunks", 0) if mode == "fused" else 0,
-                "fused_chunked_step_ms": chunk_ms, "fused_chunked_check": chunk_ok, "expand_wait_us": chunk_wait_us,
+                "chunks": getattr(fop, "chunks", 0) if fop is not None else 0,
+                "chunked_step_ms": chunk_ms, "fused_chunked_step_ms": chunk_ms, "fused_chunked_check": chunk_ok,
+                "expand_wait_us": chunk_wait_us,
                 "fused_pipelined_step_ms": pipe_ms, "fused_pipelined_check": pipe_ok,
                 "gather_ms": gather_s / k * 1e3, "rccl_step_ms": rccl_s / k * 1e3,
-                "fused_step_ms": elapsed / args.steps * 1e3 if mode == "fused" else None,
+                "fused_step_ms": fused_ms,
+                "fused_check": (None if args.fused != "auto" else bool(fused_op is not None and fused_post_check)),
+                "fused_failure": str(fused_fail) if fused_fail is not None else None,
+                "link_gbs_estimate": link_gbs,
                 "fused_post_check": fused_post_check,
                 "gather": getattr(rccl_op, "gather_mode", "inplace"),
                 "rows_per_rank": [bounds[r + 1] - bounds[r] for r in range(world)],
@@ -664,7 +749,10 @@ def main():
             exit_code = 3
     if multi:
         if fused_op is not None:
-            fused_op.check_status()
+            try:
+                fused_op.check_status()
+            except Exception as e:  # noqa: BLE001 - a diagnostic form of the fused step timed out: reported, not fatal
+                print(f"[bench] rank {rank}: {e}", file=sys.stderr)
             fused_op.close()
         dist.destroy_process_group()
     return exit_code

@@ -12,6 +12,8 @@ xGMI is point-to-point (7 links x ~153 GB/s per GPU): an all-gather moves each s
 once over each link, so bigger, fewer collectives win; y shards are gathered in a single
 call, in place when the shards are equal-sized.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -556,11 +558,19 @@ class FusedShardedSpMV:
                                                     self.bounds[self.rank], self.stripes), "spmv_step_bcast")
         if events is not None:
             events[0][1].record()
-        api.check(lib.spblas_gfx950_step_signal(h, ct.c_void_p(self._tabs[2].data_ptr()), self.world, self.rank,
-                                                self._step), "step_signal")
+        if not self._muted():
+            api.check(lib.spblas_gfx950_step_signal(h, ct.c_void_p(self._tabs[2].data_ptr()), self.world, self.rank,
+                                                    self._step), "step_signal")
         api.check(lib.spblas_gfx950_step_wait(h, ct.c_void_p(self.flags.data_ptr()), self.world, self._step,
                                               self._timeout, ct.c_void_p(self._status.data_ptr())), "step_wait")
         return self.y[b]
+
+    def _muted(self):
+        """Test hook (tests/test_gpu_fused_sharding.py): SPBLAS_GFX950_TEST_MUTE_RANK=r makes rank r stop publishing its step
+        flag after step SPBLAS_GFX950_TEST_MUTE_AFTER (default 0: never publishes) -- what a dead link or a lost flag store
+        looks like to the peers, whose bounded waits must time out and whose callers must fall back."""
+        r = os.environ.get("SPBLAS_GFX950_TEST_MUTE_RANK")
+        return r is not None and int(r) == self.rank and self._step > int(os.environ.get("SPBLAS_GFX950_TEST_MUTE_AFTER", "0"))
 
     def step_pipelined(self, x):
         """Throughput form of step() for INDEPENDENT right-hand sides (back-to-back SpMVs whose x does not depend on the

@@ -68,12 +68,17 @@ def test_bench_multi_gpu_code_path_with_one_rank(gpu, fused):
     assert r.returncode == 0 and len(lines) == 1, (r.stdout[-2000:], r.stderr[-2000:])
     out = json.loads(lines[0])
     assert out["value"] > 0 and out["steps"] == 5
-    assert ("fused into the reduce kernels" in out["config"]["parallelism"]) == (fused == "auto")
     mg = out["multi_gpu"]  # where the step time goes: one SCALE run must be diagnostic
-    assert mg["mode_timed"] == ("fused" if fused == "auto" else "plain")
+    # (round 5: the RCCL path is always timed; the fused path is the timed one when it is valid AND faster)
+    assert mg["mode_timed"] in (("fused", "plain") if fused == "auto" else ("plain",))
+    assert mg["path_used"] == ("fused" if mg["mode_timed"] == "fused" else "rccl")
+    assert ("fused into the reduce kernels" in out["config"]["parallelism"]) == (mg["mode_timed"] == "fused")
     assert mg["local_spmv_ms"] > 0 and mg["gather_ms"] >= 0 and mg["rccl_step_ms"] > 0
     assert (mg["fused_step_ms"] is not None) == (fused == "auto")
+    assert mg["fused_check"] is (True if fused == "auto" else None)
     assert mg["fused_post_check"] is (True if fused == "auto" else None)   # fused results re-checked after the timed loop
+    want = min(mg["rccl_step_ms"], mg["fused_step_ms"]) if fused == "auto" else mg["rccl_step_ms"]
+    assert abs(out["ms_per_step"] - want) <= 1e-6 * want + 1e-9  # the faster valid path is the published number
 
 
 def test_bench_cfg4_rmat_multi_gpu_code_path_with_one_rank(gpu):
@@ -144,9 +149,11 @@ def test_bench_with_several_ranks_on_one_gpu(gpu, world, workload, fused):
     mg = out["multi_gpu"]
     assert len(mg["rows_per_rank"]) == world and sum(mg["rows_per_rank"]) == out["config"]["rows"]
     if workload == "spmv":
-        assert mg["mode_timed"] == ("fused" if fused == "auto" else "plain")
+        assert mg["mode_timed"] in (("fused", "plain") if fused == "auto" else ("plain",))
         assert mg["fused_post_check"] is (True if fused == "auto" else None)
+        assert mg["backend"] == "gloo" and mg["rccl_nranks"] == world and mg["rccl_step_ms"] > 0
         if fused == "auto":  # the throughput form is measured next to the timed one and reproduces its bits
+            assert mg["fused_check"] is True and mg["fused_step_ms"] > 0 and mg["chunked_step_ms"] is not None
             assert mg["fused_pipelined_step_ms"] > 0 and mg["fused_pipelined_check"] is True
     else:
         assert len(set(mg["rows_per_rank"])) > 1 and mg["gather"] == "p2p"   # nnz-prefix shards differ in rows
@@ -165,3 +172,24 @@ def test_bench_secondary_workloads_check_themselves(gpu, workload, rows):
     out = json.loads(lines[0])
     assert out["parity_check"] == "pass", out["parity"]
     assert out["roofline"]["kernel"] and out["value"] > 0
+
+
+@pytest.mark.parametrize("mute_after", [0, 12])
+def test_bench_falls_back_to_rccl_when_a_rank_stops_publishing_its_flags(gpu, mute_after):
+    """First-contact safety of the SCALE run: a rank whose step flag never reaches its peers (mute_after = 0: from the
+    first fused step, so the validation in try_fused already fails) or stops reaching them in the middle of the timed fused
+    loop (mute_after = 12: after validation and probe) must cost bounded waits, not a hang: every rank falls back to the
+    RCCL path collectively, the line carries the RCCL number as ms_per_step, fused_check false, parity pass, exit code 0."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(SPBLAS_GFX950_TEST_MUTE_RANK="1", SPBLAS_GFX950_TEST_MUTE_AFTER=str(mute_after))
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--debug-one-gpu", "--steps", "5", "--warmup", "2",
+           "--rows", "1200000", "--fused", "auto", "--flag-chunks", "0"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.stdout[-2000:], r.stderr[-3000:])
+    out = json.loads(lines[0])
+    mg = out["multi_gpu"]
+    assert out["parity_check"] == "pass" and mg["path_used"] == "rccl" and mg["mode_timed"] == "plain"
+    assert mg["fused_check"] is False and mg["fused_step_ms"] is None
+    assert abs(out["ms_per_step"] - mg["rccl_step_ms"]) <= 1e-6 * mg["rccl_step_ms"] + 1e-9
