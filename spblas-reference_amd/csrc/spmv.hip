@@ -762,7 +762,11 @@ int spblas_gfx950_spmv_plan_create(spblas_gfx950_handle_t handle, spblas_gfx950_
     const int rc2 = spmv_sliced_build(handle, pl, values, true);
     if (rc2 == SPBLAS_GFX950_STATUS_SUCCESS) {
       bool keep = true;
-      if (pl->s_uncertain || pl->refresh_each_call)
+      // (the copying form of a refreshing plan pays a value refresh per multiply and is only kept when it beats the
+      // row-block kernel in a timed trial; the value-free form costs what a snapshot plan costs plus the window reads --
+      // 0.37 against 1.71 ms at cfg2 -- and is decided by the same static rules as a snapshot plan: no trial, whose two
+      // row-block multiplies alone were 3.4 of the 10 ms of this inspect)
+      if (pl->s_uncertain || (pl->refresh_each_call && !pl->vfree))
         (void) auto_trial(handle, pl, values, &keep);
       if (keep) {
         pl->alg = SPBLAS_GFX950_SPMV_SLICED;

@@ -330,23 +330,84 @@ template <typename O>
 __global__ __launch_bounds__(256) void pb_count_kernel(int64_t m, const O* __restrict__ rowptr,
                                                        const int32_t* __restrict__ colind, int W, int H, int S, int NB,
                                                        int32_t* __restrict__ cnt, int hub_len,
-                                                       const int32_t* __restrict__ binrow) {
-  extern __shared__ int hist[];  // [S]
+                                                       const int32_t* __restrict__ binrow,
+                                                       uint16_t* __restrict__ wpart) {
+  // wpart != nullptr (round 5, plans whose scatter stages in order: one-byte row codes): the counts are taken per PART of
+  // the bin as well -- part w = the positions [w L, (w + 1) L) the w-th wavefront of the staged scatter owns -- so that the
+  // scatter need not walk the bin's columns once more just to count them: wpart[(bin * 16 + w) * S + slice]
+  extern __shared__ int hist[];  // [S] (+ [16][S] per part)
   const int wb = blockIdx.x;
-  for (int i = threadIdx.x; i < S; i += 256)
+  const int nh = wpart ? 17 * S : S;
+  for (int i = threadIdx.x; i < nh; i += 256)
     hist[i] = 0;
   __syncthreads();
   int64_t r0, r1;
   pb_bin_rows(binrow, wb, H, m, &r0, &r1);
   if (r0 < m) {
     const O p0 = rowptr[r0], p1 = rowptr[r1];
-    for (O p = p0 + threadIdx.x; p < p1; p += 256) {
-      if (hub_len > 0) {
+    if (hub_len <= 0) {
+      // four columns per lane and load (round 5: one 4-byte load and one integer division per entry made this pass 150 us at
+      // cfg2 -- 2.7 TB/s); the slice comes from a float reciprocal with one correction step, exact for S <= 16 384 slices
+      const float inv_w = 1.0f / (float) W;
+      auto slice_of = [&](int c) {
+        int sl = (int) ((float) c * inv_w);
+        if (sl * W > c)
+          --sl;
+        else if ((sl + 1) * W <= c)
+          ++sl;
+        return sl;
+      };
+      O pa = (p0 + 3) & ~(O) 3;  // first 16-byte aligned position (colind itself is at least 16-byte aligned: hipMalloc / torch)
+      if ((reinterpret_cast<uintptr_t>(colind) & 15) != 0 || pa > p1)
+        pa = p1;
+      const O pb = pa + ((p1 - pa) & ~(O) 3);
+      // (per-part histograms: the total per slice is summed from them below)
+      const int ne = (int) (p1 - p0);
+      const int L = (((ne + 15) / 16) + 63) & ~63;  // = the staged scatter's share of one wavefront
+      const float inv_l = 1.0f / (float) (L > 0 ? L : 1);
+      auto add = [&](O p, int c) {
+        if (wpart) {
+          const int q = (int) (p - p0);
+          int w = (int) ((float) q * inv_l);
+          if (w * L > q)
+            --w;
+          else if ((w + 1) * L <= q)
+            ++w;
+          atomicAdd(&hist[S + w * S + slice_of(c)], 1);
+        } else {
+          atomicAdd(&hist[slice_of(c)], 1);
+        }
+      };
+      for (O p = p0 + threadIdx.x; p < pa; p += 256)
+        add(p, colind[p]);
+      for (O p = pa + 4 * (O) threadIdx.x; p < pb; p += 4 * 256) {
+        const int4 c4 = *reinterpret_cast<const int4*>(colind + p);
+        add(p, c4.x);
+        add(p + 1, c4.y);
+        add(p + 2, c4.z);
+        add(p + 3, c4.w);
+      }
+      for (O p = pb + threadIdx.x; p < p1; p += 256)
+        add(p, colind[p]);
+      if (wpart) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < S; i += 256) {
+          int t = 0;
+          for (int w = 0; w < 16; ++w) {
+            const int c = hist[S + w * S + i];
+            wpart[((size_t) wb * 16 + w) * S + i] = (uint16_t) (c < 65535 ? c : 65535);
+            t += c;
+          }
+          hist[i] = t;
+        }
+      }
+    } else {
+      for (O p = p0 + threadIdx.x; p < p1; p += 256) {
         const int64_t r = pb_row_of(rowptr, r0, r1, p);
         if (rowptr[r + 1] - rowptr[r] > (O) hub_len)
           continue;
+        atomicAdd(&hist[colind[p] / W], 1);
       }
-      atomicAdd(&hist[colind[p] / W], 1);
     }
   }
   __syncthreads();
@@ -488,8 +549,8 @@ static constexpr int PB_STAGE_SP = 256;  // enc8: at most this many slices (per-
 // order the LDS atomic served the lanes.  Sort every such group in place by position: each lane ranks its entry inside
 // its group (a walk to both ends of the group) and the chunk is rewritten one chunk behind the reads, so that a group
 // straddling two chunks of 64 is read whole before any of it is overwritten (a group has at most 64 entries).
-template <typename T>
-__device__ __forceinline__ void pb_sort_rounds(int n, int lo, int lane, int* __restrict__ st, T* __restrict__ stv,
+template <typename T, typename Q>
+__device__ __forceinline__ void pb_sort_rounds(int n, int lo, int lane, Q* __restrict__ st, T* __restrict__ stv,
                                                uint16_t* __restrict__ stc) {
   struct item_t {
     int q, np;
@@ -504,20 +565,20 @@ __device__ __forceinline__ void pb_sort_rounds(int n, int lo, int lane, int* __r
     it.v = T(0);
     it.c = 0;
     if (j < n) {
-      it.q = st[lo + j];
+      it.q = (int) st[lo + j];
       it.v = stv[lo + j];
       it.c = stc[lo + j];
       const int gid = it.q >> 6;
       int start = j, smaller = 0;
       for (int k = j - 1; k >= 0; --k) {
-        const int qk = st[lo + k];
+        const int qk = (int) st[lo + k];
         if ((qk >> 6) != gid)
           break;
         start = k;
         smaller += qk < it.q ? 1 : 0;
       }
       for (int k = j + 1; k < n; ++k) {
-        const int qk = st[lo + k];
+        const int qk = (int) st[lo + k];
         if ((qk >> 6) != gid)
           break;
         smaller += qk < it.q ? 1 : 0;
@@ -533,7 +594,7 @@ __device__ __forceinline__ void pb_sort_rounds(int n, int lo, int lane, int* __r
     if (ch + 1 < nch)
       nxt = load(ch + 1);
     if (cur.np >= 0 && cur.np != ch * 64 + lane) {
-      st[lo + cur.np] = cur.q;
+      st[lo + cur.np] = (Q) cur.q;
       stv[lo + cur.np] = cur.v;
       stc[lo + cur.np] = cur.c;
     }
@@ -544,8 +605,8 @@ __device__ __forceinline__ void pb_sort_rounds(int n, int lo, int lane, int* __r
 // enc8 write-out of one staged run by one wavefront.  The run lies in the staging area sorted by source position (= by
 // row: positions grow with the row; the ordered staging of pb_scatter_staged_kernel sees to that): emit values /
 // columns / source positions in that order and the one-byte row codes, block bases and exceptions.
-template <typename T, typename RowOf>
-__device__ __forceinline__ void pb_emit_sorted_run(int n, int lo, int g, int gp, int p0, int lane, const int* __restrict__ st,
+template <typename T, typename RowOf, typename Q>
+__device__ __forceinline__ void pb_emit_sorted_run(int n, int lo, int g, int gp, int p0, int lane, const Q* __restrict__ st,
                                                    const T* __restrict__ stv, const uint16_t* __restrict__ stc, RowOf row_of,
                                                    T* __restrict__ s_val, uint16_t* __restrict__ s_col,
                                                    int32_t* __restrict__ perm, unsigned char* __restrict__ s_code,
@@ -557,7 +618,7 @@ __device__ __forceinline__ void pb_emit_sorted_run(int n, int lo, int g, int gp,
   for (int j0 = 0; j0 < nb * PB_BLK; j0 += 64) {
     const int j = j0 + lane;
     const bool valid = j < n;
-    const int qq = valid ? st[lo + j] : 0;
+    const int qq = valid ? (int) st[lo + j] : 0;
     const int r = valid ? row_of(qq) : 0;
     const int bi = lane & (PB_BLK - 1);  // j0 is a multiple of 64, 64 a multiple of the block
     // D_j = 255 bi + min over the block's entries k <= j of (r_k - 255 k): the decoder's position after entry j
@@ -601,7 +662,10 @@ __device__ __forceinline__ void pb_emit_sorted_run(int n, int lo, int g, int gp,
   }
 }
 
-template <typename T, typename O, bool ENC8>
+// Q16 (round 5): positions inside the bin, row offsets and the row table are staged as 16-bit words (the build checked that
+// no bin's window holds 65 536 entries or more): 8 instead of 10 bytes per staged fp32 entry and 12 KB of tables less --
+// cfg2's bins of 48 830 entries go through LDS in three passes instead of five (each pass walks all of the bin's columns)
+template <typename T, typename O, bool ENC8, bool Q16>
 __global__ __launch_bounds__(PB_STAGE_THREADS) void pb_scatter_staged_kernel(
     int64_t m, const O* __restrict__ rowptr, const int32_t* __restrict__ colind, const T* __restrict__ values, int W,
     int H, int S, int NB, const int32_t* __restrict__ cnt, const int32_t* __restrict__ aoff,
@@ -611,7 +675,7 @@ __global__ __launch_bounds__(PB_STAGE_THREADS) void pb_scatter_staged_kernel(
     unsigned char* __restrict__ s_code, typename pb_hdr<T>::type* __restrict__ s_hdr, unsigned* __restrict__ exc_idx,
     uint16_t* __restrict__ exc_row, int32_t* __restrict__ exc_cnt, int exc_cap, int32_t* __restrict__ enc_fail,
     const int32_t* __restrict__ eoff, int32_t* __restrict__ blksrc, const int32_t* __restrict__ bin_order,
-    uint16_t* __restrict__ s_src) {
+    uint16_t* __restrict__ s_src, const uint16_t* __restrict__ wpart) {
   constexpr int PB_BLK = pb_geom<T>::BLK;
   __shared__ int exc_n;
   if (ENC8 && threadIdx.x == 0)
@@ -621,13 +685,14 @@ __global__ __launch_bounds__(PB_STAGE_THREADS) void pb_scatter_staged_kernel(
   int* gdst = lcnt + S;                      // [S] first A' position of the run
   int* pdst = gdst + S;                      // [S] first P position of the run
   int* lcur = pdst + S;                      // [S] staging cursor (local offset, advanced by the atomics)
-  int* rp = lcur + S;                        // [H + 1] the bin's row offsets relative to its first entry
-  int* rt = rp + H + 1;                      // [rt_len] row of every 64th entry (narrows the row search)
+  typedef typename std::conditional<Q16, uint16_t, int>::type q_t;
   // enc8: [16 waves][PB_STAGE_SP] entries of the pass per (wave, slice) -> first staging position of that wave's part
-  int* wcnt = rt + rt_len;
-  int* st = wcnt + (ENC8 ? (PB_STAGE_THREADS / 64) * PB_STAGE_SP : 0);  // [cap] staged entries: position relative to the first entry,
-  T* stv = reinterpret_cast<T*>(st + cap);   // [cap] value,
-  uint16_t* stc = reinterpret_cast<uint16_t*>(stv + cap);  // [cap] column inside the slice
+  int* wcnt = lcur + S;
+  T* stv = reinterpret_cast<T*>(wcnt + (ENC8 ? (PB_STAGE_THREADS / 64) * PB_STAGE_SP : 0));  // [cap] staged entries: value,
+  q_t* st = reinterpret_cast<q_t*>(stv + cap);  // [cap] position relative to the bin's first entry,
+  uint16_t* stc = reinterpret_cast<uint16_t*>(st + cap);  // [cap] column inside the slice
+  q_t* rp = reinterpret_cast<q_t*>(stc + cap);  // [H + 1] the bin's row offsets relative to its first entry
+  q_t* rt = rp + H + 1;                         // [rt_len] row of every 64th entry (narrows the row search)
   __shared__ int pass_end, pass_direct;
   // bin_order (row-skewed matrices): the bins heaviest first -- a bin of 131 k entries makes 13 staging passes over all
   // of them, a light one a single pass over 10 k, and a heavy bin that starts last finishes alone
@@ -650,7 +715,7 @@ __global__ __launch_bounds__(PB_STAGE_THREADS) void pb_scatter_staged_kernel(
     pdst[i] = p0b * PB_BLK;
   }
   for (int i = tid; i <= nr; i += PB_STAGE_THREADS)
-    rp[i] = (int) (rowptr[r0 + i] - p0);
+    rp[i] = (q_t) (rowptr[r0 + i] - p0);
   __syncthreads();
   // the block map of the bin's runs: one wavefront per run, a lane per block
   for (int sl = wave; sl < S; sl += PB_STAGE_THREADS / 64) {
@@ -664,7 +729,7 @@ __global__ __launch_bounds__(PB_STAGE_THREADS) void pb_scatter_staged_kernel(
   auto row_between = [&](int q, int lo, int hi) {
     while (hi - lo > 1) {
       const int mid = (lo + hi) >> 1;
-      if (rp[mid] <= q)
+      if ((int) rp[mid] <= q)
         lo = mid;
       else
         hi = mid;
@@ -677,14 +742,14 @@ __global__ __launch_bounds__(PB_STAGE_THREADS) void pb_scatter_staged_kernel(
   const bool use_rt = nblk + 1 <= rt_len;
   if (use_rt) {
     for (int k = tid; k <= nblk; k += PB_STAGE_THREADS)
-      rt[k] = k < nblk ? row_between(k << 6, 0, nr) : (nr > 0 ? nr - 1 : 0);
+      rt[k] = (q_t) (k < nblk ? row_between(k << 6, 0, nr) : (nr > 0 ? nr - 1 : 0));
     __syncthreads();
   }
   auto row_of = [&](int q) {
     if (!use_rt)
       return row_between(q, 0, nr);
     const int k = q >> 6;
-    return row_between(q, rt[k], rt[k + 1] + 1);
+    return row_between(q, (int) rt[k], (int) rt[k + 1] + 1);
   };
   // slice of column c (exact: float reciprocal + one correction step; S <= 256 slices keep the quotient far inside the
   // float's 24 bits), or -1 for an entry of a hub row that stays out of the tiles
@@ -697,7 +762,7 @@ __global__ __launch_bounds__(PB_STAGE_THREADS) void pb_scatter_staged_kernel(
       ++sl;
     if (hub_len > 0) {
       const int r = row_of(q);
-      if (rp[r + 1] - rp[r] > hub_len)
+      if ((int) rp[r + 1] - (int) rp[r] > hub_len)
         return -1;
     }
     return sl;
@@ -711,6 +776,10 @@ __global__ __launch_bounds__(PB_STAGE_THREADS) void pb_scatter_staged_kernel(
       wcnt[i] = 0;
     __syncthreads();
     constexpr int CU4 = 8;
+    if (wpart) {  // counted by pb_count_kernel already (same partition of the bin's positions): 8 KB instead of a walk
+      for (int i = tid; i < NW * S; i += PB_STAGE_THREADS)
+        wcnt[(i / S) * PB_STAGE_SP + i % S] = (int) wpart[((size_t) wb * NW) * S + i];
+    } else
     for (int qb = qlo; qb < qhi; qb += 64 * CU4) {
       int cbuf[CU4];
 #pragma unroll
@@ -801,17 +870,32 @@ __global__ __launch_bounds__(PB_STAGE_THREADS) void pb_scatter_staged_kernel(
           const int q = qb + 64 * u + lane;
           cbuf[u] = colind[p0 + (q < qhi ? q : qhi - 1)];
         }
+        // the values of the entries this pass places: predicated loads, all CU4 rounds in flight BEFORE the first LDS
+        // atomic (round 5: a load inside the placing branch was waited for round by round -- 48 dependent round trips to
+        // memory per wavefront and pass, most of the 2.2 ms of this kernel at cfg2)
+        int slb[CU4];
+        T vbuf[CU4];
 #pragma unroll
         for (int u = 0; u < CU4; ++u) {
           const int q = qb + 64 * u + lane;
-          const int c = cbuf[u];
-          const int sl = q < qhi ? slice_of(q, c) : -1;
-          if (sl >= s0 && sl < s1) {
+          const int sl = q < qhi ? slice_of(q, cbuf[u]) : -1;
+          slb[u] = (sl >= s0 && sl < s1) ? sl : -1;
+        }
+        if (!s_src) {
+#pragma unroll
+          for (int u = 0; u < CU4; ++u)
+            vbuf[u] = slb[u] >= 0 ? values[p0 + qb + 64 * u + lane] : T(0);
+        }
+#pragma unroll
+        for (int u = 0; u < CU4; ++u) {
+          const int q = qb + 64 * u + lane;
+          const int sl = slb[u];
+          if (sl >= 0) {
             const int pos = atomicAdd(&mycur[sl], 1);
-            st[pos] = q;
+            st[pos] = (q_t) q;
             if (!s_src)
-              stv[pos] = values[p0 + q];
-            stc[pos] = (uint16_t) (c - sl * W);
+              stv[pos] = vbuf[u];
+            stc[pos] = (uint16_t) (cbuf[u] - sl * W);
           }
         }
       }
@@ -839,7 +923,7 @@ __global__ __launch_bounds__(PB_STAGE_THREADS) void pb_scatter_staged_kernel(
       int r = -1;
       if (hub_len > 0 || direct) {
         r = row_of(q);
-        if (hub_len > 0 && rp[r + 1] - rp[r] > hub_len)
+        if (hub_len > 0 && (int) rp[r + 1] - (int) rp[r] > hub_len)
           continue;
       }
       const int pos = atomicAdd(&lcur[sl], 1);
@@ -857,7 +941,7 @@ __global__ __launch_bounds__(PB_STAGE_THREADS) void pb_scatter_staged_kernel(
         }
         s_row[pdst[sl] + pos] = (uint16_t) r;
       } else {
-        st[pos] = q;
+        st[pos] = (q_t) q;
         if (!s_src)
           stv[pos] = values[p0 + q];  // neighbouring threads: neighbouring addresses
         stc[pos] = (uint16_t) (c - sl * W);
@@ -899,7 +983,7 @@ __global__ __launch_bounds__(PB_STAGE_THREADS) void pb_scatter_staged_kernel(
           continue;
         }
         for (int j = lane; j < n; j += 64) {
-          const int q = st[lo + j];
+          const int q = (int) st[lo + j];
           s_col[g + j] = stc[lo + j];
           if (s_src) {
             s_src[gp + j] = (uint16_t) q;
@@ -1467,10 +1551,19 @@ __global__ __launch_bounds__(PB_FTHREADS) void pb_flag_dups8_kernel(int Hw, int6
   if (wb >= NBw)
     return;
   const int g0 = binblk[wb] / PB_GBLK, g1 = binblk[wb + 1] / PB_GBLK;
+  if (g0 >= g1)
+    return;
+  unsigned cw_n = *reinterpret_cast<const unsigned*>(s_code + (int64_t) g0 * PB_GRP + 4 * lane);
+  typename pb_hdr<T>::type hd_n = s_hdr[(int64_t) g0 * PB_GBLK + lane / LPB];
   for (int g = g0; g < g1; ++g) {
-    const unsigned cw = *reinterpret_cast<const unsigned*>(s_code + (int64_t) g * PB_GRP + 4 * lane);
+    // (the next group's words are on their way while this one goes through the tag array: one wave per bin and a load ->
+    // LDS -> store chain per group made this kernel 190 us at cfg2)
+    const unsigned cw = cw_n;
     const int64_t blk = (int64_t) g * PB_GBLK + lane / LPB;
-    const typename pb_hdr<T>::type hd = s_hdr[blk];
+    const typename pb_hdr<T>::type hd = hd_n;
+    const int gn = g + 1 < g1 ? g + 1 : g;
+    cw_n = *reinterpret_cast<const unsigned*>(s_code + (int64_t) gn * PB_GRP + 4 * lane);
+    hd_n = s_hdr[(int64_t) gn * PB_GBLK + lane / LPB];
     unsigned row[4];
     bool skip[4];
     pb_decode_rows<LPB>(cw, pb_hdr<T>::base(hd), lane, (unsigned) Hw, row, skip);
@@ -1980,12 +2073,15 @@ static const void* pb_reduce_vf_fn(int nw, int ub, bool enc8) {
 // widest bin window of the arithmetic bin grid: max over b of rowptr[min((b + 1) H, m)] - rowptr[b H]
 template <typename O>
 __global__ __launch_bounds__(256) void pb_bin_span_kernel(int64_t m, int H, int64_t NB, const O* __restrict__ rowptr,
-                                                          unsigned long long* __restrict__ out) {
+                                                          unsigned long long* __restrict__ out,
+                                                          const int32_t* __restrict__ binrow = nullptr) {
   const int64_t b = (int64_t) blockIdx.x * 256 + threadIdx.x;
   unsigned long long span = 0;
   if (b < NB) {
-    const int64_t r0 = b * H, r1 = (r0 + H) < m ? (r0 + H) : m;
-    span = (unsigned long long) (rowptr[r1] - rowptr[r0]);
+    int64_t r0, r1;
+    pb_bin_rows(binrow, b, H, m, &r0, &r1);
+    if (r0 < m)
+      span = (unsigned long long) (rowptr[r1] - rowptr[r0]);
   }
   for (int o = 32; o > 0; o >>= 1) {
     const unsigned long long u = __shfl_xor(span, o, 64);
@@ -2625,8 +2721,15 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
     if (rc_h)
       return rc_h;
   }
-  hipLaunchKernelGGL((pb_count_kernel<O>), dim3((unsigned) NB), dim3(256), (size_t) S * 4, s, m, rowptr, pl->colind, W, H, S,
-                     NB, cnt, pl->hub_len, binrow);
+  // plans that are going to stage their scatter in order (one-byte row codes: large, at most PB_STAGE_SP slices, no rows
+  // left out of the tiles) have the count pass count per part of the bin as well: the scatter then skips its own counting walk
+  uint16_t* wpart = nullptr;
+  if (S <= PB_STAGE_SP && pl->hub_len == 0 && NB >= 1536 && nnz >= ((int64_t) 32 << 20) && env_int("SPBLAS_GFX950_PB_ENC8", 1) &&
+      env_int("SPBLAS_GFX950_PB_STAGED_SCATTER", 1) && env_int("SPBLAS_GFX950_PB_WPART", 1) &&
+      dev_alloc((void**) &wpart, (size_t) NB * 16 * S * 2, s) != SPBLAS_GFX950_STATUS_SUCCESS)
+    wpart = nullptr;
+  hipLaunchKernelGGL((pb_count_kernel<O>), dim3((unsigned) NB), dim3(256), (size_t) S * 4 * (wpart ? 17 : 1), s, m, rowptr,
+                     pl->colind, W, H, S, NB, cnt, pl->hub_len, binrow, wpart);
   tr.mark("count kernel");
   // One probe pass over the counters, read back once: entries per slice, non-empty tiles per slice, entries
   // per bin group.  AUTO uses them to decline matrices the plan does not suit; the work lists below use them
@@ -2634,20 +2737,35 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
   const int64_t ngroups = cdiv(NB, RW);
   std::vector<unsigned long long> h_sum((size_t) (2 * S + ngroups + S));  // ..., then the longest run per slice
   unsigned long long* d_sum = nullptr;
-  if ((rc = dev_alloc((void**) &d_sum, h_sum.size() * sizeof(unsigned long long), s)))
+  if ((rc = dev_alloc((void**) &d_sum, h_sum.size() * sizeof(unsigned long long), s))) {
+    dev_free(wpart, s);
     return rc;
+  }
   struct temp_guard {  // inspect temporaries are released on every exit path
     hipStream_t s;
-    void* p[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    void* p[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     ~temp_guard() {
       for (void* q : p)
         dev_free(q, s);
     }
   } temps{s};
   temps.p[0] = d_sum;
+  temps.p[7] = wpart;
   hipLaunchKernelGGL(pb_balance_kernel, dim3((unsigned) (S + ngroups)), dim3(256), 0, s, S, NB, RW, cnt, d_sum,
                      d_sum + S, d_sum + 2 * S, d_sum + 2 * S + ngroups);
   if ((rc = readback_add(h, h_sum.data(), d_sum, h_sum.size() * sizeof(unsigned long long))))
+    return rc;
+  // widest window of the caller's arrays a bin covers (entries of its rows, hub rows included): decides whether the staged
+  // scatter may keep positions as 16-bit words
+  unsigned long long* d_span = nullptr;
+  unsigned long long h_span = ~0ull;
+  if ((rc = dev_alloc((void**) &d_span, sizeof(unsigned long long), s)))
+    return rc;
+  temps.p[6] = d_span;
+  SPB_HIP(hipMemsetAsync(d_span, 0, sizeof(unsigned long long), s));
+  hipLaunchKernelGGL((pb_bin_span_kernel<O>), dim3((unsigned) cdiv(NB, 256)), dim3(256), 0, s, m, H, (int64_t) NB, rowptr, d_span,
+                     binrow);
+  if ((rc = readback_add(h, &h_span, d_span, sizeof(h_span))))
     return rc;
   // the block offsets of both orders are computed meanwhile (the probe read-back below is the only wait)
   if ((rc = dev_alloc((void**) &aoff, (size_t) (nseg + 1) * 4, s)))
@@ -2809,7 +2927,10 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
   } else {
     SPB_HIP(hipMemsetD16Async(reinterpret_cast<hipDeviceptr_t>(pl->s_lrow), (unsigned short) H, (size_t) (p_pad + PB_GRP), s));
   }
-  SPB_HIP(hipMemsetAsync(pl->s_products, 0, (size_t) (p_pad + PB_GRP) * sizeof(T), s));
+  // (the product stream needs no clearing: the expand writes every block of every run, and what lies between -- the pads that
+  // round a bin up to whole groups -- is only ever added to a dummy accumulator; 0.43 GB of memset at cfg2)
+  if (env_int("SPBLAS_GFX950_PB_CLEAR", 0))
+    SPB_HIP(hipMemsetAsync(pl->s_products, 0, (size_t) (p_pad + PB_GRP) * sizeof(T), s));
   tr.mark("plan arrays allocated + cleared");
   pl->n_ksplit = pick_ksplit(NB, NB > 0 ? p_blocks / PB_GBLK / NB : 0);
   {
@@ -2932,8 +3053,9 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
     }
   }
   tr.mark("work lists");
-  // a quarter of the staging area at most goes to the row table (one entry per 64 matrix entries of a bin)
-  const int rt_len = 2048;
+  // the row table: one entry per 64 matrix entries of a bin (a bin too long for it searches all of its rows), at most 2 048
+  const bool q16 = h_span < 65536ull && H < 65536 && env_int("SPBLAS_GFX950_PB_STAGE_Q16", 1);
+  const int rt_len = (int) std::min<unsigned long long>(2048, ((h_span >> 6) + 2 + 63) & ~63ull);
   // bins in the order the scatter should take them: groups of RW bins by weight, heaviest first (variable-height bins with
   // more bins than CUs only; the weights are the group sums of the probe)
   int32_t* bin_order_dev = nullptr;
@@ -2956,14 +3078,17 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
       return rc;
   }
   auto stage_cap = [&](bool e8) {
-    return (int) (((size_t) PB_STAGE_LDS - (size_t) 16 * S - (size_t) 4 * (H + 1) - (size_t) 4 * rt_len - 128 -
+    const size_t qb = q16 ? 2 : 4;  // bytes per staged position / row offset / row table entry
+    return (int) (((size_t) PB_STAGE_LDS - (size_t) 16 * S - qb * (size_t) (H + 1) - qb * (size_t) rt_len - 256 -
                    (e8 ? (size_t) (PB_STAGE_THREADS / 64) * PB_STAGE_SP * 4 : 0)) /
-                  (6 + sizeof(T))) & ~7;
+                  (qb + 2 + sizeof(T))) & ~7;
   };
   auto launch_staged = [&](bool e8) {
     const int cap = stage_cap(e8);
-    const void* fn = e8 ? reinterpret_cast<const void*>(pb_scatter_staged_kernel<T, O, true>)
-                        : reinterpret_cast<const void*>(pb_scatter_staged_kernel<T, O, false>);
+    const void* fn = e8 ? (q16 ? reinterpret_cast<const void*>(pb_scatter_staged_kernel<T, O, true, true>)
+                               : reinterpret_cast<const void*>(pb_scatter_staged_kernel<T, O, true, false>))
+                        : (q16 ? reinterpret_cast<const void*>(pb_scatter_staged_kernel<T, O, false, true>)
+                               : reinterpret_cast<const void*>(pb_scatter_staged_kernel<T, O, false, false>));
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, PB_STAGE_LDS - 64);
     if (e != hipSuccess)
       return e;
@@ -2983,8 +3108,10 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
     int32_t* bs = static_cast<int32_t*>(pl->s_blksrc);
     const int32_t* bo = bin_order_dev;
     uint16_t* ssrc = pl->s_src;
+    // (the per-part counts are 16-bit: only with 16-bit staging is no part of a bin long enough to overflow them)
+    const uint16_t* wp = (e8 && q16) ? wpart : nullptr;
     void* args[] = {&mm, &rowptr, &ci, &vp, &W_, &H_, &S_, &NB_, &cnt_, &aoff_, &prel_, &binblk_, &sv, &sc, &sr, &pm, &bd,
-                    &hub, &cap_, &rt_, &binrow, &code, &hdr, &ei, &er, &ec, &ecap, &fail, &eoff_, &bs, &bo, &ssrc};
+                    &hub, &cap_, &rt_, &binrow, &code, &hdr, &ei, &er, &ec, &ecap, &fail, &eoff_, &bs, &bo, &ssrc, &wp};
     return hipLaunchKernel(fn, dim3((unsigned) NB), dim3(PB_STAGE_THREADS), args, (size_t) PB_STAGE_LDS - 64, s);
   };
   if (staged) {
