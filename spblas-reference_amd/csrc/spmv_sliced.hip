@@ -862,42 +862,44 @@ __global__ __launch_bounds__(PB_STAGE_THREADS) void pb_scatter_staged_kernel(
         wcnt[w * PB_STAGE_SP + sl] += lcur[sl];
       }
       __syncthreads();
-      constexpr int CU4 = 8;  // rounds whose column loads are issued together
-      for (int qb = qlo; qb < qhi; qb += 64 * CU4) {
-        int cbuf[CU4];
+      constexpr int CU4 = 8;  // rounds whose loads are issued together
+      // Columns AND values of a batch of CU4 rounds are loaded together, unconditionally, one batch ahead of the batch being
+      // placed (two register sets): nothing the placing loop waits for is a round trip to memory.  (Round 5: the value load
+      // sat inside the placing branch and was waited for round by round -- 48 dependent round trips per wavefront and pass,
+      // most of the 2.2 ms of this kernel at cfg2; with predicated loads batched behind the columns 1.42 ms; the price of
+      // loading every value in every pass is 0.8 GB of coalesced reads.)
+      auto load_batch = [&](int qb, int (&cb)[CU4], T (&vb)[CU4]) {
 #pragma unroll
         for (int u = 0; u < CU4; ++u) {
           const int q = qb + 64 * u + lane;
-          cbuf[u] = colind[p0 + (q < qhi ? q : qhi - 1)];
+          const int qq = q < qhi ? q : (qhi > qlo ? qhi - 1 : qlo < ne ? qlo : ne - 1);
+          cb[u] = colind[p0 + qq];
+          if (!s_src)
+            vb[u] = values[p0 + qq];
         }
-        // the values of the entries this pass places: predicated loads, all CU4 rounds in flight BEFORE the first LDS
-        // atomic (round 5: a load inside the placing branch was waited for round by round -- 48 dependent round trips to
-        // memory per wavefront and pass, most of the 2.2 ms of this kernel at cfg2)
-        int slb[CU4];
-        T vbuf[CU4];
+      };
+      auto place_batch = [&](int qb, const int (&cb)[CU4], const T (&vb)[CU4]) {
 #pragma unroll
         for (int u = 0; u < CU4; ++u) {
           const int q = qb + 64 * u + lane;
-          const int sl = q < qhi ? slice_of(q, cbuf[u]) : -1;
-          slb[u] = (sl >= s0 && sl < s1) ? sl : -1;
-        }
-        if (!s_src) {
-#pragma unroll
-          for (int u = 0; u < CU4; ++u)
-            vbuf[u] = slb[u] >= 0 ? values[p0 + qb + 64 * u + lane] : T(0);
-        }
-#pragma unroll
-        for (int u = 0; u < CU4; ++u) {
-          const int q = qb + 64 * u + lane;
-          const int sl = slb[u];
-          if (sl >= 0) {
+          const int sl = q < qhi ? slice_of(q, cb[u]) : -1;
+          if (sl >= s0 && sl < s1) {
             const int pos = atomicAdd(&mycur[sl], 1);
             st[pos] = (q_t) q;
             if (!s_src)
-              stv[pos] = vbuf[u];
-            stc[pos] = (uint16_t) (cbuf[u] - sl * W);
+              stv[pos] = vb[u];
+            stc[pos] = (uint16_t) (cb[u] - sl * W);
           }
         }
+      };
+      int c_a[CU4], c_b[CU4];
+      T v_a[CU4], v_b[CU4];
+      load_batch(qlo, c_a, v_a);
+      for (int qb = qlo; qb < qhi; qb += 2 * 64 * CU4) {
+        load_batch(qb + 64 * CU4, c_b, v_b);
+        place_batch(qb, c_a, v_a);
+        load_batch(qb + 2 * 64 * CU4, c_a, v_a);
+        place_batch(qb + 64 * CU4, c_b, v_b);
       }
       __syncthreads();
     } else {
