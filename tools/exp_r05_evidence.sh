@@ -1,0 +1,30 @@
+#!/bin/bash
+# Round 5, evidence at HEAD for every record the default bench line prints: one tools/profile.sh run (kernel stats + PMC passes +
+# calibration) per workload, the traffic stamped into profiles/pmc_traffic.json with the hash of the kernel source, and the
+# matrix-core counters of the SpMM panel kernel.  Usage: tools/exp_r05_evidence.sh [which ...]  (default: all)
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+cd $ROOT
+WHICH=${*:-"cfg2 plain cfg4 cfg3 banded cfg5 add transpose sptrsv mfma"}
+for w in $WHICH; do
+  case $w in
+    cfg2) bash tools/profile.sh r05x > gpurun_out/ev_$w.log 2>&1; python3 tools/stamp_traffic.py r05x >> gpurun_out/ev_$w.log 2>&1;;
+    plain) bash tools/profile.sh r05p --workload spmv_plain > gpurun_out/ev_$w.log 2>&1
+           python3 tools/stamp_traffic.py r05p spmv_plain_cfg2 spmv_sliced.hip 'pb_expand_kernel<float' 'pb_reduce_vf_kernel<float' >> gpurun_out/ev_$w.log 2>&1;;
+    cfg4) bash tools/profile.sh r05x4 --workload spmv_rmat1 > gpurun_out/ev_$w.log 2>&1
+          python3 tools/stamp_traffic.py r05x4 spmv_rmat spmv_sliced.hip 'pb_expand_kernel<double' 'pb_reduce_kernel<double' 'pb_split_finish_kernel<double' 'pb_empty_rows_kernel<double' 'pb_hot_rows_kernel<double' 'pb_hot_fixup_kernel<double' >> gpurun_out/ev_$w.log 2>&1;;
+    cfg3) bash tools/profile.sh r05a3 --workload spmm > gpurun_out/ev_$w.log 2>&1
+          python3 tools/stamp_traffic.py r05a3 spmm_cfg3 spmm.hip 'spmm_rowgroup_kernel<float' >> gpurun_out/ev_$w.log 2>&1;;
+    banded) bash tools/profile.sh r05b3 --workload spmm_banded > gpurun_out/ev_$w.log 2>&1
+          python3 tools/stamp_traffic.py r05b3 spmm_banded spmm.hip 'spmm_panel_kernel' 'spmm_rowgroup_kernel<float' >> gpurun_out/ev_$w.log 2>&1;;
+    cfg5) bash tools/profile.sh r05r5 --workload spgemm > gpurun_out/ev_$w.log 2>&1
+          python3 tools/stamp_traffic.py r05r5 spgemm_cfg5 spgemm.hip 'spg_pack_b_kernel' 'spg_direct_kernel<float, true, false>' 'spg_direct_kernel<float, true, true>' >> gpurun_out/ev_$w.log 2>&1;;
+    add) bash tools/profile.sh r05ad --workload add > gpurun_out/ev_$w.log 2>&1
+          python3 tools/stamp_traffic.py r05ad add_8f spgemm.hip 'spg_ranked_fill_kernel' >> gpurun_out/ev_$w.log 2>&1;;
+    transpose) bash tools/profile.sh r05tr --workload transpose > gpurun_out/ev_$w.log 2>&1
+          python3 tools/stamp_traffic.py r05tr transpose_8f transpose.hip 'spt_tile_rows_kernel' 'spt_count_kernel*3' 'spt_scatter_kernel<float, 8, true>' 'spt_scatter_kernel<float, 8, false>*2' 'scan_block_sums_kernel*3' 'scan_partials_kernel*3' 'scan_apply_kernel*3' 'spt_rowptr_fill_kernel' 'spt_rowptr_long_kernel' >> gpurun_out/ev_$w.log 2>&1;;
+    sptrsv) bash tools/profile.sh r05ts --workload sptrsv > gpurun_out/ev_$w.log 2>&1
+          python3 tools/stamp_traffic.py r05ts sptrsv_8f sptrsv.hip 'trsv_coop_kernel' >> gpurun_out/ev_$w.log 2>&1;;
+    mfma) bash tools/prof_mfma.sh r05 > gpurun_out/ev_$w.log 2>&1;;
+  esac
+  tail -3 gpurun_out/ev_$w.log
+done

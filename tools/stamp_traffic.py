@@ -9,8 +9,8 @@ the hash of the kernel source the profile was taken on -- run it on the same tre
     python tools/stamp_traffic.py r04e spmm_cfg3 spmm.hip 'spmm_rowgroup_kernel<float'
     python tools/stamp_traffic.py r04f spgemm_cfg5 spgemm.hip 'spg_hash_kernel<float'
 
-Each named kernel counts ONCE per step with its mean bytes per dispatch (every workload here launches each of its kernels
-once per step); a pattern that matches nothing is reported and skipped."""
+Each named kernel counts ONCE per step with its mean bytes per dispatch unless the pattern ends in `*N` (N launches per step:
+`'spt_count_kernel*3'`); a pattern that matches nothing is reported and skipped."""
 import hashlib, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
@@ -26,13 +26,16 @@ if prev and key in d:
     det[f"previous {key} ({prev})"] = {key: d[key]}
 total, parts = 0.0, {}
 for pat in pats:
+    mult = 1  # 'pattern*N': the kernel is launched N times per step (the radix passes of the transpose)
+    if "*" in pat and pat.rsplit("*", 1)[1].isdigit():
+        pat, mult = pat.rsplit("*", 1)[0], int(pat.rsplit("*", 1)[1])
     hits = [k for k in t if pat in k]
     if not hits:
         print(f"  (no kernel matches {pat!r})")
         continue
     for k in hits:
-        total += t[k]["hbm_bytes"]
-        parts[k] = [t[k]["read_bytes"], t[k]["write_bytes"]]
+        total += mult * t[k]["hbm_bytes"]
+        parts[k + (f" x{mult}" if mult != 1 else "")] = [mult * t[k]["read_bytes"], mult * t[k]["write_bytes"]]
 d[key] = total
 det[f"{key}: source"] = (f"profiles/{tag}_summary.md (rocprofv3 --pmc, separate passes, tools/profile.sh {tag}; bytes from the "
                          "request-size counters, see 'source')")
