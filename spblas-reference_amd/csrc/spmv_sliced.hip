@@ -2471,9 +2471,11 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
   const bool vf_forced = env_int("SPBLAS_GFX950_PB_VFREE", 1) == 2;  // test hook: also for small / skewed matrices
   int vfree = pl->vfree && env_int("SPBLAS_GFX950_PB_VFREE", 1) && !compact && split_len == 0 && h->bin_row_align <= 1 &&
               env_int("SPBLAS_GFX950_SLICE_ROWS", 0) <= 0;
-  int NWv = env_int("SPBLAS_GFX950_PB_VF_WAVES", 4);
+  // (eight wavefronts per bin against four: 243 against 267 us for the reduce at cfg2 -- the shorter runs of the lower bins
+  // cost less than the latency four wavefronts per CU cannot hide)
+  int NWv = env_int("SPBLAS_GFX950_PB_VF_WAVES", 8);
   if (NWv != 4 && NWv != 8)
-    NWv = 4;
+    NWv = 8;
   constexpr int VF_LDS = 160 * 1024 - 64;
   const int vf_elems = VF_LDS / (int) sizeof(T);
   int vf_rows = 0, vf_cap = 0;
