@@ -18,7 +18,9 @@ HOOKS = ["SPBLAS_GFX950_SLICE_COLS", "SPBLAS_GFX950_SLICE_ROWS", "SPBLAS_GFX950_
          "SPBLAS_GFX950_PB_HUB_LEN", "SPBLAS_GFX950_PB_COMPACT", "SPBLAS_GFX950_PB_ENC8", "SPBLAS_GFX950_PB_ENC8_FAIL",
          "SPBLAS_GFX950_PB_LPT", "SPBLAS_GFX950_PB_XITEM_DIV", "SPBLAS_GFX950_PB_RITEMS", "SPBLAS_GFX950_PB_XLDS_KB",
          "SPBLAS_GFX950_PB_STAGED_SCATTER", "SPBLAS_GFX950_PB_SPLIT_LEN", "SPBLAS_GFX950_PB_RUN_MIN", "SPBLAS_GFX950_PB_NT", "SPBLAS_GFX950_PB_TUNE_MIN",
-         "SPBLAS_GFX950_PB_HOT", "SPBLAS_GFX950_PB_HOT_MIN_PCT"]
+         "SPBLAS_GFX950_PB_HOT", "SPBLAS_GFX950_PB_HOT_MIN_PCT", "SPBLAS_GFX950_PB_VFREE", "SPBLAS_GFX950_PB_VF_ROWS",
+         "SPBLAS_GFX950_PB_VF_WAVES", "SPBLAS_GFX950_PB_VF_GRID", "SPBLAS_GFX950_PB_KEEP_SRC", "SPBLAS_GFX950_PB_KEEP_REST",
+         "SPBLAS_GFX950_PB_STAGE_Q16", "SPBLAS_GFX950_PB_WPART"]
 dev = torch.device("cuda:0")
 bad = 0
 for it in range(iters):
@@ -101,6 +103,17 @@ for it in range(iters):
         hooks["SPBLAS_GFX950_PB_HOT_MIN_PCT"] = str(int(rng.choice([0, 1, 15])))
         if os.environ.get("FUZZ_FORCE_HOT"):
             hooks["SPBLAS_GFX950_PB_HOT"], hooks["SPBLAS_GFX950_PB_HOT_MIN_PCT"] = "1", "0"
+        # round 5: value-free tiles on request (the build falls back by itself where they do not apply), bin height / waves /
+        # grid of its reduce; source positions kept or not; 16-bit staging and per-part counts of the scatter on / off
+        if rng.random() < 0.45 or os.environ.get("FUZZ_FORCE_VFREE"):
+            hooks["SPBLAS_GFX950_PB_VFREE"] = "2"
+            hooks["SPBLAS_GFX950_PB_VF_ROWS"] = str(int(rng.choice([0, 7, 64, 300, 3000])))
+            hooks["SPBLAS_GFX950_PB_VF_WAVES"] = str(int(rng.choice([4, 8])))
+            hooks["SPBLAS_GFX950_PB_VF_GRID"] = str(int(rng.choice([1, 3, 256])))
+        hooks["SPBLAS_GFX950_PB_KEEP_SRC"] = str(int(rng.choice([0, 1])))
+        hooks["SPBLAS_GFX950_PB_KEEP_REST"] = str(int(rng.choice([0, 1])))
+        hooks["SPBLAS_GFX950_PB_STAGE_Q16"] = str(int(rng.choice([0, 1])))
+        hooks["SPBLAS_GFX950_PB_WPART"] = str(int(rng.choice([0, 1])))
     os.environ.update(hooks)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     rp_dev = t(rowptr.astype(np.int64 if off64 else np.int32))
@@ -130,6 +143,14 @@ for it in range(iters):
                 A = sp.scaled(alpha, a) if alpha != 1.0 else a
                 sp.multiply(info, A, xd, y)
                 desc += " +rebound"
+            if alg == "sliced" and info.state_.sliced_info().get("value_free"):
+                desc += " [value-free]"
+                if rng.random() < 0.5:  # written in place, behind the library's back: a value-free plan reads the array as it is
+                    values = (values * dtype(2.0) - dtype(0.125)).astype(dtype)
+                    raw = a.values()
+                    torch.as_strided(raw, raw.shape, raw.stride()).data.copy_(t(values))
+                    sp.multiply(info, A, xd, y)
+                    desc += " +in place"
         torch.cuda.synchronize()
         yh = y.cpu().numpy()
         rp32 = rowptr.astype(np.int32)
