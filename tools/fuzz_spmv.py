@@ -110,6 +110,10 @@ for it in range(iters):
             hooks["SPBLAS_GFX950_PB_VF_ROWS"] = str(int(rng.choice([0, 7, 64, 300, 3000])))
             hooks["SPBLAS_GFX950_PB_VF_WAVES"] = str(int(rng.choice([4, 8])))
             hooks["SPBLAS_GFX950_PB_VF_GRID"] = str(int(rng.choice([1, 3, 256])))
+        if os.environ.get("FUZZ_FORCE_VFREE"):  # ... and nothing that would make the build fall back to the copying form
+            hooks["SPBLAS_GFX950_PB_COMPACT"], hooks["SPBLAS_GFX950_PB_SPLIT_LEN"], hooks["SPBLAS_GFX950_PB_VARBINS"] = "0", "1000000", "0"
+            hooks.pop("SPBLAS_GFX950_SLICE_ROWS", None)
+            hooks["SPBLAS_GFX950_PB_HOT"] = "0"
         hooks["SPBLAS_GFX950_PB_KEEP_SRC"] = str(int(rng.choice([0, 1])))
         hooks["SPBLAS_GFX950_PB_KEEP_REST"] = str(int(rng.choice([0, 1])))
         hooks["SPBLAS_GFX950_PB_STAGE_Q16"] = str(int(rng.choice([0, 1])))
