@@ -1903,6 +1903,9 @@ __global__ __launch_bounds__(NW * 64) void pb_reduce_vf_kernel(int64_t m, int Hw
   // wave-uniform LDS base + 16 B per lane, no registers, no ds_write pass), the whole window in flight at once
   int shift = 0;  // position of the bin's first entry inside the staged window
   auto stage_window = [&](int64_t b) {
+#ifdef PB_EXP_VF_NOWIN  // timing experiment only (results wrong): no window staging
+    return;
+#endif
     const int64_t r0 = b * Hw, r1 = (r0 + Hw) < m ? (r0 + Hw) : m;
     const int64_t p0 = row_off(r0), p1 = row_off(r1);
     const bool vec_ok = (reinterpret_cast<uintptr_t>(values) & 15) == 0;
@@ -1935,6 +1938,17 @@ __global__ __launch_bounds__(NW * 64) void pb_reduce_vf_kernel(int64_t m, int Hw
     for (int u = 0; u < UB; ++u) {
       if (g + u >= g_hi)
         break;
+#ifdef PB_EXP_VF_NOACC  // timing experiment only (results wrong): the stream and the window without the LDS accumulation
+      {
+        T t = q.p[u][0] + q.p[u][1] + q.p[u][2] + q.p[u][3] + T(q.s[u][0] ^ q.s[u][1] ^ q.s[u][2] ^ q.s[u][3]);
+        if (ENC8)
+          t += T(q.cw[u] ^ (unsigned) q.hd[u]);
+        else
+          t += T(q.r[u][0]);
+        *dummy += t;
+        continue;
+      }
+#endif
       T v[4], pr[4];
       T* slot[4];
       bool flagged[4], atomic[4];
@@ -2477,7 +2491,9 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
   if (NWv != 4 && NWv != 8)
     NWv = 8;
   constexpr int VF_LDS = 160 * 1024 - 64;
-  const int vf_elems = VF_LDS / (int) sizeof(T);
+  // (SPBLAS_GFX950_PB_VF_LDS_KB = 80: two workgroups per CU with bins half as tall -- measured)
+  const int vf_lds_req = env_int("SPBLAS_GFX950_PB_VF_LDS_KB", 160) == 80 ? 80 * 1024 - 64 : VF_LDS;
+  const int vf_elems = vf_lds_req / (int) sizeof(T);
   int vf_rows = 0, vf_cap = 0;
   if (vfree) {
     const double avg = m > 0 ? (double) nnz / (double) m : 0.0;
