@@ -153,11 +153,16 @@ int spblas_gfx950_set_option(spblas_gfx950_handle_t handle, int option, int64_t 
  * caller's values.  The SLICED plan holds a re-tiled COPY of the values.  On request (alg = SLICED) or by AUTO under
  * SPBLAS_GFX950_OPT_VALUE_SNAPSHOT the copy is a SNAPSHOT: after changing the values IN PLACE call
  * spblas_gfx950_spmv_plan_update_values; a multiply that passes a DIFFERENT values pointer than the one
- * the copy was taken from refreshes the copy by itself first (one extra pass over A).  AUTO WITHOUT the option may
- * choose the SLICED plan too (>= 16 M entries, a timed trial against the row-block kernel): such a plan takes the values
- * again on EVERY multiply (plan_info_sliced[9] bit 6), so the caller sees the same semantics as with a structure-only
- * plan; the two-stage calls (spmv_expand / spmv_reduce_rows), which are not given the values, refuse it.
- * The plan is tied to (m, n, nnz, rowptr, colind). */
+ * the copy was taken from refreshes the copy by itself first (one extra pass over A).  A snapshot plan keeps no source
+ * positions until then: the FIRST refresh builds the plan again from the caller's arrays (inspect-class work: not inside a
+ * stream capture) and keeps them, every later refresh is a gather.  AUTO WITHOUT the option may choose the SLICED plan
+ * too (>= 16 M entries, not skewed): such a plan reads the caller's values on EVERY multiply (plan_info_sliced[9] bit 6),
+ * so the caller sees the same semantics as with a structure-only plan.  Its default form is VALUE-FREE (bit 7, round 5):
+ * the plan holds no values at all -- the first kernel gathers x, the second multiplies by the caller's array, staged bin by
+ * bin through LDS; where that form does not apply, the copying form of round 4 (a value refresh per multiply, kept only
+ * if it beats the row-block kernel in a timed trial).  The calls that are not given the values -- the two-stage calls
+ * (spmv_expand / spmv_reduce_rows) and the multi-GPU steps (spmv_reduce_rows_bcast, spmv_step_bcast[_chunked]) -- refuse
+ * such a plan.  The plan is tied to (m, n, nnz, rowptr, colind). */
 int spblas_gfx950_spmv_plan_create(spblas_gfx950_handle_t handle, spblas_gfx950_plan_t* plan,
                                    int64_t m, int64_t n, int64_t nnz, const void* rowptr,
                                    const int32_t* colind, const void* values, int offset_type,
@@ -179,7 +184,9 @@ int spblas_gfx950_plan_info(spblas_gfx950_plan_t plan, int64_t info[12]);
  * than m when the empty rows were taken out).  For ANY plan: [9] bit 0 = AUTO decided by a timed trial, bit 1 = the
  * reduce streams one-byte row codes (runs sorted by row) instead of 16-bit rows, bit 2 = the expand stores its products
  * with the non-temporal hint, bit 3 = this plan ran the store trial that decides bit 2 (plans with >= 32 M placed
- * entries, once per process, device and value size; SPBLAS_GFX950_PB_NT=0/1 forces the flavour); [10]/[11]=time of the
+ * entries, once per process, device and value size; SPBLAS_GFX950_PB_NT=0/1 forces the flavour), bit 4 = hot-column
+ * split (plan_info_hot), bit 6 = the plan reads the caller's values on every multiply (made without the snapshot opt-in),
+ * bit 7 = ... and holds no copy of them (value-free tiles); [10]/[11]=time of the
  * row-block / the sliced plan in AUTO's trial, nanoseconds -- or, when only the store trial ran, of one SpMV with plain /
  * non-temporal product stores. */
 int spblas_gfx950_plan_info_sliced(spblas_gfx950_plan_t plan, int64_t info[12]);
