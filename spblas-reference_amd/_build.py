@@ -89,6 +89,7 @@ def build_rccl_test(force=False):
     """The C++ row-sharded SpMV over RCCL (include/spblas/vendor/gfx950/sharded_spmv.hpp): a caller-side program that links
     librccl itself (the backend library does not)."""
     deps = [RCCL_TEST_SRC, os.path.join(_ROOT, "include", "spblas", "vendor", "gfx950", "sharded_spmv.hpp"),
+            os.path.join(_ROOT, "include", "spblas", "vendor", "gfx950", "fused_sharded_spmv.hpp"),
             os.path.join(_ROOT, "include", "spblas", "vendor", "gfx950", "detail", "backend_calls.hpp"), LIBPATH]
     if not force and os.path.exists(RCCL_TEST_BIN) and os.path.getmtime(RCCL_TEST_BIN) >= max(map(os.path.getmtime, deps)):
         return RCCL_TEST_BIN
