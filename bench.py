@@ -619,15 +619,19 @@ def main():
 
     # a second inspect of the same matrix (N = 1 only): the first one of a process also loads the code objects and
     # first-touches the pool, this one is what a caller pays from then on
+    # (twice, the smaller figure: the first of the two still grows the memory pool by a second plan next to the live one)
     inspect_warm_ms = None
     if not multi and args.alg != "noplan" and mode == "plain":
         y_tmp = torch.empty(rows_local, dtype=dtype, device=device)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        info_w = sp.multiply_inspect(sp.matrix_opt(a_chunks[0]), x, y_tmp, alg=algs[args.alg])
-        torch.cuda.synchronize()
-        inspect_warm_ms = (time.perf_counter() - t1) * 1e3
-        del info_w, y_tmp
+        for _ in range(2):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            info_w = sp.multiply_inspect(sp.matrix_opt(a_chunks[0]), x, y_tmp, alg=algs[args.alg])
+            torch.cuda.synchronize()
+            ms_w = (time.perf_counter() - t1) * 1e3
+            inspect_warm_ms = ms_w if inspect_warm_ms is None else min(inspect_warm_ms, ms_w)
+            del info_w
+        del y_tmp
 
     # What was timed is also what is checked (outside the timed region): y of the timed operator for this x.
     y_timed = op.step(x)

@@ -418,16 +418,20 @@ def _run(args, device):
         reuse_elapsed, reuse_ms = _time_steps(lambda: sp.multiply_fill(state, a, b, c), args.warmup, args.steps)
         reuse_bytes = alg_bytes - cn * 4  # the column indices are neither read nor written by those fills
         # the symbolic phase once more on a fresh state: the first call above also loaded the code object of spgemm.hip
-        c2_rp = torch.zeros(m + 1, dtype=torch.int32, device=device)
-        c2 = sp.csr_view(None, c2_rp, None, (m, m), 0)
-        state2 = sp.spgemm_state_t()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        sp.multiply_compute(state2, a, b, c2)
-        torch.cuda.synchronize()
-        compute_warm_ms = (time.perf_counter() - t0) * 1e3
-        assert state2.result_nnz() == cn and torch.equal(c2_rp, c_rp)
-        del state2
+        # (best of three: the call is host-driven -- a dozen launches and two waits -- and the figure is taken right after other
+        # workloads' CPU baselines, whose OpenMP threads may still be spinning on the host's cores)
+        compute_warm_ms = float("inf")
+        for _ in range(3):
+            c2_rp = torch.zeros(m + 1, dtype=torch.int32, device=device)
+            c2 = sp.csr_view(None, c2_rp, None, (m, m), 0)
+            state2 = sp.spgemm_state_t()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            sp.multiply_compute(state2, a, b, c2)
+            torch.cuda.synchronize()
+            compute_warm_ms = min(compute_warm_ms, (time.perf_counter() - t0) * 1e3)
+            assert state2.result_nnz() == cn and torch.equal(c2_rp, c_rp)
+            del state2
         cpu = None
         if not args.no_cpu_baseline:
             rows = min(20_000, m)
