@@ -125,7 +125,11 @@ typedef enum spblas_gfx950_option {
    * vendor/rocsparse/detail/spmv_impl.hpp:72-77).  The host layers set it for operands wrapped in
    * matrix_opt (views/matrix_opt_impl.hpp: the view that owns a vendor-optimised form of the matrix), the
    * same opt-in oneMKL's optimize_* stage gets in vendor/onemkl_sycl/spmm_impl.hpp:48-61.  Asking for
-   * alg = SLICED explicitly needs no option. */
+   * alg = SLICED explicitly needs no option.
+   * value = 2: as 1, and the caller announces that the values WILL change (a time-stepping solver): SLICED snapshot
+   * plans -- chosen by AUTO or requested explicitly -- keep the source position of every entry from the start (+4 B per
+   * entry), so that the first spblas_gfx950_spmv_plan_update_values is a gather like every later one instead of a second
+   * inspect (see the value snapshot contract below). */
   SPBLAS_GFX950_OPT_VALUE_SNAPSHOT = 3,
   /* value = 1: the caller GUARANTEES that a c_colind array it passes to spblas_gfx950_spgemm_numeric[_addend] still
    * holds what the previous numeric call on the same state wrote there whenever it is the same address; repeated
@@ -155,7 +159,7 @@ int spblas_gfx950_set_option(spblas_gfx950_handle_t handle, int option, int64_t 
  * spblas_gfx950_spmv_plan_update_values; a multiply that passes a DIFFERENT values pointer than the one
  * the copy was taken from refreshes the copy by itself first (one extra pass over A).  A snapshot plan keeps no source
  * positions until then: the FIRST refresh builds the plan again from the caller's arrays (inspect-class work: not inside a
- * stream capture) and keeps them, every later refresh is a gather.  AUTO WITHOUT the option may choose the SLICED plan
+ * stream capture) and keeps them, every later refresh is a gather (option value 2 above: kept from the start).  AUTO WITHOUT the option may choose the SLICED plan
  * too (>= 16 M entries, not skewed): such a plan reads the caller's values on EVERY multiply (plan_info_sliced[9] bit 6),
  * so the caller sees the same semantics as with a structure-only plan.  Its default form is VALUE-FREE (bit 7, round 5):
  * the plan holds no values at all -- the first kernel gathers x, the second multiplies by the caller's array, staged bin by

@@ -488,13 +488,14 @@ def _plan_key(a_base):
             a_base.rowptr().dtype, a_base.values().dtype)
 
 
-def _build_plan(a_base, alg=_capi.SPMV_AUTO, snapshot=False):
-    """snapshot: AUTO may choose the plan that keeps a re-tiled copy of the values (matrix_opt operands)."""
+def _build_plan(a_base, alg=_capi.SPMV_AUTO, snapshot=0):
+    """snapshot: the value of SPBLAS_GFX950_OPT_VALUE_SNAPSHOT -- 1 / True: AUTO may choose the plan that keeps a re-tiled
+    copy of the values (matrix_opt operands); 2: and the plan keeps its source positions from the start."""
     hd = _Handle.current(a_base.rowptr().device)
     vt, _ = _vtype(a_base.values(), "multiply_inspect")
     plan = ctypes.c_void_p()
     m, n = a_base.shape()
-    hd.set_option(_capi.OPT_VALUE_SNAPSHOT, 1 if snapshot else 0)
+    hd.set_option(_capi.OPT_VALUE_SNAPSHOT, int(snapshot))
     try:
         check(_capi.lib().spblas_gfx950_spmv_plan_create(hd.h, ctypes.byref(plan), m, n, a_base.size(),
                                                          _ptr(a_base.rowptr()), _ptr(a_base.colind()),
@@ -775,7 +776,7 @@ def multiply(*args):
     return _spmm(info, a, b, c)
 
 
-def multiply_inspect(*args, alg=_capi.SPMV_AUTO):
+def multiply_inspect(*args, alg=_capi.SPMV_AUTO, values_will_change=False):
     """multiply_inspect(a, b, c) -> operation_info_t, or multiply_inspect(info, a, b, c).
     Builds the gfx950 row partition on device and stores it in the info's state_; when A
     is wrapped in matrix_opt it is cached there too (the oneMKL model,
@@ -787,7 +788,9 @@ def multiply_inspect(*args, alg=_capi.SPMV_AUTO):
     multiplies with its own copy of the values (5x faster when x misses every cache).  The copy is refreshed
     automatically when a.values() is rebound, modified in place through torch, or scaled with scale();
     after writing it with a kernel of your own call info.state_.update_values(values).  alg=SPMV_SLICED asks
-    for that plan explicitly, with the same contract."""
+    for that plan explicitly, with the same contract.  values_will_change=True (a time-stepping caller) makes such a plan
+    keep the source position of every entry from the start (+4 B per entry): the first refresh is then a gather like every
+    later one instead of a second inspect (SPBLAS_GFX950_OPT_VALUE_SNAPSHOT = 2)."""
     info, a, b, c = _split_info(args)
     ret = info is None
     if info is None:
@@ -803,7 +806,7 @@ def multiply_inspect(*args, alg=_capi.SPMV_AUTO):
         is_spmm = _is_tensor(b_base) and b_base.dim() == 2
         mo = _get_matrix_opt(a)
         plan = _build_plan(a_base, _capi.SPMV_ROWBLOCK if is_spmm and alg == _capi.SPMV_AUTO else alg,
-                           snapshot=mo is not None)
+                           snapshot=0 if mo is None and alg != _capi.SPMV_SLICED else (2 if values_will_change else 1))
         if is_spmm:
             plan.spmm_inspect()
         info.state_ = plan

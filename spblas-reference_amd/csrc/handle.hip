@@ -102,7 +102,7 @@ int spblas_gfx950_set_option(spblas_gfx950_handle_t handle, int option, int64_t 
     return SPBLAS_GFX950_STATUS_SUCCESS;
   }
   if (option == SPBLAS_GFX950_OPT_VALUE_SNAPSHOT) {
-    if (value != 0 && value != 1)
+    if (value < 0 || value > 2)
       return SPBLAS_GFX950_STATUS_INVALID_VALUE;
     handle->value_snapshot = value;
     return SPBLAS_GFX950_STATUS_SUCCESS;

@@ -723,6 +723,9 @@ int spblas_gfx950_spmv_plan_create(spblas_gfx950_handle_t handle, spblas_gfx950_
   pl->colind = colind;
   pl->offset_type = offset_type;
   pl->value_type = value_type;
+  // (SPBLAS_GFX950_OPT_VALUE_SNAPSHOT = 2: the caller announces that the values WILL change -- a snapshot plan then keeps
+  // its source positions from the start and the first update_values is a gather, not a second inspect)
+  pl->keep_src = handle->value_snapshot == 2 ? 1 : 0;
   int rc = offset_type == SPBLAS_GFX950_I32 ? plan_build<int32_t>(handle, pl, alg)
                                             : plan_build<int64_t>(handle, pl, alg);
   pl->base_device_bytes = pl->device_bytes;

@@ -1124,3 +1124,45 @@ def test_spmv_snapshot_plan_keeps_no_source_positions_until_the_values_change(gp
     assert info.state_.info()["device_bytes"] == bytes1
     sp.multiply(info, a, xd, y)
     check(values * -2.0 + 0.125, rowptr, colind, (m, n), x, G.host(y), what=f"{shape}: second change", ref_cmp=False)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", ["plain", "hot_split"])
+def test_spmv_snapshot_plan_keeps_source_positions_from_the_start_on_request(gpu, monkeypatch, shape):
+    """SPBLAS_GFX950_OPT_VALUE_SNAPSHOT = 2 (multiply_inspect(..., values_will_change=True)): the caller announces that the
+    values will change, the plan holds its source positions from inspect on -- the first update_values is the gather, the
+    plan is not built again (device_bytes does not move) -- and is 4 B per entry larger than the default plan."""
+    monkeypatch.setenv("SPBLAS_GFX950_SLICE_COLS", "128")
+    rng = np.random.default_rng(53)
+    m, n = 6000, 4000
+    if shape == "hot_split":
+        monkeypatch.setenv("SPBLAS_GFX950_PB_HOT", "1")
+        lens = rng.integers(1, 40, m)
+        nnz = int(lens.sum())
+        colind = np.where(rng.random(nnz) < 0.4, rng.integers(0, 64, nnz), rng.integers(0, n, nnz)).astype(np.int32)
+    else:
+        lens = rng.integers(0, 24, m)
+        nnz = int(lens.sum())
+        colind = rng.integers(0, n, nnz).astype(np.int32)
+    rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    values = (rng.random(nnz) - 0.5).astype(np.float32)
+    x = (rng.random(n) - 0.5).astype(np.float32)
+    a = G.csr_on_device(values, rowptr, colind, (m, n), nnz)
+    xd = G.dev(x)
+    y = torch.full((m,), float("nan"), dtype=torch.float32, device="cuda")
+    lean = sp.multiply_inspect(a, xd, y, alg=_capi.SPMV_SLICED).state_.info()["device_bytes"]
+    info = sp.multiply_inspect(a, xd, y, alg=_capi.SPMV_SLICED, values_will_change=True)
+    bytes0 = info.state_.info()["device_bytes"]
+    assert bytes0 >= lean + 4 * nnz, (lean, bytes0, nnz)
+    sp.multiply(info, a, xd, y)
+    check(values, rowptr, colind, (m, n), x, G.host(y), what=f"{shape}: as inspected", ref_cmp=False)
+    for k, f in enumerate((-2.0, 0.5)):
+        a.values().mul_(f)
+        values = values * np.float32(f)
+        info.state_.update_values(a.values())
+        assert info.state_.info()["device_bytes"] == bytes0, "the plan was built again"
+        sp.multiply(info, a, xd, y)
+        check(values, rowptr, colind, (m, n), x, G.host(y), what=f"{shape}: change {k}", ref_cmp=False)
+    # the option leaves a plain inspected view's semantics alone: AUTO without matrix_opt still reads the caller's values
+    plain = sp.multiply_inspect(a, xd, y, values_will_change=True)
+    assert plain.state_.info()["alg"] != _capi.SPMV_SLICED or plain.state_.sliced_info()["refresh_each_call"]
