@@ -213,9 +213,11 @@ __global__ __launch_bounds__(1024) void spg_fill_perm_kernel(int64_t m, const in
 // (ds_add_f32) retires only 0.33 lanes/clk/CU on this part (tools/ubench/lds_atomic.hip: 12x slower
 // than integer LDS atomics), and a hash slot is rarely contended, so read + cmpswap usually
 // succeeds at the first attempt.
+// (The first read goes through an explicit LDS pointer: a volatile read through the generic one was compiled as a FLAT
+// load with system-scope cache bits -- a vector-memory operation that waits behind every global load in flight.)
 __device__ __forceinline__ void spg_lds_add(float* addr, float v) {
   int* ai = reinterpret_cast<int*>(addr);
-  int old = *reinterpret_cast<volatile int*>(ai);
+  int old = *(volatile __attribute__((address_space(3))) int*) ai;
   while (true) {
     const int assumed = old;
     old = atomicCAS(ai, assumed, __float_as_int(__int_as_float(assumed) + v));
@@ -225,7 +227,7 @@ __device__ __forceinline__ void spg_lds_add(float* addr, float v) {
 }
 __device__ __forceinline__ void spg_lds_add(double* addr, double v) {
   unsigned long long* ai = reinterpret_cast<unsigned long long*>(addr);
-  unsigned long long old = *reinterpret_cast<volatile unsigned long long*>(ai);
+  unsigned long long old = *(volatile __attribute__((address_space(3))) unsigned long long*) ai;
   while (true) {
     const unsigned long long assumed = old;
     old = atomicCAS(ai, assumed, (unsigned long long) __double_as_longlong(__longlong_as_double((long long) assumed) + v));
