@@ -19,7 +19,7 @@ for f in glob.glob("$OUT/p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         acc[r["Kernel_Name"].split("(")[0][-60:]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, c in acc.items():
-    if not any(x in k for x in ("spb::pb_", "spb::spmv", "spb::spmm", "spb::spg_hash")): continue
+    if not any(x in k for x in ("spb::pb_", "spb::spmv", "spb::spmm", "spb::spg_", "spb::spt_", "spb::trsv")): continue
     print("==", k)
     for n in sorted(c):
         v = c[n]; print(f"   {n:40s} {sum(v)/len(v):16.0f}  (n={len(v)})")
