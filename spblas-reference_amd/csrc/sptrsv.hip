@@ -397,26 +397,32 @@ __device__ __forceinline__ void trsv_row(int r, int lane, const int32_t* __restr
                                          const int32_t* __restrict__ colind, const T* __restrict__ values, T alpha,
                                          const T* __restrict__ b, T* x, int upper, int unit, int m,
                                          unsigned long long* __restrict__ gran, unsigned epoch) {
-  T dot = T(0);
+  T dot = T(0), dval = T(0);
   int dpos = -1;
   const int p1 = rowptr[r + 1];
+  const T br = b[r];  // (issued with the row's other loads, not after the reduction)
   for (int p = rowptr[r] + lane; p < p1; p += G) {
     const int c = colind[p];
+    const T a = values[p];
     if (c >= 0 && c < m && trsv_strict(c, r, upper))
-      dot += values[p] * __hip_atomic_load(&x[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      dot += a * __hip_atomic_load(&x[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else if (c == r)
-      dpos = p;  // the last stored diagonal entry wins (triangular_solve_impl.hpp:64-66,81-83)
+      dpos = p, dval = a;  // the last stored diagonal entry wins (triangular_solve_impl.hpp:64-66,81-83)
   }
+  // the diagonal VALUE travels with its position through the reduction: a load of values[dpos] afterwards was one more
+  // memory round trip on the critical path of every level
 #pragma unroll
   for (int o = G >> 1; o > 0; o >>= 1) {
     dot += __shfl_xor(dot, o, SPB_WAVE);
     const int other = __shfl_xor(dpos, o, SPB_WAVE);
-    dpos = other > dpos ? other : dpos;
+    const T oval = __shfl_xor(dval, o, SPB_WAVE);
+    if (other > dpos)
+      dpos = other, dval = oval;
   }
   if (lane == 0) {
-    T v = b[r] - alpha * dot;
+    T v = br - alpha * dot;
     if (!unit)
-      v = v / (alpha * (dpos >= 0 ? values[dpos] : T(0)));
+      v = v / (alpha * (dpos >= 0 ? dval : T(0)));
     __hip_atomic_store(&x[r], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (gran)
       trsv_publish<T>(gran, r, v, epoch);  // consumers inside a later self-scheduling launch poll the granule
@@ -598,13 +604,13 @@ __global__ __launch_bounds__(TRSV_COOP_THREADS) void trsv_coop_kernel(int n_leve
   };
   // pipeline registers per slot: A = row known, B = row + entry range, C = first two entries per lane loaded
   int rA[R], rB[R], pB[R], qB[R], rC[R], pC[R], qC[R], c0[R], c1[R];
-  T v0[R], v1[R];
+  T v0[R], v1[R], bC[R];
 #pragma unroll
   for (int k = 0; k < R; ++k) {
     rA[k] = rB[k] = rC[k] = -1;
     pB[k] = qB[k] = pC[k] = qC[k] = 0;
     c0[k] = c1[k] = -1;
-    v0[k] = v1[k] = T(0);
+    v0[k] = v1[k] = bC[k] = T(0);
   }
   // one pipeline step: C <- entries of B's rows, B <- entry range of A's rows, A <- rows of level L (all loads
   // independent of each other and of x)
@@ -617,8 +623,9 @@ __global__ __launch_bounds__(TRSV_COOP_THREADS) void trsv_coop_kernel(int n_leve
       pC[k] = pB[k];
       qC[k] = qB[k];
       c0[k] = c1[k] = -1;
-      v0[k] = v1[k] = T(0);
+      v0[k] = v1[k] = bC[k] = T(0);
       if (rB[k] >= 0) {
+        bC[k] = b[rB[k]];  // (with the entries: not after the reduction, on the level's critical path)
         if (pB[k] < qB[k]) {
           c0[k] = colind[pB[k]];
           v0[k] = values[pB[k]];
@@ -659,33 +666,37 @@ __global__ __launch_bounds__(TRSV_COOP_THREADS) void trsv_coop_kernel(int n_leve
       }
 #pragma unroll
       for (int k = 0; k < R; ++k) {
-        T dot = T(0);
+        T dot = T(0), dval = T(0);
         int dpos = -1;
         if (s0[k])
           dot += v0[k] * x0[k];
         else if (rC[k] >= 0 && c0[k] == rC[k])
-          dpos = pC[k];
+          dpos = pC[k], dval = v0[k];
         if (s1[k])
           dot += v1[k] * x1[k];
         else if (rC[k] >= 0 && c1[k] == rC[k])
-          dpos = pC[k] + G;
+          dpos = pC[k] + G, dval = v1[k];
         for (int p = pC[k] + 2 * G; p < qC[k]; p += G) {  // rows longer than 2 G entries
           const int c = colind[p];
+          const T a = values[p];
           if (c >= 0 && c < m && trsv_strict(c, rC[k], upper))
-            dot += values[p] * __hip_atomic_load(&x[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            dot += a * __hip_atomic_load(&x[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           else if (c == rC[k])
-            dpos = p;
+            dpos = p, dval = a;
         }
+        // (the diagonal value travels with its position: no load of values[dpos] after the reduction)
 #pragma unroll
         for (int o = G >> 1; o > 0; o >>= 1) {
           dot += __shfl_xor(dot, o, SPB_WAVE);
           const int other = __shfl_xor(dpos, o, SPB_WAVE);
-          dpos = other > dpos ? other : dpos;
+          const T oval = __shfl_xor(dval, o, SPB_WAVE);
+          if (other > dpos)
+            dpos = other, dval = oval;
         }
         if (rC[k] >= 0 && gl == 0) {
-          T v = b[rC[k]] - alpha * dot;
+          T v = bC[k] - alpha * dot;
           if (!unit)
-            v = v / (alpha * (dpos >= 0 ? values[dpos] : T(0)));
+            v = v / (alpha * (dpos >= 0 ? dval : T(0)));
           __hip_atomic_store(&x[rC[k]], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
