@@ -25,7 +25,7 @@ namespace spb {
 //     of rowptr, held in LDS) -- no payload pass;
 //   * the last pass writes t_colind / t_values directly -- no split pass;
 //   * keys, rows and values travel as three arrays (three coalesced streams per piece);
-//   * a tile is 8 waves x SPT_ROUNDS x 64 = 4096 entries per workgroup of 512 lanes (58 / 74 KiB of LDS: two
+//   * a tile is 8 waves x SPT_ROUNDS x 64 = 4096 entries per workgroup of 512 lanes (46 / 62 KiB of LDS: three / two
 //     workgroups per CU), so a tile's piece of one of the 256 buckets averages 16 entries; tiles of 8192 (one
 //     workgroup per CU) and of 3072 / 2048 entries were measured and are slower or equal;
 //   * every XCD works on a contiguous range of tiles, so the pieces of neighbouring tiles, adjacent in memory, are
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void spt_tile_rows_kernel(int64_t ntiles, int 
 }
 
 template <typename T, int SPT_ROUNDS, bool FIRST>
-__global__ __launch_bounds__(512) void spt_scatter_kernel(int64_t nnz, int shift, const int32_t* __restrict__ in_keys,
+__global__ __launch_bounds__(512, sizeof(T) == 4 ? 6 : 4) void spt_scatter_kernel(int64_t nnz, int shift, const int32_t* __restrict__ in_keys,
                                                           const int32_t* __restrict__ in_rows,
                                                           const T* __restrict__ in_vals, int64_t m,
                                                           const int32_t* __restrict__ rowptr, int64_t ntiles,
@@ -103,9 +103,10 @@ __global__ __launch_bounds__(512) void spt_scatter_kernel(int64_t nnz, int shift
   typedef __attribute__((address_space(3))) T lds_T;
   typedef __attribute__((address_space(3))) int lds_int;
   lds_T* stage_val = (lds_T*) spt_smem;                              // [TILE]
-  lds_int* stage_key = (lds_int*) (stage_val + SPT_TILE);            // [TILE]
-  lds_int* stage_row = stage_key + SPT_TILE;                         // [TILE]
-  volatile lds_int* cnt = stage_row + SPT_TILE;                      // [WAVES][256] running counts -> wave offsets
+  lds_int* stage_row = (lds_int*) (stage_val + SPT_TILE);            // [TILE] rows, then (second write-out) the keys
+  typedef __attribute__((address_space(3))) unsigned char lds_u8;
+  lds_u8* stage_dig = (lds_u8*) (stage_row + SPT_TILE);              // [TILE] digit of the staged entry
+  volatile lds_int* cnt = (lds_int*) (stage_dig + SPT_TILE);         // [WAVES][256] running counts -> wave offsets
   lds_int* lstart = (lds_int*) cnt + SPT_WAVES * 256;                // [256] first local position of a bucket
   lds_int* delta = lstart + 256;                                     // [256] global - local position of a bucket
   lds_int* misc = delta + 256;                                       // [8]
@@ -233,25 +234,34 @@ __global__ __launch_bounds__(512) void spt_scatter_kernel(int64_t nnz, int shift
     delta[tid] = offsets[(int64_t) tid * ntiles + tile] - ls;
   }
   __syncthreads();
+  // Staged in TWO rounds through the same space -- rows and values first, then the keys where the rows were, the digit of
+  // every staged entry kept as a byte for the address of both write-outs: 46 KiB of LDS per workgroup instead of 59.5 (fp32),
+  // THREE workgroups per CU instead of two.  The kernel lives on overlap between workgroups (with one per CU a pass took
+  // 895 us instead of 570); two more barriers per tile pay for a third.
 #pragma unroll
   for (int r = 0; r < SPT_ROUNDS; ++r) {
-    const int li = (w * SPT_ROUNDS + r) * 64 + lane;
-    if (li < tile_n) {
-      const int d = (key[r] >> shift) & 255;
-      const int lp = lstart[d] + cnt[w * 256 + d] + rank[r];
-      stage_key[lp] = key[r];
-      stage_row[lp] = row[r];
-      stage_val[lp] = val[r];
+    const int d = (key[r] >> shift) & 255;
+    rank[r] += lstart[d] + cnt[w * 256 + d];  // now the entry's position in the staged tile
+    if ((w * SPT_ROUNDS + r) * 64 + lane < tile_n) {
+      stage_row[rank[r]] = row[r];
+      stage_val[rank[r]] = val[r];
+      stage_dig[rank[r]] = (unsigned char) d;
     }
   }
   __syncthreads();
   for (int j = tid; j < tile_n; j += 512) {
-    const int k = stage_key[j];
-    const int64_t g = (int64_t) j + delta[(k >> shift) & 255];
-    out_keys[g] = k;
+    const int64_t g = (int64_t) j + delta[stage_dig[j]];
     out_rows[g] = stage_row[j];
     out_vals[g] = stage_val[j];
   }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < SPT_ROUNDS; ++r)
+    if ((w * SPT_ROUNDS + r) * 64 + lane < tile_n)
+      stage_row[rank[r]] = key[r];
+  __syncthreads();
+  for (int j = tid; j < tile_n; j += 512)
+    out_keys[(int64_t) j + delta[stage_dig[j]]] = stage_row[j];
 }
 
 // t_rowptr from the sorted columns, one streaming pass: entry k-1 is the last entry of its column c when the next
@@ -371,7 +381,8 @@ static int transpose_radix(spblas_gfx950_handle_t handle, int64_t m, int64_t n, 
   unsigned* n_longs = reinterpret_cast<unsigned*>(q + key_b + cnt_b + part_b + long_b - 256);
   int32_t* tile_row = reinterpret_cast<int32_t*>(q + key_b + cnt_b + part_b + long_b);
 
-  const size_t smem = (size_t) SPT_TILE * (8 + sizeof(T)) + (size_t) (SPT_WAVES * 256 + 512 + 16) * 4;
+  const size_t smem = (size_t) SPT_TILE * (5 + sizeof(T)) + (size_t) (SPT_WAVES * 256 + 512 + 16) * 4 +
+                      (size_t) (std::getenv("SPBLAS_GFX950_TRANSPOSE_LDS_PAD") ? std::atoi(std::getenv("SPBLAS_GFX950_TRANSPOSE_LDS_PAD")) : 0) * 1024;
   auto k_first = spt_scatter_kernel<T, SPT_ROUNDS, true>;
   auto k_next = spt_scatter_kernel<T, SPT_ROUNDS, false>;
   SPB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_first), hipFuncAttributeMaxDynamicSharedMemorySize,
