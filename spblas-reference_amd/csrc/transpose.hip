@@ -39,13 +39,21 @@ constexpr int SPT_WAVES = 8;
 
 __global__ __launch_bounds__(512) void spt_count_kernel(int64_t nnz, int shift, int tile_size,
                                                         const int32_t* __restrict__ keys, int64_t ntiles,
-                                                        int32_t* __restrict__ counts) {
+                                                        int32_t* __restrict__ counts, int xcd_map) {
   // (one histogram per wave instead: no faster; 16-byte key loads: 172 -> 104 us per pass at 1e8 entries)
   __shared__ int hist[256];
   if (threadIdx.x < 256)
     hist[threadIdx.x] = 0;
   __syncthreads();
-  const int64_t base = (int64_t) blockIdx.x * tile_size;
+  // the same tile -> XCD mapping as the scatter kernel: the counters of neighbouring tiles are neighbours in counts[digit][tile],
+  // and dealt round-robin they reached their 32-byte sector from eight different L2s -- eight partial writes per sector
+  int64_t tile = blockIdx.x;
+  if (xcd_map) {
+    const int64_t per = ntiles / 8, body = per * 8;
+    if (tile < body)
+      tile = (tile & 7) * per + (tile >> 3);
+  }
+  const int64_t base = tile * tile_size;
   int* mine = hist;
   const int tile_n = (int) (nnz - base < tile_size ? nnz - base : tile_size);
   if (tile_n == tile_size && (reinterpret_cast<uintptr_t>(keys + base) & 15) == 0) {
@@ -63,7 +71,7 @@ __global__ __launch_bounds__(512) void spt_count_kernel(int64_t nnz, int shift, 
   }
   __syncthreads();
   if (threadIdx.x < 256)
-    counts[(int64_t) threadIdx.x * ntiles + blockIdx.x] = hist[threadIdx.x];
+    counts[(int64_t) threadIdx.x * ntiles + tile] = hist[threadIdx.x];
 }
 
 // tile_row[t] = row that owns entry t * tile_size (the last r with rowptr[r] <= it), tile_row[ntiles] = the row of the
@@ -400,7 +408,7 @@ static int transpose_radix(spblas_gfx950_handle_t handle, int64_t m, int64_t n, 
     int32_t* out_rows = last ? t_colind : set_rows[p & 1];
     T* out_vals = last ? t_values : set_vals[p & 1];
     hipLaunchKernelGGL(spt_count_kernel, dim3((unsigned) ntiles), dim3(512), 0, s, nnz, 8 * p, SPT_TILE, in_keys, ntiles,
-                       counts);
+                       counts, xcd_map);
     scan_counts_i32(s, nscan, counts, partials);
     if (p == 0)
       hipLaunchKernelGGL(k_first, dim3((unsigned) ntiles), dim3(512), smem, s, nnz, 8 * p, in_keys, in_rows, in_vals, m,
