@@ -23,7 +23,7 @@ for w in $WHICH; do
     transpose) bash tools/profile.sh r05tr --workload transpose > gpurun_out/ev_$w.log 2>&1
           python3 tools/stamp_traffic.py r05tr transpose_8f transpose.hip 'spt_tile_rows_kernel' 'spt_count_kernel*3' 'spt_scatter_kernel<float, 8, true>' 'spt_scatter_kernel<float, 8, false>*2' 'scan_block_sums_kernel*3' 'scan_partials_kernel*3' 'scan_apply_kernel*3' 'spt_rowptr_fill_kernel' 'spt_rowptr_long_kernel' >> gpurun_out/ev_$w.log 2>&1;;
     sptrsv) bash tools/profile.sh r05ts --workload sptrsv > gpurun_out/ev_$w.log 2>&1
-          python3 tools/stamp_traffic.py r05ts sptrsv_8f sptrsv.hip 'trsv_coop_kernel' >> gpurun_out/ev_$w.log 2>&1;;
+          python3 tools/stamp_traffic.py r05ts sptrsv_8f sptrsv.hip 'trsv_level_kernel<float, 8>*158' 'trsv_chain_kernel<float, 8>*3' >> gpurun_out/ev_$w.log 2>&1;;
     mfma) bash tools/prof_mfma.sh r05 > gpurun_out/ev_$w.log 2>&1;;
   esac
   tail -3 gpurun_out/ev_$w.log
