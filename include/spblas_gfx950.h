@@ -103,7 +103,11 @@ int spblas_gfx950_last_hip_error(void);
  * spblas_gfx950_spmm, spblas_gfx950_sptrsv_solve, spblas_gfx950_spgemm_numeric after the first fill) only launch kernels
  * and memsets on this stream and may be recorded with hipStreamBeginCapture and replayed.  Nothing is allocated on a
  * capturing stream: a call that would have to (plan creation, inspect, symbolic passes, the first execute of a plan that
- * sizes a workspace) returns SPBLAS_GFX950_STATUS_NOT_SUPPORTED there -- run it once outside the capture. */
+ * sizes a workspace) returns SPBLAS_GFX950_STATUS_NOT_SUPPORTED there -- run it once outside the capture.
+ * The FIRST handle a process creates loads the library's code objects on the current device (about 16 ms on MI355X, once):
+ * the runtime would otherwise load each one at the first launch of one of its kernels -- 5.5 of the 9 ms of a first
+ * multiply_inspect, 2.2 of the 3.2 ms of a first multiply_compute.  SPBLAS_GFX950_PRELOAD=0 in the environment leaves it to
+ * the first use. */
 int spblas_gfx950_create(spblas_gfx950_handle_t* handle, void* stream);
 int spblas_gfx950_destroy(spblas_gfx950_handle_t handle);
 int spblas_gfx950_set_stream(spblas_gfx950_handle_t handle, void* stream);

@@ -12,6 +12,17 @@ namespace spb {
 thread_local int g_last_hip_error = 0;
 }
 
+namespace spb {
+void preload_spmv();
+void preload_sliced();
+void preload_hot();
+void preload_spmm();
+void preload_spgemm();
+void preload_transpose();
+void preload_sptrsv();
+void preload_multigpu();
+} // namespace spb
+
 extern "C" {
 
 int spblas_gfx950_version(void) {
@@ -53,6 +64,23 @@ int spblas_gfx950_create(spblas_gfx950_handle_t* handle, void* stream) {
   h->device = dev;
   h->num_cus = cus;
   *handle = h;
+  // The first handle of a process loads the library's code objects (SPBLAS_GFX950_PRELOAD=0: left to the first use, as the
+  // runtime does by itself).  Measured on MI355X: see DESIGN.md section 2, "first call".
+  static const bool preloaded = [] {
+    const char* e = std::getenv("SPBLAS_GFX950_PRELOAD");
+    if (e && std::atoi(e) == 0)
+      return false;
+    spb::preload_spmv();
+    spb::preload_sliced();
+    spb::preload_hot();
+    spb::preload_spmm();
+    spb::preload_spgemm();
+    spb::preload_transpose();
+    spb::preload_sptrsv();
+    spb::preload_multigpu();
+    return true;
+  }();
+  (void) preloaded;
   return SPBLAS_GFX950_STATUS_SUCCESS;
 }
 

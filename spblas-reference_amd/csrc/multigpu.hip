@@ -189,3 +189,13 @@ int spblas_gfx950_bcast_wait_before(spblas_gfx950_handle_t handle, const void* f
 }
 
 } // extern "C"
+
+// Loads this file's code object (the runtime loads a code object at the first use of one of its kernels: milliseconds
+// that would otherwise fall on the caller's first inspect / compute call -- handle.hip: spblas_gfx950_create).
+namespace spb {
+void preload_multigpu() {
+  hipFuncAttributes attr;
+  (void) hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&step_signal_kernel));
+  (void) hipGetLastError();
+}
+} // namespace spb

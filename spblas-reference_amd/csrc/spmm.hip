@@ -824,3 +824,13 @@ extern "C" int spblas_gfx950_spmm_plan_info(spblas_gfx950_plan_t plan, int64_t i
   info[3] = plan->mm_ready ? plan->n_long : 0;  // rows cut into parts by the long-row kernel
   return SPBLAS_GFX950_STATUS_SUCCESS;
 }
+
+// Loads this file's code object (the runtime loads a code object at the first use of one of its kernels: milliseconds
+// that would otherwise fall on the caller's first inspect / compute call -- handle.hip: spblas_gfx950_create).
+namespace spb {
+void preload_spmm() {
+  hipFuncAttributes attr;
+  (void) hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&scale_matrix_kernel<float>));
+  (void) hipGetLastError();
+}
+} // namespace spb

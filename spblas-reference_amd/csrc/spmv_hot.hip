@@ -848,3 +848,13 @@ int spmv_hot_update(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const vo
 }
 
 } // namespace spb
+
+// Loads this file's code object (the runtime loads a code object at the first use of one of its kernels: milliseconds
+// that would otherwise fall on the caller's first inspect / compute call -- handle.hip: spblas_gfx950_create).
+namespace spb {
+void preload_hot() {
+  hipFuncAttributes attr;
+  (void) hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&hot_sample_kernel));
+  (void) hipGetLastError();
+}
+} // namespace spb

@@ -3805,3 +3805,13 @@ void spmv_sliced_free(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl) {
 }
 
 } // namespace spb
+
+// Loads this file's code object (the runtime loads a code object at the first use of one of its kernels: milliseconds
+// that would otherwise fall on the caller's first inspect / compute call -- handle.hip: spblas_gfx950_create).
+namespace spb {
+void preload_sliced() {
+  hipFuncAttributes attr;
+  (void) hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&pb_bin_orig_rows_kernel));
+  (void) hipGetLastError();
+}
+} // namespace spb

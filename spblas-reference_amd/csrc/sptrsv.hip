@@ -1164,3 +1164,13 @@ int spblas_gfx950_sptrsv_solve(spblas_gfx950_handle_t handle, spblas_gfx950_trsv
 }
 
 } // extern "C"
+
+// Loads this file's code object (the runtime loads a code object at the first use of one of its kernels: milliseconds
+// that would otherwise fall on the caller's first inspect / compute call -- handle.hip: spblas_gfx950_create).
+namespace spb {
+void preload_sptrsv() {
+  hipFuncAttributes attr;
+  (void) hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&trsv_degree_kernel));
+  (void) hipGetLastError();
+}
+} // namespace spb

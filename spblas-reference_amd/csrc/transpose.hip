@@ -503,3 +503,13 @@ extern "C" int spblas_gfx950_scale(spblas_gfx950_handle_t handle, int64_t n, con
   SPB_HIP(hipGetLastError());
   return SPBLAS_GFX950_STATUS_SUCCESS;
 }
+
+// Loads this file's code object (the runtime loads a code object at the first use of one of its kernels: milliseconds
+// that would otherwise fall on the caller's first inspect / compute call -- handle.hip: spblas_gfx950_create).
+namespace spb {
+void preload_transpose() {
+  hipFuncAttributes attr;
+  (void) hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&spt_count_kernel));
+  (void) hipGetLastError();
+}
+} // namespace spb
