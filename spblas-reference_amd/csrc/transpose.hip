@@ -40,7 +40,8 @@ constexpr int SPT_WAVES = 8;
 __global__ __launch_bounds__(512) void spt_count_kernel(int64_t nnz, int shift, int tile_size,
                                                         const int32_t* __restrict__ keys, int64_t ntiles,
                                                         int32_t* __restrict__ counts, int xcd_map) {
-  // (one histogram per wave instead: no faster; 16-byte key loads: 172 -> 104 us per pass at 1e8 entries)
+  // (one histogram per wave instead: no faster; 16-byte key loads: 172 -> 104 us per pass at 1e8 entries; four tiles per
+  // workgroup with all their keys requested up front: 109 against 100 us)
   __shared__ int hist[256];
   if (threadIdx.x < 256)
     hist[threadIdx.x] = 0;
@@ -389,8 +390,7 @@ static int transpose_radix(spblas_gfx950_handle_t handle, int64_t m, int64_t n, 
   unsigned* n_longs = reinterpret_cast<unsigned*>(q + key_b + cnt_b + part_b + long_b - 256);
   int32_t* tile_row = reinterpret_cast<int32_t*>(q + key_b + cnt_b + part_b + long_b);
 
-  const size_t smem = (size_t) SPT_TILE * (5 + sizeof(T)) + (size_t) (SPT_WAVES * 256 + 512 + 16) * 4 +
-                      (size_t) (std::getenv("SPBLAS_GFX950_TRANSPOSE_LDS_PAD") ? std::atoi(std::getenv("SPBLAS_GFX950_TRANSPOSE_LDS_PAD")) : 0) * 1024;
+  const size_t smem = (size_t) SPT_TILE * (5 + sizeof(T)) + (size_t) (SPT_WAVES * 256 + 512 + 16) * 4;
   auto k_first = spt_scatter_kernel<T, SPT_ROUNDS, true>;
   auto k_next = spt_scatter_kernel<T, SPT_ROUNDS, false>;
   SPB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_first), hipFuncAttributeMaxDynamicSharedMemorySize,
