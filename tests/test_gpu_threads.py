@@ -131,3 +131,37 @@ def test_plan_made_in_one_thread_refreshes_on_the_calling_threads_stream(gpu):
         util.assert_parity(G.host(used[k]), oracle.spmv(shape, rowptr, colind, v, x_h),
                            oracle.spmv_absrow(rowptr, colind, v, x_h), np.float32, row_len=lens,
                            what=f"cross-thread plan after in-place scaling by {k}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("preload", ["1", "0"])
+def test_first_handle_loads_the_code_objects_or_leaves_it_to_the_first_use(gpu, preload):
+    """spblas_gfx950_create: the first handle of a process loads the library's code objects (SPBLAS_GFX950_PRELOAD=0:
+    the runtime loads each at the first launch, as before).  Either way a fresh process computes the same product; with
+    the preload the first inspect no longer pays for the loading."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import time, numpy as np, torch, spblas_reference_amd as sp\n"
+        "from spblas_reference_amd.api import _Handle\n"
+        "dev = torch.device('cuda:0')\n"
+        "torch.cuda.synchronize(); t0 = time.perf_counter(); _Handle.current(dev); t_handle = time.perf_counter() - t0\n"
+        "rng = np.random.default_rng(5); m, n = 3000, 2000\n"
+        "lens = rng.integers(0, 12, m); rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32); nnz = int(rp[-1])\n"
+        "ci = rng.integers(0, n, nnz).astype(np.int32); v = rng.random(nnz).astype(np.float32); x = rng.random(n).astype(np.float32)\n"
+        "a = sp.csr_view(torch.from_numpy(v).to(dev), torch.from_numpy(rp).to(dev), torch.from_numpy(ci).to(dev), (m, n), nnz)\n"
+        "xd = torch.from_numpy(x).to(dev); y = torch.empty(m, device=dev)\n"
+        "torch.cuda.synchronize(); t0 = time.perf_counter(); info = sp.multiply_inspect(a, xd, y); torch.cuda.synchronize()\n"
+        "t_inspect = time.perf_counter() - t0\n"
+        "sp.multiply(info, a, xd, y)\n"
+        "ref = np.zeros(m, dtype=np.float64); np.add.at(ref, np.repeat(np.arange(m), lens), v.astype(np.float64) * x[ci])\n"
+        "assert np.allclose(y.cpu().numpy(), ref, rtol=1e-5, atol=1e-5)\n"
+        "print('TIMES', t_handle * 1e3, t_inspect * 1e3)\n")
+    env = dict(os.environ, SPBLAS_GFX950_PRELOAD=preload)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=root, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    t_handle, t_inspect = (float(t) for t in r.stdout.split("TIMES")[1].split())
+    if preload == "0":
+        assert t_handle < 5.0, f"no preload asked for, yet the handle took {t_handle:.1f} ms"
