@@ -219,6 +219,14 @@ static int cmp_i32(const void* a, const void* b) {
   int32_t x = *(const int32_t*) a, y = *(const int32_t*) b;
   return (x > y) - (x < y);
 }
+/* The column sort of every result row (spgemm_gustavsons.hpp:42, add_impl.hpp).  -DORACLE_MUTATION_NO_SORT builds a
+ * deliberately broken oracle for ONE test (tests/test_oracle_reference_tests.py: the reference's own tests, which do not
+ * look at column order themselves, must fail on it through the shim's order check). */
+#ifdef ORACLE_MUTATION_NO_SORT
+#define ORACLE_SORT_COLUMNS(stored, cnt) ((void) 0)
+#else
+#define ORACLE_SORT_COLUMNS(stored, cnt) qsort((stored), (size_t) (cnt), sizeof(int32_t), cmp_i32)
+#endif
 
 /* ------------------------------------------------------------------------ */
 /* SpGEMM numeric: multiply_fill(info,A,B,C) -> multiply(A,B,C)               */
@@ -271,7 +279,7 @@ static int cmp_i32(const void* a, const void* b) {
           data[j] += a_v * b_v;                                                \
         }                                                                      \
       }                                                                        \
-      qsort(stored, (size_t) cnt, sizeof(int32_t), cmp_i32);                   \
+      ORACLE_SORT_COLUMNS(stored, cnt);                                                           \
       if (jp + cnt > capacity) {                                               \
         rc = ORACLE_ERR_NOSPACE;                                               \
         for (int64_t t = 0; t < cnt; t++) {                                    \
@@ -407,7 +415,7 @@ int oracle_spgemm_symbolic_d(int64_t m, int64_t k, int64_t n, int64_t c_rows,
         }                                                                      \
         data[j] += beta * d_values[q];                                         \
       }                                                                        \
-      qsort(stored, (size_t) cnt, sizeof(int32_t), cmp_i32);                   \
+      ORACLE_SORT_COLUMNS(stored, cnt);                                                           \
       if (jp + cnt > capacity) {                                               \
         rc = ORACLE_ERR_NOSPACE;                                               \
         for (int64_t t = 0; t < cnt; t++) {                                    \
@@ -488,7 +496,7 @@ DEF_SPGEMM_NUMERIC_D(oracle_spgemm_numeric_d_f64, double)
         if (numeric)                                                           \
           data[j] += has_sb ? sb * b_values[p] : b_values[p];                  \
       }                                                                        \
-      qsort(stored, (size_t) cnt, sizeof(int32_t), cmp_i32);                   \
+      ORACLE_SORT_COLUMNS(stored, cnt);                                                           \
       if (numeric && jp + cnt > capacity) {                                    \
         rc = ORACLE_ERR_NOSPACE;                                               \
         break;                                                                 \

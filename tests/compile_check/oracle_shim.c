@@ -11,6 +11,7 @@
  * Nothing in the product links or loads this file.
  */
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -63,6 +64,25 @@ struct spblas_gfx950_spgemm_s {
 struct spblas_gfx950_trsv_s {
   int uplo, diag;
 };
+
+/* Column order of a result the reference's own comparators do not look at (they re-accumulate C's rows through a sparse
+ * accumulator, test/gtest/spgemm_test.cpp:56-65): every row of an SpGEMM / add result must come back with strictly
+ * ascending columns (spgemm_gustavsons.hpp:42 sorts).  Checked here so that the reference's tests,
+ * run on the oracle, fail when the oracle stops sorting. */
+static int rows_strictly_ascending(int64_t m, const int32_t* rowptr, const int32_t* colind) {
+  for (int64_t r = 0; r < m; ++r)
+    for (int32_t p = rowptr[r] + 1; p < rowptr[r + 1]; ++p)
+      if (colind[p - 1] >= colind[p]) {
+        fprintf(stderr, "oracle shim: row %lld of the result is not in ascending column order\n", (long long) r);
+        return 0;
+      }
+  return 1;
+}
+static int checked(int rc, int64_t m, const int32_t* rowptr, const int32_t* colind) {
+  if (rc == 0 && !rows_strictly_ascending(m, rowptr, colind))
+    return 3;
+  return rc;
+}
 
 static int map_rc(int rc) {
   switch (rc) {
@@ -284,14 +304,16 @@ int spblas_gfx950_spgemm_numeric(spblas_gfx950_handle_t handle, spblas_gfx950_sp
     return SPBLAS_GFX950_STATUS_INSUFFICIENT_SPACE;
   if (value_type == SPBLAS_GFX950_F32) {
     const float a = *(const float*) alpha;
-    return map_rc(oracle_spgemm_numeric_f32(m, k, n, m, n, k, a_rowptr, a_colind, (const float*) a_values, a != 1.f, a,
-                                            b_rowptr, b_colind, (const float*) b_values, 0, 0.f, c_rowptr, c_colind,
-                                            (float*) c_values, c_capacity, &nnz));
+    return map_rc(checked(oracle_spgemm_numeric_f32(m, k, n, m, n, k, a_rowptr, a_colind, (const float*) a_values, a != 1.f, a,
+                                                    b_rowptr, b_colind, (const float*) b_values, 0, 0.f, c_rowptr, c_colind,
+                                                    (float*) c_values, c_capacity, &nnz),
+                          m, c_rowptr, c_colind));
   }
   const double a = *(const double*) alpha;
-  return map_rc(oracle_spgemm_numeric_f64(m, k, n, m, n, k, a_rowptr, a_colind, (const double*) a_values, a != 1.0, a,
-                                          b_rowptr, b_colind, (const double*) b_values, 0, 0.0, c_rowptr, c_colind,
-                                          (double*) c_values, c_capacity, &nnz));
+  return map_rc(checked(oracle_spgemm_numeric_f64(m, k, n, m, n, k, a_rowptr, a_colind, (const double*) a_values, a != 1.0, a,
+                                                  b_rowptr, b_colind, (const double*) b_values, 0, 0.0, c_rowptr, c_colind,
+                                                  (double*) c_values, c_capacity, &nnz),
+                        m, c_rowptr, c_colind));
 }
 int spblas_gfx950_spgemm_numeric_addend(spblas_gfx950_handle_t handle, spblas_gfx950_spgemm_t state, const void* alpha,
                                         const int32_t* a_rowptr, const int32_t* a_colind, const void* a_values,
@@ -307,14 +329,16 @@ int spblas_gfx950_spgemm_numeric_addend(spblas_gfx950_handle_t handle, spblas_gf
   if (c_capacity < state->c_nnz)
     return SPBLAS_GFX950_STATUS_INSUFFICIENT_SPACE;
   if (value_type == SPBLAS_GFX950_F32)
-    return map_rc(oracle_spgemm_numeric_d_f32(m, k, n, m, n, k, m, n, a_rowptr, a_colind, (const float*) a_values,
-                                              *(const float*) alpha, b_rowptr, b_colind, (const float*) b_values,
-                                              *(const float*) beta, d_rowptr, d_colind, (const float*) d_values, c_rowptr,
-                                              c_colind, (float*) c_values, c_capacity, &nnz));
-  return map_rc(oracle_spgemm_numeric_d_f64(m, k, n, m, n, k, m, n, a_rowptr, a_colind, (const double*) a_values,
-                                            *(const double*) alpha, b_rowptr, b_colind, (const double*) b_values,
-                                            *(const double*) beta, d_rowptr, d_colind, (const double*) d_values, c_rowptr,
-                                            c_colind, (double*) c_values, c_capacity, &nnz));
+    return map_rc(checked(oracle_spgemm_numeric_d_f32(m, k, n, m, n, k, m, n, a_rowptr, a_colind, (const float*) a_values,
+                                                      *(const float*) alpha, b_rowptr, b_colind, (const float*) b_values,
+                                                      *(const float*) beta, d_rowptr, d_colind, (const float*) d_values,
+                                                      c_rowptr, c_colind, (float*) c_values, c_capacity, &nnz),
+                          m, c_rowptr, c_colind));
+  return map_rc(checked(oracle_spgemm_numeric_d_f64(m, k, n, m, n, k, m, n, a_rowptr, a_colind, (const double*) a_values,
+                                                    *(const double*) alpha, b_rowptr, b_colind, (const double*) b_values,
+                                                    *(const double*) beta, d_rowptr, d_colind, (const double*) d_values,
+                                                    c_rowptr, c_colind, (double*) c_values, c_capacity, &nnz),
+                        m, c_rowptr, c_colind));
 }
 int spblas_gfx950_csr_add_symbolic(spblas_gfx950_handle_t handle, spblas_gfx950_spgemm_t state, int64_t m, int64_t n,
                                    int64_t a_nnz, const int32_t* a_rowptr, const int32_t* a_colind, int64_t b_nnz,
@@ -337,14 +361,16 @@ int spblas_gfx950_csr_add_numeric(spblas_gfx950_handle_t handle, spblas_gfx950_s
   const int64_t m = state->m, n = state->n;
   if (value_type == SPBLAS_GFX950_F32) {
     const float a = *(const float*) alpha, b = *(const float*) beta;
-    return map_rc(oracle_add_f32(m, n, m, n, m, n, a_rowptr, a_colind, (const float*) a_values, a != 1.f, a, b_rowptr,
-                                 b_colind, (const float*) b_values, b != 1.f, b, c_rowptr, c_colind, (float*) c_values,
-                                 c_capacity, &nnz));
+    return map_rc(checked(oracle_add_f32(m, n, m, n, m, n, a_rowptr, a_colind, (const float*) a_values, a != 1.f, a, b_rowptr,
+                                         b_colind, (const float*) b_values, b != 1.f, b, c_rowptr, c_colind, (float*) c_values,
+                                         c_capacity, &nnz),
+                          m, c_rowptr, c_colind));
   }
   const double a = *(const double*) alpha, b = *(const double*) beta;
-  return map_rc(oracle_add_f64(m, n, m, n, m, n, a_rowptr, a_colind, (const double*) a_values, a != 1.0, a, b_rowptr, b_colind,
-                               (const double*) b_values, b != 1.0, b, c_rowptr, c_colind, (double*) c_values, c_capacity,
-                               &nnz));
+  return map_rc(checked(oracle_add_f64(m, n, m, n, m, n, a_rowptr, a_colind, (const double*) a_values, a != 1.0, a, b_rowptr,
+                                       b_colind, (const double*) b_values, b != 1.0, b, c_rowptr, c_colind, (double*) c_values,
+                                       c_capacity, &nnz),
+                        m, c_rowptr, c_colind));
 }
 
 /* ---- transpose, scale, triangular solve ---- */

@@ -84,3 +84,34 @@ def test_cpu_stack_is_clean_under_asan_and_ubsan(which):
     assert r.returncode == 0, tail
     assert ("28 tests ran, 0 failed" if which == "host" else "14 tests ran, 0 failed") in r.stdout, tail
     assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error:" not in r.stderr, tail
+
+
+def test_reference_tests_notice_an_oracle_that_stops_sorting(tmp_path):
+    """Mutation check of the pin itself.  The reference's SpGEMM / add comparators re-accumulate C's rows through a sparse
+    accumulator (test/gtest/spgemm_test.cpp:56-65), so they accept any column order -- while the result must come back
+    sorted (spgemm_gustavsons.hpp:42).  oracle_shim.c therefore checks the order of every SpGEMM / add
+    result it hands back; an oracle built WITHOUT its column sort (-DORACLE_MUTATION_NO_SORT), preloaded over the shim of
+    the very same test binary, must make the reference's own tests fail."""
+    import shutil
+    binp = build_dropin.ORACLE_HOST_TESTS
+    if os.path.isdir(build_dropin.REF):
+        binp = build_dropin.build_reference_host_tests_on_oracle() or binp
+    if not os.path.exists(binp):
+        pytest.skip("no reference tree here and no prebuilt reference_host_tests_on_oracle")
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    mutant = str(tmp_path / "liboracle_shim_nosort.so")
+    here = os.path.join(ROOT, "tests", "compile_check")
+    r = subprocess.run([gcc, "-O2", "-fPIC", "-shared", "-DORACLE_MUTATION_NO_SORT", "-I", os.path.join(ROOT, "include"),
+                        os.path.join(here, "oracle_shim.c"), os.path.join(ROOT, "oracle", "spblas_oracle.c"), "-o", mutant],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    good = subprocess.run([binp], capture_output=True, text=True, timeout=900)
+    assert good.returncode == 0 and "0 failed" in good.stdout
+    bad = subprocess.run([binp], capture_output=True, text=True, timeout=900, env=dict(os.environ, LD_PRELOAD=mutant))
+    out = bad.stdout + bad.stderr
+    assert bad.returncode != 0, "the reference's tests passed on an oracle that does not sort its rows"
+    assert "not in ascending column order" in out, out[-3000:]
+    failed = [line for line in bad.stdout.splitlines() if line.startswith("[  FAILED  ]")]
+    assert any("SpGEMM" in line for line in failed), failed
