@@ -126,7 +126,7 @@ def secondary(args, device, log=None):
     HIP events and checked against the oracle; compact records for the `secondary` object of bench.py's JSON line."""
     import copy
     res = {}
-    todo = [("cfg2_plain_csr_view", "spmv_plain"), ("cfg4", "spmv_rmat1"), ("cfg3", "spmm"), ("spmm_banded", "spmm_banded"),
+    todo = [("cfg2_plain_csr_view", "spmv_plain"), ("cfg2_poisson", "spmv_poisson1"), ("cfg4", "spmv_rmat1"), ("cfg3", "spmm"), ("spmm_banded", "spmm_banded"),
             ("cfg5", "spgemm")]
     if not getattr(args, "no_8f", False):  # SURVEY 8(f): add, transpose, triangular solve at their bench sizes
         todo += [("f_add", "add"), ("f_transpose", "transpose"), ("f_sptrsv", "sptrsv")]
@@ -296,6 +296,54 @@ def _run_spmv_plain(args, device, sp, oracle, generate):
                  pmc_key="spmv_plain_cfg2" if (args.rows is None and vf) else None)
 
 
+def _run_spmv_poisson(args, device, sp, oracle, generate):
+    """cfg2 with Poisson(10) row lengths instead of exactly 10 ("row lengths = 10 exactly and a
+    Poisson(10) variant (report both)"): the same columns / values distributions, matrix_opt operand like the headline."""
+    m = n = args.rows or 10_000_000
+    values, rowptr, colind, shape, nnz = generate.uniform_csr_device(m, n, 10, seed=0, device=device, poisson=True)
+    a = sp.csr_view(values, rowptr, colind, shape, nnz)
+    g = torch.Generator(device=device).manual_seed(11)
+    x = torch.rand(n, device=device, generator=g)
+    y = torch.empty(m, device=device)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    a_opt = sp.matrix_opt(a)
+    info = sp.multiply_inspect(a_opt, x, y)
+    torch.cuda.synchronize()
+    inspect_ms = (time.perf_counter() - t0) * 1e3
+    elapsed, ms = _time_steps(lambda: sp.multiply(info, a_opt, x, y), args.warmup, args.steps)
+    plan = info.state_.info()
+    if plan.get("alg") == 3 and hasattr(info.state_, "sliced_info"):
+        plan["sliced"] = info.state_.sliced_info()
+    y.fill_(float("nan"))
+    sp.multiply(info, a_opt, x, y)
+    torch.cuda.synchronize()
+    alg_bytes = nnz * 8 + (m + 1) * 4 + (n + m) * 4
+    rows = np.unique(np.concatenate([np.arange(0, min(m, 1500)), np.arange(max(0, m - 1500), m),
+                                     np.random.default_rng(5).integers(0, m, 3000)]))
+    sub_rp, sub_ci, sub_v = rows_subproblem(rows, rowptr, colind, values)
+    xh = x.cpu().numpy()
+    y_ref = oracle.spmv((len(rows), n), sub_rp, sub_ci, sub_v, xh)
+    absrow = oracle.spmv_absrow(sub_rp, sub_ci, sub_v, xh)
+    nbad, worst = parity_rows(y[torch.from_numpy(rows).to(device)].cpu().numpy(), y_ref, absrow.astype(np.float64), 1e-6,
+                              float(np.finfo(np.float32).eps), np.diff(sub_rp))
+    # every row: the fp64 checksum of y against the one computed from the entries (a dropped or doubled entry anywhere shows)
+    chk = float(y.double().sum().item())
+    ref_chk = float((values.double() * x[colind.long()].double()).sum().item())
+    chk_ok = abs(chk - ref_chk) <= 1e-6 * abs(ref_chk)
+    parity = {"status": "pass" if nbad == 0 and chk_ok else "fail", "rows": int(len(rows)), "rows_out_of_bound": nbad,
+              "tol": 1e-6, "worst_err_over_rownorm": worst, "checksum_rel_err": abs(chk - ref_chk) / max(abs(ref_chk), 1e-300),
+              "against": "oracle_spmv on the first / last 1 500 and 3 000 sampled rows; fp64 checksum of all of y against "
+                         "sum(values * x[colind]) on the device"}
+    return _emit(args, "csr_spmv_gflops", 2.0 * nnz, alg_bytes, elapsed, ms,
+                 f"cfg2, Poisson variant: fp32 CSR SpMV {m}x{n}, Poisson(10) nnz/row, uniform random unsorted columns, nnz={nnz}",
+                 {"dtype": "f32", "rows": m, "nnz": nnz, "operand": "matrix_opt(csr_view) + multiply_inspect", "plan": plan,
+                  "plan_bytes": plan.get("device_bytes"), "inspect_ms_untimed": inspect_ms,
+                  "kernel": "pb_expand_kernel<float,false,false> + pb_reduce_kernel<float,...>" if plan.get("alg") == 3
+                  else "spmv_rowblock_kernel<float,int,1024>"}, None, parity=parity,
+                 pmc_key="spmv_poisson_cfg2" if args.rows is None else None)
+
+
 def _run(args, device):
     import spblas_reference_amd as sp
     from oracle import oracle
@@ -303,6 +351,8 @@ def _run(args, device):
 
     if args.workload == "spmv_plain":
         return _run_spmv_plain(args, device, sp, oracle, generate)
+    if args.workload == "spmv_poisson1":
+        return _run_spmv_poisson(args, device, sp, oracle, generate)
     if args.workload == "spmv_rmat1":
         return _run_spmv_rmat1(args, device, sp, oracle, generate)
 

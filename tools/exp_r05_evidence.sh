@@ -4,12 +4,14 @@
 # matrix-core counters of the SpMM panel kernel.  Usage: tools/exp_r05_evidence.sh [which ...]  (default: all)
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $ROOT
-WHICH=${*:-"cfg2 plain cfg4 cfg3 banded cfg5 add transpose sptrsv mfma"}
+WHICH=${*:-"cfg2 plain poisson cfg4 cfg3 banded cfg5 add transpose sptrsv mfma"}
 for w in $WHICH; do
   case $w in
     cfg2) bash tools/profile.sh r05x > gpurun_out/ev_$w.log 2>&1; python3 tools/stamp_traffic.py r05x >> gpurun_out/ev_$w.log 2>&1;;
     plain) bash tools/profile.sh r05p --workload spmv_plain > gpurun_out/ev_$w.log 2>&1
            python3 tools/stamp_traffic.py r05p spmv_plain_cfg2 spmv_sliced.hip 'pb_expand_kernel<float' 'pb_reduce_vf_kernel<float' >> gpurun_out/ev_$w.log 2>&1;;
+    poisson) bash tools/profile.sh r05pp --workload spmv_poisson1 > gpurun_out/ev_$w.log 2>&1
+           python3 tools/stamp_traffic.py r05pp spmv_poisson_cfg2 spmv_sliced.hip 'pb_expand_kernel<float' 'pb_reduce_kernel<float' >> gpurun_out/ev_$w.log 2>&1;;
     cfg4) bash tools/profile.sh r05x4 --workload spmv_rmat1 > gpurun_out/ev_$w.log 2>&1
           python3 tools/stamp_traffic.py r05x4 spmv_rmat spmv_sliced.hip 'pb_expand_kernel<double' 'pb_reduce_kernel<double' 'pb_split_finish_kernel<double' 'pb_empty_rows_kernel<double' 'pb_hot_rows_kernel<double' 'pb_hot_fixup_kernel<double' >> gpurun_out/ev_$w.log 2>&1;;
     cfg3) bash tools/profile.sh r05a3 --workload spmm > gpurun_out/ev_$w.log 2>&1
