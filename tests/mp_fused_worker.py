@@ -149,8 +149,13 @@ def main():
             op2.check_status()
             assert torch.equal(y, ref_chain[-1]), f"rank {rank}: chunked chain differs from the barrier chain (delay {delay})"
             waited = op2.chunk_wait_us()
-            if delay != "0" and world > 1 and chunks > 1 and rank != world - 1:
-                assert waited >= 2000.0, f"rank {rank}: no expand waited for the late chunk ({waited} us)"
+            # Some expand must have waited for the late chunk (and report it).  Not EVERY rank's: with the ranks sharing one
+            # GPU their kernels are time-sliced, and a rank whose expand was only scheduled after the late chunk had landed
+            # never waits (seen once in five runs of the 8-rank case) -- so the largest wait over the other ranks is checked.
+            w_all = torch.tensor([waited if rank != world - 1 else 0.0], dtype=torch.float64)
+            dist.all_reduce(w_all, op=dist.ReduceOp.MAX)
+            if delay != "0" and world > 1 and chunks > 1:
+                assert float(w_all.item()) >= 2000.0, f"no expand on any rank waited for the late chunk ({float(w_all.item())} us)"
             # a step() after the chain flushes it; both copies of y are in use again afterwards
             assert torch.equal(op2.step(x0), ref_chain[0])
         os.environ.pop("SPBLAS_GFX950_CHUNK_DELAY_US", None)
