@@ -18,11 +18,13 @@
 //             inside a run of NARROW levels (workgroup 0 alone), the loads that do not depend on x pipelined three
 //             levels ahead.  Where a cooperative launch is not possible (stream capture, device attribute missing,
 //             a narrow run longer than 4096 levels, SPBLAS_GFX950_TRSV_COOP=0): one launch per wide level and one
-//             single-workgroup launch per narrow run.  SPBLAS_GFX950_TRSV_SELFSCHED=1 selects a third form, one
-//             self-scheduling launch per run of wide levels with {value, solve number} granules as the hand-off.
-//             Measured at 4 M rows / 246 levels / 36 M entries: 1.70 ms cooperative, 1.86 ms launch per level,
-//             2.59 ms self-scheduling; the floor is the x gather (32 M agent-scope 64-byte fetches, ~0.5 ms) plus
-//             one store -> load hand-off per level.
+//             single-workgroup launch per narrow run.  Measured at 4 M rows / 246 levels / 36 M entries: 1.70 ms
+//             cooperative, 1.74 ms launch per level; the floor is the x gather (32 M agent-scope 64-byte fetches,
+//             ~0.5 ms) plus one store -> load hand-off per level.  (Rounds 2 - 4 carried a third, barrier-free form
+//             behind SPBLAS_GFX950_TRSV_SELFSCHED=1 -- one self-scheduling launch per run of wide levels with {value,
+//             solve number} granules as the hand-off, 2.59 ms.  Round 5's fuzzer found that its fp64 form stops making
+//             progress on some 400 k-row matrices (the bounded polls then gave up with wrong values); a slower opt-in
+//             path has no user, so it was removed rather than repaired.)
 // Row sums are computed G lanes wide and tree-reduced, so they re-associate with respect to the
 // reference's sequential loop: parity is norm-wise, not bit-wise.
 #include "common.hpp"
@@ -40,8 +42,6 @@ static int env_int(const char* name, int def) {  // tuning / test hook
 
 #define TRSV_NARROW 2048       // inspect: frontiers with fewer rows are advanced by the single-workgroup kernel
 #define TRSV_BLOCK_THREADS 1024
-#define TRSV_SC_PASSES 2        // solve: wavefront passes per ticket of the self-scheduling kernel
-#define TRSV_SS_WAVES 16        // wavefronts per workgroup of the self-scheduling kernel (2 workgroups per CU fill it)
 
 struct spblas_gfx950_trsv_s {
   int64_t m = 0, nnz = 0;
@@ -58,14 +58,7 @@ struct spblas_gfx950_trsv_s {
   int lanes = 8;  // lanes per row in the solve kernels
   int narrow = 128;      // levels with fewer rows are "narrow": walked by one workgroup
   bool coop_ok = false;  // the solve is ONE cooperative launch (trsv_coop_kernel)
-  // self-scheduling solve of the wide runs: per wide group the cumulative chunk counts of its levels
-  // (chunk_ptr[group.cp0 .. group.cp0 + levels]), one ticket counter per group, and the granules
-  int32_t* chunk_ptr = nullptr;       // device
-  int32_t* tickets = nullptr;         // device [n_groups + 1] (+ 1 status word at the end)
-  unsigned long long* gran = nullptr; // device [2 * m]: {x bits (fp32) or half of them (fp64), solve number}
-  unsigned epoch = 0;                 // solve number (tags of earlier solves never match)
-  std::vector<int32_t> group_cp0;     // per group: first index into chunk_ptr (wide groups), -1 otherwise
-  std::vector<int32_t> group_chunks;  // per group: chunks in total
+  int32_t* tickets = nullptr;         // device: status word and the grid barrier's counters / release lines
 };
 
 namespace spb {
@@ -353,50 +346,13 @@ __global__ __launch_bounds__(TRSV_BLOCK_THREADS) void trsv_bfs_block_kernel(cons
   }
 }
 
-// ---- granules: x_r published for consumers INSIDE a running kernel ---------------------------------------
-// gran[2r] (fp32) / gran[2r], gran[2r+1] (fp64: low and high half) = {payload : 32, solve number : 32}, written by
-// ONE naturally aligned 8-byte agent-scope store each: the data is the flag (cdna_hip_programming.md, Guideline 16,
-// form R2) -- a consumer that reads the current solve number in the tag holds the value, no fence on either side.
-template <typename T>
-__device__ __forceinline__ void trsv_publish(unsigned long long* gran, int r, T v, unsigned epoch);
-template <>
-__device__ __forceinline__ void trsv_publish<float>(unsigned long long* gran, int r, float v, unsigned epoch) {
-  __hip_atomic_store(&gran[2 * (int64_t) r], ((unsigned long long) epoch << 32) | __float_as_uint(v), __ATOMIC_RELAXED,
-                     __HIP_MEMORY_SCOPE_AGENT);
-}
-template <>
-__device__ __forceinline__ void trsv_publish<double>(unsigned long long* gran, int r, double v, unsigned epoch) {
-  const unsigned long long bits = (unsigned long long) __double_as_longlong(v);
-  __hip_atomic_store(&gran[2 * (int64_t) r], ((unsigned long long) epoch << 32) | (bits & 0xFFFFFFFFull), __ATOMIC_RELAXED,
-                     __HIP_MEMORY_SCOPE_AGENT);
-  __hip_atomic_store(&gran[2 * (int64_t) r + 1], ((unsigned long long) epoch << 32) | (bits >> 32), __ATOMIC_RELAXED,
-                     __HIP_MEMORY_SCOPE_AGENT);
-}
-// one poll: true when x_c of this solve has arrived (then *out holds it)
-template <typename T>
-__device__ __forceinline__ bool trsv_try_read(const unsigned long long* gran, int c, unsigned epoch, T* out);
-template <>
-__device__ __forceinline__ bool trsv_try_read<float>(const unsigned long long* gran, int c, unsigned epoch, float* out) {
-  const unsigned long long g = __hip_atomic_load(&gran[2 * (int64_t) c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  *out = __uint_as_float((unsigned) g);
-  return (unsigned) (g >> 32) == epoch;
-}
-template <>
-__device__ __forceinline__ bool trsv_try_read<double>(const unsigned long long* gran, int c, unsigned epoch, double* out) {
-  const unsigned long long lo = __hip_atomic_load(&gran[2 * (int64_t) c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const unsigned long long hi = __hip_atomic_load(&gran[2 * (int64_t) c + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  *out = __longlong_as_double((long long) ((hi << 32) | (lo & 0xFFFFFFFFull)));
-  return (unsigned) (lo >> 32) == epoch && (unsigned) (hi >> 32) == epoch;
-}
-
 // x_r for one row, computed by a group of G lanes (all lanes of the group return the same values).
 // Entries whose column lies outside [0, m) are ignored, as the inspect kernels ignore them; a row without a
 // stored diagonal divides by alpha * 0 (the reference would reuse the previous row's diagonal: undefined input).
 template <typename T, int G>
 __device__ __forceinline__ void trsv_row(int r, int lane, const int32_t* __restrict__ rowptr,
                                          const int32_t* __restrict__ colind, const T* __restrict__ values, T alpha,
-                                         const T* __restrict__ b, T* x, int upper, int unit, int m,
-                                         unsigned long long* __restrict__ gran, unsigned epoch) {
+                                         const T* __restrict__ b, T* x, int upper, int unit, int m) {
   T dot = T(0), dval = T(0);
   int dpos = -1;
   const int p1 = rowptr[r + 1];
@@ -424,95 +380,6 @@ __device__ __forceinline__ void trsv_row(int r, int lane, const int32_t* __restr
     if (!unit)
       v = v / (alpha * (dpos >= 0 ? dval : T(0)));
     __hip_atomic_store(&x[r], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (gran)
-      trsv_publish<T>(gran, r, v, epoch);  // consumers inside a later self-scheduling launch poll the granule
-  }
-}
-
-// A run of consecutive WIDE levels [l0, l0 + nlev) in one launch.  Work = chunks of 64 / G rows that never cross a
-// level boundary (rows of one level are independent); chunk_ptr[i] = chunks before level l0 + i.  A wavefront takes
-// the next chunk from the ticket counter, loads its rows (independent of x), and polls the granule of every x_c it
-// needs: chunks are handed out in level order to RUNNING wavefronts, so whatever a wavefront waits for belongs to a
-// ticket taken earlier by a wavefront that is running too -- no residency assumption, no grid barrier.  Every spin is
-// bounded: after `spin_limit` polls the wave raises status[0] and gives up (the host reports HIP_ERROR).
-template <typename T, int G>
-__global__ __launch_bounds__(TRSV_SS_WAVES * 64) void trsv_selfsched_kernel(int l0, int nlev, const int32_t* __restrict__ chunk_ptr,
-                                                             const int32_t* __restrict__ level_ptr,
-                                                             const int32_t* __restrict__ order,
-                                                             const int32_t* __restrict__ rowptr,
-                                                             const int32_t* __restrict__ colind,
-                                                             const T* __restrict__ values, T alpha,
-                                                             const T* __restrict__ b, T* x, int upper, int unit, int m,
-                                                             unsigned long long* __restrict__ gran, unsigned epoch,
-                                                             int* __restrict__ ticket, int* __restrict__ status,
-                                                             int spin_limit) {
-  constexpr int RPW = 64 / G;                 // rows per wavefront pass
-  constexpr int SC = TRSV_SC_PASSES * TRSV_SS_WAVES * RPW;  // rows per ticket: the workgroup's wavefronts x passes
-  __shared__ int s_ticket;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, gl = lane % G, grp = lane / G;
-  const int total = chunk_ptr[nlev];
-  while (true) {
-    // one ticket per workgroup and 32 * RPW rows: a single counter hands out ~90 tickets per microsecond
-    // (MI355X_MICROARCH.md, dequeue), 4 M rows in tickets of 8 would queue for milliseconds
-    __syncthreads();
-    if (threadIdx.x == 0)
-      s_ticket = atomicAdd(ticket, 1);
-    __syncthreads();
-    const int t = s_ticket;
-    if (t >= total)
-      return;
-    int lo = 0, hi = nlev;  // level of chunk t: last i with chunk_ptr[i] <= t
-    while (hi - lo > 1) {
-      const int mid = (lo + hi) >> 1;
-      if (chunk_ptr[mid] <= t)
-        lo = mid;
-      else
-        hi = mid;
-    }
-    const int f0 = level_ptr[l0 + lo], f1 = level_ptr[l0 + lo + 1];
-    const int base = f0 + (t - chunk_ptr[lo]) * SC;
-   for (int pass = 0; pass < TRSV_SC_PASSES; ++pass) {
-    const int idx = base + (pass * TRSV_SS_WAVES + wave) * RPW + grp;
-    if (base + pass * TRSV_SS_WAVES * RPW >= f1)
-      break;
-    const bool live = idx < f1;
-    const int r = live ? order[idx] : 0;
-    T dot = T(0);
-    int dpos = -1;
-    const int p0 = live ? rowptr[r] : 0, p1 = live ? rowptr[r + 1] : 0;
-    for (int p = p0 + gl; p < p1; p += G) {
-      const int c = colind[p];
-      const T v = values[p];
-      if (c >= 0 && c < m && trsv_strict(c, r, upper)) {
-        T xc;
-        int spins = 0;
-        while (!trsv_try_read<T>(gran, c, epoch, &xc)) {
-          __builtin_amdgcn_s_sleep(2);
-          if (++spins > spin_limit) {
-            status[0] = 1;
-            xc = T(0);
-            break;
-          }
-        }
-        dot += v * xc;
-      } else if (c == r) {
-        dpos = p;
-      }
-    }
-#pragma unroll
-    for (int o = G >> 1; o > 0; o >>= 1) {
-      dot += __shfl_xor(dot, o, SPB_WAVE);
-      const int other = __shfl_xor(dpos, o, SPB_WAVE);
-      dpos = other > dpos ? other : dpos;
-    }
-    if (live && gl == 0) {
-      T v = b[r] - alpha * dot;
-      if (!unit)
-        v = v / (alpha * (dpos >= 0 ? values[dpos] : T(0)));
-      x[r] = v;
-      trsv_publish<T>(gran, r, v, epoch);
-    }
-   }
   }
 }
 
@@ -706,7 +573,7 @@ __global__ __launch_bounds__(TRSV_COOP_THREADS) void trsv_coop_kernel(int n_leve
       const int slot = first_slot(l, &f1, &stride);
       if (!(dbg & 8))
       for (int idx = slot + R * stride; idx < f1; idx += stride)
-        trsv_row<T, G>(order[idx], gl, rowptr, colind, values, alpha, b, x, upper, unit, m, nullptr, 0u);
+        trsv_row<T, G>(order[idx], gl, rowptr, colind, values, alpha, b, x, upper, unit, m);
     }
     if (l + 1 == n_levels)
       break;
@@ -736,12 +603,11 @@ __global__ __launch_bounds__(256) void trsv_level_kernel(int f0, int f1, const i
                                                          const int32_t* __restrict__ rowptr,
                                                          const int32_t* __restrict__ colind,
                                                          const T* __restrict__ values, T alpha,
-                                                         const T* __restrict__ b, T* x, int upper, int unit, int m,
-                                                         unsigned long long* __restrict__ gran, unsigned epoch) {
+                                                         const T* __restrict__ b, T* x, int upper, int unit, int m) {
   const int idx = f0 + blockIdx.x * (256 / G) + threadIdx.x / G;
   if (idx >= f1)
     return;
-  trsv_row<T, G>(order[idx], threadIdx.x % G, rowptr, colind, values, alpha, b, x, upper, unit, m, gran, epoch);
+  trsv_row<T, G>(order[idx], threadIdx.x % G, rowptr, colind, values, alpha, b, x, upper, unit, m);
 }
 
 // levels [l0, l1), all narrow: one workgroup, a barrier between levels
@@ -753,13 +619,11 @@ __global__ __launch_bounds__(TRSV_BLOCK_THREADS) void trsv_chain_kernel(int l0, 
                                                                        const int32_t* __restrict__ colind,
                                                                        const T* __restrict__ values, T alpha,
                                                                        const T* __restrict__ b, T* x, int upper,
-                                                                       int unit, int m,
-                                                                       unsigned long long* __restrict__ gran,
-                                                                       unsigned epoch) {
+                                                                       int unit, int m) {
   for (int l = l0; l < l1; ++l) {
     const int f0 = level_ptr[l], f1 = level_ptr[l + 1];
     for (int idx = f0 + threadIdx.x / G; idx < f1; idx += TRSV_BLOCK_THREADS / G)
-      trsv_row<T, G>(order[idx], threadIdx.x % G, rowptr, colind, values, alpha, b, x, upper, unit, m, gran, epoch);
+      trsv_row<T, G>(order[idx], threadIdx.x % G, rowptr, colind, values, alpha, b, x, upper, unit, m);
     __threadfence();  // x of this level must be visible to the whole workgroup before the next one
     __syncthreads();
   }
@@ -772,52 +636,27 @@ static int trsv_solve_typed(spblas_gfx950_handle_t h, spblas_gfx950_trsv_s* pl, 
   const int upper = pl->uplo == SPBLAS_GFX950_UPPER, unit = pl->diag == SPBLAS_GFX950_DIAG_UNIT;
   const int m = (int) pl->m;
   const size_t ng = pl->groups.size();
-  bool any_selfsched = false;
-  for (size_t gi = 0; gi < ng; ++gi)
-    any_selfsched = any_selfsched || (pl->groups[gi].wide && pl->group_cp0[gi] >= 0);
   const int cus = h->num_cus > 0 ? h->num_cus : 256;
-  // ticket counters, [ng] unused, [ng + 1] = status word, then (32-int aligned) the grid barrier: one line for the
-  // arrival counter and one release flag line per workgroup
+  // [ng + 1] = status word (the leading words are unused since the self-scheduling form left), then (32-int aligned) the
+  // grid barrier: one line for the arrival counter and one release flag line per workgroup
   const size_t bar_off = (ng + 2 + 31) / 32 * 32, ctl_ints = bar_off + 32 * (size_t) (9 + 2 * cus);
   // A solve recorded into a graph (hipStreamBeginCapture / torch.cuda.graph) is replayed with the arguments it was
   // recorded with: no cooperative launch (the kernel node does not carry the co-residency guarantee of the launch: replays
-  // were seen to leave rows unsolved), no allocation (the first solve of a plan must run outside the capture), and the
-  // granule tags, which an ordinary solve tells apart by the solve number, are cleared by a recorded memset instead.
+  // were seen to leave rows unsolved), no allocation (the first solve of a plan must run outside the capture).
   const bool capturing = stream_capturing(s);
-  if (capturing && (!pl->tickets || (any_selfsched && !pl->gran)))
+  if (capturing && !pl->tickets)
     return SPBLAS_GFX950_STATUS_NOT_SUPPORTED;
   if (!pl->tickets) {
     int rc = dev_alloc((void**) &pl->tickets, ctl_ints * 4, s);
     if (rc)
       return rc;
   }
-  if (any_selfsched && !pl->gran) {  // granules (tag 0 = never written)
-    int rc = dev_alloc((void**) &pl->gran, (size_t) pl->m * 16, s);
-    if (rc)
-      return rc;
-    SPB_HIP(hipMemsetAsync(pl->gran, 0, (size_t) pl->m * 16, s));
-  }
-  unsigned epoch;
-  if (capturing) {
-    // tag 0xffffffff belongs to recorded solves: every replay clears the granules first, and an ordinary solve that
-    // follows never reaches that number (the wrap below restarts at 1)
-    epoch = 0xffffffffu;
-    if (pl->gran)
-      SPB_HIP(hipMemsetAsync(pl->gran, 0, (size_t) pl->m * 16, s));
-  } else {
-    if (++pl->epoch == 0xffffffffu) {  // the solve number wrapped: start over with clean tags
-      if (pl->gran)
-        SPB_HIP(hipMemsetAsync(pl->gran, 0, (size_t) pl->m * 16, s));
-      pl->epoch = 1;
-    }
-    epoch = pl->epoch;
-  }
   SPB_HIP(hipMemsetAsync(pl->tickets, 0, ctl_ints * 4, s));
   int* status = pl->tickets + ng + 1;
   const int spin_limit = env_int("SPBLAS_GFX950_TRSV_SPIN_LIMIT", 1 << 22);  // ~ seconds of polling
   // the whole solve as one cooperative launch (default when the device offers it and no narrow run is so long
   // that the waiting workgroups could exhaust their bounded spin: 4096 levels ~ 10 ms)
-  if (pl->coop_ok && !any_selfsched && ng > 1 && !capturing) {
+  if (pl->coop_ok && ng > 1 && !capturing) {
     int n_levels = (int) pl->h_level_ptr.size() - 1, narrow = pl->narrow;
     int wgs = env_int("SPBLAS_GFX950_TRSV_COOP_WGS", 1);
     int occ = 0;
@@ -845,28 +684,17 @@ static int trsv_solve_typed(spblas_gfx950_handle_t h, spblas_gfx950_trsv_s* pl, 
       (void) hipGetLastError();  // not launched (e.g. the stream is being captured): one launch per group below
     }
   }
-  bool used_selfsched = false;
   for (size_t gi = 0; gi < ng; ++gi) {
     const auto& g = pl->groups[gi];
-    if (g.wide && pl->group_cp0[gi] >= 0) {
-      const int chunks = pl->group_chunks[gi];
-      // 2 workgroups of 16 wavefronts per CU at most; fewer when the run is short
-      const int grid = (int) std::min<int64_t>((int64_t) cus * 2, chunks);
-      hipLaunchKernelGGL((trsv_selfsched_kernel<T, G>), dim3((unsigned) (grid > 0 ? grid : 1)), dim3(TRSV_SS_WAVES * 64), 0, s, g.l0,
-                         g.l1 - g.l0, pl->chunk_ptr + pl->group_cp0[gi], pl->level_ptr, pl->order, rowptr, colind, values,
-                         alpha, b, x, upper, unit, m, pl->gran, epoch, pl->tickets + gi, status, spin_limit);
-      used_selfsched = true;
-    } else if (g.wide) {
+    if (g.wide) {
       const int f0 = pl->h_level_ptr[g.l0], f1 = pl->h_level_ptr[g.l0 + 1];
       hipLaunchKernelGGL((trsv_level_kernel<T, G>), dim3((unsigned) cdiv(f1 - f0, 256 / G)), dim3(256), 0, s, f0, f1,
-                         pl->order, rowptr, colind, values, alpha, b, x, upper, unit, m, pl->gran, epoch);
+                         pl->order, rowptr, colind, values, alpha, b, x, upper, unit, m);
     } else {
       hipLaunchKernelGGL((trsv_chain_kernel<T, G>), dim3(1), dim3(TRSV_BLOCK_THREADS), 0, s, g.l0, g.l1,
-                         pl->level_ptr, pl->order, rowptr, colind, values, alpha, b, x, upper, unit, m, pl->gran,
-                         epoch);
+                         pl->level_ptr, pl->order, rowptr, colind, values, alpha, b, x, upper, unit, m);
     }
   }
-  (void) used_selfsched;
   SPB_HIP(hipGetLastError());
   return SPBLAS_GFX950_STATUS_SUCCESS;
 }
@@ -931,7 +759,6 @@ int spblas_gfx950_sptrsv_create(spblas_gfx950_handle_t handle, spblas_gfx950_trs
     dev_free(level_ptr, s);
     dev_free(pl->order, s);
     dev_free(pl->level_ptr, s);
-    dev_free(pl->chunk_ptr, s);
     delete pl;
     *plan_out = nullptr;
     return code;
@@ -1046,40 +873,18 @@ int spblas_gfx950_sptrsv_create(spblas_gfx950_handle_t handle, spblas_gfx950_trs
   }  // Kahn fallback
   pl->level_ptr = level_ptr;
   level_ptr = nullptr;
-  // launch groups of the solve: a run of consecutive levels of >= `narrow` rows is ONE self-scheduling launch,
-  // a run of narrower levels ONE single-workgroup launch (SPBLAS_GFX950_TRSV_SELFSCHED=0: one launch per wide level)
+  // launch groups of the solve: every level of >= `narrow` rows is a group of its own (one grid-wide step), a run of
+  // narrower levels ONE single-workgroup group
   const int narrow = env_int("SPBLAS_GFX950_TRSV_NARROW", 128);
-  // measured at 4 M rows / 246 levels: 2.59 ms self-scheduling (5 launches) vs 2.00 ms with one launch per wide level
-  // (161 launches) -- a producer -> consumer hand-off through L2 / fabric costs ~3 us under load and a 512-workgroup
-  // grid keeps fewer rows in flight than a launch per level does, so the launch-per-level solve stays the default
-  const bool selfsched = env_int("SPBLAS_GFX950_TRSV_SELFSCHED", 0) != 0;
-  const int rpw = TRSV_SC_PASSES * TRSV_SS_WAVES * (64 / pl->lanes);  // rows per ticket of the self-scheduling kernel
-  std::vector<int32_t> h_chunk_ptr;
   for (int32_t l = 0; l < n_levels;) {
     const bool wide = lp[l + 1] - lp[l] >= narrow;
     int32_t e1 = l + 1;
-    if (wide && !selfsched) {
-      pl->max_width = std::max<int64_t>(pl->max_width, lp[l + 1] - lp[l]);
-    } else {
-      while (e1 < n_levels && ((lp[e1 + 1] - lp[e1] >= narrow) == wide))
+    if (!wide)
+      while (e1 < n_levels && lp[e1 + 1] - lp[e1] < narrow)
         ++e1;
-      for (int32_t q = l; q < e1; ++q)
-        pl->max_width = std::max<int64_t>(pl->max_width, lp[q + 1] - lp[q]);
-    }
+    for (int32_t q = l; q < e1; ++q)
+      pl->max_width = std::max<int64_t>(pl->max_width, lp[q + 1] - lp[q]);
     pl->groups.push_back({l, e1, wide ? 1 : 0});
-    if (wide && selfsched) {
-      pl->group_cp0.push_back((int32_t) h_chunk_ptr.size());
-      int32_t acc = 0;
-      for (int32_t q = l; q < e1; ++q) {
-        h_chunk_ptr.push_back(acc);
-        acc += (int32_t) cdiv(lp[q + 1] - lp[q], rpw);
-      }
-      h_chunk_ptr.push_back(acc);
-      pl->group_chunks.push_back(acc);
-    } else {
-      pl->group_cp0.push_back(-1);
-      pl->group_chunks.push_back(0);
-    }
     l = e1;
   }
   pl->narrow = narrow;
@@ -1098,15 +903,8 @@ int spblas_gfx950_sptrsv_create(spblas_gfx950_handle_t handle, spblas_gfx950_trs
     const char* tool = std::getenv("ROCP_TOOL_LIBRARIES");
     const char* tool2 = std::getenv("HSA_TOOLS_LIB");
     const bool intercepted = (tool && *tool) || (tool2 && *tool2);
-    pl->coop_ok = coop_attr != 0 && !selfsched && env_int("SPBLAS_GFX950_TRSV_COOP", intercepted ? 0 : 1) != 0 &&
+    pl->coop_ok = coop_attr != 0 && env_int("SPBLAS_GFX950_TRSV_COOP", intercepted ? 0 : 1) != 0 &&
                   longest_run <= env_int("SPBLAS_GFX950_TRSV_COOP_MAX_RUN", 4096);
-  }
-  if (!h_chunk_ptr.empty()) {
-    if ((rc = dev_alloc((void**) &pl->chunk_ptr, h_chunk_ptr.size() * 4, s)))
-      return fail(rc);
-    if ((e = hipMemcpyAsync(pl->chunk_ptr, h_chunk_ptr.data(), h_chunk_ptr.size() * 4, hipMemcpyHostToDevice, s)) != hipSuccess ||
-        (e = hipStreamSynchronize(s)) != hipSuccess)
-      return fail(hip_fail(e));
   }
   dev_free(indeg, s);
   dev_free(adj_ptr, s);
@@ -1124,9 +922,7 @@ int spblas_gfx950_sptrsv_destroy(spblas_gfx950_handle_t handle, spblas_gfx950_tr
     return SPBLAS_GFX950_STATUS_SUCCESS;
   dev_free(plan->order, handle->stream);
   dev_free(plan->level_ptr, handle->stream);
-  dev_free(plan->chunk_ptr, handle->stream);
   dev_free(plan->tickets, handle->stream);
-  dev_free(plan->gran, handle->stream);
   delete plan;
   return SPBLAS_GFX950_STATUS_SUCCESS;
 }

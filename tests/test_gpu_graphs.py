@@ -131,17 +131,13 @@ def test_spgemm_numeric_refill_is_capturable(gpu):
         np.testing.assert_allclose(G.host(c_val), cv, rtol=2e-5)
 
 
-@pytest.mark.parametrize("mode", ["default", "selfsched_solve"])
 @pytest.mark.parametrize("upper", [False, True])
-def test_triangular_solve_with_inspect_is_capturable(gpu, monkeypatch, upper, mode):
+def test_triangular_solve_with_inspect_is_capturable(gpu, monkeypatch, upper):
     """A recorded solve is replayed with the arguments it was recorded with, so inside a capture the library (a) does not
     use the cooperative kernel (its graph node carries no co-residency guarantee: replays left rows unsolved) but one
-    launch per level group, and (b) clears the granule tags of the self-scheduling kernels with a recorded memset instead
-    of telling solves apart by their number (csrc/sptrsv.hip: trsv_solve_typed).  Replays and ordinary solves alternate
-    here on purpose: tags left by the one must never satisfy the other."""
+    launch per level group, and (b) allocates nothing (csrc/sptrsv.hip: trsv_solve_typed).  Replays and ordinary solves
+    alternate here on purpose."""
     import scipy.sparse as sps
-    if mode == "selfsched_solve":
-        monkeypatch.setenv("SPBLAS_GFX950_TRSV_SELFSCHED", "1")
     rng = np.random.default_rng(21)
     n, k = 30000, 6
     rows = np.repeat(np.arange(n), k)
