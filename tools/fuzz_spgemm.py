@@ -34,7 +34,8 @@ def rcsr(rng, m, n, kind, dtype):
 for it in range(iters):
     rng = np.random.default_rng(seed0 + it)
     dtype = rng.choice([np.float32, np.float64])
-    m, k, n = (int(rng.choice([1, 30, 400, 3000])) for _ in range(3))
+    # FUZZ_BIG=1: sizes at which the binned kernels (direct sort, hash tables by row size, dense bitmap) all get rows
+    m, k, n = (int(rng.choice([3000, 40000, 200000] if os.environ.get("FUZZ_BIG") else [1, 30, 400, 3000])) for _ in range(3))
     kinds = [rng.choice(["uniform", "skew", "sparse"]) for _ in range(3)]
     desc = f"seed {seed0 + it}: {m}x{k}x{n} {kinds} {np.dtype(dtype).name}"
     try:
