@@ -133,7 +133,11 @@ for it in range(iters):
         else:
             algs = {"auto": _capi.SPMV_AUTO, "vector": _capi.SPMV_VECTOR, "rowblock": _capi.SPMV_ROWBLOCK, "sliced": _capi.SPMV_SLICED}
             try:
-                info = sp.multiply_inspect(a, xd, y, alg=algs[alg])
+                # (round 5: a caller that announces value changes gets the source positions at inspect)
+                vwc = bool(alg == "sliced" and rng.random() < 0.4)
+                info = sp.multiply_inspect(a, xd, y, alg=algs[alg], values_will_change=vwc)
+                if vwc:
+                    desc += " [values_will_change]"
             except Exception as e:  # noqa: BLE001 -- "not supported" for a forced algorithm is a legal answer
                 print("SKIP", desc, "->", type(e).__name__, str(e)[:80])
                 continue
@@ -147,6 +151,12 @@ for it in range(iters):
                 A = sp.scaled(alpha, a) if alpha != 1.0 else a
                 sp.multiply(info, A, xd, y)
                 desc += " +rebound"
+                if rng.random() < 0.5:  # ... and again: the second change of a snapshot plan is the gather through the sources
+                    values = (values * dtype(1.5) - dtype(0.0625)).astype(dtype)
+                    a.update(t(values), a.rowptr(), a.colind())
+                    A = sp.scaled(alpha, a) if alpha != 1.0 else a
+                    sp.multiply(info, A, xd, y)
+                    desc += " +rebound"
             if alg == "sliced" and info.state_.sliced_info().get("value_free"):
                 desc += " [value-free]"
                 if rng.random() < 0.5:  # written in place, behind the library's back: a value-free plan reads the array as it is
