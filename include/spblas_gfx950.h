@@ -408,7 +408,11 @@ int spblas_gfx950_csr_add_numeric(spblas_gfx950_handle_t handle, spblas_gfx950_s
  *   sptrsv_solve   = triangular_solve: one launch per wide level, one single-workgroup launch per
  *                    run of narrow levels.  alpha (HOST pointer) is the scaled_view factor of A
  *                    (x = inv(alpha*A) b); b and x are device vectors of m entries (b == x is fine).
- *   sptrsv_info    : info[0] levels, [1] widest level, [2] kernel launches per solve, [3] lanes/row. */
+ *   sptrsv_info    : info[0] levels, [1] widest level, [2] kernel launches per solve, [3] lanes/row.
+ *   sptrsv_status  : synchronises the handle's stream and reports how the LAST solve of the plan ended: 0 = complete,
+ *                    1 = a device-side wait of the cooperative kernel (its grid barrier: bounded polls,
+ *                    SPBLAS_GFX950_TRSV_SPIN_LIMIT) gave up -- x is not valid.  Nothing in a correct program makes
+ *                    that happen; a caller that wants certainty asks once after the solves it cares about. */
 enum spblas_gfx950_uplo {
   SPBLAS_GFX950_LOWER = 0, /* lower_triangle_t  (detail/triangular_types.hpp:10-13) */
   SPBLAS_GFX950_UPPER = 1  /* upper_triangle_t  (detail/triangular_types.hpp:5-8)   */
@@ -421,6 +425,7 @@ int spblas_gfx950_sptrsv_create(spblas_gfx950_handle_t handle, spblas_gfx950_trs
                                 const int32_t* rowptr, const int32_t* colind, int uplo, int diag);
 int spblas_gfx950_sptrsv_destroy(spblas_gfx950_handle_t handle, spblas_gfx950_trsv_t plan);
 int spblas_gfx950_sptrsv_info(spblas_gfx950_trsv_t plan, int64_t info[4]);
+int spblas_gfx950_sptrsv_status(spblas_gfx950_handle_t handle, spblas_gfx950_trsv_t plan, int* status);
 int spblas_gfx950_sptrsv_solve(spblas_gfx950_handle_t handle, spblas_gfx950_trsv_t plan, int64_t m, int64_t nnz,
                                const void* alpha, const int32_t* rowptr, const int32_t* colind, const void* values,
                                const void* b, void* x, int value_type);

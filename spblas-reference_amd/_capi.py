@@ -104,6 +104,7 @@ PROTOTYPES = [
      [c_void_p, ctypes.POINTER(c_void_p), c_i64, c_i64, c_void_p, c_void_p, c_int, c_int]),
     ("spblas_gfx950_sptrsv_destroy", c_int, [c_void_p, c_void_p]),
     ("spblas_gfx950_sptrsv_info", c_int, [c_void_p, ctypes.POINTER(c_i64)]),
+    ("spblas_gfx950_sptrsv_status", c_int, [c_void_p, c_void_p, ctypes.POINTER(c_int)]),
     ("spblas_gfx950_sptrsv_solve", c_int,
      [c_void_p, c_void_p, c_i64, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int]),
     ("spblas_gfx950_spgemm_set_addend", c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_void_p]),

@@ -1117,6 +1117,14 @@ class _TrsvPlan:
         check(_capi.lib().spblas_gfx950_sptrsv_info(self.plan, arr), "spblas_gfx950_sptrsv_info")
         return dict(zip(("levels", "max_level_width", "launches_per_solve", "lanes_per_row"), list(arr)))
 
+    def check_status(self):
+        """Synchronises the stream; raises if a device-side wait of the last solve gave up (spblas_gfx950_sptrsv_status)."""
+        st = ctypes.c_int(0)
+        hd = _Handle.current(torch.device("cuda", self.hd.device))
+        check(_capi.lib().spblas_gfx950_sptrsv_status(hd.h, self.plan, ctypes.byref(st)), "spblas_gfx950_sptrsv_status")
+        if st.value != 0:
+            raise RuntimeError("triangular_solve: a device-side wait ran into its bound; the result is not valid")
+
     def __del__(self):
         try:
             if self.plan:

@@ -937,6 +937,23 @@ int spblas_gfx950_sptrsv_info(spblas_gfx950_trsv_t plan, int64_t info[4]) {
   return SPBLAS_GFX950_STATUS_SUCCESS;
 }
 
+int spblas_gfx950_sptrsv_status(spblas_gfx950_handle_t handle, spblas_gfx950_trsv_t plan, int* status) {
+  if (!handle)
+    return SPBLAS_GFX950_STATUS_INVALID_HANDLE;
+  if (!plan || !status)
+    return SPBLAS_GFX950_STATUS_INVALID_POINTER;
+  if (stream_capturing(handle->stream))
+    return SPBLAS_GFX950_STATUS_NOT_SUPPORTED;
+  *status = 0;
+  if (!plan->tickets)  // no solve yet
+    return SPBLAS_GFX950_STATUS_SUCCESS;
+  int st = 0;
+  SPB_HIP(hipMemcpyAsync(&st, plan->tickets + plan->groups.size() + 1, sizeof(int), hipMemcpyDeviceToHost, handle->stream));
+  SPB_HIP(hipStreamSynchronize(handle->stream));
+  *status = st;
+  return SPBLAS_GFX950_STATUS_SUCCESS;
+}
+
 int spblas_gfx950_sptrsv_solve(spblas_gfx950_handle_t handle, spblas_gfx950_trsv_t plan, int64_t m, int64_t nnz,
                                const void* alpha, const int32_t* rowptr, const int32_t* colind, const void* values,
                                const void* b, void* x, int value_type) {

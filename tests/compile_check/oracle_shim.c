@@ -407,6 +407,13 @@ int spblas_gfx950_sptrsv_destroy(spblas_gfx950_handle_t handle, spblas_gfx950_tr
   free(plan);
   return 0;
 }
+int spblas_gfx950_sptrsv_status(spblas_gfx950_handle_t handle, spblas_gfx950_trsv_t plan, int* status) {
+  (void) handle; (void) plan;
+  if (!status)
+    return SPBLAS_GFX950_STATUS_INVALID_POINTER;
+  *status = 0;  /* the oracle solves on the host, in program order */
+  return SPBLAS_GFX950_STATUS_SUCCESS;
+}
 int spblas_gfx950_sptrsv_info(spblas_gfx950_trsv_t plan, int64_t info[4]) {
   (void) plan;
   memset(info, 0, 4 * sizeof(int64_t));

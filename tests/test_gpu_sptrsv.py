@@ -263,3 +263,34 @@ def test_alternative_inspect_and_solve_paths(gpu, monkeypatch, mode, upper):
             # (under an HSA tool such as rocprofv3 the default falls back to one launch per level, sptrsv.hip)
             if not (os.environ.get("ROCP_TOOL_LIBRARIES") or os.environ.get("HSA_TOOLS_LIB")):
                 assert info["launches_per_solve"] == 1
+
+
+def test_a_solve_that_gave_up_waiting_is_reported(gpu, monkeypatch):
+    """The grid barrier of the cooperative solve polls with a bound (SPBLAS_GFX950_TRSV_SPIN_LIMIT); a workgroup that runs
+    into it raises the plan's status word and every workgroup leaves -- x is then incomplete.  spblas_gfx950_sptrsv_status
+    (check_status) makes that visible.  A bound of zero polls forces it; the next solve with the default bound is whole again
+    and reports success."""
+    rng = np.random.default_rng(91)
+    n, k = 200000, 6
+    rows = np.repeat(np.arange(n), k)
+    cols = (rng.random(n * k) * rows).astype(np.int64)
+    keep = cols < rows
+    S = sps.csr_matrix(((rng.random(keep.sum()) - 0.5) * (0.5 / k), (rows[keep], cols[keep])), shape=(n, n))
+    M = (S + sps.diags(1.0 + rng.random(n))).tocsr()
+    vals = M.data.astype(np.float32)
+    d_a = G.csr_on_device(vals, M.indptr.astype(np.int32), M.indices.astype(np.int32), M.shape, M.nnz)
+    b = (rng.random(n) + 0.5).astype(np.float32)
+    d_b, d_x = G.dev(b), torch.zeros(n, dtype=torch.float32, device="cuda")
+    info = sp.triangular_solve_inspect(d_a, sp.lower_triangle, sp.explicit_diagonal, d_b, d_x)
+    if info.state_.info()["launches_per_solve"] != 1:
+        pytest.skip("the cooperative solve is not in use here (an HSA tool is loaded)")
+    info.state_.check_status()  # nothing solved yet: fine
+    monkeypatch.setenv("SPBLAS_GFX950_TRSV_SPIN_LIMIT", "0")
+    sp.triangular_solve(info, d_a, sp.lower_triangle, sp.explicit_diagonal, d_b, d_x)
+    with pytest.raises(RuntimeError, match="ran into its bound"):
+        info.state_.check_status()
+    monkeypatch.delenv("SPBLAS_GFX950_TRSV_SPIN_LIMIT")
+    sp.triangular_solve(info, d_a, sp.lower_triangle, sp.explicit_diagonal, d_b, d_x)
+    info.state_.check_status()
+    ref = oracle.triangular_solve(M.shape, M.indptr, M.indices, vals, b, upper=False, unit=False)
+    assert np.allclose(G.host(d_x), ref, rtol=1e-4, atol=1e-6)
