@@ -59,6 +59,8 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-secondary", action="store_true",
                    help="default N=1 cfg2 run only: skip the cfg4 / cfg3 / cfg5 / 8(f) records of the `secondary` object")
+    p.add_argument("--full-line", action="store_true",
+                   help="print the complete result object instead of the compact headline (tools/*.sh that read the plan)")
     p.add_argument("--no-8f", dest="no_8f", action="store_true",
                    help="`secondary` without the SURVEY 8(f) records (add, transpose, triangular solve)")
     return p.parse_args()
@@ -713,6 +715,11 @@ def main():
                        # tiles WITHOUT a copy of the values (round 5: the reduce reads the caller's array through LDS): 0.37 ms
                        # at cfg2 (secondary.cfg2_plain_csr_view; the row-block kernel on the caller's arrays: 1.71 ms)
                        "operand": "matrix_opt(csr_view) + multiply_inspect" if args.alg != "noplan" else "csr_view, no inspect",
+                       # whose values a multiply reads: the reference's CPU path reads the caller's array of that call
+                       # (multiply_impl.hpp:48-52); a snapshot plan reads the copy taken at inspect
+                       "value_contract": ("snapshot" if (plan_info.get("alg") == 3 and not plan_info.get("sliced", {}).get("value_free")
+                                                         and not plan_info.get("sliced", {}).get("refresh_each_call"))
+                                          else "reads caller's values per call"),
                        "alg": args.alg, "plan": plan_info,
                        # what the plan holds on the device next to the caller's CSR arrays (which it does not copy or free)
                        "plan_bytes": plan_info.get("device_bytes"),
@@ -754,8 +761,24 @@ def main():
             if any(v.get("parity_check") == "fail" for v in out["secondary"].values()):
                 sys.stderr.write("[bench] SECONDARY PARITY CHECK FAILED\n")
                 exit_code = 3
+        # stdout carries the HEADLINE object alone (< 4 KB: bench_line.compact, tests/test_bench_line.py); the complete
+        # result -- every secondary record with its plan, roofline, cpu_baseline and parity report -- goes to
+        # bench_secondary.json (next to this file, and under gpurun_out/ where that exists) and, one short line per
+        # record, to stderr
+        from bench_line import compact, secondary_stderr_line
+        detail = "bench_secondary.json" if world == 1 else f"bench_secondary_n{world}.json"
+        for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+            if os.path.isdir(d):
+                try:
+                    with open(os.path.join(d, detail), "w") as f:
+                        json.dump(out, f, indent=1)
+                except OSError as e:
+                    print(f"[bench] {detail} not written in {d}: {e}", file=sys.stderr)
+        for name, rec in (out.get("secondary") or {}).items():
+            print("[bench] " + secondary_stderr_line(name, rec), file=sys.stderr)
+        sys.stderr.flush()
         sys.stdout.flush()
-        os.write(json_fd, (json.dumps(out) + "\n").encode())
+        os.write(json_fd, (json.dumps(out if args.full_line else compact(out, detail_file=detail)) + "\n").encode())
         if parity and parity["status"] == "fail":
             sys.stderr.write("[bench] PARITY CHECK FAILED: the timed operator's y is outside the parity bound\n")
             exit_code = 3

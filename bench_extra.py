@@ -116,7 +116,17 @@ def _emit(args, metric, flops, alg_bytes, elapsed, ms, workload, extra, cpu, par
 def run_extra(args, device):
     """One secondary workload as its own bench line (python bench.py --workload spmm|spgemm|...)."""
     out = _run(args, device)
-    print(json.dumps(out))
+    # like the headline: the compact object on stdout, the complete record next to bench.py (and under gpurun_out/)
+    from bench_line import compact
+    detail = f"bench_secondary_{args.workload}.json"
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        if os.path.isdir(d):
+            try:
+                with open(os.path.join(d, detail), "w") as f:
+                    json.dump(out, f, indent=1)
+            except OSError:
+                pass
+    print(json.dumps(out if getattr(args, "full_line", False) else compact(out, detail_file=detail)))
     return 3 if out.get("parity_check") == "fail" else 0
 
 

@@ -11,6 +11,20 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _bench_full(line):
+    """bench.py prints a compact headline (< 4 KB, bench_line.compact); the complete record -- plan, parity report, every
+    multi_gpu figure -- is in the `detail_file` it names, written next to bench.py.  Returns that record after checking
+    that the line is the small one and agrees with it."""
+    import json
+    head = json.loads(line)
+    assert len(line) + 1 < 4096, len(line)
+    with open(os.path.join(ROOT, head["detail_file"])) as f:
+        full = json.load(f)
+    assert abs(full["ms_per_step"] - head["ms_per_step"]) <= 1e-5 * full["ms_per_step"]
+    assert full.get("parity_check") == head.get("parity_check")
+    return full
+
+
 @pytest.mark.parametrize("world,dt,stripes", [(2, "f32", 1), (4, "f32", 3), (2, "f64", 4)])
 def test_fused_sharded_spmv_multiprocess(gpu, world, dt, stripes):
     """stripes > 1: the reduces of contiguous bin groups alternate between two streams (the groups need not
@@ -66,7 +80,7 @@ def test_bench_multi_gpu_code_path_with_one_rank(gpu, fused):
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert r.returncode == 0 and len(lines) == 1, (r.stdout[-2000:], r.stderr[-2000:])
-    out = json.loads(lines[0])
+    out = _bench_full(lines[0])
     assert out["value"] > 0 and out["steps"] == 5
     mg = out["multi_gpu"]  # where the step time goes: one SCALE run must be diagnostic
     # (round 5: the RCCL path is always timed; the fused path is the timed one when it is valid AND faster)
@@ -92,7 +106,7 @@ def test_bench_cfg4_rmat_multi_gpu_code_path_with_one_rank(gpu):
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert r.returncode == 0 and len(lines) == 1, (r.stdout[-2000:], r.stderr[-2000:])
-    out = json.loads(lines[0])
+    out = _bench_full(lines[0])
     assert out["value"] > 0 and out["dtype"] == "f64" and out["config"]["nnz"] == 16 << 18
     assert "R-MAT scale 18" in out["config"]["workload"] and out["multi_gpu"]["rccl_step_ms"] > 0
 
@@ -109,7 +123,7 @@ def test_bench_launches_its_own_ranks_and_checks_what_it_timed(gpu, workload):
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert r.returncode == 0 and len(lines) == 1, (r.stdout[-2000:], r.stderr[-2000:])
-    out = json.loads(lines[0])
+    out = _bench_full(lines[0])
     assert out["multi_gpu"]["rccl_step_ms"] > 0
     assert out["parity_check"] == "pass" and out["parity"]["rows_out_of_bound"] == 0, out["parity"]
     assert out["parity"]["rows"] == out["config"]["rows"]
@@ -123,7 +137,7 @@ def test_bench_single_gpu_line_is_self_checking(gpu):
                        capture_output=True, text=True, timeout=900, cwd=ROOT)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert r.returncode == 0 and len(lines) == 1, (r.stdout[-2000:], r.stderr[-2000:])
-    out = json.loads(lines[0])
+    out = _bench_full(lines[0])
     assert out["parity_check"] == "pass" and out["parity"]["rows"] == 1000000
     assert out["cpu_baseline"]["cores"] == 1 and out["cpu_baseline"]["cpu_model"]
     assert out["multi_gpu"] is None
@@ -144,7 +158,7 @@ def test_bench_with_several_ranks_on_one_gpu(gpu, world, workload, fused):
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert r.returncode == 0 and len(lines) == 1 and r.stdout.strip() == lines[0], (r.stdout[-2000:], r.stderr[-3000:])
-    out = json.loads(lines[0])
+    out = _bench_full(lines[0])
     assert out["n_gpus"] == world and out["parity_check"] == "pass", out["parity"]
     mg = out["multi_gpu"]
     assert len(mg["rows_per_rank"]) == world and sum(mg["rows_per_rank"]) == out["config"]["rows"]
@@ -169,7 +183,7 @@ def test_bench_secondary_workloads_check_themselves(gpu, workload, rows):
                         "--steps", "3", "--warmup", "1"], capture_output=True, text=True, timeout=900, cwd=ROOT)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert r.returncode == 0 and len(lines) == 1, (r.stdout[-2000:], r.stderr[-2000:])
-    out = json.loads(lines[0])
+    out = _bench_full(lines[0])
     assert out["parity_check"] == "pass", out["parity"]
     assert out["roofline"]["kernel"] and out["value"] > 0
 
@@ -188,7 +202,7 @@ def test_bench_falls_back_to_rccl_when_a_rank_stops_publishing_its_flags(gpu, mu
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert r.returncode == 0 and len(lines) == 1, (r.stdout[-2000:], r.stderr[-3000:])
-    out = json.loads(lines[0])
+    out = _bench_full(lines[0])
     mg = out["multi_gpu"]
     assert out["parity_check"] == "pass" and mg["path_used"] == "rccl" and mg["mode_timed"] == "plain"
     assert mg["fused_check"] is False and mg["fused_step_ms"] is None

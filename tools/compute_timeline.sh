@@ -5,7 +5,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/ctl
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT -o ctl -- python3 $ROOT/bench.py --workload spgemm --steps 5 --warmup 2 --no-cpu-baseline > $OUT/run.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT -o ctl -- python3 $ROOT/bench.py --full-line --workload spgemm --steps 5 --warmup 2 --no-cpu-baseline > $OUT/run.log 2>&1
 cd $ROOT
 python3 - <<PY
 import csv,glob

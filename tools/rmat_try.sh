@@ -1,7 +1,7 @@
 #!/bin/bash
 # tools/rmat_try.sh "ENV=VAL ..." ...: cfg4 forced SLICED under each environment; ms per step + padding
 for e in "$@"; do
-  env $e timeout 600 python bench.py --workload spmv_rmat --alg ${RMAT_ALG:-sliced} --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 > /tmp/rmat_try.json
+  env $e timeout 600 python bench.py --full-line --workload spmv_rmat --alg ${RMAT_ALG:-sliced} --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 > /tmp/rmat_try.json
   python3 - "$e" <<'PY'
 import json,sys
 try:

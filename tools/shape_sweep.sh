@@ -7,7 +7,7 @@ mkdir -p $OUT
 cd $ROOT
 run() {  # label, env...
   local label=$1; shift
-  local line=$(env "$@" timeout 300 python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1)
+  local line=$(env "$@" timeout 300 python3 bench.py --full-line --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1)
   python3 - "$label" <<PY "$line"
 import json,sys
 try:
