@@ -139,7 +139,8 @@ def secondary(args, device, log=None):
     todo = [("cfg2_plain_csr_view", "spmv_plain"), ("cfg2_poisson", "spmv_poisson1"), ("cfg4", "spmv_rmat1"), ("cfg3", "spmm"), ("spmm_banded", "spmm_banded"),
             ("cfg5", "spgemm")]
     if not getattr(args, "no_8f", False):  # add, transpose, triangular solve at their bench sizes
-        todo += [("f_add", "add"), ("f_transpose", "transpose"), ("f_sptrsv", "sptrsv")]
+        todo += [("f_csc_spmv", "csc_spmv"), ("f_add", "add"), ("f_spgemm4", "spgemm4"), ("f_transpose", "transpose"),
+                 ("f_sptrsv", "sptrsv")]
     for name, workload in todo:
         a2 = copy.copy(args)
         a2.workload, a2.rows, a2.cols = workload, None, None
@@ -354,6 +355,163 @@ def _run_spmv_poisson(args, device, sp, oracle, generate):
                  pmc_key="spmv_poisson_cfg2" if args.rows is None else None)
 
 
+def _run_csc_spmv(args, device, sp, oracle, generate):
+    """y = A^T x on cfg2's matrix handed over as a csc_view (= transposed(csr_view): the stored arrays are
+    the CSR of the transpose; backend/algorithms.hpp:21-29, vendor/rocsparse/detail/get_transpose.hpp:19-29).  Two call
+    shapes: un-inspected multiply(a_csc, x, y) -- the op = T scatter kernel on the caller's arrays -- and the inspected one
+    (multiply_inspect materialises the operand row-major and plans it); the record's value is the inspected multiply, the
+    un-inspected time, the inspect time and the bytes the plan holds are in `config`.  Parity: EVERY element of both y
+    against oracle_spmv_csc on the host."""
+    k = args.rows or 10_000_000                     # stored CSR: k x k with 10 entries per row; the operand is its transpose
+    values, rowptr, colind, shape, nnz = generate.uniform_csr_device(k, k, 10, seed=0, device=device)
+    a_csc = sp.csc_view(values, rowptr, colind, (k, k), nnz)
+    g = torch.Generator(device=device).manual_seed(13)
+    x = torch.rand(k, device=device, generator=g)
+    y = torch.empty(k, device=device)
+    # un-inspected
+    el_t, ms_t = _time_steps(lambda: sp.multiply(a_csc, x, y), args.warmup, max(3, args.steps // 2))
+    y.fill_(float("nan"))
+    sp.multiply(a_csc, x, y)
+    torch.cuda.synchronize()
+    y_scatter = y.clone()
+    # inspected
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    info = sp.multiply_inspect(a_csc, x, y)
+    torch.cuda.synchronize()
+    inspect_ms = (time.perf_counter() - t0) * 1e3
+    elapsed, ms = _time_steps(lambda: sp.multiply(info, a_csc, x, y), args.warmup, args.steps)
+    y.fill_(float("nan"))
+    sp.multiply(info, a_csc, x, y)
+    torch.cuda.synchronize()
+    plan = info.state_.info()
+    held = int(plan.get("device_bytes") or 0) + int(getattr(info.state_, "held_bytes", lambda: 0)())
+    alg_bytes = nnz * 8 + (k + 1) * 4 + 2 * k * 4
+    cpu, parity = None, None
+    if not args.no_cpu_baseline:
+        v, cp, ri, xh = values.cpu().numpy(), rowptr.cpu().numpy(), colind.cpu().numpy(), x.cpu().numpy()
+        t0 = time.perf_counter()
+        y_ref = oracle.spmv_csc((k, k), cp, ri, v, xh)
+        dt = time.perf_counter() - t0
+        cpu = {"value": 2.0 * nnz / dt / 1e9, "unit": "GFLOP/s", "cores": 1, "kind": "port", "seconds": dt,
+               "sample": f"full workload ({nnz} nnz), 1 run of oracle_spmv_csc (column traversal, scatter into y)"}
+        # sum_p |a_p x_p| per output element and the entries per element (for the k/2 * eps floor), on the device in fp64
+        src_row = torch.repeat_interleave(torch.arange(k, device=device), (rowptr[1:] - rowptr[:-1]).long())
+        absy = torch.zeros(k, dtype=torch.float64, device=device).index_add_(
+            0, colind.long(), values.double().abs() * x.double()[src_row].abs())
+        del src_row
+        cnt = torch.bincount(colind.long(), minlength=k).cpu().numpy()
+        absy = absy.cpu().numpy()
+        eps = float(np.finfo(np.float32).eps)
+        nb1, w1 = parity_rows(y.cpu().numpy(), y_ref, absy, 1e-6, eps, cnt)
+        nb2, w2 = parity_rows(y_scatter.cpu().numpy(), y_ref, absy, 1e-6, eps, cnt)
+        parity = {"status": "pass" if nb1 == 0 and nb2 == 0 else "fail", "rows": int(k), "rows_out_of_bound": nb1 + nb2,
+                  "tol": 1e-6, "worst_err_over_rownorm": max(w1, w2),
+                  "against": "oracle_spmv_csc (CPU restatement of backend/algorithms.hpp:21-29 + multiply_impl.hpp:33-53), every "
+                             "element, both the inspected and the un-inspected multiply"}
+    return _emit(args, "csc_spmv_gflops", 2.0 * nnz, alg_bytes, elapsed, ms,
+                 f"8f: fp32 SpMV y = A^T x, csc_view of cfg2's matrix ({k}x{k}, 10 entries per stored row, nnz={nnz}); "
+                 "timed step = multiply(info, csc_view, x, y) after multiply_inspect",
+                 {"dtype": "f32", "rows": k, "nnz": nnz, "operand": "csc_view + multiply_inspect", "plan": plan,
+                  "uninspected_ms_per_step": el_t / max(3, args.steps // 2) * 1e3,
+                  "uninspected_roofline_frac": alg_bytes / (ms_t[0] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                  "uninspected_kernel": "scale_vector_kernel + spmv_transpose_kernel<float,int> (float atomics into y)",
+                  "inspect_ms_untimed": inspect_ms, "plan_bytes": held,
+                  "plan_bytes_over_matrix": held / float(nnz * 8 + (k + 1) * 4),
+                  "kernel": "device transpose at inspect (spt_* kernels), then the CSR plan's kernels on the materialised copy"},
+                 cpu, parity=parity, pmc_key=None if args.rows else "csc_spmv_8f")
+
+
+def _run_spgemm4(args, device, sp, oracle, generate):
+    """C = alpha * A B + beta * D (vendor/rocsparse/multiply_spgemm.hpp:237-250) at cfg5's size with an
+    addend of 16 entries per row; timed step = one multiply_fill with the addend, multiply_compute reported beside it."""
+    m = args.rows or 1_000_000
+    av, ar, ac, ash, annz = generate.uniform_csr_device(m, m, 16, seed=0, device=device)
+    bv, br, bc, bsh, bnnz = generate.uniform_csr_device(m, m, 16, seed=1, device=device)
+    dv, dr, dc, dsh, dnnz = generate.uniform_csr_device(m, m, 16, seed=2, device=device)
+    # the addend's rows with ascending columns (the reference's operands come from sorted generators, test/gtest/util.hpp)
+    key = torch.repeat_interleave(torch.arange(m, device=device), 16) * m + dc.long()
+    order = torch.argsort(key)
+    dc, dv = dc[order].contiguous(), dv[order].contiguous()
+    del key, order
+    a, b, d = sp.csr_view(av, ar, ac, ash, annz), sp.csr_view(bv, br, bc, bsh, bnnz), sp.csr_view(dv, dr, dc, dsh, dnnz)
+    alpha, beta = 1.5, -0.5
+    a_s, d_s = sp.scaled(alpha, a), sp.scaled(beta, d)
+    c_rp = torch.zeros(m + 1, dtype=torch.int32, device=device)
+    c = sp.csr_view(None, c_rp, None, (m, m), 0)
+    state = sp.spgemm_state_t()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    sp.multiply_compute(state, a_s, b, c, d_s)
+    torch.cuda.synchronize()
+    compute_first_ms = (time.perf_counter() - t0) * 1e3
+    cn = state.result_nnz()
+    c.update(torch.empty(cn, device=device), c_rp, torch.empty(cn, dtype=torch.int32, device=device), (m, m), cn)
+    products = int((br.long()[ac.long() + 1] - br.long()[ac.long()]).sum().item())
+    os.environ["SPBLAS_GFX950_SPGEMM_REUSE"] = "0"
+    try:
+        elapsed, ms = _time_steps(lambda: sp.multiply_fill(state, a_s, b, c, d_s), args.warmup, args.steps)
+    finally:
+        del os.environ["SPBLAS_GFX950_SPGEMM_REUSE"]
+    torch.cuda.synchronize()
+    got_ci, got_v = c.colind().clone(), c.values().clone()
+    compute_ms = float("inf")
+    for _ in range(3):
+        c2_rp = torch.zeros(m + 1, dtype=torch.int32, device=device)
+        c2 = sp.csr_view(None, c2_rp, None, (m, m), 0)
+        st2 = sp.spgemm_state_t()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        sp.multiply_compute(st2, a_s, b, c2, d_s)
+        torch.cuda.synchronize()
+        compute_ms = min(compute_ms, (time.perf_counter() - t0) * 1e3)
+        assert st2.result_nnz() == cn and torch.equal(c2_rp, c_rp)
+        del st2
+    alg_bytes = 3 * (annz * 8 + (m + 1) * 4) + cn * 8 + (m + 1) * 4
+    cpu, parity = None, None
+    if not args.no_cpu_baseline:
+        a_h, b_h, d_h = (ar.cpu().numpy(), ac.cpu().numpy()), (br.cpu().numpy(), bc.cpu().numpy()), (dr.cpu().numpy(), dc.cpu().numpy())
+        n_ref, row_nnz = oracle.spgemm_symbolic_d((m, m), a_h[0], a_h[1], (m, m), b_h[0], b_h[1], (m, m), d_h[0], d_h[1])
+        rowptr_ok = bool(cn == n_ref and np.array_equal(c_rp.cpu().numpy().astype(np.int64),
+                                                        np.concatenate([[0], np.cumsum(row_nnz)])))
+        rows = np.unique(np.concatenate([np.arange(0, m, 1009), [m - 1]]))
+        sa_rp, sa_c, sa_v = rows_subproblem(rows, ar, ac, av)
+        sd_rp, sd_c, sd_v = rows_subproblem(rows, dr, dc, dv)
+        bv_h = bv.cpu().numpy()
+        sub = (len(rows), m)
+        n_sub, _ = oracle.spgemm_symbolic_d(sub, sa_rp, sa_c, (m, m), b_h[0], b_h[1], sub, sd_rp, sd_c)
+        t0 = time.perf_counter()
+        cr, cc, cv = oracle.spgemm_numeric_d(sub, sa_rp, sa_c, sa_v, (m, m), b_h[0], b_h[1], bv_h, sub, sd_rp, sd_c, sd_v, n_sub,
+                                             alpha, beta)
+        dt = time.perf_counter() - t0
+        _, _, cabs = oracle.spgemm_numeric_d(sub, sa_rp, sa_c, np.abs(sa_v), (m, m), b_h[0], b_h[1], np.abs(bv_h), sub, sd_rp, sd_c,
+                                             np.abs(sd_v), n_sub, abs(alpha), abs(beta))
+        sub_products = int((br.long()[torch.from_numpy(sa_c).to(device).long() + 1]
+                            - br.long()[torch.from_numpy(sa_c).to(device).long()]).sum().item())
+        cpu = {"value": 2.0 * sub_products / dt / 1e9, "unit": "GFLOP/s", "cores": 1, "kind": "port",
+               "sample": f"every 1 009th row of A and D ({len(rows)} rows) x full B, oracle_spgemm_numeric_d (numeric timed)"}
+        g_rp, g_c, g_v = rows_subproblem(rows, c_rp, got_ci, got_v)
+        cols_ok = bool(np.array_equal(g_rp, cr) and np.array_equal(g_c, cc))
+        nbad, worst = (1, float("inf"))
+        if cols_ok:
+            nbad, worst = parity_rows(g_v, cv, cabs.astype(np.float64), 1e-6, float(np.finfo(np.float32).eps), np.zeros(len(cv)))
+        ok = rowptr_ok and cols_ok and nbad == 0 and bool(torch.isfinite(got_v).all())
+        parity = {"status": "pass" if ok else "fail", "nnz_c": int(cn), "nnz_c_oracle": int(n_ref), "rows": int(m),
+                  "rowptr_exact_all_rows": rowptr_ok, "sampled_rows": int(len(rows)), "sampled_colind_exact": cols_ok,
+                  "values_out_of_bound": nbad, "tol": 1e-6, "worst_err_over_norm": worst,
+                  "against": "oracle_spgemm_symbolic_d over all rows; oracle_spgemm_numeric_d (alpha*A*B + beta*D, "
+                             "multiply_spgemm.hpp:118-214) on every 1 009th row: sorted columns exact, values norm-wise"}
+    return _emit(args, "csr_spgemm4_fill_gflops", 2.0 * products, alg_bytes, elapsed, ms,
+                 f"8f: fp32 C = alpha*A*B + beta*D, {m}x{m}, 16 nnz/row each, uniform random; timed step = one multiply_fill "
+                 "with the addend, after multiply_compute",
+                 {"dtype": "f32", "rows": m, "products": products, "nnz_c": cn, "alpha": alpha, "beta": beta,
+                  "state": state.info(), "multiply_compute_ms_untimed": compute_ms,
+                  "multiply_compute_first_call_ms": compute_first_ms,
+                  "compute_plus_one_shot_fill_ms": compute_ms + elapsed / args.steps * 1e3,
+                  "kernel": "spg_pack_b_kernel + spg_direct_kernel<float,...> with the addend merged (one fill = this launch group)"},
+                 cpu, parity=parity, pmc_key=None if args.rows else "spgemm4_8f")
+
+
 def _run(args, device):
     import spblas_reference_amd as sp
     from oracle import oracle
@@ -365,6 +523,10 @@ def _run(args, device):
         return _run_spmv_poisson(args, device, sp, oracle, generate)
     if args.workload == "spmv_rmat1":
         return _run_spmv_rmat1(args, device, sp, oracle, generate)
+    if args.workload == "csc_spmv":
+        return _run_csc_spmv(args, device, sp, oracle, generate)
+    if args.workload == "spgemm4":
+        return _run_spgemm4(args, device, sp, oracle, generate)
 
     if args.workload in ("spmm", "spmm_banded", "spmm_rmat"):
         m = args.rows or 2_000_000

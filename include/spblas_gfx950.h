@@ -163,7 +163,10 @@ int spblas_gfx950_set_option(spblas_gfx950_handle_t handle, int option, int64_t 
  * spblas_gfx950_spmv_plan_update_values; a multiply that passes a DIFFERENT values pointer than the one
  * the copy was taken from refreshes the copy by itself first (one extra pass over A).  A snapshot plan keeps no source
  * positions until then: the FIRST refresh builds the plan again from the caller's arrays (inspect-class work: not inside a
- * stream capture) and keeps them, every later refresh is a gather (option value 2 above: kept from the start).  AUTO WITHOUT the option may choose the SLICED plan
+ * stream capture: STATUS_NOT_SUPPORTED there, also from a spblas_gfx950_spmv that meets a new values pointer) and keeps
+ * them, every later refresh is a gather (option value 2 above: kept from the start).  If that second build runs out of memory
+ * or declines, the plan falls back to its structure-only form (row-block windows on the caller's arrays, plan_info[0]
+ * changes) and the call succeeds: a plan is never left half built.  AUTO WITHOUT the option may choose the SLICED plan
  * too (>= 16 M entries, not skewed): such a plan reads the caller's values on EVERY multiply (plan_info_sliced[9] bit 6),
  * so the caller sees the same semantics as with a structure-only plan.  Its default form is VALUE-FREE (bit 7, round 5):
  * the plan holds no values at all -- the first kernel gathers x, the second multiplies by the caller's array, staged bin by
@@ -412,7 +415,11 @@ int spblas_gfx950_csr_add_numeric(spblas_gfx950_handle_t handle, spblas_gfx950_s
  *   sptrsv_status  : synchronises the handle's stream and reports how the LAST solve of the plan ended: 0 = complete,
  *                    1 = a device-side wait of the cooperative kernel (its grid barrier: bounded polls,
  *                    SPBLAS_GFX950_TRSV_SPIN_LIMIT) gave up -- x is not valid.  Nothing in a correct program makes
- *                    that happen; a caller that wants certainty asks once after the solves it cares about. */
+ *                    that happen; a caller that wants certainty asks once after the solves it cares about.  A caller that
+ *                    never asks still hears of it: the kernel raises a pinned host word on that path and the NEXT
+ *                    sptrsv_solve on the plan returns STATUS_HIP_ERROR (last_hip_error = hipErrorLaunchTimeOut) once,
+ *                    before it launches anything, without synchronising the stream.  The x of a solve that no later
+ *                    call follows is unverified unless sptrsv_status is asked. */
 enum spblas_gfx950_uplo {
   SPBLAS_GFX950_LOWER = 0, /* lower_triangle_t  (detail/triangular_types.hpp:10-13) */
   SPBLAS_GFX950_UPPER = 1  /* upper_triangle_t  (detail/triangular_types.hpp:5-8)   */

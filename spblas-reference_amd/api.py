@@ -555,6 +555,11 @@ class _CscPlan:
     def info(self):
         return self.plan.info()
 
+    def held_bytes(self):
+        """device bytes of the materialised row-major copy this plan holds next to the CSR plan's own (info()['device_bytes'])"""
+        t = [self.rowptr, self.colind, self.values]
+        return sum(x.numel() * x.element_size() for x in t)
+
 
 def _csc_key(a_csc):
     return (a_csc.colptr().data_ptr(), a_csc.rowind().data_ptr(), tuple(a_csc.shape()), a_csc.size(),

@@ -5,6 +5,7 @@
 #include "common.hpp"
 
 #include <cstdlib>
+#include <mutex>
 
 #include <new>
 
@@ -64,23 +65,25 @@ int spblas_gfx950_create(spblas_gfx950_handle_t* handle, void* stream) {
   h->device = dev;
   h->num_cus = cus;
   *handle = h;
-  // The first handle of a process loads the library's code objects (SPBLAS_GFX950_PRELOAD=0: left to the first use, as the
-  // runtime does by itself).  Measured on MI355X: see DESIGN.md section 2, "first call".
-  static const bool preloaded = [] {
+  // The first handle on each DEVICE loads the library's code objects there (SPBLAS_GFX950_PRELOAD=0: left to the first use,
+  // as the runtime does by itself; code objects are loaded per device, so a process that drives several GPUs pays once per
+  // GPU at its first handle there, not at its first inspect).  Measured on MI355X: see DESIGN.md section 2, "first call".
+  static std::once_flag preload_once[64];
+  static const bool preload_on = [] {
     const char* e = std::getenv("SPBLAS_GFX950_PRELOAD");
-    if (e && std::atoi(e) == 0)
-      return false;
-    spb::preload_spmv();
-    spb::preload_sliced();
-    spb::preload_hot();
-    spb::preload_spmm();
-    spb::preload_spgemm();
-    spb::preload_transpose();
-    spb::preload_sptrsv();
-    spb::preload_multigpu();
-    return true;
+    return !(e && std::atoi(e) == 0);
   }();
-  (void) preloaded;
+  if (preload_on && dev >= 0 && dev < 64)
+    std::call_once(preload_once[dev], [] {
+      spb::preload_spmv();
+      spb::preload_sliced();
+      spb::preload_hot();
+      spb::preload_spmm();
+      spb::preload_spgemm();
+      spb::preload_transpose();
+      spb::preload_sptrsv();
+      spb::preload_multigpu();
+    });
   return SPBLAS_GFX950_STATUS_SUCCESS;
 }
 

@@ -1827,7 +1827,7 @@ __global__ __launch_bounds__(RW * 64) void pb_reduce_kernel(int64_t m, int Hw, i
 // LDS read-add-write stays race free: nobody else touches them; duplicates inside a group are flagged as before), and the
 // NW partial rows are added in wave order at the end -- the order of additions is fixed by the plan.
 //   rowptr: the caller's row offsets (o64: 64-bit); values: the caller's array of THIS call; win_cap: entries the window area
-//   holds (the build checked every bin's span + the alignment shift against it)
+//   holds = the widest span the build accepted + 16 for the alignment shift of the staged copy
 #ifndef PB_VF_GLDS_AUX
 #define PB_VF_GLDS_AUX 2  // non-temporal: every window is read by one CU, once per multiply
 #endif
@@ -2525,7 +2525,11 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
         return hip_fail(e);
       if ((int64_t) h_span <= cap && h_span < 65536ull) {
         vf_rows = (int) hh;
-        vf_cap = (int) cap;
+        // the window AREA is the accepted span plus the 16 elements set aside above: stage_window aligns the window's start
+        // down to 16 bytes and writes span + shift elements (shift <= 16 / sizeof(T) - 1), and the accumulators begin right
+        // behind the area -- a bin whose span reaches `cap` with a misaligned rowptr[r0] used to put raw values of A into
+        // the first accumulators of wave 0 (round-5 advisor; tests: test_spmv_value_free_tiles_widest_window_misaligned)
+        vf_cap = (int) cap + 16;
         break;
       }
       // a denser stretch of rows than the average: shrink the bins in proportion (with a margin) and look again
@@ -3312,8 +3316,28 @@ int spmv_sliced_update(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const
     pl->device_bytes = pl->base_device_bytes;
     pl->keep_src = 1;
     pl->refresh_each_call = refresh;
-    const int rc = spmv_sliced_build(h, pl, values, false);
+    int rc = spmv_sliced_build(h, pl, values, false);
     pl->nt_products = nt;
+    if (rc == SPBLAS_GFX950_STATUS_SUCCESS && env_int("SPBLAS_GFX950_TEST_FAIL_REBUILD", 0))
+      rc = SPBLAS_GFX950_STATUS_ALLOC_FAILED;  // test hook: the failure path below with a fully built plan to tear down
+    if (rc != SPBLAS_GFX950_STATUS_SUCCESS) {
+      // The second build needs 4 B per entry more than the first and may not fit (or decline).  A half-built tiled plan
+      // must not stay behind: the plan goes back to the structures plan_build always makes (row-block windows / the
+      // plan-free kernel, both of which read the caller's arrays of each call -- the values just handed over included), as
+      // plan_create does when the tiles cannot be built at inspect.  Out-of-memory and "declined" are absorbed that way; any
+      // other error is reported, with the plan equally consistent.
+      spmv_sliced_free(h, pl);
+      pl->device_bytes = pl->base_device_bytes;
+      pl->values_ptr = nullptr;
+      pl->refresh_each_call = 0;
+      pl->vfree = 0;
+      pl->keep_src = 0;
+      pl->alg = pl->nnz >= pl->m / 2 ? SPBLAS_GFX950_SPMV_ROWBLOCK : SPBLAS_GFX950_SPMV_VECTOR;
+      if (rc == SPBLAS_GFX950_STATUS_ALLOC_FAILED || rc == SPBLAS_GFX950_STATUS_NOT_SUPPORTED) {
+        (void) hipGetLastError();
+        return SPBLAS_GFX950_STATUS_SUCCESS;
+      }
+    }
     return rc;
   }
   if (pl->rest_plan)

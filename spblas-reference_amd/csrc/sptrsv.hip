@@ -59,6 +59,9 @@ struct spblas_gfx950_trsv_s {
   int narrow = 128;      // levels with fewer rows are "narrow": walked by one workgroup
   bool coop_ok = false;  // the solve is ONE cooperative launch (trsv_coop_kernel)
   int32_t* tickets = nullptr;         // device: status word and the grid barrier's counters / release lines
+  // pinned, device-visible host word: a solve whose grid barrier ran into its poll bound sets it (system-scope store, only
+  // on that path), the NEXT solve on this plan -- and spblas_gfx950_sptrsv_status -- reads it without touching the stream
+  int* sticky = nullptr;
 };
 
 namespace spb {
@@ -417,7 +420,7 @@ __device__ __forceinline__ void trsv_barrier_arrive(unsigned* bar, unsigned n, i
 }
 // Second half: the last workgroup to arrive releases the others through one flag LINE per workgroup
 // (bar[32 * (9 + w)]): 256 workgroups polling one address saturate its memory channel (measured 45 us per barrier).
-__device__ __forceinline__ bool trsv_barrier_wait(unsigned* bar, unsigned n, int spin_limit, int* status, int* s_flags) {
+__device__ __forceinline__ bool trsv_barrier_wait(unsigned* bar, unsigned n, int spin_limit, int* status, int* sticky, int* s_flags) {
   __syncthreads();
   if (s_flags[1]) {
     for (unsigned w = threadIdx.x; w < gridDim.x; w += blockDim.x)
@@ -428,6 +431,8 @@ __device__ __forceinline__ bool trsv_barrier_wait(unsigned* bar, unsigned n, int
       __builtin_amdgcn_s_sleep(1);
       if (++spins > spin_limit) {
         status[0] = 1;
+        if (sticky)
+          __hip_atomic_store(sticky, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         s_flags[0] = 1;
         break;
       }
@@ -445,7 +450,7 @@ __global__ __launch_bounds__(TRSV_COOP_THREADS) void trsv_coop_kernel(int n_leve
                                                                       const int32_t* __restrict__ colind,
                                                                       const T* __restrict__ values, T alpha,
                                                                       const T* __restrict__ b, T* x, int upper,
-                                                                      int unit, int m, unsigned* bar, int* status,
+                                                                      int unit, int m, unsigned* bar, int* status, int* sticky,
                                                                       int spin_limit, int dbg) {
   constexpr int RPB = TRSV_COOP_THREADS / G;  // rows per workgroup and slot
   const int gl = threadIdx.x % G, grp = threadIdx.x / G;
@@ -591,7 +596,7 @@ __global__ __launch_bounds__(TRSV_COOP_THREADS) void trsv_coop_kernel(int n_leve
       ++n_bar;
       trsv_barrier_arrive(bar, n_bar, s_flags);
       advance(l + 3);
-      if (!trsv_barrier_wait(bar, n_bar, spin_limit, status, s_flags))
+      if (!trsv_barrier_wait(bar, n_bar, spin_limit, status, sticky, s_flags))
         return;
     }
   }
@@ -651,8 +656,24 @@ static int trsv_solve_typed(spblas_gfx950_handle_t h, spblas_gfx950_trsv_s* pl, 
     if (rc)
       return rc;
   }
+  // A solve of this plan whose grid barrier gave up (x incomplete) is reported by the NEXT call on the plan at the latest:
+  // the kernel set the pinned word, no stream work is needed to see it.  The word is cleared by the report.
+  if (pl->sticky && __atomic_load_n(pl->sticky, __ATOMIC_RELAXED) != 0) {
+    __atomic_store_n(pl->sticky, 0, __ATOMIC_RELAXED);
+    return hip_fail(hipErrorLaunchTimeOut);
+  }
+  if (!pl->sticky && !capturing) {
+    void* hp = nullptr;
+    if (hipHostMalloc(&hp, 64, hipHostMallocMapped) == hipSuccess) {
+      pl->sticky = static_cast<int*>(hp);
+      *pl->sticky = 0;
+    } else {
+      (void) hipGetLastError();  // no pinned word: spblas_gfx950_sptrsv_status (device word) remains
+    }
+  }
   SPB_HIP(hipMemsetAsync(pl->tickets, 0, ctl_ints * 4, s));
   int* status = pl->tickets + ng + 1;
+  int* sticky = pl->sticky;
   const int spin_limit = env_int("SPBLAS_GFX950_TRSV_SPIN_LIMIT", 1 << 22);  // ~ seconds of polling
   // the whole solve as one cooperative launch (default when the device offers it and no narrow run is so long
   // that the waiting workgroups could exhaust their bounded spin: 4096 levels ~ 10 ms)
@@ -673,7 +694,7 @@ static int trsv_solve_typed(spblas_gfx950_handle_t h, spblas_gfx950_trsv_s* pl, 
       const int32_t* ord = pl->order;
       int mm = m, up = upper, un = unit, sl = spin_limit, bm = env_int("SPBLAS_GFX950_TRSV_DBG", 0);
       void* args[] = {&n_levels, &narrow, (void*) &lp, (void*) &ord, (void*) &rowptr, (void*) &colind, (void*) &values,
-                      &alpha, (void*) &b, (void*) &x, &up, &un, &mm, &bar, &status, &sl, &bm};
+                      &alpha, (void*) &b, (void*) &x, &up, &un, &mm, &bar, &status, &sticky, &sl, &bm};
       int grid = env_int("SPBLAS_GFX950_TRSV_COOP_GRID", 0);
       if (grid < 1 || grid > cus * wgs)
         grid = cus * wgs;
@@ -923,6 +944,11 @@ int spblas_gfx950_sptrsv_destroy(spblas_gfx950_handle_t handle, spblas_gfx950_tr
   dev_free(plan->order, handle->stream);
   dev_free(plan->level_ptr, handle->stream);
   dev_free(plan->tickets, handle->stream);
+  if (plan->sticky) {
+    // (the kernel of the last solve may still be running: the word must outlive it)
+    (void) hipStreamSynchronize(handle->stream);
+    (void) hipHostFree(plan->sticky);
+  }
   delete plan;
   return SPBLAS_GFX950_STATUS_SUCCESS;
 }
@@ -951,6 +977,8 @@ int spblas_gfx950_sptrsv_status(spblas_gfx950_handle_t handle, spblas_gfx950_trs
   SPB_HIP(hipMemcpyAsync(&st, plan->tickets + plan->groups.size() + 1, sizeof(int), hipMemcpyDeviceToHost, handle->stream));
   SPB_HIP(hipStreamSynchronize(handle->stream));
   *status = st;
+  if (plan->sticky)  // reported here: the next solve need not report it again
+    __atomic_store_n(plan->sticky, 0, __ATOMIC_RELAXED);
   return SPBLAS_GFX950_STATUS_SUCCESS;
 }
 

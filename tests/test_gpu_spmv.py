@@ -1059,6 +1059,52 @@ def test_spmv_value_free_tiles(gpu, monkeypatch, dtype, offsets, waves, enc):
         assert rc == _capi.NOT_SUPPORTED
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("waves", [8, 4])
+@pytest.mark.parametrize("offset_mod", [1, 3])
+def test_spmv_value_free_tiles_widest_window_misaligned(gpu, monkeypatch, dtype, waves, offset_mod):
+    """Round-5 advisor (high): a bin whose span of the caller's array equals the accepted capacity EXACTLY, starting at an
+    offset that is not a multiple of 16 bytes.  stage_window copies from the aligned-down start, i.e. span + shift elements;
+    the window area therefore holds the capacity + 16 (the accumulators of wave 0 used to begin right at the capacity and
+    received raw values of A in rows 0 .. 2 of such a bin).  Bin height 500 through the test hook; the capacity follows
+    csrc/spmv_sliced.hip: (160 KiB - 64) / sizeof(T) - waves * (500 + 64) - 16."""
+    H = 500
+    monkeypatch.setenv("SPBLAS_GFX950_PB_VFREE", "2")
+    monkeypatch.setenv("SPBLAS_GFX950_SLICE_COLS", "128")
+    monkeypatch.setenv("SPBLAS_GFX950_PB_VF_ROWS", str(H))
+    monkeypatch.setenv("SPBLAS_GFX950_PB_VF_WAVES", str(waves))
+    size = np.dtype(dtype).itemsize
+    cap = (160 * 1024 - 64) // size - waves * (H + 64) - 16
+    assert cap < 65536
+    rng = np.random.default_rng(53)
+    m, n = 3 * H, 3000
+    lens = np.empty(m, dtype=np.int64)
+    lens[:H] = 10
+    lens[7] += offset_mod                               # bin 1 starts at 5000 + offset_mod: never 16-byte aligned for fp32,
+    lens[H:2 * H] = cap // H                            # odd for fp64
+    lens[H:H + cap % H] += 1                            # bin 1 spans exactly `cap` entries
+    lens[2 * H:] = rng.integers(0, 20, H)
+    assert lens[H:2 * H].sum() == cap and lens[:H].sum() % (16 // size) != 0
+    rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    nnz = int(rowptr[-1])
+    colind = rng.integers(0, n, nnz).astype(np.int32)
+    values = (1.0 + rng.random(nnz)).astype(dtype)      # all >= 1: a stray value in an accumulator cannot hide
+    x = (rng.random(n) - 0.5).astype(dtype)
+    a = G.csr_on_device(values, rowptr, colind, (m, n), nnz)
+    assert a.values().data_ptr() % 16 == 0
+    xd = G.dev(x)
+    tdt = torch.float32 if dtype == np.float32 else torch.float64
+    y = torch.full((m,), float("nan"), dtype=tdt, device="cuda")
+    info = sp.multiply_inspect(a, xd, y, alg=_capi.SPMV_SLICED)
+    si = info.state_.sliced_info()
+    assert si["value_free"] == 1 and info.state_.info()["rows_per_bin"] == H, (si, info.state_.info())
+    for _ in range(2):                                  # (persistent workgroups: the second pass reuses warm accumulators)
+        y.fill_(float("nan"))
+        sp.multiply(info, a, xd, y)
+        check(values, rowptr, colind, (m, n), x, G.host(y), what="value-free tiles, widest window at a misaligned offset",
+              ref_cmp=False)
+
+
 def test_spmv_value_free_tiles_fall_back_when_the_matrix_does_not_fit(gpu, monkeypatch):
     """A matrix the value-free form does not take (a row far longer than the rest is cut into pieces: a row map) still
     gets the copying plan on explicit request, and the answer."""
@@ -1124,6 +1170,61 @@ def test_spmv_snapshot_plan_keeps_no_source_positions_until_the_values_change(gp
     assert info.state_.info()["device_bytes"] == bytes1
     sp.multiply(info, a, xd, y)
     check(values * -2.0 + 0.125, rowptr, colind, (m, n), x, G.host(y), what=f"{shape}: second change", ref_cmp=False)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", ["uniform", "hot_split"])
+@pytest.mark.parametrize("via", ["update_values", "new_pointer"])
+def test_spmv_snapshot_plan_whose_second_build_fails_falls_back_to_the_structure_only_plan(gpu, monkeypatch, shape, via):
+    """Round-5 advisor (medium): the first value change of a snapshot plan builds the tiles again (with source positions).
+    When that build fails -- out of memory with the pool still warm, or declined -- the plan must not stay `SLICED` on freed
+    arrays: it goes back to the row-block plan on the caller's arrays (alg changes, device_bytes drops to the structure-only
+    figure), the call succeeds, and every later multiply, whichever values pointer it passes, is right.  The failure is
+    injected after a complete second build (SPBLAS_GFX950_TEST_FAIL_REBUILD), so the teardown frees a whole plan."""
+    monkeypatch.setenv("SPBLAS_GFX950_SLICE_COLS", "128")
+    rng = np.random.default_rng(59)
+    m, n = 6000, 4000
+    lens = rng.integers(1, 40, m)
+    nnz = int(lens.sum())
+    if shape == "hot_split":
+        monkeypatch.setenv("SPBLAS_GFX950_PB_HOT", "1")
+        colind = np.where(rng.random(nnz) < 0.4, rng.integers(0, 64, nnz), rng.integers(0, n, nnz)).astype(np.int32)
+    else:
+        colind = rng.integers(0, n, nnz).astype(np.int32)
+    rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    values = (rng.random(nnz) - 0.5).astype(np.float32)
+    x = (rng.random(n) - 0.5).astype(np.float32)
+    a = G.csr_on_device(values, rowptr, colind, (m, n), nnz)
+    xd = G.dev(x)
+    y = torch.full((m,), float("nan"), device="cuda")
+    info = sp.multiply_inspect(a, xd, y, alg=_capi.SPMV_SLICED)
+    assert info.state_.info()["alg"] == _capi.SPMV_SLICED
+    bytes_tiles = info.state_.info()["device_bytes"]
+    sp.multiply(info, a, xd, y)
+    check(values, rowptr, colind, (m, n), x, G.host(y), what="as inspected", ref_cmp=False)
+    monkeypatch.setenv("SPBLAS_GFX950_TEST_FAIL_REBUILD", "1")
+    v2 = (values * np.float32(-2.0)).astype(np.float32)
+    if via == "update_values":
+        a.values().mul_(-2.0)
+        info.state_.update_values(a.values())
+        a2 = a
+    else:  # a multiply that passes another array refreshes by itself
+        a2 = sp.csr_view(G.dev(v2), a.rowptr(), a.colind(), (m, n), nnz)
+    y.fill_(float("nan"))
+    sp.multiply(info, a2, xd, y)
+    monkeypatch.delenv("SPBLAS_GFX950_TEST_FAIL_REBUILD")
+    pi = info.state_.info()
+    assert pi["alg"] == _capi.SPMV_ROWBLOCK and pi["device_bytes"] < bytes_tiles, pi
+    check(v2, rowptr, colind, (m, n), x, G.host(y), what="after the failed second build", ref_cmp=False)
+    # the same pointer again (the call that used to skip the update and run on a torn-down plan), then a changed array
+    y.fill_(float("nan"))
+    sp.multiply(info, a2, xd, y)
+    check(v2, rowptr, colind, (m, n), x, G.host(y), what="same pointer after the fallback", ref_cmp=False)
+    a2.values().add_(0.25)
+    y.fill_(float("nan"))
+    sp.multiply(info, a2, xd, y)
+    check(v2 + np.float32(0.25), rowptr, colind, (m, n), x, G.host(y), what="values changed in place after the fallback",
+          ref_cmp=False)
 
 
 @pytest.mark.gpu

@@ -295,3 +295,35 @@ def test_a_solve_that_gave_up_waiting_is_reported(gpu, monkeypatch):
     info.state_.check_status()
     ref = oracle.triangular_solve(M.shape, M.indptr, M.indices, vals, b, upper=False, unit=False)
     assert np.allclose(G.host(d_x), ref, rtol=1e-4, atol=1e-6)
+
+
+def test_a_solve_that_gave_up_waiting_fails_the_next_solve_by_itself(gpu, monkeypatch):
+    """Round-5 advisor: no default path called check_status, so an incomplete x went unnoticed.  The kernel now also raises a
+    pinned host word on that path and the NEXT solve on the plan reads it before it launches anything: it fails (once) with
+    a HIP error status instead of running, without a stream synchronisation in any successful call; the solve after that is
+    whole again."""
+    rng = np.random.default_rng(93)
+    n, k = 150000, 5
+    rows = np.repeat(np.arange(n), k)
+    cols = (rng.random(n * k) * rows).astype(np.int64)
+    keep = cols < rows
+    S = sps.csr_matrix(((rng.random(keep.sum()) - 0.5) * (0.5 / k), (rows[keep], cols[keep])), shape=(n, n))
+    M = (S + sps.diags(1.0 + rng.random(n))).tocsr()
+    vals = M.data.astype(np.float32)
+    d_a = G.csr_on_device(vals, M.indptr.astype(np.int32), M.indices.astype(np.int32), M.shape, M.nnz)
+    b = (rng.random(n) + 0.5).astype(np.float32)
+    d_b, d_x = G.dev(b), torch.zeros(n, dtype=torch.float32, device="cuda")
+    info = sp.triangular_solve_inspect(d_a, sp.lower_triangle, sp.explicit_diagonal, d_b, d_x)
+    if info.state_.info()["launches_per_solve"] != 1:
+        pytest.skip("the cooperative solve is not in use here (an HSA tool is loaded)")
+    sp.triangular_solve(info, d_a, sp.lower_triangle, sp.explicit_diagonal, d_b, d_x)   # allocates the control words
+    monkeypatch.setenv("SPBLAS_GFX950_TRSV_SPIN_LIMIT", "0")
+    sp.triangular_solve(info, d_a, sp.lower_triangle, sp.explicit_diagonal, d_b, d_x)   # gives up; the call itself succeeds
+    monkeypatch.delenv("SPBLAS_GFX950_TRSV_SPIN_LIMIT")
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError):
+        sp.triangular_solve(info, d_a, sp.lower_triangle, sp.explicit_diagonal, d_b, d_x)
+    sp.triangular_solve(info, d_a, sp.lower_triangle, sp.explicit_diagonal, d_b, d_x)   # reported once; this one runs
+    info.state_.check_status()
+    ref = oracle.triangular_solve(M.shape, M.indptr, M.indices, vals, b, upper=False, unit=False)
+    assert np.allclose(G.host(d_x), ref, rtol=1e-4, atol=1e-6)
