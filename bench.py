@@ -37,7 +37,7 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=50)
     p.add_argument("--warmup", type=int, default=5)
-    p.add_argument("--workload", default="spmv", choices=["spmv", "spmv_poisson", "spmv_poisson1", "spmv_rmat", "spmv_rmat1", "spmv_plain", "spmm", "spmm_banded", "spmm_rmat", "spgemm", "add", "transpose", "sptrsv", "csc_spmv", "spgemm4"])
+    p.add_argument("--workload", default="spmv", choices=["spmv", "spmv_poisson", "spmv_poisson1", "spmv_rmat", "spmv_rmat1", "spmv_plain", "spmm", "spmm_banded", "spmm_rmat", "spgemm", "add", "transpose", "sptrsv", "csc_spmv", "spgemm4", "spmv_rmat_shards"])
     p.add_argument("--rows", type=int, default=None, help="override the row count (debug only; reported)")
     p.add_argument("--cols", type=int, default=None, help="override the column count (debug: emulate one row shard)")
     p.add_argument("--alg", default="auto", choices=["auto", "vector", "rowblock", "sliced", "noplan"])
@@ -339,7 +339,7 @@ def main():
     _Handle.current(device)
     args.handle_create_ms = (time.perf_counter() - t_h) * 1e3
 
-    if args.workload in ("spmv_rmat1", "spmv_plain", "spmv_poisson1", "spmm", "spmm_banded", "spmm_rmat", "spgemm", "add", "transpose", "sptrsv", "csc_spmv", "spgemm4"):
+    if args.workload in ("spmv_rmat1", "spmv_plain", "spmv_poisson1", "spmm", "spmm_banded", "spmm_rmat", "spgemm", "add", "transpose", "sptrsv", "csc_spmv", "spgemm4", "spmv_rmat_shards"):
         from bench_extra import run_extra  # secondary configs (cfg3 / cfg5 / 8f rows), 1 GPU
         sys.stdout.flush()
         os.dup2(json_fd, 1)  # single-GPU secondary workloads print their own line

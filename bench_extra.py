@@ -136,7 +136,7 @@ def secondary(args, device, log=None):
     HIP events and checked against the oracle; compact records for the `secondary` object of bench.py's JSON line."""
     import copy
     res = {}
-    todo = [("cfg2_plain_csr_view", "spmv_plain"), ("cfg2_poisson", "spmv_poisson1"), ("cfg4", "spmv_rmat1"), ("cfg3", "spmm"), ("spmm_banded", "spmm_banded"),
+    todo = [("cfg2_plain_csr_view", "spmv_plain"), ("cfg2_poisson", "spmv_poisson1"), ("cfg4", "spmv_rmat1"), ("cfg4_shards_of_8", "spmv_rmat_shards"), ("cfg3", "spmm"), ("spmm_banded", "spmm_banded"),
             ("cfg5", "spgemm")]
     if not getattr(args, "no_8f", False):  # SURVEY 8(f): add, transpose, triangular solve at their bench sizes
         todo += [("f_csc_spmv", "csc_spmv"), ("f_add", "add"), ("f_spgemm4", "spgemm4"), ("f_transpose", "transpose"),
@@ -512,6 +512,76 @@ def _run_spgemm4(args, device, sp, oracle, generate):
                  cpu, parity=parity, pmc_key=None if args.rows else "spgemm4_8f")
 
 
+def _run_rmat_shards(args, device, sp, oracle, generate):
+    """BASELINE cfg4 as the 8-GPU run will see it, measured on ONE GPU: the eight nnz-prefix row shards of the R-MAT scale-24
+    graph (sharded.partition_rows_by_nnz, exactly what bench.py --gpus 8 --workload spmv_rmat gives rank r), each inspected
+    and timed one after another.  The slowest shard's local step IS the critical path of the 8-GPU step before the gather;
+    max / mean says how well the nnz-prefix split balances TIME (it balances entries by construction).  value = the whole
+    matrix's flops over the slowest shard's step; parity: every row of the eight local results against oracle_spmv."""
+    from spblas_reference_amd import sharded
+    world = 8
+    scale = 24 if args.rows is None else int(np.log2(args.rows))
+    values, rowptr, colind, shape, nnz = generate.rmat_csr_device(scale, 16, dtype=torch.float64, seed=0, device=device)
+    m = n = shape[0]
+    bounds = sharded.partition_rows_by_nnz(rowptr, world)
+    g = torch.Generator(device=device).manual_seed(7)
+    x = torch.rand(n, dtype=torch.float64, device=device, generator=g)
+    y_all = torch.full((m,), float("nan"), dtype=torch.float64, device=device)
+    per = []
+    wall = 0.0
+    for r in range(world):
+        lo, hi = bounds[r], bounds[r + 1]
+        a = sharded.shard_csr(values, rowptr, colind, shape, lo, hi)
+        y = y_all[lo:hi]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        info = sp.multiply_inspect(sp.matrix_opt(a), x, y)
+        torch.cuda.synchronize()
+        inspect_ms = (time.perf_counter() - t0) * 1e3
+        elapsed, ms = _time_steps(lambda: sp.multiply(info, a, x, y), args.warmup, args.steps)
+        wall += elapsed
+        plan = info.state_.info()
+        y.fill_(float("nan"))
+        sp.multiply(info, a, x, y)
+        torch.cuda.synchronize()
+        per.append({"rank": r, "rows": int(hi - lo), "nnz": int(a.size()), "ms": elapsed / args.steps * 1e3, "event_ms": ms[0],
+                    "plan_alg": plan.get("alg"), "plan_bytes": plan.get("device_bytes"), "inspect_ms": inspect_ms,
+                    "alg_bytes": int(a.size()) * 12 + (hi - lo + 1) * 4 + (n + hi - lo) * 8})
+        del info, a
+        torch.cuda.empty_cache()
+    t = [p["ms"] for p in per]
+    worst = max(range(world), key=lambda r: t[r])
+    cpu, parity = None, None
+    if not args.no_cpu_baseline:
+        v, rp, ci, xh = values.cpu().numpy(), rowptr.cpu().numpy(), colind.cpu().numpy(), x.cpu().numpy()
+        try:
+            oracle.load(native=True)
+            native = True
+        except Exception:
+            native = False
+        t0 = time.perf_counter()
+        y_ref = oracle.spmv(shape, rp, ci, v, xh, native=native)
+        dt = time.perf_counter() - t0
+        absrow = oracle.spmv_absrow(rp, ci, v, xh)
+        cpu = {"value": 2.0 * nnz / dt / 1e9, "unit": "GFLOP/s", "cores": 1, "kind": "port", "seconds": dt,
+               "sample": f"full workload ({nnz} nnz), 1 run of oracle_spmv over all rows (the eight shards together)"}
+        nbad, w = parity_rows(y_all.cpu().numpy(), y_ref, absrow.astype(np.float64), 1e-12, float(np.finfo(np.float64).eps), np.diff(rp))
+        parity = {"status": "pass" if nbad == 0 else "fail", "rows": int(m), "rows_out_of_bound": nbad, "tol": 1e-12,
+                  "worst_err_over_rownorm": w, "against": "oracle_spmv, every row of the eight shards' local results"}
+    # the record's step = the slowest shard (what an 8-GPU step waits for); roofline on that shard's own algorithmic bytes
+    out = _emit(args, "csr_spmv_gflops", 2.0 * nnz, per[worst]["alg_bytes"], t[worst] * 1e-3 * args.steps, [per[worst]["event_ms"], per[worst]["event_ms"]],
+                f"cfg4 as eight nnz-prefix row shards (the local steps of an 8-GPU run), one after another on one GPU: fp64 "
+                f"R-MAT scale {scale}, nnz={nnz}; step = the SLOWEST shard's local SpMV",
+                {"dtype": "f64", "rows": m, "nnz": nnz, "operand": "matrix_opt(csr_view of the shard) + multiply_inspect",
+                 "shard_ms": [round(v_, 5) for v_ in t], "shard_rows": [p["rows"] for p in per], "shard_nnz": [p["nnz"] for p in per],
+                 "shard_plan_alg": [p["plan_alg"] for p in per], "shard_inspect_ms": [round(p["inspect_ms"], 2) for p in per],
+                 "max_ms": max(t), "mean_ms": sum(t) / world, "max_over_mean": max(t) / (sum(t) / world),
+                 "slowest_rank": worst, "sum_ms": sum(t),
+                 "speedup_bound_vs_one_gpu_note": "one-GPU cfg4 step / max_ms bounds the 8-GPU speed-up before the all-gather",
+                 "kernel": "the shard's plan (see shard_plan_alg: 3 = SLICED tiles, 2 = row blocks)"}, cpu, parity=parity)
+    return out
+
+
 def _run(args, device):
     import spblas_reference_amd as sp
     from oracle import oracle
@@ -523,6 +593,8 @@ def _run(args, device):
         return _run_spmv_poisson(args, device, sp, oracle, generate)
     if args.workload == "spmv_rmat1":
         return _run_spmv_rmat1(args, device, sp, oracle, generate)
+    if args.workload == "spmv_rmat_shards":
+        return _run_rmat_shards(args, device, sp, oracle, generate)
     if args.workload == "csc_spmv":
         return _run_csc_spmv(args, device, sp, oracle, generate)
     if args.workload == "spgemm4":
@@ -598,10 +670,19 @@ def _run(args, device):
                f"B {m}x{ncols} row-major" if banded else
                f"cfg3: fp32 CSR x dense SpMM, A {m}x{m} 32 nnz/row uniform random, B {m}x{ncols} row-major"),
               {"dtype": "f32", "rows": m, "nnz": nnz, "ncols": ncols, "spmm_inspect": mi,
-               "kernel": "spmm_panel_kernel<int> (v_mfma_f32_32x32x2_f32)" if mi["panel_blocks"] > 0 else
-                         "spmm_rowgroup_kernel<float,int,4>"}, cpu, parity=parity,
+               # which kernel owns the qualifying row blocks (csrc/spmm.hip): round 6's default is the band kernel -- LDS-staged B
+               # window, vector FMAs over the STORED entries; the matrix-core forms (tile kernel of rounds 3 - 5:
+               # SPBLAS_GFX950_SPMM_BAND=0; dense-window kernel: SPBLAS_GFX950_SPMM_BAND_DENSE=250) were measured slower and are opt-in
+               "kernel": (("spmm_panel_kernel<int> (v_mfma_f32_32x32x2_f32)" if os.environ.get("SPBLAS_GFX950_SPMM_BAND") == "0" else
+                           "spmm_band_mfma_kernel<int> (v_mfma_f32_16x16x4_f32)" if int(os.environ.get("SPBLAS_GFX950_SPMM_BAND_DENSE", "1001")) <= 1000 else
+                           "spmm_band_kernel<int,8> (LDS-staged B window, v_pk_fma_f32 over the stored entries; no matrix-core work)")
+                          if mi["panel_blocks"] > 0 else "spmm_rowgroup_kernel<float,int,4>"),
+               "matrix_core_alternatives_ms": ({"note": "same workload, measured in round 6 (profiles/r06_spmm_band.md)",
+                                                "spmm_panel_kernel (tiles, 32x32x2)": 2.37, "spmm_band_mfma_kernel (window, 16x16x4)": 2.38}
+                                               if banded and not args.rows else None)}, cpu, parity=parity,
                      pmc_key=None if (rmat or args.rows) else ("spmm_banded" if banded else "spmm_cfg3"),
-                     mfma_key="spmm_banded_mfma" if (banded and not args.rows and mi["panel_blocks"] > 0) else None)
+                     mfma_key="spmm_banded_mfma" if (banded and not args.rows and mi["panel_blocks"] > 0 and
+                                                     os.environ.get("SPBLAS_GFX950_SPMM_BAND") == "0") else None)
 
     if args.workload == "spgemm":
         m = args.rows or 1_000_000

@@ -53,6 +53,8 @@ def summarize_secondary(rec):
         out["traffic_x"] = _r(tr / ab, 3)
     if roof.get("mfma_util") is not None:
         out["mfma"] = _r(roof["mfma_util"], 3)
+    if (rec.get("detail") or rec.get("config") or {}).get("max_over_mean") is not None:  # cfg4_shards_of_8: balance of the shards
+        out["max_over_mean"] = _r((rec.get("detail") or rec.get("config"))["max_over_mean"], 3)
     out["parity"] = rec.get("parity_check", "not run")
     return out
 

@@ -130,6 +130,13 @@ struct spblas_gfx950_plan_s {
   unsigned char* mm_is_panel = nullptr;  // [mm_nblk] 1 = the panel kernel owns the block (the row kernel skips it)
   int32_t* mm_panel_blocks = nullptr;    // [mm_npanel] block ids
   int32_t* mm_tiles = nullptr;           // [mm_nblk * 9]: count + up to 8 ascending column-tile ids per block
+  void* mm_win = nullptr;                // int2[mm_nblk]: smallest / largest column of every qualifying block (spmm_band_kernel)
+  int32_t* mm_vec_blocks = nullptr;      // band path: the qualifying blocks for the entry-loop kernel, ascending
+  int32_t* mm_dense_blocks = nullptr;    // ... and those dense in their window (spmm_band_mfma_kernel)
+  int64_t mm_ndense = 0;
+  int mm_band = 1;                       // qualifying blocks go to the band kernels (0: the tile kernel of rounds 3 - 5)
+  int mm_band_ch = 128, mm_band_waves = 8;  // B rows staged per chunk, wavefronts per workgroup
+  int mm_band_dense_pm = 1001;           // window density (per mille) from which a block's contraction runs on the matrix cores
   void* mm_long_part = nullptr;          // T[n_long * mm_long_parts * n] partial rows of the long rows (grown on demand)
   int64_t mm_long_cap = 0;               // elements held by mm_long_part
   int mm_long_parts = 1;

@@ -169,13 +169,24 @@ def _banded(m, k, per_row, half_width, rng, clusters=(0,), dup=True):
     return rowptr.astype(np.int32), cols.reshape(-1).astype(np.int32)
 
 
+# which kernel takes the qualifying row blocks (csrc/spmm.hip): round 6's default -- the band kernel: B window staged in LDS,
+# vector FMAs over the stored entries, single-window and tile-group modes --, its matrix-core sibling for blocks dense in
+# their window (opt-in: every block that fits), and the tile kernel of rounds 3 - 5
+PANEL_KERNELS = {"band": {}, "band_mfma": {"SPBLAS_GFX950_SPMM_BAND_DENSE": "0"}, "tiles": {"SPBLAS_GFX950_SPMM_BAND": "0"},
+                 "band_4_waves_small_chunks": {"SPBLAS_GFX950_SPMM_BAND_WAVES": "4", "SPBLAS_GFX950_SPMM_BAND_CH": "64"}}
+
+
+@pytest.mark.parametrize("kernel", list(PANEL_KERNELS))
 @pytest.mark.parametrize("n", [32, 128, 200])
 @pytest.mark.parametrize("clusters", [(0,), (0, 5000, 11000)])
-def test_spmm_panel_path_matrix_cores(gpu, n, clusters, monkeypatch):
-    """SpMM inspect is consumed: row blocks whose entries fall into a few aligned 128-column tiles are multiplied
-    from LDS-staged B tiles on the matrix cores (spmm_panel_kernel, exact-f32 MFMA); the result must equal the
-    oracle like every other path, including repeated (row, column) pairs, unsorted columns, a ragged last block,
-    n that is not a multiple of 32 and n > 128 (two passes)."""
+def test_spmm_panel_path_matrix_cores(gpu, n, clusters, kernel, monkeypatch):
+    """SpMM inspect is consumed: row blocks whose entries fall into a few aligned 64-column tiles are multiplied
+    from LDS-staged B rows (band kernels / tile kernel, see PANEL_KERNELS); the result must equal the
+    oracle like every other path, including repeated (row, column) pairs, unsorted columns, a ragged last block, rows of
+    more than 64 entries, windows that wrap around or span three clusters (tile groups), n that is not a multiple of 32 and
+    n > 128 (two passes)."""
+    for k_, v_ in PANEL_KERNELS[kernel].items():
+        monkeypatch.setenv(k_, v_)
     monkeypatch.setenv("SPBLAS_GFX950_SPMM_PANEL_MIN", "64")  # below the performance threshold: exercise the kernel
     rng = np.random.default_rng(17)
     m, k, per_row = 20011, 23000, 24 * len(clusters)
@@ -217,7 +228,10 @@ def test_spmm_panel_threshold_default(gpu):
     assert info.state_.spmm_info() == {"inspected": 1, "panel_blocks": 0, "panel_nnz": 0, "long_rows": 0}
 
 
-def test_spmm_panel_path_nonfinite_b_rows(gpu, monkeypatch):
+@pytest.mark.parametrize("kernel", list(PANEL_KERNELS))
+def test_spmm_panel_path_nonfinite_b_rows(gpu, kernel, monkeypatch):
+    for k_, v_ in PANEL_KERNELS[kernel].items():
+        monkeypatch.setenv(k_, v_)
     monkeypatch.setenv("SPBLAS_GFX950_SPMM_PANEL_MIN", "64")
     """The dense tile holds zeros where A has no entry; 0 * inf must not leak into rows that do not reference the
     non-finite B row (the reference multiplies stored entries only, multiply_impl.hpp:85-91)."""
