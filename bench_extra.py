@@ -535,7 +535,9 @@ def _run_rmat_shards(args, device, sp, oracle, generate):
         y = y_all[lo:hi]
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        info = sp.multiply_inspect(sp.matrix_opt(a), x, y)
+        algs = {"auto": sp._capi.SPMV_AUTO, "vector": sp._capi.SPMV_VECTOR, "rowblock": sp._capi.SPMV_ROWBLOCK,
+                "sliced": sp._capi.SPMV_SLICED}
+        info = sp.multiply_inspect(sp.matrix_opt(a), x, y, alg=algs.get(getattr(args, "alg", "auto"), sp._capi.SPMV_AUTO))
         torch.cuda.synchronize()
         inspect_ms = (time.perf_counter() - t0) * 1e3
         elapsed, ms = _time_steps(lambda: sp.multiply(info, a, x, y), args.warmup, args.steps)

@@ -531,7 +531,10 @@ static bool sliced_candidate(const spblas_gfx950_plan_s* pl) {
   const double tile = 80.0 * 1024 / tsz;
   const double nseg = (pl->n / tile + 1) * (pl->m / tile + 1);
   return (size_t) pl->n * tsz >= ((size_t) 3 << 20) && pl->nnz >= ((int64_t) 2 << 20) &&
-         pl->nnz < INT32_MAX - 8 && (double) pl->nnz / nseg >= 48.0 &&
+         // (entries per 80 KiB x 80 KiB tile.  48 until round 5; the last of the eight nnz-prefix row shards of R-MAT scale 24 --
+         // 7.3 M rows of 4.6 entries, 28.7 per tile -- was kept off the tiles by it and ran the row-block kernel at 0.463 ms
+         // against 0.374 tiled: the build's own padding guard (padded stream <= 2 nnz) is the better judge)
+         pl->nnz < INT32_MAX - 8 && (double) pl->nnz / nseg >= 24.0 &&
          // rows longer than the window: a few dense rows are fine; a matrix living in its long rows (power law) gets
          // variable-height bins and is decided by the timed trial (below) -- unless trials are switched off
          (pl->max_row_len <= 4096 || (pl->n_long <= 65536 && pl->long_nnz * 4 <= pl->nnz) ||
@@ -769,8 +772,21 @@ int spblas_gfx950_spmv_plan_create(spblas_gfx950_handle_t handle, spblas_gfx950_
       // row-block kernel in a timed trial; the value-free form costs what a snapshot plan costs plus the window reads --
       // 0.37 against 1.71 ms at cfg2 -- and is decided by the same static rules as a snapshot plan: no trial, whose two
       // row-block multiplies alone were 3.4 of the 10 ms of this inspect)
-      if (pl->s_uncertain || (pl->refresh_each_call && !pl->vfree))
-        (void) auto_trial(handle, pl, values, &keep);
+      // Round 6: by default a RULE, not a stopwatch, so that the same matrix gets the same plan -- and the same bits -- on
+      // every box: skewed matrices (s_uncertain) keep the tiles when x is far larger than what the caches hold for the
+      // row-block kernel's gathers (measured pairs, tiled vs row-block: R-MAT scale 20, x of 4 - 8 MB: 0.14 / 0.18 vs 0.13 /
+      // 0.14 ms; scale 22, x of 16 / 32 MB: 0.40 vs 0.47 and 0.59 vs 0.52; scale 24, x of 64 / 128 MB: 1.47 vs 2.33 and 1.7
+      // vs 3.4; its eight row shards 0.31 - 0.37 vs 0.44 - 0.58), copying plans that refresh their values on every multiply
+      // from 32 MB (cfg2, 40 MB: 0.76 vs 1.71).  SPBLAS_GFX950_AUTO_TRIAL=1 brings the timed trial back, =0 the static
+      // decline of rounds 2 - 5.
+      if (pl->s_uncertain || (pl->refresh_each_call && !pl->vfree)) {
+        if (env_int_spmv("SPBLAS_GFX950_AUTO_TRIAL", -1) == 1) {
+          (void) auto_trial(handle, pl, values, &keep);
+        } else {
+          const double x_bytes = (double) pl->n * (pl->value_type == SPBLAS_GFX950_F32 ? 4.0 : 8.0);
+          keep = x_bytes >= (pl->s_uncertain ? 40.0 : 32.0) * 1024.0 * 1024.0;
+        }
+      }
       if (keep) {
         pl->alg = SPBLAS_GFX950_SPMV_SLICED;
         store_trial(handle, pl, values);

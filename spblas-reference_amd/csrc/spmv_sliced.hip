@@ -2859,9 +2859,9 @@ static int sliced_build_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl
       // bins flatten heavy rows, so such a matrix CAN run well here (R-MAT scale 24 fp64: 2.4 vs 3.4 ms) -- but hot
       // columns also serve the row-block kernel from L2.  No static rule separates the two: the plan is finished
       // and plan_create times it against the row-block kernel.
-      if (!env_int("SPBLAS_GFX950_AUTO_TRIAL", 1))
+      if (!env_int("SPBLAS_GFX950_AUTO_TRIAL", -1))
         return SPBLAS_GFX950_STATUS_NOT_SUPPORTED;
-      pl->s_uncertain = 1;
+      pl->s_uncertain = 1;  // (plan_create decides: by rule since round 6, by the stopwatch with SPBLAS_GFX950_AUTO_TRIAL=1)
     }
   }
   tr.mark("probe + block offsets read back");

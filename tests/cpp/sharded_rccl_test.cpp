@@ -81,7 +81,7 @@ int main() {
     }
   int failed = 0;
   using op_t = spblas::__gfx950::sharded_spmv_t<T, std::int32_t>;
-  const auto by_nnz = op_t::partition_rows_by_nnz(rowptr.data(), m, 4);
+  const auto by_nnz = op_t::partition_rows_by_nnz(rowptr.data(), m, 4, 0);  // (row_weight 0: the entries alone)
   if (!(by_nnz.size() == 5 && by_nnz[0] == 0 && by_nnz[4] == m && by_nnz[1] <= by_nnz[2] && by_nnz[2] <= by_nnz[3])) {
     std::fprintf(stderr, "FAILED: partition_rows_by_nnz shape\n");
     ++failed;

@@ -673,17 +673,22 @@ def test_spmv_sliced_with_a_few_dense_rows(gpu, monkeypatch, split):
           ref_cmp=False)
 
 
-@pytest.mark.parametrize("varbins", ["0", "1"])
+@pytest.mark.parametrize("varbins", ["0", "1", "rule"])
 def test_spmv_auto_declines_sliced_for_skewed_matrices(gpu, monkeypatch, varbins):
     """Hot columns (one slice carries most entries) or a heavy block of rows (one bin group does): the
     sliced plan would leave the chip waiting for a single workgroup, so AUTO must keep the row-block
     kernel; a forced SLICED plan must still be correct.  With variable-height bins (the default for row-skewed
     matrices; SPBLAS_GFX950_PB_VARBINS=0 keeps the arithmetic bins and their reduce work list under test) the
     heavy block of rows is spread over many bins and AUTO may take either plan."""
-    monkeypatch.setenv("SPBLAS_GFX950_PB_VARBINS", varbins)
-    # the static rules ("0": no variable bins, no timed trial -- AUTO must decline) and the round-2 default ("1": the plan
-    # is built and AUTO keeps whichever of the two was faster in the trial)
-    monkeypatch.setenv("SPBLAS_GFX950_AUTO_TRIAL", varbins)
+    # the static rules ("0": no variable bins, no timed trial -- AUTO must decline), the opt-in of rounds 2 - 5 ("1": the plan
+    # is built and AUTO keeps whichever of the two was faster in a timed trial) and round 6's default ("rule": the plan is
+    # built and kept by a RULE -- x of 8 MB here is far below the 40 MB from which a skewed matrix keeps its tiles -- so that
+    # the same matrix gets the same plan on every box)
+    if varbins == "rule":
+        monkeypatch.delenv("SPBLAS_GFX950_AUTO_TRIAL", raising=False)
+    else:
+        monkeypatch.setenv("SPBLAS_GFX950_PB_VARBINS", varbins)
+        monkeypatch.setenv("SPBLAS_GFX950_AUTO_TRIAL", varbins)
     # (rows stay whole here: a plan that cuts long rows into pieces reduces all rows at once, and this test also drives
     # the two-stage row-range form; test_spmv_sliced_compacts_empty_rows covers the pieces)
     monkeypatch.setenv("SPBLAS_GFX950_PB_SPLIT_LEN", "0")
@@ -700,8 +705,9 @@ def test_spmv_auto_declines_sliced_for_skewed_matrices(gpu, monkeypatch, varbins
         xd = G.dev(x)
         y = torch.full((m,), float("nan"), device="cuda")
         info = sp.multiply_inspect(sp.matrix_opt(a), xd, y)
-        if varbins == "0":
+        if varbins in ("0", "rule"):
             assert info.state_.info()["alg"] == _capi.SPMV_ROWBLOCK, what
+            assert info.state_.sliced_info()["auto_trial"] == 0
         else:
             assert info.state_.info()["alg"] in (_capi.SPMV_ROWBLOCK, _capi.SPMV_SLICED), what
         sp.multiply(info, a, xd, y)

@@ -149,11 +149,19 @@ def test_pipelined_striped_all_gather_world2_gloo(tmp_path):
 
 def test_partition_rows_by_nnz_balances_nnz():
     rowptr = torch.tensor(np.concatenate([[0], np.cumsum([1000] * 4 + [1] * 4000)]))
-    b = sharded.partition_rows_by_nnz(rowptr, 8)
+    b = sharded.partition_rows_by_nnz(rowptr, 8, row_weight=0)
     assert b[0] == 0 and b[-1] == 4004 and all(b[i] <= b[i + 1] for i in range(8))
     per = [int(rowptr[b[i + 1]] - rowptr[b[i]]) for i in range(8)]
     assert max(per) <= 1000 + 1  # no shard exceeds nnz/P by more than one (heavy) row
     assert sharded.partition_rows_even(10, 4) == [0, 2, 5, 7, 10]
+    # the default weighs a row like one entry (its offset + its element of y cost what an entry costs): the four heavy rows
+    # and the 4 000 single-entry rows hold 8 000 entries + 4 004 rows = 12 004 units, ~1 500 per shard
+    b = sharded.partition_rows_by_nnz(rowptr, 8)
+    assert b[0] == 0 and b[-1] == 4004 and all(b[i] <= b[i + 1] for i in range(8))
+    work = [int(rowptr[b[i + 1]] - rowptr[b[i]]) + (b[i + 1] - b[i]) for i in range(8)]
+    assert max(work) <= 12004 // 8 + 1001 and min(work) >= 500
+    # (the shards of single-entry rows now hold fewer entries than an equal split of the entries would give them)
+    assert int(rowptr[b[8]] - rowptr[b[7]]) < 1000
 
 
 def test_sharded_default_compute_is_the_hip_path():
