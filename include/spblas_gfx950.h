@@ -171,9 +171,12 @@ int spblas_gfx950_set_option(spblas_gfx950_handle_t handle, int option, int64_t 
  * so the caller sees the same semantics as with a structure-only plan.  Its default form is VALUE-FREE (bit 7, round 5):
  * the plan holds no values at all -- the first kernel gathers x, the second multiplies by the caller's array, staged bin by
  * bin through LDS; where that form does not apply, the copying form of round 4 (a value refresh per multiply, kept only
- * if it beats the row-block kernel in a timed trial).  The calls that are not given the values -- the two-stage calls
- * (spmv_expand / spmv_reduce_rows) and the multi-GPU steps (spmv_reduce_rows_bcast, spmv_step_bcast[_chunked]) -- refuse
- * such a plan.  The plan is tied to (m, n, nnz, rowptr, colind). */
+ * if it beats the row-block kernel by rule -- x of 32 MB or more -- or, with SPBLAS_GFX950_AUTO_TRIAL=1, in a timed trial).
+ * The calls that are not given the values -- the two-stage calls (spmv_expand / spmv_reduce_rows) and the multi-GPU steps
+ * (spmv_reduce_rows_bcast, spmv_step_bcast[_chunked]) -- refuse the COPYING form.  Since round 6 the value-free form is
+ * accepted by spmv_reduce_rows_bcast and spmv_step_bcast: it reads the value array registered with the plan (plan_create,
+ * the last spblas_gfx950_spmv, plan_update_values) as it is when the step runs -- no copy that could go stale.
+ * The plan is tied to (m, n, nnz, rowptr, colind). */
 int spblas_gfx950_spmv_plan_create(spblas_gfx950_handle_t handle, spblas_gfx950_plan_t* plan,
                                    int64_t m, int64_t n, int64_t nnz, const void* rowptr,
                                    const int32_t* colind, const void* values, int offset_type,

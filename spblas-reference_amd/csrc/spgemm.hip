@@ -28,6 +28,7 @@
 // (kk, 1), the product is the A entry itself) and D := the second summand.  add_inspect is the
 // symbolic pass, add_compute the numeric one; columns come out ascending like the CPU SPA + sort.
 #include "common.hpp"
+#include <type_traits>
 #include "scan.hpp"
 
 #include <cstdlib>
@@ -92,6 +93,7 @@ struct spblas_gfx950_spgemm_s {
   int64_t n_nodup = 0;          // the first n_nodup descriptors: no two products share a column
   int64_t n_sortable = 0;       // rows at the end of bin 2's range that are one round of vector loads
   int2* b_pack = nullptr;       // fp32 fills with many direct rows: (column, value bits) of B interleaved, REWRITTEN BY EVERY FILL
+  int2* dir_ddesc = nullptr;    // with an addend: (first entry, length) of the addend's row of every direct row, in dir_desc order
   int32_t* sym_flag = nullptr;  // symbolic pass only: [n_sortable] 1 = no two products of the row share a column
   bool r_ready = false;
   int numeric_calls = 0;        // numeric passes since the symbolic one (the SECOND records: a one-shot fill pays nothing)
@@ -159,11 +161,19 @@ __global__ __launch_bounds__(256) void spg_bound_kernel(int64_t m, const int32_t
     }
     ub = group_sum_c<8>(ub);
     bad = group_sum_c<8>(bad);
-    if (d_rowptr)
-      ub += d_rowptr[row + 1] - d_rowptr[row];
+    const int64_t ub_prod = ub;
+    int d_len = 0;
+    if (d_rowptr) {
+      d_len = d_rowptr[row + 1] - d_rowptr[row];
+      ub += d_len;
+    }
     if (lane == 0) {
       int b = spg_bin_of(ub);
-      if (b == 2 && sortable_ok && !bad && p1 - p0 <= 4 * (64 / sub) && p1 - p0 <= 64)
+      // sortable: the products fit one round of a wavefront's vector loads (<= 256) and the addend's row, if there is one,
+      // one entry per lane (round 6: cfg5's rows with an addend of 16 entries count 272 and used to fall to the 2 048-slot
+      // hash of bin 3 -- 6.3 ms per fill against 0.85 without the addend)
+      if ((b == 2 || (b == 3 && d_rowptr)) && sortable_ok && !bad && p1 - p0 <= 4 * (64 / sub) && p1 - p0 <= 64 &&
+          ub_prod <= 256 && d_len <= 64)
         b = SPG_SORTABLE;
       bin_of_row[row] = b;
       atomicAdd(&hist[b], 1u);
@@ -1035,17 +1045,19 @@ __global__ __launch_bounds__(256) void spg_direct_lists_kernel(int64_t count, co
                                                                const int32_t* __restrict__ a_rowptr,
                                                                const int32_t* __restrict__ c_rowptr,
                                                                const int32_t* __restrict__ flag_excl,
-                                                               int4* __restrict__ desc) {
+                                                               int4* __restrict__ desc,
+                                                               const int32_t* __restrict__ d_rowptr,
+                                                               int2* __restrict__ ddesc) {
   const int64_t idx = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= count)
     return;
   const int row = rows[idx];
   const int p0 = a_rowptr[row], out0 = c_rowptr[row], pos = flag_excl[idx];
   const int4 d = make_int4(p0, a_rowptr[row + 1] - p0, out0, c_rowptr[row + 1] - out0);
-  if (flag_excl[idx + 1] != pos)
-    desc[pos] = d;
-  else
-    desc[count - 1 - (idx - pos)] = d;
+  const int64_t at = flag_excl[idx + 1] != pos ? (int64_t) pos : count - 1 - (idx - pos);
+  desc[at] = d;
+  if (ddesc)
+    ddesc[at] = make_int2(d_rowptr[row], d_rowptr[row + 1] - d_rowptr[row]);
 }
 
 // Inclusive scan of one int per lane over the wavefront with DPP moves (row_shr 1 / 2 / 4 / 8 inside the rows of 16 lanes,
@@ -1084,20 +1096,26 @@ __global__ __launch_bounds__(256) void spg_pack_b_kernel(int64_t nnz, const int3
     out[i] = make_int2(col[i], __float_as_int(val[i]));
 }
 
-template <typename T, bool PACKED, bool DUP>
+// ADD (round 6, C = alpha A B + beta D): the row of the addend joins the products as a FIFTH element per lane (<= 64 entries:
+// the classification; enumerated after the products, as the reference adds it after them), 320 slots instead of 256.
+template <typename T, bool PACKED, bool DUP, bool ADD = false>
 __global__ __launch_bounds__(256) void spg_direct_kernel(
     int n_dir, const int4* __restrict__ desc, const int2* __restrict__ adesc, const T* __restrict__ a_values,
     const int32_t* __restrict__ b_colind, const T* __restrict__ b_values, int32_t* __restrict__ c_colind,
-    T* __restrict__ c_values, T alpha, int sub, unsigned bucket_mul, const int2* __restrict__ b_pack) {
+    T* __restrict__ c_values, T alpha, int sub, unsigned bucket_mul, const int2* __restrict__ b_pack,
+    const int2* __restrict__ ddesc = nullptr, const int32_t* __restrict__ d_colind = nullptr,
+    const T* __restrict__ d_values = nullptr, T beta = T(0)) {
   constexpr int NBK = SPG_DIR_NBK, BPL = NBK / 64;
+  constexpr int CAP = ADD ? 320 : 256;
   typedef typename spg_vec4<T>::type v4u;
-  __shared__ __attribute__((aligned(16))) int s_keys[4][256 + 4];
-  __shared__ __attribute__((aligned(16))) T s_vals[4][256];
+  typedef typename std::conditional<ADD, unsigned short, unsigned char>::type enum_t;
+  __shared__ __attribute__((aligned(16))) int s_keys[4][CAP + 4];
+  __shared__ __attribute__((aligned(16))) T s_vals[4][CAP];
   __shared__ __attribute__((aligned(16))) int s_bcnt[4][NBK + 4];
-  __shared__ unsigned char s_enum[4][DUP ? 256 + 4 : 4];  // DUP: the enumeration number of the product behind every key
+  __shared__ enum_t s_enum[4][DUP ? CAP + 4 : 4];  // DUP: the enumeration number of the product behind every key
   const int wave = threadIdx.x >> 6, lt = threadIdx.x & 63;
   int* tkeys = s_keys[wave];
-  unsigned char* tenum = s_enum[wave];
+  enum_t* tenum = s_enum[wave];
   T* tvals = s_vals[wave];
   int* bcnt = s_bcnt[wave];
   // sub / 4 lanes per B row, four consecutive entries each: lane lt works on entries c4 .. c4 + 3 of the B row of A entry jr
@@ -1105,7 +1123,7 @@ __global__ __launch_bounds__(256) void spg_direct_kernel(
   const int jr = lt >> lshift, c4 = (lt & ((1 << lshift) - 1)) * 4;
   const int stride = (int) gridDim.x * 4;
   int i = __builtin_amdgcn_readfirstlane((int) blockIdx.x * 4 + wave);
-  constexpr int U = 4;
+  constexpr int U = ADD ? 5 : 4;
   struct arow {
     int qb, len;
     T a;
@@ -1114,7 +1132,10 @@ __global__ __launch_bounds__(256) void spg_direct_kernel(
     spg_i4u cc;  // the classification admits a row only if reading up to the next multiple of four entries of each of its
     v4u vv;      // B rows stays inside B's arrays (spg_direct_flag_kernel); what lies beyond the row is masked out by n
     int n;       // entries of the lane: 0 .. 4
+    int dc;      // ADD: the lane's entry of the addend's row: column (-1: none) and beta * value
+    T dv;
   };
+  auto load_ddesc = [&](int r) { return (ADD && r < n_dir) ? ddesc[r] : make_int2(0, 0); };
   auto load_desc = [&](int r) { return r < n_dir ? desc[r] : make_int4(0, 0, 0, 0); };
   auto load_a = [&](const int4& d) {
     arow a{0, 0, T(0)};
@@ -1126,9 +1147,16 @@ __global__ __launch_bounds__(256) void spg_direct_kernel(
     }
     return a;
   };
-  auto load_b = [&](const arow& a, int na_f) {
+  auto load_b = [&](const arow& a, int na_f, const int2& dd) {
     const int na = na_f & 0xFFFF;
     brow b;
+    b.dc = -1;
+    b.dv = T(0);
+    if constexpr (ADD)
+      if (lt < dd.y) {
+        b.dc = d_colind[dd.x + lt];
+        b.dv = beta * d_values[dd.x + lt];
+      }
     const int q0 = __shfl(a.qb, jr, 64) + c4, ln = __shfl(a.len, jr, 64) - c4;  // (lanes >= na hold length 0)
     b.n = jr < na ? (ln < 0 ? 0 : ln > 4 ? 4 : ln) : 0;
     const int q = b.n > 0 ? q0 : 0;  // (entries 0 .. 3 exist: some admitted row has a B row whose padded range is inside)
@@ -1143,8 +1171,9 @@ __global__ __launch_bounds__(256) void spg_direct_kernel(
     return b;
   };
   int4 d0 = load_desc(i), d1 = load_desc(i + stride), d2 = load_desc(i + 2 * stride);
+  int2 e0d = load_ddesc(i), e1d = load_ddesc(i + stride), e2d = load_ddesc(i + 2 * stride);
   arow a0 = load_a(d0), a1 = load_a(d1);
-  brow b0 = load_b(a0, d0.y);
+  brow b0 = load_b(a0, d0.y, e0d);
   auto zero_buckets = [&]() {
 #pragma unroll
     for (int j = 0; j < BPL; ++j)
@@ -1157,9 +1186,10 @@ __global__ __launch_bounds__(256) void spg_direct_kernel(
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the loop is entered with every load complete, like its back edge
   while (i < n_dir) {
     // the next rows' loads first: B entries of row i + 1, A entries of row i + 2, descriptor of row i + 3
-    const brow b1 = load_b(a1, d1.y);
+    const brow b1 = load_b(a1, d1.y, e1d);
     const arow a2 = load_a(d2);
     const int4 d3 = load_desc(i + 3 * stride);
+    const int2 e3d = load_ddesc(i + 3 * stride);
     // row i: products, bucket counts (the atomic returns the arrival number inside the bucket), scan, keys in bucket
     // order, rank of every product's key inside its bucket, sorted row in LDS, write
     const int out0 = d0.z, dlen = d0.w;
@@ -1170,8 +1200,8 @@ __global__ __launch_bounds__(256) void spg_direct_kernel(
     T pv[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      col[u] = u < b0.n ? b0.cc[u] : -1;
-      pv[u] = av * b0.vv[u];
+      col[u] = u < 4 ? (u < b0.n ? b0.cc[u & 3] : -1) : b0.dc;
+      pv[u] = u < 4 ? av * b0.vv[u & 3] : b0.dv;
       bk[u] = col[u] >= 0 ? (int) __umulhi((unsigned) col[u], bucket_mul) : 0;
       ai[u] = col[u] >= 0 ? atomicAdd(&bcnt[bk[u]], 1) : 0;
     }
@@ -1199,7 +1229,7 @@ __global__ __launch_bounds__(256) void spg_direct_kernel(
       if (col[u] >= 0) {
         tkeys[bcnt[bk[u]] + ai[u]] = col[u];
         if constexpr (dup)  // lane lt, entry u = product number 4 lt + u of the reference's enumeration (A entry, then B entry)
-          tenum[bcnt[bk[u]] + ai[u]] = (unsigned char) (4 * lt + u);
+          tenum[bcnt[bk[u]] + ai[u]] = (enum_t) (u < 4 ? 4 * lt + u : 256 + lt);
       }
     spg_team_sync<64>();
     int rank[U];
@@ -1211,7 +1241,7 @@ __global__ __launch_bounds__(256) void spg_direct_kernel(
         rank[u] = e0;
 #if SPG_DIR_READ2
         if (dup) {  // equal keys in the order the reference enumerates the products: the run sums below then add in its order
-          const int me = 4 * lt + u;
+          const int me = u < 4 ? 4 * lt + u : 256 + lt;
           for (int j = e0; j < e1; ++j) {
             const int k0 = tkeys[j];
             rank[u] += (int) (k0 < col[u]) + (int) ((k0 == col[u]) & ((int) tenum[j] < me));
@@ -1249,7 +1279,7 @@ __global__ __launch_bounds__(256) void spg_direct_kernel(
       // the reference's sequence of += on one accumulator, multiply_impl / spgemm_gustavsons.hpp:30-41) and moves
       // to position (number of runs before it); every lane works its four elements out in registers before anything is
       // written back
-      const int n = n_prod, e = 4 * lt;
+      const int n = n_prod, e = U * lt;  // (U consecutive elements per lane: 4, or 5 with an addend)
       int k[U], o[U];
       T sv[U];
       bool head[U];
@@ -1299,6 +1329,11 @@ __global__ __launch_bounds__(256) void spg_direct_kernel(
             c_values[out0 + e + u] = tvals[e + u];
           }
       }
+      if constexpr (ADD)  // elements 256 .. 319: one per lane
+        if (256 + lt < dlen) {
+          c_colind[out0 + 256 + lt] = tkeys[256 + lt];
+          c_values[out0 + 256 + lt] = tvals[256 + lt];
+        }
     }
     spg_team_sync<64>();  // (the next row's keys go into the same array)
     b0 = b1;
@@ -1307,6 +1342,9 @@ __global__ __launch_bounds__(256) void spg_direct_kernel(
     d0 = d1;
     d1 = d2;
     d2 = d3;
+    e0d = e1d;
+    e1d = e2d;
+    e2d = e3d;
     i += stride;
   }
 }
@@ -1315,14 +1353,19 @@ __global__ __launch_bounds__(256) void spg_direct_kernel(
 // columns of a row are its products minus the keys that have an equal key at a lower position of their bucket.
 // row_nnz[row] = distinct columns; flag[i] = 1 when every product has a column of its own (the row is direct).  The LDS
 // hash of spg_hash_kernel<.., false> was VALU-bound on these rows (308 vector instructions per row, 90 % busy).
+// ADD (round 6): the row of an addend joins the products, one entry per lane (<= 64: the classification), as a fifth key.
+template <bool ADD>
 __global__ __launch_bounds__(256) void spg_sort_symbolic_kernel(int n_rows, const int32_t* __restrict__ rows,
                                                                 const int32_t* __restrict__ a_rowptr,
                                                                 const int2* __restrict__ adesc,
                                                                 const int32_t* __restrict__ b_colind,
                                                                 int32_t* __restrict__ row_nnz, int32_t* __restrict__ flag,
-                                                                int sub, unsigned bucket_mul) {
+                                                                int sub, unsigned bucket_mul,
+                                                                const int32_t* __restrict__ d_rowptr,
+                                                                const int32_t* __restrict__ d_colind) {
   constexpr int NBK = SPG_DIR_NBK, BPL = NBK / 64;
-  __shared__ __attribute__((aligned(16))) int s_keys[4][256 + 4];
+  constexpr int CAP = ADD ? 320 : 256;
+  __shared__ __attribute__((aligned(16))) int s_keys[4][CAP + 4];
   __shared__ __attribute__((aligned(16))) int s_bcnt[4][NBK + 4];
   const int wave = threadIdx.x >> 6, lt = threadIdx.x & 63;
   int* tkeys = s_keys[wave];
@@ -1331,9 +1374,9 @@ __global__ __launch_bounds__(256) void spg_sort_symbolic_kernel(int n_rows, cons
   const int jr = lt >> lshift, c4 = (lt & ((1 << lshift) - 1)) * 4;
   const int stride = (int) gridDim.x * 4;
   int i = __builtin_amdgcn_readfirstlane((int) blockIdx.x * 4 + wave);
-  constexpr int U = 4;
+  constexpr int U = ADD ? 5 : 4;
   struct rdesc {
-    int row, p0, na;
+    int row, p0, na, dp0, dn;
   };
   struct arow {
     int qb, len;
@@ -1341,13 +1384,18 @@ __global__ __launch_bounds__(256) void spg_sort_symbolic_kernel(int n_rows, cons
   struct brow {
     spg_i4u cc;
     int n;
+    int dc;  // ADD: the lane's column of the addend's row (-1: none)
   };
   auto load_row = [&](int r) { return r < n_rows ? rows[r] : -1; };
   auto load_rp = [&](int row) {
-    rdesc d{row, 0, 0};
+    rdesc d{row, 0, 0, 0, 0};
     if (row >= 0) {
       d.p0 = a_rowptr[row];
       d.na = a_rowptr[row + 1] - d.p0;
+      if constexpr (ADD) {
+        d.dp0 = d_rowptr[row];
+        d.dn = d_rowptr[row + 1] - d.dp0;
+      }
     }
     return d;
   };
@@ -1360,17 +1408,22 @@ __global__ __launch_bounds__(256) void spg_sort_symbolic_kernel(int n_rows, cons
     }
     return a;
   };
-  auto load_b = [&](const arow& a, int na) {
+  auto load_b = [&](const arow& a, const rdesc& d) {
+    const int na = d.na;
     brow b;
     const int q0 = __shfl(a.qb, jr, 64) + c4, ln = __shfl(a.len, jr, 64) - c4;
     b.n = jr < na ? (ln < 0 ? 0 : ln > 4 ? 4 : ln) : 0;
     b.cc = *reinterpret_cast<const spg_i4u*>(b_colind + (b.n > 0 ? q0 : 0));
+    b.dc = -1;
+    if constexpr (ADD)
+      if (lt < d.dn)
+        b.dc = d_colind[d.dp0 + lt];
     return b;
   };
   int r3 = load_row(i + 3 * stride);
   rdesc d0 = load_rp(load_row(i)), d1 = load_rp(load_row(i + stride)), d2 = load_rp(load_row(i + 2 * stride));
   arow a0 = load_a(d0), a1 = load_a(d1);
-  brow b0 = load_b(a0, d0.na);
+  brow b0 = load_b(a0, d0);
   auto zero_buckets = [&]() {
 #pragma unroll
     for (int j = 0; j < BPL; ++j)
@@ -1382,14 +1435,14 @@ __global__ __launch_bounds__(256) void spg_sort_symbolic_kernel(int n_rows, cons
   spg_team_sync<64>();
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): as in spg_direct_kernel
   while (i < n_rows) {
-    const brow b1 = load_b(a1, d1.na);
+    const brow b1 = load_b(a1, d1);
     const arow a2 = load_a(d2);
     const rdesc d3 = load_rp(r3);
     const int r4 = load_row(i + 4 * stride);
     int col[U], bk[U], ai[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      col[u] = u < b0.n ? b0.cc[u] : -1;
+      col[u] = u < 4 ? (u < b0.n ? b0.cc[u & 3] : -1) : b0.dc;
       bk[u] = col[u] >= 0 ? (int) __umulhi((unsigned) col[u], bucket_mul) : 0;
       ai[u] = col[u] >= 0 ? atomicAdd(&bcnt[bk[u]], 1) : 0;
     }
@@ -1506,7 +1559,7 @@ static int run_bins(spblas_gfx950_handle_t h, spblas_gfx950_spgemm_s* st, const 
     return rc;
   // bin 2: a wave per row for the numeric pass (its rank sort works on TPR buckets: 32-lane teams take 3.2 instead of
   // 2.1 ms at cfg5), two rows per wave for the symbolic one (0.61 -> 0.56 ms: more rows' loads in flight)
-  if (NUMERIC && skip_upto < 2 && st->dir_desc && !st->d_rowptr && st->b_rowptr && st->r_adesc) {
+  if (NUMERIC && skip_upto < 2 && st->dir_desc && (!st->d_rowptr || st->dir_ddesc) && st->b_rowptr && st->r_adesc) {
     if constexpr (NUMERIC) {
       if (st->n_dir > 0) {
         // fp32 with enough direct rows: one pass interleaves B's columns and values (3 ps per entry of B against ~30 ps
@@ -1533,9 +1586,18 @@ static int run_bins(spblas_gfx950_handle_t h, spblas_gfx950_spgemm_s* st, const 
         auto launch = [&](auto kern, int64_t g, int64_t first, int64_t cnt) {
           if (cnt > 0)
             hipLaunchKernelGGL(kern, dim3((unsigned) g), dim3(256), 0, s, (int) cnt, st->dir_desc + first, st->r_adesc, a_values,
-                               st->b_colind, b_values, c_colind, c_values, alpha, sub_k, bmul, st->b_pack);
+                               st->b_colind, b_values, c_colind, c_values, alpha, sub_k, bmul, st->b_pack,
+                               st->dir_ddesc ? st->dir_ddesc + first : nullptr, st->d_colind, d_values, beta);
         };
-        if (packed) {
+        if (st->d_rowptr) {  // with an addend: its row is a fifth element per lane
+          if (packed) {
+            launch(spg_direct_kernel<T, true, false, true>, wgs1, 0, st->n_nodup);
+            launch(spg_direct_kernel<T, true, true, true>, wgs2, st->n_nodup, n_dup);
+          } else {
+            launch(spg_direct_kernel<T, false, false, true>, wgs1, 0, st->n_nodup);
+            launch(spg_direct_kernel<T, false, true, true>, wgs2, st->n_nodup, n_dup);
+          }
+        } else if (packed) {
           launch(spg_direct_kernel<T, true, false>, wgs1, 0, st->n_nodup);
           launch(spg_direct_kernel<T, true, true>, wgs2, st->n_nodup, n_dup);
         } else {
@@ -1559,9 +1621,15 @@ static int run_bins(spblas_gfx950_handle_t h, spblas_gfx950_spgemm_s* st, const 
         return rc;
     }
     const int64_t wgs = std::min<int64_t>(cdiv(st->n_sortable, 4), (int64_t) h->num_cus * 8);
-    hipLaunchKernelGGL(spg_sort_symbolic_kernel, dim3((unsigned) wgs), dim3(256), 0, s, (int) st->n_sortable,
-                       st->perm + st->bin_off[3] - st->n_sortable, st->a_rowptr, st->r_adesc, st->b_colind, c_rowptr,
-                       st->sym_flag, st->sub < 64 ? st->sub : 64, spg_bucket_mul(SPG_DIR_NBK, st->n));
+    if (st->d_rowptr)
+      hipLaunchKernelGGL(spg_sort_symbolic_kernel<true>, dim3((unsigned) wgs), dim3(256), 0, s, (int) st->n_sortable,
+                         st->perm + st->bin_off[3] - st->n_sortable, st->a_rowptr, st->r_adesc, st->b_colind, c_rowptr,
+                         st->sym_flag, st->sub < 64 ? st->sub : 64, spg_bucket_mul(SPG_DIR_NBK, st->n), st->d_rowptr,
+                         st->d_colind);
+    else
+      hipLaunchKernelGGL(spg_sort_symbolic_kernel<false>, dim3((unsigned) wgs), dim3(256), 0, s, (int) st->n_sortable,
+                         st->perm + st->bin_off[3] - st->n_sortable, st->a_rowptr, st->r_adesc, st->b_colind, c_rowptr,
+                         st->sym_flag, st->sub < 64 ? st->sub : 64, spg_bucket_mul(SPG_DIR_NBK, st->n), nullptr, nullptr);
     SPB_HIP(hipGetLastError());
   } else if (skip_upto < 2 &&
              (rc = launch_hash<T, 9, NUMERIC ? 64 : 32, NUMERIC>(s, st, 2, a_values, b_values, c_rowptr, c_colind,
@@ -1708,7 +1776,10 @@ static int spgemm_numeric_typed(spblas_gfx950_handle_t h, spblas_gfx950_spgemm_s
   // the first fill of a symbolic result stays a plain hash pass; a second one shows that the structure is being
   // reused and records the ranks (hash pass + 1.3 ms once at cfg5), the third and later ones take the rank path
   const char* env = std::getenv("SPBLAS_GFX950_SPGEMM_REUSE");
-  const bool want = !(env && env[0] == '0') && ++st->numeric_calls >= (env && env[0] == '2' ? 1 : 2);
+  // (sortable rows with an addend may hold up to 320 entries in bin 2's range of perm[], whose rank path has 256 slots per
+  // row: such a result keeps the sort-based fill, which costs what a first fill costs)
+  const bool want = !(env && env[0] == '0') && ++st->numeric_calls >= (env && env[0] == '2' ? 1 : 2) &&
+                    !(st->d_rowptr && st->n_sortable > 0);
   const int64_t small_rows = st->bin_off[4] - st->bin_off[1];  // bins 1-3
   if (!want || small_rows == 0 || st->m == 0)
     return SPBLAS_GFX950_STATUS_SUCCESS;
@@ -1772,6 +1843,8 @@ static void spgemm_release(spblas_gfx950_spgemm_s* st, hipStream_t s) {
   dev_free(st->r_adesc, s);
   st->r_adesc = nullptr;
   dev_free(st->dir_desc, s);
+  dev_free(st->dir_ddesc, s);
+  st->dir_ddesc = nullptr;
   dev_free(st->dir_rest, s);
   dev_free(st->b_pack, s);
   st->dir_desc = nullptr;
@@ -1911,7 +1984,9 @@ static int spgemm_symbolic_impl(spblas_gfx950_handle_t handle, spblas_gfx950_spg
     const char* ev = std::getenv("SPBLAS_GFX950_SPG_DIRECT");
     return ev ? std::atoi(ev) : 1;
   }();
-  const int sortable_ok = dir_env != 0 && !identity_b && b_rowptr && st->r_adesc && !st->d_rowptr && b_nnz >= 4;
+  const int sortable_ok = dir_env != 0 && !identity_b && b_rowptr && st->r_adesc && b_nnz >= 4 &&
+                          (!st->d_rowptr || std::getenv("SPBLAS_GFX950_SPG_DIRECT_ADD") == nullptr ||
+                           std::atoi(std::getenv("SPBLAS_GFX950_SPG_DIRECT_ADD")) != 0);
   hipLaunchKernelGGL(spg_bound_kernel, dim3((unsigned) bound_wgs), dim3(256), 0, s, m, a_rowptr, a_colind,
                      b_rowptr, st->d_rowptr, st->r_adesc, bin_of_row, d_cnt, st->sub < 64 ? st->sub : 64, b_nnz, sortable_ok,
                      st->r_adesc);
@@ -1958,10 +2033,13 @@ static int spgemm_symbolic_impl(spblas_gfx950_handle_t handle, spblas_gfx950_spg
     const int64_t c2 = st->bin_off[3] - st->bin_off[2], ns = st->n_sortable, n_other = c2 - ns;
     bool classify = e == hipSuccess && ns > 0 && st->sym_flag && ns <= INT32_MAX - 16;
     if (classify && (dev_alloc((void**) &st->dir_desc, (size_t) ns * sizeof(int4), s) != SPBLAS_GFX950_STATUS_SUCCESS ||
+                     (st->d_rowptr && dev_alloc((void**) &st->dir_ddesc, (size_t) ns * sizeof(int2), s) != SPBLAS_GFX950_STATUS_SUCCESS) ||
                      (n_other > 0 && dev_alloc((void**) &st->dir_rest, (size_t) n_other * 4, s) != SPBLAS_GFX950_STATUS_SUCCESS))) {
       dev_free(st->dir_desc, s);
+      dev_free(st->dir_ddesc, s);
       dev_free(st->dir_rest, s);
       st->dir_desc = nullptr;
+      st->dir_ddesc = nullptr;
       st->dir_rest = nullptr;
       classify = false;  // out of memory for the optional lists: every row hashes
     }
@@ -1972,7 +2050,8 @@ static int spgemm_symbolic_impl(spblas_gfx950_handle_t handle, spblas_gfx950_spg
       // (the scan's partial sums reuse `partials`: the copy of the total above is ordered before these kernels)
       long long* n_nodup_dev = scan_counts_i32(s, ns, st->sym_flag, partials);
       hipLaunchKernelGGL(spg_direct_lists_kernel, dim3((unsigned) cdiv(ns, 256)), dim3(256), 0, s, ns,
-                         st->perm + st->bin_off[3] - ns, a_rowptr, st->rowptr, st->sym_flag, st->dir_desc);
+                         st->perm + st->bin_off[3] - ns, a_rowptr, st->rowptr, st->sym_flag, st->dir_desc, st->d_rowptr,
+                         st->dir_ddesc);
       if (e == hipSuccess && (rc = readback_add(handle, &n_nodup, n_nodup_dev, sizeof(n_nodup))))
         return rc;
     }

@@ -864,8 +864,10 @@ int spblas_gfx950_spmv_reduce_rows_bcast(spblas_gfx950_handle_t handle, spblas_g
   bcast_wait_disarm disarm{handle};
   if (!plan || !alpha || !y_peers)
     return SPBLAS_GFX950_STATUS_INVALID_POINTER;
-  // (a plan made without the snapshot opt-in must take A's values of THIS call: these entry points are not given them)
-  if (plan->alg != SPBLAS_GFX950_SPMV_SLICED || plan->refresh_each_call)
+  // (a plan made without the snapshot opt-in must take A's values of THIS call: these entry points are not given them.  A
+  // value-free plan holds no copy that could go stale: it reads the array registered with the plan -- plan_create, the last
+  // spblas_gfx950_spmv, plan_update_values -- as it is when the step runs, which is the same promise.  Round 6.)
+  if (plan->alg != SPBLAS_GFX950_SPMV_SLICED || (plan->refresh_each_call && !plan->vfree))
     return SPBLAS_GFX950_STATUS_NOT_SUPPORTED;
   if (n_peers < 1 || y_row_offset < 0 || row_begin < 0 || row_end > plan->m || row_begin > row_end)
     return SPBLAS_GFX950_STATUS_INVALID_SIZE;
@@ -888,7 +890,7 @@ int spblas_gfx950_spmv_step_bcast(spblas_gfx950_handle_t handle, spblas_gfx950_p
   bcast_wait_disarm disarm{handle};
   if (!plan || !alpha || !x || !y_peers)
     return SPBLAS_GFX950_STATUS_INVALID_POINTER;
-  if (plan->alg != SPBLAS_GFX950_SPMV_SLICED || plan->refresh_each_call)  // (as above: no values of this call here)
+  if (plan->alg != SPBLAS_GFX950_SPMV_SLICED || (plan->refresh_each_call && !plan->vfree))  // (as above)
     return SPBLAS_GFX950_STATUS_NOT_SUPPORTED;
   if (n_peers < 1 || y_row_offset < 0 || stripes < 1)
     return SPBLAS_GFX950_STATUS_INVALID_SIZE;

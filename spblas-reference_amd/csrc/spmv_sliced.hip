@@ -1849,7 +1849,8 @@ __global__ __launch_bounds__(NW * 64) void pb_reduce_vf_kernel(int64_t m, int Hw
                                                                const typename pb_hdr<T>::type* __restrict__ s_hdr,
                                                                const unsigned* __restrict__ exc_idx,
                                                                const uint16_t* __restrict__ exc_row,
-                                                               const int32_t* __restrict__ exc_cnt, int exc_cap) {
+                                                               const int32_t* __restrict__ exc_cnt, int exc_cap,
+                                                               T* const* __restrict__ peers, int n_peers, int64_t peer_off) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   T* win = reinterpret_cast<T*>(smem);                      // [win_cap] the bin's window of the caller's values
@@ -2023,7 +2024,14 @@ __global__ __launch_bounds__(NW * 64) void pb_reduce_vf_kernel(int64_t m, int Hw
       for (int u = 0; u < 4; ++u) {
         const int i = i0 + u * NW * 64;
         if (i < rh) {
-          y[r0 + i] = beta == T(0) ? sum[u] : sum[u] + beta * y[r0 + i];
+          if (peers) {
+            // fused all-gather (round 6: value-free plans too): local row r is row peer_off + r of the full y, stored into
+            // every rank's copy -- the local buffer and the IPC-mapped ones, those over xGMI.  beta = 0 by contract.
+            for (int p = 0; p < n_peers; ++p)
+              peers[p][peer_off + r0 + i] = sum[u];
+          } else {
+            y[r0 + i] = beta == T(0) ? sum[u] : sum[u] + beta * y[r0 + i];
+          }
 #pragma unroll
           for (int w = 0; w < NW; ++w)
             acc0[(size_t) w * (Hw + 64) + i] = T(0);
@@ -3499,8 +3507,8 @@ static int sliced_reduce_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* p
   if (h->max_ksplit > 0 && K > h->max_ksplit)
     K = (int) h->max_ksplit;  // striped callers run several reduces side by side
   if (pl->vfree) {
-    if (peers_p)
-      return SPBLAS_GFX950_STATUS_NOT_SUPPORTED;  // value-free tiles: single-device multiplies only
+    // (the multi-GPU steps are not handed A's values: a value-free plan multiplies with the array registered at plan_create,
+    // the last spblas_gfx950_spmv or plan_update_values -- its contents at the time of the step)
     if (!pl->values_ptr)
       return SPBLAS_GFX950_STATUS_INVALID_VALUE;
     K = 1;
@@ -3566,8 +3574,9 @@ static int sliced_reduce_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* p
     int UBv = env_int("SPBLAS_GFX950_PB_RBATCH", pl->enc8 ? 2 : 4);
     if (UBv != 2)
       UBv = 4;
+    T* const* peers = reinterpret_cast<T* const*>(peers_p);
     void* args[] = {&mm, &Hw, &wb_begin, &wb_end, &binblk, &Pp, &rowp, &srcp, &vals, &rp, &o64, &yp, &a, &b, &cap, &hdr,
-                    &exc_idx, &exc_row, &exc_cnt, &exc_cap};
+                    &exc_idx, &exc_row, &exc_cnt, &exc_cap, &peers, &n_peers, &peer_off};
     const size_t lds = ((size_t) cap + (size_t) pl->vf_waves * (Hw + 64)) * sizeof(T);
     // persistent: one workgroup per CU walks the bins (SPBLAS_GFX950_PB_VF_GRID: test / experiment hook)
     int64_t grid = env_int("SPBLAS_GFX950_PB_VF_GRID", h->num_cus > 0 ? h->num_cus : 256);

@@ -428,10 +428,15 @@ class FusedShardedSpMV:
                                                                            y_probe, **kw)
             if not isinstance(self.info.state_, api._Plan) or self.info.state_.info()["alg"] != api._capi.SPMV_SLICED:
                 raise RuntimeError("FusedShardedSpMV needs a SLICED local plan")
-            if self.info.state_.sliced_info().get("refresh_each_call"):
-                # (a plan made from a plain inspected csr_view must read A's values of every call; the fused entry
-                # points are not given them -- they would multiply with the inspect-time copy, or have none at all)
-                raise RuntimeError("FusedShardedSpMV needs a plan that owns its values: inspect matrix_opt(a_local)")
+            si_ = self.info.state_.sliced_info()
+            if si_.get("refresh_each_call") and not si_.get("value_free"):
+                # (a plan made from a plain inspected csr_view must read A's values of every call; the fused entry points are
+                # not given them.  A VALUE-FREE plan -- what such an operand gets at this size since round 5 -- holds no copy
+                # that could go stale: its reduce reads the caller's array through the pointer registered with the plan, as it
+                # is when the step runs (round 6: that kernel has the broadcast epilogue too).  Only the copying form is left out.)
+                raise RuntimeError("FusedShardedSpMV needs a plan that owns its values or reads the caller's: inspect "
+                                   "matrix_opt(a_local) or a matrix large enough for value-free tiles")
+            self.value_free = bool(si_.get("value_free"))
             # buffers: two copies of y, one flag array (slot q = last step signalled by rank q)
             self.chunks = max(0, int(chunks))
             if self.world * max(self.chunks, 1) > 64:

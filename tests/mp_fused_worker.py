@@ -55,6 +55,34 @@ def main():
     dist.all_gather_object(gathered, outs[0].tobytes())
     assert all(gb == gathered[0] for gb in gathered), "ranks hold different y"
     op.close()
+    if os.environ.get("FUSED_VFREE"):
+        # Round 6: the fused exchange on a VALUE-FREE local plan (what a plain inspected csr_view gets at cfg2's size; forced here
+        # through the test hooks).  The plan holds no copy of A's values: every step multiplies with the caller's array as it is
+        # THEN -- so values rewritten in place between two steps must show in every rank's copy of y, with no update call.
+        os.environ["SPBLAS_GFX950_PB_VFREE"] = "2"
+        os.environ["SPBLAS_GFX950_PB_VF_ROWS"] = "500"
+        y_loc = torch.empty(bounds[rank + 1] - bounds[rank], dtype=dtype, device=dev)
+        info_vf = sp.multiply_inspect(a_loc, x, y_loc, alg=sp._capi.SPMV_SLICED)
+        del os.environ["SPBLAS_GFX950_PB_VFREE"], os.environ["SPBLAS_GFX950_PB_VF_ROWS"]
+        assert info_vf.state_.sliced_info()["value_free"] == 1
+        saved_vals = a_loc.values().clone()
+        op_vf = sharded.FusedShardedSpMV(a_loc, bounds, info=info_vf, timeout_ms=5000, stripes=stripes)
+        assert op_vf.value_free
+        for it, vscale in enumerate((1.0, -0.5, 3.0)):
+            if vscale != 1.0:
+                a_loc.values().mul_(vscale)      # in place, every rank its own rows; no update_values anywhere
+            total = float(np.prod((1.0, -0.5, 3.0)[:it + 1]))
+            y = op_vf.step(x)
+            torch.cuda.synchronize()
+            op_vf.check_status()
+            err = np.abs(y.cpu().numpy().astype(np.float64) - total * ref.astype(np.float64))
+            assert (err <= tol * abs(total) * absrow + 1e-30).all(), f"rank {rank} value-free step {it}: parity failed"
+        gathered = [None] * world
+        dist.all_gather_object(gathered, y.cpu().numpy().tobytes())
+        assert all(gb == gathered[0] for gb in gathered), "value-free plans: ranks hold different y"
+        a_loc.values().copy_(saved_vals)                 # (bit-exact restore: the rest of the worker compares bits)
+        op_vf.close()
+        print("FUSED_VFREE_OK", flush=True)
     # the selection helper bench.py uses: adopted only when bit-identical to a reference path on every rank
     plans = []
     for q in range(world):

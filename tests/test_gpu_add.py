@@ -214,6 +214,49 @@ def test_spgemm_4args_numeric_reuse_and_mismatch(gpu):
         sp.multiply_compute(state, d_a, d_b, d_c, d_a)
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("n_cols,d_max", [(40000, 16), (900, 64), (40000, 70)])
+def test_spgemm_4args_sorted_rows_take_the_addend_as_a_fifth_element(gpu, dtype, n_cols, d_max, monkeypatch):
+    """Round 6: rows whose products a wavefront sorts in registers (<= 256 products, A row in one round of loads: cfg5's shape)
+    keep that path when an addend is present -- its row joins as a fifth element per lane, up to 320 entries per row -- instead
+    of falling to the hash of the next bin (cfg5 + D: 6.3 -> 1.0 ms per fill).  16 x 16 products exactly fill the 256 slots;
+    n_cols = 900 makes products and addend entries share columns (the duplicate-summing variant, enumeration order:
+    products, then the addend); d_max = 70 puts some addend rows beyond one entry per lane (those rows must hash); ragged A
+    rows and empty addend rows included.  Structure exact, values norm-wise, against the oracle; then a second fill with new
+    values (which must NOT switch to the rank path: its per-row capacity is 256)."""
+    rng = np.random.default_rng(61)
+    m, k = 3000, 5000
+
+    def csr(rows, cols, lens, seed):
+        r = np.random.default_rng(seed)
+        rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        ci = np.concatenate([r.choice(cols, l, replace=False) for l in lens] + [np.zeros(0, np.int64)]).astype(np.int32)
+        return (r.random(len(ci)) - 0.5).astype(dtype), rp, ci, (rows, cols)
+
+    a_len = np.full(m, 16)
+    a_len[::7] = rng.integers(1, 16, len(a_len[::7]))
+    d_len = rng.integers(0, d_max + 1, m)
+    d_len[::5] = 0
+    a_h, b_h, d_h = csr(m, k, a_len, 1), csr(k, n_cols, np.full(k, 16), 2), csr(m, n_cols, d_len, 3)
+    new = tuple((np.random.default_rng(9 + i).random(len(x[0])) - 0.5).astype(dtype) for i, x in enumerate((a_h, b_h, d_h)))
+    first, second = device_spgemm4(a_h, b_h, d_h, sa=1.5, sd=-0.5, reuse_values=new)
+    check_spgemm4(a_h, b_h, d_h, first, dtype, 1.5, -0.5)
+    a2, b2, d2 = ((new[i],) + t[1:] for i, t in enumerate((a_h, b_h, d_h)))
+    check_spgemm4(a2, b2, d2, second, dtype, 1.5, -0.5)
+    # the state says which rows took the sort-based kernel
+    d_a, d_b, d_d = (G.csr_on_device(v, r, c, s_, len(v)) for v, r, c, s_ in (a_h, b_h, d_h))
+    rp = torch.zeros(m + 1, dtype=torch.int32, device="cuda")
+    state = sp.spgemm_state_t()
+    sp.multiply_compute(state, d_a, d_b, sp.csr_view(None, rp, None, (m, n_cols), 0), d_d)
+    info = state.info()
+    assert info["direct_rows"] >= (0.5 if d_max <= 64 else 0.3) * m, info
+    monkeypatch.setenv("SPBLAS_GFX950_SPG_DIRECT_ADD", "0")      # the hash path of round 5 gives the same structure
+    state0 = sp.spgemm_state_t()
+    rp0 = torch.zeros(m + 1, dtype=torch.int32, device="cuda")
+    sp.multiply_compute(state0, d_a, d_b, sp.csr_view(None, rp0, None, (m, n_cols), 0), d_d)
+    assert state0.info()["direct_rows"] == 0 and torch.equal(rp, rp0)
+
+
 def test_spgemm_4args_all_bins(gpu):
     """Rows of every accumulator size (empty, 128/512/2048/8192-slot hash, dense bitmap) with an addend
     that alone decides the bin for some rows."""

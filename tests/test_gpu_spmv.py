@@ -1059,10 +1059,21 @@ def test_spmv_value_free_tiles(gpu, monkeypatch, dtype, offsets, waves, enc):
         y_ref = -1.5 * oracle.spmv((m, n), rp32, colind, v2, x).astype(np.float64) + 0.25 * y0
         util.assert_parity(G.host(y), y_ref, 1.5 * absrow + 0.25 * np.abs(y0), dtype, row_len=np.diff(rp32) + 1,
                            what="value-free tiles alpha / beta")
-        # the multi-GPU entry points are not given A's values: a plan that must read them on every call refuses
-        peers = (ctypes.c_void_p * 1)(y.data_ptr())
-        rc = _capi.lib().spblas_gfx950_spmv_step_bcast(hd.h, info.state_.plan, ctypes.byref(al), sp.api._ptr(xd), peers, 1, 0, 1)
-        assert rc == _capi.NOT_SUPPORTED
+        # the multi-GPU step (round 6: value-free plans are accepted -- the reduce has the broadcast epilogue and reads the
+        # value array registered with the plan as it is when the step runs): one "rank", two copies of y as the peers, rows
+        # at an offset; values rewritten in place once more before the step
+        raw.data.mul_(0.5).sub_(0.125)
+        v3 = (v2 * dtype(0.5) - dtype(0.125)).astype(dtype)
+        big = torch.full((2, m + 7), float("nan"), dtype=tdt, device="cuda")
+        tab = torch.tensor([big[0].data_ptr(), big[1].data_ptr()], dtype=torch.int64, device="cuda")
+        rc = _capi.lib().spblas_gfx950_spmv_step_bcast(hd.h, info.state_.plan, ctypes.byref(al), sp.api._ptr(xd),
+                                                       ctypes.c_void_p(tab.data_ptr()), 2, 7, 1)
+        assert rc == _capi.SUCCESS, rc
+        torch.cuda.synchronize()
+        assert bool(torch.isnan(big[:, :7]).all()) and torch.equal(big[0, 7:], big[1, 7:])
+        _, absrow3 = util.spmv_exact(rp32, colind, v3, x)
+        util.assert_parity(G.host(big[0, 7:]), -1.5 * oracle.spmv((m, n), rp32, colind, v3, x).astype(np.float64), 1.5 * absrow3,
+                           dtype, row_len=np.diff(rp32), what="value-free tiles, fused broadcast step")
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
