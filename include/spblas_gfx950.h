@@ -445,6 +445,15 @@ int spblas_gfx950_sptrsv_solve(spblas_gfx950_handle_t handle, spblas_gfx950_trsv
  * SpMV plan holds a snapshot of the values: refresh it with spblas_gfx950_spmv_plan_update_values. */
 int spblas_gfx950_scale(spblas_gfx950_handle_t handle, int64_t n, const void* alpha, void* values, int value_type);
 
+/* ---- 64-bit indices ---------------------------------------------------------------------- */
+/* The kernels of this library take int32 column (row) indices; the slot it replaces also admits int64 ones
+ * (vendor/rocsparse/types.hpp:16-24: rocsparse_indextype_i64).  dst[i] = (int32) src[i] for count device elements;
+ * STATUS_INVALID_VALUE when an index lies outside [0, bound) (bound <= 2^31 - 1: the number of columns), in which case
+ * dst is not to be used.  Inspect-class: it synchronises the handle's stream (STATUS_NOT_SUPPORTED inside a capture).
+ * The host layers call it once per index array (multiply_inspect, or the first multiply) and keep the narrowed copy. */
+int spblas_gfx950_narrow_indices(spblas_gfx950_handle_t handle, int64_t count, const int64_t* src, int32_t* dst,
+                                 int64_t bound);
+
 /* ---- transpose:  B = A^T  (CSR -> CSR, int32 indices) ------------------------------------ */
 /* Device counterpart of transpose(a, b) (algorithms/transpose_impl.hpp:14-53): stable counting
  * sort by column, so every output row lists its entries in source order.  t_rowptr has n+1

@@ -69,6 +69,7 @@ PROTOTYPES = [
     ("spblas_gfx950_csr_transpose", c_int,
      [c_void_p, c_i64, c_i64, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int]),
     ("spblas_gfx950_scale", c_int, [c_void_p, c_i64, c_void_p, c_void_p, c_int]),
+    ("spblas_gfx950_narrow_indices", c_int, [c_void_p, c_i64, c_void_p, c_void_p, c_i64]),
     ("spblas_gfx950_spgemm_create", c_int, [c_void_p, ctypes.POINTER(c_void_p)]),
     ("spblas_gfx950_spgemm_destroy", c_int, [c_void_p, c_void_p]),
     ("spblas_gfx950_spgemm_info", c_int, [c_void_p, ctypes.POINTER(ctypes.c_int64)]),

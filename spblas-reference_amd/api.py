@@ -466,9 +466,39 @@ def _vtype(t, what):
     return _VT[t.dtype]
 
 
+_NARROWED = {}  # id of an int64 index tensor -> (the tensor, its int32 copy); a handful of entries, oldest dropped first
+
+
+def _int32_columns(a, what):
+    """A csr_view / csc_view whose index array is int64 -- the slot this backend replaces admits them
+    (vendor/rocsparse/types.hpp:16-24) -- as the same view over an int32 copy (spblas_gfx950_narrow_indices: ValueError if an
+    index does not fit the other dimension).  The copy is made once per index tensor and kept, so that multiply_inspect and
+    the multiplies that follow see ONE array (a plan is tied to its structure arrays); the kernels take int32 indices only.
+    SpMV and SpMM operands only (what the slot's type list admits and this backend does not)."""
+    csr = isinstance(a, csr_view)
+    idx = a.colind() if csr else a.rowind()
+    if idx is None or idx.dtype != torch.int64:
+        return a
+    hit = _NARROWED.get(id(idx))
+    if hit is None or hit[0] is not idx:
+        bound = a.shape()[1] if csr else a.shape()[0]
+        dst = torch.empty(idx.numel(), dtype=torch.int32, device=idx.device)
+        hd = _Handle.current(idx.device)
+        rc = _capi.lib().spblas_gfx950_narrow_indices(hd.h, a.size(), _ptr(idx), _ptr(dst), int(bound))
+        if rc == _capi.INVALID_VALUE:
+            raise ValueError(f"{what}: a 64-bit index lies outside the matrix (or beyond 2^31 - 1)")
+        check(rc, what)
+        while len(_NARROWED) >= 8:
+            _NARROWED.pop(next(iter(_NARROWED)))
+        hit = _NARROWED[id(idx)] = (idx, dst)
+    if csr:
+        return csr_view(a.values(), a.rowptr(), hit[1], a.shape(), a.size())
+    return csc_view(a.values(), a.colptr(), hit[1], a.shape(), a.size())
+
+
 def _check_csr(a, what):
     if a.colind() is not None and a.colind().dtype != torch.int32:
-        raise TypeError(f"{what}: column indices must be int32 (spblas::index_t on GPU backends)")
+        raise TypeError(f"{what}: column indices must be int32 (spblas::index_t on GPU backends; SpMV / SpMM also take int64)")
     if a.rowptr().dtype not in _OT:
         raise TypeError(f"{what}: row offsets must be int32 or int64")
     for t in (a.values(), a.rowptr(), a.colind()):
@@ -633,6 +663,7 @@ def _find_plan(info, a, a_base):
 # --------------------------------------------------------------------------- SpMV / SpMM
 def _spmv(info, a, b, c, prepare_only=False):
     a_base, b_base = get_ultimate_base(a), get_ultimate_base(b)
+    a_base = _int32_columns(a_base, "multiply")
     _reject_conjugated(a, b, c)
     if not _is_tensor(c) or c.dim() != 1:
         raise TypeError("multiply: the output vector must be a plain 1-D device tensor")
@@ -703,6 +734,7 @@ class prepared_multiply:
 
 def _spmm(info, a, b, c):
     a_base, b_base = get_ultimate_base(a), get_ultimate_base(b)
+    a_base = _int32_columns(a_base, "multiply")
     _reject_conjugated(a, b, c)
     plan = None
     if isinstance(a_base, csc_view):
@@ -804,6 +836,8 @@ def multiply_inspect(*args, alg=_capi.SPMV_AUTO, values_will_change=False):
         return None  # vendor/rocsparse/multiply_spgemm.hpp:232-235: no-op
     a_base = get_ultimate_base(a)
     _reject_conjugated(a, b, c)
+    if isinstance(a_base, (csr_view, csc_view)) and not _is_sparse(b) and a_base.values() is not None:
+        a_base = _int32_columns(a_base, "multiply_inspect")
     if isinstance(a_base, csr_view) and not _is_sparse(b) and a_base.values() is not None:
         _check_csr(a_base, "multiply_inspect")
         # the column-sliced plan serves SpMV only; SpMM uses the row partition (spmm_impl.hpp of the C++ layer)

@@ -475,6 +475,55 @@ extern "C" int spblas_gfx950_csr_transpose(spblas_gfx950_handle_t handle, int64_
                                  t_colind, static_cast<double*>(t_values));
 }
 
+// dst[i] = (int32) src[i]; *bad is raised when an index does not fit [0, bound)
+__global__ __launch_bounds__(256) void spt_narrow_kernel(int64_t n, const int64_t* __restrict__ src, int32_t* __restrict__ dst,
+                                                         int64_t bound, int* __restrict__ bad) {
+  bool off = false;
+  for (int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t) gridDim.x * 256) {
+    const int64_t v = src[i];
+    off |= v < 0 || v >= bound;
+    dst[i] = (int32_t) v;
+  }
+  if (__ballot(off) != 0ull && (threadIdx.x & 63) == 0)
+    atomicOr(bad, 1);
+}
+
+// 64-bit column (row) indices of a view -- the rocSPARSE slot admits them (vendor/rocsparse/types.hpp:16-24) -- narrowed into
+// a 32-bit array the kernels of this library take; inspect-class (it answers on the host whether every index fitted).
+extern "C" int spblas_gfx950_narrow_indices(spblas_gfx950_handle_t handle, int64_t count, const int64_t* src, int32_t* dst,
+                                            int64_t bound) {
+  if (!handle)
+    return SPBLAS_GFX950_STATUS_INVALID_HANDLE;
+  if (stream_capturing(handle->stream))
+    return SPBLAS_GFX950_STATUS_NOT_SUPPORTED;
+  if (count < 0 || bound < 0 || bound > (int64_t) INT32_MAX)
+    return SPBLAS_GFX950_STATUS_INVALID_SIZE;
+  if (count > 0 && (!src || !dst))
+    return SPBLAS_GFX950_STATUS_INVALID_POINTER;
+  if (count == 0)
+    return SPBLAS_GFX950_STATUS_SUCCESS;
+  hipStream_t s = handle->stream;
+  int* bad = nullptr;
+  int rc = dev_alloc((void**) &bad, sizeof(int), s);
+  if (rc)
+    return rc;
+  int h_bad = 0;
+  hipError_t e = hipMemsetAsync(bad, 0, sizeof(int), s);
+  if (e == hipSuccess) {
+    int64_t blocks = cdiv(count, 1024);
+    const int64_t cap = (int64_t) (handle->num_cus > 0 ? handle->num_cus : 256) * 16;
+    blocks = blocks > cap ? cap : blocks;
+    hipLaunchKernelGGL(spt_narrow_kernel, dim3((unsigned) blocks), dim3(256), 0, s, count, src, dst, bound, bad);
+    e = hipMemcpyAsync(&h_bad, bad, sizeof(int), hipMemcpyDeviceToHost, s);
+  }
+  if (e == hipSuccess)
+    e = hipStreamSynchronize(s);
+  dev_free(bad, s);
+  if (e != hipSuccess)
+    return hip_fail(e);
+  return h_bad ? SPBLAS_GFX950_STATUS_INVALID_VALUE : SPBLAS_GFX950_STATUS_SUCCESS;
+}
+
 extern "C" int spblas_gfx950_scale(spblas_gfx950_handle_t handle, int64_t n, const void* alpha, void* values,
                                    int value_type) {
   if (!handle)

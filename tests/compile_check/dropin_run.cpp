@@ -396,6 +396,57 @@ int main() {
     expect(close64(dc.host(), wantc, scalec), "multiply(info, csr_view<double, int32, int64>, B, C)");
   }
 
+  // ---- 64-bit COLUMN indices: csr_view<float, int64, int32> / <float, int64, int64> -- the rocSPARSE slot admits them
+  //      (vendor/rocsparse/types.hpp:16-24); narrowed once per index array on the device, range-checked ----
+  {
+    using I64 = std::int64_t;
+    const I m = 7000, n = 9000;
+    const host_csr ha = random_csr(m, n, 6);
+    std::vector<I64> ci64(ha.colind.begin(), ha.colind.end());
+    std::vector<I64> rp64(ha.rowptr.begin(), ha.rowptr.end());
+    dev_array<T> dv(ha.values);
+    dev_array<O> drp(ha.rowptr);
+    dev_array<I64> drp64(rp64), dci(ci64);
+    std::vector<T> hx(n);
+    for (auto& v : hx)
+      v = next_val();
+    dev_array<T> dx(hx), dy(static_cast<std::size_t>(m));
+    std::vector<double> want, absrow;
+    host_spmv(ha, hx, 1.0, want, absrow);
+    {
+      csr_view<T, I64, O> a(dv.p, drp.p, dci.p, {static_cast<I64>(m), static_cast<I64>(n)}, static_cast<O>(ha.nnz()));
+      multiply(a, dx.span(), dy.span());
+      expect(close_vec(dy.host(), want, absrow), "multiply(csr_view<float, int64, int32>, x, y)");
+      HIP_OK(hipMemset(dy.p, 0xFF, m * sizeof(T)));
+      operation_info_t info = multiply_inspect(a, dx.span(), dy.span());
+      multiply(info, a, dx.span(), dy.span());
+      multiply(info, a, dx.span(), dy.span());
+      expect(close_vec(dy.host(), want, absrow), "multiply(info, csr_view<float, int64, int32>, x, y)");
+    }
+    {
+      csr_view<T, I64, I64> a(dv.p, drp64.p, dci.p, {static_cast<I64>(m), static_cast<I64>(n)}, static_cast<I64>(ha.nnz()));
+      HIP_OK(hipMemset(dy.p, 0xFF, m * sizeof(T)));
+      operation_info_t info = multiply_inspect(a, dx.span(), dy.span());
+      std::vector<double> want2, abs2;
+      host_spmv(ha, hx, -2.0, want2, abs2);
+      multiply(info, scaled(-2.0f, a), dx.span(), dy.span());
+      expect(close_vec(dy.host(), want2, abs2), "multiply(info, scaled(csr_view<float, int64, int64>), x, y)");
+    }
+    {
+      std::vector<I64> bad = ci64;
+      bad[bad.size() / 2] = (static_cast<I64>(1) << 32) + 5;  // would wrap to column 5
+      dev_array<I64> dbad(bad);
+      csr_view<T, I64, O> a(dv.p, drp.p, dbad.p, {static_cast<I64>(m), static_cast<I64>(n)}, static_cast<O>(ha.nnz()));
+      bool threw = false;
+      try {
+        multiply(a, dx.span(), dy.span());
+      } catch (const std::invalid_argument&) {
+        threw = true;
+      }
+      expect(threw, "a 64-bit column index outside the matrix throws std::invalid_argument");
+    }
+  }
+
   // ---- SpGEMM: multiply_compute / multiply_fill, then the symbolic / numeric split with reuse ----
   {
     const I m = 4000, k = 3000, n = 3500;

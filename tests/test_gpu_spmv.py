@@ -594,6 +594,108 @@ def test_spmv_full_size_properties_cfg2(gpu, poisson):
         util.assert_parity(y_h[chunk], y_ref, absrow, np.float32, what="cfg2 sampled rows")
 
 
+@pytest.mark.parametrize("poisson", [False, True])
+def test_spmv_full_size_plain_csr_view_reads_the_values_of_the_call_cfg2(gpu, poisson):
+    """Round 6 (review item): north_star's literal call shape at BASELINE cfg2's FULL size -- multiply_inspect on a plain
+    csr_view (no matrix_opt), AUTO -> the value-free tiles -- with the values REWRITTEN IN PLACE after inspect, twice, through a
+    raw view that moves no version counter.  Every multiply must read the caller's array of that call
+    (multiply_impl.hpp:48-52; vendor/rocsparse/detail/spmv_impl.hpp:72-77).  Checked by (1) 6 000 sampled rows (first / last
+    2 000 + random) against the oracle, (2) the fp64 checksum of all of y against sum(values * x[colind]) on the device,
+    (3) agreement with the row-block kernel on the caller's arrays, all three after EACH rewrite, and (4) that the plan holds
+    no values (value_free, no update call made anywhere)."""
+    m = n = 10_000_000
+    values, rowptr, colind, shape, nnz = generate.uniform_csr_device(m, n, 10, poisson=poisson, seed=0)
+    a = sp.csr_view(values, rowptr, colind, shape, nnz)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    x = torch.rand(n, device="cuda", generator=g)
+    y, yv = torch.empty(m, device="cuda"), torch.empty(m, device="cuda")
+    info = sp.multiply_inspect(a, x, y)
+    si = info.state_.sliced_info()
+    assert info.state_.info()["alg"] == _capi.SPMV_SLICED and si["value_free"] == 1 and si["refresh_each_call"] == 1, si
+    assert si["auto_trial"] == 0                                   # decided by rule: same plan on every box
+    info_rb = sp.multiply_inspect(a, x, yv, alg=_capi.SPMV_ROWBLOCK)
+    rp = rowptr.cpu().numpy().astype(np.int64)
+    rows = np.unique(np.concatenate([np.arange(2000), np.arange(m - 2000, m), np.random.default_rng(0).integers(0, m, 2000)]))
+    lens = rp[rows + 1] - rp[rows]
+    sub_rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    idx_t = torch.from_numpy(np.concatenate([np.arange(rp[r], rp[r + 1]) for r in rows])).cuda()
+    sub_c = colind[idx_t].cpu().numpy()
+    x_h = x.cpu().numpy()
+    rows_t = torch.from_numpy(rows).cuda()
+    raw = torch.as_strided(values, values.shape, values.stride())
+    for step, (mul, add) in enumerate(((1.0, 0.0), (-0.5, 0.125), (3.0, -1.0))):
+        raw.data.mul_(mul).add_(add)                                # in place, after inspect; no update call anywhere
+        y.fill_(float("nan"))
+        sp.multiply(info, a, x, y)
+        sp.multiply(info_rb, a, x, yv)
+        sub_v = values[idx_t].cpu().numpy()
+        y_ref = oracle.spmv((len(rows), n), sub_rp, sub_c, sub_v, x_h)
+        absrow = oracle.spmv_absrow(sub_rp, sub_c, sub_v, x_h)
+        util.assert_parity(y[rows_t].cpu().numpy(), y_ref, absrow, np.float32, row_len=lens,
+                           what=f"cfg2 plain csr_view, sampled rows, rewrite {step}")
+        prod = values.double() * x[colind.long()].double()
+        lhs, rhs, scale = y.double().sum().item(), prod.sum().item(), prod.abs().sum().item()
+        assert abs(lhs - rhs) <= 1e-6 * scale, (step, lhs, rhs)
+        absy = torch.zeros(m, dtype=torch.float64, device="cuda").index_add_(
+            0, torch.repeat_interleave(torch.arange(m, device="cuda"), (rowptr[1:] - rowptr[:-1]).long()), prod.abs())
+        assert bool(((y - yv).abs().double() <= 2e-6 * absy + 1e-30).all()), step
+        del prod, absy
+
+
+@pytest.mark.parametrize("offsets", [np.int32, np.int64])
+def test_spmv_and_spmm_take_64_bit_column_indices(gpu, offsets):
+    """Round 6 (slot type surface): the rocSPARSE slot admits 64-bit indices (vendor/rocsparse/types.hpp:16-24); a csr_view /
+    csc_view whose index array is int64 is narrowed once on the device (spblas_gfx950_narrow_indices, range-checked) and then
+    takes every SpMV / SpMM path -- plan-free, inspected (the plan must be FOUND again by the multiplies: one narrowed array
+    per index tensor), matrix_opt, op = T.  An index outside the matrix is an error, not a wrapped 32-bit value."""
+    rng = np.random.default_rng(71)
+    m, n, per = 30000, 50000, 12
+    values, rowptr, colind, shape, nnz = generate.generate_csr(m, n, m * per, seed=5)
+    x = (rng.random(n) - 0.5).astype(np.float32)
+    t = lambda a_: torch.from_numpy(np.ascontiguousarray(a_)).cuda()
+    ci64 = t(colind.astype(np.int64))
+    a = sp.csr_view(t(values), t(rowptr.astype(offsets)), ci64, shape, nnz)
+    xd = t(x)
+    y = torch.full((m,), float("nan"), device="cuda")
+    sp.multiply(a, xd, y)
+    check(values, rowptr, colind, shape, x, G.host(y), what="int64 columns, plan-free", ref_cmp=False)
+    for alg in (_capi.SPMV_ROWBLOCK, _capi.SPMV_SLICED):
+        info = sp.multiply_inspect(a, xd, y, alg=alg)
+        y.fill_(float("nan"))
+        sp.multiply(info, sp.scaled(-2.0, a), xd, y)
+        check(values, rowptr, colind, shape, x, G.host(y), scale=-2.0, what=f"int64 columns, inspected alg {alg}", ref_cmp=False)
+        assert sp.api._find_plan(info, a, sp.api._int32_columns(a, "t")) is info.state_   # the multiply used THE plan
+    a_opt = sp.matrix_opt(a)
+    info = sp.multiply_inspect(a_opt, xd, y)
+    y.fill_(float("nan"))
+    sp.multiply(a_opt, xd, y)
+    check(values, rowptr, colind, shape, x, G.host(y), what="int64 columns, matrix_opt", ref_cmp=False)
+    # SpMM
+    B = (rng.random((n, 24)) - 0.5).astype(np.float32)
+    C = torch.full((m, 24), float("nan"), device="cuda")
+    info = sp.multiply_inspect(a, t(B), C)
+    sp.multiply(info, a, t(B), C)
+    C_ref = oracle.spmm(shape, rowptr, colind, values, B)
+    C_abs = oracle.spmm(shape, rowptr, colind, np.abs(values), np.abs(B))
+    util.assert_parity(G.host(C), C_ref, C_abs, np.float32, row_len=np.diff(rowptr), what="int64 columns, SpMM")
+    # the same arrays as a csc_view (64-bit row indices): y = A^T x
+    a_csc = sp.csc_view(t(values), t(rowptr.astype(offsets)), ci64, (n, m), nnz)
+    xt = (rng.random(m) - 0.5).astype(np.float32)
+    yt = torch.full((n,), float("nan"), device="cuda")
+    sp.multiply(a_csc, t(xt), yt)
+    ref_t = oracle.spmv_csc((n, m), rowptr, colind, values, xt)
+    abs_t = oracle.spmv_csc((n, m), rowptr, colind, np.abs(values), np.abs(xt))
+    util.assert_parity(G.host(yt), ref_t, abs_t, np.float32, row_len=np.full(n, 64), what="int64 row indices, csc_view")
+    # an index that does not fit the matrix
+    bad = colind.astype(np.int64)
+    bad[12345] = (1 << 32) + 7            # would wrap to column 7
+    with pytest.raises(ValueError, match="outside the matrix"):
+        sp.multiply(sp.csr_view(t(values), t(rowptr.astype(offsets)), t(bad), shape, nnz), xd, y)
+    bad[12345] = n
+    with pytest.raises(ValueError, match="outside the matrix"):
+        sp.multiply_inspect(sp.csr_view(t(values), t(rowptr.astype(offsets)), t(bad), shape, nnz), xd, y)
+
+
 def test_spmv_two_stage_and_overlapped_sharding_single_rank(gpu):
     """expand + reduce_rows (the stage API behind the overlapped multi-GPU step) equals one spmv;
     OverlappedShardedSpMV at world size 1 exercises the stripe-aligned plan and the y-base arithmetic."""
