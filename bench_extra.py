@@ -431,7 +431,9 @@ def _run_csc_spmv(args, device, sp, oracle, generate):
                   "uninspected_kernel": "scale_vector_kernel + spmv_transpose_kernel<float,int> (float atomics into y)",
                   "inspect_ms_untimed": inspect_ms, "plan_bytes": held,
                   "plan_bytes_over_matrix": held / float(nnz * 8 + (k + 1) * 4),
-                  "kernel": "device transpose at inspect (spt_* kernels), then the CSR plan's kernels on the materialised copy"},
+                  "plan_detached_from_materialised_arrays": bool(getattr(info.state_, "detached", False)),
+                  "kernel": "device transpose at inspect (spt_* kernels), then the CSR plan's kernels (pb_expand_kernel + pb_reduce_kernel); "
+                            "the materialised row-major arrays are released once the plan is built (round 6)"},
                  cpu, parity=parity, pmc_key=None if args.rows else "csc_spmv_8f")
 
 
@@ -655,7 +657,12 @@ def _run(args, device):
             oracle.spmm((rows, m), rp, ci, v, Bh)
             dt = time.perf_counter() - t0
             cpu = {"value": 2.0 * rp[-1] * ncols / dt / 1e9, "unit": "GFLOP/s", "cores": 1, "kind": "port",
-                   "sample": f"first {rows} rows ({int(rp[-1])} nnz x {ncols} columns) of the same A and B, 1 run of oracle_spmm"}
+                   "sample": f"first {rows} rows ({int(rp[-1])} nnz x {ncols} columns) of the same A and B, 1 run of oracle_spmm",
+                   # (round-5 review: say it in the record)
+                   "note": "NOT the reference as written: the C restatement's inner loop runs over the n columns of one B row and "
+                           "the compiler vectorises it; the reference looks every element up through its mdspan accessors "
+                           "(multiply_impl.hpp:85-91) and was measured at 0.41 GFLOP/s (BASELINE.md section 2) -- as a timing proxy "
+                           "this port flatters the CPU by 10 - 75x; the values are the reference's"}
         mi = info.state_.spmm_info()
         # parity (outside the timed region): the first and last 1 500 rows and 1 500 sampled rows of the timed C against
         # oracle_spmm on the compacted sub-problem (tests/test_gpu_configs.py does the same), plus the fp64 column checksum

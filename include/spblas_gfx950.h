@@ -183,6 +183,15 @@ int spblas_gfx950_spmv_plan_create(spblas_gfx950_handle_t handle, spblas_gfx950_
                                    int value_type, int alg);
 int spblas_gfx950_spmv_plan_update_values(spblas_gfx950_handle_t handle, spblas_gfx950_plan_t plan,
                                           const void* values);
+/* The owner of a plan declares that it is about to RELEASE the arrays the plan was built from -- what a host layer does
+ * for an inspected csc_view / transposed(csr) operand, whose row-major form it materialised for the plan alone
+ * (vendor/rocsparse/detail/get_transpose.hpp:19-29 has rocSPARSE do the transposition inside the call; here it is done
+ * once, at inspect).  Succeeds only for a self-contained plan: SLICED with its own copy of the values, no hub rows, no
+ * hot-column split (STATUS_NOT_SUPPORTED otherwise: keep the arrays).  Afterwards spblas_gfx950_spmv with this plan takes
+ * rowptr = colind = values = NULL (op = N, same m / n / nnz / types), plan_update_values returns STATUS_NOT_SUPPORTED (the
+ * values changed: inspect again), spblas_gfx950_spmm does not accept the plan.  cfg2-sized transposed operand: the inspected
+ * form holds 1.43 x the matrix instead of 2.43 x. */
+int spblas_gfx950_spmv_plan_detach(spblas_gfx950_handle_t handle, spblas_gfx950_plan_t plan);
 /* A plan carries workspaces (products, partial sums): it must not run on two streams at once.  plan_destroy frees on
  * the handle's current stream, ordered behind the last launch that used the plan on whichever stream that was. */
 int spblas_gfx950_plan_destroy(spblas_gfx950_handle_t handle, spblas_gfx950_plan_t plan);

@@ -51,6 +51,7 @@ PROTOTYPES = [
     ("spblas_gfx950_spmv_plan_create", c_int,
      [c_void_p, ctypes.POINTER(c_void_p), c_i64, c_i64, c_i64, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int]),
     ("spblas_gfx950_spmv_plan_update_values", c_int, [c_void_p, c_void_p, c_void_p]),
+    ("spblas_gfx950_spmv_plan_detach", c_int, [c_void_p, c_void_p]),
     ("spblas_gfx950_plan_destroy", c_int, [c_void_p, c_void_p]),
     ("spblas_gfx950_plan_info", c_int, [c_void_p, ctypes.POINTER(c_i64)]),
     ("spblas_gfx950_plan_info_sliced", c_int, [c_void_p, ctypes.POINTER(c_i64)]),

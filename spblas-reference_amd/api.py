@@ -563,12 +563,25 @@ class _CscPlan:
               "multiply_inspect")
         self.a_csr = csr_view(self.values[:nnz], self.rowptr, self.colind[:nnz], (m, n), nnz)
         self.plan = _build_plan(self.a_csr, alg, snapshot=True)  # the materialised form is a copy anyway
+        # a self-contained plan (tiles with their own values, no hub rows, no hot split) needs the materialised arrays no
+        # longer: they are released, and the inspected operand holds the plan alone (cfg2-sized: 1.43 instead of 2.43 x the
+        # matrix).  SpMM plans and every other SpMV plan keep them.
+        self.detached = False
+        self._alg, self._vtype = alg, _vtype(vals, "multiply_inspect")[0]
+        if alg != _capi.SPMV_ROWBLOCK and alg != _capi.SPMV_VECTOR and \
+                _capi.lib().spblas_gfx950_spmv_plan_detach(hd.h, self.plan.plan) == _capi.SUCCESS:
+            self.detached = True
+            self.plan.tensors = None
+            self.a_csr = self.rowptr = self.colind = self.values = None
 
     def refresh_if_stale(self, a_csc):
         """The operand's values were rebound or changed in place (torch / scale()) since inspect: transpose
         again into the same arrays (the structure is unchanged, so the plan stays valid) and refresh the plan's
         own copy, so that multiply reads current values like the reference (multiply_impl.hpp:48-52)."""
         if _values_stamp(a_csc.values()) == self.stamp:
+            return
+        if self.detached:  # (the arrays the plan could be refreshed from are gone: materialise and plan again)
+            self.__init__(a_csc, self._alg)
             return
         m, n = a_csc.shape()
         nnz = a_csc.size()
@@ -588,7 +601,7 @@ class _CscPlan:
     def held_bytes(self):
         """device bytes of the materialised row-major copy this plan holds next to the CSR plan's own (info()['device_bytes'])"""
         t = [self.rowptr, self.colind, self.values]
-        return sum(x.numel() * x.element_size() for x in t)
+        return sum(x.numel() * x.element_size() for x in t if x is not None)
 
 
 def _csc_key(a_csc):
@@ -681,12 +694,14 @@ def _spmv(info, a, b, c, prepare_only=False):
             op = _capi.OP_T
     else:
         a_csr = a_base
-    _check_csr(a_csr, "multiply")
+    detached = csc_plan is not None and csc_plan.detached
+    if not detached:
+        _check_csr(a_csr, "multiply")
     if a_base.shape()[0] != c.shape[0] or a_base.shape()[1] != b_base.shape[0]:
         # algorithms/multiply_impl.hpp:37-41
         raise ValueError("multiply: matrix and vector dimensions are incompatible.")
-    vt, ct = _vtype(a_csr.values(), "multiply")
-    if b_base.dtype != a_csr.values().dtype or c.dtype != a_csr.values().dtype:
+    vt, ct = _vtype(a_base.values() if detached else a_csr.values(), "multiply")
+    if b_base.dtype != a_base.values().dtype or c.dtype != a_base.values().dtype:
         raise TypeError("multiply: A, x and y must share one value type")
     if not (b_base.is_contiguous() and c.is_contiguous()):
         raise ValueError("multiply: x and y must be contiguous")
@@ -697,10 +712,15 @@ def _spmv(info, a, b, c, prepare_only=False):
     plan = csc_plan.plan if csc_plan else (_find_plan(info, a, a_base) if op == _capi.OP_N else None)
     if plan is not None and not csc_plan:
         plan.refresh_if_stale(a_csr.values())
-    m, n = a_csr.shape()
-    args = (hd.h, plan.plan if plan else None, op, m, n, a_csr.size(), ctypes.byref(alpha), _ptr(a_csr.rowptr()),
-            _ptr(a_csr.colind()), _ptr(a_csr.values()), _ptr(b_base), ctypes.byref(beta), _ptr(c),
-            _OT[a_csr.rowptr().dtype], vt)
+    if detached:  # the plan is all there is of the materialised operand: no matrix arrays in the call
+        m, n = a_base.shape()
+        args = (hd.h, plan.plan, op, m, n, a_base.size(), ctypes.byref(alpha), None, None, None, _ptr(b_base),
+                ctypes.byref(beta), _ptr(c), _capi.I32, vt)
+    else:
+        m, n = a_csr.shape()
+        args = (hd.h, plan.plan if plan else None, op, m, n, a_csr.size(), ctypes.byref(alpha), _ptr(a_csr.rowptr()),
+                _ptr(a_csr.colind()), _ptr(a_csr.values()), _ptr(b_base), ctypes.byref(beta), _ptr(c),
+                _OT[a_csr.rowptr().dtype], vt)
     if prepare_only:
         return args, (alpha, beta, plan, a, b, c)  # keep the operands alive with the bound call
     check(_capi.lib().spblas_gfx950_spmv(*args), "multiply")
@@ -740,7 +760,8 @@ def _spmm(info, a, b, c):
     if isinstance(a_base, csc_view):
         # CSC operand (test/gtest/spmm_test.cpp:181): run the CSR kernel on the materialised row-major
         # form -- taken from the inspect result when there is one, otherwise transposed for this call
-        if info is not None and isinstance(info.state_, _CscPlan) and info.state_.key == _csc_key(a_base):
+        if info is not None and isinstance(info.state_, _CscPlan) and info.state_.key == _csc_key(a_base) and \
+                not info.state_.detached:  # (a plan inspected for SpMV may have released its row-major arrays)
             info.state_.refresh_if_stale(a_base)
             plan = info.state_.plan
             a_base = info.state_.a_csr

@@ -115,6 +115,9 @@ struct spblas_gfx950_plan_s {
   // carries mutable workspaces -- products, partial sums, long-row partials -- and must not run on two streams at once.)
   hipStream_t last_stream = nullptr;
   bool used = false;
+  // spblas_gfx950_spmv_plan_detach: the plan is self-contained (SLICED snapshot, no hub rows, no hot split) and its owner has
+  // released the structure / value arrays it was built from -- multiplies take no array arguments, the values cannot be refreshed
+  int detached = 0;
   // AUTO: the static rules could not tell which plan is faster (hot columns / heavy rows): plan_create times both
   int s_uncertain = 0;
   float trial_ms[2] = {0.f, 0.f};  // {row-block, sliced} when the trial ran

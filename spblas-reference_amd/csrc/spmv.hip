@@ -810,12 +810,33 @@ int spblas_gfx950_spmv_plan_create(spblas_gfx950_handle_t handle, spblas_gfx950_
   return SPBLAS_GFX950_STATUS_SUCCESS;
 }
 
+int spblas_gfx950_spmv_plan_detach(spblas_gfx950_handle_t handle, spblas_gfx950_plan_t plan) {
+  if (!handle)
+    return SPBLAS_GFX950_STATUS_INVALID_HANDLE;
+  if (!plan)
+    return SPBLAS_GFX950_STATUS_INVALID_POINTER;
+  if (plan->detached)
+    return SPBLAS_GFX950_STATUS_SUCCESS;
+  // self-contained: the tiles hold their own copy of the values and every row (no hub rows multiplied from the caller's
+  // arrays, no hot-column split with its own CSR parts, no per-call value refresh, not the value-free form)
+  if (plan->alg != SPBLAS_GFX950_SPMV_SLICED || plan->vfree || plan->refresh_each_call || plan->n_hub > 0 || plan->rest_plan ||
+      plan->hot_plan || plan->nnz == 0)
+    return SPBLAS_GFX950_STATUS_NOT_SUPPORTED;
+  plan->detached = 1;
+  plan->rowptr = nullptr;
+  plan->colind = nullptr;
+  plan->values_ptr = nullptr;
+  return SPBLAS_GFX950_STATUS_SUCCESS;
+}
+
 int spblas_gfx950_spmv_plan_update_values(spblas_gfx950_handle_t handle, spblas_gfx950_plan_t plan,
                                           const void* values) {
   if (!handle)
     return SPBLAS_GFX950_STATUS_INVALID_HANDLE;
   if (!plan || !values)
     return SPBLAS_GFX950_STATUS_INVALID_POINTER;
+  if (plan->detached)  // (the source positions index arrays that are gone: inspect again)
+    return SPBLAS_GFX950_STATUS_NOT_SUPPORTED;
   if (plan->alg != SPBLAS_GFX950_SPMV_SLICED)
     return SPBLAS_GFX950_STATUS_SUCCESS;  // other algorithms read the caller's values directly
   return spmv_sliced_update(handle, plan, values);
@@ -1195,10 +1216,16 @@ int spblas_gfx950_spmv(spblas_gfx950_handle_t handle, spblas_gfx950_plan_t plan,
       (value_type != SPBLAS_GFX950_F32 && value_type != SPBLAS_GFX950_F64))
     return SPBLAS_GFX950_STATUS_INVALID_VALUE;
   const int64_t ylen = op == SPBLAS_GFX950_OP_N ? m : n, xlen = op == SPBLAS_GFX950_OP_N ? n : m;
-  if (!alpha || !beta || !rowptr || (nnz > 0 && (!colind || !values)) || (ylen > 0 && !y) ||
+  const bool detached = plan && plan->detached;  // (spblas_gfx950_spmv_plan_detach: the multiply takes no matrix arrays)
+  if (!alpha || !beta || (!detached && (!rowptr || (nnz > 0 && (!colind || !values)))) || (ylen > 0 && !y) ||
       (xlen > 0 && nnz > 0 && !x))
     return SPBLAS_GFX950_STATUS_INVALID_POINTER;
-  if (plan) {
+  if (detached) {
+    if (plan->m != m || plan->n != n || plan->nnz != nnz || plan->offset_type != offset_type || plan->value_type != value_type)
+      return SPBLAS_GFX950_STATUS_PLAN_MISMATCH;
+    if (op != SPBLAS_GFX950_OP_N)
+      return SPBLAS_GFX950_STATUS_INVALID_VALUE;
+  } else if (plan) {
     if (plan->m != m || plan->n != n || plan->nnz != nnz || plan->rowptr != rowptr ||
         plan->colind != colind || plan->offset_type != offset_type || plan->value_type != value_type)
       return SPBLAS_GFX950_STATUS_PLAN_MISMATCH;
