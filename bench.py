@@ -678,10 +678,24 @@ def main():
             bad = ~(err <= tol_row * y_abs.double() + float(np.finfo(np.float32 if tsize == 4 else np.float64).tiny))
             stat = torch.stack([bad.sum().double(), (err / y_abs.double().clamp_min(1e-300)).max()])
             dist.all_reduce(stat, op=dist.ReduceOp.MAX)
-            parity = {"status": "pass" if int(stat[0].item()) == 0 else "fail", "rows": int(y_timed.numel()),
+            # The reference above comes through the same kind of collective as the timed y: rows that never ARRIVED would be
+            # the same stale values on both sides.  Independent of any gather: every rank sums ITS OWN rows of the timed y
+            # (they are computed locally) in fp64, the sums are all-reduced, and the total must equal the sum over the whole
+            # gathered vector on every rank -- a shard that a peer did not deliver, delivered twice or put at the wrong offset
+            # changes that sum.  (Round 6; first exercised across devices by the SCALE run.)
+            own = y_timed[bounds[rank]:bounds[rank + 1]].double()
+            sums = torch.stack([own.sum(), own.abs().sum()])
+            dist.all_reduce(sums)
+            whole = torch.stack([y_timed.double().sum(), y_timed.double().abs().sum()])
+            gather_bad = torch.tensor([float(((whole - sums).abs() > 1e-9 * sums[1] + 1e-300).any())], dtype=torch.float64, device=device)
+            dist.all_reduce(gather_bad, op=dist.ReduceOp.MAX)
+            gather_ok = not bool(gather_bad.item())
+            parity = {"status": "pass" if (int(stat[0].item()) == 0 and gather_ok) else "fail", "rows": int(y_timed.numel()),
                       "rows_out_of_bound": int(stat[0].item()), "tol": f"max({2.0 * tol:g}, row_length * eps) * sum|a x|",
                       "worst_err_over_rownorm": float(stat[1].item()),
-                      "against": "plan-free local SpMV (spmv_vector_kernel) + RCCL all-gather, every row, every rank"}
+                      "gather_checksum": "pass" if gather_ok else "fail",
+                      "against": "plan-free local SpMV (spmv_vector_kernel) + RCCL all-gather, every row, every rank; the gather "
+                                 "itself by an all-reduced fp64 checksum of every rank's own rows against the gathered vector"}
             del y_ref, y_abs, abs_chunks, err, bad, row_len, tol_row, ref_op
 
     if rank == 0:
