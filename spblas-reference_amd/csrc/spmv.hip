@@ -244,6 +244,328 @@ __global__ __launch_bounds__(256) void spmv_transpose_kernel(int64_t m, const O*
     unsafeAtomicAdd(y + stream_load(colind + p), stream_load(values + p) * xi);
 }
 
+// ---- op = T without a plan, large matrices: two passes through a workspace instead of 1e8 float atomics --------------------
+// Round 6.  The scatter kernel above issues one global float atomic per entry: 21 G / s chip-wide whatever the kernel does
+// (profiles/r03_*: L2 atomics), 4.75 ms at cfg2's size = 2.4 % of the HBM roofline (bench.py --workload csc_spmv).  y = A^T x
+// needs no gather -- x[i] is one scalar per ROW of A, streamed -- only its accumulation is scattered.  So: (1) t2_hist: entries
+// per column slice (S slices of W columns, W sized for an LDS-resident slice of y); (2) t2_plan: offsets, cursors and a list of
+// work items -- a slice whose share exceeds SEG entries is cut into segments (hot columns); (3) t2_scatter: a tile of 16 384
+// consecutive entries per workgroup, the row of an entry by binary search in the tile's row offsets staged in LDS, the
+// product alpha * a * x[i] and its 16-bit local column written to the slice's run (one reservation per (tile, slice): the
+// pieces of a tile reach the L2 together and leave as whole lines); (4) t2_accumulate: a work item sums its segment into an
+// LDS copy of the slice (LDS float add by compare-and-swap: integer LDS atomics run 12 x faster than ds_add_f32) and writes
+// y = beta y + sum -- or, for the segments of a cut slice, adds its partial sums to a y that (2) has scaled already.  The
+// order of additions inside a slice follows the order in which tiles reserved their runs: like the scatter kernel's, the
+// bits of y can differ from run to run (reproducibility).
+static constexpr int T2_TILE = 8192, T2_THREADS = 1024, T2_SMAX = 1024, T2_ROWS = 2048;
+// the global counters and cursors sit one per 128-byte line: thousands of atomics on 511 neighbouring words are thousands of
+// atomics on 16 lines, which the L2 serialises (first version: t2_scatter_kernel 1.81 ms, t2_hist_kernel 0.14 ms)
+static constexpr int T2_PAD = 32;
+// ... and every slice has T2_GRP cursors, one per residue class of the tile number: a cursor is hit once per tile, and twelve
+// thousand atomics on ONE address are served one after another (one cursor per slice: t2_scatter_kernel 0.87 ms)
+static constexpr int T2_GRP = 16;
+
+// slice = col / W without a division: rec = floor(2^32 / W) under-estimates by at most one
+__device__ __forceinline__ int t2_slice(int col, int W, unsigned rec) {
+  const unsigned q = __umulhi((unsigned) col, rec);
+  return (int) (q + (unsigned) ((unsigned) col - q * (unsigned) W >= (unsigned) W));
+}
+
+__global__ __launch_bounds__(256) void t2_hist_kernel(int64_t nnz, const int32_t* __restrict__ colind, int W, unsigned rec, int S,
+                                                      int64_t ntile, unsigned* __restrict__ cnt) {
+  // workgroup b counts the tiles b, b + gridDim.x, ... (gridDim.x is a multiple of T2_GRP: all of one residue class)
+  __shared__ unsigned hist[T2_SMAX];
+  for (int i = threadIdx.x; i < S; i += 256)
+    hist[i] = 0;
+  __syncthreads();
+  for (int64_t t = blockIdx.x; t < ntile; t += gridDim.x) {
+    const int64_t e0 = t * T2_TILE, e1 = (e0 + T2_TILE) < nnz ? (e0 + T2_TILE) : nnz;
+    for (int64_t e = e0 + threadIdx.x; e < e1; e += 256)
+      atomicAdd(&hist[t2_slice(stream_load(colind + e), W, rec)], 1u);
+  }
+  __syncthreads();
+  const int g = blockIdx.x % T2_GRP;
+  for (int i = threadIdx.x; i < S; i += 256)
+    if (hist[i])
+      atomicAdd(&cnt[((size_t) i * T2_GRP + g) * T2_PAD], hist[i]);
+}
+
+// one workgroup: base[s] = exclusive scan of cnt, cursor[s] = base[s]; work items (slice, first, last, cut) with segments of at
+// most seg entries; the slices that are cut get their part of y scaled by beta here (their segments only ADD)
+template <typename T>
+__global__ __launch_bounds__(1024) void t2_plan_kernel(int S, int W, int64_t n, unsigned seg, const unsigned* __restrict__ cnt,
+                                                       unsigned* __restrict__ base, unsigned* __restrict__ cursor,
+                                                       int4* __restrict__ items, int* __restrict__ n_items,
+                                                       T* __restrict__ y, T beta) {
+  __shared__ unsigned s_cnt[T2_SMAX], s_off[T2_SMAX + 1], s_it[T2_SMAX + 1];
+  for (int i = threadIdx.x; i < S; i += 1024) {  // a slice's entries: the sum over the residue classes of the tiles
+    unsigned c = 0;
+    for (int g = 0; g < T2_GRP; ++g)
+      c += cnt[((size_t) i * T2_GRP + g) * T2_PAD];
+    s_cnt[i] = c;
+  }
+  __syncthreads();
+  {
+    // exclusive scans of the counts and of the item counts: two elements per thread, Hillis-Steele over the 1024 pair sums
+    __shared__ unsigned s_a[1024], s_b[1024];
+    const int i0 = 2 * threadIdx.x, i1 = i0 + 1;
+    const unsigned c0 = i0 < S ? s_cnt[i0] : 0u, c1 = i1 < S ? s_cnt[i1] : 0u;
+    const unsigned t0 = i0 < S ? (c0 == 0 ? 1u : (c0 + seg - 1) / seg) : 0u;  // (an empty slice still owns its part of y)
+    const unsigned t1 = i1 < S ? (c1 == 0 ? 1u : (c1 + seg - 1) / seg) : 0u;
+    unsigned a = c0 + c1, b = t0 + t1;
+    s_a[threadIdx.x] = a;
+    s_b[threadIdx.x] = b;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+      const unsigned pa = threadIdx.x >= (unsigned) d ? s_a[threadIdx.x - d] : 0u, pb = threadIdx.x >= (unsigned) d ? s_b[threadIdx.x - d] : 0u;
+      __syncthreads();
+      a += pa;
+      b += pb;
+      s_a[threadIdx.x] = a;
+      s_b[threadIdx.x] = b;
+      __syncthreads();
+    }
+    const unsigned ea = a - (c0 + c1), eb = b - (t0 + t1);  // exclusive prefix of this thread's pair
+    if (i0 < S) {
+      s_off[i0] = ea;
+      s_it[i0] = eb;
+    }
+    if (i1 < S) {
+      s_off[i1] = ea + c0;
+      s_it[i1] = eb + t0;
+    }
+    if (threadIdx.x == 1023) {  // (the inclusive sums of the last thread are the totals, whatever S is)
+      s_off[S] = a;
+      s_it[S] = b;
+      *n_items = (int) b;
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i <= S; i += 1024)
+    base[i] = s_off[i];
+  for (int i = threadIdx.x; i < S; i += 1024) {
+    unsigned run = s_off[i];  // the classes' pieces of the slice's run, one behind the other
+    for (int g = 0; g < T2_GRP; ++g) {
+      cursor[((size_t) i * T2_GRP + g) * T2_PAD] = run;
+      run += cnt[((size_t) i * T2_GRP + g) * T2_PAD];
+    }
+    const unsigned nseg = s_it[i + 1] - s_it[i];
+    for (unsigned q = 0; q < nseg; ++q) {
+      const unsigned lo = s_off[i] + q * seg, hi = (lo + seg) < (s_off[i] + s_cnt[i]) ? (lo + seg) : (s_off[i] + s_cnt[i]);
+      items[s_it[i] + q] = make_int4(i, (int) lo, (int) hi, nseg > 1 ? 1 : 0);
+    }
+  }
+  // the cut slices' part of y: scaled now, added to by every segment later
+  for (int i = 0; i < S; ++i) {
+    if (s_it[i + 1] - s_it[i] > 1) {
+      const int64_t c0 = (int64_t) i * W, c1 = (c0 + W) < n ? (c0 + W) : n;
+      for (int64_t c = c0 + threadIdx.x; c < c1; c += 1024)
+        y[c] = beta == T(0) ? T(0) : beta * y[c];
+    }
+  }
+}
+
+template <typename T, typename O>
+__global__ __launch_bounds__(T2_THREADS) void t2_scatter_kernel(int64_t m, int64_t nnz, const O* __restrict__ rowptr,
+                                                                const int32_t* __restrict__ colind,
+                                                                const T* __restrict__ values, const T* __restrict__ x,
+                                                                T alpha, int W, unsigned rec, int S, const int32_t* __restrict__ tile_row,
+                                                                unsigned* __restrict__ cursor, T* __restrict__ prod,
+                                                                uint16_t* __restrict__ lcol) {
+  // The tile's products leave SORTED BY SLICE through LDS: 64 lanes storing 4 + 2 bytes each at 64 unrelated addresses were
+  // two address-unit passes of 64 separate accesses per wave-instruction (first version: 1.7 ms at cfg2's size, the whole
+  // kernel); staged, consecutive lanes write consecutive elements of a run.
+  extern __shared__ __attribute__((aligned(16))) unsigned char t2s_smem[];
+  T* s_val = reinterpret_cast<T*>(t2s_smem);                       // [TILE] products (first: the widest alignment)
+  uint16_t* s_lc = reinterpret_cast<uint16_t*>(s_val + T2_TILE);   // [TILE] local columns
+  unsigned* s_cnt = reinterpret_cast<unsigned*>(s_lc + T2_TILE);   // [SMAX] entries of the tile per slice
+  unsigned* s_loff = s_cnt + T2_SMAX;                              // [SMAX + 1] their exclusive scan (positions in the stage)
+  unsigned* s_fill = s_loff + T2_SMAX + 1;                         // [SMAX] next free position of a slice's piece of the stage
+  unsigned* s_gbase = s_fill + T2_SMAX;                            // [SMAX] where the slice's piece goes in the global run
+  int* s_rp = reinterpret_cast<int*>(s_gbase + T2_SMAX);           // [ROWS + 2] row offsets relative to e0, clamped to the tile
+  __shared__ unsigned s_scan[T2_THREADS / 64];
+  constexpr int PER = T2_TILE / T2_THREADS;
+  const int tid = threadIdx.x;
+  const int64_t e0 = (int64_t) blockIdx.x * T2_TILE, e1 = (e0 + T2_TILE) < nnz ? (e0 + T2_TILE) : nnz;
+  // rows that have entries in [e0, e1): tile_row[w] = first row r with rowptr[r] >= w * TILE; the row before it may reach in
+  int64_t r_lo = tile_row[blockIdx.x], r_hi = tile_row[blockIdx.x + 1];
+  r_lo = r_lo > 0 ? r_lo - 1 : 0;
+  r_hi = r_hi < m ? r_hi : m;  // (r_hi itself starts at or beyond e1)
+  const int64_t nrows = r_hi - r_lo;
+  const bool staged = nrows <= T2_ROWS;
+  for (int i = tid; i < S; i += T2_THREADS) {
+    s_cnt[i] = 0;
+    s_fill[i] = 0;
+  }
+  if (staged)
+    for (int64_t i = tid; i <= nrows; i += T2_THREADS) {
+      const int64_t d = (int64_t) rowptr[r_lo + i] - e0;
+      s_rp[i] = (int) (d < -1 ? -1 : d > T2_TILE + 1 ? T2_TILE + 1 : d);
+    }
+  int col[PER];
+  T val[PER];
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const int64_t e = e0 + tid + (int64_t) k * T2_THREADS;
+    col[k] = e < e1 ? stream_load(colind + e) : -1;
+    val[k] = e < e1 ? stream_load(values + e) : T(0);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < PER; ++k)
+    if (col[k] >= 0)
+      atomicAdd(&s_cnt[t2_slice(col[k], W, rec)], 1u);
+  __syncthreads();
+  {
+    // exclusive scan of s_cnt[0 .. S) -> s_loff: one counter per thread (S <= THREADS), scans inside the wavefronts, the 16
+    // wave totals through LDS: two barriers (a Hillis-Steele scan over the workgroup was twenty, at one workgroup per CU)
+    const unsigned c = tid < S ? s_cnt[tid] : 0u;
+    unsigned a = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const unsigned t = __shfl_up(a, d, 64);
+      if ((tid & 63) >= d)
+        a += t;
+    }
+    if ((tid & 63) == 63)
+      s_scan[tid >> 6] = a;
+    __syncthreads();
+    unsigned before = 0;
+    for (int w = 0; w < (tid >> 6); ++w)
+      before += s_scan[w];
+    if (tid < S)
+      s_loff[tid] = before + a - c;
+    if (tid == T2_THREADS - 1)
+      s_loff[S] = before + a;
+  }
+  for (int i = tid; i < S; i += T2_THREADS)
+#ifdef T2_EXP_NOATOM
+    s_gbase[i] = cursor[((size_t) i * T2_GRP + (blockIdx.x % T2_GRP)) * T2_PAD];
+#else
+    s_gbase[i] = s_cnt[i] ? atomicAdd(&cursor[((size_t) i * T2_GRP + (blockIdx.x % T2_GRP)) * T2_PAD], s_cnt[i]) : 0u;  // this tile's piece
+#endif
+  __syncthreads();
+  // the row of entry e: the last row r with rowptr[r] <= e.  Three sub-phases so that the PER loads of x are in flight together
+  // (search, load and stage in ONE loop per entry put a dependent global load behind every search: 0.22 of 0.77 ms; a
+  // fixed-length branch-free search with the PER searches side by side was slower still: 1.06 ms)
+  int rrow[PER];
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const int64_t e = e0 + tid + (int64_t) k * T2_THREADS;
+    int64_t lo = 0, hi = col[k] >= 0 ? nrows : 1;  // invariant: rowptr[r_lo + lo] <= e < rowptr[r_lo + hi]
+#ifdef T2_EXP_NOSEARCH  // timing experiments only (results wrong): tools/build_variant.sh
+    hi = 1;
+#endif
+    if (staged) {
+      while (hi - lo > 1) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (s_rp[mid] <= (int) (e - e0))
+          lo = mid;
+        else
+          hi = mid;
+      }
+    } else {
+      while (hi - lo > 1) {
+        const int64_t mid = (lo + hi) >> 1;
+        if ((int64_t) rowptr[r_lo + mid] <= e)
+          lo = mid;
+        else
+          hi = mid;
+      }
+    }
+    rrow[k] = (int) lo;
+  }
+  T xv[PER];
+#pragma unroll
+  for (int k = 0; k < PER; ++k)
+    xv[k] = x[r_lo + rrow[k]];
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    if (col[k] < 0)
+      continue;
+    const int sl = t2_slice(col[k], W, rec);
+    const unsigned at = s_loff[sl] + atomicAdd(&s_fill[sl], 1u);
+    s_val[at] = alpha * val[k] * xv[k];
+    s_lc[at] = (uint16_t) (col[k] - sl * W);
+  }
+  __syncthreads();
+  const int count = (int) (e1 - e0);
+  for (int q = tid; q < count; q += T2_THREADS) {
+    // the slice of stage position q: the last s with s_loff[s] <= q (ten LDS reads instead of four more bytes per staged
+    // entry: at 72 KiB two workgroups share a CU)
+    int lo = 0, hi = S;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (s_loff[mid] <= (unsigned) q)
+        lo = mid;
+      else
+        hi = mid;
+    }
+    const unsigned g = s_gbase[lo] + ((unsigned) q - s_loff[lo]);
+#ifndef T2_EXP_NOWRITE
+    prod[g] = s_val[q];
+    lcol[g] = s_lc[q];
+#else
+    if (g == 0xffffffffu)
+      prod[0] = s_val[q];
+#endif
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ void t2_lds_add(T* addr, T v);
+template <>
+__device__ __forceinline__ void t2_lds_add<float>(float* addr, float v) {
+  int* ai = reinterpret_cast<int*>(addr);
+  int old = *(volatile __attribute__((address_space(3))) int*) ai;
+  while (true) {
+    const int assumed = old;
+    old = atomicCAS(ai, assumed, __float_as_int(__int_as_float(assumed) + v));
+    if (old == assumed)
+      break;
+  }
+}
+template <>
+__device__ __forceinline__ void t2_lds_add<double>(double* addr, double v) {
+  unsigned long long* ai = reinterpret_cast<unsigned long long*>(addr);
+  unsigned long long old = *(volatile __attribute__((address_space(3))) unsigned long long*) ai;
+  while (true) {
+    const unsigned long long assumed = old;
+    old = atomicCAS(ai, assumed, (unsigned long long) __double_as_longlong(__longlong_as_double((long long) assumed) + v));
+    if (old == assumed)
+      break;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(1024) void t2_accumulate_kernel(int W, int64_t n, const int4* __restrict__ items,
+                                                             const int* __restrict__ n_items, const T* __restrict__ prod,
+                                                             const uint16_t* __restrict__ lcol, T* __restrict__ y, T beta) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char t2_smem[];
+  T* acc = reinterpret_cast<T*>(t2_smem);  // [W]
+  const int count = *n_items;
+  for (int it = blockIdx.x; it < count; it += gridDim.x) {
+    const int4 w = items[it];
+    for (int i = threadIdx.x; i < W; i += 1024)
+      acc[i] = T(0);
+    __syncthreads();
+    for (int64_t e = (int64_t) (unsigned) w.y + threadIdx.x; e < (int64_t) (unsigned) w.z; e += 1024)
+      t2_lds_add<T>(acc + stream_load(lcol + e), stream_load(prod + e));
+    __syncthreads();
+    const int64_t c0 = (int64_t) w.x * W, c1 = (c0 + W) < n ? (c0 + W) : n;
+    if (w.w) {  // a segment of a cut slice: y was scaled by t2_plan_kernel, the segments add
+      for (int64_t c = c0 + threadIdx.x; c < c1; c += 1024)
+        if (acc[c - c0] != T(0))
+          unsafeAtomicAdd(y + c, acc[c - c0]);
+    } else {
+      for (int64_t c = c0 + threadIdx.x; c < c1; c += 1024)
+        y[c] = beta == T(0) ? acc[c - c0] : acc[c - c0] + beta * y[c];
+    }
+    __syncthreads();
+  }
+}
+
+
 // ---------------------------------------------------------------------------
 // inspect kernels
 // ---------------------------------------------------------------------------
@@ -386,6 +708,8 @@ void spmv_sliced_free(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl);
 void spmm_plan_free(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl);
 int spmv_hot_rows(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, const void* alpha, const void* x, void* y);
 
+static int env_int_spmv(const char* name, int def);
+
 template <typename T, typename O>
 static int spmv_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, int op, int64_t m, int64_t n,
                       int64_t nnz, const void* alpha_p, const void* rowptr_p, const int32_t* colind,
@@ -399,6 +723,71 @@ static int spmv_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, int op
   hipStream_t s = h->stream;
 
   if (op == SPBLAS_GFX950_OP_T) {
+    // Large matrices: two passes through a workspace (t2_* kernels above) instead of one float atomic per entry.  Needs the
+    // handle's scratch (6 or 10 B per entry + tables): grown outside stream captures only; SPBLAS_GFX950_SPMV_T2=0 keeps the
+    // scatter kernel, =1 forces the two-pass form for any size (tests).
+    const int t2_env = env_int_spmv("SPBLAS_GFX950_SPMV_T2", -1);
+    const int cus = h->num_cus > 0 ? h->num_cus : 256;
+    // slice width: as many slices as the accumulate pass has workgroup slots (two per CU: ONE round of work items -- 611 slices
+    // of 16 384 columns on 512 slots were two rounds, 0.236 against 0.170 ms), a multiple of 64, an LDS-resident slice of y of
+    // at most 76 KiB (two workgroups per CU), 16-bit local columns, at most T2_SMAX slices
+    int64_t Wsl = (cdiv(n, (int64_t) 2 * cus) + 63) & ~(int64_t) 63;
+    const int64_t Wcap = (76 * 1024) / (int64_t) sizeof(T);
+    Wsl = Wsl < 4096 ? 4096 : Wsl > Wcap ? Wcap : Wsl;
+    if (cdiv(n, Wsl) > T2_SMAX)  // (a matrix with more columns than 1 024 such slices: wider slices, one workgroup per CU)
+      Wsl = std::min<int64_t>((cdiv(n, (int64_t) T2_SMAX) + 63) & ~(int64_t) 63, std::min<int64_t>(65536, (152 * 1024) / (int64_t) sizeof(T)));
+    const unsigned wrec = (unsigned) (((uint64_t) 1 << 32) / (uint64_t) Wsl);
+    const int64_t Ssl = cdiv(n, Wsl), ntile = cdiv(nnz, T2_TILE);
+    const bool t2_fits = m > 0 && nnz > 0 && nnz < INT32_MAX - T2_TILE && Ssl <= T2_SMAX && ntile < INT32_MAX;
+    const bool t2_want = t2_env == 1 || (t2_env != 0 && nnz >= ((int64_t) 4 << 20) && n >= 65536);
+    if (t2_fits && t2_want) {
+      const size_t off_cnt = 0, off_base = off_cnt + (size_t) T2_SMAX * T2_GRP * T2_PAD * 4,
+                   off_cur = (off_base + (size_t) (T2_SMAX + 1) * 4 + 127) & ~(size_t) 127,
+                   off_nit = off_cur + (size_t) T2_SMAX * T2_GRP * T2_PAD * 4, off_tile = (off_nit + 4 + 15) & ~(size_t) 15;
+      const unsigned seg = (unsigned) std::max<int64_t>(65536, 2 * cdiv(nnz, Ssl));
+      const size_t max_items = (size_t) Ssl + (size_t) (nnz / seg) + 1;
+      const size_t off_items = (off_tile + (size_t) (ntile + 1) * 4 + 15) & ~(size_t) 15;
+      const size_t off_prod = (off_items + max_items * sizeof(int4) + 255) & ~(size_t) 255;
+      const size_t off_lcol = (off_prod + (size_t) nnz * sizeof(T) + 255) & ~(size_t) 255;
+      const size_t bytes = off_lcol + (size_t) nnz * 2 + 256;
+      void* ws = nullptr;
+      if (!(stream_capturing(s) && bytes > h->scratch_bytes) && handle_scratch(h, bytes, &ws) == SPBLAS_GFX950_STATUS_SUCCESS) {
+        char* w8 = static_cast<char*>(ws);
+        unsigned* cnt = reinterpret_cast<unsigned*>(w8 + off_cnt);
+        unsigned* base = reinterpret_cast<unsigned*>(w8 + off_base);
+        unsigned* cursor = reinterpret_cast<unsigned*>(w8 + off_cur);
+        int* n_items = reinterpret_cast<int*>(w8 + off_nit);
+        int32_t* tile_row = reinterpret_cast<int32_t*>(w8 + off_tile);
+        int4* items = reinterpret_cast<int4*>(w8 + off_items);
+        T* prod = reinterpret_cast<T*>(w8 + off_prod);
+        uint16_t* lcol = reinterpret_cast<uint16_t*>(w8 + off_lcol);
+        SPB_HIP(hipMemsetAsync(cnt, 0, (size_t) Ssl * T2_GRP * T2_PAD * 4, s));
+        hipLaunchKernelGGL((plan_window_rows_kernel<O>), dim3((unsigned) cdiv(ntile + 1, 256)), dim3(256), 0, s, m, ntile, T2_TILE,
+                           rowptr, tile_row);
+        const int64_t hist_wgs = std::min<int64_t>(cdiv(ntile, T2_GRP), (int64_t) cus * 8 / T2_GRP) * T2_GRP;  // a multiple of T2_GRP
+        hipLaunchKernelGGL(t2_hist_kernel, dim3((unsigned) hist_wgs), dim3(256), 0, s, nnz, colind, (int) Wsl, wrec, (int) Ssl, ntile, cnt);
+        hipLaunchKernelGGL((t2_plan_kernel<T>), dim3(1), dim3(1024), 0, s, (int) Ssl, (int) Wsl, n, seg, cnt, base, cursor, items,
+                           n_items, y, beta);
+        static std::atomic<bool> t2_attr[64][2][2] = {};
+        const int dv = h->device >= 0 && h->device < 64 ? h->device : 0;
+        constexpr int ti = sizeof(T) == 4 ? 0 : 1, oi = sizeof(O) == 4 ? 0 : 1;
+        const size_t lds_sc = (size_t) (4 * T2_SMAX + 1) * 4 + (size_t) (T2_ROWS + 2) * 4 + (size_t) T2_TILE * (2 + sizeof(T)) + 16;
+        if (!t2_attr[dv][ti][oi].load(std::memory_order_acquire) || h->device >= 64) {
+          SPB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(t2_accumulate_kernel<T>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
+          SPB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(t2_scatter_kernel<T, O>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_sc));
+          t2_attr[dv][ti][oi].store(true, std::memory_order_release);
+        }
+        hipLaunchKernelGGL((t2_scatter_kernel<T, O>), dim3((unsigned) ntile), dim3(T2_THREADS), lds_sc, s, m, nnz, rowptr, colind,
+                           values, x, alpha, (int) Wsl, wrec, (int) Ssl, tile_row, cursor, prod, lcol);
+        hipLaunchKernelGGL((t2_accumulate_kernel<T>), dim3((unsigned) std::min<size_t>(max_items, (size_t) cus * 2)), dim3(1024),
+                           (size_t) Wsl * sizeof(T), s, (int) Wsl, n, items, n_items, prod, lcol, y, beta);
+        SPB_HIP(hipGetLastError());
+        return SPBLAS_GFX950_STATUS_SUCCESS;
+      }
+      (void) hipGetLastError();
+    }
     // y has n entries: scale, then scatter-add.
     if (n > 0)
       hipLaunchKernelGGL((scale_vector_kernel<T>), dim3((unsigned) cdiv(n, 256)), dim3(256), 0, s, n, y,

@@ -516,6 +516,69 @@ def test_spmv_csc_and_transposed_operand(gpu):
     util.assert_parity(G.host(y), 2 * y_ref, 2 * absrow, np.float32, row_len=np.full(200, 64), what="csc scaled")
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("offsets", [np.int32, np.int64])
+@pytest.mark.parametrize("shape_kind", ["ragged", "hot_column", "many_empty_rows", "wide"])
+def test_spmv_transposed_without_a_plan_two_pass_form(gpu, monkeypatch, dtype, offsets, shape_kind):
+    """Round 6: un-inspected y = alpha A^T x + beta y on large matrices goes through a workspace instead of one global float
+    atomic per entry (csrc/spmv.hip: t2_* kernels; cfg2-sized operand 4.75 -> see bench.py --workload csc_spmv): entries per
+    column slice, cursors + work items (a slice holding far more than its share is cut into segments), products with 16-bit
+    local columns scattered tile by tile -- the row of an entry by binary search in the tile's staged row offsets --, one LDS
+    accumulation per slice.  Forced here for small shapes (SPBLAS_GFX950_SPMV_T2=1): ragged rows, a hot column that forces the
+    segment path, a stretch of tens of thousands of empty rows inside one tile (row offsets not staged), a wide matrix with
+    several slices; alpha / beta through the C ABI with NaN in the old y for beta = 0; compared with the oracle and with the
+    scatter kernel (SPBLAS_GFX950_SPMV_T2=0)."""
+    rng = np.random.default_rng(83)
+    if shape_kind == "wide":
+        m, n = 3000, 300_000
+        lens = rng.integers(0, 60, m)
+    elif shape_kind == "many_empty_rows":
+        m, n = 120_000, 9000
+        lens = np.zeros(m, np.int64)
+        lens[rng.choice(m, 3000, replace=False)] = rng.integers(1, 40, 3000)
+    else:
+        m, n = 20_000, 70_000
+        lens = rng.integers(0, 30, m)
+        lens[777] = 5000
+    rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(offsets)
+    nnz = int(rowptr[-1])
+    colind = rng.integers(0, n, nnz).astype(np.int32)
+    if shape_kind == "hot_column":
+        colind[rng.random(nnz) < 0.5] = 12345           # half of all entries in one column: its slice is cut into segments
+    values = (rng.random(nnz) - 0.5).astype(dtype)
+    x = (rng.random(m) - 0.5).astype(dtype)
+    y0 = (rng.random(n) - 0.5).astype(dtype)
+    tdt = torch.float32 if dtype == np.float32 else torch.float64
+    t = lambda a_: torch.from_numpy(np.ascontiguousarray(a_)).cuda()
+    dv, drp, dci, dx = t(values), t(rowptr), t(colind), t(x)
+    rp32 = rowptr.astype(np.int32)
+    ref = oracle.spmv_csc((n, m), rp32, colind, values, x).astype(np.float64)
+    ab = oracle.spmv_csc((n, m), rp32, colind, np.abs(values), np.abs(x)).astype(np.float64)
+    cnt = np.bincount(colind, minlength=n)
+    hd = sp.api._Handle.current(dx.device)
+    ct = ctypes.c_float if dtype == np.float32 else ctypes.c_double
+    got = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("SPBLAS_GFX950_SPMV_T2", mode)
+        for alpha, beta in ((1.0, 0.0), (-1.5, 0.25)):
+            y = torch.full((n,), float("nan"), dtype=tdt, device="cuda") if beta == 0.0 else t(y0)
+            al, be = ct(alpha), ct(beta)
+            sp.api.check(_capi.lib().spblas_gfx950_spmv(hd.h, None, _capi.OP_T, m, n, nnz, ctypes.byref(al), sp.api._ptr(drp),
+                                                        sp.api._ptr(dci), sp.api._ptr(dv), sp.api._ptr(dx), ctypes.byref(be),
+                                                        sp.api._ptr(y), _capi.I32 if offsets == np.int32 else _capi.I64,
+                                                        _capi.F32 if dtype == np.float32 else _capi.F64), "spmv")
+            want = alpha * ref + (beta * y0 if beta else 0.0)
+            scale = abs(alpha) * ab + (abs(beta) * np.abs(y0) if beta else 0.0)
+            util.assert_parity(G.host(y), want, scale, dtype, row_len=cnt + 1, what=f"op = T, T2={mode}, {shape_kind}, beta={beta}")
+            got[(mode, beta)] = G.host(y)
+    # through the host layer: multiply(transposed(a), x, y)
+    monkeypatch.setenv("SPBLAS_GFX950_SPMV_T2", "1")
+    a = sp.csr_view(dv, drp, dci, (m, n), nnz)
+    y = torch.full((n,), float("nan"), dtype=tdt, device="cuda")
+    sp.multiply(sp.scaled(2.0, sp.transposed(a)), dx, y)
+    util.assert_parity(G.host(y), 2.0 * ref, 2.0 * ab, dtype, row_len=cnt + 1, what="multiply(transposed(a), x, y), two-pass form")
+
+
 def test_spmv_degenerate_shapes(gpu):
     # all rows empty; zero rows; single entry
     z = sp.csr_view(torch.zeros(0, device="cuda"), torch.zeros(6, dtype=torch.int32, device="cuda"),
