@@ -724,7 +724,7 @@ static int spmv_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, int op
 
   if (op == SPBLAS_GFX950_OP_T) {
     // Large matrices: two passes through a workspace (t2_* kernels above) instead of one float atomic per entry.  Needs the
-    // handle's scratch (6 or 10 B per entry + tables): grown outside stream captures only; SPBLAS_GFX950_SPMV_T2=0 keeps the
+    // handle's scratch (6 or 10 B per entry + tables), hence not inside stream captures; SPBLAS_GFX950_SPMV_T2=0 keeps the
     // scatter kernel, =1 forces the two-pass form for any size (tests).
     const int t2_env = env_int_spmv("SPBLAS_GFX950_SPMV_T2", -1);
     const int cus = h->num_cus > 0 ? h->num_cus : 256;
@@ -751,7 +751,9 @@ static int spmv_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, int op
       const size_t off_lcol = (off_prod + (size_t) nnz * sizeof(T) + 255) & ~(size_t) 255;
       const size_t bytes = off_lcol + (size_t) nnz * 2 + 256;
       void* ws = nullptr;
-      if (!(stream_capturing(s) && bytes > h->scratch_bytes) && handle_scratch(h, bytes, &ws) == SPBLAS_GFX950_STATUS_SUCCESS) {
+      // (never inside a stream capture: the recorded launches would keep pointers into the handle's scratch, which a later call
+      // may grow, i.e. free and allocate again -- a captured un-inspected transposed multiply keeps the scatter kernel)
+      if (!stream_capturing(s) && handle_scratch(h, bytes, &ws) == SPBLAS_GFX950_STATUS_SUCCESS) {
         char* w8 = static_cast<char*>(ws);
         unsigned* cnt = reinterpret_cast<unsigned*>(w8 + off_cnt);
         unsigned* base = reinterpret_cast<unsigned*>(w8 + off_base);
