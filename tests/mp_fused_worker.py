@@ -25,7 +25,7 @@ def main():
     bounds = sharded.partition_rows_even(m, world)
     a_loc = sharded.shard_csr(values, rowptr, colind, shape, bounds[rank], bounds[rank + 1])
     stripes = int(os.environ.get("FUSED_STRIPES", "1"))
-    op = sharded.FusedShardedSpMV(a_loc, bounds, alg=sp._capi.SPMV_SLICED, timeout_ms=5000, stripes=stripes)
+    op = sharded.FusedShardedSpMV(a_loc, bounds, alg=sp._capi.SPMV_SLICED, timeout_ms=15000, stripes=stripes)
     g = torch.Generator(device=dev).manual_seed(7)
     x = torch.rand(n, dtype=dtype, device=dev, generator=g)
     vh, rh, ch, xh = values.cpu().numpy(), rowptr.cpu().numpy(), colind.cpu().numpy(), x.cpu().numpy()
@@ -66,7 +66,7 @@ def main():
         del os.environ["SPBLAS_GFX950_PB_VFREE"], os.environ["SPBLAS_GFX950_PB_VF_ROWS"]
         assert info_vf.state_.sliced_info()["value_free"] == 1
         saved_vals = a_loc.values().clone()
-        op_vf = sharded.FusedShardedSpMV(a_loc, bounds, info=info_vf, timeout_ms=5000, stripes=stripes)
+        op_vf = sharded.FusedShardedSpMV(a_loc, bounds, info=info_vf, timeout_ms=15000, stripes=stripes)
         assert op_vf.value_free
         for it, vscale in enumerate((1.0, -0.5, 3.0)):
             if vscale != 1.0:
@@ -155,7 +155,7 @@ def main():
             limit = (torch.div(row_of, msq // world, rounding_mode="floor") + 1) * (msq // world)
             ci2 = (ci2.long() % limit).to(torch.int32)
         a2 = sharded.shard_csr(v2, rp2, ci2, shape2, b2[rank], b2[rank + 1])
-        op2 = sharded.FusedShardedSpMV(a2, b2, alg=sp._capi.SPMV_SLICED, timeout_ms=8000, chunks=chunks, shared_device=True)
+        op2 = sharded.FusedShardedSpMV(a2, b2, alg=sp._capi.SPMV_SLICED, timeout_ms=20000, chunks=chunks, shared_device=True)
         x0 = torch.rand(msq, dtype=dtype, device=dev, generator=g)
         nsteps = 7  # (entries in [0, 1): y grows by ~2.2x per step, far from overflow)
         y = op2.step(x0).clone()
