@@ -139,9 +139,26 @@ int spblas_gfx950_spmv_plan_update_values(spblas_gfx950_handle_t handle, spblas_
   (void) handle; (void) plan; (void) values;
   return 0;
 }
+/* the shim's plans are empty, there is nothing self-contained to keep: the owner goes on holding its arrays */
+int spblas_gfx950_spmv_plan_detach(spblas_gfx950_handle_t handle, spblas_gfx950_plan_t plan) {
+  (void) handle; (void) plan;
+  return SPBLAS_GFX950_STATUS_NOT_SUPPORTED;
+}
 int spblas_gfx950_plan_destroy(spblas_gfx950_handle_t handle, spblas_gfx950_plan_t plan) {
   (void) handle;
   free(plan);
+  return 0;
+}
+int spblas_gfx950_narrow_indices(spblas_gfx950_handle_t handle, int64_t count, const int64_t* src, int32_t* dst,
+                                 int64_t bound) {
+  (void) handle;
+  if (count < 0 || bound < 0 || bound > (int64_t) INT32_MAX)
+    return SPBLAS_GFX950_STATUS_INVALID_SIZE;
+  for (int64_t i = 0; i < count; ++i) {
+    if (src[i] < 0 || src[i] >= bound)
+      return SPBLAS_GFX950_STATUS_INVALID_VALUE;
+    dst[i] = (int32_t) src[i];
+  }
   return 0;
 }
 int spblas_gfx950_spmm_inspect(spblas_gfx950_handle_t handle, spblas_gfx950_plan_t plan) {
