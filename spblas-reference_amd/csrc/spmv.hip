@@ -736,6 +736,11 @@ static int spmv_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, int op
     Wsl = Wsl < 4096 ? 4096 : Wsl > Wcap ? Wcap : Wsl;
     if (cdiv(n, Wsl) > T2_SMAX)  // (a matrix with more columns than 1 024 such slices: wider slices, one workgroup per CU)
       Wsl = std::min<int64_t>((cdiv(n, (int64_t) T2_SMAX) + 63) & ~(int64_t) 63, std::min<int64_t>(65536, (152 * 1024) / (int64_t) sizeof(T)));
+    if (t2_env == 1) {  // tests / tools/fuzz_spmv_t.py: any slice width (a multiple of 64 that the LDS holds), any segment length
+      const int w_env = env_int_spmv("SPBLAS_GFX950_SPMV_T2_W", 0);
+      if (w_env >= 64 && w_env <= Wcap)
+        Wsl = w_env & ~63;
+    }
     const unsigned wrec = (unsigned) (((uint64_t) 1 << 32) / (uint64_t) Wsl);
     const int64_t Ssl = cdiv(n, Wsl), ntile = cdiv(nnz, T2_TILE);
     const bool t2_fits = m > 0 && nnz > 0 && nnz < INT32_MAX - T2_TILE && Ssl <= T2_SMAX && ntile < INT32_MAX;
@@ -744,7 +749,9 @@ static int spmv_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, int op
       const size_t off_cnt = 0, off_base = off_cnt + (size_t) T2_SMAX * T2_GRP * T2_PAD * 4,
                    off_cur = (off_base + (size_t) (T2_SMAX + 1) * 4 + 127) & ~(size_t) 127,
                    off_nit = off_cur + (size_t) T2_SMAX * T2_GRP * T2_PAD * 4, off_tile = (off_nit + 4 + 15) & ~(size_t) 15;
-      const unsigned seg = (unsigned) std::max<int64_t>(65536, 2 * cdiv(nnz, Ssl));
+      unsigned seg = (unsigned) std::max<int64_t>(65536, 2 * cdiv(nnz, Ssl));
+      if (t2_env == 1 && env_int_spmv("SPBLAS_GFX950_SPMV_T2_SEG", 0) >= 64)
+        seg = (unsigned) env_int_spmv("SPBLAS_GFX950_SPMV_T2_SEG", 0);
       const size_t max_items = (size_t) Ssl + (size_t) (nnz / seg) + 1;
       const size_t off_items = (off_tile + (size_t) (ntile + 1) * 4 + 15) & ~(size_t) 15;
       const size_t off_prod = (off_items + max_items * sizeof(int4) + 255) & ~(size_t) 255;
