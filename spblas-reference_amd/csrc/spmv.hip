@@ -257,7 +257,7 @@ __global__ __launch_bounds__(256) void spmv_transpose_kernel(int64_t m, const O*
 // y = beta y + sum -- or, for the segments of a cut slice, adds its partial sums to a y that (2) has scaled already.  The
 // order of additions inside a slice follows the order in which tiles reserved their runs: like the scatter kernel's, the
 // bits of y can differ from run to run (reproducibility).
-static constexpr int T2_TILE = 8192, T2_THREADS = 1024, T2_SMAX = 1024, T2_ROWS = 2048;
+static constexpr int T2_TILE = 8192, T2_THREADS = 1024, T2_SMAX = 1024;
 // the global counters and cursors sit one per 128-byte line: thousands of atomics on 511 neighbouring words are thousands of
 // atomics on 16 lines, which the L2 serialises (first version: t2_scatter_kernel 1.81 ms, t2_hist_kernel 0.14 ms)
 static constexpr int T2_PAD = 32;
@@ -271,17 +271,69 @@ __device__ __forceinline__ int t2_slice(int col, int W, unsigned rec) {
   return (int) (q + (unsigned) ((unsigned) col - q * (unsigned) W >= (unsigned) W));
 }
 
+// four consecutive elements in one access at the element's own alignment (global memory takes unaligned vector accesses; the
+// address unit spends its cycles per INSTRUCTION, however wide)
+typedef int t2_i4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef float t2_f4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef double t2_d4u __attribute__((ext_vector_type(4), aligned(8)));
+typedef unsigned short t2_h4u __attribute__((ext_vector_type(4), aligned(2)));
+template <typename T> struct t2_vec4;
+template <> struct t2_vec4<float> { typedef t2_f4u type; };
+template <> struct t2_vec4<double> { typedef t2_d4u type; };
+
+// wavefront scans by DPP moves (row_shr 1 / 2 / 4 / 8, row_bcast:15 / :31; a lane without a source reads 0): six vector
+// instructions, no LDS round trip (the shuffle form is six dependent ds_bpermute)
+template <int CTRL, int ROWS>
+__device__ __forceinline__ int t2_dpp(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, ROWS, 0xf, true);
+}
+__device__ __forceinline__ int t2_wave_incl_max(int v) {  // v >= 0
+  int t;
+  t = t2_dpp<0x111, 0xf>(v), v = v > t ? v : t;
+  t = t2_dpp<0x112, 0xf>(v), v = v > t ? v : t;
+  t = t2_dpp<0x114, 0xf>(v), v = v > t ? v : t;
+  t = t2_dpp<0x118, 0xf>(v), v = v > t ? v : t;
+  t = t2_dpp<0x142, 0xa>(v), v = v > t ? v : t;
+  t = t2_dpp<0x143, 0xc>(v), v = v > t ? v : t;
+  return v;
+}
+__device__ __forceinline__ unsigned t2_wave_incl_sum(unsigned v) {
+  v += (unsigned) t2_dpp<0x111, 0xf>((int) v);
+  v += (unsigned) t2_dpp<0x112, 0xf>((int) v);
+  v += (unsigned) t2_dpp<0x114, 0xf>((int) v);
+  v += (unsigned) t2_dpp<0x118, 0xf>((int) v);
+  v += (unsigned) t2_dpp<0x142, 0xa>((int) v);
+  v += (unsigned) t2_dpp<0x143, 0xc>((int) v);
+  return v;
+}
+
 __global__ __launch_bounds__(256) void t2_hist_kernel(int64_t nnz, const int32_t* __restrict__ colind, int W, unsigned rec, int S,
                                                       int64_t ntile, unsigned* __restrict__ cnt) {
-  // workgroup b counts the tiles b, b + gridDim.x, ... (gridDim.x is a multiple of T2_GRP: all of one residue class)
+  // workgroup b counts the tiles b, b + gridDim.x, ... (gridDim.x is a multiple of T2_GRP: all of one residue class); a full
+  // tile is eight 16-byte loads per lane, all in flight together (one 4-byte load per lane and round: 139 us at cfg2's size)
   __shared__ unsigned hist[T2_SMAX];
   for (int i = threadIdx.x; i < S; i += 256)
     hist[i] = 0;
   __syncthreads();
   for (int64_t t = blockIdx.x; t < ntile; t += gridDim.x) {
     const int64_t e0 = t * T2_TILE, e1 = (e0 + T2_TILE) < nnz ? (e0 + T2_TILE) : nnz;
-    for (int64_t e = e0 + threadIdx.x; e < e1; e += 256)
-      atomicAdd(&hist[t2_slice(stream_load(colind + e), W, rec)], 1u);
+    if (e1 - e0 == T2_TILE) {
+      constexpr int ROUNDS = T2_TILE / (256 * 4);
+      t2_i4u c[ROUNDS];
+#pragma unroll
+      for (int k = 0; k < ROUNDS; ++k)
+        c[k] = __builtin_nontemporal_load(reinterpret_cast<const t2_i4u*>(colind + e0 + (int64_t) (k * 256 + threadIdx.x) * 4));
+#pragma unroll
+      for (int k = 0; k < ROUNDS; ++k) {
+        atomicAdd(&hist[t2_slice(c[k].x, W, rec)], 1u);
+        atomicAdd(&hist[t2_slice(c[k].y, W, rec)], 1u);
+        atomicAdd(&hist[t2_slice(c[k].z, W, rec)], 1u);
+        atomicAdd(&hist[t2_slice(c[k].w, W, rec)], 1u);
+      }
+    } else {
+      for (int64_t e = e0 + threadIdx.x; e < e1; e += 256)
+        atomicAdd(&hist[t2_slice(stream_load(colind + e), W, rec)], 1u);
+    }
   }
   __syncthreads();
   const int g = blockIdx.x % T2_GRP;
@@ -290,19 +342,39 @@ __global__ __launch_bounds__(256) void t2_hist_kernel(int64_t nnz, const int32_t
       atomicAdd(&cnt[((size_t) i * T2_GRP + g) * T2_PAD], hist[i]);
 }
 
-// one workgroup: base[s] = exclusive scan of cnt, cursor[s] = base[s]; work items (slice, first, last, cut) with segments of at
-// most seg entries; the slices that are cut get their part of y scaled by beta here (their segments only ADD)
+// one workgroup: base[s] = exclusive scan of the slices' counts, cursor[s][g] = where residue class g of the tiles starts inside
+// the slice's run; work items (slice, first, last, cut) with segments of at most seg entries; the slices that are cut get their
+// part of y scaled by beta here (their segments only ADD).  One thread per (slice, class) pair for the padded counters -- one
+// line each --, so that the S * T2_GRP loads are in flight together (one thread per slice walking its 16 lines twice: 48 us).
 template <typename T>
 __global__ __launch_bounds__(1024) void t2_plan_kernel(int S, int W, int64_t n, unsigned seg, const unsigned* __restrict__ cnt,
                                                        unsigned* __restrict__ base, unsigned* __restrict__ cursor,
                                                        int4* __restrict__ items, int* __restrict__ n_items,
                                                        T* __restrict__ y, T beta) {
   __shared__ unsigned s_cnt[T2_SMAX], s_off[T2_SMAX + 1], s_it[T2_SMAX + 1];
-  for (int i = threadIdx.x; i < S; i += 1024) {  // a slice's entries: the sum over the residue classes of the tiles
-    unsigned c = 0;
-    for (int g = 0; g < T2_GRP; ++g)
-      c += cnt[((size_t) i * T2_GRP + g) * T2_PAD];
-    s_cnt[i] = c;
+  static_assert(T2_GRP == 16, "a slice's classes are the 16 lanes of one DPP row");
+  constexpr int PAIRS = T2_SMAX * T2_GRP / 1024;  // pairs per thread: pair p = r * 1024 + tid, slice p / 16, class p % 16
+  unsigned c_pair[PAIRS], x_pair[PAIRS];          // the pair's count; the counts of the slice's earlier classes
+  for (int i = threadIdx.x; i < S; i += 1024)
+    s_cnt[i] = 0;
+#pragma unroll
+  for (int r = 0; r < PAIRS; ++r) {
+    const int p = r * 1024 + threadIdx.x;
+    c_pair[r] = p < S * T2_GRP ? cnt[(size_t) p * T2_PAD] : 0u;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < PAIRS; ++r) {
+    // inclusive sums inside the rows of 16 lanes = inside one slice
+    unsigned v = c_pair[r];
+    v += (unsigned) t2_dpp<0x111, 0xf>((int) v);
+    v += (unsigned) t2_dpp<0x112, 0xf>((int) v);
+    v += (unsigned) t2_dpp<0x114, 0xf>((int) v);
+    v += (unsigned) t2_dpp<0x118, 0xf>((int) v);
+    x_pair[r] = v - c_pair[r];
+    const int p = r * 1024 + threadIdx.x;
+    if ((p & (T2_GRP - 1)) == T2_GRP - 1 && p < S * T2_GRP)
+      s_cnt[p / T2_GRP] = v;
   }
   __syncthreads();
   {
@@ -343,12 +415,13 @@ __global__ __launch_bounds__(1024) void t2_plan_kernel(int S, int W, int64_t n, 
   __syncthreads();
   for (int i = threadIdx.x; i <= S; i += 1024)
     base[i] = s_off[i];
+#pragma unroll
+  for (int r = 0; r < PAIRS; ++r) {  // the classes' pieces of a slice's run, one behind the other
+    const int p = r * 1024 + threadIdx.x;
+    if (p < S * T2_GRP)
+      cursor[(size_t) p * T2_PAD] = s_off[p / T2_GRP] + x_pair[r];
+  }
   for (int i = threadIdx.x; i < S; i += 1024) {
-    unsigned run = s_off[i];  // the classes' pieces of the slice's run, one behind the other
-    for (int g = 0; g < T2_GRP; ++g) {
-      cursor[((size_t) i * T2_GRP + g) * T2_PAD] = run;
-      run += cnt[((size_t) i * T2_GRP + g) * T2_PAD];
-    }
     const unsigned nseg = s_it[i + 1] - s_it[i];
     for (unsigned q = 0; q < nseg; ++q) {
       const unsigned lo = s_off[i] + q * seg, hi = (lo + seg) < (s_off[i] + s_cnt[i]) ? (lo + seg) : (s_off[i] + s_cnt[i]);
@@ -365,8 +438,14 @@ __global__ __launch_bounds__(1024) void t2_plan_kernel(int S, int W, int64_t n, 
   }
 }
 
+// LDS of the scatter kernel: products + packed (local column, slice) words of a tile, three tables of Sa words
+static inline size_t t2_scatter_lds(size_t value_size, int S) {
+  const size_t Sa = ((size_t) S + 4) & ~(size_t) 3;
+  return (size_t) T2_TILE * (value_size + 4) + 3 * Sa * 4;
+}
+
 template <typename T, typename O>
-__global__ __launch_bounds__(T2_THREADS) void t2_scatter_kernel(int64_t m, int64_t nnz, const O* __restrict__ rowptr,
+__global__ __launch_bounds__(T2_THREADS, sizeof(T) == 4 ? 8 : 4) void t2_scatter_kernel(int64_t m, int64_t nnz, const O* __restrict__ rowptr,
                                                                 const int32_t* __restrict__ colind,
                                                                 const T* __restrict__ values, const T* __restrict__ x,
                                                                 T alpha, int W, unsigned rec, int S, const int32_t* __restrict__ tile_row,
@@ -375,33 +454,30 @@ __global__ __launch_bounds__(T2_THREADS) void t2_scatter_kernel(int64_t m, int64
   // The tile's products leave SORTED BY SLICE through LDS: 64 lanes storing 4 + 2 bytes each at 64 unrelated addresses were
   // two address-unit passes of 64 separate accesses per wave-instruction (first version: 1.7 ms at cfg2's size, the whole
   // kernel); staged, consecutive lanes write consecutive elements of a run.
+  // Second version (0.72 ms): the kernel was bound by its LDS instructions -- a binary search per entry for its row (11 reads)
+  // and one per staged position for its slice (10 reads) next to the two atomics and three stores an entry needs.  Now the row
+  // of an entry comes from marks + a running maximum (the rows that start inside the tile leave their number at their first
+  // entry; DPP scans inside the wavefronts, one carry per 64 positions -- the scheme of transpose.hip's first pass), and a
+  // staged entry carries its slice next to its local column (one 32-bit word), so the write-out reads three words per entry.
   extern __shared__ __attribute__((aligned(16))) unsigned char t2s_smem[];
-  T* s_val = reinterpret_cast<T*>(t2s_smem);                       // [TILE] products (first: the widest alignment)
-  uint16_t* s_lc = reinterpret_cast<uint16_t*>(s_val + T2_TILE);   // [TILE] local columns
-  unsigned* s_cnt = reinterpret_cast<unsigned*>(s_lc + T2_TILE);   // [SMAX] entries of the tile per slice
-  unsigned* s_loff = s_cnt + T2_SMAX;                              // [SMAX + 1] their exclusive scan (positions in the stage)
-  unsigned* s_fill = s_loff + T2_SMAX + 1;                         // [SMAX] next free position of a slice's piece of the stage
-  unsigned* s_gbase = s_fill + T2_SMAX;                            // [SMAX] where the slice's piece goes in the global run
-  int* s_rp = reinterpret_cast<int*>(s_gbase + T2_SMAX);           // [ROWS + 2] row offsets relative to e0, clamped to the tile
+  typedef __attribute__((address_space(3))) int lds_int;
+  const int Sa = (S + 4) & ~3;
+  T* s_val = reinterpret_cast<T*>(t2s_smem);                         // [TILE] products; before that: the marks of the row search
+  unsigned* s_pack = reinterpret_cast<unsigned*>(s_val + T2_TILE);   // [TILE] local column | slice << 16
+  unsigned* s_cnt = s_pack + T2_TILE;                                // [Sa] entries of the tile per slice, then the fill counters
+  unsigned* s_loff = s_cnt + Sa;                                     // [Sa] exclusive scan of the counts (positions in the stage)
+  unsigned* s_delta = s_loff + Sa;                                   // [Sa] global position - staged position of a slice's piece
   __shared__ unsigned s_scan[T2_THREADS / 64];
-  constexpr int PER = T2_TILE / T2_THREADS;
-  const int tid = threadIdx.x;
+  constexpr int PER = T2_TILE / T2_THREADS, NSEG = T2_TILE / 64;
+  __shared__ int s_seg[NSEG];                                        // running maximum at the end of every 64 positions
+  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
   const int64_t e0 = (int64_t) blockIdx.x * T2_TILE, e1 = (e0 + T2_TILE) < nnz ? (e0 + T2_TILE) : nnz;
+  const int count = (int) (e1 - e0);
   // rows that have entries in [e0, e1): tile_row[w] = first row r with rowptr[r] >= w * TILE; the row before it may reach in
   int64_t r_lo = tile_row[blockIdx.x], r_hi = tile_row[blockIdx.x + 1];
   r_lo = r_lo > 0 ? r_lo - 1 : 0;
   r_hi = r_hi < m ? r_hi : m;  // (r_hi itself starts at or beyond e1)
   const int64_t nrows = r_hi - r_lo;
-  const bool staged = nrows <= T2_ROWS;
-  for (int i = tid; i < S; i += T2_THREADS) {
-    s_cnt[i] = 0;
-    s_fill[i] = 0;
-  }
-  if (staged)
-    for (int64_t i = tid; i <= nrows; i += T2_THREADS) {
-      const int64_t d = (int64_t) rowptr[r_lo + i] - e0;
-      s_rp[i] = (int) (d < -1 ? -1 : d > T2_TILE + 1 ? T2_TILE + 1 : d);
-    }
   int col[PER];
   T val[PER];
 #pragma unroll
@@ -410,101 +486,98 @@ __global__ __launch_bounds__(T2_THREADS) void t2_scatter_kernel(int64_t m, int64
     col[k] = e < e1 ? stream_load(colind + e) : -1;
     val[k] = e < e1 ? stream_load(values + e) : T(0);
   }
-  __syncthreads();
+  lds_int* mark = (lds_int*) (int*) t2s_smem;
+  for (int i = tid; i < S; i += T2_THREADS)
+    s_cnt[i] = 0;
 #pragma unroll
   for (int k = 0; k < PER; ++k)
-    if (col[k] >= 0)
-      atomicAdd(&s_cnt[t2_slice(col[k], W, rec)], 1u);
+    mark[k * T2_THREADS + tid] = 0;
   __syncthreads();
-  {
-    // exclusive scan of s_cnt[0 .. S) -> s_loff: one counter per thread (S <= THREADS), scans inside the wavefronts, the 16
-    // wave totals through LDS: two barriers (a Hillis-Steele scan over the workgroup was twenty, at one workgroup per CU)
-    const unsigned c = tid < S ? s_cnt[tid] : 0u;
-    unsigned a = c;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const unsigned t = __shfl_up(a, d, 64);
-      if ((tid & 63) >= d)
-        a += t;
-    }
-    if ((tid & 63) == 63)
-      s_scan[tid >> 6] = a;
-    __syncthreads();
-    unsigned before = 0;
-    for (int w = 0; w < (tid >> 6); ++w)
-      before += s_scan[w];
-    if (tid < S)
-      s_loff[tid] = before + a - c;
-    if (tid == T2_THREADS - 1)
-      s_loff[S] = before + a;
+  // row r_lo + j (j >= 1) that starts inside the tile: j at its first entry; of several rows starting at one position -- empty
+  // ones -- the last owns the entry (LDS max)
+  for (int64_t j = 1 + tid; j <= nrows; j += T2_THREADS) {
+    const int64_t pos = (int64_t) rowptr[r_lo + j] - e0;
+    if (pos >= 0 && pos < count)
+      __hip_atomic_fetch_max(&mark[pos], (int) j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   }
-  for (int i = tid; i < S; i += T2_THREADS)
-#ifdef T2_EXP_NOATOM
-    s_gbase[i] = cursor[((size_t) i * T2_GRP + (blockIdx.x % T2_GRP)) * T2_PAD];
-#else
-    s_gbase[i] = s_cnt[i] ? atomicAdd(&cursor[((size_t) i * T2_GRP + (blockIdx.x % T2_GRP)) * T2_PAD], s_cnt[i]) : 0u;  // this tile's piece
-#endif
-  __syncthreads();
-  // the row of entry e: the last row r with rowptr[r] <= e.  Three sub-phases so that the PER loads of x are in flight together
-  // (search, load and stage in ONE loop per entry put a dependent global load behind every search: 0.22 of 0.77 ms; a
-  // fixed-length branch-free search with the PER searches side by side was slower still: 1.06 ms)
-  int rrow[PER];
+  int sl[PER];
 #pragma unroll
   for (int k = 0; k < PER; ++k) {
-    const int64_t e = e0 + tid + (int64_t) k * T2_THREADS;
-    int64_t lo = 0, hi = col[k] >= 0 ? nrows : 1;  // invariant: rowptr[r_lo + lo] <= e < rowptr[r_lo + hi]
-#ifdef T2_EXP_NOSEARCH  // timing experiments only (results wrong): tools/build_variant.sh
-    hi = 1;
-#endif
-    if (staged) {
-      while (hi - lo > 1) {
-        const int64_t mid = (lo + hi) >> 1;
-        if (s_rp[mid] <= (int) (e - e0))
-          lo = mid;
-        else
-          hi = mid;
-      }
-    } else {
-      while (hi - lo > 1) {
-        const int64_t mid = (lo + hi) >> 1;
-        if ((int64_t) rowptr[r_lo + mid] <= e)
-          lo = mid;
-        else
-          hi = mid;
-      }
-    }
-    rrow[k] = (int) lo;
+    sl[k] = col[k] >= 0 ? t2_slice(col[k], W, rec) : 0;
+    if (col[k] >= 0)
+      atomicAdd(&s_cnt[sl[k]], 1u);
   }
-  T xv[PER];
+  __syncthreads();
+  int rrow[PER];
 #pragma unroll
   for (int k = 0; k < PER; ++k)
+    rrow[k] = mark[k * T2_THREADS + tid];
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    rrow[k] = t2_wave_incl_max(rrow[k]);
+    if (lane == 63)
+      s_seg[k * (T2_THREADS / 64) + wv] = rrow[k];  // positions k * THREADS + wv * 64 .. + 63: segment k * 16 + wv
+  }
+  // exclusive scan of s_cnt[0 .. S) -> s_loff: one counter per thread (S <= THREADS), scans inside the wavefronts, the 16
+  // wave totals through LDS
+  const unsigned c_mine = tid < S ? s_cnt[tid] : 0u;
+  const unsigned a_mine = t2_wave_incl_sum(c_mine);
+  if (lane == 63)
+    s_scan[wv] = a_mine;
+  __syncthreads();
+  if (tid < S) {
+    unsigned before = 0;
+    for (int w = 0; w < wv; ++w)
+      before += s_scan[w];
+    const unsigned loff = before + a_mine - c_mine;
+    s_loff[tid] = loff;
+    // this tile's piece of the slice's run (one reservation per (tile, slice))
+#ifdef T2_EXP_NOATOM
+    const unsigned gb = cursor[((size_t) tid * T2_GRP + (blockIdx.x % T2_GRP)) * T2_PAD];
+#else
+    const unsigned gb = c_mine ? atomicAdd(&cursor[((size_t) tid * T2_GRP + (blockIdx.x % T2_GRP)) * T2_PAD], c_mine) : 0u;
+#endif
+    s_delta[tid] = gb - loff;
+    s_cnt[tid] = 0;  // from here on: the next free place inside the slice's piece of the stage
+  }
+  if (wv == T2_THREADS / 64 - 1) {
+    // (the last wavefront has no counters for S <= 960) exclusive running maximum over the NSEG segment ends, two per lane
+    static_assert(NSEG == 128, "two segment ends per lane");
+    const int a = s_seg[2 * lane], b = s_seg[2 * lane + 1];
+    const int ab = a > b ? a : b;
+    const int inc = t2_wave_incl_max(ab);
+    int exc = __shfl_up(inc, 1, 64);  // the inclusive maximum of the lanes before this one
+    exc = lane == 0 ? 0 : exc;
+    __builtin_amdgcn_wave_barrier();
+    s_seg[2 * lane] = exc;
+    s_seg[2 * lane + 1] = exc > a ? exc : a;
+  }
+  __syncthreads();
+  T xv[PER];
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const int pre = s_seg[k * (T2_THREADS / 64) + wv];
+    rrow[k] = rrow[k] > pre ? rrow[k] : pre;
+#ifdef T2_EXP_NOSEARCH
+    rrow[k] = 0;
+#endif
     xv[k] = x[r_lo + rrow[k]];
+  }
 #pragma unroll
   for (int k = 0; k < PER; ++k) {
     if (col[k] < 0)
       continue;
-    const int sl = t2_slice(col[k], W, rec);
-    const unsigned at = s_loff[sl] + atomicAdd(&s_fill[sl], 1u);
+    const unsigned at = s_loff[sl[k]] + atomicAdd(&s_cnt[sl[k]], 1u);
     s_val[at] = alpha * val[k] * xv[k];
-    s_lc[at] = (uint16_t) (col[k] - sl * W);
+    s_pack[at] = (unsigned) (col[k] - sl[k] * W) | ((unsigned) sl[k] << 16);
   }
   __syncthreads();
-  const int count = (int) (e1 - e0);
   for (int q = tid; q < count; q += T2_THREADS) {
-    // the slice of stage position q: the last s with s_loff[s] <= q (ten LDS reads instead of four more bytes per staged
-    // entry: at 72 KiB two workgroups share a CU)
-    int lo = 0, hi = S;
-    while (hi - lo > 1) {
-      const int mid = (lo + hi) >> 1;
-      if (s_loff[mid] <= (unsigned) q)
-        lo = mid;
-      else
-        hi = mid;
-    }
-    const unsigned g = s_gbase[lo] + ((unsigned) q - s_loff[lo]);
+    const unsigned pk = s_pack[q];
+    const unsigned g = (unsigned) q + s_delta[pk >> 16];
 #ifndef T2_EXP_NOWRITE
     prod[g] = s_val[q];
-    lcol[g] = s_lc[q];
+    lcol[g] = (uint16_t) pk;
 #else
     if (g == 0xffffffffu)
       prod[0] = s_val[q];
@@ -543,14 +616,35 @@ __global__ __launch_bounds__(1024) void t2_accumulate_kernel(int W, int64_t n, c
                                                              const uint16_t* __restrict__ lcol, T* __restrict__ y, T beta) {
   extern __shared__ __attribute__((aligned(16))) unsigned char t2_smem[];
   T* acc = reinterpret_cast<T*>(t2_smem);  // [W]
+  typedef typename t2_vec4<T>::type vec4;
   const int count = *n_items;
   for (int it = blockIdx.x; it < count; it += gridDim.x) {
     const int4 w = items[it];
     for (int i = threadIdx.x; i < W; i += 1024)
       acc[i] = T(0);
     __syncthreads();
-    for (int64_t e = (int64_t) (unsigned) w.y + threadIdx.x; e < (int64_t) (unsigned) w.z; e += 1024)
-      t2_lds_add<T>(acc + stream_load(lcol + e), stream_load(prod + e));
+    // four consecutive entries per lane and access, two accesses in flight (one 4 + 2 byte pair per lane and round: 267 us at
+    // cfg2's size, 2.2 TB/s)
+    const int64_t lo = (int64_t) (unsigned) w.y, hi = (int64_t) (unsigned) w.z;
+    int64_t e = lo + (int64_t) threadIdx.x * 4;
+    for (; e + 4096 + 4 <= hi; e += 8192) {
+      const vec4 p0 = __builtin_nontemporal_load(reinterpret_cast<const vec4*>(prod + e));
+      const t2_h4u c0 = __builtin_nontemporal_load(reinterpret_cast<const t2_h4u*>(lcol + e));
+      const vec4 p1 = __builtin_nontemporal_load(reinterpret_cast<const vec4*>(prod + e + 4096));
+      const t2_h4u c1 = __builtin_nontemporal_load(reinterpret_cast<const t2_h4u*>(lcol + e + 4096));
+      t2_lds_add<T>(acc + c0.x, p0.x);
+      t2_lds_add<T>(acc + c0.y, p0.y);
+      t2_lds_add<T>(acc + c0.z, p0.z);
+      t2_lds_add<T>(acc + c0.w, p0.w);
+      t2_lds_add<T>(acc + c1.x, p1.x);
+      t2_lds_add<T>(acc + c1.y, p1.y);
+      t2_lds_add<T>(acc + c1.z, p1.z);
+      t2_lds_add<T>(acc + c1.w, p1.w);
+    }
+    for (; e < hi; e += 4096)
+      for (int j = 0; j < 4; ++j)
+        if (e + j < hi)
+          t2_lds_add<T>(acc + stream_load(lcol + e + j), stream_load(prod + e + j));
     __syncthreads();
     const int64_t c0 = (int64_t) w.x * W, c1 = (c0 + W) < n ? (c0 + W) : n;
     if (w.w) {  // a segment of a cut slice: y was scaled by t2_plan_kernel, the segments add
@@ -780,12 +874,12 @@ static int spmv_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, int op
         static std::atomic<bool> t2_attr[64][2][2] = {};
         const int dv = h->device >= 0 && h->device < 64 ? h->device : 0;
         constexpr int ti = sizeof(T) == 4 ? 0 : 1, oi = sizeof(O) == 4 ? 0 : 1;
-        const size_t lds_sc = (size_t) (4 * T2_SMAX + 1) * 4 + (size_t) (T2_ROWS + 2) * 4 + (size_t) T2_TILE * (2 + sizeof(T)) + 16;
+        const size_t lds_sc = t2_scatter_lds(sizeof(T), (int) Ssl);
         if (!t2_attr[dv][ti][oi].load(std::memory_order_acquire) || h->device >= 64) {
           SPB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(t2_accumulate_kernel<T>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
           SPB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(t2_scatter_kernel<T, O>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_sc));
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int) t2_scatter_lds(sizeof(T), T2_SMAX)));
           t2_attr[dv][ti][oi].store(true, std::memory_order_release);
         }
         hipLaunchKernelGGL((t2_scatter_kernel<T, O>), dim3((unsigned) ntile), dim3(T2_THREADS), lds_sc, s, m, nnz, rowptr, colind,
