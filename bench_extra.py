@@ -428,7 +428,7 @@ def _run_csc_spmv(args, device, sp, oracle, generate):
                  {"dtype": "f32", "rows": k, "nnz": nnz, "operand": "csc_view + multiply_inspect", "plan": plan,
                   "uninspected_ms_per_step": el_t / max(3, args.steps // 2) * 1e3,
                   "uninspected_roofline_frac": alg_bytes / (ms_t[0] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                  "uninspected_kernel": "t2_hist_kernel + t2_plan_kernel + t2_scatter_kernel<float,int> + t2_accumulate_kernel<float> (round 6: products "
+                  "uninspected_kernel": "t2_hist_kernel + scan + t2_plan_kernel + t2_scatter_kernel<float,int> + t2_accumulate_kernel<float> (round 6: products "
                                         "binned by column slice through the handle's workspace; SPBLAS_GFX950_SPMV_T2=0: the float-atomic scatter)",
                   "inspect_ms_untimed": inspect_ms, "plan_bytes": held,
                   "plan_bytes_over_matrix": held / float(nnz * 8 + (k + 1) * 4),

@@ -16,6 +16,7 @@
 //   spmv_transpose_kernel  op = T (CSC / transposed(csr)): scatter with HW float atomics.
 #include "common.hpp"
 #include "plan.hpp"
+#include "scan.hpp"
 
 #include <atomic>
 #include <cstdlib>
@@ -247,23 +248,30 @@ __global__ __launch_bounds__(256) void spmv_transpose_kernel(int64_t m, const O*
 // ---- op = T without a plan, large matrices: two passes through a workspace instead of 1e8 float atomics --------------------
 // Round 6.  The scatter kernel above issues one global float atomic per entry: 21 G / s chip-wide whatever the kernel does
 // (profiles/r03_*: L2 atomics), 4.75 ms at cfg2's size = 2.4 % of the HBM roofline (bench.py --workload csc_spmv).  y = A^T x
-// needs no gather -- x[i] is one scalar per ROW of A, streamed -- only its accumulation is scattered.  So: (1) t2_hist: entries
-// per column slice (S slices of W columns, W sized for an LDS-resident slice of y); (2) t2_plan: offsets, cursors and a list of
-// work items -- a slice whose share exceeds SEG entries is cut into segments (hot columns); (3) t2_scatter: a tile of 16 384
-// consecutive entries per workgroup, the row of an entry by binary search in the tile's row offsets staged in LDS, the
-// product alpha * a * x[i] and its 16-bit local column written to the slice's run (one reservation per (tile, slice): the
-// pieces of a tile reach the L2 together and leave as whole lines); (4) t2_accumulate: a work item sums its segment into an
-// LDS copy of the slice (LDS float add by compare-and-swap: integer LDS atomics run 12 x faster than ds_add_f32) and writes
-// y = beta y + sum -- or, for the segments of a cut slice, adds its partial sums to a y that (2) has scaled already.  The
-// order of additions inside a slice follows the order in which tiles reserved their runs: like the scatter kernel's, the
-// bits of y can differ from run to run (reproducibility).
+// needs no gather -- x[i] is one scalar per ROW of A, streamed -- only its accumulation is scattered.  So: (1) t2_hist: the
+// entries of every tile of 8 192 consecutive entries per column slice (S slices of W columns, W sized for an LDS-resident slice
+// of y), scanned into the place of every (slice, tile) piece; (2) t2_plan: a list of work items -- a slice whose share exceeds
+// SEG entries is cut into segments (hot columns); (3) t2_scatter: a tile per workgroup, the row of an entry from marks + a
+// running maximum over the tile, the product alpha * a * x[i] and its 16-bit local column staged in LDS by slice and written
+// to the slices' runs (the pieces of a tile leave as runs, those of neighbouring tiles as whole lines); (4) t2_accumulate: a
+// work item sums its segment into an LDS copy of the slice (LDS float add by compare-and-swap: integer LDS atomics run 12 x
+// faster than ds_add_f32) and writes y = beta y + sum -- or, for the segments of a cut slice, adds its partial sums to a y
+// that (2) has scaled already.  The products of a slice lie in row order, but 1 024 lanes add them to the LDS copy as they
+// come: like the scatter kernel's, the bits of y can differ from run to run (reproducibility).
 static constexpr int T2_TILE = 8192, T2_THREADS = 1024, T2_SMAX = 1024;
-// the global counters and cursors sit one per 128-byte line: thousands of atomics on 511 neighbouring words are thousands of
-// atomics on 16 lines, which the L2 serialises (first version: t2_scatter_kernel 1.81 ms, t2_hist_kernel 0.14 ms)
-static constexpr int T2_PAD = 32;
-// ... and every slice has T2_GRP cursors, one per residue class of the tile number: a cursor is hit once per tile, and twelve
-// thousand atomics on ONE address are served one after another (one cursor per slice: t2_scatter_kernel 0.87 ms)
-static constexpr int T2_GRP = 16;
+// Where a tile's piece of a slice's run goes is COUNTED, not reserved: t2_hist writes the tile's entries per slice to
+// counts[slice][tile], one exclusive scan over that matrix (scan.hpp, the transpose's) gives every piece its place -- the
+// pieces of a slice in tile order, those of neighbouring tiles adjacent in memory.  (Reserved by atomics -- 511 per tile, 6.2 M
+// at cfg2's size, on cursors padded to one per 128-byte line and split 16 ways per slice because atomics on one line, let alone
+// one address, are served one after another -- the scatter kernel spent a third of its 0.39 ms on them: the chip takes about
+// 21 G device-scope atomics per second whatever else a kernel does.)
+// Workgroup -> tile: every XCD takes a contiguous range of tiles (workgroups are dealt round-robin to the 8 XCDs), so that the
+// adjacent pieces of neighbouring tiles meet in ONE L2 and leave it as whole lines, and the counters of neighbouring tiles --
+// neighbours in counts[slice][tile] -- are written through one L2 as well (transpose.hip: 4.0 -> 3.3 ms from this mapping).
+__device__ __forceinline__ int64_t t2_tile_of(int64_t b, int64_t ntile) {
+  const int64_t per = ntile / 8, body = per * 8;
+  return b < body ? (b & 7) * per + (b >> 3) : b;
+}
 
 // slice = col / W without a division: rec = floor(2^32 / W) under-estimates by at most one
 __device__ __forceinline__ int t2_slice(int col, int W, unsigned rec) {
@@ -308,133 +316,82 @@ __device__ __forceinline__ unsigned t2_wave_incl_sum(unsigned v) {
 }
 
 __global__ __launch_bounds__(256) void t2_hist_kernel(int64_t nnz, const int32_t* __restrict__ colind, int W, unsigned rec, int S,
-                                                      int64_t ntile, unsigned* __restrict__ cnt) {
-  // workgroup b counts the tiles b, b + gridDim.x, ... (gridDim.x is a multiple of T2_GRP: all of one residue class); a full
-  // tile is eight 16-byte loads per lane, all in flight together (one 4-byte load per lane and round: 139 us at cfg2's size)
+                                                      int64_t ntile, int32_t* __restrict__ counts) {
+  // one tile per workgroup: eight 16-byte loads per lane, all in flight together (one 4-byte load per lane and round: 139 us
+  // at cfg2's size)
   __shared__ unsigned hist[T2_SMAX];
   for (int i = threadIdx.x; i < S; i += 256)
     hist[i] = 0;
   __syncthreads();
-  for (int64_t t = blockIdx.x; t < ntile; t += gridDim.x) {
-    const int64_t e0 = t * T2_TILE, e1 = (e0 + T2_TILE) < nnz ? (e0 + T2_TILE) : nnz;
-    if (e1 - e0 == T2_TILE) {
-      constexpr int ROUNDS = T2_TILE / (256 * 4);
-      t2_i4u c[ROUNDS];
+  const int64_t t = t2_tile_of(blockIdx.x, ntile);
+  const int64_t e0 = t * T2_TILE, e1 = (e0 + T2_TILE) < nnz ? (e0 + T2_TILE) : nnz;
+  if (e1 - e0 == T2_TILE) {
+    constexpr int ROUNDS = T2_TILE / (256 * 4);
+    t2_i4u c[ROUNDS];
 #pragma unroll
-      for (int k = 0; k < ROUNDS; ++k)
-        c[k] = __builtin_nontemporal_load(reinterpret_cast<const t2_i4u*>(colind + e0 + (int64_t) (k * 256 + threadIdx.x) * 4));
+    for (int k = 0; k < ROUNDS; ++k)
+      c[k] = __builtin_nontemporal_load(reinterpret_cast<const t2_i4u*>(colind + e0 + (int64_t) (k * 256 + threadIdx.x) * 4));
 #pragma unroll
-      for (int k = 0; k < ROUNDS; ++k) {
-        atomicAdd(&hist[t2_slice(c[k].x, W, rec)], 1u);
-        atomicAdd(&hist[t2_slice(c[k].y, W, rec)], 1u);
-        atomicAdd(&hist[t2_slice(c[k].z, W, rec)], 1u);
-        atomicAdd(&hist[t2_slice(c[k].w, W, rec)], 1u);
-      }
-    } else {
-      for (int64_t e = e0 + threadIdx.x; e < e1; e += 256)
-        atomicAdd(&hist[t2_slice(stream_load(colind + e), W, rec)], 1u);
+    for (int k = 0; k < ROUNDS; ++k) {
+      atomicAdd(&hist[t2_slice(c[k].x, W, rec)], 1u);
+      atomicAdd(&hist[t2_slice(c[k].y, W, rec)], 1u);
+      atomicAdd(&hist[t2_slice(c[k].z, W, rec)], 1u);
+      atomicAdd(&hist[t2_slice(c[k].w, W, rec)], 1u);
     }
+  } else {
+    for (int64_t e = e0 + threadIdx.x; e < e1; e += 256)
+      atomicAdd(&hist[t2_slice(stream_load(colind + e), W, rec)], 1u);
   }
   __syncthreads();
-  const int g = blockIdx.x % T2_GRP;
   for (int i = threadIdx.x; i < S; i += 256)
-    if (hist[i])
-      atomicAdd(&cnt[((size_t) i * T2_GRP + g) * T2_PAD], hist[i]);
+    counts[(int64_t) i * ntile + t] = (int32_t) hist[i];
 }
 
-// one workgroup: base[s] = exclusive scan of the slices' counts, cursor[s][g] = where residue class g of the tiles starts inside
-// the slice's run; work items (slice, first, last, cut) with segments of at most seg entries; the slices that are cut get their
-// part of y scaled by beta here (their segments only ADD).  One thread per (slice, class) pair for the padded counters -- one
-// line each --, so that the S * T2_GRP loads are in flight together (one thread per slice walking its 16 lines twice: 48 us).
+// one workgroup: work items (slice, first, last, cut) with segments of at most seg entries -- a slice's run is
+// offsets[slice][0] .. offsets[slice + 1][0] of the scanned counts --; the slices that are cut get their part of y scaled by beta
+// here (their segments only ADD)
 template <typename T>
-__global__ __launch_bounds__(1024) void t2_plan_kernel(int S, int W, int64_t n, unsigned seg, const unsigned* __restrict__ cnt,
-                                                       unsigned* __restrict__ base, unsigned* __restrict__ cursor,
-                                                       int4* __restrict__ items, int* __restrict__ n_items,
-                                                       T* __restrict__ y, T beta) {
-  __shared__ unsigned s_cnt[T2_SMAX], s_off[T2_SMAX + 1], s_it[T2_SMAX + 1];
-  static_assert(T2_GRP == 16, "a slice's classes are the 16 lanes of one DPP row");
-  constexpr int PAIRS = T2_SMAX * T2_GRP / 1024;  // pairs per thread: pair p = r * 1024 + tid, slice p / 16, class p % 16
-  unsigned c_pair[PAIRS], x_pair[PAIRS];          // the pair's count; the counts of the slice's earlier classes
-  for (int i = threadIdx.x; i < S; i += 1024)
-    s_cnt[i] = 0;
-#pragma unroll
-  for (int r = 0; r < PAIRS; ++r) {
-    const int p = r * 1024 + threadIdx.x;
-    c_pair[r] = p < S * T2_GRP ? cnt[(size_t) p * T2_PAD] : 0u;
-  }
+__global__ __launch_bounds__(1024) void t2_plan_kernel(int S, int W, int64_t n, int64_t ntile, unsigned seg,
+                                                       const int32_t* __restrict__ offsets, int4* __restrict__ items,
+                                                       int* __restrict__ n_items, T* __restrict__ y, T beta) {
+  // one slice per thread (S <= 1024): exclusive scan of the item counts by DPP scans inside the wavefronts + the 16 wave totals
+  // through LDS (a Hillis-Steele scan over the workgroup -- twenty barriers -- and a serial walk over the slices for the cut
+  // ones were 35 of this kernel's first 49 us)
+  __shared__ unsigned s_wb[16];
+  __shared__ int s_ncut, s_cut[T2_SMAX];
+  const int i = threadIdx.x, wv = i >> 6, lane = i & 63;
+  const unsigned off = i < S ? (unsigned) offsets[(int64_t) i * ntile] : 0u;
+  const unsigned end = i < S ? (unsigned) offsets[(int64_t) (i + 1) * ntile] : 0u;  // (offsets[S * ntile] = the total)
+  const unsigned c = end - off;
+  const unsigned t = i < S ? (c == 0 ? 1u : (c + seg - 1) / seg) : 0u;  // (an empty slice still owns its part of y)
+  const unsigned b = t2_wave_incl_sum(t);
+  if (lane == 63)
+    s_wb[wv] = b;
+  if (i == 0)
+    s_ncut = 0;
   __syncthreads();
-#pragma unroll
-  for (int r = 0; r < PAIRS; ++r) {
-    // inclusive sums inside the rows of 16 lanes = inside one slice
-    unsigned v = c_pair[r];
-    v += (unsigned) t2_dpp<0x111, 0xf>((int) v);
-    v += (unsigned) t2_dpp<0x112, 0xf>((int) v);
-    v += (unsigned) t2_dpp<0x114, 0xf>((int) v);
-    v += (unsigned) t2_dpp<0x118, 0xf>((int) v);
-    x_pair[r] = v - c_pair[r];
-    const int p = r * 1024 + threadIdx.x;
-    if ((p & (T2_GRP - 1)) == T2_GRP - 1 && p < S * T2_GRP)
-      s_cnt[p / T2_GRP] = v;
+  unsigned bb = 0;
+  for (int w = 0; w < wv; ++w)
+    bb += s_wb[w];
+  const unsigned it0 = bb + b - t;
+  if (i < S) {
+    if (t > 1)
+      s_cut[atomicAdd(&s_ncut, 1)] = i;
+    for (unsigned q = 0; q < t; ++q) {
+      const unsigned lo = off + q * seg, hi = (lo + seg) < end ? (lo + seg) : end;
+      items[it0 + q] = make_int4(i, (int) lo, (int) hi, t > 1 ? 1 : 0);
+    }
   }
+  if (i == 1023)  // (the threads behind the last slice add nothing: the last thread's inclusive sum is the total)
+    *n_items = (int) (bb + b);
   __syncthreads();
-  {
-    // exclusive scans of the counts and of the item counts: two elements per thread, Hillis-Steele over the 1024 pair sums
-    __shared__ unsigned s_a[1024], s_b[1024];
-    const int i0 = 2 * threadIdx.x, i1 = i0 + 1;
-    const unsigned c0 = i0 < S ? s_cnt[i0] : 0u, c1 = i1 < S ? s_cnt[i1] : 0u;
-    const unsigned t0 = i0 < S ? (c0 == 0 ? 1u : (c0 + seg - 1) / seg) : 0u;  // (an empty slice still owns its part of y)
-    const unsigned t1 = i1 < S ? (c1 == 0 ? 1u : (c1 + seg - 1) / seg) : 0u;
-    unsigned a = c0 + c1, b = t0 + t1;
-    s_a[threadIdx.x] = a;
-    s_b[threadIdx.x] = b;
-    __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {
-      const unsigned pa = threadIdx.x >= (unsigned) d ? s_a[threadIdx.x - d] : 0u, pb = threadIdx.x >= (unsigned) d ? s_b[threadIdx.x - d] : 0u;
-      __syncthreads();
-      a += pa;
-      b += pb;
-      s_a[threadIdx.x] = a;
-      s_b[threadIdx.x] = b;
-      __syncthreads();
-    }
-    const unsigned ea = a - (c0 + c1), eb = b - (t0 + t1);  // exclusive prefix of this thread's pair
-    if (i0 < S) {
-      s_off[i0] = ea;
-      s_it[i0] = eb;
-    }
-    if (i1 < S) {
-      s_off[i1] = ea + c0;
-      s_it[i1] = eb + t0;
-    }
-    if (threadIdx.x == 1023) {  // (the inclusive sums of the last thread are the totals, whatever S is)
-      s_off[S] = a;
-      s_it[S] = b;
-      *n_items = (int) b;
-    }
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i <= S; i += 1024)
-    base[i] = s_off[i];
-#pragma unroll
-  for (int r = 0; r < PAIRS; ++r) {  // the classes' pieces of a slice's run, one behind the other
-    const int p = r * 1024 + threadIdx.x;
-    if (p < S * T2_GRP)
-      cursor[(size_t) p * T2_PAD] = s_off[p / T2_GRP] + x_pair[r];
-  }
-  for (int i = threadIdx.x; i < S; i += 1024) {
-    const unsigned nseg = s_it[i + 1] - s_it[i];
-    for (unsigned q = 0; q < nseg; ++q) {
-      const unsigned lo = s_off[i] + q * seg, hi = (lo + seg) < (s_off[i] + s_cnt[i]) ? (lo + seg) : (s_off[i] + s_cnt[i]);
-      items[s_it[i] + q] = make_int4(i, (int) lo, (int) hi, nseg > 1 ? 1 : 0);
-    }
-  }
   // the cut slices' part of y: scaled now, added to by every segment later
-  for (int i = 0; i < S; ++i) {
-    if (s_it[i + 1] - s_it[i] > 1) {
-      const int64_t c0 = (int64_t) i * W, c1 = (c0 + W) < n ? (c0 + W) : n;
-      for (int64_t c = c0 + threadIdx.x; c < c1; c += 1024)
-        y[c] = beta == T(0) ? T(0) : beta * y[c];
-    }
+  const int ncut = s_ncut;
+  for (int q = 0; q < ncut; ++q) {
+    const int sc = s_cut[q];
+    const int64_t c0 = (int64_t) sc * W, c1 = (c0 + W) < n ? (c0 + W) : n;
+    for (int64_t cc = c0 + threadIdx.x; cc < c1; cc += 1024)
+      y[cc] = beta == T(0) ? T(0) : beta * y[cc];
   }
 }
 
@@ -449,8 +406,8 @@ __global__ __launch_bounds__(T2_THREADS, sizeof(T) == 4 ? 8 : 4) void t2_scatter
                                                                 const int32_t* __restrict__ colind,
                                                                 const T* __restrict__ values, const T* __restrict__ x,
                                                                 T alpha, int W, unsigned rec, int S, const int32_t* __restrict__ tile_row,
-                                                                unsigned* __restrict__ cursor, T* __restrict__ prod,
-                                                                uint16_t* __restrict__ lcol) {
+                                                                int64_t ntile, const int32_t* __restrict__ offsets,
+                                                                T* __restrict__ prod, uint16_t* __restrict__ lcol) {
   // The tile's products leave SORTED BY SLICE through LDS: 64 lanes storing 4 + 2 bytes each at 64 unrelated addresses were
   // two address-unit passes of 64 separate accesses per wave-instruction (first version: 1.7 ms at cfg2's size, the whole
   // kernel); staged, consecutive lanes write consecutive elements of a run.
@@ -471,10 +428,13 @@ __global__ __launch_bounds__(T2_THREADS, sizeof(T) == 4 ? 8 : 4) void t2_scatter
   constexpr int PER = T2_TILE / T2_THREADS, NSEG = T2_TILE / 64;
   __shared__ int s_seg[NSEG];                                        // running maximum at the end of every 64 positions
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
-  const int64_t e0 = (int64_t) blockIdx.x * T2_TILE, e1 = (e0 + T2_TILE) < nnz ? (e0 + T2_TILE) : nnz;
+  const int64_t tile = t2_tile_of(blockIdx.x, ntile);
+  const int64_t e0 = tile * T2_TILE, e1 = (e0 + T2_TILE) < nnz ? (e0 + T2_TILE) : nnz;
   const int count = (int) (e1 - e0);
+  // where this tile's piece of slice `tid` goes (needed behind the third barrier)
+  const unsigned gb = tid < S ? (unsigned) offsets[(int64_t) tid * ntile + tile] : 0u;
   // rows that have entries in [e0, e1): tile_row[w] = first row r with rowptr[r] >= w * TILE; the row before it may reach in
-  int64_t r_lo = tile_row[blockIdx.x], r_hi = tile_row[blockIdx.x + 1];
+  int64_t r_lo = tile_row[tile], r_hi = tile_row[tile + 1];
   r_lo = r_lo > 0 ? r_lo - 1 : 0;
   r_hi = r_hi < m ? r_hi : m;  // (r_hi itself starts at or beyond e1)
   const int64_t nrows = r_hi - r_lo;
@@ -531,12 +491,6 @@ __global__ __launch_bounds__(T2_THREADS, sizeof(T) == 4 ? 8 : 4) void t2_scatter
       before += s_scan[w];
     const unsigned loff = before + a_mine - c_mine;
     s_loff[tid] = loff;
-    // this tile's piece of the slice's run (one reservation per (tile, slice))
-#ifdef T2_EXP_NOATOM
-    const unsigned gb = cursor[((size_t) tid * T2_GRP + (blockIdx.x % T2_GRP)) * T2_PAD];
-#else
-    const unsigned gb = c_mine ? atomicAdd(&cursor[((size_t) tid * T2_GRP + (blockIdx.x % T2_GRP)) * T2_PAD], c_mine) : 0u;
-#endif
     s_delta[tid] = gb - loff;
     s_cnt[tid] = 0;  // from here on: the next free place inside the slice's piece of the stage
   }
@@ -563,13 +517,17 @@ __global__ __launch_bounds__(T2_THREADS, sizeof(T) == 4 ? 8 : 4) void t2_scatter
 #endif
     xv[k] = x[r_lo + rrow[k]];
   }
+  // (places first, products second: the gathers of x stay in flight behind the LDS atomics)
+  unsigned at[PER];
+#pragma unroll
+  for (int k = 0; k < PER; ++k)
+    at[k] = col[k] >= 0 ? s_loff[sl[k]] + atomicAdd(&s_cnt[sl[k]], 1u) : 0u;
 #pragma unroll
   for (int k = 0; k < PER; ++k) {
     if (col[k] < 0)
       continue;
-    const unsigned at = s_loff[sl[k]] + atomicAdd(&s_cnt[sl[k]], 1u);
-    s_val[at] = alpha * val[k] * xv[k];
-    s_pack[at] = (unsigned) (col[k] - sl[k] * W) | ((unsigned) sl[k] << 16);
+    s_pack[at[k]] = (unsigned) (col[k] - sl[k] * W) | ((unsigned) sl[k] << 16);
+    s_val[at[k]] = alpha * val[k] * xv[k];
   }
   __syncthreads();
   for (int q = tid; q < count; q += T2_THREADS) {
@@ -837,12 +795,14 @@ static int spmv_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, int op
     }
     const unsigned wrec = (unsigned) (((uint64_t) 1 << 32) / (uint64_t) Wsl);
     const int64_t Ssl = cdiv(n, Wsl), ntile = cdiv(nnz, T2_TILE);
-    const bool t2_fits = m > 0 && nnz > 0 && nnz < INT32_MAX - T2_TILE && Ssl <= T2_SMAX && ntile < INT32_MAX;
+    const bool t2_fits = m > 0 && nnz > 0 && nnz < INT32_MAX - T2_TILE && Ssl <= T2_SMAX && ntile < INT32_MAX &&
+                         Ssl * ntile < INT32_MAX;
     const bool t2_want = t2_env == 1 || (t2_env != 0 && nnz >= ((int64_t) 4 << 20) && n >= 65536);
     if (t2_fits && t2_want) {
-      const size_t off_cnt = 0, off_base = off_cnt + (size_t) T2_SMAX * T2_GRP * T2_PAD * 4,
-                   off_cur = (off_base + (size_t) (T2_SMAX + 1) * 4 + 127) & ~(size_t) 127,
-                   off_nit = off_cur + (size_t) T2_SMAX * T2_GRP * T2_PAD * 4, off_tile = (off_nit + 4 + 15) & ~(size_t) 15;
+      const int64_t nscan = Ssl * ntile, nblk = cdiv(nscan, 2048);  // counts[slice][tile] + the total; the scan's block sums
+      const size_t off_cnt = 0, off_part = (off_cnt + (size_t) (nscan + 1) * 4 + 255) & ~(size_t) 255,
+                   off_nit = (off_part + (size_t) (nblk + 2) * sizeof(long long) + 15) & ~(size_t) 15,
+                   off_tile = (off_nit + 4 + 15) & ~(size_t) 15;
       unsigned seg = (unsigned) std::max<int64_t>(65536, 2 * cdiv(nnz, Ssl));
       if (t2_env == 1 && env_int_spmv("SPBLAS_GFX950_SPMV_T2_SEG", 0) >= 64)
         seg = (unsigned) env_int_spmv("SPBLAS_GFX950_SPMV_T2_SEG", 0);
@@ -856,20 +816,19 @@ static int spmv_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, int op
       // may grow, i.e. free and allocate again -- a captured un-inspected transposed multiply keeps the scatter kernel)
       if (!stream_capturing(s) && handle_scratch(h, bytes, &ws) == SPBLAS_GFX950_STATUS_SUCCESS) {
         char* w8 = static_cast<char*>(ws);
-        unsigned* cnt = reinterpret_cast<unsigned*>(w8 + off_cnt);
-        unsigned* base = reinterpret_cast<unsigned*>(w8 + off_base);
-        unsigned* cursor = reinterpret_cast<unsigned*>(w8 + off_cur);
+        int32_t* counts = reinterpret_cast<int32_t*>(w8 + off_cnt);
+        long long* partials = reinterpret_cast<long long*>(w8 + off_part);
         int* n_items = reinterpret_cast<int*>(w8 + off_nit);
         int32_t* tile_row = reinterpret_cast<int32_t*>(w8 + off_tile);
         int4* items = reinterpret_cast<int4*>(w8 + off_items);
         T* prod = reinterpret_cast<T*>(w8 + off_prod);
         uint16_t* lcol = reinterpret_cast<uint16_t*>(w8 + off_lcol);
-        SPB_HIP(hipMemsetAsync(cnt, 0, (size_t) Ssl * T2_GRP * T2_PAD * 4, s));
         hipLaunchKernelGGL((plan_window_rows_kernel<O>), dim3((unsigned) cdiv(ntile + 1, 256)), dim3(256), 0, s, m, ntile, T2_TILE,
                            rowptr, tile_row);
-        const int64_t hist_wgs = std::min<int64_t>(cdiv(ntile, T2_GRP), (int64_t) cus * 8 / T2_GRP) * T2_GRP;  // a multiple of T2_GRP
-        hipLaunchKernelGGL(t2_hist_kernel, dim3((unsigned) hist_wgs), dim3(256), 0, s, nnz, colind, (int) Wsl, wrec, (int) Ssl, ntile, cnt);
-        hipLaunchKernelGGL((t2_plan_kernel<T>), dim3(1), dim3(1024), 0, s, (int) Ssl, (int) Wsl, n, seg, cnt, base, cursor, items,
+        hipLaunchKernelGGL(t2_hist_kernel, dim3((unsigned) ntile), dim3(256), 0, s, nnz, colind, (int) Wsl, wrec, (int) Ssl, ntile,
+                           counts);
+        scan_counts_i32(s, nscan, counts, partials);
+        hipLaunchKernelGGL((t2_plan_kernel<T>), dim3(1), dim3(1024), 0, s, (int) Ssl, (int) Wsl, n, ntile, seg, counts, items,
                            n_items, y, beta);
         static std::atomic<bool> t2_attr[64][2][2] = {};
         const int dv = h->device >= 0 && h->device < 64 ? h->device : 0;
@@ -883,7 +842,7 @@ static int spmv_typed(spblas_gfx950_handle_t h, spblas_gfx950_plan_s* pl, int op
           t2_attr[dv][ti][oi].store(true, std::memory_order_release);
         }
         hipLaunchKernelGGL((t2_scatter_kernel<T, O>), dim3((unsigned) ntile), dim3(T2_THREADS), lds_sc, s, m, nnz, rowptr, colind,
-                           values, x, alpha, (int) Wsl, wrec, (int) Ssl, tile_row, cursor, prod, lcol);
+                           values, x, alpha, (int) Wsl, wrec, (int) Ssl, tile_row, ntile, counts, prod, lcol);
         hipLaunchKernelGGL((t2_accumulate_kernel<T>), dim3((unsigned) std::min<size_t>(max_items, (size_t) cus * 2)), dim3(1024),
                            (size_t) Wsl * sizeof(T), s, (int) Wsl, n, items, n_items, prod, lcol, y, beta);
         SPB_HIP(hipGetLastError());
