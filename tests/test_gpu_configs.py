@@ -202,6 +202,33 @@ def test_cfg4_spmv_rmat_scale24_f64(gpu, alg):
         util.assert_parity(y_h[rows], y_ref, absrow, np.float64, row_len=np.diff(sub_rp), what=f"cfg4 {alg} {what}")
 
 
+def test_cfg4_matrix_transposed_without_a_plan_f64(gpu):
+    """cfg4's matrix as a csc_view operand, NOT inspected: y = A^T x on the R-MAT graph of 2^24 vertices goes through the
+    two-pass form of csrc/spmv.hip (t2_* kernels) in its widest configuration -- 1 024 column slices of 16 384 columns (the
+    LDS copy of a slice takes a whole CU), hot columns cut into segments that add into y.  Every element of y against
+    oracle_spmv_csc (backend/algorithms.hpp:21-29 + multiply_impl.hpp:33-53) at 1e-12 norm-wise, alpha folded in, and the
+    fp64 checksum sum(y) == sum_p v_p x[row_p]."""
+    values, rowptr, colind, shape, nnz = generate.rmat_csr_device(24, 16, dtype=torch.float64, seed=0)
+    m, n = shape
+    a = sp.csr_view(values, rowptr, colind, shape, nnz)
+    g = torch.Generator(device="cuda").manual_seed(9)
+    x = torch.rand(m, dtype=torch.float64, device="cuda", generator=g) - 0.25
+    y = torch.full((n,), float("nan"), dtype=torch.float64, device="cuda")
+    sp.multiply(sp.scaled(-1.5, sp.transposed(a)), x, y)
+    assert bool(torch.isfinite(y).all())
+    lens = (rowptr[1:].long() - rowptr[:-1].long())
+    rows_of = torch.repeat_interleave(torch.arange(m, device="cuda"), lens)
+    rhs = (-1.5 * (values * x[rows_of]).sum()).item()
+    mag = (1.5 * (values.abs() * x[rows_of].abs()).sum()).item()
+    del rows_of
+    assert abs(y.sum().item() - rhs) <= 1e-11 * mag, "checksum of the transposed product"
+    rp_h, ci_h, v_h, x_h = rowptr.cpu().numpy().astype(np.int32), colind.cpu().numpy(), values.cpu().numpy(), x.cpu().numpy()
+    ref = -1.5 * oracle.spmv_csc((n, m), rp_h, ci_h, v_h, x_h)
+    ab = 1.5 * oracle.spmv_csc((n, m), rp_h, ci_h, np.abs(v_h), np.abs(x_h))
+    cnt = np.bincount(ci_h, minlength=n) + 1
+    util.assert_parity(y.cpu().numpy(), ref, ab, np.float64, row_len=cnt, what="cfg4 matrix, y = A^T x without a plan")
+
+
 # --------------------------------------------------------------------------------------------- cfg5
 def test_cfg5_spgemm_full_size(gpu):
     """BASELINE cfg5 at its stated size: fp32 CSR x CSR, 1M x 1M, 16 nnz/row each, multiply_compute +
