@@ -25,6 +25,9 @@ for it in range(iters):
         os.environ.pop(h, None)
     m = int(rng.choice([1, 7, 300, 5000, 40000, 150000]))
     n = int(rng.choice([1, 13, 999, 20000, 70000, 300000]))
+    if os.environ.get("FUZZ_BIG"):  # sizes at which the two-pass form is the default (>= 4 M entries, >= 65 536 columns)
+        m = int(rng.choice([200000, 1500000, 6000000]))
+        n = int(rng.choice([70000, 900000, 12000000, 40000000]))
     kind = rng.choice(["uniform", "powerlaw", "banded", "sparse_rows", "dups", "hotcols", "empty_stretch"])
     if kind == "uniform":
         lens = rng.integers(0, 24, m)
@@ -44,8 +47,11 @@ for it in range(iters):
     else:
         lens = rng.integers(0, 80, m)
     lens = lens.astype(np.int64)
-    if lens.sum() > 3_000_000:
-        lens = (lens * (3_000_000 / lens.sum())).astype(np.int64)
+    cap = 24_000_000 if os.environ.get("FUZZ_BIG") else 3_000_000
+    if os.environ.get("FUZZ_BIG") and lens.sum() < 5_000_000:
+        lens = lens * int(np.ceil(5_000_000 / max(1, lens.sum())))
+    if lens.sum() > cap:
+        lens = (lens * (cap / lens.sum())).astype(np.int64)
     rowptr = np.concatenate([[0], np.cumsum(lens)])
     nnz = int(rowptr[-1])
     if kind == "banded":
@@ -68,10 +74,12 @@ for it in range(iters):
     alpha = float(rng.choice([1.0, -2.5]))
     beta = float(rng.choice([0.0, 0.0, 0.75]))
     hooks = {}
-    if rng.random() < 0.8:
+    if os.environ.get("FUZZ_BIG"):
+        pass  # the sizes speak for themselves: default slice width and segment length
+    elif rng.random() < 0.8:
         hooks["SPBLAS_GFX950_SPMV_T2_W"] = str(int(rng.choice([64, 320, 4096, 9984, 19392 if dtype == np.float32 else 9728])))
     if rng.random() < 0.6:
-        hooks["SPBLAS_GFX950_SPMV_T2_SEG"] = str(int(rng.choice([64, 1000, 8192, 100000])))
+        hooks["SPBLAS_GFX950_SPMV_T2_SEG"] = str(int(rng.choice([100000, 1000000] if os.environ.get("FUZZ_BIG") else [64, 1000, 8192, 100000])))
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     tdt = torch.float32 if dtype == np.float32 else torch.float64
     dv, drp, dci, dx = t(values), t(rowptr.astype(np.int64 if off64 else np.int32)), t(colind), t(x)
