@@ -428,6 +428,9 @@ def _run_csc_spmv(args, device, sp, oracle, generate):
                  {"dtype": "f32", "rows": k, "nnz": nnz, "operand": "csc_view + multiply_inspect", "plan": plan,
                   "uninspected_ms_per_step": el_t / max(3, args.steps // 2) * 1e3,
                   "uninspected_roofline_frac": alg_bytes / (ms_t[0] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                  "uninspected_traffic": (lambda tr: None if args.rows or tr[0] is None else
+                                          {"bytes": tr[0], "over_algorithmic": tr[0] / alg_bytes, "profile": (tr[1] or {}).get("profile"),
+                                           "stale": (tr[1] or {}).get("stale")})(read_pmc_traffic("csc_spmv_uninspected_8f")),
                   "uninspected_kernel": "t2_hist_kernel + scan + t2_plan_kernel + t2_scatter_kernel<float,int> + t2_accumulate_kernel<float> (round 6: products "
                                         "binned by column slice through the handle's workspace; SPBLAS_GFX950_SPMV_T2=0: the float-atomic scatter)",
                   "inspect_ms_untimed": inspect_ms, "plan_bytes": held,
