@@ -59,6 +59,38 @@ def test_spmv_execute_is_capturable(gpu, alg, dtype):
         util.assert_parity(G.host(y), y_ref, absrow, dtype, row_len=lens, what=f"graph replay {seed} ({alg})")
 
 
+def test_transposed_multiply_without_a_plan_is_capturable(gpu, monkeypatch):
+    """y = A^T x on a csc_view that was never inspected: outside a capture large operands go through a workspace in the
+    handle's scratch (two-pass form, csrc/spmv.hip t2_*), which a later call may re-allocate -- so a RECORDED call keeps the
+    scatter kernel (scale + one float atomic per entry: launches only).  The two-pass form is forced for this small matrix
+    (SPBLAS_GFX950_SPMV_T2=1) to show that the capture does not take it; a larger un-captured call between the replays grows
+    the scratch, and the replays stay right."""
+    monkeypatch.setenv("SPBLAS_GFX950_SPMV_T2", "1")
+    m, n, nnz = 30000, 50000, 600000
+    values, rowptr, colind, shape, _ = generate.generate_csr(m, n, nnz, dtype=np.float32, seed=12)
+    a = sp.csr_view(G.dev(values), G.dev(rowptr), G.dev(colind), shape, nnz)
+    x = torch.zeros(m, device="cuda")
+    y = torch.full((n,), float("nan"), device="cuda")
+    g = capture(lambda: sp.multiply(sp.scaled(0.5, sp.transposed(a)), x, y))
+    cnt = np.bincount(colind, minlength=n) + 1
+    # a bigger product outside the capture: the handle's scratch is released and allocated again
+    v2, rp2, ci2, shape2, _ = generate.generate_csr(4 * m, n, 8 * nnz, dtype=np.float32, seed=13)
+    a2 = sp.csr_view(G.dev(v2), G.dev(rp2), G.dev(ci2), shape2, 8 * nnz)
+    for seed in range(3):
+        x_h = np.random.default_rng(seed).standard_normal(m).astype(np.float32)
+        x.copy_(G.dev(x_h))
+        y.fill_(float("nan"))
+        g.replay()
+        torch.cuda.synchronize()
+        ref = 0.5 * oracle.spmv_csc((n, m), rowptr, colind, values, x_h)
+        ab = 0.5 * oracle.spmv_csc((n, m), rowptr, colind, np.abs(values), np.abs(x_h))
+        util.assert_parity(G.host(y), ref, ab, np.float32, row_len=cnt, what=f"graph replay {seed} of an un-inspected A^T x")
+        if seed == 0:
+            y2 = torch.empty(n, device="cuda")
+            sp.multiply(sp.transposed(a2), torch.ones(4 * m, device="cuda"), y2)
+            torch.cuda.synchronize()
+
+
 def test_spmv_rmat_row_map_plan_is_capturable(gpu):
     # the cfg4 plan shape: row map, long rows in pieces, variable-height bins, empty-row fill -- five launches per call
     v, rp, ci, sh, nnz = generate.rmat_csr_device(14, 16, dtype=torch.float64, device="cuda", seed=9)
