@@ -433,6 +433,33 @@ int main() {
       expect(close_vec(dy.host(), want2, abs2), "multiply(info, scaled(csr_view<float, int64, int64>), x, y)");
     }
     {
+      // SpMM with 64-bit column indices: plain, inspected (twice through the plan), both offset types
+      const I nc = 20;
+      std::vector<T> hb(static_cast<std::size_t>(n) * nc);
+      for (auto& v : hb)
+        v = next_val();
+      dev_array<T> db(hb), dc(static_cast<std::size_t>(m) * nc);
+      mdspan_row_major<T, I> B(db.p, n, nc), C(dc.p, m, nc);
+      std::vector<double> wantc(static_cast<std::size_t>(m) * nc, 0.0), scalec(static_cast<std::size_t>(m) * nc, 0.0);
+      for (I r = 0; r < m; ++r)
+        for (O p = ha.rowptr[r]; p < ha.rowptr[r + 1]; ++p)
+          for (I j = 0; j < nc; ++j) {
+            const double t = static_cast<double>(ha.values[p]) * hb[static_cast<std::size_t>(ha.colind[p]) * nc + j];
+            wantc[static_cast<std::size_t>(r) * nc + j] += t;
+            scalec[static_cast<std::size_t>(r) * nc + j] += std::fabs(t);
+          }
+      csr_view<T, I64, O> a(dv.p, drp.p, dci.p, {static_cast<I64>(m), static_cast<I64>(n)}, static_cast<O>(ha.nnz()));
+      HIP_OK(hipMemset(dc.p, 0xFF, dc.n * sizeof(T)));
+      multiply(a, B, C);
+      expect(close_vec(dc.host(), wantc, scalec), "multiply(csr_view<float, int64, int32>, B, C)");
+      csr_view<T, I64, I64> a64(dv.p, drp64.p, dci.p, {static_cast<I64>(m), static_cast<I64>(n)}, static_cast<I64>(ha.nnz()));
+      HIP_OK(hipMemset(dc.p, 0xFF, dc.n * sizeof(T)));
+      operation_info_t info = multiply_inspect(a64, B, C);
+      multiply(info, a64, B, C);
+      multiply(info, a64, B, C);
+      expect(close_vec(dc.host(), wantc, scalec), "multiply(info, csr_view<float, int64, int64>, B, C)");
+    }
+    {
       std::vector<I64> bad = ci64;
       bad[bad.size() / 2] = (static_cast<I64>(1) << 32) + 5;  // would wrap to column 5
       dev_array<I64> dbad(bad);
