@@ -14,7 +14,7 @@ SPBLAS_GFX950_SPMM_PANEL_MIN=32 run timeout 300 python tools/fuzz_spmm.py 500 $(
 SPBLAS_GFX950_SPMM_PANEL_MIN=32 SPBLAS_GFX950_SPMM_BAND_DENSE=0 run timeout 240 python tools/fuzz_spmm.py 400 $((62000 + O))
 SPBLAS_GFX950_SPMM_PANEL_MIN=32 SPBLAS_GFX950_SPMM_BAND=0 run timeout 240 python tools/fuzz_spmm.py 300 $((63000 + O))
 run timeout 360 python tools/fuzz_spgemm.py 700 $((70000 + O))
-FUZZ_BIG=1 run timeout 300 python tools/fuzz_spgemm.py 40 $((71000 + O))
+FUZZ_BIG=1 run timeout 600 python tools/fuzz_spgemm.py 12 $((71000 + O))
 run timeout 240 python tools/fuzz_transpose.py 250 $((80000 + O))
 run timeout 240 python tools/fuzz_sptrsv.py 150 $((90000 + O))
 cat $L
